@@ -1,0 +1,579 @@
+"""CPU ORACLE (test infrastructure, NOT product code) for the Neural-SDE hot path.
+
+This file restates, in plain numpy, the arithmetic of the reference's
+``torchsde.sdeint(...)`` call over ``Diffusion_model.f/g`` plus the cubic-spline
+control path.  It is the checker the HIP path is compared against.  Only
+``tests/``, ``__graft_entry__.smoke()`` and ``bench.py``'s ``cpu_baseline`` leg
+may import it; the shipped package never does.
+
+Pinning status
+--------------
+* ``drift_f`` / ``diffusion_g`` / ``spline_evaluate`` /
+  ``natural_cubic_spline_coeffs`` are PINNED: ``tests/golden/*.npz`` were
+  generated in the build container by importing the reference's own
+  ``Diffusion_model`` and vendored ``controldiffeq`` code
+  (``tests/golden/make_golden.py``) and this file reproduces them
+  (``tests/test_oracle_golden.py``).
+* ``step_grid`` / ``integrate`` (torchsde 0.2.5 ``BaseSDESolver.integrate``,
+  ``Euler.step``, ``Milstein.step``) and
+  ``hermite_cubic_coefficients_with_backward_differences`` (torchcde 0.2.5) are
+  restated from the published behaviour of those pinned third-party packages,
+  whose sources are NOT under /root/reference and are not installed here:
+  **parity unpinned** at that boundary.  They are guarded by
+  analytic known-answer tests instead (tests/test_oracle_analytic.py).
+
+Reference lines followed (relative to /root/reference):
+  benchmark_classification/models_sde/neuralsde.py:186-231   drift helpers
+  benchmark_classification/models_sde/neuralsde.py:233-293   diffusion
+  benchmark_classification/models_sde/neuralsde.py:295-307   f, g
+  benchmark_classification/controldiffeq/interpolate.py:9-55   natural spline, no NaN
+  benchmark_classification/controldiffeq/interpolate.py:58-155 natural spline, NaN path
+  benchmark_classification/controldiffeq/interpolate.py:255-276 evaluate
+  benchmark_classification/controldiffeq/misc.py:12-66         Thomas solve
+"""
+import math
+
+import numpy as np
+
+# --------------------------------------------------------------------------------------
+# cubic spline control path
+# --------------------------------------------------------------------------------------
+
+
+def spline_index(times, t):
+    """interpolate.py:263-268 ``_interpret_t``: index = clamp(#{j: times[j] < t} - 1, 0, L-2).
+
+    torchcde's ``bucketize(t, times) - 1`` gives the same integer.
+    Returns (index, fractional_part) with fractional_part in the dtype of ``times``.
+    """
+    times = np.asarray(times)
+    t = times.dtype.type(t)
+    L = times.shape[0]
+    idx = int((t > times).sum()) - 1
+    idx = min(max(idx, 0), L - 2)
+    return idx, t - times[idx]
+
+
+def spline_evaluate(coeffs, times, t):
+    """X(t) for coeffs (B, L-1, 4C) = cat[a, b, two_c, three_d]; interpolate.py:270-276.
+
+    Operation order kept exactly: inner = 0.5*two_c + three_d*frac/3;
+    inner = b + inner*frac; out = a + inner*frac.
+    """
+    coeffs = np.asarray(coeffs)
+    dt = coeffs.dtype.type
+    times = np.asarray(times, dtype=coeffs.dtype)
+    idx, frac = spline_index(times, t)
+    C = coeffs.shape[-1] // 4
+    row = coeffs[..., idx, :]
+    a, b, two_c, three_d = (row[..., k * C:(k + 1) * C] for k in range(4))
+    inner = dt(0.5) * two_c + three_d * frac / dt(3)
+    inner = b + inner * frac
+    return a + inner * frac
+
+
+def spline_derivative(coeffs, times, t):
+    """dX/dt; interpolate.py:278-283."""
+    coeffs = np.asarray(coeffs)
+    times = np.asarray(times, dtype=coeffs.dtype)
+    idx, frac = spline_index(times, t)
+    C = coeffs.shape[-1] // 4
+    row = coeffs[..., idx, :]
+    _, b, two_c, three_d = (row[..., k * C:(k + 1) * C] for k in range(4))
+    inner = two_c + three_d * frac
+    return b + inner * frac
+
+
+def _tridiagonal_solve(b, upper, diag, lower):
+    """misc.py:12-66 Thomas algorithm along the last axis (b: (..., k))."""
+    k = b.shape[-1]
+    new_b = [None] * k
+    new_d = [None] * k
+    new_b[0] = b[..., 0]
+    new_d[0] = diag[0] * np.ones_like(b[..., 0])
+    for i in range(1, k):
+        w = lower[i - 1] / new_d[i - 1]
+        new_d[i] = diag[i] - w * upper[i - 1]
+        new_b[i] = b[..., i] - w * new_b[i - 1]
+    out = [None] * k
+    out[k - 1] = new_b[k - 1] / new_d[k - 1]
+    for i in range(k - 2, -1, -1):
+        out[i] = (new_b[i] - upper[i] * out[i + 1]) / new_d[i]
+    return np.stack(out, axis=-1)
+
+
+def _natural_coeffs_no_nan(times, path):
+    """interpolate.py:9-55; path (..., length)."""
+    length = path.shape[-1]
+    dt = path.dtype.type
+    if length < 2:
+        raise ValueError("Must have a time dimension of size at least 2.")
+    if length == 2:
+        a = path[..., :1]
+        b = (path[..., 1:] - path[..., :1]) / (times[1:] - times[:1])
+        z = np.zeros(path.shape[:-1] + (1,), dtype=path.dtype)
+        return a, b, z, z.copy()
+    time_diffs = times[1:] - times[:-1]
+    rec = dt(1) / time_diffs
+    rec2 = rec ** 2
+    three_path_diffs = dt(3) * (path[..., 1:] - path[..., :-1])
+    six_path_diffs = dt(2) * three_path_diffs
+    path_diffs_scaled = three_path_diffs * rec2
+    diag = np.empty(length, dtype=path.dtype)
+    diag[:-1] = rec
+    diag[-1] = 0
+    diag[1:] += rec
+    diag *= 2
+    rhs = np.empty_like(path)
+    rhs[..., :-1] = path_diffs_scaled
+    rhs[..., -1] = 0
+    rhs[..., 1:] += path_diffs_scaled
+    kd = _tridiagonal_solve(rhs, rec, diag, rec)
+    a = path[..., :-1]
+    b = kd[..., :-1]
+    two_c = (six_path_diffs * rec - dt(4) * kd[..., :-1] - dt(2) * kd[..., 1:]) * rec
+    three_d = (-six_path_diffs * rec + dt(3) * (kd[..., :-1] + kd[..., 1:])) * rec2
+    return a, b, two_c, three_d
+
+
+def _natural_coeffs_nan_scalar(times, path):
+    """interpolate.py:80-155; times, path both (length,)."""
+    n = path.shape[0]
+    dt = path.dtype.type
+    not_nan = ~np.isnan(path)
+    if not not_nan.any():
+        z = np.zeros(n - 1, dtype=path.dtype)
+        return z, z.copy(), z.copy(), z.copy()
+    path = path.copy()
+    pnn = path[not_nan]
+    if np.isnan(path[0]):
+        path[0] = pnn[0]
+    if np.isnan(path[-1]):
+        path[-1] = pnn[-1]
+    not_nan = ~np.isnan(path)
+    pnn = path[not_nan]
+    tnn = times[not_nan]
+    a_nn, b_nn, c_nn, d_nn = _natural_coeffs_no_nan(tnn, pnn)
+    a_p, b_p, c_p, d_p = [], [], [], []
+    it_t = iter(tnn)
+    it_c = iter(zip(a_nn, b_nn, c_nn, d_nn))
+    next_t = next(it_t)
+    prev_t = None
+    na = nb = nc = nd = None
+    for time in times[:-1]:
+        if time >= next_t:
+            prev_t = next_t
+            next_t = next(it_t)
+            na, nb, nc, nd = next(it_c)
+        offset = prev_t - time
+        a_inner = (dt(0.5) * nc - nd * offset / dt(3)) * offset
+        a_p.append(na + (a_inner - nb) * offset)
+        b_p.append(nb + (nd * offset - nc) * offset)
+        c_p.append(nc - dt(2) * nd * offset)
+        d_p.append(nd)
+    return (np.array(a_p, dtype=path.dtype), np.array(b_p, dtype=path.dtype),
+            np.array(c_p, dtype=path.dtype), np.array(d_p, dtype=path.dtype))
+
+
+def natural_cubic_spline_coeffs(times, X):
+    """interpolate.py:161-228.  times (L,), X (..., L, C) with NaN = missing.
+
+    Returns a, b, two_c, three_d each (..., L-1, C).
+    """
+    times = np.asarray(times)
+    X = np.asarray(X)
+    if times.ndim != 1:
+        raise ValueError("t must be one dimensional.")
+    if np.any(times[1:] <= times[:-1]):
+        raise ValueError("t must be monotonically increasing.")
+    if X.ndim < 2:
+        raise ValueError("X must have at least two dimensions, corresponding to time and channels.")
+    if X.shape[-2] != times.shape[0]:
+        raise ValueError("The time dimension of X must equal the length of t.")
+    if times.shape[0] < 2:
+        raise ValueError("Must have a time dimension of size at least 2.")
+    Xt = np.swapaxes(X, -1, -2)  # (..., C, L)
+    if np.isnan(X).any():
+        flat = Xt.reshape(-1, Xt.shape[-1])
+        pieces = [_natural_coeffs_nan_scalar(times, p) for p in flat]
+        outs = [np.stack([p[k] for p in pieces], 0).reshape(Xt.shape[:-1] + (times.shape[0] - 1,))
+                for k in range(4)]
+    else:
+        outs = _natural_coeffs_no_nan(times, Xt)
+    return tuple(np.ascontiguousarray(np.swapaxes(o, -1, -2)) for o in outs)
+
+
+def _linear_fill_nan(times, x):
+    """Forward/linear interpolation fill used by torchcde's hermite builder.
+
+    Interior NaNs are filled linearly in time between the nearest observed neighbours;
+    leading NaNs take the first observation, trailing NaNs the last.  An all-NaN channel
+    becomes zeros.  x: (L,) one channel.
+    """
+    x = x.copy()
+    ok = ~np.isnan(x)
+    if not ok.any():
+        return np.zeros_like(x)
+    idx = np.nonzero(ok)[0]
+    x[:idx[0]] = x[idx[0]]
+    x[idx[-1] + 1:] = x[idx[-1]]
+    for lo, hi in zip(idx[:-1], idx[1:]):
+        if hi > lo + 1:
+            w = (times[lo + 1:hi] - times[lo]) / (times[hi] - times[lo])
+            x[lo + 1:hi] = x[lo] + w * (x[hi] - x[lo])
+    return x
+
+
+def hermite_cubic_coefficients_with_backward_differences(X, t=None):
+    """torchcde 0.2.5 ``hermite_cubic_coefficients_with_backward_differences`` (restated; unpinned).
+
+    Per interval k of width h_k with forward slope m_k = (x_{k+1}-x_k)/h_k and entering slope
+    b_k = m_{k-1} (b_0 = m_0):  a = x_k, b = b_k, two_c = 2*(3(m_k - b_k)/h_k - (m_k - b_k)/h_k)...
+    written as the unique cubic with p(0)=x_k, p(h)=x_{k+1}, p'(0)=b_k, p'(h)=m_k:
+        two_c   = 2 * (m_k - b_k) / h_k * 2   -> 4 (m_k - b_k) / h_k
+        three_d = -3 (m_k - b_k) / h_k^2
+    Output (..., L-1, 4C) = cat[a, b, two_c, three_d].
+    """
+    X = np.asarray(X)
+    L = X.shape[-2]
+    if t is None:
+        t = np.linspace(0, L - 1, L).astype(X.dtype)
+    t = np.asarray(t, dtype=X.dtype)
+    if np.isnan(X).any():
+        Xf = np.swapaxes(X, -1, -2).reshape(-1, L)
+        Xf = np.stack([_linear_fill_nan(t, row) for row in Xf], 0)
+        X = np.swapaxes(Xf.reshape(np.swapaxes(X, -1, -2).shape), -1, -2)
+    h = (t[1:] - t[:-1])[:, None]
+    m = (X[..., 1:, :] - X[..., :-1, :]) / h
+    b = np.concatenate([m[..., :1, :], m[..., :-1, :]], axis=-2)
+    a = X[..., :-1, :]
+    dt = X.dtype.type
+    two_c = dt(4) * (m - b) / h
+    three_d = dt(-3) * (m - b) / (h * h)
+    return np.concatenate([a, b, two_c, three_d], axis=-1)
+
+
+# --------------------------------------------------------------------------------------
+# vector field: drift f and diagonal diffusion g
+# --------------------------------------------------------------------------------------
+
+
+def _lin(x, W, b):
+    return x @ W.T + b
+
+
+def _sigmoid(x):
+    return 1 / (1 + np.exp(-x))
+
+
+def _nan_to_num(x):
+    fmax = np.finfo(x.dtype).max
+    return np.nan_to_num(x, nan=0.0, posinf=fmax, neginf=-fmax)
+
+
+def cast_params(params, dtype):
+    return {k: np.asarray(v, dtype=dtype) for k, v in params.items()}
+
+
+def time_features(t, B, dtype):
+    """neuralsde.py:186-193: t -> (B,1), features [sin t, cos t] (B,2)."""
+    t = np.full((B, 1), t, dtype=dtype)
+    return t, np.concatenate([np.sin(t), np.cos(t)], axis=-1)
+
+
+def drift_f(p, io, t, y, Xt_raw):
+    """neuralsde.py:295-302.  ``Xt_raw`` = X.evaluate(t), shape (B, C)."""
+    dtype = y.dtype
+    B = y.shape[0]
+    Xt = _lin(Xt_raw, p['initial_network.weight'], p['initial_network.bias'])
+    if io in (3, 4, 5, 6):
+        _, tf = time_features(t, B, dtype)
+        yy = _lin(np.concatenate([tf, y], axis=-1), p['linear_in.weight'], p['linear_in.bias'])
+    else:
+        yy = _lin(y, p['linear_in.weight'], p['linear_in.bias'])
+    if io == 0:
+        z = Xt
+    elif io in (1, 3, 5):
+        z = yy
+    else:
+        z = _lin(np.concatenate([yy, Xt], axis=-1), p['emb.weight'], p['emb.bias'])
+    z = np.maximum(z, 0)
+    i = 0
+    while f'linears.{i}.weight' in p:
+        z = np.maximum(_lin(z, p[f'linears.{i}.weight'], p[f'linears.{i}.bias']), 0)
+        i += 1
+    z = _lin(z, p['linear_out.weight'], p['linear_out.bias'])
+    if io in (5, 6):
+        z = z * np.tanh(y)
+    return np.tanh(z)
+
+
+def _noise_net(p, prefix, x):
+    if f'{prefix}.0.weight' in p:
+        h = np.maximum(_lin(x, p[f'{prefix}.0.weight'], p[f'{prefix}.0.bias']), 0)
+        return _lin(h, p[f'{prefix}.2.weight'], p[f'{prefix}.2.bias'])
+    return _lin(x, p[f'{prefix}.weight'], p[f'{prefix}.bias'])
+
+
+def raw_diffusion(p, no, t, y):
+    """neuralsde.py:233-288."""
+    dtype = y.dtype
+    B, H = y.shape
+    tt, tf = time_features(t, B, dtype)
+    with np.errstate(all='ignore'):
+        if no == 0:
+            return np.zeros((B, H), dtype=dtype)
+        if no in (1, 2, 3):
+            s = np.broadcast_to(np.exp(p['sigma']), (B, H))
+            return s if no == 1 else (s * tt if no == 2 else s * y)
+        if no in (4, 5, 6):
+            s = np.broadcast_to(np.exp(p['sigma_diag'])[None, :], (B, H))
+            return s if no == 4 else (s * tt if no == 5 else s * y)
+        if no == 7:
+            return np.sqrt(y)
+        if no == 8:
+            return y ** 3
+        if no == 9:
+            return _sigmoid(y)
+        if no == 10:
+            return np.maximum(y, 0)
+        if no == 11:
+            return tt * y
+        if no == 12:
+            return _noise_net(p, 'noise_t', tf)
+        if no == 13:
+            return _noise_net(p, 'noise_t', tf) * y
+        ty = np.concatenate([tf, y], axis=-1)
+        if no == 14:
+            return _noise_net(p, 'noise_y', ty)
+        if no == 15:
+            return _noise_net(p, 'noise_y', ty) * y
+        if no == 16:
+            return np.maximum(_noise_net(p, 'noise_t', tf), 0)
+        if no == 17:
+            return np.maximum(_noise_net(p, 'noise_t', tf), 0) * y
+        if no == 18:
+            return np.maximum(_noise_net(p, 'noise_y', ty), 0)
+        if no == 19:
+            return np.maximum(_noise_net(p, 'noise_y', ty), 0) * y
+    raise ValueError(f"Unknown noise_option {no}.")
+
+
+def diffusion_g(p, no, t, y):
+    """neuralsde.py:304-307: g = tanh(sigmoid(theta) * nan_to_num(raw))."""
+    raw = raw_diffusion(p, no, t, y)
+    with np.errstate(all='ignore'):
+        noise = _sigmoid(p['theta']).reshape(1, 1) * _nan_to_num(raw.astype(y.dtype))
+    return np.tanh(noise)
+
+
+MILSTEIN_ELEMENTWISE_NO = (0, 1, 2, 3, 4, 5, 6, 8, 9, 10, 11, 12, 13, 16, 17)
+
+
+def diffusion_g_dgdy(p, no, t, y):
+    """(g, dg_i/dy_i) for the noise options whose g_i depends on y only through y_i.
+
+    torchsde's Milstein forms g * dg/dy by a VJP of g with cotangent g*v, which
+    for these options equals the closed form used here:
+        dg/dy = (1 - g^2) * sigmoid(theta) * d raw / dy   (raw finite).
+    """
+    if no not in MILSTEIN_ELEMENTWISE_NO:
+        raise ValueError(f"closed-form Milstein derivative not defined for noise_option {no}")
+    dtype = y.dtype
+    B, H = y.shape
+    g = diffusion_g(p, no, t, y)
+    tt, tf = time_features(t, B, dtype)
+    one = np.ones((B, H), dtype=dtype)
+    if no in (0, 1, 2, 4, 5, 12, 16):
+        draw = np.zeros((B, H), dtype=dtype)
+    elif no == 3:
+        draw = np.exp(p['sigma']) * one
+    elif no == 6:
+        draw = np.exp(p['sigma_diag'])[None, :] * one
+    elif no == 8:
+        draw = 3 * y * y
+    elif no == 9:
+        s = _sigmoid(y)
+        draw = s * (1 - s)
+    elif no == 10:
+        draw = (y > 0).astype(dtype)
+    elif no == 11:
+        draw = tt * one
+    elif no == 13:
+        draw = _noise_net(p, 'noise_t', tf) * one
+    elif no == 17:
+        draw = np.maximum(_noise_net(p, 'noise_t', tf), 0) * one
+    raw = raw_diffusion(p, no, t, y)
+    draw = np.where(np.isfinite(raw), draw, 0).astype(dtype)
+    dg = (1 - g * g) * _sigmoid(p['theta']).reshape(1, 1) * draw
+    return g, dg.astype(dtype)
+
+
+# --------------------------------------------------------------------------------------
+# torchsde fixed-step integrate semantics (restated; unpinned)
+# --------------------------------------------------------------------------------------
+
+
+def step_grid(ts, dt):
+    """torchsde 0.2.5 ``BaseSDESolver.integrate`` time bookkeeping, emulated in fp32.
+
+        curr_t = ts[0]
+        for out_t in ts[1:]:
+            while curr_t < out_t:
+                next_t = min(curr_t + dt, ts[-1]); step(curr_t, next_t); curr_t = next_t
+            ys.append(linear_interp(prev_t, prev_y, curr_t, curr_y, out_t))
+
+    ``ts`` is a float32 tensor and ``dt`` a python float, so ``curr_t + dt`` rounds to float32 at
+    every step.  Returns
+        t0[n], t1[n]      float32 (N,)  start/end time of solver step n
+        out_step[k]       int (T-1,)    index n of the step after which output k+1 is emitted
+        w0[k], w1[k]      float32       linear_interp weights (t1-t)/(t1-t0), (t-t0)/(t1-t0)
+    """
+    ts = np.asarray(ts, dtype=np.float32)
+    if ts.ndim != 1 or ts.shape[0] < 2:
+        raise ValueError("ts must be one-dimensional with at least two entries")
+    if np.any(ts[1:] <= ts[:-1]):
+        raise ValueError("Evaluation times `ts` must be strictly increasing.")
+    if not dt > 0:
+        raise ValueError("dt must be positive")
+    f32 = np.float32
+    step = f32(dt)
+    t_end = ts[-1]
+    curr = ts[0]
+    prev = ts[0]
+    t0s, t1s, out_step, w0, w1 = [], [], [], [], []
+    for out_t in ts[1:]:
+        while curr < out_t:
+            nxt = f32(curr + step)
+            if t_end < nxt:
+                nxt = t_end
+            if not nxt > curr:
+                raise ValueError("dt too small for float32 time accumulation (no progress)")
+            t0s.append(curr)
+            t1s.append(nxt)
+            prev, curr = curr, nxt
+        out_step.append(len(t0s) - 1)
+        denom = f32(curr - prev)
+        w0.append(f32(f32(curr - out_t) / denom))
+        w1.append(f32(f32(out_t - prev) / denom))
+    return (np.array(t0s, f32), np.array(t1s, f32), np.array(out_step, np.int32),
+            np.array(w0, f32), np.array(w1, f32))
+
+
+def integrate(f, g, y0, ts, dt, dW, method='euler', gdg=None):
+    """Fixed-step Ito integration with supplied increments.
+
+    f(t, y), g(t, y) -> (B, H);  dW (N, B, H) = bm(t0_n, t1_n) for the steps of ``step_grid``.
+    Euler:    y1 = y0 + f*dt + g*dW
+    Milstein: y1 = y0 + f*dt + g*dW + 0.5 * g*dg/dy * (dW^2 - dt); ``gdg(t,y)`` returns (g, dg/dy).
+    Returns ys (T, B, H) and the full trajectory (N+1, B, H), computed in y0.dtype.
+    """
+    dtype = y0.dtype
+    t0s, t1s, out_step, w0, w1 = step_grid(ts, dt)
+    N = t0s.shape[0]
+    assert dW.shape[0] == N, (dW.shape, N)
+    y = y0.copy()
+    prev_y = y0
+    ys = [y0.copy()]
+    traj = [y0.copy()]
+    k = 0
+    for n in range(N):
+        t = dtype.type(t0s[n])
+        h = dtype.type(t1s[n]) - dtype.type(t0s[n])
+        I = dW[n].astype(dtype)
+        prev_y = y
+        if method == 'euler':
+            y = y + f(t, y) * h + g(t, y) * I
+        elif method == 'milstein':
+            gv, dg = gdg(t, y)
+            y = y + f(t, y) * h + gv * I + dtype.type(0.5) * (gv * dg) * (I * I - h)
+        else:
+            raise ValueError(method)
+        traj.append(y.copy())
+        while k < out_step.shape[0] and out_step[k] == n:
+            a, b = dtype.type(w0[k]), dtype.type(w1[k])
+            ys.append(y.copy() if a == 0 else a * prev_y + b * y)
+            k += 1
+    return np.stack(ys, 0), np.stack(traj, 0)
+
+
+def solve_diffusion_model(p, io, no, coeffs, times, y0, ts, dt, dW, method='euler', dtype=np.float64):
+    """Whole hot path for a ``Diffusion_model`` parameter dict: spline -> f/g -> integrate."""
+    p = cast_params(p, dtype)
+    coeffs = np.asarray(coeffs, dtype=dtype)
+    times32 = np.asarray(times, dtype=np.float32)
+    times_d = times32.astype(dtype)
+    y0 = np.asarray(y0, dtype=dtype)
+
+    def f(t, y):
+        return drift_f(p, io, t, y, spline_evaluate(coeffs, times_d, t))
+
+    def g(t, y):
+        return diffusion_g(p, no, t, y)
+
+    def gdg(t, y):
+        return diffusion_g_dgdy(p, no, t, y)
+
+    return integrate(f, g, y0, ts, dt, np.asarray(dW), method=method, gdg=gdg)
+
+
+# --------------------------------------------------------------------------------------
+# Philox4x32-10 Brownian increments (specification of the in-kernel generator)
+# --------------------------------------------------------------------------------------
+
+_PHILOX_M0 = np.uint64(0xD2511F53)
+_PHILOX_M1 = np.uint64(0xCD9E8D57)
+_PHILOX_W0 = np.uint32(0x9E3779B9)
+_PHILOX_W1 = np.uint32(0xBB67AE85)
+
+
+def philox4x32_10(c0, c1, c2, c3, k0, k1):
+    """Philox4x32-10 (Salmon et al. 2011) on uint32 numpy arrays (broadcast)."""
+    c0, c1, c2, c3 = (np.asarray(c, dtype=np.uint32) for c in (c0, c1, c2, c3))
+    c0, c1, c2, c3 = np.broadcast_arrays(c0, c1, c2, c3)
+    k0 = np.uint32(k0)
+    k1 = np.uint32(k1)
+    with np.errstate(over='ignore'):
+        for r in range(10):
+            p0 = _PHILOX_M0 * c0.astype(np.uint64)
+            p1 = _PHILOX_M1 * c2.astype(np.uint64)
+            hi0, lo0 = (p0 >> np.uint64(32)).astype(np.uint32), p0.astype(np.uint32)
+            hi1, lo1 = (p1 >> np.uint64(32)).astype(np.uint32), p1.astype(np.uint32)
+            c0, c1, c2, c3 = hi1 ^ c1 ^ k0, lo1, hi0 ^ c3 ^ k1, lo0
+            k0 = np.uint32((int(k0) + int(_PHILOX_W0)) & 0xFFFFFFFF)
+            k1 = np.uint32((int(k1) + int(_PHILOX_W1)) & 0xFFFFFFFF)
+    return c0, c1, c2, c3
+
+
+def philox_normals(seed, rows, step, H):
+    """Standard normals Z[row, col] for global row indices ``rows`` at solver step ``step``.
+
+    counter = (row, step, col // 4, 0), key = (seed & 0xffffffff, seed >> 32); the four 32-bit
+    outputs x0..x3 give columns 4q..4q+3 by two Box-Muller pairs:
+        u = ((x >> 8) + 0.5) * 2^-24;  r = sqrt(-2 ln u_a);  (r cos 2 pi u_b, r sin 2 pi u_b)
+    Computed in float64 and rounded to float32 (the kernel's fp32 result agrees to a few ulp).
+    """
+    rows = np.asarray(rows, dtype=np.uint32)[:, None]
+    q = np.arange((H + 3) // 4, dtype=np.uint32)[None, :]
+    x0, x1, x2, x3 = philox4x32_10(rows, np.uint32(step), q, np.uint32(0),
+                                   seed & 0xFFFFFFFF, (seed >> 32) & 0xFFFFFFFF)
+
+    def u(x):
+        return ((x >> np.uint32(8)).astype(np.float64) + 0.5) * (2.0 ** -24)
+
+    ra = np.sqrt(-2.0 * np.log(u(x0)))
+    rb = np.sqrt(-2.0 * np.log(u(x2)))
+    z = np.stack([ra * np.cos(2 * math.pi * u(x1)), ra * np.sin(2 * math.pi * u(x1)),
+                  rb * np.cos(2 * math.pi * u(x3)), rb * np.sin(2 * math.pi * u(x3))], axis=-1)
+    z = z.reshape(rows.shape[0], -1)[:, :H]
+    return z.astype(np.float32)
+
+
+def philox_dW(seed, row_offset, B, H, t0s, t1s):
+    """dW (N, B, H) float32: Z * sqrt(t1 - t0), both factors float32."""
+    rows = np.arange(row_offset, row_offset + B)
+    out = np.empty((t0s.shape[0], B, H), dtype=np.float32)
+    for n in range(t0s.shape[0]):
+        h = np.float32(t1s[n]) - np.float32(t0s[n])
+        out[n] = philox_normals(seed, rows, n, H) * np.sqrt(h, dtype=np.float32)
+    return out
