@@ -1,0 +1,163 @@
+#!/usr/bin/env python
+"""bench.py - SDE solver row-steps/s on the BASELINE.json headline configuration.
+
+One "step" of this benchmark = ONE forward solve (torchsde.sdeint replacement) of the K2 workload
+(BASELINE.json configs[1]): Neural LNSDE (input_option 4, noise_option 17), NL=2,
+B=1024 rows per GPU, H=HH=128, C=21, times=arange(101), 30 % NaN observations -> natural-spline
+coefficients (1024, 100, 84), dt=1 -> N=100 Euler steps, ts=[0, 100], Brownian increments from the
+in-kernel Philox generator, inputs resident in HBM.  value = rows x solver-steps x K / wall time.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+Multi-GPU: the batch shards by rows, one process per GPU, no collective inside the solver
+(weak scaling: every rank solves its own 1024-row shard of a 1024*N-row global batch, Philox counters
+use the global row index).  Timing: barrier + synchronize on both sides, MAX over ranks.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import stable_neural_sdes_amd as S  # noqa: E402
+
+# K2 workload -----------------------------------------------------------------------------------------
+IO, NO, NL, B, H, C, L, NSTEP = 4, 17, 2, 1024, 128, 21, 101, 100
+FLOP_PER_ROWSTEP = 169_728          # SURVEY.md 8d "ALGORITHMIC flops per unit", K2 (t-only diffusion hoisted)
+BYTES_PER_ROWSTEP = 346             # SURVEY.md 8d algorithmic HBM bytes, Philox + final state only
+PEAK_FP32_TFLOPS = 157.3            # MI355X_MICROARCH.md: fp32 vector = fp32 MFMA peak
+PEAK_HBM_GBS = 8000.0
+
+
+def build_inputs(device, rank):
+    from tests.helpers import make_problem, param_spec
+    pr = make_problem(1234 + rank, IO, NO, NL, B, H, C, L, nan_frac=0.3)
+    # weights are replicated: every rank uses rank 0's parameter draw
+    p0 = make_problem(1234, IO, NO, NL, 1, H, C, L, nan_frac=0.0)['params'] if rank else pr['params']
+    flat = torch.from_numpy(np.concatenate([p0[n].reshape(-1) for n, _ in param_spec(IO, NO, NL, C, H)])).to(device)
+    coeffs = torch.from_numpy(pr['coeffs']).to(device)
+    y0 = torch.from_numpy(pr['y0']).to(device)
+    return pr, p0, flat, coeffs, y0
+
+
+def cpu_baseline(pr, params, budget_s=12.0):
+    """The reference's CPU path restated op-for-op with torch CPU tensors (oracle/torch_loop.py), timed on
+    this host with all cores: solves of the SAME K2 workload until ~budget_s seconds have elapsed."""
+    from oracle import torch_loop as T
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    p = {k: torch.from_numpy(np.asarray(v, dtype=np.float32)) for k, v in params.items()}
+    coeffs, times, y0 = torch.from_numpy(pr['coeffs']), torch.from_numpy(pr['times']), torch.from_numpy(pr['y0'])
+    gen = torch.Generator().manual_seed(0)
+    T.euler_solve(p, IO, NO, coeffs, times, y0, 0.0, 5, 1.0, generator=gen)   # warm-up
+    solves, t_begin = 0, time.perf_counter()
+    while True:
+        T.euler_solve(p, IO, NO, coeffs, times, y0, 0.0, NSTEP, 1.0, generator=gen)
+        solves += 1
+        el = time.perf_counter() - t_begin
+        if el > budget_s or solves >= 50:
+            break
+    return {"value": B * NSTEP * solves / el, "unit": "row-steps/s", "cores": cores, "kind": "port",
+            "sample": f"{solves} full K2 forward solves (B={B}, {NSTEP} Euler steps each) of oracle/torch_loop.py "
+                      f"(torch {torch.__version__} CPU fp32, {cores} threads), {el:.1f} s"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=50)
+    ap.add_argument('--warmup', type=int, default=5)
+    ap.add_argument('--kernel', default='auto')
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    args = ap.parse_args()
+
+    rank = int(os.environ.get('RANK', '0'))
+    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    if args.gpus > 1 and world == 1:
+        raise SystemExit('for --gpus N > 1 launch with: python -m torch.distributed.run --nnodes=1 '
+                         '--nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...')
+    assert torch.cuda.is_available(), 'bench.py needs a GPU (there is no CPU fallback for the product path)'
+    torch.cuda.set_device(local_rank)
+    dev = torch.device('cuda', local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        dist.init_process_group('nccl', device_id=dev)
+
+    pr, params, flat, coeffs, y0 = build_inputs(dev, rank)
+    model = S.engine.model_struct(C, H, H, NL, IO, NO)
+    grid = S.engine.step_grid(np.array([0.0, float(NSTEP)], np.float32), 1.0, pr['times'], dev)
+    assert grid.N == NSTEP
+    call = S.engine.SolveCall(model, flat, coeffs, grid, y0, dW=None, method='euler', seed=2024,
+                              row_offset=rank * B, kernel=args.kernel)
+    stream = torch.cuda.current_stream(dev)
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+
+    for _ in range(args.warmup):
+        call.launch(stream)
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        call.launch(stream)          # full call: weight pack + time table + fused solve
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    # dominant kernel: the fused solve alone (prepared workspace reused), HIP events on the launch stream
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(20)]
+    for a, b in ev:
+        a.record(stream)
+        call.launch(stream, reuse_prepared=True)
+        b.record(stream)
+    torch.cuda.synchronize(dev)
+    kern_ms = float(np.mean([a.elapsed_time(b) for a, b in ev]))
+    ys = call.ys
+    assert bool(torch.isfinite(ys).all()), 'non-finite solver output'
+
+    if rank == 0:
+        rowsteps = B * NSTEP
+        value = world * rowsteps * args.steps / elapsed
+        ach_tf = rowsteps * FLOP_PER_ROWSTEP / (kern_ms * 1e-3) / 1e12
+        ach_gbs = rowsteps * BYTES_PER_ROWSTEP / (kern_ms * 1e-3) / 1e9
+        out = {
+            "metric": "SDE solver steps/sec (batch x steps / s), forward solve",
+            "value": value, "unit": "row-steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "K2: Neural LNSDE (io=4,no=17) NL=2 B=1024/GPU H=128 C=21 L=101 natural-spline "
+                                   "coeffs 30% NaN, 100 Euler steps dt=1, ts=[0,100], in-kernel Philox dW",
+                       "rows_per_gpu": B, "solver_steps": NSTEP, "global_rows": world * B,
+                       "parallelism": f"row-shard x{world}, no collective in the solver", "kernel": args.kernel},
+            "roofline": {"bound": "mfma", "achieved": ach_tf, "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s",
+                         "frac": ach_tf / PEAK_FP32_TFLOPS, "traffic": None,
+                         "kernel_ms": kern_ms, "flop_per_rowstep": FLOP_PER_ROWSTEP,
+                         "hbm_frac": ach_gbs / PEAK_HBM_GBS, "hbm_achieved_GBs": ach_gbs,
+                         "note": "fp32 FMA/MFMA roof binds (intensity ~490 FLOP/B); hbm_* = algorithmic 346 B/row-step"},
+        }
+        if not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(pr, params)
+            out["speedup_vs_cpu"] = value / world / out["cpu_baseline"]["value"]
+        print(json.dumps(out))
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

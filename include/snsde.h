@@ -1,0 +1,148 @@
+/*
+ * snsde.h - C ABI of the MI355X-native Neural-SDE integration engine (libsnsde.so).
+ *
+ * The reference (yongkyung-oh/Stable-Neural-SDEs) is pure Python: it has no native interface.
+ * The entry points below are what a binding for the hot path
+ *
+ *     torchsde.sdeint(sde=Diffusion_model, y0, ts, dt, method=...)
+ *         benchmark_classification/models_sde/neuralsde.py:71-82   (call site, "A1" in SURVEY.md 8a)
+ *         benchmark_forecasting/models_sde/neuralsde.py:71-82,145-156
+ *         torch-ists/torch_ists/diff_module/NSDE/nsde_model.py:63-74
+ *     torchcde.CubicSpline(coeffs, times).evaluate(t)
+ *         benchmark_classification/models_sde/neuralsde.py:181-184, 296   (set_X / f)
+ *         benchmark_classification/controldiffeq/interpolate.py:263-276    (vendored twin)
+ *
+ * would bind.  Plain C types, device pointers and sizes only; no torch types.  Every buffer is
+ * caller-owned.  Launch functions only ENQUEUE work on the given HIP stream: they never allocate,
+ * never synchronise and never throw, so a solve can be captured into a hipGraph.  All functions
+ * return SNSDE_OK (0) or a negative error code (snsde_strerror()).  The library is stateless and
+ * re-entrant; concurrent calls on different streams / devices are legal.
+ *
+ * All tensors are float32, row-major, contiguous.
+ */
+#ifndef SNSDE_H
+#define SNSDE_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SNSDE_VERSION 1
+
+enum {
+    SNSDE_OK = 0,
+    SNSDE_ERR_NULL = -1,         /* required pointer is NULL                                  */
+    SNSDE_ERR_DIMS = -2,         /* non-positive / inconsistent dimension                      */
+    SNSDE_ERR_OPTION = -3,       /* input_option not in 0..6 or noise_option not in 0..19      */
+    SNSDE_ERR_UNSUPPORTED = -4,  /* valid request this build has no kernel for                 */
+    SNSDE_ERR_WORKSPACE = -5,    /* workspace too small (see snsde_workspace_bytes)             */
+    SNSDE_ERR_LDS = -6,          /* configuration exceeds the 160 KiB LDS budget of a CU        */
+    SNSDE_ERR_TS = -7,           /* ts not strictly increasing / dt <= 0 / no fp32 progress     */
+    SNSDE_ERR_LAUNCH = -8,       /* hipLaunchKernel reported an error                           */
+    SNSDE_ERR_INDEX = -9         /* index out of range                                          */
+};
+
+enum { SNSDE_EULER = 0, SNSDE_MILSTEIN = 1 };
+
+/* kernel selection (for tests / benchmarking); 0 lets the library choose */
+enum { SNSDE_KERNEL_AUTO = 0, SNSDE_KERNEL_GENERIC = 1, SNSDE_KERNEL_MFMA = 2 };
+
+/* flags: REUSE_PREPARED skips the weight packing / time-table kernels; legal when `params`,
+ * `step_tab` and `workspace` are unchanged since the previous call that ran them (e.g. every
+ * batch of an evaluation epoch, or graph replays between optimizer steps). */
+enum { SNSDE_FLAG_REUSE_PREPARED = 1 };
+
+/* Shape of a Diffusion_model: neuralsde.py:123-179 constructor arguments. */
+typedef struct snsde_model {
+    int32_t input_channels;          /* C  */
+    int32_t hidden_channels;         /* H  */
+    int32_t hidden_hidden_channels;  /* HH (the reference requires HH == H whenever emb is used) */
+    int32_t num_hidden_layers;       /* NL >= 1; there are NL-1 `linears` */
+    int32_t input_option;            /* 0..6  */
+    int32_t noise_option;            /* 0..19 */
+} snsde_model;
+
+/* ---- parameter block ------------------------------------------------------------------------
+ * The engine reads ONE flat float32 buffer holding every parameter of the Diffusion_model in
+ * state_dict order with the reference's names and nn.Linear layout (weight (out,in) row-major):
+ *   theta (1,1) | sigma (1) | sigma_diag (H) | initial_network.{weight (H,C),bias} |
+ *   linear_in.{weight (HH, H or H+2),bias} | emb.{weight (H,2H),bias} | linears.i.{weight,bias} |
+ *   linear_out.{weight (H,HH),bias} | noise_t[.0/.2].* | noise_y[.0/.2].*
+ * (neuralsde.py:142-179).  These functions describe that layout so a host can fill it. */
+int     snsde_param_count(const snsde_model* m);                 /* number of tensors, or <0 */
+int64_t snsde_param_numel(const snsde_model* m);                 /* total floats, or <0      */
+int     snsde_param_info(const snsde_model* m, int index, char* name, int name_cap,
+                         int64_t* offset, int32_t* rows, int32_t* cols);
+
+/* ---- fixed-step time grid (host, CPU) --------------------------------------------------------
+ * torchsde 0.2.5 BaseSDESolver.integrate bookkeeping, emulated in float32:
+ *   curr = ts[0]; for out_t in ts[1:]: while curr < out_t: next = min(curr + dt, ts[-1]); step
+ * plus, per step, the spline interval of t0 on the knot grid `times`
+ * (interpolate.py:263-268: idx = clamp(#{j: times[j] < t} - 1, 0, L-2), frac = t - times[idx]).
+ *
+ * step_tab row (SNSDE_STEP_STRIDE floats): t0, h = t1-t0, sin(t0), cos(t0), frac, idx (int32 bit
+ * pattern), sqrt(h), t1.  out_step[k] = index of the solver step after which output k+1 is
+ * emitted; out_w[2k], out_w[2k+1] = linear_interp weights (t1-t)/(t1-t0), (t-t0)/(t1-t0).   */
+#define SNSDE_STEP_STRIDE 8
+int snsde_grid_count(const float* ts, int32_t n_out, double dt, int32_t* n_steps);
+int snsde_grid_build(const float* ts, int32_t n_out, double dt, const float* times, int32_t knots,
+                     int32_t n_steps, float* step_tab, int32_t* out_step, float* out_w);
+
+/* ---- the solve --------------------------------------------------------------------------------
+ * Replaces torchsde.sdeint(sde=Diffusion_model, y0, ts, dt, method) (neuralsde.py:78-82):
+ * every solver step fuses X(t) (A10), f (A7), g (A8), the Brownian increment (A5) and the
+ * Euler / Milstein update (A4/A6) for a tile of batch rows; rows are independent.            */
+typedef struct snsde_solve {
+    snsde_model model;
+    int32_t  batch;        /* B: rows on this device                                             */
+    int32_t  knots;        /* L: len(times); coeffs has L-1 intervals                            */
+    int32_t  n_steps;      /* N (snsde_grid_count)                                               */
+    int32_t  n_out;        /* T = len(ts)                                                        */
+    int32_t  method;       /* SNSDE_EULER | SNSDE_MILSTEIN                                       */
+    int32_t  kernel;       /* SNSDE_KERNEL_*                                                     */
+    int32_t  flags;        /* SNSDE_FLAG_*                                                       */
+    int32_t  reserved;     /* must be 0                                                          */
+    int64_t  row_offset;   /* global index of local row 0 (batch shards keep the global Philox   */
+                           /* stream: counter = (row_offset + row, step, col/4, 0))              */
+    uint64_t seed;         /* Philox key                                                         */
+    const float*   params;    /* device, snsde_param_numel floats                                */
+    const float*   coeffs;    /* device (B, L-1, 4C) = cat[a, b, two_c, three_d]                  */
+    const float*   step_tab;  /* device (N, SNSDE_STEP_STRIDE)                                   */
+    const int32_t* out_step;  /* device (T-1)                                                    */
+    const float*   out_w;     /* device (T-1, 2)                                                 */
+    const float*   y0;        /* device (B, H)                                                   */
+    const float*   dW;        /* device (N, B, H) supplied increments bm(t0,t1), or NULL: Philox */
+    float*         ys;        /* device (T, B, H) out; ys[0] = y0                                */
+    float*         traj;      /* optional device (N+1, B, H): every solver state                 */
+    float*         dW_out;    /* optional device (N, B, H): the increments actually used         */
+    void*          workspace; /* device scratch, >= snsde_workspace_bytes()                      */
+    size_t         workspace_bytes;
+} snsde_solve;
+
+size_t snsde_workspace_bytes(const snsde_solve* s);
+int    snsde_solve_forward(const snsde_solve* s, void* hip_stream);
+
+/* ---- cubic spline evaluation (A10) -----------------------------------------------------------
+ * out[b, c] = a + (b + (0.5*two_c + three_d*frac/3)*frac)*frac   on interval `index`
+ * (derivative != 0: b + (two_c + three_d*frac)*frac), operation order as
+ * controldiffeq/interpolate.py:270-283 (bit-exact with the CPU reference).                      */
+int snsde_spline_evaluate(const float* coeffs, int32_t batch, int32_t knots, int32_t channels,
+                          int32_t index, float frac, int32_t derivative, float* out, void* hip_stream);
+
+/* vector-field probe: one evaluation of f(t,y) and g(t,y) (neuralsde.py:295-307) through the same
+ * device code the solver uses.  `step_row` = one step_tab row (device, SNSDE_STEP_STRIDE floats)
+ * describing t; y, f_out, g_out are device (B, H).  Uses s->model/batch/knots/params/coeffs/
+ * workspace only.                                                                             */
+int snsde_eval_fg(const snsde_solve* s, const float* step_row, const float* y, float* f_out,
+                  float* g_out, void* hip_stream);
+
+int         snsde_version(void);
+const char* snsde_strerror(int code);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SNSDE_H */

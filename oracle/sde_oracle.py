@@ -550,7 +550,8 @@ def philox_normals(seed, rows, step, H):
 
     counter = (row, step, col // 4, 0), key = (seed & 0xffffffff, seed >> 32); the four 32-bit
     outputs x0..x3 give columns 4q..4q+3 by two Box-Muller pairs:
-        u = ((x >> 8) + 0.5) * 2^-24;  r = sqrt(-2 ln u_a);  (r cos 2 pi u_b, r sin 2 pi u_b)
+        u = ((x >> 9) + 0.5) * 2^-23  (exact in fp32);  r = sqrt(-2 ln u_a);
+        (r cos 2 pi u_b, r sin 2 pi u_b)
     Computed in float64 and rounded to float32 (the kernel's fp32 result agrees to a few ulp).
     """
     rows = np.asarray(rows, dtype=np.uint32)[:, None]
@@ -559,7 +560,7 @@ def philox_normals(seed, rows, step, H):
                                    seed & 0xFFFFFFFF, (seed >> 32) & 0xFFFFFFFF)
 
     def u(x):
-        return ((x >> np.uint32(8)).astype(np.float64) + 0.5) * (2.0 ** -24)
+        return ((x >> np.uint32(9)).astype(np.float64) + 0.5) * (2.0 ** -23)
 
     ra = np.sqrt(-2.0 * np.log(u(x0)))
     rb = np.sqrt(-2.0 * np.log(u(x2)))

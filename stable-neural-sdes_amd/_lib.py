@@ -1,0 +1,99 @@
+"""ctypes binding of libsnsde.so (C ABI: include/snsde.h).
+
+The shared library is built in-tree by ``build.py`` (``__graft_entry__.build()``).  There is no
+Python/CPU substitute for it: ``lib()`` raises if it is missing.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, 'libsnsde.so')
+
+SNSDE_STEP_STRIDE = 8
+EULER, MILSTEIN = 0, 1
+KERNEL_AUTO, KERNEL_GENERIC, KERNEL_MFMA = 0, 1, 2
+FLAG_REUSE_PREPARED = 1
+KERNELS = {'auto': KERNEL_AUTO, 'generic': KERNEL_GENERIC, 'mfma': KERNEL_MFMA}
+
+
+class Model(C.Structure):
+    _fields_ = [('input_channels', C.c_int32), ('hidden_channels', C.c_int32),
+                ('hidden_hidden_channels', C.c_int32), ('num_hidden_layers', C.c_int32),
+                ('input_option', C.c_int32), ('noise_option', C.c_int32)]
+
+
+class Solve(C.Structure):
+    _fields_ = [('model', Model), ('batch', C.c_int32), ('knots', C.c_int32), ('n_steps', C.c_int32),
+                ('n_out', C.c_int32), ('method', C.c_int32), ('kernel', C.c_int32), ('flags', C.c_int32),
+                ('reserved', C.c_int32),
+                ('row_offset', C.c_int64), ('seed', C.c_uint64),
+                ('params', C.c_void_p), ('coeffs', C.c_void_p), ('step_tab', C.c_void_p),
+                ('out_step', C.c_void_p), ('out_w', C.c_void_p), ('y0', C.c_void_p), ('dW', C.c_void_p),
+                ('ys', C.c_void_p), ('traj', C.c_void_p), ('dW_out', C.c_void_p),
+                ('workspace', C.c_void_p), ('workspace_bytes', C.c_size_t)]
+
+
+class SnsdeError(RuntimeError):
+    def __init__(self, code, what=''):
+        self.code = code
+        msg = lib().snsde_strerror(code).decode()
+        super().__init__(f'libsnsde: {msg} (code {code}){": " + what if what else ""}')
+
+
+_lib = None
+
+EXPORTS = ('snsde_version', 'snsde_strerror', 'snsde_param_count', 'snsde_param_numel', 'snsde_param_info',
+           'snsde_grid_count', 'snsde_grid_build', 'snsde_workspace_bytes', 'snsde_solve_forward',
+           'snsde_spline_evaluate', 'snsde_eval_fg')
+
+
+def lib():
+    """Load libsnsde.so once.  Raises RuntimeError when it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(
+            f'{LIB_PATH} not found: the HIP engine is not built. Run `python -c "import __graft_entry__ as g; '
+            f'g.build()"` (hipcc --offload-arch=gfx950) from the repository root. There is no CPU fallback.')
+    L = C.CDLL(LIB_PATH)
+    L.snsde_version.restype = C.c_int
+    L.snsde_strerror.restype = C.c_char_p
+    L.snsde_strerror.argtypes = [C.c_int]
+    L.snsde_param_count.argtypes = [C.POINTER(Model)]
+    L.snsde_param_numel.argtypes = [C.POINTER(Model)]
+    L.snsde_param_numel.restype = C.c_int64
+    L.snsde_param_info.argtypes = [C.POINTER(Model), C.c_int, C.c_char_p, C.c_int, C.POINTER(C.c_int64),
+                                   C.POINTER(C.c_int32), C.POINTER(C.c_int32)]
+    L.snsde_grid_count.argtypes = [C.c_void_p, C.c_int32, C.c_double, C.POINTER(C.c_int32)]
+    L.snsde_grid_build.argtypes = [C.c_void_p, C.c_int32, C.c_double, C.c_void_p, C.c_int32, C.c_int32,
+                                   C.c_void_p, C.c_void_p, C.c_void_p]
+    L.snsde_workspace_bytes.argtypes = [C.POINTER(Solve)]
+    L.snsde_workspace_bytes.restype = C.c_size_t
+    L.snsde_solve_forward.argtypes = [C.POINTER(Solve), C.c_void_p]
+    L.snsde_spline_evaluate.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_float,
+                                        C.c_int32, C.c_void_p, C.c_void_p]
+    L.snsde_eval_fg.argtypes = [C.POINTER(Solve), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+    _lib = L
+    return L
+
+
+def check(code, what=''):
+    if code != 0:
+        raise SnsdeError(code, what)
+
+
+def param_layout(model):
+    """[(name, offset, shape)] of the flat parameter block, in state_dict order."""
+    L = lib()
+    n = L.snsde_param_count(C.byref(model))
+    check(min(n, 0), 'snsde_param_count')
+    out = []
+    buf = C.create_string_buffer(64)
+    off, rows, cols = C.c_int64(), C.c_int32(), C.c_int32()
+    for i in range(n):
+        check(L.snsde_param_info(C.byref(model), i, buf, 64, C.byref(off), C.byref(rows), C.byref(cols)))
+        name = buf.value.decode()
+        shape = (rows.value, cols.value) if cols.value > 0 else (rows.value,)
+        out.append((name, off.value, shape))
+    return out, int(L.snsde_param_numel(C.byref(model)))

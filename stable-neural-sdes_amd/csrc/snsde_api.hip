@@ -1,0 +1,330 @@
+// C-ABI entry points of libsnsde.so (include/snsde.h): parameter layout, torchsde-style fixed-step
+// time grid (host), argument validation and kernel dispatch.
+#include <math.h>
+#include <stdio.h>
+#include <string.h>
+
+#include "snsde_internal.h"
+
+namespace {
+
+struct ParamEntry {
+    char name[40];
+    int64_t offset;
+    int32_t rows, cols;  // bias / vectors: rows = n, cols = 0 ; theta: (1,1)
+};
+
+constexpr int MAX_PARAMS = 2 * (SNSDE_MAX_HIDDEN + 8) + 4;
+
+int validate_model(const snsde_model* m) {
+    if (!m) return SNSDE_ERR_NULL;
+    if (m->input_channels <= 0 || m->hidden_channels <= 0 || m->hidden_hidden_channels <= 0 ||
+        m->num_hidden_layers <= 0)
+        return SNSDE_ERR_DIMS;
+    if (m->num_hidden_layers - 1 > SNSDE_MAX_HIDDEN) return SNSDE_ERR_UNSUPPORTED;
+    if (m->input_option < 0 || m->input_option > 6 || m->noise_option < 0 || m->noise_option > 19)
+        return SNSDE_ERR_OPTION;
+    const int io = m->input_option;
+    // emb = Linear(2H, H) consumes cat[yy (HH), Xt (H)] and io 0 feeds Xt (H) to the HH-wide MLP:
+    // both need HH == H (neuralsde.py:150-158, 206-210)
+    if ((io == 0 || io == 2 || io == 4 || io == 6) && m->hidden_hidden_channels != m->hidden_channels)
+        return SNSDE_ERR_DIMS;
+    return SNSDE_OK;
+}
+
+// state_dict order of the reference Diffusion_model (neuralsde.py:142-179): direct parameters
+// (theta, sigma, sigma_diag) first, then the sub-modules in definition order.
+int build_params(const snsde_model* m, ParamEntry* e, int* count, int64_t* total) {
+    int rc = validate_model(m);
+    if (rc) return rc;
+    const int C = m->input_channels, H = m->hidden_channels, HH = m->hidden_hidden_channels;
+    const int io = m->input_option, no = m->noise_option;
+    int n = 0;
+    int64_t off = 0;
+    auto vec = [&](const char* name, int len) {
+        snprintf(e[n].name, sizeof(e[n].name), "%s", name);
+        e[n].offset = off; e[n].rows = len; e[n].cols = 0; off += len; ++n;
+    };
+    auto lin = [&](const char* name, int rows, int cols) {
+        snprintf(e[n].name, sizeof(e[n].name), "%s.weight", name);
+        e[n].offset = off; e[n].rows = rows; e[n].cols = cols; off += (int64_t)rows * cols; ++n;
+        snprintf(e[n].name, sizeof(e[n].name), "%s.bias", name);
+        e[n].offset = off; e[n].rows = rows; e[n].cols = 0; off += rows; ++n;
+    };
+    snprintf(e[n].name, sizeof(e[n].name), "theta");
+    e[n].offset = off; e[n].rows = 1; e[n].cols = 1; off += 1; ++n;
+    if (no >= 1 && no <= 3) vec("sigma", 1);
+    if (no >= 4 && no <= 6) vec("sigma_diag", H);
+    lin("initial_network", H, C);
+    lin("linear_in", HH, (io >= 3) ? H + 2 : H);
+    if (io == 2 || io == 4 || io == 6) lin("emb", H, 2 * H);
+    for (int i = 0; i < m->num_hidden_layers - 1; ++i) {
+        char nm[32];
+        snprintf(nm, sizeof(nm), "linears.%d", i);
+        lin(nm, HH, HH);
+    }
+    lin("linear_out", H, HH);
+    if (no == 12 || no == 13) lin("noise_t", H, 2);
+    if (no == 14 || no == 15) lin("noise_y", H, H + 2);
+    if (no == 16 || no == 17) { lin("noise_t.0", H, 2); lin("noise_t.2", H, H); }
+    if (no == 18 || no == 19) { lin("noise_y.0", H, H + 2); lin("noise_y.2", H, H); }
+    *count = n;
+    *total = off;
+    return SNSDE_OK;
+}
+
+int find(const ParamEntry* e, int n, const char* name) {
+    for (int i = 0; i < n; ++i)
+        if (strcmp(e[i].name, name) == 0) return i;
+    return -1;
+}
+
+}  // namespace
+
+int snsde_build_net(const snsde_model& m, int32_t n_steps, SnsdeNet* net) {
+    ParamEntry e[MAX_PARAMS];
+    int n = 0;
+    int64_t total = 0;
+    int rc = build_params(&m, e, &n, &total);
+    if (rc) return rc;
+    if (total > 0x7fffffffLL) return SNSDE_ERR_DIMS;
+    memset(net, 0, sizeof(*net));
+    const int io = m.input_option, no = m.noise_option;
+    int32_t woff = 0;
+    auto fill = [&](SnsdeLayer& L, const char* name, int tshift, bool packed) {
+        char w[48], b[48];
+        snprintf(w, sizeof(w), "%s.weight", name);
+        snprintf(b, sizeof(b), "%s.bias", name);
+        const int iw = find(e, n, w), ib = find(e, n, b);
+        if (iw < 0) { L.present = 0; L.w = -1; return; }
+        L.present = 1;
+        L.src_w = (int32_t)e[iw].offset;
+        L.src_b = (int32_t)e[ib].offset;
+        L.N = e[iw].rows;
+        L.K = e[iw].cols;
+        L.Kpad = (L.K + 3) & ~3;
+        L.tshift = tshift;
+        if (packed) { L.w = woff; woff += L.Kpad * L.N; } else { L.w = -1; }
+    };
+    const bool uses_x = (io == 0 || io == 2 || io == 4 || io == 6);
+    fill(net->init, "initial_network", 0, uses_x);
+    if (!uses_x) net->init.w = -1;
+    fill(net->in, "linear_in", io >= 3 ? 2 : 0, io != 0);
+    if (io == 0) net->in.w = -1;
+    fill(net->emb, "emb", 0, true);
+    net->n_hid = m.num_hidden_layers - 1;
+    for (int i = 0; i < net->n_hid; ++i) {
+        char nm[32];
+        snprintf(nm, sizeof(nm), "linears.%d", i);
+        fill(net->hid[i], nm, 0, true);
+    }
+    fill(net->out, "linear_out", 0, true);
+    if (no == 14 || no == 15) fill(net->ny0, "noise_y", 2, true);
+    if (no == 18 || no == 19) { fill(net->ny0, "noise_y.0", 2, true); fill(net->ny1, "noise_y.2", 0, true); }
+    if (no == 12 || no == 13) fill(net->nt0, "noise_t", 0, false);
+    if (no == 16 || no == 17) { fill(net->nt0, "noise_t.0", 0, false); fill(net->nt1, "noise_t.2", 0, false); }
+    net->off_theta = (int32_t)e[find(e, n, "theta")].offset;
+    int i = find(e, n, "sigma");
+    net->off_sigma = i >= 0 ? (int32_t)e[i].offset : -1;
+    i = find(e, n, "sigma_diag");
+    net->off_sigma_diag = i >= 0 ? (int32_t)e[i].offset : -1;
+    net->packed_floats = (woff + 3) & ~3;
+    net->gt_tab = (no == 12 || no == 13 || no == 16 || no == 17) ? net->packed_floats : -1;
+    (void)n_steps;
+    return SNSDE_OK;
+}
+
+extern "C" {
+
+int snsde_version(void) { return SNSDE_VERSION; }
+
+const char* snsde_strerror(int code) {
+    switch (code) {
+        case SNSDE_OK: return "ok";
+        case SNSDE_ERR_NULL: return "required pointer is NULL";
+        case SNSDE_ERR_DIMS: return "bad or inconsistent dimensions";
+        case SNSDE_ERR_OPTION: return "input_option must be 0..6 and noise_option 0..19";
+        case SNSDE_ERR_UNSUPPORTED: return "configuration not supported by this build";
+        case SNSDE_ERR_WORKSPACE: return "workspace too small";
+        case SNSDE_ERR_LDS: return "configuration exceeds the LDS budget";
+        case SNSDE_ERR_TS: return "ts must be strictly increasing, dt > 0 and representable progress in float32";
+        case SNSDE_ERR_LAUNCH: return "HIP kernel launch failed";
+        case SNSDE_ERR_INDEX: return "index out of range";
+        default: return "unknown error";
+    }
+}
+
+int snsde_param_count(const snsde_model* m) {
+    ParamEntry e[MAX_PARAMS];
+    int n = 0;
+    int64_t total = 0;
+    int rc = build_params(m, e, &n, &total);
+    return rc ? rc : n;
+}
+
+int64_t snsde_param_numel(const snsde_model* m) {
+    ParamEntry e[MAX_PARAMS];
+    int n = 0;
+    int64_t total = 0;
+    int rc = build_params(m, e, &n, &total);
+    return rc ? rc : total;
+}
+
+int snsde_param_info(const snsde_model* m, int index, char* name, int name_cap, int64_t* offset, int32_t* rows,
+                     int32_t* cols) {
+    ParamEntry e[MAX_PARAMS];
+    int n = 0;
+    int64_t total = 0;
+    int rc = build_params(m, e, &n, &total);
+    if (rc) return rc;
+    if (index < 0 || index >= n) return SNSDE_ERR_INDEX;
+    if (name && name_cap > 0) snprintf(name, name_cap, "%s", e[index].name);
+    if (offset) *offset = e[index].offset;
+    if (rows) *rows = e[index].rows;
+    if (cols) *cols = e[index].cols;
+    return SNSDE_OK;
+}
+
+// torchsde 0.2.5 BaseSDESolver.integrate time bookkeeping in float32.
+static int walk_grid(const float* ts, int32_t T, double dt, const float* times, int32_t L, int32_t cap,
+                     float* step_tab, int32_t* out_step, float* out_w, int32_t* n_steps) {
+    if (!ts) return SNSDE_ERR_NULL;
+    if (T < 2) return SNSDE_ERR_TS;
+    if (!(dt > 0)) return SNSDE_ERR_TS;
+    for (int k = 1; k < T; ++k)
+        if (!(ts[k] > ts[k - 1])) return SNSDE_ERR_TS;
+    const float step = (float)dt;
+    const float t_end = ts[T - 1];
+    float curr = ts[0], prev = ts[0];
+    int32_t n = 0;
+    for (int k = 1; k < T; ++k) {
+        const float out_t = ts[k];
+        while (curr < out_t) {
+            volatile float nx = curr + step;  // force fp32 rounding
+            float nxt = nx;
+            if (t_end < nxt) nxt = t_end;
+            if (!(nxt > curr)) return SNSDE_ERR_TS;
+            if (step_tab) {
+                if (n >= cap) return SNSDE_ERR_DIMS;
+                float* r = step_tab + (size_t)n * SNSDE_STEP_STRIDE;
+                volatile float h = nxt - curr;
+                r[0] = curr;
+                r[1] = h;
+                r[2] = sinf(curr);
+                r[3] = cosf(curr);
+                int idx = 0;
+                if (times) {
+                    int cnt = 0;
+                    for (int j = 0; j < L; ++j) cnt += (curr > times[j]) ? 1 : 0;
+                    idx = cnt - 1;
+                    if (idx < 0) idx = 0;
+                    if (idx > L - 2) idx = L - 2;
+                    volatile float fr = curr - times[idx];
+                    r[4] = fr;
+                } else {
+                    r[4] = 0.0f;
+                }
+                memcpy(&r[5], &idx, sizeof(float));
+                r[6] = sqrtf(h);
+                r[7] = nxt;
+            }
+            prev = curr;
+            curr = nxt;
+            ++n;
+        }
+        if (out_step) {
+            out_step[k - 1] = n - 1;
+            volatile float denom = curr - prev;
+            volatile float a = curr - out_t, b = out_t - prev;
+            out_w[2 * (k - 1)] = a / denom;
+            out_w[2 * (k - 1) + 1] = b / denom;
+        }
+    }
+    *n_steps = n;
+    return SNSDE_OK;
+}
+
+int snsde_grid_count(const float* ts, int32_t n_out, double dt, int32_t* n_steps) {
+    if (!n_steps) return SNSDE_ERR_NULL;
+    return walk_grid(ts, n_out, dt, nullptr, 0, 0, nullptr, nullptr, nullptr, n_steps);
+}
+
+int snsde_grid_build(const float* ts, int32_t n_out, double dt, const float* times, int32_t knots, int32_t n_steps,
+                     float* step_tab, int32_t* out_step, float* out_w) {
+    if (!step_tab || !out_step || !out_w || !times) return SNSDE_ERR_NULL;
+    if (knots < 2) return SNSDE_ERR_DIMS;
+    int32_t n = 0;
+    int rc = walk_grid(ts, n_out, dt, times, knots, n_steps, step_tab, out_step, out_w, &n);
+    if (rc) return rc;
+    return n == n_steps ? SNSDE_OK : SNSDE_ERR_DIMS;
+}
+
+static int validate_solve(const snsde_solve* s, bool eval) {
+    if (!s) return SNSDE_ERR_NULL;
+    int rc = validate_model(&s->model);
+    if (rc) return rc;
+    if (s->batch <= 0 || s->knots < 2) return SNSDE_ERR_DIMS;
+    if (!s->params || !s->coeffs || !s->workspace) return SNSDE_ERR_NULL;
+    if (!eval) {
+        if (s->n_steps <= 0 || s->n_out < 2) return SNSDE_ERR_DIMS;
+        if (!s->step_tab || !s->out_step || !s->out_w || !s->y0 || !s->ys) return SNSDE_ERR_NULL;
+        if (s->method != SNSDE_EULER && s->method != SNSDE_MILSTEIN) return SNSDE_ERR_OPTION;
+        const int no = s->model.noise_option;
+        // Milstein needs dg_i/dy_i in closed form: g_i may depend on y only through y_i
+        if (s->method == SNSDE_MILSTEIN && (no == 7 || no == 14 || no == 15 || no == 18 || no == 19))
+            return SNSDE_ERR_UNSUPPORTED;
+    }
+    return SNSDE_OK;
+}
+
+size_t snsde_workspace_bytes(const snsde_solve* s) {
+    if (!s) return 0;
+    SnsdeNet net;
+    if (snsde_build_net(s->model, s->n_steps, &net)) return 0;
+    size_t f = 0;
+    snsde_solve tmp = *s;
+    if (tmp.n_steps < 1) tmp.n_steps = 1;
+    snsde_generic_workspace_floats(&tmp, net, &f);
+    return (f + 64) * sizeof(float);
+}
+
+int snsde_solve_forward(const snsde_solve* s, void* hip_stream) {
+    int rc = validate_solve(s, false);
+    if (rc) return rc;
+    if (s->workspace_bytes < snsde_workspace_bytes(s)) return SNSDE_ERR_WORKSPACE;
+    SnsdeNet net;
+    rc = snsde_build_net(s->model, s->n_steps, &net);
+    if (rc) return rc;
+    if (s->kernel == SNSDE_KERNEL_MFMA) return SNSDE_ERR_UNSUPPORTED;
+    if (s->kernel != SNSDE_KERNEL_AUTO && s->kernel != SNSDE_KERNEL_GENERIC) return SNSDE_ERR_OPTION;
+    return snsde_generic_launch(s, net, static_cast<hipStream_t>(hip_stream), 0, nullptr, nullptr, nullptr, nullptr);
+}
+
+int snsde_eval_fg(const snsde_solve* s, const float* step_row, const float* y, float* f_out, float* g_out,
+                  void* hip_stream) {
+    int rc = validate_solve(s, true);
+    if (rc) return rc;
+    if (!step_row || !y || !f_out || !g_out) return SNSDE_ERR_NULL;
+    snsde_solve tmp = *s;
+    tmp.n_steps = 1;
+    tmp.n_out = 2;
+    tmp.dW = nullptr;
+    tmp.traj = nullptr;
+    tmp.dW_out = nullptr;
+    if (s->workspace_bytes < snsde_workspace_bytes(&tmp)) return SNSDE_ERR_WORKSPACE;
+    SnsdeNet net;
+    rc = snsde_build_net(s->model, 1, &net);
+    if (rc) return rc;
+    return snsde_generic_launch(&tmp, net, static_cast<hipStream_t>(hip_stream), 1, y, f_out, g_out, step_row);
+}
+
+int snsde_spline_evaluate(const float* coeffs, int32_t batch, int32_t knots, int32_t channels, int32_t index,
+                          float frac, int32_t derivative, float* out, void* hip_stream) {
+    if (!coeffs || !out) return SNSDE_ERR_NULL;
+    if (batch <= 0 || knots < 2 || channels <= 0) return SNSDE_ERR_DIMS;
+    if (index < 0 || index > knots - 2) return SNSDE_ERR_INDEX;
+    return snsde_spline_launch(coeffs, batch, knots, channels, index, frac, derivative, out,
+                               static_cast<hipStream_t>(hip_stream));
+}
+
+}  // extern "C"

@@ -1,0 +1,115 @@
+// Internal declarations shared by the HIP translation units of libsnsde.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "snsde.h"
+
+#define SNSDE_MAX_HIDDEN 8  // NL-1 <= 8 (`linears`, neuralsde.py:156-157; the reference sweeps NL 1..4)
+
+// One nn.Linear inside the flat parameter block (src_*) and inside the packed workspace (w/b).
+// Packed weight = W^T with K padded to a multiple of 4: wt[k * N + n], zero rows for k >= K.
+// `tshift` = number of leading source columns (the [sin t, cos t] features, neuralsde.py:191-201)
+// that are rotated to the END of the packed K axis, so the state y sits at k = 0..H-1, 16-byte
+// aligned in LDS, and the time features at k = K-2, K-1.
+struct SnsdeLayer {
+    int32_t src_w;   // float offset of weight (N, K) in params
+    int32_t src_b;   // float offset of bias (N)
+    int32_t w;       // float offset of packed W^T (Kpad, N) in workspace
+    int32_t K;
+    int32_t Kpad;
+    int32_t N;
+    int32_t tshift;
+    int32_t present;
+};
+
+struct SnsdeNet {
+    SnsdeLayer init;  // initial_network   C -> H          (io 0,2,4,6)
+    SnsdeLayer in;    // linear_in         H(+2) -> HH     (io != 0)
+    SnsdeLayer emb;   // emb               2H -> H         (io 2,4,6)
+    SnsdeLayer hid[SNSDE_MAX_HIDDEN];
+    SnsdeLayer out;   // linear_out        HH -> H
+    SnsdeLayer ny0;   // noise_y / noise_y.0   H+2 -> H    (no 14,15,18,19)
+    SnsdeLayer ny1;   // noise_y.2             H -> H      (no 18,19)
+    SnsdeLayer nt0;   // noise_t / noise_t.0   2 -> H      (no 12,13,16,17)  (never packed)
+    SnsdeLayer nt1;   // noise_t.2             H -> H      (no 16,17)        (never packed)
+    int32_t n_hid;
+    int32_t off_theta, off_sigma, off_sigma_diag;  // float offsets in params (-1 if absent)
+    int32_t gt_tab;      // float offset in workspace of the time-only diffusion table (N, H), -1 if none
+    int32_t packed_floats;  // total packed weight floats
+};
+
+struct SnsdeDims {
+    int32_t B, H, HH, C, L, NL, io, no, N, T, method;
+};
+
+// host-side helpers (snsde_api.cpp)
+int snsde_build_net(const snsde_model& m, int32_t n_steps, SnsdeNet* net);
+
+// launchers (snsde_generic.hip)
+int snsde_generic_workspace_floats(const snsde_solve* s, const SnsdeNet& net, size_t* floats);
+int snsde_generic_launch(const snsde_solve* s, const SnsdeNet& net, hipStream_t stream, int eval_mode,
+                         const float* eval_y, float* eval_f, float* eval_g, const float* step_row_dev);
+int snsde_spline_launch(const float* coeffs, int32_t B, int32_t L, int32_t C, int32_t index, float frac,
+                        int32_t derivative, float* out, hipStream_t stream);
+
+// ------------------------------------------------------------------------------------------------
+// device helpers
+// ------------------------------------------------------------------------------------------------
+#ifdef __HIPCC__
+
+__device__ __forceinline__ float snsde_sigmoid(float x) { return 1.0f / (1.0f + expf(-x)); }
+
+// torch.nan_to_num defaults: NaN -> 0, +inf -> FLT_MAX, -inf -> -FLT_MAX (neuralsde.py:306)
+__device__ __forceinline__ float snsde_nan_to_num(float x) {
+    if (x != x) return 0.0f;
+    return fminf(fmaxf(x, -3.402823466e+38f), 3.402823466e+38f);
+}
+
+// Cubic piece evaluation with the reference's exact operation order and no FMA contraction
+// (controldiffeq/interpolate.py:270-276): bit-identical to the CPU reference.
+__device__ __forceinline__ float snsde_spline_eval(float a, float b, float two_c, float three_d, float frac) {
+    float inner = __fadd_rn(__fmul_rn(0.5f, two_c), __fdiv_rn(__fmul_rn(three_d, frac), 3.0f));
+    inner = __fadd_rn(b, __fmul_rn(inner, frac));
+    return __fadd_rn(a, __fmul_rn(inner, frac));
+}
+__device__ __forceinline__ float snsde_spline_deriv(float b, float two_c, float three_d, float frac) {
+    float inner = __fadd_rn(two_c, __fmul_rn(three_d, frac));
+    return __fadd_rn(b, __fmul_rn(inner, frac));
+}
+
+// Philox4x32-10 (Salmon et al., SC'11).  Specification = oracle/sde_oracle.py:philox4x32_10.
+__device__ __forceinline__ void snsde_philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3,
+                                                    uint32_t k0, uint32_t k1, uint32_t out[4]) {
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        const uint32_t hi0 = __umulhi(0xD2511F53u, c0), lo0 = 0xD2511F53u * c0;
+        const uint32_t hi1 = __umulhi(0xCD9E8D57u, c2), lo1 = 0xCD9E8D57u * c2;
+        c0 = hi1 ^ c1 ^ k0;
+        c1 = lo1;
+        c2 = hi0 ^ c3 ^ k1;
+        c3 = lo0;
+        k0 += 0x9E3779B9u;
+        k1 += 0xBB67AE85u;
+    }
+    out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
+}
+
+// Four standard normals for (global row, step, column quad): two Box-Muller pairs on 23-bit
+// uniforms u = ((x >> 9) + 0.5) * 2^-23 (exactly representable in fp32).
+__device__ __forceinline__ void snsde_philox_normal4(uint64_t seed, uint32_t row, uint32_t step, uint32_t quad,
+                                                     float z[4]) {
+    uint32_t x[4];
+    snsde_philox4x32_10(row, step, quad, 0u, (uint32_t)seed, (uint32_t)(seed >> 32), x);
+    const float s = 1.1920928955078125e-07f;  // 2^-23
+    const float ua = ((float)(x[0] >> 9) + 0.5f) * s, ub = ((float)(x[1] >> 9) + 0.5f) * s;
+    const float uc = ((float)(x[2] >> 9) + 0.5f) * s, ud = ((float)(x[3] >> 9) + 0.5f) * s;
+    const float ra = sqrtf(-2.0f * logf(ua)), rb = sqrtf(-2.0f * logf(uc));
+    float sn, cs;
+    sincospif(2.0f * ub, &sn, &cs);
+    z[0] = ra * cs; z[1] = ra * sn;
+    sincospif(2.0f * ud, &sn, &cs);
+    z[2] = rb * cs; z[3] = rb * sn;
+}
+
+#endif  // __HIPCC__

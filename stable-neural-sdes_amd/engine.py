@@ -1,0 +1,199 @@
+"""Host plumbing around the C ABI: model recognition, flat parameter block, time grid, launch.
+
+PyTorch is used only for device memory and streams; all arithmetic of the hot path runs in
+libsnsde.so (HIP).  Nothing here falls back to CPU math.
+"""
+import ctypes as C
+from collections import OrderedDict
+
+import numpy as np
+import torch
+
+from . import _lib
+
+_GRID_CACHE = OrderedDict()
+_GRID_CACHE_MAX = 16
+
+
+def model_struct(input_channels, hidden_channels, hidden_hidden_channels, num_hidden_layers, input_option,
+                 noise_option):
+    return _lib.Model(int(input_channels), int(hidden_channels), int(hidden_hidden_channels),
+                      int(num_hidden_layers), int(input_option), int(noise_option))
+
+
+def recognise(sde):
+    """Fast-path contract: an object exposing the reference Diffusion_model's attributes
+    (models_sde/neuralsde.py:123-184) and exactly its parameter names/shapes.  Returns
+    (Model struct, layout, numel) or None."""
+    need = ('input_option', 'noise_option', 'hidden_channels', 'input_channels', 'coeffs', 'times')
+    if not all(hasattr(sde, a) for a in need) or not hasattr(sde, 'named_parameters'):
+        return None
+    if getattr(sde, 'sde_type', 'ito') != 'ito' or getattr(sde, 'noise_type', 'diagonal') != 'diagonal':
+        return None
+    params = dict(sde.named_parameters())
+    lin = params.get('linear_in.weight')
+    out = params.get('linear_out.weight')
+    if lin is None or out is None:
+        return None
+    n_hidden = sum(1 for k in params if k.startswith('linears.') and k.endswith('.weight'))
+    m = model_struct(sde.input_channels, sde.hidden_channels, lin.shape[0], n_hidden + 1, sde.input_option,
+                     sde.noise_option)
+    try:
+        layout, numel = _lib.param_layout(m)
+    except _lib.SnsdeError:
+        return None
+    if set(params) != {n for n, _, _ in layout}:
+        return None
+    for name, _, shape in layout:
+        if tuple(params[name].shape) != tuple(shape):
+            return None
+    return m, layout, numel
+
+
+def flatten_params(sde, layout, numel, device):
+    """One float32 device buffer in the C ABI's layout (state_dict order)."""
+    params = dict(sde.named_parameters())
+    flat = torch.cat([params[name].detach().reshape(-1).to(device=device, dtype=torch.float32)
+                      for name, _, _ in layout])
+    assert flat.numel() == numel
+    return flat
+
+
+class StepGrid:
+    """Host + device copy of the fixed-step grid (snsde_grid_build)."""
+
+    def __init__(self, ts_host, dt, times_host, device):
+        L = _lib.lib()
+        ts32 = np.ascontiguousarray(ts_host, dtype=np.float32)
+        times32 = np.ascontiguousarray(times_host, dtype=np.float32)
+        if ts32.ndim != 1 or ts32.shape[0] < 2:
+            raise ValueError('`ts` must be a 1-D sequence of at least two times.')
+        n = C.c_int32()
+        rc = L.snsde_grid_count(ts32.ctypes.data, ts32.shape[0], float(dt), C.byref(n))
+        if rc == -7:
+            raise ValueError('Evaluation times `ts` must be strictly increasing and `dt` positive '
+                             '(and large enough to advance float32 time).')
+        _lib.check(rc, 'snsde_grid_count')
+        self.N = n.value
+        self.T = ts32.shape[0]
+        self.step_tab = np.zeros((self.N, _lib.SNSDE_STEP_STRIDE), dtype=np.float32)
+        self.out_step = np.zeros(self.T - 1, dtype=np.int32)
+        self.out_w = np.zeros((self.T - 1, 2), dtype=np.float32)
+        _lib.check(L.snsde_grid_build(ts32.ctypes.data, self.T, float(dt), times32.ctypes.data, times32.shape[0],
+                                      self.N, self.step_tab.ctypes.data, self.out_step.ctypes.data,
+                                      self.out_w.ctypes.data), 'snsde_grid_build')
+        self.t0 = self.step_tab[:, 0].copy()
+        self.t1 = self.step_tab[:, 7].copy()
+        self.device = device
+        if device is not None and device.type == 'cuda':
+            self.d_step_tab = torch.from_numpy(self.step_tab).to(device)
+            self.d_out_step = torch.from_numpy(self.out_step).to(device)
+            self.d_out_w = torch.from_numpy(self.out_w).to(device)
+
+
+def step_grid(ts_host, dt, times_host, device):
+    key = (np.asarray(ts_host, dtype=np.float32).tobytes(), float(dt),
+           np.asarray(times_host, dtype=np.float32).tobytes(), str(device))
+    g = _GRID_CACHE.get(key)
+    if g is None:
+        g = StepGrid(ts_host, dt, times_host, device)
+        _GRID_CACHE[key] = g
+        if len(_GRID_CACHE) > _GRID_CACHE_MAX:
+            _GRID_CACHE.popitem(last=False)
+    else:
+        _GRID_CACHE.move_to_end(key)
+    return g
+
+
+def _ptr(t):
+    return None if t is None else C.c_void_p(t.data_ptr())
+
+
+def _check_f32(name, t, shape=None):
+    if t.dtype != torch.float32 or not t.is_contiguous() or not t.is_cuda:
+        raise ValueError(f'{name} must be a contiguous float32 CUDA tensor')
+    if shape is not None and tuple(t.shape) != tuple(shape):
+        raise ValueError(f'{name} has shape {tuple(t.shape)}, expected {tuple(shape)}')
+
+
+class SolveCall:
+    """A fully prepared solve: owns references to every device buffer named in the descriptor so the
+    launch itself is one C call that only enqueues kernels (hipGraph-capturable)."""
+
+    def __init__(self, model, flat_params, coeffs, grid, y0, dW=None, method='euler', seed=0, row_offset=0,
+                 kernel='auto', save_traj=False, save_dW=False):
+        B, H = y0.shape
+        C_ = model.input_channels
+        L = coeffs.shape[1] + 1
+        dev = y0.device
+        _check_f32('y0', y0, (B, model.hidden_channels))
+        _check_f32('coeffs', coeffs, (B, L - 1, 4 * C_))
+        _check_f32('params', flat_params)
+        if dW is not None:
+            _check_f32('dW', dW, (grid.N, B, H))
+        self.model, self.grid = model, grid
+        self.keep = (flat_params, coeffs, y0, dW, grid)
+        self.ys = torch.empty((grid.T, B, H), device=dev, dtype=torch.float32)
+        self.traj = torch.empty((grid.N + 1, B, H), device=dev, dtype=torch.float32) if save_traj else None
+        self.dW_out = torch.empty((grid.N, B, H), device=dev, dtype=torch.float32) if save_dW else None
+        s = _lib.Solve()
+        s.model = model
+        s.batch, s.knots, s.n_steps, s.n_out = B, L, grid.N, grid.T
+        s.method = {'euler': _lib.EULER, 'milstein': _lib.MILSTEIN}[method]
+        s.kernel = _lib.KERNELS[kernel]
+        s.row_offset = int(row_offset)
+        s.seed = int(seed) & 0xFFFFFFFFFFFFFFFF
+        s.params, s.coeffs = _ptr(flat_params), _ptr(coeffs)
+        s.step_tab, s.out_step, s.out_w = _ptr(grid.d_step_tab), _ptr(grid.d_out_step), _ptr(grid.d_out_w)
+        s.y0, s.dW, s.ys = _ptr(y0), _ptr(dW), _ptr(self.ys)
+        s.traj, s.dW_out = _ptr(self.traj), _ptr(self.dW_out)
+        nbytes = _lib.lib().snsde_workspace_bytes(C.byref(s))
+        self.workspace = torch.empty(max(nbytes, 256), device=dev, dtype=torch.uint8)
+        s.workspace = _ptr(self.workspace)
+        s.workspace_bytes = self.workspace.numel()
+        self.desc = s
+
+    def launch(self, stream=None, reuse_prepared=False):
+        """Enqueue the solve.  reuse_prepared=True skips weight packing / time tables (legal while the
+        parameter block and grid are unchanged since the previous launch of this call)."""
+        stream = torch.cuda.current_stream(self.ys.device) if stream is None else stream
+        self.desc.flags = _lib.FLAG_REUSE_PREPARED if reuse_prepared else 0
+        _lib.check(_lib.lib().snsde_solve_forward(C.byref(self.desc), C.c_void_p(stream.cuda_stream)),
+                   'snsde_solve_forward')
+        return self.ys
+
+
+def eval_fg(model, flat_params, coeffs, times_host, t, y, kernel='auto'):
+    """f(t, y), g(t, y) through the solver's device code (snsde_eval_fg)."""
+    B, H = y.shape
+    L = coeffs.shape[1] + 1
+    dev = y.device
+    t = float(np.float32(t))
+    # one-row step table for time t (h is irrelevant here); nextafter keeps ts increasing
+    ts = np.array([t, np.nextafter(np.float32(t), np.float32(np.inf)) + np.float32(1.0)], dtype=np.float32)
+    g = StepGrid(ts, 2.0 + abs(t), times_host, dev)
+    s = _lib.Solve()
+    s.model = model
+    s.batch, s.knots, s.n_steps, s.n_out = B, L, 1, 2
+    s.kernel = _lib.KERNELS[kernel]
+    s.params, s.coeffs = _ptr(flat_params), _ptr(coeffs)
+    nbytes = _lib.lib().snsde_workspace_bytes(C.byref(s))
+    ws = torch.empty(max(nbytes, 256), device=dev, dtype=torch.uint8)
+    s.workspace, s.workspace_bytes = _ptr(ws), ws.numel()
+    f = torch.empty_like(y)
+    gg = torch.empty_like(y)
+    stream = torch.cuda.current_stream(dev)
+    _lib.check(_lib.lib().snsde_eval_fg(C.byref(s), _ptr(g.d_step_tab), _ptr(y), _ptr(f), _ptr(gg),
+                                        C.c_void_p(stream.cuda_stream)), 'snsde_eval_fg')
+    return f, gg
+
+
+def spline_evaluate(coeffs, index, frac, derivative=False):
+    B, Lm1, C4 = coeffs.shape
+    _check_f32('coeffs', coeffs)
+    out = torch.empty((B, C4 // 4), device=coeffs.device, dtype=torch.float32)
+    stream = torch.cuda.current_stream(coeffs.device)
+    _lib.check(_lib.lib().snsde_spline_evaluate(_ptr(coeffs), B, Lm1 + 1, C4 // 4, int(index), float(frac),
+                                                int(bool(derivative)), _ptr(out), C.c_void_p(stream.cuda_stream)),
+               'snsde_spline_evaluate')
+    return out

@@ -1,0 +1,272 @@
+"""nn.Module API of the reference's SDE models with identical constructor signatures, attribute names
+and state_dict keys/shapes, so checkpoints and the ``common_sde.py`` training loop carry over:
+
+  Diffusion_model          models_sde/neuralsde.py:123-307 (three numerically identical copies in the
+                           reference: benchmark_classification, benchmark_forecasting, torch_ists)
+  NeuralSDE                benchmark_classification/models_sde/neuralsde.py:51-120
+  NeuralSDE_forecasting    benchmark_forecasting/models_sde/neuralsde.py:123-186
+  IstsNeuralSDE            torch-ists/torch_ists/diff_module/NSDE/nsde_model.py:46-84
+
+``NeuralSDE*.forward`` reach the integrator through ``torchsde.sdeint`` exactly like the reference;
+with this package's ``torchsde`` that is the fused HIP solve for CUDA tensors.  ``Diffusion_model.f/g``
+exist for the generic tensor-op loop (CPU plumbing, autograd) and for probing; on CUDA float32
+tensors under no_grad they run through the HIP vector-field kernel.
+"""
+import torch
+from torch import nn
+
+from . import engine
+from . import torchcde as _torchcde
+from . import torchsde as _torchsde
+from .controldiffeq import _HostTimes
+
+PROPOSAL_METHOD_CONTRACT = {"lsde": (2, 16), "lnsde": (4, 17), "gsde": (6, 17)}
+
+_TIME_IN = (3, 4, 5, 6)      # linear_in sees [sin t, cos t, y]
+_CONTROL_EMB = (2, 4, 6)     # emb(cat[yy, Xt])
+_GEOMETRIC = (5, 6)          # z * tanh(y)
+
+
+def prepare_sde_solver_kwargs(times, kwargs, *, default_method, respect_euler_grid):
+    """dt = max(min gap of `times`, 1e-3); default method; options['dt'] (neuralsde.py:30-48)."""
+    kwargs = dict(kwargs)
+    host = _HostTimes.get(times)
+    dt = max(float((host[1:] - host[:-1]).min()), 1e-3)
+    kwargs.setdefault('method', default_method)
+    if kwargs['method'] in ('srk', 'euler'):
+        options = kwargs.setdefault('options', {})
+        grid_given = 'step_size' in options or 'grid_constructor' in options
+        if 'dt' not in options and (kwargs['method'] == 'srk' or not respect_euler_grid or not grid_given):
+            options['dt'] = dt
+    return kwargs, dt
+
+
+_prepare_sde_solver_kwargs = prepare_sde_solver_kwargs
+
+
+class Diffusion_model(nn.Module):
+    def __init__(self, input_channels, hidden_channels, hidden_hidden_channels, num_hidden_layers, theta=1.0,
+                 sigma=1.0, input_option=0, noise_option=0):
+        super().__init__()
+        if input_option not in range(7):
+            raise ValueError(f"Unknown input_option {input_option}.")
+        if noise_option not in range(20):
+            raise ValueError(f"Unknown noise_option {noise_option}.")
+        self.sde_type = "ito"
+        self.noise_type = "diagonal"
+        self.input_option = input_option
+        self.noise_option = noise_option
+        self.input_channels = input_channels
+        self.hidden_channels = hidden_channels
+        H, HH = hidden_channels, hidden_hidden_channels
+        # creation order = the reference's, so a given torch.manual_seed yields the same initialisation
+        self.initial_network = nn.Linear(input_channels, H)
+        self.linear_in = nn.Linear(H + 2 if input_option in _TIME_IN else H, HH)
+        if input_option in _CONTROL_EMB:
+            self.emb = nn.Linear(2 * H, H)
+        self.linears = nn.ModuleList(nn.Linear(HH, HH) for _ in range(num_hidden_layers - 1))
+        self.linear_out = nn.Linear(HH, H)
+        self.theta = nn.Parameter(torch.tensor([[theta]]))
+        if noise_option in (1, 2, 3):
+            self.sigma = nn.Parameter(torch.tensor([sigma]))
+        if noise_option in (4, 5, 6):
+            self.sigma_diag = nn.Parameter(torch.tensor([sigma] * H))
+        if noise_option in (12, 13):
+            self.noise_t = nn.Linear(2, H)
+        if noise_option in (14, 15):
+            self.noise_y = nn.Linear(H + 2, H)
+        if noise_option in (16, 17):
+            self.noise_t = nn.Sequential(nn.Linear(2, H), nn.ReLU(), nn.Linear(H, H))
+        if noise_option in (18, 19):
+            self.noise_y = nn.Sequential(nn.Linear(H + 2, H), nn.ReLU(), nn.Linear(H, H))
+
+    # -- control path ------------------------------------------------------------------------------
+    def set_X(self, coeffs, times):
+        self.coeffs = coeffs
+        self.times = times
+        self.X = _torchcde.CubicSpline(self.coeffs, self.times)
+
+    # -- vector field --------------------------------------------------------------------------------
+    def _fused_ok(self, y):
+        return (y.is_cuda and y.dtype == torch.float32 and not torch.is_grad_enabled()
+                and hasattr(self, 'coeffs') and self.coeffs.is_cuda)
+
+    def _fused_fg(self, t, y):
+        rec = engine.recognise(self)
+        model, layout, numel = rec
+        flat = engine.flatten_params(self, layout, numel, y.device)
+        coeffs = self.coeffs.detach().to(torch.float32).contiguous()
+        return engine.eval_fg(model, flat, coeffs, _HostTimes.get(self.times), float(t), y.contiguous())
+
+    @staticmethod
+    def _tau(t, y):
+        t = torch.as_tensor(t, dtype=y.dtype, device=y.device)
+        col = t.expand(y.shape[0], 1) if t.dim() == 0 else t.reshape(y.shape[0], 1)
+        return col, torch.cat([col.sin(), col.cos()], dim=-1)
+
+    def _drift(self, t, y):
+        io = self.input_option
+        Xt = self.initial_network(self.X.evaluate(t)) if io in (0,) + _CONTROL_EMB else None
+        if io == 0:
+            z = Xt
+        else:
+            inp = torch.cat([self._tau(t, y)[1], y], dim=-1) if io in _TIME_IN else y
+            z = self.linear_in(inp)
+            if io in _CONTROL_EMB:
+                z = self.emb(torch.cat([z, Xt], dim=-1))
+        z = z.relu()
+        for layer in self.linears:
+            z = layer(z).relu()
+        z = self.linear_out(z)
+        if io in _GEOMETRIC:
+            z = z * y.tanh()
+        return z.tanh()
+
+    def _raw_diffusion(self, t, y):
+        no = self.noise_option
+        col, tau = self._tau(t, y)
+        if no == 0:
+            return torch.zeros_like(y)
+        if no <= 6:
+            scale = (self.sigma if no <= 3 else self.sigma_diag).exp().expand_as(y)
+            return scale * (1, col, y)[(no - 1) % 3] if (no - 1) % 3 else scale
+        if no == 7:
+            return y.sqrt()
+        if no == 8:
+            return y ** 3
+        if no == 9:
+            return y.sigmoid()
+        if no == 10:
+            return y.relu()
+        if no == 11:
+            return col * y
+        net_in = tau if no in (12, 13, 16, 17) else torch.cat([tau, y], dim=-1)
+        out = (self.noise_t if no in (12, 13, 16, 17) else self.noise_y)(net_in)
+        if no >= 16:
+            out = out.relu()
+        return out * y if no % 2 == 1 else out
+
+    def f(self, t, y):
+        if self._fused_ok(y):
+            return self._fused_fg(t, y)[0]
+        return self._drift(t, y)
+
+    def g(self, t, y):
+        if self._fused_ok(y):
+            return self._fused_fg(t, y)[1]
+        return (self.theta.sigmoid() * torch.nan_to_num(self._raw_diffusion(t, y))).tanh()
+
+
+class _SDEHead(nn.Module):
+    default_method = 'euler'
+    respect_euler_grid = False
+
+    def _prepare_initial_state(self, times, z0):
+        if z0 is None:
+            assert self.initial, "Was not expecting to be given no value of z0."
+            return self.initial_network(self.func.X.evaluate(times[0]))
+        assert not self.initial, "Was expecting to be given a value of z0."
+        return z0
+
+    def _solve_sde_path(self, times, ts, z0, kwargs):
+        kwargs, dt = prepare_sde_solver_kwargs(times, kwargs, default_method=self.default_method,
+                                               respect_euler_grid=self.respect_euler_grid)
+        return _torchsde.sdeint(sde=self.func, y0=z0, ts=ts, dt=dt, **kwargs)
+
+
+class NeuralSDE(_SDEHead):
+    """Classification head: solve to each row's own final time, read out with an MLP."""
+
+    def __init__(self, func, input_channels, hidden_channels, output_channels, initial=True):
+        super().__init__()
+        self.func = func
+        self.initial = initial
+        self.initial_network = nn.Linear(input_channels, hidden_channels)
+        self.linear = nn.Sequential(nn.Linear(hidden_channels, hidden_channels), nn.BatchNorm1d(hidden_channels),
+                                    nn.ReLU(), nn.Dropout(0.1), nn.Linear(hidden_channels, output_channels))
+
+    @staticmethod
+    def output_times(times, final_index):
+        """ts = [times[0]] + times[unique(final_index) minus {0, L-1}] + [times[-1]] and the per-row index
+        into it (neuralsde.py:91-103)."""
+        uniq, inverse = final_index.unique(sorted=True, return_inverse=True)
+        has_first = bool(uniq[0] == 0)
+        if has_first:
+            uniq = uniq[1:]
+        row_slot = inverse if has_first else inverse + 1
+        if uniq.numel() > 0 and bool(uniq[-1] == len(times) - 1):
+            uniq = uniq[:-1]
+        ts = torch.cat([times[:1], times[uniq], times[-1:]])
+        return ts, row_slot
+
+    def forward(self, times, coeffs, final_index, z0=None, stream=False, **kwargs):
+        self.func.set_X(*coeffs, times)
+        z0 = self._prepare_initial_state(times, z0)
+        if stream:
+            ts, row_slot = times, None
+        else:
+            ts, row_slot = self.output_times(times, final_index)
+        z_t = self._solve_sde_path(times, ts, z0, kwargs)
+        if stream:
+            z = z_t.movedim(0, -2)
+        else:
+            idx = row_slot.reshape(1, -1, 1).expand(1, z_t.shape[1], z_t.shape[2])
+            z = z_t.gather(0, idx).squeeze(0)
+        return self.linear(z)
+
+
+class NeuralSDE_forecasting(_SDEHead):
+    """Forecasting head: the four natural-spline tensors are concatenated, every knot is an output time and
+    the last ``output_time`` states are decoded."""
+
+    def __init__(self, func, input_channels, output_time, hidden_channels, output_channels, initial=True):
+        super().__init__()
+        self.func = func
+        self.initial = initial
+        self.output_time = output_time
+        self.initial_network = nn.Linear(input_channels, hidden_channels)
+        self.linear = nn.Sequential(nn.Linear(hidden_channels, hidden_channels), nn.ReLU(),
+                                    nn.Linear(hidden_channels, output_channels))
+
+    def forward(self, times, coeffs, final_index, z0=None, stream=False, **kwargs):
+        self.func.set_X(torch.cat(coeffs, dim=-1), times)
+        z0 = self._prepare_initial_state(times, z0)
+        z = self._solve_sde_path(times, times, z0, kwargs).movedim(0, -2)
+        return self.linear(z[:, z.shape[1] - self.output_time:, :])
+
+
+class IstsNeuralSDE(_SDEHead):
+    """torch_ists flavour: ``forward(coeffs, times)`` -> (readout, latent path); default method srk."""
+    default_method = 'srk'
+    respect_euler_grid = True
+
+    def __init__(self, func, input_channels, hidden_channels, output_channels, initial=True):
+        super().__init__()
+        self.func = func
+        self.initial = initial
+        self.initial_network = nn.Linear(input_channels, hidden_channels)
+        self.linear = nn.Sequential(nn.Tanh(), nn.Linear(hidden_channels, hidden_channels), nn.ReLU(),
+                                    nn.Linear(hidden_channels, output_channels))
+
+    def forward(self, coeffs, times, **kwargs):
+        self.func.set_X(coeffs, times)
+        x0 = self.func.X.evaluate(times[0])
+        if not self.initial:
+            x0 = torch.zeros_like(x0)
+        z = self._solve_sde_path(times, times, self.initial_network(x0), kwargs).permute(1, 0, 2)
+        return self.linear(z), z
+
+
+def make_sde_model(name, input_channels, output_channels, hidden_channels, hidden_hidden_channels,
+                   num_hidden_layers, initial=True):
+    """The five SDE entries of ``common_sde.make_model`` (benchmark_classification/common_sde.py:301-342)."""
+    options = {'staticsde': (1, 0), 'naivesde': (1, 18), 'neurallsde': (2, 16), 'neurallnsde': (4, 17),
+               'neuralgsde': (6, 17)}
+    if name not in options:
+        raise ValueError(f"Unrecognised SDE model name {name}. Valid names are {sorted(options)}.")
+    io, no = options[name]
+    field = Diffusion_model(input_channels, hidden_channels, hidden_hidden_channels, num_hidden_layers,
+                            input_option=io, noise_option=no)
+    model = NeuralSDE(func=field, input_channels=input_channels, hidden_channels=hidden_channels,
+                      output_channels=output_channels, initial=initial)
+    return model, field

@@ -1,0 +1,174 @@
+"""``sdeint`` with the call contract of torchsde 0.2.5 at the reference's four call sites
+(benchmark_classification/models_sde/neuralsde.py:71-82, benchmark_forecasting/...:71-82,145-156,
+torch-ists/.../nsde_model.py:63-74):
+
+    sdeint(sde=func, y0=z0, ts=ts, dt=dt, method='euler', options={'dt': dt})  ->  (T, B, H)
+
+Dispatch
+  * ``sde`` honours the Diffusion_model contract (engine.recognise) and ``y0`` is a CUDA tensor:
+    ONE fused HIP solve (libsnsde.so).  No fallback: if the library is missing this raises.
+  * anything else (arbitrary ``sde.f/g`` such as the tutorial's vector fields, or CPU tensors = the
+    reference's CPU plumbing configuration): the same fixed-step scheme written with tensor ops,
+    calling ``sde.f`` / ``sde.g`` once per step.
+
+Fixed-step semantics (restated from torchsde 0.2.5; its source is not in the
+reference tree): time accumulates in float32 by repeated ``curr_t + dt`` clamped to ``ts[-1]``;
+outputs are linearly interpolated between the two solver states bracketing each ``ts[k]``;
+Euler ``y + f*h + g*dW``; Milstein adds ``0.5 * g * dg/dy * (dW^2 - h)`` (Ito, diagonal noise).
+"""
+import warnings
+
+import numpy as np
+import torch
+
+from . import engine
+from .controldiffeq import _HostTimes
+
+METHODS = ('euler', 'milstein', 'srk')
+
+
+class BrownianIncrements:
+    """Minimal Brownian-motion object: ``bm(ta, tb)`` ~ N(0, (tb - ta) I) of shape (B, H).
+
+    Increments over disjoint intervals are independent draws from one generator; unlike
+    torchsde.BrownianInterval it does not support re-querying overlapping intervals (the fixed-step
+    solvers never do)."""
+
+    def __init__(self, t0=0.0, t1=1.0, size=None, dtype=torch.float32, device=None, entropy=None, **kwargs):
+        self.shape = tuple(size)
+        self.dtype, self.device = dtype, device
+        self.generator = torch.Generator(device=device if device is not None else 'cpu')
+        self.generator.manual_seed(int(entropy) if entropy is not None else int(torch.empty((), dtype=torch.int64).random_().item()))
+
+    def __call__(self, ta, tb=None, **kwargs):
+        h = torch.as_tensor(tb, dtype=self.dtype) - torch.as_tensor(ta, dtype=self.dtype)
+        z = torch.randn(self.shape, dtype=self.dtype, device=self.device, generator=self.generator)
+        return z * h.to(z.device).sqrt()
+
+
+def _as_ts(ts, y0):
+    if not torch.is_tensor(ts):
+        if not isinstance(ts, (tuple, list)) or not all(isinstance(t, (float, int)) for t in ts):
+            raise ValueError("Evaluation times `ts` must be a 1-D Tensor or list/tuple of floats.")
+        ts = torch.tensor(ts, dtype=y0.dtype, device=y0.device)
+    if ts.dim() != 1 or ts.numel() < 2:
+        raise ValueError("Evaluation times `ts` must be a 1-D Tensor with at least two entries.")
+    return ts
+
+
+def _fresh_seed():
+    # drawn from torch's CPU generator: reproducible under torch.manual_seed, no device sync
+    return int(torch.empty((), dtype=torch.int64).random_().item())
+
+
+def sdeint(sde, y0, ts, bm=None, method=None, dt=1e-3, adaptive=False, rtol=1e-5, atol=1e-4, dt_min=1e-5,
+           options=None, names=None, logqp=False, extra=False, extra_solver_state=None, **unused_kwargs):
+    if unused_kwargs:
+        warnings.warn(f"Unexpected arguments {unused_kwargs}")
+    if adaptive:
+        raise NotImplementedError("adaptive stepping is not implemented; the reference only uses fixed dt")
+    if logqp or extra or extra_solver_state is not None:
+        raise NotImplementedError("logqp / extra solver state are not implemented")
+    if not torch.is_tensor(y0) or y0.dim() != 2:
+        raise ValueError("`y0` must be a 2-dimensional tensor of shape (batch, channels).")
+    ts = _as_ts(ts, y0)
+    options = dict(options or {})
+    if method is None:
+        method = 'srk'   # torchsde's default for Ito / diagonal noise
+    if method not in METHODS:
+        raise ValueError(f"Expected method in {METHODS}, but found {method}.")
+    if method == 'srk':
+        raise NotImplementedError("method='srk' (SRID2) is not implemented yet; use 'euler' or 'milstein'")
+    if not (float(dt) > 0):
+        raise ValueError("`dt` must be positive.")
+    backend = options.get('backend', 'auto')
+    if backend not in ('auto', 'hip', 'torch'):
+        raise ValueError("options['backend'] must be 'auto', 'hip' or 'torch'")
+
+    rec = engine.recognise(sde) if names is None else None
+    want_hip = backend == 'hip' or (backend == 'auto' and rec is not None and y0.is_cuda)
+    if want_hip:
+        if rec is None:
+            raise ValueError("options['backend']='hip' needs an sde honouring the Diffusion_model contract")
+        if not y0.is_cuda:
+            raise ValueError("the HIP engine needs CUDA (ROCm) tensors")
+        return _sdeint_hip(sde, rec, y0, ts, bm, method, float(dt), options)
+    return _sdeint_torch(sde, y0, ts, bm, method, float(dt), options, names)
+
+
+def _sdeint_hip(sde, rec, y0, ts, bm, method, dt, options):
+    model, layout, numel = rec
+    if torch.is_grad_enabled() and (y0.requires_grad or any(p.requires_grad for p in sde.parameters())):
+        raise NotImplementedError(
+            "backward through the fused HIP solve is not implemented in this round: call under "
+            "torch.no_grad(), or pass options={'backend': 'torch'} to differentiate through the unfused "
+            "tensor-op loop")
+    dev = y0.device
+    coeffs = sde.coeffs
+    if coeffs.dim() != 3 or coeffs.shape[0] != y0.shape[0]:
+        raise ValueError("sde.coeffs must have shape (batch, len(times) - 1, 4 * input_channels)")
+    coeffs = coeffs.detach().to(device=dev, dtype=torch.float32).contiguous()
+    y0c = y0.detach().to(torch.float32).contiguous()
+    times_host = _HostTimes.get(sde.times)
+    ts_host = ts.detach().to('cpu', torch.float32).numpy()
+    grid = engine.step_grid(ts_host, dt, times_host, dev)
+    flat = engine.flatten_params(sde, layout, numel, dev)
+    dW = None
+    if bm is not None:
+        t0 = torch.from_numpy(grid.t0)
+        t1 = torch.from_numpy(grid.t1)
+        dW = torch.stack([bm(t0[n], t1[n]).to(device=dev, dtype=torch.float32) for n in range(grid.N)]).contiguous()
+    seed = options.get('seed')
+    seed = _fresh_seed() if seed is None else int(seed)
+    call = engine.SolveCall(model, flat, coeffs, grid, y0c, dW=dW, method=method, seed=seed,
+                            row_offset=int(options.get('row_offset', 0)), kernel=options.get('kernel', 'auto'),
+                            save_traj=bool(options.get('save_traj', False)))
+    ys = call.launch()
+    if options.get('save_traj', False):
+        sde.last_trajectory = call.traj
+    return ys.to(y0.dtype)
+
+
+def _call(sde, names, key, default):
+    return getattr(sde, (names or {}).get(key, default))
+
+
+def _sdeint_torch(sde, y0, ts, bm, method, dt, options, names):
+    """Unfused scheme on tensor ops (arbitrary sde, CPU plumbing, autograd)."""
+    f = _call(sde, names, 'drift', 'f')
+    g = _call(sde, names, 'diffusion', 'g')
+    if getattr(sde, 'noise_type', 'diagonal') != 'diagonal':
+        raise NotImplementedError("only diagonal noise is implemented")
+    if getattr(sde, 'sde_type', 'ito') != 'ito':
+        raise NotImplementedError("only Ito SDEs are implemented")
+    ts_host = ts.detach().to('cpu', torch.float32).numpy()
+    grid = engine.StepGrid(ts_host, dt, np.array([0.0, 1.0], dtype=np.float32), None)
+    if bm is None:
+        bm = BrownianIncrements(size=tuple(y0.shape), dtype=y0.dtype, device=y0.device, entropy=options.get('seed'))
+    t0s = torch.from_numpy(grid.t0).to(y0.device)
+    t1s = torch.from_numpy(grid.t1).to(y0.device)
+    w = torch.from_numpy(grid.out_w).to(device=y0.device, dtype=y0.dtype)
+    y = y0
+    ys = [y0]
+    k = 0
+    for n in range(grid.N):
+        t0, t1 = t0s[n], t1s[n]
+        h = (t1 - t0).to(y0.dtype)
+        I = bm(t0, t1)
+        prev = y
+        if method == 'euler':
+            y = y + f(t0, y) * h + g(t0, y) * I
+        else:
+            v = I * I - h
+            with torch.enable_grad():
+                yy = y if y.requires_grad else y.detach().requires_grad_(True)
+                gv = g(t0, yy)
+                gdg, = torch.autograd.grad(gv, yy, grad_outputs=gv.detach() * v, allow_unused=True,
+                                           create_graph=torch.is_grad_enabled() and y.requires_grad)
+            gv = gv if y.requires_grad else gv.detach()
+            gdg = torch.zeros_like(y) if gdg is None else gdg
+            y = y + f(t0, y) * h + gv * I + 0.5 * gdg
+        while k < grid.T - 1 and grid.out_step[k] == n:
+            ys.append(y if grid.out_w[k, 0] == 0 else w[k, 0] * prev + w[k, 1] * y)
+            k += 1
+    return torch.stack(ys, dim=0)

@@ -76,3 +76,63 @@ def random_params(rng, io, no, NL, C, H, scale=None):
             b = (scale or 1.0) / np.sqrt(fan_in)
             p[name] = rng.uniform(-b, b, size=shape).astype(np.float32)
     return p
+
+
+# ---------------------------------------------------------------------------------------------------
+# synthetic problems + the stated fp32 parity criterion
+# ---------------------------------------------------------------------------------------------------
+def make_problem(seed, io, no, NL, B, H, C, L, times=None, nan_frac=0.2, y0_scale=0.5, hermite=False):
+    """Seeded inputs for one solve: params (reference names), coeffs (B, L-1, 4C), times, y0."""
+    import torch
+    import stable_neural_sdes_amd as S
+    rng = np.random.default_rng(seed)
+    p = random_params(rng, io, no, NL, C, H)
+    if times is None:
+        times = np.arange(L, dtype=np.float32)
+    times = np.asarray(times, dtype=np.float32)
+    X = (rng.standard_normal((B, L, C)) * 0.1).cumsum(1).astype(np.float32)
+    X[:, :, 0] = times[None, :]          # channel 0 = time, as in the reference's datasets
+    if nan_frac > 0:
+        mask = rng.random((B, L, C)) < nan_frac
+        mask[:, :, 0] = False
+        X[mask] = np.nan
+    Xt, tt = torch.from_numpy(X), torch.from_numpy(times)
+    if hermite:
+        coeffs = S.torchcde.hermite_cubic_coefficients_with_backward_differences(Xt, tt)
+    else:
+        coeffs = torch.cat(S.controldiffeq.natural_cubic_spline_coeffs(tt, Xt), dim=-1)
+    y0 = (y0_scale * rng.standard_normal((B, H))).astype(np.float32)
+    return dict(params=p, coeffs=coeffs.numpy().astype(np.float32), times=times, y0=y0, io=io, no=no, NL=NL,
+                B=B, H=H, C=C, L=L)
+
+
+def draw_dW(seed, ts, dt, B, H):
+    from oracle import sde_oracle as O
+    t0, t1, *_ = O.step_grid(np.asarray(ts, np.float32), dt)
+    rng = np.random.default_rng(seed + 1)
+    Z = rng.standard_normal((len(t0), B, H)).astype(np.float32)
+    return Z * np.sqrt(t1 - t0).astype(np.float32)[:, None, None]
+
+
+def parity_report(got, ref64, cpu32=None):
+    """SURVEY.md 8c criterion.  got: HIP fp32, ref64: fp64 arbiter on identical dW, cpu32: fp32 oracle."""
+    got = np.asarray(got, dtype=np.float64)
+    err = np.abs(got - ref64)
+    rep = dict(mean=float(err.mean()), max=float(err.max()),
+               frac_ok=float((err <= 1e-4 + 1e-4 * np.abs(ref64)).mean()))
+    if cpu32 is not None:
+        e32 = np.abs(np.asarray(cpu32, dtype=np.float64) - ref64)
+        rep.update(cpu_mean=float(e32.mean()), cpu_max=float(e32.max()))
+    return rep
+
+
+def assert_parity(got, ref64, cpu32=None, what=''):
+    assert np.all(np.isfinite(got)), f'{what}: non-finite output'
+    rep = parity_report(got, ref64, cpu32)
+    assert rep['mean'] <= 1e-5, (what, rep)
+    assert rep['frac_ok'] >= 0.9999, (what, rep)
+    assert rep['max'] <= 5e-3, (what, rep)
+    if cpu32 is not None:
+        assert rep['mean'] <= 4 * rep['cpu_mean'] + 1e-7, (what, rep)
+        assert rep['max'] <= 4 * rep['cpu_max'] + 1e-6, (what, rep)
+    return rep

@@ -1,0 +1,288 @@
+"""GPU parity tests (run with -m gpu on an MI355X): the HIP path, called through the C ABI
+(libsnsde.so via ctypes), against the oracle on identical seeded inputs and against the golden
+vectors generated from the reference.  Tolerances are the ones stated in SURVEY.md 8c:
+  single f/g evaluation:  allclose(rtol=1e-5, atol=2e-6) vs the reference's fp32 output
+  trajectories (vs fp64 arbiter, identical dW): mean |err| <= 1e-5, |err| <= 1e-4 + 1e-4 |z| for
+  >= 99.99 % of elements, max |err| <= 5e-3, and <= 4x the CPU-fp32-vs-fp64 error."""
+import numpy as np
+import pytest
+import torch
+
+import stable_neural_sdes_amd as S
+from oracle import sde_oracle as O
+from tests.helpers import (assert_parity, draw_dW, group, load, make_problem, param_spec, params_of, unflatten)
+
+pytestmark = pytest.mark.gpu
+DEV = 'cuda:0'
+
+
+def flat_params(p, io, no, NL, C, H):
+    return torch.from_numpy(np.concatenate([np.asarray(p[n], np.float32).reshape(-1)
+                                            for n, _ in param_spec(io, no, NL, C, H)])).to(DEV)
+
+
+def hip_solve(pr, ts, dt, dW=None, method='euler', seed=0, row_offset=0, kernel='auto', rows=None, save_traj=False,
+              save_dW=False):
+    io, no, NL, C, H = pr['io'], pr['no'], pr['NL'], pr['C'], pr['H']
+    sl = slice(None) if rows is None else rows
+    model = S.engine.model_struct(C, H, H, NL, io, no)
+    flat = flat_params(pr['params'], io, no, NL, C, H)
+    coeffs = torch.from_numpy(np.ascontiguousarray(pr['coeffs'][sl])).to(DEV)
+    y0 = torch.from_numpy(np.ascontiguousarray(pr['y0'][sl])).to(DEV)
+    grid = S.engine.step_grid(np.asarray(ts, np.float32), dt, pr['times'], torch.device(DEV))
+    dWd = None if dW is None else torch.from_numpy(np.ascontiguousarray(dW[:, sl])).to(DEV)
+    call = S.engine.SolveCall(model, flat, coeffs, grid, y0, dW=dWd, method=method, seed=seed, row_offset=row_offset,
+                              kernel=kernel, save_traj=save_traj, save_dW=save_dW)
+    ys = call.launch()
+    torch.cuda.synchronize()
+    return ys.cpu().numpy(), call
+
+
+def oracle_solve(pr, ts, dt, dW, method, dtype):
+    ys, traj = O.solve_diffusion_model(pr['params'], pr['io'], pr['no'], pr['coeffs'], pr['times'], pr['y0'],
+                                       np.asarray(ts, np.float32), dt, dW, method=method, dtype=dtype)
+    return ys, traj
+
+
+# ------------------------------------------------------------------------------------------------
+SPL, FG, TRAJ = load('spline.npz'), load('fg.npz'), load('traj.npz')
+G1_CASES = sorted({k.split('/')[1] for k in SPL.files if k.startswith('G1/')})
+
+
+@pytest.mark.parametrize('case', G1_CASES)
+def test_spline_evaluate_hip_bit_exact_vs_reference(case):
+    c = group(SPL, f'G1/{case}/f32')
+    g = group(SPL, f'G2/{case}/f32')
+    coeffs = torch.from_numpy(np.concatenate([c['a'], c['b'], c['two_c'], c['three_d']], -1)).to(DEV)
+    sp = S.torchcde.CubicSpline(coeffs, torch.from_numpy(c['times']).to(DEV))
+    for i, t in enumerate(g['t']):
+        np.testing.assert_array_equal(sp.evaluate(torch.tensor(t)).cpu().numpy(), g['evaluate'][i])
+        np.testing.assert_array_equal(sp.derivative(torch.tensor(t)).cpu().numpy(), g['derivative'][i])
+
+
+MODELS = FG['G3/models']
+
+
+@pytest.mark.parametrize('mi', range(len(MODELS)))
+def test_f_g_hip_vs_reference_golden(mi):
+    io, no, NL = (int(v) for v in MODELS[mi])
+    coeffs, times, y, tv = FG['G3/coeffs'], FG['G3/times'], FG['G3/y'], FG['G3/t']
+    B, H = y.shape
+    C = coeffs.shape[-1] // 4
+    off = FG['G3/params_off']
+    p = unflatten(FG['G3/params_flat'][off[mi]:off[mi + 1]], param_spec(io, no, NL, C, H))
+    model = S.engine.model_struct(C, H, H, NL, io, no)
+    flat = flat_params(p, io, no, NL, C, H)
+    cd, yd = torch.from_numpy(coeffs).to(DEV), torch.from_numpy(y).to(DEV)
+    exp32, exp64 = FG['G3/out32'][mi], FG['G3/out64'][mi]
+    for ti, t in enumerate(tv):
+        f, g = S.engine.eval_fg(model, flat, cd, times, np.float32(t), yd)
+        f, g = f.cpu().numpy(), g.cpu().numpy()
+        np.testing.assert_allclose(f, exp32[0, ti], rtol=1e-5, atol=2e-6, err_msg=f'f io={io} no={no} t={t}')
+        np.testing.assert_allclose(g, exp32[1, ti], rtol=1e-5, atol=2e-6, err_msg=f'g io={io} no={no} t={t}')
+        # and no further from the fp64 reference than fp32 round-off allows
+        if float(t) == float(np.float32(t)):
+            np.testing.assert_allclose(f, exp64[0, ti], rtol=2e-5, atol=4e-6)
+            np.testing.assert_allclose(g, exp64[1, ti], rtol=2e-5, atol=4e-6)
+
+
+G5_CASES = sorted({k.split('/')[1] for k in TRAJ.files if k.startswith('G5/')})
+
+
+@pytest.mark.parametrize('case', G5_CASES)
+def test_trajectory_hip_vs_reference_golden(case):
+    """Golden trajectories = the reference's own f/g modules driven by the torchsde-style loop."""
+    g = group(TRAJ, f'G5/{case}')
+    io, no, NL = (int(v) for v in g['io_no_nl'])
+    C, H = g['coeffs'].shape[-1] // 4, g['y0'].shape[1]
+    pr = dict(params=params_of(TRAJ, f'G5/{case}'), coeffs=g['coeffs'], times=g['times'], y0=g['y0'], io=io, no=no,
+              NL=NL, C=C, H=H)
+    ys, _ = hip_solve(pr, g['ts'], float(g['dt']), dW=g['dW'], method=str(g['method']))
+    assert ys.shape == g['ys64'].shape
+    assert_parity(ys, g['ys64'], g['ys32'], what=case)
+
+
+SEEDED = [
+    # io, no, NL, B, H, C, L, ts, dt, method
+    (4, 17, 2, 37, 32, 5, 13, [0, 12], 1.0, 'euler'),
+    (6, 17, 2, 16, 64, 7, 21, [0, 3, 4, 11, 20], 1.0, 'euler'),
+    (2, 16, 1, 9, 32, 2, 20, None, 0.02, 'euler'),           # ts = times = linspace(0,1,20): interpolated outputs
+    (3, 18, 2, 24, 16, 9, 10, [0, 4.5, 9], 1.0, 'euler'),
+    (1, 18, 3, 8, 24, 3, 8, [0, 7], 0.5, 'euler'),
+    (1, 0, 2, 5, 10, 3, 8, [0, 2.5, 7], 1.0, 'euler'),        # H not a multiple of 4
+    (0, 13, 2, 8, 12, 3, 8, [0, 7], 1.0, 'euler'),
+    (5, 19, 2, 8, 16, 4, 8, [0, 7], 1.0, 'euler'),
+    (2, 14, 2, 8, 16, 4, 8, [0, 7], 1.0, 'euler'),
+    (4, 15, 4, 8, 16, 4, 8, [0, 7], 1.0, 'euler'),
+    (4, 17, 2, 33, 32, 5, 13, [0, 5, 12], 1.0, 'milstein'),
+    (6, 17, 2, 16, 16, 3, 9, None, None, 'milstein'),
+    (2, 16, 2, 8, 16, 3, 9, [0, 8], 1.0, 'milstein'),
+    (5, 8, 2, 8, 8, 3, 9, [0, 8], 0.5, 'milstein'),
+    (3, 3, 2, 8, 8, 3, 9, [0, 8], 0.5, 'milstein'),
+    (3, 6, 2, 8, 8, 3, 9, [0, 8], 0.5, 'milstein'),
+    (3, 11, 2, 8, 8, 3, 9, [0, 8], 0.25, 'milstein'),
+    (4, 17, 2, 64, 128, 21, 26, [0, 25], 1.0, 'euler'),      # headline model shape, short horizon
+    (4, 17, 2, 12, 256, 14, 11, [0, 10], 1.0, 'euler'),
+]
+
+
+@pytest.mark.parametrize('ci', range(len(SEEDED)))
+def test_trajectory_hip_vs_oracle_seeded(ci):
+    io, no, NL, B, H, C, L, ts, dt, method = SEEDED[ci]
+    times = np.linspace(0, 1, L).astype(np.float32) if ts is None else None
+    pr = make_problem(100 + ci, io, no, NL, B, H, C, L, times=times)
+    if ts is None:
+        ts = pr['times']
+        dt = dt or max(float(np.diff(pr['times']).min()), 1e-3)
+    dW = draw_dW(100 + ci, ts, dt, B, H)
+    ys, call = hip_solve(pr, ts, dt, dW=dW, method=method, save_traj=True)
+    ref64, traj64 = oracle_solve(pr, ts, dt, dW, method, np.float64)
+    cpu32, _ = oracle_solve(pr, ts, dt, dW, method, np.float32)
+    assert_parity(ys, ref64, cpu32, what=f'case {ci}')
+    assert_parity(call.traj.cpu().numpy(), traj64, what=f'traj {ci}')
+    np.testing.assert_array_equal(ys[0], pr['y0'])
+
+
+def test_all_noise_options_one_step_chain():
+    """Every (io, no) pair through the SOLVER (not just the f/g probe), 6 Euler steps."""
+    bad = []
+    for io in range(7):
+        for no in range(20):
+            pr = make_problem(7 * io + no, io, no, 2, 6, 8, 3, 7)
+            pr['y0'][0, 0] = -1.5
+            dW = draw_dW(io * 20 + no, [0, 6], 1.0, 6, 8)
+            ys, _ = hip_solve(pr, [0, 6], 1.0, dW=dW)
+            ref64, _ = oracle_solve(pr, [0, 6], 1.0, dW, 'euler', np.float64)
+            cpu32, _ = oracle_solve(pr, [0, 6], 1.0, dW, 'euler', np.float32)
+            try:
+                assert_parity(ys, ref64, cpu32, what=f'io={io} no={no}')
+            except AssertionError as e:
+                bad.append(str(e))
+    assert not bad, bad
+
+
+def test_milstein_unsupported_for_dense_jacobian_options():
+    pr = make_problem(1, 1, 18, 2, 4, 8, 3, 5)
+    with pytest.raises(S._lib.SnsdeError) as e:
+        hip_solve(pr, [0, 4], 1.0, dW=draw_dW(1, [0, 4], 1.0, 4, 8), method='milstein')
+    assert e.value.code == -4
+
+
+def test_drift_only_control_is_a_quadrature():
+    """io=0, no=0: f depends on X(t) only, so y_N = y0 + sum_n f(X(t_n)) h_n exactly as the oracle sums it."""
+    pr = make_problem(5, 0, 0, 2, 10, 16, 4, 12, nan_frac=0.0)
+    ys, _ = hip_solve(pr, [0, 11], 1.0, dW=None, seed=1)
+    p64 = O.cast_params(pr['params'], np.float64)
+    acc = pr['y0'].astype(np.float64)
+    for n in range(11):
+        Xt = O.spline_evaluate(pr['coeffs'].astype(np.float64), pr['times'].astype(np.float64), float(n))
+        acc = acc + O.drift_f(p64, 0, float(n), acc, Xt) * 1.0
+    np.testing.assert_allclose(ys[-1], acc, rtol=1e-5, atol=1e-5)
+
+
+# ---- in-kernel Philox ------------------------------------------------------------------------------
+def test_philox_increments_match_specification():
+    pr = make_problem(11, 4, 17, 2, 40, 32, 5, 9)
+    ts, dt = [0, 2.5, 8], 0.5
+    ys, call = hip_solve(pr, ts, dt, dW=None, seed=0x1234_5678_9ABC_DEF0, row_offset=1000, save_dW=True)
+    t0, t1, *_ = O.step_grid(np.asarray(ts, np.float32), dt)
+    exp = O.philox_dW(0x1234_5678_9ABC_DEF0, 1000, 40, 32, t0, t1)
+    got = call.dW_out.cpu().numpy()
+    np.testing.assert_allclose(got, exp, rtol=2e-6, atol=2e-7)
+    # and the trajectory is the Euler scheme on exactly those increments
+    ref64, _ = oracle_solve(pr, ts, dt, got, 'euler', np.float64)
+    cpu32, _ = oracle_solve(pr, ts, dt, got, 'euler', np.float32)
+    assert_parity(ys, ref64, cpu32, what='philox')
+
+
+def test_philox_statistics_and_seed_sensitivity():
+    pr = make_problem(12, 2, 16, 2, 512, 64, 3, 5)
+    _, c1 = hip_solve(pr, [0, 4], 1.0, seed=1, save_dW=True)
+    _, c2 = hip_solve(pr, [0, 4], 1.0, seed=2, save_dW=True)
+    z = c1.dW_out.cpu().numpy()
+    assert abs(z.mean()) < 1e-2 and abs(z.std() - 1) < 1e-2
+    assert abs((z ** 4).mean() - 3) < 0.1
+    assert not np.array_equal(z, c2.dW_out.cpu().numpy())
+    # distinct steps / rows are uncorrelated
+    assert abs(np.corrcoef(z[0].ravel(), z[1].ravel())[0, 1]) < 2e-2
+
+
+def test_batch_shards_reproduce_the_global_solve_bitwise():
+    """Rows are independent and Philox counters use the GLOBAL row: any sharding (1/2/4/8 GPUs) gives
+    bit-identical trajectories."""
+    pr = make_problem(13, 6, 17, 2, 96, 32, 5, 9)
+    full, _ = hip_solve(pr, [0, 3, 8], 1.0, seed=77)
+    for nshard in (2, 4, 8):
+        per = 96 // nshard
+        parts = [hip_solve(pr, [0, 3, 8], 1.0, seed=77, row_offset=r * per, rows=slice(r * per, (r + 1) * per))[0]
+                 for r in range(nshard)]
+        np.testing.assert_array_equal(np.concatenate(parts, axis=1), full)
+
+
+# ---- drop-in API ------------------------------------------------------------------------------------
+class _ReplayBM:
+    def __init__(self, dW):
+        self.dW, self.n = dW, 0
+
+    def __call__(self, ta, tb):
+        out = self.dW[self.n]
+        self.n += 1
+        return out
+
+
+def test_sdeint_drop_in_on_cuda_dispatches_to_hip():
+    pr = make_problem(21, 4, 17, 2, 20, 32, 5, 9)
+    m = S.Diffusion_model(5, 32, 32, 2, input_option=4, noise_option=17)
+    m.load_state_dict({k: torch.from_numpy(v.copy()) for k, v in pr['params'].items()})
+    m = m.to(DEV)
+    m.set_X(torch.from_numpy(pr['coeffs']).to(DEV), torch.from_numpy(pr['times']).to(DEV))
+    ts = torch.tensor([0., 3., 8.], device=DEV)
+    dW = draw_dW(21, [0, 3, 8], 1.0, 20, 32)
+    with torch.no_grad():
+        ys = S.sdeint(sde=m, y0=torch.from_numpy(pr['y0']).to(DEV), ts=ts, dt=1.0, method='euler',
+                      options={'dt': 1.0}, bm=_ReplayBM(torch.from_numpy(dW).to(DEV)))
+    ref64, _ = oracle_solve(pr, [0, 3, 8], 1.0, dW, 'euler', np.float64)
+    assert_parity(ys.cpu().numpy(), ref64, what='sdeint')
+    # grads requested -> loud error, never a silent unfused fallback
+    with pytest.raises(NotImplementedError):
+        S.sdeint(sde=m, y0=torch.from_numpy(pr['y0']).to(DEV), ts=ts, dt=1.0, method='euler')
+    # vector-field probes go through the HIP kernel too
+    with torch.no_grad():
+        f = m.f(torch.tensor(2.0), torch.from_numpy(pr['y0']).to(DEV)).cpu().numpy()
+    p64 = O.cast_params(pr['params'], np.float64)
+    Xt = O.spline_evaluate(pr['coeffs'].astype(np.float64), pr['times'].astype(np.float64), 2.0)
+    np.testing.assert_allclose(f, O.drift_f(p64, 4, 2.0, pr['y0'].astype(np.float64), Xt), rtol=1e-5, atol=2e-6)
+
+
+def test_neuralsde_forward_on_cuda():
+    pr = make_problem(22, 6, 17, 2, 12, 16, 4, 9)
+    torch.manual_seed(0)
+    model, field = S.make_sde_model('neuralgsde', 4, 3, 16, 16, 2, initial=True)
+    model = model.to(DEV).eval()
+    times = torch.from_numpy(pr['times']).to(DEV)
+    fi = torch.tensor([8, 3, 3, 5, 0, 8, 1, 2, 7, 8, 4, 4], device=DEV)
+    with torch.no_grad():
+        out = model(times, [torch.from_numpy(pr['coeffs']).to(DEV)], fi, options={'seed': 5})
+        out2 = model(times, [torch.from_numpy(pr['coeffs']).to(DEV)], fi, options={'seed': 5})
+    assert out.shape == (12, 3) and torch.isfinite(out).all()
+    assert torch.equal(out, out2)
+
+
+# ---- full-size configuration (BASELINE.json configs[1]) ---------------------------------------------
+def test_k2_full_size_parity_and_properties():
+    B, H, C, L, N = 1024, 128, 21, 101, 100
+    pr = make_problem(1234, 4, 17, 2, B, H, C, L, nan_frac=0.3)
+    ts, dt = [0, N], 1.0
+    dW = draw_dW(2024, ts, dt, B, H)
+    ys, _ = hip_solve(pr, ts, dt, dW=dW)
+    ref64, _ = oracle_solve(pr, ts, dt, dW, 'euler', np.float64)
+    cpu32, _ = oracle_solve(pr, ts, dt, dW, 'euler', np.float32)
+    rep = assert_parity(ys, ref64, cpu32, what='K2')
+    print('K2 parity', rep)
+    # determinism + shard invariance at full size with in-kernel Philox
+    a, _ = hip_solve(pr, ts, dt, seed=2024)
+    b, _ = hip_solve(pr, ts, dt, seed=2024)
+    np.testing.assert_array_equal(a, b)
+    halves = [hip_solve(pr, ts, dt, seed=2024, row_offset=o, rows=slice(o, o + 512))[0] for o in (0, 512)]
+    np.testing.assert_array_equal(np.concatenate(halves, axis=1), a)
+    assert np.isfinite(a).all()

@@ -1,0 +1,324 @@
+"""CPU tests of the host side: C-ABI surface, parameter layout, time grid, module API, spline
+construction and the generic (tensor-op) sdeint loop - all against the oracle / golden vectors.
+No GPU compute is launched here."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+import stable_neural_sdes_amd as S
+from oracle import sde_oracle as O
+from stable_neural_sdes_amd import _lib
+from tests.helpers import group, load, param_spec, params_of, unflatten
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+SPL, FG, TRAJ, WRAP = load('spline.npz'), load('fg.npz'), load('traj.npz'), load('wrapper.npz')
+
+
+def test_library_exports_every_declared_symbol():
+    header = open(os.path.join(ROOT, 'include', 'snsde.h')).read()
+    declared = set(re.findall(r'\b(snsde_[a-z_]+)\s*\(', header))
+    assert declared, 'no declarations parsed'
+    assert declared == set(_lib.EXPORTS)
+    lib = _lib.lib()
+    for name in declared:
+        assert hasattr(lib, name), name
+    assert lib.snsde_version() == 1
+    assert lib.snsde_strerror(-7).decode().startswith('ts must')
+
+
+@pytest.mark.parametrize('io', range(7))
+@pytest.mark.parametrize('no', range(20))
+def test_param_layout_matches_reference_state_dict(io, no):
+    for NL, C_, H in ((1, 3, 8), (3, 5, 12)):
+        m = S.engine.model_struct(C_, H, H, NL, io, no)
+        layout, numel = _lib.param_layout(m)
+        spec = param_spec(io, no, NL, C_, H)
+        assert [(n, s) for n, _, s in layout] == [(n, s if len(s) == 2 else s) for n, s in spec]
+        off = 0
+        for (name, o, shape) in layout:
+            assert o == off, name
+            off += int(np.prod(shape))
+        assert off == numel
+        mod = S.Diffusion_model(C_, H, H, NL, input_option=io, noise_option=no)
+        assert [(k, tuple(v.shape)) for k, v in mod.state_dict().items()] == spec
+
+
+def test_model_validation_errors():
+    lib = _lib.lib()
+    assert lib.snsde_param_count(C.byref(S.engine.model_struct(3, 8, 8, 2, 7, 0))) == -3
+    assert lib.snsde_param_count(C.byref(S.engine.model_struct(3, 8, 8, 2, 0, 20))) == -3
+    assert lib.snsde_param_count(C.byref(S.engine.model_struct(0, 8, 8, 2, 0, 0))) == -2
+    assert lib.snsde_param_count(C.byref(S.engine.model_struct(3, 8, 6, 2, 2, 0))) == -2   # emb needs HH == H
+    assert lib.snsde_param_count(C.byref(S.engine.model_struct(3, 8, 6, 2, 1, 0))) > 0
+    with pytest.raises(ValueError):
+        S.Diffusion_model(3, 8, 8, 2, input_option=9)
+    with pytest.raises(ValueError):
+        S.Diffusion_model(3, 8, 8, 2, noise_option=20)
+
+
+GRID_CASES = [
+    (np.array([0., 100.]), 1.0, np.arange(101.)),
+    (np.array([1., 4., 6., 8.]), 1.0, np.linspace(1, 8, 8)),
+    (np.linspace(0, 1, 20), 0.05, np.linspace(0, 1, 20)),
+    (np.linspace(0, 1, 20), 0.02, np.linspace(0, 1, 20)),
+    (np.linspace(0, 1, 12), float(np.float32(1 / 11)), np.linspace(0, 1, 12)),
+    (np.array([0., 0.3, 0.6, 2.0]), 1.0, np.array([0., 0.5, 1.0, 2.0])),
+    (np.array([0., 7.]), 0.5, np.arange(8.)),
+]
+
+
+@pytest.mark.parametrize('ci', range(len(GRID_CASES)))
+def test_grid_build_bit_exact_vs_oracle(ci):
+    ts, dt, times = GRID_CASES[ci]
+    ts32, times32 = ts.astype(np.float32), times.astype(np.float32)
+    g = S.engine.StepGrid(ts32, dt, times32, None)
+    t0, t1, out_step, w0, w1 = O.step_grid(ts32, dt)
+    assert g.N == len(t0)
+    np.testing.assert_array_equal(g.step_tab[:, 0], t0)
+    np.testing.assert_array_equal(g.step_tab[:, 7], t1)
+    np.testing.assert_array_equal(g.step_tab[:, 1], t1 - t0)
+    np.testing.assert_array_equal(g.out_step, out_step)
+    np.testing.assert_array_equal(g.out_w[:, 0], w0)
+    np.testing.assert_array_equal(g.out_w[:, 1], w1)
+    idx = g.step_tab[:, 5].view(np.int32)
+    for n in range(g.N):
+        i, frac = O.spline_index(times32, t0[n])
+        assert idx[n] == i and g.step_tab[n, 4] == frac
+    np.testing.assert_allclose(g.step_tab[:, 2], np.sin(t0.astype(np.float64)), atol=1e-7)
+    np.testing.assert_allclose(g.step_tab[:, 3], np.cos(t0.astype(np.float64)), atol=1e-7)
+    np.testing.assert_array_equal(g.step_tab[:, 6], np.sqrt(t1 - t0))
+
+
+def test_grid_errors():
+    with pytest.raises(ValueError):
+        S.engine.StepGrid(np.array([0., 0.]), 1.0, np.array([0., 1.]), None)
+    with pytest.raises(ValueError):
+        S.engine.StepGrid(np.array([1., 0.5]), 1.0, np.array([0., 1.]), None)
+    with pytest.raises(ValueError):
+        S.engine.StepGrid(np.array([0., 1.]), -1.0, np.array([0., 1.]), None)
+    with pytest.raises(ValueError):
+        S.engine.StepGrid(np.array([1e8, 1e8 + 64]), 1.0, np.array([0., 1.]), None)
+    with pytest.raises(ValueError):
+        S.engine.StepGrid(np.array([0.]), 1.0, np.array([0., 1.]), None)
+
+
+G1_CASES = sorted({k.split('/')[1] for k in SPL.files if k.startswith('G1/')})
+
+
+@pytest.mark.parametrize('case', G1_CASES)
+@pytest.mark.parametrize('prec', ['f32', 'f64'])
+def test_natural_spline_coeffs_vs_golden(case, prec):
+    g = group(SPL, f'G1/{case}/{prec}')
+    out = S.controldiffeq.natural_cubic_spline_coeffs(torch.from_numpy(g['times']), torch.from_numpy(g['X']))
+    tol = dict(rtol=5e-5, atol=5e-5) if prec == 'f32' else dict(rtol=1e-10, atol=1e-10)
+    for got, name in zip(out, ('a', 'b', 'two_c', 'three_d')):
+        assert got.shape == g[name].shape
+        np.testing.assert_allclose(got.numpy(), g[name], err_msg=name, **tol)
+
+
+@pytest.mark.parametrize('case', G1_CASES)
+def test_spline_evaluate_cpu_vs_golden(case):
+    c = group(SPL, f'G1/{case}/f32')
+    g = group(SPL, f'G2/{case}/f32')
+    coeffs = tuple(torch.from_numpy(c[n]) for n in ('a', 'b', 'two_c', 'three_d'))
+    sp = S.controldiffeq.NaturalCubicSpline(torch.from_numpy(c['times']), coeffs)
+    cs = S.torchcde.CubicSpline(torch.cat(coeffs, dim=-1), torch.from_numpy(c['times']))
+    for i, t in enumerate(g['t']):
+        np.testing.assert_allclose(sp.evaluate(torch.tensor(t)).numpy(), g['evaluate'][i], rtol=1e-6, atol=1e-6)
+        np.testing.assert_allclose(cs.derivative(torch.tensor(t)).numpy(), g['derivative'][i], rtol=1e-6, atol=1e-6)
+
+
+def test_natural_spline_input_errors():
+    t = torch.linspace(0, 1, 5)
+    X = torch.randn(2, 5, 3)
+    with pytest.raises(ValueError):
+        S.controldiffeq.natural_cubic_spline_coeffs(t.long(), X)
+    with pytest.raises(ValueError):
+        S.controldiffeq.natural_cubic_spline_coeffs(t.flip(0), X)
+    with pytest.raises(ValueError):
+        S.controldiffeq.natural_cubic_spline_coeffs(t[:4], X)
+    with pytest.raises(ValueError):
+        S.controldiffeq.natural_cubic_spline_coeffs(t[:1], X[:, :1])
+
+
+def test_hermite_vs_oracle():
+    rng = np.random.default_rng(3)
+    t = np.cumsum(rng.uniform(0.2, 1.0, 9))
+    X = rng.standard_normal((4, 9, 3)).cumsum(1)
+    X[0, 2, 1] = X[0, 3, 1] = np.nan
+    X[1, 0, 0] = np.nan
+    X[2, 8, 2] = np.nan
+    X[3, :, 0] = np.nan
+    got = S.torchcde.hermite_cubic_coefficients_with_backward_differences(torch.from_numpy(X), torch.from_numpy(t))
+    exp = O.hermite_cubic_coefficients_with_backward_differences(X, t)
+    np.testing.assert_allclose(got.numpy(), exp, rtol=1e-12, atol=1e-12)
+
+
+MODELS = FG['G3/models']
+
+
+@pytest.mark.parametrize('mi', range(0, len(MODELS), 3))
+def test_module_fg_cpu_vs_golden(mi):
+    io, no, NL = (int(v) for v in MODELS[mi])
+    coeffs, times, y, tv = FG['G3/coeffs'], FG['G3/times'], FG['G3/y'], FG['G3/t']
+    B, H = y.shape
+    C_ = coeffs.shape[-1] // 4
+    off = FG['G3/params_off']
+    p = unflatten(FG['G3/params_flat'][off[mi]:off[mi + 1]], param_spec(io, no, NL, C_, H))
+    m = S.Diffusion_model(C_, H, H, NL, input_option=io, noise_option=no)
+    m.load_state_dict({k: torch.from_numpy(v.copy()) for k, v in p.items()})
+    m.set_X(torch.from_numpy(coeffs), torch.from_numpy(times))
+    exp = FG['G3/out32'][mi]
+    with torch.no_grad():
+        for ti, t in enumerate(tv):
+            f = m.f(torch.tensor(np.float32(t)), torch.from_numpy(y))
+            g = m.g(torch.tensor(np.float32(t)), torch.from_numpy(y))
+            np.testing.assert_allclose(f.numpy(), exp[0, ti], rtol=1e-5, atol=2e-6)
+            np.testing.assert_allclose(g.numpy(), exp[1, ti], rtol=1e-5, atol=2e-6)
+
+
+class _Recorder:
+    def __init__(self):
+        self.calls = []
+
+    def __call__(self, sde, y0, ts, dt, **kw):
+        self.calls.append(dict(ts=ts.clone(), dt=dt, kw=kw, y0=y0.clone()))
+        return torch.stack([y0 + ts[k] for k in range(ts.shape[0])])
+
+
+@pytest.mark.parametrize('case', ['int_grid', 'no_ends', 'all_last', 'lin01'])
+def test_neuralsde_wrapper_bookkeeping_vs_golden(case, monkeypatch):
+    g = group(WRAP, f'G4/{case}')
+    times, fi, coeffs = (torch.from_numpy(g[k]) for k in ('times', 'final_index', 'coeffs'))
+    C_, H = coeffs.shape[-1] // 4, g['y0'].shape[1]
+    func = S.Diffusion_model(C_, H, H, 2, input_option=4, noise_option=17)
+    model = S.NeuralSDE(func, C_, H, 2, initial=True).eval()
+    model.load_state_dict({k: torch.from_numpy(v.copy()) for k, v in params_of(WRAP, f'G4/{case}').items()})
+    rec = _Recorder()
+    monkeypatch.setattr(S.modules._torchsde, 'sdeint', rec)
+    with torch.no_grad():
+        pred = model(times, [coeffs], fi)
+    call = rec.calls[0]
+    np.testing.assert_array_equal(call['ts'].numpy(), g['ts'])
+    assert call['dt'] == float(g['dt']) and call['kw']['method'] == 'euler'
+    assert call['kw']['options']['dt'] == float(g['options_dt'])
+    np.testing.assert_allclose(call['y0'].numpy(), g['y0'], rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(pred.numpy(), g['pred'], rtol=1e-4, atol=1e-5)
+
+
+def test_forecasting_and_ists_wrappers_vs_golden(monkeypatch):
+    rec = _Recorder()
+    monkeypatch.setattr(S.modules._torchsde, 'sdeint', rec)
+    g = group(WRAP, 'G4/forecast')
+    times = torch.from_numpy(g['times'])
+    cs = [torch.from_numpy(g[k]) for k in ('a', 'b', 'two_c', 'three_d')]
+    C_ = cs[0].shape[-1]
+    sd = params_of(WRAP, 'G4/forecast')
+    H = sd['initial_network.weight'].shape[0]
+    func = S.Diffusion_model(C_, H, H, 2, input_option=2, noise_option=16)
+    model = S.NeuralSDE_forecasting(func, C_, 3, H, 5, initial=True).eval()
+    model.load_state_dict({k: torch.from_numpy(v.copy()) for k, v in sd.items()})
+    with torch.no_grad():
+        pred = model(times, cs, torch.zeros(cs[0].shape[0], dtype=torch.long))
+    np.testing.assert_array_equal(rec.calls[-1]['ts'].numpy(), g['ts'])
+    assert rec.calls[-1]['dt'] == float(g['dt'])
+    np.testing.assert_allclose(pred.numpy(), g['pred'], rtol=1e-4, atol=1e-5)
+
+    g = group(WRAP, 'G4/ists')
+    times, coeffs = torch.from_numpy(g['times']), torch.from_numpy(g['coeffs'])
+    sd = params_of(WRAP, 'G4/ists')
+    H = sd['initial_network.weight'].shape[0]
+    func = S.Diffusion_model(coeffs.shape[-1] // 4, H, H, 2, input_option=6, noise_option=17)
+    model = S.IstsNeuralSDE(func, coeffs.shape[-1] // 4, H, 2, initial=True).eval()
+    model.load_state_dict({k: torch.from_numpy(v.copy()) for k, v in sd.items()})
+    with torch.no_grad():
+        pred, z = model(coeffs, times)
+    assert rec.calls[-1]['kw']['method'] == str(g['method']) == 'srk'
+    assert rec.calls[-1]['dt'] == float(g['dt'])
+    np.testing.assert_array_equal(rec.calls[-1]['ts'].numpy(), g['ts'])
+    np.testing.assert_allclose(z.numpy(), g['z'], rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(pred.numpy(), g['pred'], rtol=1e-4, atol=1e-5)
+
+
+@pytest.mark.parametrize('name', ['arange', 'lin01_20', 'tiny', 'irr'])
+def test_prepare_solver_kwargs_dt(name):
+    g = group(WRAP, f'G4/dt/{name}')
+    kw, dt = S.prepare_sde_solver_kwargs(torch.from_numpy(g['times']), {}, default_method='euler',
+                                         respect_euler_grid=False)
+    assert dt == float(g['dt']) and kw == {'method': 'euler', 'options': {'dt': dt}}
+    kw, _ = S.prepare_sde_solver_kwargs(torch.from_numpy(g['times']), {'options': {'step_size': 0.1}},
+                                        default_method='euler', respect_euler_grid=True)
+    assert 'dt' not in kw['options']
+
+
+class _ReplayBM:
+    def __init__(self, dW):
+        self.dW, self.n = dW, 0
+
+    def __call__(self, ta, tb):
+        out = self.dW[self.n]
+        self.n += 1
+        return out
+
+
+G5_CASES = sorted({k.split('/')[1] for k in TRAJ.files if k.startswith('G5/')})
+
+
+@pytest.mark.parametrize('case', G5_CASES)
+def test_sdeint_tensor_loop_cpu_vs_golden(case):
+    g = group(TRAJ, f'G5/{case}')
+    io, no, NL = (int(v) for v in g['io_no_nl'])
+    coeffs = torch.from_numpy(g['coeffs'])
+    C_, H = coeffs.shape[-1] // 4, g['y0'].shape[1]
+    m = S.Diffusion_model(C_, H, H, NL, input_option=io, noise_option=no)
+    m.load_state_dict({k: torch.from_numpy(v.copy()) for k, v in params_of(TRAJ, f'G5/{case}').items()})
+    m.set_X(coeffs, torch.from_numpy(g['times']))
+    with torch.no_grad():
+        ys = S.sdeint(m, torch.from_numpy(g['y0']), torch.from_numpy(g['ts']), bm=_ReplayBM(torch.from_numpy(g['dW'])),
+                      method=str(g['method']), dt=float(g['dt']))
+    scale = 1.0 + np.abs(g['ys64'])
+    err_ref = np.max(np.abs(g['ys32'] - g['ys64']) / scale)
+    err = np.max(np.abs(ys.numpy() - g['ys64']) / scale)
+    assert ys.shape == g['ys64'].shape
+    assert err < max(4 * err_ref, 2e-6), (err, err_ref)
+
+
+def test_sdeint_argument_errors():
+    m = S.Diffusion_model(3, 8, 8, 2, input_option=4, noise_option=17)
+    m.set_X(torch.zeros(2, 4, 12), torch.arange(5.))
+    y0 = torch.zeros(2, 8)
+    with pytest.raises(ValueError):
+        S.sdeint(m, torch.zeros(8), torch.tensor([0., 1.]), method='euler')
+    with pytest.raises(ValueError):
+        S.sdeint(m, y0, torch.tensor([1., 0.]), method='euler', dt=1.0)
+    with pytest.raises(ValueError):
+        S.sdeint(m, y0, torch.tensor([0., 1.]), method='rk4', dt=1.0)
+    with pytest.raises(ValueError):
+        S.sdeint(m, y0, torch.tensor([0., 1.]), method='euler', dt=0.0)
+    with pytest.raises(NotImplementedError):
+        S.sdeint(m, y0, torch.tensor([0., 1.]), method='euler', dt=1.0, adaptive=True)
+    with pytest.raises(NotImplementedError):
+        S.sdeint(m, y0, torch.tensor([0., 1.]), dt=1.0)   # default method srk
+    with pytest.raises(ValueError):   # HIP engine requested on CPU tensors: loud, no fallback
+        with torch.no_grad():
+            S.sdeint(m, y0, torch.tensor([0., 1.]), method='euler', dt=1.0, options={'backend': 'hip'})
+
+
+def test_install_registers_shims():
+    import sys
+    saved = {k: sys.modules.pop(k, None) for k in ('torchsde', 'torchcde', 'controldiffeq')}
+    try:
+        S.install()
+        import torchcde
+        import torchsde
+        assert torchsde.sdeint is S.sdeint
+        assert torchcde.CubicSpline is S.torchcde.CubicSpline
+    finally:
+        for k, v in saved.items():
+            sys.modules.pop(k, None)
+            if v is not None:
+                sys.modules[k] = v
