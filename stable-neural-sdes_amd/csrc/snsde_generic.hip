@@ -276,9 +276,9 @@ __global__ void __launch_bounds__(GT) snsde_generic_kernel(GenericArgs a) {
                 }
             }
         }
+        if (a.eval_mode) return;
         while (kout_next < d.T - 1 && a.out_step[kout_next] == n) ++kout_next;
         kout = kout_next;
-        if (a.eval_mode) return;
         __syncthreads();
     }
 }

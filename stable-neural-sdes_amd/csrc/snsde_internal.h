@@ -66,16 +66,19 @@ __device__ __forceinline__ float snsde_nan_to_num(float x) {
     return fminf(fmaxf(x, -3.402823466e+38f), 3.402823466e+38f);
 }
 
-// Cubic piece evaluation with the reference's exact operation order and no FMA contraction
-// (controldiffeq/interpolate.py:270-276): bit-identical to the CPU reference.
+// Cubic piece evaluation with the reference's exact operation order (controldiffeq/interpolate.py:270-283).
+// FMA contraction is switched off for these two functions (HIP's __fmul_rn/__fadd_rn are plain
+// operators and would be contracted), so the result is bit-identical to the CPU reference.
 __device__ __forceinline__ float snsde_spline_eval(float a, float b, float two_c, float three_d, float frac) {
-    float inner = __fadd_rn(__fmul_rn(0.5f, two_c), __fdiv_rn(__fmul_rn(three_d, frac), 3.0f));
-    inner = __fadd_rn(b, __fmul_rn(inner, frac));
-    return __fadd_rn(a, __fmul_rn(inner, frac));
+#pragma clang fp contract(off)
+    float inner = 0.5f * two_c + three_d * frac / 3.0f;
+    inner = b + inner * frac;
+    return a + inner * frac;
 }
 __device__ __forceinline__ float snsde_spline_deriv(float b, float two_c, float three_d, float frac) {
-    float inner = __fadd_rn(two_c, __fmul_rn(three_d, frac));
-    return __fadd_rn(b, __fmul_rn(inner, frac));
+#pragma clang fp contract(off)
+    float inner = two_c + three_d * frac;
+    return b + inner * frac;
 }
 
 // Philox4x32-10 (Salmon et al., SC'11).  Specification = oracle/sde_oracle.py:philox4x32_10.
