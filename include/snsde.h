@@ -48,7 +48,13 @@ enum {
 enum { SNSDE_EULER = 0, SNSDE_MILSTEIN = 1 };
 
 /* kernel selection (for tests / benchmarking); 0 lets the library choose */
-enum { SNSDE_KERNEL_AUTO = 0, SNSDE_KERNEL_GENERIC = 1, SNSDE_KERNEL_MFMA = 2 };
+enum {
+    SNSDE_KERNEL_AUTO = 0,      /* MFMA fast path when the configuration is covered, else generic  */
+    SNSDE_KERNEL_GENERIC = 1,   /* VALU kernel: every (input_option, noise_option), any dims        */
+    SNSDE_KERNEL_MFMA = 2,      /* MFMA fast path, tile flavour chosen from the batch size          */
+    SNSDE_KERNEL_MFMA_M16 = 3,  /* 16-row tiles (v_mfma_f32_16x16x4_f32)                            */
+    SNSDE_KERNEL_MFMA_M4 = 4    /* 4-row tiles  (v_mfma_f32_4x4x1_16b_f32)                          */
+};
 
 /* flags: REUSE_PREPARED skips the weight packing / time-table kernels; legal when `params`,
  * `step_tab` and `workspace` are unchanged since the previous call that ran them (e.g. every

@@ -285,6 +285,8 @@ size_t snsde_workspace_bytes(const snsde_solve* s) {
     snsde_solve tmp = *s;
     if (tmp.n_steps < 1) tmp.n_steps = 1;
     snsde_generic_workspace_floats(&tmp, net, &f);
+    const size_t fm = snsde_mfma_workspace_floats(&tmp, net);
+    if (fm > f) f = fm;
     return (f + 64) * sizeof(float);
 }
 
@@ -295,8 +297,17 @@ int snsde_solve_forward(const snsde_solve* s, void* hip_stream) {
     SnsdeNet net;
     rc = snsde_build_net(s->model, s->n_steps, &net);
     if (rc) return rc;
-    if (s->kernel == SNSDE_KERNEL_MFMA) return SNSDE_ERR_UNSUPPORTED;
-    if (s->kernel != SNSDE_KERNEL_AUTO && s->kernel != SNSDE_KERNEL_GENERIC) return SNSDE_ERR_OPTION;
+    hipStream_t st = static_cast<hipStream_t>(hip_stream);
+    switch (s->kernel) {
+        case SNSDE_KERNEL_AUTO:
+            if (snsde_mfma_supported(s, net)) return snsde_mfma_launch(s, net, st, -1);
+            break;
+        case SNSDE_KERNEL_GENERIC: break;
+        case SNSDE_KERNEL_MFMA: return snsde_mfma_launch(s, net, st, -1);
+        case SNSDE_KERNEL_MFMA_M16: return snsde_mfma_launch(s, net, st, 0);
+        case SNSDE_KERNEL_MFMA_M4: return snsde_mfma_launch(s, net, st, 1);
+        default: return SNSDE_ERR_OPTION;
+    }
     return snsde_generic_launch(s, net, static_cast<hipStream_t>(hip_stream), 0, nullptr, nullptr, nullptr, nullptr);
 }
 

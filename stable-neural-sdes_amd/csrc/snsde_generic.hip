@@ -297,6 +297,13 @@ inline int round4(int x) { return (x + 3) & ~3; }
 
 }  // namespace
 
+int snsde_time_table_launch(const float* params, const float* step_tab, float* gt, const SnsdeLayer& nt0,
+                            const SnsdeLayer& nt1, int H, int no, int n_steps, hipStream_t stream) {
+    hipLaunchKernelGGL(snsde_time_table_kernel, dim3(n_steps), dim3(128), H * sizeof(float), stream, params, step_tab,
+                       gt, nt0, nt1, H, no);
+    return hipGetLastError() == hipSuccess ? SNSDE_OK : SNSDE_ERR_LAUNCH;
+}
+
 int snsde_generic_workspace_floats(const snsde_solve* s, const SnsdeNet& net, size_t* floats) {
     size_t f = (size_t)net.packed_floats;
     if (net.gt_tab >= 0) f = (size_t)net.gt_tab + (size_t)s->n_steps * s->model.hidden_channels;

@@ -50,6 +50,12 @@ int snsde_build_net(const snsde_model& m, int32_t n_steps, SnsdeNet* net);
 int snsde_generic_workspace_floats(const snsde_solve* s, const SnsdeNet& net, size_t* floats);
 int snsde_generic_launch(const snsde_solve* s, const SnsdeNet& net, hipStream_t stream, int eval_mode,
                          const float* eval_y, float* eval_f, float* eval_g, const float* step_row_dev);
+int snsde_time_table_launch(const float* params, const float* step_tab, float* gt, const SnsdeLayer& nt0,
+                            const SnsdeLayer& nt1, int H, int no, int n_steps, hipStream_t stream);
+// launchers (snsde_mfma.hip)
+bool snsde_mfma_supported(const snsde_solve* s, const SnsdeNet& net);
+size_t snsde_mfma_workspace_floats(const snsde_solve* s, const SnsdeNet& net);
+int snsde_mfma_launch(const snsde_solve* s, const SnsdeNet& net, hipStream_t stream, int flavor_hint);
 int snsde_spline_launch(const float* coeffs, int32_t B, int32_t L, int32_t C, int32_t index, float frac,
                         int32_t derivative, float* out, hipStream_t stream);
 

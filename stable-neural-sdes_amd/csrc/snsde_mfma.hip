@@ -1,0 +1,545 @@
+// MFMA fast path of the fused Neural-SDE solver for gfx950 (CDNA4).
+//
+// One persistent workgroup owns a tile of M batch rows for ALL solver steps.  Per step the MLP drift
+// (neuralsde.py:295-302) is a chain of small GEMMs  out^T (features x rows) = W (features x K) . act^T,
+// executed on the f32 matrix cores (exact f32: an MFMA is bit-for-bit an fmaf chain):
+//
+//   * every wave of the workgroup owns a slice of OUTPUT FEATURES of every layer and keeps that slice
+//     of every weight matrix RESIDENT IN REGISTERS (VGPR+AGPR, one wave per SIMD, 512 registers/lane)
+//     for the whole solve: zero weight traffic per step;
+//   * weights are the MFMA A operand, activations the B operand ("transposed" product), so a batch row
+//     stays in one lane column: the D fragment of a layer IS one 16-byte LDS store per lane, and the
+//     next layer's B fragment is plain ds_read_b128 of the row-major LDS activation buffer (the k-slot
+//     to feature assignment is arbitrary as long as A and B agree: k(u, s, e) = 16u + 4s + e);
+//   * the state y, dW, f, g and the Euler/Milstein update live in registers in the D layout of the last
+//     layer; the time-only diffusion MLP of noise_option 16/17 is a per-step table (hoisted);
+//   * activations cross waves through padded LDS buffers (row stride = 8 or 16 mod 64 floats:
+//     conflict-free ds_read_b128), one s_barrier per layer.
+//
+// Two tile flavours share the code:
+//   M16: v_mfma_f32_16x16x4_f32, 16 rows per workgroup  (lane = 16*s + row).        Large batches.
+//   M4 : v_mfma_f32_4x4x1_16b_f32, 4 rows per workgroup: the 16 independent 4x4 blocks are used as
+//        4 k-slots x 4 feature quads (lane = 16*q + 4*s + row) and the k-slot partial sums are
+//        combined with two DPP row rotations.  Fills all 256 CUs at batch 1024.
+#include "snsde_internal.h"
+
+namespace {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int MAXL = 4 + SNSDE_MAX_HIDDEN;
+
+struct MfmaLayerPack {
+    int32_t src_w, src_b, K, tshift, N, KU, dst;  // dst = float offset of the packed fragment block
+};
+
+struct MfmaPackJob {
+    MfmaLayerPack layer[MAXL];
+    int32_t n_layers, flavor, TPW, NW, bias_off, H;
+};
+
+// packed[dst + ((w*TPW + t)*KU + u)*256 + lane*4 + e] = W[feature][k(u,s,e)]
+__global__ void snsde_mfma_pack_kernel(const float* __restrict__ params, float* __restrict__ ws, MfmaPackJob job) {
+    const MfmaLayerPack L = job.layer[blockIdx.y];
+    const int per_wave = job.TPW * L.KU * 256;
+    const int total = job.NW * per_wave;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+        const int e = i & 3, lane = (i >> 2) & 63, blk = i >> 8;
+        const int u = blk % L.KU, wt = blk / L.KU;  // wt = w*TPW + t
+        int feat, s;
+        if (job.flavor == 0) { feat = lane & 15; s = lane >> 4; }
+        else { feat = 4 * (lane >> 4) + (lane & 3); s = (lane >> 2) & 3; }
+        feat += 16 * wt;
+        const int k = 16 * u + 4 * s + e;
+        float v = 0.0f;
+        if (feat < L.N && k < L.K) {
+            const int sk = (k < L.K - L.tshift) ? k + L.tshift : k - (L.K - L.tshift);
+            v = params[L.src_w + feat * L.K + sk];
+        }
+        ws[L.dst + i] = v;
+    }
+    // bias table [layer][H]
+    if (blockIdx.x == 0) {
+        for (int j = threadIdx.x; j < job.H; j += blockDim.x)
+            ws[job.bias_off + blockIdx.y * job.H + j] = (j < L.N) ? params[L.src_b + j] : 0.0f;
+    }
+}
+
+struct MfmaArgs {
+    const float* params;
+    const float* ws;
+    const float* coeffs;
+    const float* step_tab;
+    const int32_t* out_step;
+    const float* out_w;
+    const float* y0;
+    const float* dW;
+    float* ys;
+    float* traj;
+    float* dW_out;
+    int64_t row_offset;
+    uint64_t seed;
+    int32_t B, L, C, N, T, method, no;
+    int32_t off_theta, gt_off, bias_off;
+    int32_t w_off[MAXL];
+};
+
+__host__ __device__ constexpr int ld_for(int K, int pad) { return ((K - pad + 63) / 64) * 64 + pad; }
+
+template <int FL> __device__ __forceinline__ f32x4 mfma(float a, float b, f32x4 c) {
+    if constexpr (FL == 0) return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
+    else return __builtin_amdgcn_mfma_f32_4x4x1f32(a, b, c, 0, 0, 0);
+}
+
+// k-slot reduction of the M4 flavour: lanes 4s+j (s = 0..3) of every 16-lane row hold partial sums
+__device__ __forceinline__ float row_ror_add(float x) {
+    float a = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x124, 0xf, 0xf, false));
+    x += a;
+    float b = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x128, 0xf, 0xf, false));
+    return x + b;
+}
+
+template <int KU, int TPW>
+__device__ __forceinline__ void load_weights(float (&w)[TPW][KU * 4], const float* __restrict__ g, int wave, int lane) {
+#pragma unroll
+    for (int t = 0; t < TPW; ++t)
+#pragma unroll
+        for (int u = 0; u < KU; ++u) {
+            const f32x4 v = *reinterpret_cast<const f32x4*>(g + (((wave * TPW + t) * KU + u) * 64 + lane) * 4);
+            w[t][4 * u + 0] = v[0]; w[t][4 * u + 1] = v[1]; w[t][4 * u + 2] = v[2]; w[t][4 * u + 3] = v[3];
+        }
+}
+
+// acc[t] += W_tile(t) . in   over KU blocks of 16 k;  `in` = this lane's LDS row pointer + 4*s
+template <int FL, int KU, int TPW>
+__device__ __forceinline__ void gemm(const float (&w)[TPW][KU * 4], const float* in, f32x4 (&acc)[TPW]) {
+    f32x4 b[KU];
+#pragma unroll
+    for (int u = 0; u < KU; ++u) b[u] = *reinterpret_cast<const f32x4*>(in + 16 * u);
+#pragma unroll
+    for (int u = 0; u < KU; ++u)
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+#pragma unroll
+            for (int t = 0; t < TPW; ++t) acc[t] = mfma<FL>(w[t][4 * u + e], b[u][e], acc[t]);
+}
+
+template <int H_, int KUX_, int NHID_, int IO_, int FL_>
+struct Cfg {
+    static constexpr int H = H_, KUX = KUX_, NHID = NHID_, IO = IO_, FL = FL_;
+    static constexpr int TPW = (H >= 128) ? 2 : 1;
+    static constexpr int NW = H / (16 * TPW);
+    static constexpr int NT = NW * 64;
+    static constexpr int M = FL ? 4 : 16;
+    static constexpr bool TIME = IO >= 3;
+    static constexpr bool EMB = (IO == 2 || IO == 4 || IO == 6);
+    static constexpr bool GEO = (IO == 5 || IO == 6);
+    static constexpr int KUH = H / 16;
+    static constexpr int KUY = KUH + (TIME ? 1 : 0);
+    static constexpr int KUE = 2 * KUH;
+    static constexpr int PAD = FL ? 16 : 8;
+    static constexpr int LDY = ld_for(16 * KUY, PAD);
+    static constexpr int LDX = ld_for(16 * KUX, PAD);
+    static constexpr int LDC = ld_for(EMB ? 32 * KUH : 16 * KUH, PAD);
+    static constexpr int LDA = ld_for(16 * KUH, PAD);
+    static constexpr int NLAYER = (EMB ? 3 : 1) + NHID + 1;          // [init, in, emb] | [in], hid.., out
+    static constexpr int XI = (M * 16 * KUX + NT - 1) / NT;           // spline items per thread
+    static constexpr int EPT = FL ? 1 : 4;                            // owned state elements per lane per tile
+    static constexpr int LDS_FLOATS = M * (LDY + LDX + LDC + 2 * LDA) + NLAYER * H;
+};
+
+template <class CF>
+__global__ void __launch_bounds__(CF::NT, 1) snsde_mfma_kernel(MfmaArgs a) {
+    constexpr int H = CF::H, TPW = CF::TPW, FL = CF::FL, M = CF::M, NT = CF::NT, NHID = CF::NHID;
+    constexpr int KUX = CF::KUX, KUY = CF::KUY, KUE = CF::KUE, KUH = CF::KUH, EPT = CF::EPT;
+    constexpr int LDY = CF::LDY, LDX = CF::LDX, LDC = CF::LDC, LDA = CF::LDA;
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    float* ybuf = lds;                   // [M][LDY]  y (H) | sin t, cos t | 0..
+    float* xbuf = ybuf + M * LDY;        // [M][LDX]  X(t) (C) | 0..
+    float* cat = xbuf + M * LDX;         // [M][LDC]  yy (H) | Xt (H)        (or layer buffer when no emb)
+    float* bufA = cat + M * LDC;         // [M][LDA]
+    float* bufB = bufA + M * LDA;        // [M][LDA]
+    float* bias = bufB + M * LDA;        // [NLAYER][H]
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int r = FL ? (lane & 3) : (lane & 15);          // batch row within the tile
+    const int s = FL ? ((lane >> 2) & 3) : (lane >> 4);   // k-slot
+    const int fsub = FL ? 4 * (lane >> 4) : 4 * s;        // first feature (within a 16-feature tile) of the D fragment
+    const int row0 = blockIdx.x * M;
+    const int B = a.B, C = a.C;
+    const int row = row0 + r;
+    const int rowc = row < B ? row : B - 1;
+    const bool row_ok = row < B;
+    const size_t BH = (size_t)B * H;
+
+    // ---- resident weights ----------------------------------------------------------------------
+    int li = 0;
+    float wx[TPW][CF::EMB ? KUX * 4 : 4];
+    float wy[TPW][KUY * 4];
+    float we[TPW][CF::EMB ? KUE * 4 : 4];
+    float wh[NHID > 0 ? NHID : 1][TPW][KUH * 4];
+    float wo[TPW][KUH * 4];
+    if constexpr (CF::EMB) load_weights<KUX, TPW>(wx, a.ws + a.w_off[li++], wave, lane);
+    load_weights<KUY, TPW>(wy, a.ws + a.w_off[li++], wave, lane);
+    if constexpr (CF::EMB) load_weights<KUE, TPW>(we, a.ws + a.w_off[li++], wave, lane);
+#pragma unroll
+    for (int l = 0; l < NHID; ++l) load_weights<KUH, TPW>(wh[l], a.ws + a.w_off[li++], wave, lane);
+    load_weights<KUH, TPW>(wo, a.ws + a.w_off[li++], wave, lane);
+
+    // ---- LDS init ------------------------------------------------------------------------------
+    for (int i = tid; i < M * (LDY + LDX + LDC + 2 * LDA); i += NT) lds[i] = 0.0f;
+    for (int i = tid; i < CF::NLAYER * H; i += NT) bias[i] = a.ws[a.bias_off + i];
+    __syncthreads();
+
+    const float sig_theta = snsde_sigmoid(a.params[a.off_theta]);
+    const int no = a.no;
+    const float* gt = a.ws + a.gt_off;
+
+    // owned state: tile t covers features 32*wave.. ; element e of this lane = feature f0(t) + fsub + (FL ? s : e)
+    float yv[TPW][EPT];
+    int fcol[TPW];
+#pragma unroll
+    for (int t = 0; t < TPW; ++t) {
+        fcol[t] = (wave * TPW + t) * 16 + fsub + (FL ? s : 0);
+        if constexpr (FL) {
+            yv[t][0] = a.y0[(size_t)rowc * H + fcol[t]];
+            ybuf[r * LDY + fcol[t]] = yv[t][0];
+            if (row_ok) {
+                a.ys[(size_t)row * H + fcol[t]] = yv[t][0];
+                if (a.traj) a.traj[(size_t)row * H + fcol[t]] = yv[t][0];
+            }
+        } else {
+            const f32x4 v = *reinterpret_cast<const f32x4*>(a.y0 + (size_t)rowc * H + fcol[t]);
+            yv[t][0] = v[0]; yv[t][1] = v[1]; yv[t][2] = v[2]; yv[t][3] = v[3];
+            *reinterpret_cast<f32x4*>(ybuf + r * LDY + fcol[t]) = v;
+            if (row_ok) {
+                *reinterpret_cast<f32x4*>(a.ys + (size_t)row * H + fcol[t]) = v;
+                if (a.traj) *reinterpret_cast<f32x4*>(a.traj + (size_t)row * H + fcol[t]) = v;
+            }
+        }
+    }
+
+    // spline items of this thread: (xr, xc) = row-in-tile, channel
+    int xr[CF::XI], xc[CF::XI];
+    bool xok[CF::XI];
+    float ca[CF::XI], cb[CF::XI], cc[CF::XI], cd[CF::XI];
+#pragma unroll
+    for (int i = 0; i < CF::XI; ++i) {
+        const int it = tid + i * NT;
+        xr[i] = it / C; xc[i] = it - xr[i] * C;
+        xok[i] = CF::EMB && it < M * C;
+        if (!xok[i]) { xr[i] = 0; xc[i] = 0; }
+    }
+    auto load_coeffs = [&](int idx) {
+#pragma unroll
+        for (int i = 0; i < CF::XI; ++i) {
+            if (xok[i]) {
+                const int rr = row0 + xr[i] < B ? row0 + xr[i] : B - 1;
+                const float* cp = a.coeffs + ((size_t)rr * (a.L - 1) + idx) * (4 * C) + xc[i];
+                ca[i] = cp[0]; cb[i] = cp[C]; cc[i] = cp[2 * C]; cd[i] = cp[3 * C];
+            }
+        }
+    };
+    auto store_x = [&](float frac) {
+#pragma unroll
+        for (int i = 0; i < CF::XI; ++i)
+            if (xok[i]) xbuf[xr[i] * LDX + xc[i]] = snsde_spline_eval(ca[i], cb[i], cc[i], cd[i], frac);
+    };
+    {   // step 0 inputs
+        const float* st = a.step_tab;
+        if constexpr (CF::EMB) { load_coeffs(__float_as_int(st[5])); store_x(st[4]); }
+        if (CF::TIME && tid < M) { ybuf[tid * LDY + H] = st[2]; ybuf[tid * LDY + H + 1] = st[3]; }
+    }
+    __syncthreads();
+
+    const float* yrow = ybuf + r * LDY + 4 * s;
+    const float* xrow = xbuf + r * LDX + 4 * s;
+    const float* crow = cat + r * LDC + 4 * s;
+    const float* arow = bufA + r * LDA + 4 * s;
+    const float* brow = bufB + r * LDA + 4 * s;
+    const bool writer = FL ? (s == 0) : true;
+    int kout = 0;
+
+    // store one layer output fragment (after bias via acc-init, optional relu) as 16 B per lane
+    auto store_frag = [&](float* buf, int ld, int col0, f32x4 v, bool relu) {
+        if constexpr (FL) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) v[i] = row_ror_add(v[i]);
+        }
+        if (relu) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) v[i] = fmaxf(v[i], 0.0f);
+        }
+        if (writer) *reinterpret_cast<f32x4*>(buf + r * ld + col0 + fsub) = v;
+    };
+    auto bias_frag = [&](int layer, int t) {
+        f32x4 v = *reinterpret_cast<const f32x4*>(bias + layer * H + (wave * TPW + t) * 16 + fsub);
+        if constexpr (FL) { if (s != 0) v = f32x4{0.f, 0.f, 0.f, 0.f}; }
+        return v;
+    };
+
+    for (int n = 0; n < a.N; ++n) {
+        const float* st = a.step_tab + (size_t)n * SNSDE_STEP_STRIDE;
+        const float t0 = st[0], h = st[1], sqh = st[6];
+        const bool more = n + 1 < a.N;
+        const float* stn = st + (more ? SNSDE_STEP_STRIDE : 0);
+        if constexpr (CF::EMB) { if (more) load_coeffs(__float_as_int(stn[5])); }   // prefetch next interval
+
+        // Brownian increments for the owned elements (independent of y: overlaps the MFMA chain)
+        float dw[TPW][EPT];
+#pragma unroll
+        for (int t = 0; t < TPW; ++t) {
+            if (a.dW) {
+                if constexpr (FL) dw[t][0] = a.dW[(size_t)n * BH + (size_t)rowc * H + fcol[t]];
+                else {
+                    const f32x4 v = *reinterpret_cast<const f32x4*>(a.dW + (size_t)n * BH + (size_t)rowc * H + fcol[t]);
+                    dw[t][0] = v[0]; dw[t][1] = v[1]; dw[t][2] = v[2]; dw[t][3] = v[3];
+                }
+            } else {
+                float z[4];
+                snsde_philox_normal4(a.seed, (uint32_t)(a.row_offset + row), (uint32_t)n, (uint32_t)(fcol[t] >> 2), z);
+                if constexpr (FL) dw[t][0] = (s == 0 ? z[0] : s == 1 ? z[1] : s == 2 ? z[2] : z[3]) * sqh;
+                else { dw[t][0] = z[0] * sqh; dw[t][1] = z[1] * sqh; dw[t][2] = z[2] * sqh; dw[t][3] = z[3] * sqh; }
+            }
+        }
+        // time-only diffusion table row (noise_option 12/13/16/17)
+        float gtv[TPW][EPT];
+#pragma unroll
+        for (int t = 0; t < TPW; ++t)
+#pragma unroll
+            for (int e = 0; e < EPT; ++e) gtv[t][e] = (a.gt_off >= 0) ? gt[(size_t)n * H + fcol[t] + e] : 0.0f;
+
+        f32x4 acc[TPW];
+        int layer = 0;
+        // ---- drift: [init, in] -> emb -> hidden.. -> out ----
+        if constexpr (CF::EMB) {
+#pragma unroll
+            for (int t = 0; t < TPW; ++t) acc[t] = bias_frag(layer, t);
+            gemm<FL, KUX, TPW>(wx, xrow, acc);
+#pragma unroll
+            for (int t = 0; t < TPW; ++t) store_frag(cat, LDC, H + (wave * TPW + t) * 16, acc[t], false);
+            ++layer;
+        }
+#pragma unroll
+        for (int t = 0; t < TPW; ++t) acc[t] = bias_frag(layer, t);
+        gemm<FL, KUY, TPW>(wy, yrow, acc);
+#pragma unroll
+        for (int t = 0; t < TPW; ++t) store_frag(cat, LDC, (wave * TPW + t) * 16, acc[t], !CF::EMB);
+        ++layer;
+        __syncthreads();
+        const float* cur = crow;
+        if constexpr (CF::EMB) {
+#pragma unroll
+            for (int t = 0; t < TPW; ++t) acc[t] = bias_frag(layer, t);
+            gemm<FL, KUE, TPW>(we, crow, acc);
+#pragma unroll
+            for (int t = 0; t < TPW; ++t) store_frag(bufA, LDA, (wave * TPW + t) * 16, acc[t], true);
+            ++layer;
+            __syncthreads();
+            cur = arow;
+        }
+#pragma unroll
+        for (int l = 0; l < NHID; ++l) {
+            // ping-pong: emb -> A -> B -> A ... ; no-emb: cat -> A -> B ...
+            const bool toB = CF::EMB ? (l % 2 == 0) : (l % 2 == 1);
+#pragma unroll
+            for (int t = 0; t < TPW; ++t) acc[t] = bias_frag(layer, t);
+            gemm<FL, KUH, TPW>(wh[l], cur, acc);
+#pragma unroll
+            for (int t = 0; t < TPW; ++t) store_frag(toB ? bufB : bufA, LDA, (wave * TPW + t) * 16, acc[t], true);
+            ++layer;
+            __syncthreads();
+            cur = toB ? brow : arow;
+        }
+#pragma unroll
+        for (int t = 0; t < TPW; ++t) acc[t] = bias_frag(layer, t);
+        gemm<FL, KUH, TPW>(wo, cur, acc);
+
+        // ---- f, g, update in the D layout ----
+        int kend = kout;
+        while (kend < a.T - 1 && a.out_step[kend] == n) ++kend;
+#pragma unroll
+        for (int t = 0; t < TPW; ++t) {
+            f32x4 zv = acc[t];
+            if constexpr (FL) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) zv[i] = row_ror_add(zv[i]);
+            }
+            float ynew[EPT], yold[EPT];
+#pragma unroll
+            for (int e = 0; e < EPT; ++e) {
+                float z = FL ? (s == 0 ? zv[0] : s == 1 ? zv[1] : s == 2 ? zv[2] : zv[3]) : zv[e];
+                const float y = yv[t][e];
+                if constexpr (CF::GEO) z *= tanhf(y);
+                const float f = tanhf(z);
+                float raw = 0.0f, draw = 0.0f;
+                if (no == 16 || no == 12) raw = gtv[t][e];
+                else if (no == 17 || no == 13) { draw = gtv[t][e]; raw = draw * y; }
+                const float g = tanhf(sig_theta * snsde_nan_to_num(raw));
+                float yn = fmaf(g, dw[t][e], fmaf(f, h, y));
+                if (a.method == SNSDE_MILSTEIN) {
+                    const float fin = (raw - raw == 0.0f) ? 1.0f : 0.0f;
+                    const float dg = (1.0f - g * g) * sig_theta * draw * fin;
+                    yn = fmaf(0.5f * (g * dg), fmaf(dw[t][e], dw[t][e], -h), yn);
+                }
+                yold[e] = y; ynew[e] = yn; yv[t][e] = yn;
+            }
+            const size_t goff = (size_t)row * H + fcol[t];
+            if constexpr (FL) {
+                ybuf[r * LDY + fcol[t]] = ynew[0];
+                if (row_ok) {
+                    if (a.traj) a.traj[(size_t)(n + 1) * BH + goff] = ynew[0];
+                    if (a.dW_out) a.dW_out[(size_t)n * BH + goff] = dw[t][0];
+                    for (int k = kout; k < kend; ++k) {
+                        const float w0 = a.out_w[2 * k], w1 = a.out_w[2 * k + 1];
+                        a.ys[(size_t)(k + 1) * BH + goff] = (w0 == 0.0f) ? ynew[0] : w0 * yold[0] + w1 * ynew[0];
+                    }
+                }
+            } else {
+                const f32x4 vn = {ynew[0], ynew[1], ynew[2], ynew[3]};
+                *reinterpret_cast<f32x4*>(ybuf + r * LDY + fcol[t]) = vn;
+                if (row_ok) {
+                    if (a.traj) *reinterpret_cast<f32x4*>(a.traj + (size_t)(n + 1) * BH + goff) = vn;
+                    if (a.dW_out) *reinterpret_cast<f32x4*>(a.dW_out + (size_t)n * BH + goff) =
+                        f32x4{dw[t][0], dw[t][1], dw[t][2], dw[t][3]};
+                    for (int k = kout; k < kend; ++k) {
+                        const float w0 = a.out_w[2 * k], w1 = a.out_w[2 * k + 1];
+                        f32x4 o;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) o[e] = (w0 == 0.0f) ? ynew[e] : w0 * yold[e] + w1 * ynew[e];
+                        *reinterpret_cast<f32x4*>(a.ys + (size_t)(k + 1) * BH + goff) = o;
+                    }
+                }
+            }
+        }
+        kout = kend;
+        // inputs of the next step
+        if (more) {
+            if constexpr (CF::EMB) store_x(stn[4]);
+            if (CF::TIME && tid < M) { ybuf[tid * LDY + H] = stn[2]; ybuf[tid * LDY + H + 1] = stn[3]; }
+        }
+        __syncthreads();
+    }
+}
+
+template <class CF>
+int launch_cfg(const MfmaArgs& a, hipStream_t stream) {
+    const size_t lds_bytes = (size_t)CF::LDS_FLOATS * sizeof(float);
+    static bool attr_set = false;   // per instantiation
+    if (lds_bytes > 64 * 1024 && !attr_set) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(snsde_mfma_kernel<CF>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes) != hipSuccess)
+            return SNSDE_ERR_LDS;
+        attr_set = true;
+    }
+    const int grid = (a.B + CF::M - 1) / CF::M;
+    hipLaunchKernelGGL(snsde_mfma_kernel<CF>, dim3(grid), dim3(CF::NT), lds_bytes, stream, a);
+    return hipGetLastError() == hipSuccess ? SNSDE_OK : SNSDE_ERR_LAUNCH;
+}
+
+struct MfmaPlan {
+    bool ok;
+    int H, KUX, NHID, IO, FL, TPW, NW;
+    int n_layers;
+    MfmaLayerPack layer[MAXL];
+    int bias_off, gt_off, total_floats;
+};
+
+// Which configurations the fast path is instantiated for.
+MfmaPlan make_plan(const snsde_solve* s, const SnsdeNet& net, int flavor_hint) {
+    MfmaPlan p{};
+    const snsde_model& m = s->model;
+    const int H = m.hidden_channels, io = m.input_option, no = m.noise_option;
+    p.ok = false;
+    if (m.hidden_hidden_channels != H) return p;
+    if (!(H == 128 || H == 64 || H == 32)) return p;
+    if (!(io >= 1 && io <= 6)) return p;
+    if (!(no == 0 || no == 12 || no == 13 || no == 16 || no == 17)) return p;
+    const bool emb = (io == 2 || io == 4 || io == 6);
+    const int nhid = m.num_hidden_layers - 1;
+    if (nhid > 1) return p;
+    if (emb && m.input_channels > 32) return p;
+    p.H = H; p.IO = io; p.NHID = nhid;
+    p.KUX = emb ? (m.input_channels <= 16 ? 1 : 2) : 1;
+    p.TPW = H >= 128 ? 2 : 1;
+    p.NW = H / (16 * p.TPW);
+    // flavour: M4 fills the chip when the batch is small (256 CUs); M16 has 4x less overhead per row
+    p.FL = flavor_hint >= 0 ? flavor_hint : ((s->batch + 15) / 16 >= 256 ? 0 : 1);
+    int off = 0, n = 0;
+    auto add = [&](const SnsdeLayer& L, int KU) {
+        MfmaLayerPack& q = p.layer[n++];
+        q.src_w = L.src_w; q.src_b = L.src_b; q.K = L.K; q.tshift = L.tshift; q.N = L.N; q.KU = KU; q.dst = off;
+        off += p.NW * p.TPW * KU * 256;
+    };
+    const int KUH = H / 16;
+    if (emb) add(net.init, p.KUX);
+    add(net.in, KUH + (io >= 3 ? 1 : 0));
+    if (emb) add(net.emb, 2 * KUH);
+    for (int l = 0; l < nhid; ++l) add(net.hid[l], KUH);
+    add(net.out, KUH);
+    p.n_layers = n;
+    p.bias_off = off;
+    off += n * H;
+    off = (off + 3) & ~3;
+    p.gt_off = (no == 12 || no == 13 || no == 16 || no == 17) ? off : -1;
+    if (p.gt_off >= 0) off += s->n_steps * H;
+    p.total_floats = off;
+    p.ok = true;
+    return p;
+}
+
+template <int H, int FL>
+int dispatch_io(const MfmaPlan& p, const MfmaArgs& a, hipStream_t st) {
+#define SNSDE_CASE(IO_, KUX_, NHID_) \
+    if (p.IO == IO_ && p.KUX == KUX_ && p.NHID == NHID_) return launch_cfg<Cfg<H, KUX_, NHID_, IO_, FL>>(a, st);
+    SNSDE_CASE(4, 2, 1) SNSDE_CASE(6, 2, 1) SNSDE_CASE(2, 2, 1)
+    SNSDE_CASE(4, 2, 0) SNSDE_CASE(6, 2, 0) SNSDE_CASE(2, 2, 0)
+    SNSDE_CASE(4, 1, 1) SNSDE_CASE(6, 1, 1) SNSDE_CASE(2, 1, 1)
+    SNSDE_CASE(4, 1, 0) SNSDE_CASE(6, 1, 0) SNSDE_CASE(2, 1, 0)
+    SNSDE_CASE(1, 1, 1) SNSDE_CASE(3, 1, 1) SNSDE_CASE(5, 1, 1)
+    SNSDE_CASE(1, 1, 0) SNSDE_CASE(3, 1, 0) SNSDE_CASE(5, 1, 0)
+#undef SNSDE_CASE
+    return SNSDE_ERR_UNSUPPORTED;
+}
+
+}  // namespace
+
+// time table kernel lives in snsde_generic.hip
+int snsde_time_table_launch(const float* params, const float* step_tab, float* gt, const SnsdeLayer& nt0,
+                            const SnsdeLayer& nt1, int H, int no, int n_steps, hipStream_t stream);
+
+bool snsde_mfma_supported(const snsde_solve* s, const SnsdeNet& net) { return make_plan(s, net, -1).ok; }
+
+size_t snsde_mfma_workspace_floats(const snsde_solve* s, const SnsdeNet& net) {
+    MfmaPlan p = make_plan(s, net, -1);
+    return p.ok ? (size_t)p.total_floats : 0;
+}
+
+int snsde_mfma_launch(const snsde_solve* s, const SnsdeNet& net, hipStream_t stream, int flavor_hint) {
+    MfmaPlan p = make_plan(s, net, flavor_hint);
+    if (!p.ok) return SNSDE_ERR_UNSUPPORTED;
+    float* ws = static_cast<float*>(s->workspace);
+    if (!(s->flags & SNSDE_FLAG_REUSE_PREPARED)) {
+        MfmaPackJob job{};
+        for (int i = 0; i < p.n_layers; ++i) job.layer[i] = p.layer[i];
+        job.n_layers = p.n_layers; job.flavor = p.FL; job.TPW = p.TPW; job.NW = p.NW; job.bias_off = p.bias_off; job.H = p.H;
+        hipLaunchKernelGGL(snsde_mfma_pack_kernel, dim3(16, p.n_layers), dim3(256), 0, stream, s->params, ws, job);
+        if (p.gt_off >= 0)
+            snsde_time_table_launch(s->params, s->step_tab, ws + p.gt_off, net.nt0, net.nt1, p.H, s->model.noise_option,
+                                    s->n_steps, stream);
+    }
+    MfmaArgs a{};
+    a.params = s->params; a.ws = ws; a.coeffs = s->coeffs; a.step_tab = s->step_tab; a.out_step = s->out_step;
+    a.out_w = s->out_w; a.y0 = s->y0; a.dW = s->dW; a.ys = s->ys; a.traj = s->traj; a.dW_out = s->dW_out;
+    a.row_offset = s->row_offset; a.seed = s->seed;
+    a.B = s->batch; a.L = s->knots; a.C = s->model.input_channels; a.N = s->n_steps; a.T = s->n_out;
+    a.method = s->method; a.no = s->model.noise_option;
+    a.off_theta = net.off_theta; a.gt_off = p.gt_off; a.bias_off = p.bias_off;
+    for (int i = 0; i < p.n_layers; ++i) a.w_off[i] = p.layer[i].dst;
+    if (p.H == 128) return p.FL ? dispatch_io<128, 1>(p, a, stream) : dispatch_io<128, 0>(p, a, stream);
+    if (p.H == 64) return p.FL ? dispatch_io<64, 1>(p, a, stream) : dispatch_io<64, 0>(p, a, stream);
+    if (p.H == 32) return p.FL ? dispatch_io<32, 1>(p, a, stream) : dispatch_io<32, 0>(p, a, stream);
+    return SNSDE_ERR_UNSUPPORTED;
+}

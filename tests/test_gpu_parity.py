@@ -286,3 +286,97 @@ def test_k2_full_size_parity_and_properties():
     halves = [hip_solve(pr, ts, dt, seed=2024, row_offset=o, rows=slice(o, o + 512))[0] for o in (0, 512)]
     np.testing.assert_array_equal(np.concatenate(halves, axis=1), a)
     assert np.isfinite(a).all()
+
+
+# ---- MFMA fast path (both tile flavours) ---------------------------------------------------------------
+MFMA_CASES = [
+    # io, no, NL, B, H, C, L, ts, dt, method
+    (4, 17, 2, 37, 128, 21, 13, [0, 12], 1.0, 'euler'),
+    (6, 17, 2, 50, 128, 21, 21, [0, 3, 4, 11, 20], 1.0, 'euler'),
+    (2, 16, 2, 18, 128, 5, 20, None, 0.02, 'euler'),
+    (4, 17, 1, 16, 128, 32, 9, [0, 8], 1.0, 'euler'),
+    (6, 16, 1, 7, 128, 3, 9, [0, 2.5, 8], 0.5, 'euler'),
+    (4, 17, 2, 33, 128, 14, 13, [0, 5, 12], 1.0, 'milstein'),
+    (6, 13, 2, 20, 128, 17, 9, [0, 8], 1.0, 'milstein'),
+    (2, 12, 2, 20, 128, 16, 9, [0, 8], 1.0, 'euler'),
+    (4, 0, 2, 20, 128, 21, 9, [0, 8], 1.0, 'euler'),
+    (4, 17, 2, 70, 64, 21, 13, [0, 12], 1.0, 'euler'),
+    (6, 17, 2, 9, 64, 7, 9, None, None, 'milstein'),
+    (2, 16, 1, 21, 64, 2, 20, None, 0.02, 'euler'),
+    (4, 17, 2, 19, 32, 5, 13, [0, 12], 1.0, 'euler'),
+    (2, 16, 1, 256, 32, 2, 20, None, 0.02, 'euler'),          # K1 shape on the GPU
+    (1, 0, 2, 11, 64, 3, 8, [0, 2.5, 7], 1.0, 'euler'),
+    (3, 17, 2, 11, 32, 3, 8, [0, 7], 1.0, 'euler'),
+    (5, 16, 1, 11, 128, 3, 8, [0, 7], 0.5, 'euler'),
+    (1, 13, 2, 11, 128, 3, 8, [0, 7], 0.5, 'milstein'),
+    (3, 0, 1, 40, 64, 3, 8, [0, 7], 1.0, 'euler'),
+]
+
+
+@pytest.mark.parametrize('kernel', ['mfma16', 'mfma4'])
+@pytest.mark.parametrize('ci', range(len(MFMA_CASES)))
+def test_mfma_trajectory_vs_oracle(ci, kernel):
+    io, no, NL, B, H, C, L, ts, dt, method = MFMA_CASES[ci]
+    times = np.linspace(0, 1, L).astype(np.float32) if ts is None else None
+    pr = make_problem(300 + ci, io, no, NL, B, H, C, L, times=times)
+    if ts is None:
+        ts = pr['times']
+        dt = dt or max(float(np.diff(pr['times']).min()), 1e-3)
+    dW = draw_dW(300 + ci, ts, dt, B, H)
+    ys, call = hip_solve(pr, ts, dt, dW=dW, method=method, save_traj=True, kernel=kernel)
+    ref64, traj64 = oracle_solve(pr, ts, dt, dW, method, np.float64)
+    cpu32, _ = oracle_solve(pr, ts, dt, dW, method, np.float32)
+    assert_parity(ys, ref64, cpu32, what=f'mfma case {ci} {kernel}')
+    assert_parity(call.traj.cpu().numpy(), traj64, what=f'mfma traj {ci} {kernel}')
+    np.testing.assert_array_equal(ys[0], pr['y0'])
+
+
+def test_mfma_unsupported_configuration_is_refused_not_silently_rerouted():
+    pr = make_problem(1, 1, 18, 2, 8, 64, 3, 5)
+    with pytest.raises(S._lib.SnsdeError) as e:
+        hip_solve(pr, [0, 4], 1.0, dW=draw_dW(1, [0, 4], 1.0, 8, 64), kernel='mfma')
+    assert e.value.code == -4
+    pr = make_problem(1, 4, 17, 2, 8, 48, 3, 5)     # H not instantiated
+    with pytest.raises(S._lib.SnsdeError):
+        hip_solve(pr, [0, 4], 1.0, dW=draw_dW(1, [0, 4], 1.0, 8, 48), kernel='mfma16')
+    # 'auto' takes the generic kernel for those
+    ys, _ = hip_solve(pr, [0, 4], 1.0, dW=draw_dW(1, [0, 4], 1.0, 8, 48), kernel='auto')
+    assert np.isfinite(ys).all()
+
+
+@pytest.mark.parametrize('kernel', ['mfma16', 'mfma4'])
+def test_mfma_philox_spec_and_shard_invariance(kernel):
+    pr = make_problem(31, 4, 17, 2, 96, 128, 21, 9)
+    ts, dt = [0, 2.5, 8], 0.5
+    ys, call = hip_solve(pr, ts, dt, dW=None, seed=0xABCDEF0123, row_offset=4096, save_dW=True, kernel=kernel)
+    t0, t1, *_ = O.step_grid(np.asarray(ts, np.float32), dt)
+    got = call.dW_out.cpu().numpy()
+    np.testing.assert_allclose(got, O.philox_dW(0xABCDEF0123, 4096, 96, 128, t0, t1), rtol=2e-6, atol=2e-7)
+    ref64, _ = oracle_solve(pr, ts, dt, got, 'euler', np.float64)
+    assert_parity(ys, ref64, what='mfma philox')
+    # the increments are the same stream the generic kernel draws
+    _, cg = hip_solve(pr, ts, dt, dW=None, seed=0xABCDEF0123, row_offset=4096, save_dW=True, kernel='generic')
+    np.testing.assert_array_equal(got, cg.dW_out.cpu().numpy())
+    full, _ = hip_solve(pr, ts, dt, seed=9, kernel=kernel)
+    for nshard in (2, 4):
+        per = 96 // nshard
+        parts = [hip_solve(pr, ts, dt, seed=9, row_offset=k * per, rows=slice(k * per, (k + 1) * per), kernel=kernel)[0]
+                 for k in range(nshard)]
+        np.testing.assert_array_equal(np.concatenate(parts, axis=1), full)
+
+
+@pytest.mark.parametrize('kernel', ['mfma16', 'mfma4'])
+def test_k2_full_size_mfma(kernel):
+    B, H, C, L, N = 1024, 128, 21, 101, 100
+    pr = make_problem(1234, 4, 17, 2, B, H, C, L, nan_frac=0.3)
+    ts, dt = [0, N], 1.0
+    dW = draw_dW(2024, ts, dt, B, H)
+    ys, _ = hip_solve(pr, ts, dt, dW=dW, kernel=kernel)
+    ref64, _ = oracle_solve(pr, ts, dt, dW, 'euler', np.float64)
+    cpu32, _ = oracle_solve(pr, ts, dt, dW, 'euler', np.float32)
+    print('K2 parity', kernel, assert_parity(ys, ref64, cpu32, what='K2 ' + kernel))
+    a, _ = hip_solve(pr, ts, dt, seed=2024, kernel=kernel)
+    b, _ = hip_solve(pr, ts, dt, seed=2024, kernel=kernel)
+    np.testing.assert_array_equal(a, b)
+    halves = [hip_solve(pr, ts, dt, seed=2024, row_offset=o, rows=slice(o, o + 512), kernel=kernel)[0] for o in (0, 512)]
+    np.testing.assert_array_equal(np.concatenate(halves, axis=1), a)
