@@ -89,10 +89,12 @@ int     snsde_param_info(const snsde_model* m, int index, char* name, int name_c
  * plus, per step, the spline interval of t0 on the knot grid `times`
  * (interpolate.py:263-268: idx = clamp(#{j: times[j] < t} - 1, 0, L-2), frac = t - times[idx]).
  *
- * step_tab row (SNSDE_STEP_STRIDE floats): t0, h = t1-t0, sin(t0), cos(t0), frac, idx (int32 bit
- * pattern), sqrt(h), t1.  out_step[k] = index of the solver step after which output k+1 is
- * emitted; out_w[2k], out_w[2k+1] = linear_interp weights (t1-t)/(t1-t0), (t-t0)/(t1-t0).   */
-#define SNSDE_STEP_STRIDE 8
+ * step_tab row (SNSDE_STEP_STRIDE floats): [0] t0, [1] h = t1-t0, [2] sin(t0), [3] cos(t0), [4] frac,
+ * [5] idx (int32 bit pattern), [6] sqrt(h), [7] t1, [8] number of outputs emitted after this step
+ * (int32 bits), [9] index k of the first of them (int32 bits), [10..11] zero.
+ * out_step[k] = index of the solver step after which output k+1 is emitted; out_w[2k], out_w[2k+1] =
+ * linear_interp weights (t1-t)/(t1-t0), (t-t0)/(t1-t0).                                          */
+#define SNSDE_STEP_STRIDE 12
 int snsde_grid_count(const float* ts, int32_t n_out, double dt, int32_t* n_steps);
 int snsde_grid_build(const float* ts, int32_t n_out, double dt, const float* times, int32_t knots,
                      int32_t n_steps, float* step_tab, int32_t* out_step, float* out_w);

@@ -9,7 +9,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, 'libsnsde.so')
 
-SNSDE_STEP_STRIDE = 8
+SNSDE_STEP_STRIDE = 12
 EULER, MILSTEIN = 0, 1
 KERNEL_AUTO, KERNEL_GENERIC, KERNEL_MFMA = 0, 1, 2
 FLAG_REUSE_PREPARED = 1

@@ -227,6 +227,7 @@ static int walk_grid(const float* ts, int32_t T, double dt, const float* times, 
                 memcpy(&r[5], &idx, sizeof(float));
                 r[6] = sqrtf(h);
                 r[7] = nxt;
+                r[8] = r[9] = r[10] = r[11] = 0.0f;
             }
             prev = curr;
             curr = nxt;
@@ -234,6 +235,16 @@ static int walk_grid(const float* ts, int32_t T, double dt, const float* times, 
         }
         if (out_step) {
             out_step[k - 1] = n - 1;
+            if (step_tab) {   // per-step output bookkeeping: count and first output index
+                float* r = step_tab + (size_t)(n - 1) * SNSDE_STEP_STRIDE;
+                int32_t cnt, first;
+                memcpy(&cnt, &r[8], 4);
+                memcpy(&first, &r[9], 4);
+                if (cnt == 0) first = k - 1;
+                ++cnt;
+                memcpy(&r[8], &cnt, 4);
+                memcpy(&r[9], &first, 4);
+            }
             volatile float denom = curr - prev;
             volatile float a = curr - out_t, b = out_t - prev;
             out_w[2 * (k - 1)] = a / denom;

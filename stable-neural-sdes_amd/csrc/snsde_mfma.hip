@@ -99,6 +99,23 @@ __device__ __forceinline__ float row_ror_add(float x) {
     return x + b;
 }
 
+// tanh on the hardware exp2 / rcp units, branch-free:
+//   |x| <  0.25 : odd Taylor polynomial to x^11 (truncation < 3e-10 relative)
+//   |x| >= 0.25 : (1 - t) / (1 + t), t = 2^(-2 log2(e) |x|) in (0, 0.61]: no cancellation in 1 - t, the result
+//                 carries <= ~3 ulp relative error; saturates to +-1, NaN preserved.
+__device__ __forceinline__ float fast_tanh(float x) {
+    const float ax = fabsf(x);
+    const float x2 = x * x;
+    float p = fmaf(x2, -0.0088632355299021967f, 0.021869488536155203f);   // -1382/155925, 62/2835
+    p = fmaf(x2, p, -0.053968253968253971f);                              // -17/315
+    p = fmaf(x2, p, 0.13333333333333333f);                                // 2/15
+    p = fmaf(x2, p, -0.33333333333333333f);
+    p = fmaf(x * x2, p, x);
+    const float t = __builtin_amdgcn_exp2f(ax * -2.8853900817779268f);
+    const float q = (1.0f - t) * __builtin_amdgcn_rcpf(1.0f + t);
+    return ax < 0.25f ? p : copysignf(q, x);
+}
+
 template <int KU, int TPW>
 __device__ __forceinline__ void load_weights(float (&w)[TPW][KU * 4], const float* __restrict__ g, int wave, int lane) {
 #pragma unroll
@@ -124,11 +141,16 @@ __device__ __forceinline__ void gemm(const float (&w)[TPW][KU * 4], const float*
             for (int t = 0; t < TPW; ++t) acc[t] = mfma<FL>(w[t][4 * u + e], b[u][e], acc[t]);
 }
 
-template <int H_, int KUX_, int NHID_, int IO_, int FL_>
+template <int H_, int KUX_, int NHID_, int IO_, int FL_, int PHX_>
 struct Cfg {
     static constexpr int H = H_, KUX = KUX_, NHID = NHID_, IO = IO_, FL = FL_;
-    static constexpr int TPW = (H >= 128) ? 2 : 1;
+    static constexpr bool PHX = PHX_ != 0;   // in-kernel Philox increments (else supplied dW)
+    // one 16-feature tile per wave: H/16 waves per workgroup (8 at H=128 = two waves per SIMD, so one wave's
+    // LDS/barrier/VALU latency hides under the other's MFMAs, and the 172 resident weight registers of a wave
+    // fit the 256-register budget without AGPR round trips)
+    static constexpr int TPW = 1;
     static constexpr int NW = H / (16 * TPW);
+    static constexpr int WPS = NW >= 4 ? NW / 4 : 1;   // waves per SIMD
     static constexpr int NT = NW * 64;
     static constexpr int M = FL ? 4 : 16;
     static constexpr bool TIME = IO >= 3;
@@ -149,7 +171,7 @@ struct Cfg {
 };
 
 template <class CF>
-__global__ void __launch_bounds__(CF::NT, 1) snsde_mfma_kernel(MfmaArgs a) {
+__global__ void __launch_bounds__(CF::NT, CF::WPS) snsde_mfma_kernel(MfmaArgs a) {
     constexpr int H = CF::H, TPW = CF::TPW, FL = CF::FL, M = CF::M, NT = CF::NT, NHID = CF::NHID;
     constexpr int KUX = CF::KUX, KUY = CF::KUY, KUE = CF::KUE, KUH = CF::KUH, EPT = CF::EPT;
     constexpr int LDY = CF::LDY, LDX = CF::LDX, LDC = CF::LDC, LDA = CF::LDA;
@@ -260,9 +282,11 @@ __global__ void __launch_bounds__(CF::NT, 1) snsde_mfma_kernel(MfmaArgs a) {
     const float* arow = bufA + r * LDA + 4 * s;
     const float* brow = bufB + r * LDA + 4 * s;
     const bool writer = FL ? (s == 0) : true;
-    int kout = 0;
+    const bool mul_y = (no == 13 || no == 17);
+    const float mil = (a.method == SNSDE_MILSTEIN) ? 0.5f : 0.0f;
+    const uint32_t grow = (uint32_t)(a.row_offset + row);
 
-    // store one layer output fragment (after bias via acc-init, optional relu) as 16 B per lane
+    // store one layer output fragment (bias came in through the accumulator init) as 16 B per lane
     auto store_frag = [&](float* buf, int ld, int col0, f32x4 v, bool relu) {
         if constexpr (FL) {
 #pragma unroll
@@ -280,28 +304,59 @@ __global__ void __launch_bounds__(CF::NT, 1) snsde_mfma_kernel(MfmaArgs a) {
         return v;
     };
 
+    // current step row (scalar registers), refreshed one step ahead
+    float c_h = a.step_tab[1], c_sqh = a.step_tab[6];
+    int c_nout = __float_as_int(a.step_tab[8]), c_kfirst = __float_as_int(a.step_tab[9]);
+
     for (int n = 0; n < a.N; ++n) {
-        const float* st = a.step_tab + (size_t)n * SNSDE_STEP_STRIDE;
-        const float t0 = st[0], h = st[1], sqh = st[6];
         const bool more = n + 1 < a.N;
-        const float* stn = st + (more ? SNSDE_STEP_STRIDE : 0);
-        if constexpr (CF::EMB) { if (more) load_coeffs(__float_as_int(stn[5])); }   // prefetch next interval
+        const float* stn = a.step_tab + (size_t)(more ? n + 1 : n) * SNSDE_STEP_STRIDE;
+        const float n_h = stn[1], n_sin = stn[2], n_cos = stn[3], n_frac = stn[4], n_sqh = stn[6];
+        const int n_idx = __float_as_int(stn[5]), n_nout = __float_as_int(stn[8]), n_kfirst = __float_as_int(stn[9]);
+        if constexpr (CF::EMB) { if (more) load_coeffs(n_idx); }   // prefetch next interval's cubic pieces
+        const float h = c_h, sqh = c_sqh;
 
         // Brownian increments for the owned elements (independent of y: overlaps the MFMA chain)
         float dw[TPW][EPT];
+        if constexpr (CF::PHX) {
+            if constexpr (FL) {
+                // lanes s = 0..3 of a (quad q, row j) group share two Philox calls (one per 16-feature tile):
+                // lane s runs call c = s>>1 and Box-Muller pair p = s&1, then the normals are routed to their
+                // owners (feature 4q+s of each tile) through the LDS crossbar.
+                const int c = s >> 1, p = s & 1;
+                uint32_t x[4];
+                snsde_philox4x32_10(grow, (uint32_t)n, (uint32_t)(((wave * TPW + (c < TPW ? c : 0)) * 16 + fsub) >> 2), 0u,
+                                    (uint32_t)a.seed, (uint32_t)(a.seed >> 32), x);
+                const float sc = 1.1920928955078125e-07f;
+                const float ua = ((float)((p ? x[2] : x[0]) >> 9) + 0.5f) * sc;
+                const float ub = ((float)((p ? x[3] : x[1]) >> 9) + 0.5f) * sc;
+                const float rad = sqrtf(-2.0f * logf(ua));
+                float sn, cs;
+                sincospif(2.0f * ub, &sn, &cs);
+                const float z0 = rad * cs * sqh, z1 = rad * sn * sqh;
 #pragma unroll
-        for (int t = 0; t < TPW; ++t) {
-            if (a.dW) {
+                for (int t = 0; t < TPW; ++t) {
+                    const int src = (lane & ~12) | ((2 * t + (s >> 1)) << 2);   // same q, j ; k-slot s' = 2t + (s>>1)
+                    const float v0 = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(src << 2, __builtin_bit_cast(int, z0)));
+                    const float v1 = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(src << 2, __builtin_bit_cast(int, z1)));
+                    dw[t][0] = (s & 1) ? v1 : v0;
+                }
+            } else {
+#pragma unroll
+                for (int t = 0; t < TPW; ++t) {
+                    float z[4];
+                    snsde_philox_normal4(a.seed, grow, (uint32_t)n, (uint32_t)(fcol[t] >> 2), z);
+                    dw[t][0] = z[0] * sqh; dw[t][1] = z[1] * sqh; dw[t][2] = z[2] * sqh; dw[t][3] = z[3] * sqh;
+                }
+            }
+        } else {
+#pragma unroll
+            for (int t = 0; t < TPW; ++t) {
                 if constexpr (FL) dw[t][0] = a.dW[(size_t)n * BH + (size_t)rowc * H + fcol[t]];
                 else {
                     const f32x4 v = *reinterpret_cast<const f32x4*>(a.dW + (size_t)n * BH + (size_t)rowc * H + fcol[t]);
                     dw[t][0] = v[0]; dw[t][1] = v[1]; dw[t][2] = v[2]; dw[t][3] = v[3];
                 }
-            } else {
-                float z[4];
-                snsde_philox_normal4(a.seed, (uint32_t)(a.row_offset + row), (uint32_t)n, (uint32_t)(fcol[t] >> 2), z);
-                if constexpr (FL) dw[t][0] = (s == 0 ? z[0] : s == 1 ? z[1] : s == 2 ? z[2] : z[3]) * sqh;
-                else { dw[t][0] = z[0] * sqh; dw[t][1] = z[1] * sqh; dw[t][2] = z[2] * sqh; dw[t][3] = z[3] * sqh; }
             }
         }
         // time-only diffusion table row (noise_option 12/13/16/17)
@@ -358,8 +413,6 @@ __global__ void __launch_bounds__(CF::NT, 1) snsde_mfma_kernel(MfmaArgs a) {
         gemm<FL, KUH, TPW>(wo, cur, acc);
 
         // ---- f, g, update in the D layout ----
-        int kend = kout;
-        while (kend < a.T - 1 && a.out_step[kend] == n) ++kend;
 #pragma unroll
         for (int t = 0; t < TPW; ++t) {
             f32x4 zv = acc[t];
@@ -372,18 +425,15 @@ __global__ void __launch_bounds__(CF::NT, 1) snsde_mfma_kernel(MfmaArgs a) {
             for (int e = 0; e < EPT; ++e) {
                 float z = FL ? (s == 0 ? zv[0] : s == 1 ? zv[1] : s == 2 ? zv[2] : zv[3]) : zv[e];
                 const float y = yv[t][e];
-                if constexpr (CF::GEO) z *= tanhf(y);
-                const float f = tanhf(z);
-                float raw = 0.0f, draw = 0.0f;
-                if (no == 16 || no == 12) raw = gtv[t][e];
-                else if (no == 17 || no == 13) { draw = gtv[t][e]; raw = draw * y; }
-                const float g = tanhf(sig_theta * snsde_nan_to_num(raw));
+                if constexpr (CF::GEO) z *= fast_tanh(y);
+                const float f = fast_tanh(z);
+                const float gq = gtv[t][e];
+                const float raw = mul_y ? gq * y : gq;
+                const float g = fast_tanh(sig_theta * snsde_nan_to_num(raw));
                 float yn = fmaf(g, dw[t][e], fmaf(f, h, y));
-                if (a.method == SNSDE_MILSTEIN) {
-                    const float fin = (raw - raw == 0.0f) ? 1.0f : 0.0f;
-                    const float dg = (1.0f - g * g) * sig_theta * draw * fin;
-                    yn = fmaf(0.5f * (g * dg), fmaf(dw[t][e], dw[t][e], -h), yn);
-                }
+                // Milstein: + 0.5 g dg/dy (dW^2 - h), dg/dy = (1 - g^2) sigmoid(theta) d raw/dy (raw finite)
+                const float draw = (mul_y && (raw - raw == 0.0f)) ? gq : 0.0f;
+                yn = fmaf(mil * (g * ((1.0f - g * g) * sig_theta * draw)), fmaf(dw[t][e], dw[t][e], -h), yn);
                 yold[e] = y; ynew[e] = yn; yv[t][e] = yn;
             }
             const size_t goff = (size_t)row * H + fcol[t];
@@ -392,7 +442,7 @@ __global__ void __launch_bounds__(CF::NT, 1) snsde_mfma_kernel(MfmaArgs a) {
                 if (row_ok) {
                     if (a.traj) a.traj[(size_t)(n + 1) * BH + goff] = ynew[0];
                     if (a.dW_out) a.dW_out[(size_t)n * BH + goff] = dw[t][0];
-                    for (int k = kout; k < kend; ++k) {
+                    for (int k = c_kfirst; k < c_kfirst + c_nout; ++k) {
                         const float w0 = a.out_w[2 * k], w1 = a.out_w[2 * k + 1];
                         a.ys[(size_t)(k + 1) * BH + goff] = (w0 == 0.0f) ? ynew[0] : w0 * yold[0] + w1 * ynew[0];
                     }
@@ -404,7 +454,7 @@ __global__ void __launch_bounds__(CF::NT, 1) snsde_mfma_kernel(MfmaArgs a) {
                     if (a.traj) *reinterpret_cast<f32x4*>(a.traj + (size_t)(n + 1) * BH + goff) = vn;
                     if (a.dW_out) *reinterpret_cast<f32x4*>(a.dW_out + (size_t)n * BH + goff) =
                         f32x4{dw[t][0], dw[t][1], dw[t][2], dw[t][3]};
-                    for (int k = kout; k < kend; ++k) {
+                    for (int k = c_kfirst; k < c_kfirst + c_nout; ++k) {
                         const float w0 = a.out_w[2 * k], w1 = a.out_w[2 * k + 1];
                         f32x4 o;
 #pragma unroll
@@ -414,12 +464,12 @@ __global__ void __launch_bounds__(CF::NT, 1) snsde_mfma_kernel(MfmaArgs a) {
                 }
             }
         }
-        kout = kend;
         // inputs of the next step
         if (more) {
-            if constexpr (CF::EMB) store_x(stn[4]);
-            if (CF::TIME && tid < M) { ybuf[tid * LDY + H] = stn[2]; ybuf[tid * LDY + H + 1] = stn[3]; }
+            if constexpr (CF::EMB) store_x(n_frac);
+            if (CF::TIME && tid < M) { ybuf[tid * LDY + H] = n_sin; ybuf[tid * LDY + H + 1] = n_cos; }
         }
+        c_h = n_h; c_sqh = n_sqh; c_nout = n_nout; c_kfirst = n_kfirst;
         __syncthreads();
     }
 }
@@ -463,7 +513,7 @@ MfmaPlan make_plan(const snsde_solve* s, const SnsdeNet& net, int flavor_hint) {
     if (emb && m.input_channels > 32) return p;
     p.H = H; p.IO = io; p.NHID = nhid;
     p.KUX = emb ? (m.input_channels <= 16 ? 1 : 2) : 1;
-    p.TPW = H >= 128 ? 2 : 1;
+    p.TPW = 1;
     p.NW = H / (16 * p.TPW);
     // flavour: M4 fills the chip when the batch is small (256 CUs); M16 has 4x less overhead per row
     p.FL = flavor_hint >= 0 ? flavor_hint : ((s->batch + 15) / 16 >= 256 ? 0 : 1);
@@ -492,8 +542,9 @@ MfmaPlan make_plan(const snsde_solve* s, const SnsdeNet& net, int flavor_hint) {
 
 template <int H, int FL>
 int dispatch_io(const MfmaPlan& p, const MfmaArgs& a, hipStream_t st) {
-#define SNSDE_CASE(IO_, KUX_, NHID_) \
-    if (p.IO == IO_ && p.KUX == KUX_ && p.NHID == NHID_) return launch_cfg<Cfg<H, KUX_, NHID_, IO_, FL>>(a, st);
+#define SNSDE_CASE(IO_, KUX_, NHID_)                                                              \
+    if (p.IO == IO_ && p.KUX == KUX_ && p.NHID == NHID_)                                          \
+        return a.dW ? launch_cfg<Cfg<H, KUX_, NHID_, IO_, FL, 0>>(a, st) : launch_cfg<Cfg<H, KUX_, NHID_, IO_, FL, 1>>(a, st);
     SNSDE_CASE(4, 2, 1) SNSDE_CASE(6, 2, 1) SNSDE_CASE(2, 2, 1)
     SNSDE_CASE(4, 2, 0) SNSDE_CASE(6, 2, 0) SNSDE_CASE(2, 2, 0)
     SNSDE_CASE(4, 1, 1) SNSDE_CASE(6, 1, 1) SNSDE_CASE(2, 1, 1)
