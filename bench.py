@@ -108,6 +108,7 @@ def main():
     ap.add_argument('--warmup', type=int, default=5)
     ap.add_argument('--kernel', default='auto')
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--exact-order', action='store_true', help='keep the unfused emb(linear_in) operation order')
     args = ap.parse_args()
 
     rank = int(os.environ.get('RANK', '0'))
@@ -130,7 +131,7 @@ def main():
     grid = S.engine.step_grid(np.array([0.0, float(NSTEP)], np.float32), 1.0, pr['times'], dev)
     assert grid.N == NSTEP
     call = S.engine.SolveCall(model, flat, coeffs, grid, y0, dW=None, method='euler', seed=2024,
-                              row_offset=rank * B, kernel=args.kernel)
+                              row_offset=rank * B, kernel=args.kernel, exact_order=args.exact_order)
     stream = torch.cuda.current_stream(dev)
 
     def barrier():

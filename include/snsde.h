@@ -59,7 +59,14 @@ enum {
 /* flags: REUSE_PREPARED skips the weight packing / time-table kernels; legal when `params`,
  * `step_tab` and `workspace` are unchanged since the previous call that ran them (e.g. every
  * batch of an evaluation epoch, or graph replays between optimizer steps). */
-enum { SNSDE_FLAG_REUSE_PREPARED = 1 };
+enum {
+    SNSDE_FLAG_REUSE_PREPARED = 1,
+    /* keep the reference's operation order yy = linear_in(..); z = emb(cat[yy, Xt]) on the MFMA path.  Default
+     * (flag clear): emb o linear_in and emb o initial_network are pre-multiplied once per solve (there is no
+     * non-linearity between them, neuralsde.py:200-210), which removes one layer and one barrier per step;
+     * the result differs from the unfused order by float32 round-off only. */
+    SNSDE_FLAG_EXACT_ORDER = 2
+};
 
 /* Shape of a Diffusion_model: neuralsde.py:123-179 constructor arguments. */
 typedef struct snsde_model {

@@ -13,6 +13,7 @@ SNSDE_STEP_STRIDE = 12
 EULER, MILSTEIN = 0, 1
 KERNEL_AUTO, KERNEL_GENERIC, KERNEL_MFMA = 0, 1, 2
 FLAG_REUSE_PREPARED = 1
+FLAG_EXACT_ORDER = 2
 KERNELS = {'auto': KERNEL_AUTO, 'generic': KERNEL_GENERIC, 'mfma': KERNEL_MFMA, 'mfma16': 3, 'mfma4': 4}
 
 

@@ -31,11 +31,16 @@ constexpr int MAXL = 4 + SNSDE_MAX_HIDDEN;
 
 struct MfmaLayerPack {
     int32_t src_w, src_b, K, tshift, N, KU, dst;  // dst = float offset of the packed fragment block
+    // folding (emb o linear_in / emb o initial_network): the product emb[:, fold_col:fold_col+H] . src is formed
+    // first by snsde_fold_kernel into a workspace temp (same (N, K) layout), which the pack kernel then reads
+    int32_t fold, fold_w, fold_col, fold_ld, fold_tmp, bias_row;   // bias_row < 0: piece has no bias row
 };
 
 struct MfmaPackJob {
     MfmaLayerPack layer[MAXL];
     int32_t n_layers, flavor, TPW, NW, bias_off, H;
+    int32_t fold_b_in, fold_b_init, fold_b_emb, fold_emb_w;   // folded bias = b_emb + E1 b_in + E2 b_init
+    int32_t fold_bias_tmp;
 };
 
 // packed[dst + ((w*TPW + t)*KU + u)*256 + lane*4 + e] = W[feature][k(u,s,e)]
@@ -54,14 +59,53 @@ __global__ void snsde_mfma_pack_kernel(const float* __restrict__ params, float* 
         float v = 0.0f;
         if (feat < L.N && k < L.K) {
             const int sk = (k < L.K - L.tshift) ? k + L.tshift : k - (L.K - L.tshift);
-            v = params[L.src_w + feat * L.K + sk];
+            v = L.fold ? ws[L.fold_tmp + feat * L.K + sk] : params[L.src_w + feat * L.K + sk];
         }
         ws[L.dst + i] = v;
     }
-    // bias table [layer][H]
-    if (blockIdx.x == 0) {
-        for (int j = threadIdx.x; j < job.H; j += blockDim.x)
-            ws[job.bias_off + blockIdx.y * job.H + j] = (j < L.N) ? params[L.src_b + j] : 0.0f;
+    // bias table [row][H]
+    if (blockIdx.x == 0 && L.bias_row >= 0) {
+        for (int j = threadIdx.x; j < job.H; j += blockDim.x) {
+            float b = 0.0f;
+            if (j < L.N) {
+                if (L.fold) {
+                    b = ws[job.fold_bias_tmp + j];
+                } else {
+                    b = params[L.src_b + j];
+                }
+            }
+            ws[job.bias_off + L.bias_row * job.H + j] = b;
+        }
+    }
+}
+
+// F = E[:, col:col+H] . W   (E = emb.weight (H, 2H), W = linear_in.weight (H, K) or initial_network.weight (H, C)),
+// one block per output row f; lanes run over the K columns (coalesced reads of W rows).  Block y = piece.
+struct FoldJob {
+    int32_t emb_w, H, n_pieces;
+    int32_t src_w[2], K[2], col[2], tmp[2];
+    int32_t b_in, b_init, b_emb, bias_tmp;
+};
+__global__ void snsde_fold_kernel(const float* __restrict__ params, float* __restrict__ ws, FoldJob job) {
+    extern __shared__ float erow[];
+    const int f = blockIdx.x, pc = blockIdx.y, H = job.H;
+    const float* e = params + job.emb_w + (size_t)f * 2 * H;
+    for (int j = threadIdx.x; j < 2 * H; j += blockDim.x) erow[j] = e[j];
+    __syncthreads();
+    const float* W = params + job.src_w[pc];
+    const int K = job.K[pc];
+    const float* ec = erow + job.col[pc];
+    for (int k = threadIdx.x; k < K; k += blockDim.x) {
+        float acc = 0.0f;
+        for (int j = 0; j < H; ++j) acc = fmaf(ec[j], W[(size_t)j * K + k], acc);
+        ws[job.tmp[pc] + f * K + k] = acc;
+    }
+    if (pc == 0 && threadIdx.x < 64) {   // folded bias: b_emb + E1 b_in + E2 b_init (one wave, shuffle reduction)
+        float acc = 0.0f;
+        for (int j = threadIdx.x; j < H; j += 64)
+            acc += erow[j] * params[job.b_in + j] + erow[H + j] * params[job.b_init + j];
+        for (int o = 32; o > 0; o >>= 1) acc += __shfl_down(acc, o, 64);
+        if (threadIdx.x == 0) ws[job.bias_tmp + f] = acc + params[job.b_emb + f];
     }
 }
 
@@ -128,20 +172,25 @@ __device__ __forceinline__ void load_weights(float (&w)[TPW][KU * 4], const floa
 }
 
 // acc[t] += W_tile(t) . in   over KU blocks of 16 k;  `in` = this lane's LDS row pointer + 4*s
+// Two interleaved accumulator chains per tile (acc / acc2, summed by the caller) keep dependent MFMAs apart.
 template <int FL, int KU, int TPW>
-__device__ __forceinline__ void gemm(const float (&w)[TPW][KU * 4], const float* in, f32x4 (&acc)[TPW]) {
+__device__ __forceinline__ void gemm(const float (&w)[TPW][KU * 4], const float* in, f32x4 (&acc)[TPW],
+                                     f32x4 (&acc2)[TPW]) {
     f32x4 b[KU];
 #pragma unroll
     for (int u = 0; u < KU; ++u) b[u] = *reinterpret_cast<const f32x4*>(in + 16 * u);
 #pragma unroll
     for (int u = 0; u < KU; ++u)
 #pragma unroll
-        for (int e = 0; e < 4; ++e)
+        for (int e = 0; e < 4; e += 2)
 #pragma unroll
-            for (int t = 0; t < TPW; ++t) acc[t] = mfma<FL>(w[t][4 * u + e], b[u][e], acc[t]);
+            for (int t = 0; t < TPW; ++t) {
+                acc[t] = mfma<FL>(w[t][4 * u + e], b[u][e], acc[t]);
+                acc2[t] = mfma<FL>(w[t][4 * u + e + 1], b[u][e + 1], acc2[t]);
+            }
 }
 
-template <int H_, int KUX_, int NHID_, int IO_, int FL_, int PHX_>
+template <int H_, int KUX_, int NHID_, int IO_, int FL_, int PHX_, int FOLD_>
 struct Cfg {
     static constexpr int H = H_, KUX = KUX_, NHID = NHID_, IO = IO_, FL = FL_;
     static constexpr bool PHX = PHX_ != 0;   // in-kernel Philox increments (else supplied dW)
@@ -156,6 +205,7 @@ struct Cfg {
     static constexpr bool TIME = IO >= 3;
     static constexpr bool EMB = (IO == 2 || IO == 4 || IO == 6);
     static constexpr bool GEO = (IO == 5 || IO == 6);
+    static constexpr bool FOLD = EMB && FOLD_ != 0;   // emb o (linear_in, initial_network) pre-multiplied
     static constexpr int KUH = H / 16;
     static constexpr int KUY = KUH + (TIME ? 1 : 0);
     static constexpr int KUE = 2 * KUH;
@@ -164,7 +214,7 @@ struct Cfg {
     static constexpr int LDX = ld_for(16 * KUX, PAD);
     static constexpr int LDC = ld_for(EMB ? 32 * KUH : 16 * KUH, PAD);
     static constexpr int LDA = ld_for(16 * KUH, PAD);
-    static constexpr int NLAYER = (EMB ? 3 : 1) + NHID + 1;          // [init, in, emb] | [in], hid.., out
+    static constexpr int NLAYER = (EMB && !FOLD ? 3 : 1) + NHID + 1;   // bias rows: [init, in, emb] | [first], hid.., out
     static constexpr int XI = (M * 16 * KUX + NT - 1) / NT;           // spline items per thread
     static constexpr int EPT = FL ? 1 : 4;                            // owned state elements per lane per tile
     static constexpr int LDS_FLOATS = M * (LDY + LDX + LDC + 2 * LDA) + NLAYER * H;
@@ -200,12 +250,12 @@ __global__ void __launch_bounds__(CF::NT, CF::WPS) snsde_mfma_kernel(MfmaArgs a)
     int li = 0;
     float wx[TPW][CF::EMB ? KUX * 4 : 4];
     float wy[TPW][KUY * 4];
-    float we[TPW][CF::EMB ? KUE * 4 : 4];
+    float we[TPW][(CF::EMB && !CF::FOLD) ? KUE * 4 : 4];
     float wh[NHID > 0 ? NHID : 1][TPW][KUH * 4];
     float wo[TPW][KUH * 4];
     if constexpr (CF::EMB) load_weights<KUX, TPW>(wx, a.ws + a.w_off[li++], wave, lane);
     load_weights<KUY, TPW>(wy, a.ws + a.w_off[li++], wave, lane);
-    if constexpr (CF::EMB) load_weights<KUE, TPW>(we, a.ws + a.w_off[li++], wave, lane);
+    if constexpr (CF::EMB && !CF::FOLD) load_weights<KUE, TPW>(we, a.ws + a.w_off[li++], wave, lane);
 #pragma unroll
     for (int l = 0; l < NHID; ++l) load_weights<KUH, TPW>(wh[l], a.ws + a.w_off[li++], wave, lane);
     load_weights<KUH, TPW>(wo, a.ws + a.w_off[li++], wave, lane);
@@ -366,51 +416,72 @@ __global__ void __launch_bounds__(CF::NT, CF::WPS) snsde_mfma_kernel(MfmaArgs a)
 #pragma unroll
             for (int e = 0; e < EPT; ++e) gtv[t][e] = (a.gt_off >= 0) ? gt[(size_t)n * H + fcol[t] + e] : 0.0f;
 
-        f32x4 acc[TPW];
+        f32x4 acc[TPW], acc2[TPW];
         int layer = 0;
-        // ---- drift: [init, in] -> emb -> hidden.. -> out ----
-        if constexpr (CF::EMB) {
+        auto init_acc = [&](int lyr) {
 #pragma unroll
-            for (int t = 0; t < TPW; ++t) acc[t] = bias_frag(layer, t);
-            gemm<FL, KUX, TPW>(wx, xrow, acc);
+            for (int t = 0; t < TPW; ++t) { acc[t] = bias_frag(lyr, t); acc2[t] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+        };
+        auto sum_acc = [&]() {
 #pragma unroll
-            for (int t = 0; t < TPW; ++t) store_frag(cat, LDC, H + (wave * TPW + t) * 16, acc[t], false);
-            ++layer;
-        }
-#pragma unroll
-        for (int t = 0; t < TPW; ++t) acc[t] = bias_frag(layer, t);
-        gemm<FL, KUY, TPW>(wy, yrow, acc);
-#pragma unroll
-        for (int t = 0; t < TPW; ++t) store_frag(cat, LDC, (wave * TPW + t) * 16, acc[t], !CF::EMB);
-        ++layer;
-        __syncthreads();
-        const float* cur = crow;
-        if constexpr (CF::EMB) {
-#pragma unroll
-            for (int t = 0; t < TPW; ++t) acc[t] = bias_frag(layer, t);
-            gemm<FL, KUE, TPW>(we, crow, acc);
+            for (int t = 0; t < TPW; ++t) acc[t] += acc2[t];
+        };
+        // ---- drift: [init, in] -> emb -> hidden.. -> out   (FOLD: [emb o in | emb o init] -> hidden.. -> out) ----
+        const float* cur;
+        if constexpr (CF::FOLD) {
+            init_acc(layer);
+            gemm<FL, KUY, TPW>(wy, yrow, acc, acc2);
+            gemm<FL, KUX, TPW>(wx, xrow, acc, acc2);
+            sum_acc();
 #pragma unroll
             for (int t = 0; t < TPW; ++t) store_frag(bufA, LDA, (wave * TPW + t) * 16, acc[t], true);
             ++layer;
             __syncthreads();
             cur = arow;
+        } else {
+            if constexpr (CF::EMB) {
+                init_acc(layer);
+                gemm<FL, KUX, TPW>(wx, xrow, acc, acc2);
+                sum_acc();
+#pragma unroll
+                for (int t = 0; t < TPW; ++t) store_frag(cat, LDC, H + (wave * TPW + t) * 16, acc[t], false);
+                ++layer;
+            }
+            init_acc(layer);
+            gemm<FL, KUY, TPW>(wy, yrow, acc, acc2);
+            sum_acc();
+#pragma unroll
+            for (int t = 0; t < TPW; ++t) store_frag(cat, LDC, (wave * TPW + t) * 16, acc[t], !CF::EMB);
+            ++layer;
+            __syncthreads();
+            cur = crow;
+            if constexpr (CF::EMB) {
+                init_acc(layer);
+                gemm<FL, KUE, TPW>(we, crow, acc, acc2);
+                sum_acc();
+#pragma unroll
+                for (int t = 0; t < TPW; ++t) store_frag(bufA, LDA, (wave * TPW + t) * 16, acc[t], true);
+                ++layer;
+                __syncthreads();
+                cur = arow;
+            }
         }
 #pragma unroll
         for (int l = 0; l < NHID; ++l) {
-            // ping-pong: emb -> A -> B -> A ... ; no-emb: cat -> A -> B ...
+            // ping-pong: (emb|fold) -> A -> B -> A ... ; no-emb: cat -> A -> B ...
             const bool toB = CF::EMB ? (l % 2 == 0) : (l % 2 == 1);
-#pragma unroll
-            for (int t = 0; t < TPW; ++t) acc[t] = bias_frag(layer, t);
-            gemm<FL, KUH, TPW>(wh[l], cur, acc);
+            init_acc(layer);
+            gemm<FL, KUH, TPW>(wh[l], cur, acc, acc2);
+            sum_acc();
 #pragma unroll
             for (int t = 0; t < TPW; ++t) store_frag(toB ? bufB : bufA, LDA, (wave * TPW + t) * 16, acc[t], true);
             ++layer;
             __syncthreads();
             cur = toB ? brow : arow;
         }
-#pragma unroll
-        for (int t = 0; t < TPW; ++t) acc[t] = bias_frag(layer, t);
-        gemm<FL, KUH, TPW>(wo, cur, acc);
+        init_acc(layer);
+        gemm<FL, KUH, TPW>(wo, cur, acc, acc2);
+        sum_acc();
 
         // ---- f, g, update in the D layout ----
 #pragma unroll
@@ -491,7 +562,9 @@ int launch_cfg(const MfmaArgs& a, hipStream_t stream) {
 
 struct MfmaPlan {
     bool ok;
-    int H, KUX, NHID, IO, FL, TPW, NW;
+    int H, KUX, NHID, IO, FL, TPW, NW, FOLD;
+    int n_bias_rows;
+    int fold_b_in, fold_b_init, fold_b_emb, fold_emb_w, fold_bias_tmp;
     int n_layers;
     MfmaLayerPack layer[MAXL];
     int bias_off, gt_off, total_floats;
@@ -517,34 +590,64 @@ MfmaPlan make_plan(const snsde_solve* s, const SnsdeNet& net, int flavor_hint) {
     p.NW = H / (16 * p.TPW);
     // flavour: M4 fills the chip when the batch is small (256 CUs); M16 has 4x less overhead per row
     p.FL = flavor_hint >= 0 ? flavor_hint : ((s->batch + 15) / 16 >= 256 ? 0 : 1);
-    int off = 0, n = 0;
-    auto add = [&](const SnsdeLayer& L, int KU) {
+    p.FOLD = (emb && !(s->flags & SNSDE_FLAG_EXACT_ORDER)) ? 1 : 0;
+    int off = 0, n = 0, rows = 0;
+    auto add = [&](const SnsdeLayer& L, int KU, int fold_col, bool bias) {
         MfmaLayerPack& q = p.layer[n++];
         q.src_w = L.src_w; q.src_b = L.src_b; q.K = L.K; q.tshift = L.tshift; q.N = L.N; q.KU = KU; q.dst = off;
+        q.fold = fold_col >= 0 ? 1 : 0;
+        q.fold_w = net.emb.src_w; q.fold_col = fold_col >= 0 ? fold_col : 0; q.fold_ld = 2 * H;
+        q.bias_row = bias ? rows++ : -1;
+        q.fold_tmp = -1;
         off += p.NW * p.TPW * KU * 256;
     };
     const int KUH = H / 16;
-    if (emb) add(net.init, p.KUX);
-    add(net.in, KUH + (io >= 3 ? 1 : 0));
-    if (emb) add(net.emb, 2 * KUH);
-    for (int l = 0; l < nhid; ++l) add(net.hid[l], KUH);
-    add(net.out, KUH);
+    const int KUYv = KUH + (io >= 3 ? 1 : 0);
+    if (p.FOLD) {
+        // kernel load order: wx (init piece), wy (in piece); ONE bias row (written by the `in` piece)
+        add(net.init, p.KUX, H, false);
+        add(net.in, KUYv, 0, true);
+        p.fold_b_in = net.in.src_b; p.fold_b_init = net.init.src_b; p.fold_b_emb = net.emb.src_b;
+        p.fold_emb_w = net.emb.src_w;
+    } else {
+        if (emb) add(net.init, p.KUX, -1, true);
+        add(net.in, KUYv, -1, true);
+        if (emb) add(net.emb, 2 * KUH, -1, true);
+    }
+    for (int l = 0; l < nhid; ++l) add(net.hid[l], KUH, -1, true);
+    add(net.out, KUH, -1, true);
+    p.n_bias_rows = rows;
     p.n_layers = n;
     p.bias_off = off;
-    off += n * H;
+    off += rows * H;
     off = (off + 3) & ~3;
     p.gt_off = (no == 12 || no == 13 || no == 16 || no == 17) ? off : -1;
     if (p.gt_off >= 0) off += s->n_steps * H;
+    if (p.FOLD) {   // temps for the folded products
+        for (int i = 0; i < 2; ++i) { p.layer[i].fold_tmp = off; off += H * p.layer[i].K; }
+        p.fold_bias_tmp = off; off += H;
+        off = (off + 3) & ~3;
+    }
     p.total_floats = off;
     p.ok = true;
     return p;
+}
+
+template <int H, int KUX, int NHID, int IO, int FL>
+int dispatch_var(const MfmaPlan& p, const MfmaArgs& a, hipStream_t st) {
+    constexpr bool emb = (IO == 2 || IO == 4 || IO == 6);
+    if constexpr (emb) {
+        if (p.FOLD) return a.dW ? launch_cfg<Cfg<H, KUX, NHID, IO, FL, 0, 1>>(a, st)
+                                : launch_cfg<Cfg<H, KUX, NHID, IO, FL, 1, 1>>(a, st);
+    }
+    return a.dW ? launch_cfg<Cfg<H, KUX, NHID, IO, FL, 0, 0>>(a, st) : launch_cfg<Cfg<H, KUX, NHID, IO, FL, 1, 0>>(a, st);
 }
 
 template <int H, int FL>
 int dispatch_io(const MfmaPlan& p, const MfmaArgs& a, hipStream_t st) {
 #define SNSDE_CASE(IO_, KUX_, NHID_)                                                              \
     if (p.IO == IO_ && p.KUX == KUX_ && p.NHID == NHID_)                                          \
-        return a.dW ? launch_cfg<Cfg<H, KUX_, NHID_, IO_, FL, 0>>(a, st) : launch_cfg<Cfg<H, KUX_, NHID_, IO_, FL, 1>>(a, st);
+        return dispatch_var<H, KUX_, NHID_, IO_, FL>(p, a, st);
     SNSDE_CASE(4, 2, 1) SNSDE_CASE(6, 2, 1) SNSDE_CASE(2, 2, 1)
     SNSDE_CASE(4, 2, 0) SNSDE_CASE(6, 2, 0) SNSDE_CASE(2, 2, 0)
     SNSDE_CASE(4, 1, 1) SNSDE_CASE(6, 1, 1) SNSDE_CASE(2, 1, 1)
@@ -576,6 +679,20 @@ int snsde_mfma_launch(const snsde_solve* s, const SnsdeNet& net, hipStream_t str
         MfmaPackJob job{};
         for (int i = 0; i < p.n_layers; ++i) job.layer[i] = p.layer[i];
         job.n_layers = p.n_layers; job.flavor = p.FL; job.TPW = p.TPW; job.NW = p.NW; job.bias_off = p.bias_off; job.H = p.H;
+        job.fold_b_in = p.fold_b_in; job.fold_b_init = p.fold_b_init; job.fold_b_emb = p.fold_b_emb;
+        job.fold_emb_w = p.fold_emb_w;
+        job.fold_bias_tmp = p.fold_bias_tmp;
+        if (p.FOLD) {
+            FoldJob fj{};
+            fj.emb_w = p.fold_emb_w; fj.H = p.H; fj.n_pieces = 2;
+            for (int i = 0; i < 2; ++i) {
+                fj.src_w[i] = p.layer[i].src_w; fj.K[i] = p.layer[i].K; fj.col[i] = p.layer[i].fold_col;
+                fj.tmp[i] = p.layer[i].fold_tmp;
+            }
+            fj.b_in = p.fold_b_in; fj.b_init = p.fold_b_init; fj.b_emb = p.fold_b_emb; fj.bias_tmp = p.fold_bias_tmp;
+            hipLaunchKernelGGL(snsde_fold_kernel, dim3(p.H, 2), dim3(256), 2 * p.H * sizeof(float), stream, s->params,
+                               ws, fj);
+        }
         hipLaunchKernelGGL(snsde_mfma_pack_kernel, dim3(16, p.n_layers), dim3(256), 0, stream, s->params, ws, job);
         if (p.gt_off >= 0)
             snsde_time_table_launch(s->params, s->step_tab, ws + p.gt_off, net.nt0, net.nt1, p.H, s->model.noise_option,

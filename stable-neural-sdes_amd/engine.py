@@ -121,7 +121,7 @@ class SolveCall:
     launch itself is one C call that only enqueues kernels (hipGraph-capturable)."""
 
     def __init__(self, model, flat_params, coeffs, grid, y0, dW=None, method='euler', seed=0, row_offset=0,
-                 kernel='auto', save_traj=False, save_dW=False):
+                 kernel='auto', save_traj=False, save_dW=False, exact_order=False):
         B, H = y0.shape
         C_ = model.input_channels
         L = coeffs.shape[1] + 1
@@ -141,6 +141,8 @@ class SolveCall:
         s.batch, s.knots, s.n_steps, s.n_out = B, L, grid.N, grid.T
         s.method = {'euler': _lib.EULER, 'milstein': _lib.MILSTEIN}[method]
         s.kernel = _lib.KERNELS[kernel]
+        self.base_flags = _lib.FLAG_EXACT_ORDER if exact_order else 0
+        s.flags = self.base_flags
         s.row_offset = int(row_offset)
         s.seed = int(seed) & 0xFFFFFFFFFFFFFFFF
         s.params, s.coeffs = _ptr(flat_params), _ptr(coeffs)
@@ -157,7 +159,7 @@ class SolveCall:
         """Enqueue the solve.  reuse_prepared=True skips weight packing / time tables (legal while the
         parameter block and grid are unchanged since the previous launch of this call)."""
         stream = torch.cuda.current_stream(self.ys.device) if stream is None else stream
-        self.desc.flags = _lib.FLAG_REUSE_PREPARED if reuse_prepared else 0
+        self.desc.flags = self.base_flags | (_lib.FLAG_REUSE_PREPARED if reuse_prepared else 0)
         _lib.check(_lib.lib().snsde_solve_forward(C.byref(self.desc), C.c_void_p(stream.cuda_stream)),
                    'snsde_solve_forward')
         return self.ys

@@ -23,6 +23,8 @@ def flat_params(p, io, no, NL, C, H):
 
 def hip_solve(pr, ts, dt, dW=None, method='euler', seed=0, row_offset=0, kernel='auto', rows=None, save_traj=False,
               save_dW=False):
+    exact = kernel.endswith('x')          # 'mfma4x' = MFMA path keeping the reference's unfused emb order
+    kernel = kernel[:-1] if exact else kernel
     io, no, NL, C, H = pr['io'], pr['no'], pr['NL'], pr['C'], pr['H']
     sl = slice(None) if rows is None else rows
     model = S.engine.model_struct(C, H, H, NL, io, no)
@@ -32,7 +34,7 @@ def hip_solve(pr, ts, dt, dW=None, method='euler', seed=0, row_offset=0, kernel=
     grid = S.engine.step_grid(np.asarray(ts, np.float32), dt, pr['times'], torch.device(DEV))
     dWd = None if dW is None else torch.from_numpy(np.ascontiguousarray(dW[:, sl])).to(DEV)
     call = S.engine.SolveCall(model, flat, coeffs, grid, y0, dW=dWd, method=method, seed=seed, row_offset=row_offset,
-                              kernel=kernel, save_traj=save_traj, save_dW=save_dW)
+                              kernel=kernel, save_traj=save_traj, save_dW=save_dW, exact_order=exact)
     ys = call.launch()
     torch.cuda.synchronize()
     return ys.cpu().numpy(), call
@@ -313,7 +315,7 @@ MFMA_CASES = [
 ]
 
 
-@pytest.mark.parametrize('kernel', ['mfma16', 'mfma4'])
+@pytest.mark.parametrize('kernel', ['mfma16', 'mfma4', 'mfma16x', 'mfma4x'])
 @pytest.mark.parametrize('ci', range(len(MFMA_CASES)))
 def test_mfma_trajectory_vs_oracle(ci, kernel):
     io, no, NL, B, H, C, L, ts, dt, method = MFMA_CASES[ci]
@@ -365,7 +367,7 @@ def test_mfma_philox_spec_and_shard_invariance(kernel):
         np.testing.assert_array_equal(np.concatenate(parts, axis=1), full)
 
 
-@pytest.mark.parametrize('kernel', ['mfma16', 'mfma4'])
+@pytest.mark.parametrize('kernel', ['mfma16', 'mfma4', 'mfma4x'])
 def test_k2_full_size_mfma(kernel):
     B, H, C, L, N = 1024, 128, 21, 101, 100
     pr = make_problem(1234, 4, 17, 2, B, H, C, L, nan_frac=0.3)
