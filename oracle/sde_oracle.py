@@ -548,25 +548,26 @@ def philox4x32_10(c0, c1, c2, c3, k0, k1):
 def philox_normals(seed, rows, step, H):
     """Standard normals Z[row, col] for global row indices ``rows`` at solver step ``step``.
 
-    counter = (row, step, col // 4, 0), key = (seed & 0xffffffff, seed >> 32); the four 32-bit
-    outputs x0..x3 give columns 4q..4q+3 by two Box-Muller pairs:
+    One Philox call per (row, block of 4 steps, column): counter = (row, step >> 2, col, 0),
+    key = (seed & 0xffffffff, seed >> 32); the four 32-bit outputs x0..x3 are that element's normals for
+    steps 4b..4b+3 by two Box-Muller pairs:
         u = ((x >> 9) + 0.5) * 2^-23  (exact in fp32);  r = sqrt(-2 ln u_a);
-        (r cos 2 pi u_b, r sin 2 pi u_b)
+        (z0, z1) = r(x0) (cos, sin)(2 pi u(x1)),  (z2, z3) = r(x2) (cos, sin)(2 pi u(x3));  Z = z[step & 3]
     Computed in float64 and rounded to float32 (the kernel's fp32 result agrees to a few ulp).
     """
     rows = np.asarray(rows, dtype=np.uint32)[:, None]
-    q = np.arange((H + 3) // 4, dtype=np.uint32)[None, :]
-    x0, x1, x2, x3 = philox4x32_10(rows, np.uint32(step), q, np.uint32(0),
+    cols = np.arange(H, dtype=np.uint32)[None, :]
+    x0, x1, x2, x3 = philox4x32_10(rows, np.uint32(step >> 2), cols, np.uint32(0),
                                    seed & 0xFFFFFFFF, (seed >> 32) & 0xFFFFFFFF)
 
     def u(x):
         return ((x >> np.uint32(9)).astype(np.float64) + 0.5) * (2.0 ** -23)
 
-    ra = np.sqrt(-2.0 * np.log(u(x0)))
-    rb = np.sqrt(-2.0 * np.log(u(x2)))
-    z = np.stack([ra * np.cos(2 * math.pi * u(x1)), ra * np.sin(2 * math.pi * u(x1)),
-                  rb * np.cos(2 * math.pi * u(x3)), rb * np.sin(2 * math.pi * u(x3))], axis=-1)
-    z = z.reshape(rows.shape[0], -1)[:, :H]
+    k = step & 3
+    xa, xb = (x0, x1) if k < 2 else (x2, x3)
+    r = np.sqrt(-2.0 * np.log(u(xa)))
+    ang = 2 * math.pi * u(xb)
+    z = r * (np.cos(ang) if (k & 1) == 0 else np.sin(ang))
     return z.astype(np.float32)
 
 

@@ -223,8 +223,15 @@ __global__ void __launch_bounds__(GT) snsde_generic_kernel(GenericArgs a) {
             const int r = i / Q, q = i - r * Q, row = row0 + r;
             if (row >= B) continue;
             float zn[4] = {0.f, 0.f, 0.f, 0.f};
-            if (!a.eval_mode && a.dW == nullptr)
-                snsde_philox_normal4(a.seed, (uint32_t)(a.row_offset + row), (uint32_t)n, (uint32_t)q, zn);
+            if (!a.eval_mode && a.dW == nullptr) {
+                // (row, 4-step block, column) -> 4 normals; this kernel recomputes the call each step and keeps z[n&3]
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    float z4[4];
+                    snsde_philox_normal4(a.seed, (uint32_t)(a.row_offset + row), (uint32_t)(n >> 2), (uint32_t)(4 * q + e), z4);
+                    zn[e] = (n & 3) == 0 ? z4[0] : (n & 3) == 1 ? z4[1] : (n & 3) == 2 ? z4[2] : z4[3];
+                }
+            }
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 const int j = 4 * q + e;

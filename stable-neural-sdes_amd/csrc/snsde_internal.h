@@ -104,12 +104,16 @@ __device__ __forceinline__ void snsde_philox4x32_10(uint32_t c0, uint32_t c1, ui
     out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
 }
 
-// Four standard normals for (global row, step, column quad): two Box-Muller pairs on 23-bit
-// uniforms u = ((x >> 9) + 0.5) * 2^-23 (exactly representable in fp32).
-__device__ __forceinline__ void snsde_philox_normal4(uint64_t seed, uint32_t row, uint32_t step, uint32_t quad,
+// Brownian increments: one Philox4x32-10 call per (global row, block of 4 solver steps, column) yields the four
+// standard normals of that state element for steps 4b .. 4b+3:
+//   counter = (row, step >> 2, col, 0), key = seed;  u = ((x >> 9) + 0.5) * 2^-23 (exact in fp32);
+//   (z0, z1) = sqrt(-2 ln u(x0)) * (cos, sin)(2 pi u(x1)),  (z2, z3) likewise from (x2, x3);  dW_n = z[n & 3] * sqrt(h_n).
+// Every state element is owned by exactly one lane in every kernel, so no lane recomputes another's call.
+// Specification: oracle/sde_oracle.py philox_normals.
+__device__ __forceinline__ void snsde_philox_normal4(uint64_t seed, uint32_t row, uint32_t step_block, uint32_t col,
                                                      float z[4]) {
     uint32_t x[4];
-    snsde_philox4x32_10(row, step, quad, 0u, (uint32_t)seed, (uint32_t)(seed >> 32), x);
+    snsde_philox4x32_10(row, step_block, col, 0u, (uint32_t)seed, (uint32_t)(seed >> 32), x);
     const float s = 1.1920928955078125e-07f;  // 2^-23
     const float ua = ((float)(x[0] >> 9) + 0.5f) * s, ub = ((float)(x[1] >> 9) + 0.5f) * s;
     const float uc = ((float)(x[2] >> 9) + 0.5f) * s, ud = ((float)(x[3] >> 9) + 0.5f) * s;

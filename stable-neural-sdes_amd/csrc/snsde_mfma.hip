@@ -354,6 +354,10 @@ __global__ void __launch_bounds__(CF::NT, CF::WPS) snsde_mfma_kernel(MfmaArgs a)
         return v;
     };
 
+    float zq[EPT][4];   // normals of the owned elements for the current block of 4 steps
+#pragma unroll
+    for (int e = 0; e < EPT; ++e) zq[e][0] = zq[e][1] = zq[e][2] = zq[e][3] = 0.0f;
+
     // current step row (scalar registers), refreshed one step ahead
     float c_h = a.step_tab[1], c_sqh = a.step_tab[6];
     int c_nout = __float_as_int(a.step_tab[8]), c_kfirst = __float_as_int(a.step_tab[9]);
@@ -366,47 +370,23 @@ __global__ void __launch_bounds__(CF::NT, CF::WPS) snsde_mfma_kernel(MfmaArgs a)
         if constexpr (CF::EMB) { if (more) load_coeffs(n_idx); }   // prefetch next interval's cubic pieces
         const float h = c_h, sqh = c_sqh;
 
-        // Brownian increments for the owned elements (independent of y: overlaps the MFMA chain)
+        // Brownian increments for the owned elements: one Philox call per (row, 4-step block, column) gives the
+        // element's normals for 4 consecutive steps (snsde_philox_normal4), regenerated every 4th step
+        static_assert(TPW == 1, "one 16-feature tile per wave");
         float dw[TPW][EPT];
         if constexpr (CF::PHX) {
-            if constexpr (FL) {
-                // lanes s = 0..3 of a (quad q, row j) group share two Philox calls (one per 16-feature tile):
-                // lane s runs call c = s>>1 and Box-Muller pair p = s&1, then the normals are routed to their
-                // owners (feature 4q+s of each tile) through the LDS crossbar.
-                const int c = s >> 1, p = s & 1;
-                uint32_t x[4];
-                snsde_philox4x32_10(grow, (uint32_t)n, (uint32_t)(((wave * TPW + (c < TPW ? c : 0)) * 16 + fsub) >> 2), 0u,
-                                    (uint32_t)a.seed, (uint32_t)(a.seed >> 32), x);
-                const float sc = 1.1920928955078125e-07f;
-                const float ua = ((float)((p ? x[2] : x[0]) >> 9) + 0.5f) * sc;
-                const float ub = ((float)((p ? x[3] : x[1]) >> 9) + 0.5f) * sc;
-                const float rad = sqrtf(-2.0f * logf(ua));
-                float sn, cs;
-                sincospif(2.0f * ub, &sn, &cs);
-                const float z0 = rad * cs * sqh, z1 = rad * sn * sqh;
+            if ((n & 3) == 0) {
 #pragma unroll
-                for (int t = 0; t < TPW; ++t) {
-                    const int src = (lane & ~12) | ((2 * t + (s >> 1)) << 2);   // same q, j ; k-slot s' = 2t + (s>>1)
-                    const float v0 = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(src << 2, __builtin_bit_cast(int, z0)));
-                    const float v1 = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(src << 2, __builtin_bit_cast(int, z1)));
-                    dw[t][0] = (s & 1) ? v1 : v0;
-                }
-            } else {
-#pragma unroll
-                for (int t = 0; t < TPW; ++t) {
-                    float z[4];
-                    snsde_philox_normal4(a.seed, grow, (uint32_t)n, (uint32_t)(fcol[t] >> 2), z);
-                    dw[t][0] = z[0] * sqh; dw[t][1] = z[1] * sqh; dw[t][2] = z[2] * sqh; dw[t][3] = z[3] * sqh;
-                }
+                for (int e = 0; e < EPT; ++e) snsde_philox_normal4(a.seed, grow, (uint32_t)(n >> 2), (uint32_t)(fcol[0] + e), zq[e]);
             }
-        } else {
+            const int k = n & 3;
 #pragma unroll
-            for (int t = 0; t < TPW; ++t) {
-                if constexpr (FL) dw[t][0] = a.dW[(size_t)n * BH + (size_t)rowc * H + fcol[t]];
-                else {
-                    const f32x4 v = *reinterpret_cast<const f32x4*>(a.dW + (size_t)n * BH + (size_t)rowc * H + fcol[t]);
-                    dw[t][0] = v[0]; dw[t][1] = v[1]; dw[t][2] = v[2]; dw[t][3] = v[3];
-                }
+            for (int e = 0; e < EPT; ++e) dw[0][e] = (k == 0 ? zq[e][0] : k == 1 ? zq[e][1] : k == 2 ? zq[e][2] : zq[e][3]) * sqh;
+        } else {
+            if constexpr (FL) dw[0][0] = a.dW[(size_t)n * BH + (size_t)rowc * H + fcol[0]];
+            else {
+                const f32x4 v = *reinterpret_cast<const f32x4*>(a.dW + (size_t)n * BH + (size_t)rowc * H + fcol[0]);
+                dw[0][0] = v[0]; dw[0][1] = v[1]; dw[0][2] = v[2]; dw[0][3] = v[3];
             }
         }
         // time-only diffusion table row (noise_option 12/13/16/17)
