@@ -7,7 +7,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, 'libsnsde.so')
+LIB_PATH = os.environ.get('SNSDE_LIB', os.path.join(_HERE, 'libsnsde.so'))   # SNSDE_LIB: debug/trace builds
 
 SNSDE_STEP_STRIDE = 12
 EULER, MILSTEIN = 0, 1

@@ -92,8 +92,9 @@ __device__ __forceinline__ void snsde_philox4x32_10(uint32_t c0, uint32_t c1, ui
                                                     uint32_t k0, uint32_t k1, uint32_t out[4]) {
 #pragma unroll
     for (int r = 0; r < 10; ++r) {
-        const uint32_t hi0 = __umulhi(0xD2511F53u, c0), lo0 = 0xD2511F53u * c0;
-        const uint32_t hi1 = __umulhi(0xCD9E8D57u, c2), lo1 = 0xCD9E8D57u * c2;
+        const uint64_t p0 = (uint64_t)0xD2511F53u * c0, p1 = (uint64_t)0xCD9E8D57u * c2;   // one v_mad_u64_u32 each
+        const uint32_t hi0 = (uint32_t)(p0 >> 32), lo0 = (uint32_t)p0;
+        const uint32_t hi1 = (uint32_t)(p1 >> 32), lo1 = (uint32_t)p1;
         c0 = hi1 ^ c1 ^ k0;
         c1 = lo1;
         c2 = hi0 ^ c3 ^ k1;
@@ -117,12 +118,12 @@ __device__ __forceinline__ void snsde_philox_normal4(uint64_t seed, uint32_t row
     const float s = 1.1920928955078125e-07f;  // 2^-23
     const float ua = ((float)(x[0] >> 9) + 0.5f) * s, ub = ((float)(x[1] >> 9) + 0.5f) * s;
     const float uc = ((float)(x[2] >> 9) + 0.5f) * s, ud = ((float)(x[3] >> 9) + 0.5f) * s;
-    const float ra = sqrtf(-2.0f * logf(ua)), rb = sqrtf(-2.0f * logf(uc));
-    float sn, cs;
-    sincospif(2.0f * ub, &sn, &cs);
-    z[0] = ra * cs; z[1] = ra * sn;
-    sincospif(2.0f * ud, &sn, &cs);
-    z[2] = rb * cs; z[3] = rb * sn;
+    // Box-Muller on the hardware transcendental units: v_log_f32 (log2), v_sqrt_f32, v_sin_f32 / v_cos_f32 (argument in
+    // revolutions, so 2*pi*u needs no range reduction).  -2 ln u = -2 ln2 * log2 u.
+    const float ra = __builtin_amdgcn_sqrtf(-1.3862943611198906f * __builtin_amdgcn_logf(ua));
+    const float rb = __builtin_amdgcn_sqrtf(-1.3862943611198906f * __builtin_amdgcn_logf(uc));
+    z[0] = ra * __builtin_amdgcn_cosf(ub); z[1] = ra * __builtin_amdgcn_sinf(ub);
+    z[2] = rb * __builtin_amdgcn_cosf(ud); z[3] = rb * __builtin_amdgcn_sinf(ud);
 }
 
 #endif  // __HIPCC__

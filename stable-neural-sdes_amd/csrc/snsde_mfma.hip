@@ -217,8 +217,21 @@ struct Cfg {
     static constexpr int NLAYER = (EMB && !FOLD ? 3 : 1) + NHID + 1;   // bias rows: [init, in, emb] | [first], hid.., out
     static constexpr int XI = (M * 16 * KUX + NT - 1) / NT;           // spline items per thread
     static constexpr int EPT = FL ? 1 : 4;                            // owned state elements per lane per tile
-    static constexpr int LDS_FLOATS = M * (LDY + LDX + LDC + 2 * LDA) + NLAYER * H;
+    static constexpr int ZB = FL ? 4 : 1;                             // Philox calls generated together per element
+    static constexpr int ROWCH = 128;                                 // step-table rows staged in LDS per chunk
+    static constexpr int ZSTASH = PHX ? 4 * ZB * 64 * EPT : 0;        // floats per wave
+    static constexpr int LDS_FLOATS = M * (LDY + LDX + LDC + 2 * LDA) + NLAYER * H + (ROWCH + 1) * SNSDE_STEP_STRIDE + NW * ZSTASH;
 };
+
+// Optional cycle trace (debug builds with -DSNSDE_TRACE): per-phase s_memtime deltas of every wave of block 0,
+// accumulated over the steps and written over dW_out[wave*16 + phase] at the end (dW_out then holds no increments).
+#ifdef SNSDE_TRACE
+#define TRACE_DECL unsigned long long tr_t = __builtin_readcyclecounter(); unsigned long long tr_acc[10] = {0,0,0,0,0,0,0,0,0,0};
+#define TRACE(i) { const unsigned long long tr_n = __builtin_readcyclecounter(); tr_acc[i] += tr_n - tr_t; tr_t = tr_n; }
+#else
+#define TRACE_DECL
+#define TRACE(i)
+#endif
 
 template <class CF>
 __global__ void __launch_bounds__(CF::NT, CF::WPS) snsde_mfma_kernel(MfmaArgs a) {
@@ -232,6 +245,8 @@ __global__ void __launch_bounds__(CF::NT, CF::WPS) snsde_mfma_kernel(MfmaArgs a)
     float* bufA = cat + M * LDC;         // [M][LDA]
     float* bufB = bufA + M * LDA;        // [M][LDA]
     float* bias = bufB + M * LDA;        // [NLAYER][H]
+    float* rowtab = bias + CF::NLAYER * H;   // [ROWCH + 1][SNSDE_STEP_STRIDE]
+    float* zstash_all = rowtab + (CF::ROWCH + 1) * SNSDE_STEP_STRIDE;   // [NW][4*ZB][64][EPT] per-wave normals
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -240,6 +255,7 @@ __global__ void __launch_bounds__(CF::NT, CF::WPS) snsde_mfma_kernel(MfmaArgs a)
     const int s = FL ? ((lane >> 2) & 3) : (lane >> 4);   // k-slot
     const int fsub = FL ? 4 * (lane >> 4) : 4 * s;        // first feature (within a 16-feature tile) of the D fragment
     const int row0 = blockIdx.x * M;
+    float* zstash = zstash_all + wave * CF::ZSTASH;
     const int B = a.B, C = a.C;
     const int row = row0 + r;
     const int rowc = row < B ? row : B - 1;
@@ -333,6 +349,7 @@ __global__ void __launch_bounds__(CF::NT, CF::WPS) snsde_mfma_kernel(MfmaArgs a)
     const float* brow = bufB + r * LDA + 4 * s;
     const bool writer = FL ? (s == 0) : true;
     const bool mul_y = (no == 13 || no == 17);
+    const bool s1 = (s == 1), s2 = (s == 2), s3 = (s == 3);
     const float mil = (a.method == SNSDE_MILSTEIN) ? 0.5f : 0.0f;
     const uint32_t grow = (uint32_t)(a.row_offset + row);
 
@@ -354,34 +371,70 @@ __global__ void __launch_bounds__(CF::NT, CF::WPS) snsde_mfma_kernel(MfmaArgs a)
         return v;
     };
 
-    float zq[EPT][4];   // normals of the owned elements for the current block of 4 steps
-#pragma unroll
-    for (int e = 0; e < EPT; ++e) zq[e][0] = zq[e][1] = zq[e][2] = zq[e][3] = 0.0f;
+    // Step-table rows are staged in LDS in chunks of ROWCH steps (a uniform global load per step would put its
+    // whole latency on the step's critical path: the row feeds scalar control flow and the coefficient addresses).
+    struct Row { float h, sn, cs, frac, sqh; int idx, nout, kfirst; };
+    auto fill_rows = [&](int base) {
+        for (int i = tid; i < (CF::ROWCH + 1) * SNSDE_STEP_STRIDE; i += NT) {
+            const int rr = base + i / SNSDE_STEP_STRIDE;
+            rowtab[i] = a.step_tab[(size_t)(rr < a.N ? rr : a.N - 1) * SNSDE_STEP_STRIDE + i % SNSDE_STEP_STRIDE];
+        }
+    };
+    auto get_row = [&](int i, int base) {
+        const float* st = rowtab + (i - base) * SNSDE_STEP_STRIDE;
+        const f32x4 v0 = *reinterpret_cast<const f32x4*>(st), v1 = *reinterpret_cast<const f32x4*>(st + 4),
+                    v2 = *reinterpret_cast<const f32x4*>(st + 8);
+        Row q;
+        q.h = v0[1]; q.sn = v0[2]; q.cs = v0[3]; q.frac = v1[0]; q.sqh = v1[2];
+        q.idx = __float_as_int(v1[1]); q.nout = __float_as_int(v2[0]); q.kfirst = __float_as_int(v2[1]);
+        return q;
+    };
+    fill_rows(0);
+    __syncthreads();
 
-    // current step row (scalar registers), refreshed one step ahead
-    float c_h = a.step_tab[1], c_sqh = a.step_tab[6];
-    int c_nout = __float_as_int(a.step_tab[8]), c_kfirst = __float_as_int(a.step_tab[9]);
-
+    TRACE_DECL
     for (int n = 0; n < a.N; ++n) {
+        TRACE(0)
         const bool more = n + 1 < a.N;
-        const float* stn = a.step_tab + (size_t)(more ? n + 1 : n) * SNSDE_STEP_STRIDE;
-        const float n_h = stn[1], n_sin = stn[2], n_cos = stn[3], n_frac = stn[4], n_sqh = stn[6];
-        const int n_idx = __float_as_int(stn[5]), n_nout = __float_as_int(stn[8]), n_kfirst = __float_as_int(stn[9]);
+        const int rbase = (n / CF::ROWCH) * CF::ROWCH;
+        if (n > 0 && n == rbase) {       // next chunk (every wave is past the previous step's closing barrier)
+            fill_rows(rbase);
+            __syncthreads();
+        }
+        const Row cur_row = get_row(n, rbase), nxt = get_row(more ? n + 1 : n, rbase);
+        const float n_sin = nxt.sn, n_cos = nxt.cs, n_frac = nxt.frac;
+        const int n_idx = nxt.idx;
+        const int c_nout = cur_row.nout, c_kfirst = cur_row.kfirst;
         if constexpr (CF::EMB) { if (more) load_coeffs(n_idx); }   // prefetch next interval's cubic pieces
-        const float h = c_h, sqh = c_sqh;
+        const float h = cur_row.h, sqh = cur_row.sqh;
 
         // Brownian increments for the owned elements: one Philox call per (row, 4-step block, column) gives the
         // element's normals for 4 consecutive steps (snsde_philox_normal4), regenerated every 4th step
         static_assert(TPW == 1, "one 16-feature tile per wave");
         float dw[TPW][EPT];
         if constexpr (CF::PHX) {
-            if ((n & 3) == 0) {
+            // ZB independent Philox calls (ZB blocks of 4 steps) are generated together (their round chains interleave)
+            // and parked in this wave's private LDS stash [4*ZB steps][64 lanes][EPT]; each step reads back one entry.
+            constexpr int ZB = CF::ZB;
+            const int k = n % (4 * ZB);
+            if (k == 0) {
+                float zq[EPT][4 * ZB];
 #pragma unroll
-                for (int e = 0; e < EPT; ++e) snsde_philox_normal4(a.seed, grow, (uint32_t)(n >> 2), (uint32_t)(fcol[0] + e), zq[e]);
+                for (int e = 0; e < EPT; ++e)
+#pragma unroll
+                    for (int bb = 0; bb < ZB; ++bb)
+                        snsde_philox_normal4(a.seed, grow, (uint32_t)((n >> 2) + bb), (uint32_t)(fcol[0] + e), &zq[e][4 * bb]);
+#pragma unroll
+                for (int i = 0; i < 4 * ZB; ++i) {
+                    if constexpr (FL) zstash[i * 64 + lane] = zq[0][i];
+                    else *reinterpret_cast<f32x4*>(zstash + (i * 64 + lane) * 4) = f32x4{zq[0][i], zq[1][i], zq[2][i], zq[3][i]};
+                }
             }
-            const int k = n & 3;
-#pragma unroll
-            for (int e = 0; e < EPT; ++e) dw[0][e] = (k == 0 ? zq[e][0] : k == 1 ? zq[e][1] : k == 2 ? zq[e][2] : zq[e][3]) * sqh;
+            if constexpr (FL) dw[0][0] = zstash[k * 64 + lane] * sqh;
+            else {
+                const f32x4 v = *reinterpret_cast<const f32x4*>(zstash + (k * 64 + lane) * 4);
+                dw[0][0] = v[0] * sqh; dw[0][1] = v[1] * sqh; dw[0][2] = v[2] * sqh; dw[0][3] = v[3] * sqh;
+            }
         } else {
             if constexpr (FL) dw[0][0] = a.dW[(size_t)n * BH + (size_t)rowc * H + fcol[0]];
             else {
@@ -396,6 +449,7 @@ __global__ void __launch_bounds__(CF::NT, CF::WPS) snsde_mfma_kernel(MfmaArgs a)
 #pragma unroll
             for (int e = 0; e < EPT; ++e) gtv[t][e] = (a.gt_off >= 0) ? gt[(size_t)n * H + fcol[t] + e] : 0.0f;
 
+        TRACE(1)
         f32x4 acc[TPW], acc2[TPW];
         int layer = 0;
         auto init_acc = [&](int lyr) {
@@ -413,10 +467,13 @@ __global__ void __launch_bounds__(CF::NT, CF::WPS) snsde_mfma_kernel(MfmaArgs a)
             gemm<FL, KUY, TPW>(wy, yrow, acc, acc2);
             gemm<FL, KUX, TPW>(wx, xrow, acc, acc2);
             sum_acc();
+            TRACE(2)
 #pragma unroll
             for (int t = 0; t < TPW; ++t) store_frag(bufA, LDA, (wave * TPW + t) * 16, acc[t], true);
             ++layer;
+            TRACE(3)
             __syncthreads();
+            TRACE(4)
             cur = arow;
         } else {
             if constexpr (CF::EMB) {
@@ -453,16 +510,19 @@ __global__ void __launch_bounds__(CF::NT, CF::WPS) snsde_mfma_kernel(MfmaArgs a)
             init_acc(layer);
             gemm<FL, KUH, TPW>(wh[l], cur, acc, acc2);
             sum_acc();
+            TRACE(5)
 #pragma unroll
             for (int t = 0; t < TPW; ++t) store_frag(toB ? bufB : bufA, LDA, (wave * TPW + t) * 16, acc[t], true);
             ++layer;
             __syncthreads();
+            TRACE(6)
             cur = toB ? brow : arow;
         }
         init_acc(layer);
         gemm<FL, KUH, TPW>(wo, cur, acc, acc2);
         sum_acc();
 
+        TRACE(7)
         // ---- f, g, update in the D layout ----
 #pragma unroll
         for (int t = 0; t < TPW; ++t) {
@@ -474,7 +534,8 @@ __global__ void __launch_bounds__(CF::NT, CF::WPS) snsde_mfma_kernel(MfmaArgs a)
             float ynew[EPT], yold[EPT];
 #pragma unroll
             for (int e = 0; e < EPT; ++e) {
-                float z = FL ? (s == 0 ? zv[0] : s == 1 ? zv[1] : s == 2 ? zv[2] : zv[3]) : zv[e];
+                float z = zv[FL ? 0 : e];
+                if constexpr (FL) { z = s1 ? zv[1] : z; z = s2 ? zv[2] : z; z = s3 ? zv[3] : z; }
                 const float y = yv[t][e];
                 if constexpr (CF::GEO) z *= fast_tanh(y);
                 const float f = fast_tanh(z);
@@ -483,8 +544,10 @@ __global__ void __launch_bounds__(CF::NT, CF::WPS) snsde_mfma_kernel(MfmaArgs a)
                 const float g = fast_tanh(sig_theta * snsde_nan_to_num(raw));
                 float yn = fmaf(g, dw[t][e], fmaf(f, h, y));
                 // Milstein: + 0.5 g dg/dy (dW^2 - h), dg/dy = (1 - g^2) sigmoid(theta) d raw/dy (raw finite)
-                const float draw = (mul_y && (raw - raw == 0.0f)) ? gq : 0.0f;
-                yn = fmaf(mil * (g * ((1.0f - g * g) * sig_theta * draw)), fmaf(dw[t][e], dw[t][e], -h), yn);
+                if (mil != 0.0f) {
+                    const float draw = (mul_y && (raw - raw == 0.0f)) ? gq : 0.0f;
+                    yn = fmaf(mil * (g * ((1.0f - g * g) * sig_theta * draw)), fmaf(dw[t][e], dw[t][e], -h), yn);
+                }
                 yold[e] = y; ynew[e] = yn; yv[t][e] = yn;
             }
             const size_t goff = (size_t)row * H + fcol[t];
@@ -520,9 +583,15 @@ __global__ void __launch_bounds__(CF::NT, CF::WPS) snsde_mfma_kernel(MfmaArgs a)
             if constexpr (CF::EMB) store_x(n_frac);
             if (CF::TIME && tid < M) { ybuf[tid * LDY + H] = n_sin; ybuf[tid * LDY + H + 1] = n_cos; }
         }
-        c_h = n_h; c_sqh = n_sqh; c_nout = n_nout; c_kfirst = n_kfirst;
+        TRACE(8)
         __syncthreads();
+        TRACE(9)
     }
+#ifdef SNSDE_TRACE
+    if (blockIdx.x == 0 && lane == 0 && a.dW_out) {
+        for (int i = 0; i < 10; ++i) a.dW_out[wave * 16 + i] = (float)tr_acc[i];
+    }
+#endif
 }
 
 template <class CF>
