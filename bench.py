@@ -34,6 +34,9 @@ FLOP_PER_ROWSTEP = 169_728          # SURVEY.md 8d "ALGORITHMIC flops per unit",
 BYTES_PER_ROWSTEP = 346             # SURVEY.md 8d algorithmic HBM bytes, Philox + final state only
 PEAK_FP32_TFLOPS = 157.3            # MI355X_MICROARCH.md: fp32 vector = fp32 MFMA peak
 PEAK_HBM_GBS = 8000.0
+# HBM bytes per launch of the solve kernel from rocprofv3 PMC passes (FETCH_SIZE doubled per the gfx950 correction
+# in MI355X_MICROARCH.md, + WRITE_SIZE; profiles/r01_pmc_traffic.txt); re-measure when the kernel's memory behaviour changes.
+HBM_TRAFFIC_BYTES_PER_LAUNCH = 38095957   # K2, MFMA M4 kernel, round 1
 
 
 def build_inputs(device, rank):
@@ -131,7 +134,8 @@ def main():
     grid = S.engine.step_grid(np.array([0.0, float(NSTEP)], np.float32), 1.0, pr['times'], dev)
     assert grid.N == NSTEP
     call = S.engine.SolveCall(model, flat, coeffs, grid, y0, dW=None, method='euler', seed=2024,
-                              row_offset=rank * B, kernel=args.kernel, exact_order=args.exact_order)
+                              row_offset=S.sharding.shard_rows(world * B, world, rank)[0], kernel=args.kernel,
+                              exact_order=args.exact_order)
     stream = torch.cuda.current_stream(dev)
 
     def barrier():
@@ -146,11 +150,7 @@ def main():
     for _ in range(args.steps):
         call.launch(stream)          # full call: weight pack + time table + fused solve
     barrier()
-    elapsed = time.perf_counter() - t0
-    if dist is not None:
-        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    elapsed = S.sharding.max_over_ranks(time.perf_counter() - t0, device=dev)
 
     # dominant kernel: the fused solve alone (prepared workspace reused), HIP events on the launch stream
     ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(20)]
@@ -178,7 +178,7 @@ def main():
                        "rows_per_gpu": B, "solver_steps": NSTEP, "global_rows": world * B,
                        "parallelism": f"row-shard x{world}, no collective in the solver", "kernel": args.kernel},
             "roofline": {"bound": "mfma", "achieved": ach_tf, "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s",
-                         "frac": ach_tf / PEAK_FP32_TFLOPS, "traffic": None,
+                         "frac": ach_tf / PEAK_FP32_TFLOPS, "traffic": HBM_TRAFFIC_BYTES_PER_LAUNCH,
                          "kernel_ms": kern_ms, "flop_per_rowstep": FLOP_PER_ROWSTEP,
                          "hbm_frac": ach_gbs / PEAK_HBM_GBS, "hbm_achieved_GBs": ach_gbs,
                          "note": "fp32 FMA/MFMA roof binds (intensity ~490 FLOP/B); hbm_* = algorithmic 346 B/row-step"},

@@ -382,3 +382,28 @@ def test_k2_full_size_mfma(kernel):
     np.testing.assert_array_equal(a, b)
     halves = [hip_solve(pr, ts, dt, seed=2024, row_offset=o, rows=slice(o, o + 512), kernel=kernel)[0] for o in (0, 512)]
     np.testing.assert_array_equal(np.concatenate(halves, axis=1), a)
+
+
+def test_solve_is_hip_graph_capturable_and_replayable():
+    """The C ABI only enqueues kernels (no allocation, no sync): a prepared solve captures into a HIP graph and
+    replays to the same result."""
+    pr = make_problem(41, 4, 17, 2, 64, 128, 21, 9)
+    io, no, NL, C, H = 4, 17, 2, 21, 128
+    model = S.engine.model_struct(C, H, H, NL, io, no)
+    flat = flat_params(pr['params'], io, no, NL, C, H)
+    grid = S.engine.step_grid(np.array([0, 3, 8], np.float32), 1.0, pr['times'], torch.device(DEV))
+    call = S.engine.SolveCall(model, flat, torch.from_numpy(pr['coeffs']).to(DEV), grid,
+                              torch.from_numpy(pr['y0']).to(DEV), seed=3)
+    eager = call.launch().clone()
+    torch.cuda.synchronize()
+    side = torch.cuda.Stream()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.stream(side):
+        call.launch(side)                      # warm-up on the capture stream
+        side.synchronize()
+        with torch.cuda.graph(g, stream=side):
+            call.launch(side)
+    call.ys.zero_()
+    g.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(call.ys, eager)
