@@ -126,9 +126,20 @@ def parity_report(got, ref64, cpu32=None):
     return rep
 
 
-def assert_parity(got, ref64, cpu32=None, what=''):
+def assert_parity(got, ref64, cpu32=None, what='', amplifying=False):
+    """amplifying=True: for long horizons whose dynamics amplify round-off (fp32 on the CPU is itself far from the
+    fp64 arbiter on isolated rows) only the relative criteria are applied: mean and 99.9th-percentile error within
+    4x of the CPU-fp32 error on the same inputs."""
     assert np.all(np.isfinite(got)), f'{what}: non-finite output'
     rep = parity_report(got, ref64, cpu32)
+    if amplifying:
+        assert cpu32 is not None
+        e = np.abs(np.asarray(got, np.float64) - ref64)
+        e32 = np.abs(np.asarray(cpu32, np.float64) - ref64)
+        rep.update(p999=float(np.quantile(e, 0.999)), cpu_p999=float(np.quantile(e32, 0.999)))
+        assert rep['mean'] <= 4 * rep['cpu_mean'] + 1e-7, (what, rep)
+        assert rep['p999'] <= 4 * rep['cpu_p999'] + 1e-6, (what, rep)
+        return rep
     assert rep['mean'] <= 1e-5, (what, rep)
     assert rep['frac_ok'] >= 0.9999, (what, rep)
     assert rep['max'] <= 5e-3, (what, rep)

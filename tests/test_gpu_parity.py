@@ -407,3 +407,51 @@ def test_solve_is_hip_graph_capturable_and_replayable():
     g.replay()
     torch.cuda.synchronize()
     assert torch.equal(call.ys, eager)
+
+
+# ---- the other BASELINE.json configurations as full-size parity cases (forward) --------------------------
+def test_k3_gsde_per_gpu_shard_full_size():
+    """configs[2]: Neural GSDE (6,17), H=128, 200 steps, Hermite coefficients; 4096 rows over 8 GPUs = 512 per GPU."""
+    B, H, C, L = 512, 128, 21, 201
+    pr = make_problem(3003, 6, 17, 2, B, H, C, L, nan_frac=0.0, hermite=True)
+    ts, dt = [0, L - 1], 1.0
+    dW = draw_dW(3003, ts, dt, B, H)
+    ref64, _ = oracle_solve(pr, ts, dt, dW, 'euler', np.float64)
+    cpu32, _ = oracle_solve(pr, ts, dt, dW, 'euler', np.float32)
+    for kernel in ('mfma4', 'mfma16', 'generic'):
+        ys, _ = hip_solve(pr, ts, dt, dW=dW, kernel=kernel)
+        # 200 GSDE steps amplify fp32 round-off on isolated rows (CPU fp32 is equally far from fp64): relative criterion
+        print('K3', kernel, assert_parity(ys, ref64, cpu32, what='K3 ' + kernel, amplifying=True))
+
+
+def test_k4_sepsis_shaped_nsde_full_size():
+    """configs[3]: Neural SDE (3,18), B=2048, H=64, C=69, times=linspace(1,72,72), per-row lengths, z0 supplied,
+    ts = the distinct final times (T ~ 70)."""
+    B, H, C, L = 2048, 64, 69, 72
+    times = np.linspace(1, 72, 72).astype(np.float32)
+    pr = make_problem(4004, 3, 18, 2, B, H, C, L, times=times, nan_frac=0.1)
+    rng = np.random.default_rng(4)
+    final_index = rng.integers(2, L, size=B)
+    uniq = np.unique(final_index)
+    uniq = uniq[(uniq != 0) & (uniq != L - 1)]
+    ts = np.concatenate([times[:1], times[uniq], times[-1:]])
+    dt = 1.0
+    dW = draw_dW(4004, ts, dt, B, H)
+    ys, _ = hip_solve(pr, ts, dt, dW=dW)
+    ref64, _ = oracle_solve(pr, ts, dt, dW, 'euler', np.float64)
+    cpu32, _ = oracle_solve(pr, ts, dt, dW, 'euler', np.float32)
+    assert ys.shape[0] == len(ts)
+    print('K4', assert_parity(ys, ref64, cpu32, what='K4'))
+
+
+def test_k5_milstein_h256_forecast_shaped():
+    """configs[4] forward leg: (4,17) Milstein, H=256, MuJoCo-shaped L=50 C=14, ts = times (T=50), 128 rows per GPU."""
+    B, H, C, L = 128, 256, 14, 50
+    pr = make_problem(5005, 4, 17, 2, B, H, C, L, nan_frac=0.3)
+    ts, dt = pr['times'], 1.0
+    dW = draw_dW(5005, ts, dt, B, H)
+    ys, _ = hip_solve(pr, ts, dt, dW=dW, method='milstein')
+    ref64, _ = oracle_solve(pr, ts, dt, dW, 'milstein', np.float64)
+    cpu32, _ = oracle_solve(pr, ts, dt, dW, 'milstein', np.float32)
+    assert ys.shape == (50, B, H)
+    print('K5', assert_parity(ys, ref64, cpu32, what='K5'))
