@@ -133,12 +133,35 @@ typedef struct snsde_solve {
     float*         ys;        /* device (T, B, H) out; ys[0] = y0                                */
     float*         traj;      /* optional device (N+1, B, H): every solver state                 */
     float*         dW_out;    /* optional device (N, B, H): the increments actually used         */
+    float*         act_save;  /* optional device (N, snsde_act_slots, B, H): per-step activations */
+                              /* the backward pass needs (MFMA path only, see snsde_solve_backward)*/
     void*          workspace; /* device scratch, >= snsde_workspace_bytes()                      */
     size_t         workspace_bytes;
 } snsde_solve;
 
 size_t snsde_workspace_bytes(const snsde_solve* s);
 int    snsde_solve_forward(const snsde_solve* s, void* hip_stream);
+
+/* ---- backward of the solve (discretise-then-optimise adjoint of the Euler scheme) ------------
+ * Replaces autograd THROUGH the unrolled solver loop (`loss.backward()` in
+ * benchmark_classification/common_sde.py:160, ~25 autograd nodes per solver step): given dL/d ys it runs the
+ * adjoint recursion  a_n = a_{n+1} + h (df/dy)^T a_{n+1} + (dg/dy)^T (a_{n+1} * dW_n)  backwards over the saved
+ * trajectory and writes EVERY a_n (adj[0] = dL/dy0).  Parameter gradients are the batched reduction
+ * sum_{n,rows} a_{n+1} . d(f h + g dW)/d theta over (traj, adj, dW_used), a plain GEMM-shaped job done by the host
+ * (engine.py) with library GEMMs.  Forward must have been run with traj, dW_out and act_save set.
+ * Euler only; covered configurations = the MFMA fast path (snsde_backward_supported). */
+typedef struct snsde_backward {
+    snsde_solve  fwd;        /* the forward descriptor (traj, dW_out, act_save filled by the forward)      */
+    const float* grad_ys;    /* device (T, B, H): dL/d ys                                                 */
+    float*       adj;        /* device (N+1, B, H) out: adjoint of every solver state                     */
+    void*        workspace;  /* device scratch >= snsde_backward_workspace_bytes (separate from fwd's)    */
+    size_t       workspace_bytes;
+} snsde_backward;
+
+int    snsde_act_slots(const snsde_model* m);             /* activation tensors saved per step, or <0     */
+int    snsde_backward_supported(const snsde_solve* s);    /* 1 / 0                                         */
+size_t snsde_backward_workspace_bytes(const snsde_backward* b);
+int    snsde_solve_backward(const snsde_backward* b, void* hip_stream);
 
 /* ---- cubic spline evaluation (A10) -----------------------------------------------------------
  * out[b, c] = a + (b + (0.5*two_c + three_d*frac/3)*frac)*frac   on interval `index`

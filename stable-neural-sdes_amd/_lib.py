@@ -30,8 +30,13 @@ class Solve(C.Structure):
                 ('row_offset', C.c_int64), ('seed', C.c_uint64),
                 ('params', C.c_void_p), ('coeffs', C.c_void_p), ('step_tab', C.c_void_p),
                 ('out_step', C.c_void_p), ('out_w', C.c_void_p), ('y0', C.c_void_p), ('dW', C.c_void_p),
-                ('ys', C.c_void_p), ('traj', C.c_void_p), ('dW_out', C.c_void_p),
+                ('ys', C.c_void_p), ('traj', C.c_void_p), ('dW_out', C.c_void_p), ('act_save', C.c_void_p),
                 ('workspace', C.c_void_p), ('workspace_bytes', C.c_size_t)]
+
+
+class Backward(C.Structure):
+    _fields_ = [('fwd', Solve), ('grad_ys', C.c_void_p), ('adj', C.c_void_p), ('workspace', C.c_void_p),
+                ('workspace_bytes', C.c_size_t)]
 
 
 class SnsdeError(RuntimeError):
@@ -45,7 +50,8 @@ _lib = None
 
 EXPORTS = ('snsde_version', 'snsde_strerror', 'snsde_param_count', 'snsde_param_numel', 'snsde_param_info',
            'snsde_grid_count', 'snsde_grid_build', 'snsde_workspace_bytes', 'snsde_solve_forward',
-           'snsde_spline_evaluate', 'snsde_eval_fg')
+           'snsde_spline_evaluate', 'snsde_eval_fg', 'snsde_act_slots', 'snsde_backward_supported',
+           'snsde_backward_workspace_bytes', 'snsde_solve_backward')
 
 
 def lib():
@@ -75,6 +81,11 @@ def lib():
     L.snsde_spline_evaluate.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_float,
                                         C.c_int32, C.c_void_p, C.c_void_p]
     L.snsde_eval_fg.argtypes = [C.POINTER(Solve), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+    L.snsde_act_slots.argtypes = [C.POINTER(Model)]
+    L.snsde_backward_supported.argtypes = [C.POINTER(Solve)]
+    L.snsde_backward_workspace_bytes.argtypes = [C.POINTER(Backward)]
+    L.snsde_backward_workspace_bytes.restype = C.c_size_t
+    L.snsde_solve_backward.argtypes = [C.POINTER(Backward), C.c_void_p]
     _lib = L
     return L
 

@@ -340,6 +340,39 @@ int snsde_eval_fg(const snsde_solve* s, const float* step_row, const float* y, f
     return snsde_generic_launch(&tmp, net, static_cast<hipStream_t>(hip_stream), 1, y, f_out, g_out, step_row);
 }
 
+int snsde_act_slots(const snsde_model* m) {
+    int rc = validate_model(m);
+    return rc ? rc : m->num_hidden_layers + 1;   // z0, hidden.., zout
+}
+
+int snsde_backward_supported(const snsde_solve* s) {
+    if (!s || validate_model(&s->model)) return 0;
+    SnsdeNet net;
+    if (snsde_build_net(s->model, s->n_steps, &net)) return 0;
+    return snsde_mfma_backward_supported(s, net) ? 1 : 0;
+}
+
+size_t snsde_backward_workspace_bytes(const snsde_backward* b) {
+    if (!b) return 0;
+    SnsdeNet net;
+    if (snsde_build_net(b->fwd.model, b->fwd.n_steps, &net)) return 0;
+    return (snsde_mfma_backward_workspace_floats(&b->fwd, net) + 64) * sizeof(float);
+}
+
+int snsde_solve_backward(const snsde_backward* b, void* hip_stream) {
+    if (!b) return SNSDE_ERR_NULL;
+    int rc = validate_solve(&b->fwd, false);
+    if (rc) return rc;
+    if (!b->grad_ys || !b->adj || !b->workspace || !b->fwd.traj || !b->fwd.dW_out || !b->fwd.act_save)
+        return SNSDE_ERR_NULL;
+    SnsdeNet net;
+    rc = snsde_build_net(b->fwd.model, b->fwd.n_steps, &net);
+    if (rc) return rc;
+    if (!snsde_mfma_backward_supported(&b->fwd, net)) return SNSDE_ERR_UNSUPPORTED;
+    if (b->workspace_bytes < snsde_backward_workspace_bytes(b)) return SNSDE_ERR_WORKSPACE;
+    return snsde_mfma_backward_launch(b, net, static_cast<hipStream_t>(hip_stream));
+}
+
 int snsde_spline_evaluate(const float* coeffs, int32_t batch, int32_t knots, int32_t channels, int32_t index,
                           float frac, int32_t derivative, float* out, void* hip_stream) {
     if (!coeffs || !out) return SNSDE_ERR_NULL;

@@ -56,6 +56,9 @@ int snsde_time_table_launch(const float* params, const float* step_tab, float* g
 bool snsde_mfma_supported(const snsde_solve* s, const SnsdeNet& net);
 size_t snsde_mfma_workspace_floats(const snsde_solve* s, const SnsdeNet& net);
 int snsde_mfma_launch(const snsde_solve* s, const SnsdeNet& net, hipStream_t stream, int flavor_hint);
+bool snsde_mfma_backward_supported(const snsde_solve* s, const SnsdeNet& net);
+size_t snsde_mfma_backward_workspace_floats(const snsde_solve* s, const SnsdeNet& net);
+int snsde_mfma_backward_launch(const snsde_backward* b, const SnsdeNet& net, hipStream_t stream);
 int snsde_spline_launch(const float* coeffs, int32_t B, int32_t L, int32_t C, int32_t index, float frac,
                         int32_t derivative, float* out, hipStream_t stream);
 

@@ -34,6 +34,9 @@ struct MfmaLayerPack {
     // folding (emb o linear_in / emb o initial_network): the product emb[:, fold_col:fold_col+H] . src is formed
     // first by snsde_fold_kernel into a workspace temp (same (N, K) layout), which the pack kernel then reads
     int32_t fold, fold_w, fold_col, fold_ld, fold_tmp, bias_row;   // bias_row < 0: piece has no bias row
+    // transpose (backward pass): packed row index = forward INPUT feature, k = forward OUTPUT feature:
+    // value = src[k * src_ld + col_off + feat]  (src = params + src_w, or the folded product in ws + fold_tmp)
+    int32_t transpose, src_ld, col_off;
 };
 
 struct MfmaPackJob {
@@ -57,7 +60,10 @@ __global__ void snsde_mfma_pack_kernel(const float* __restrict__ params, float* 
         feat += 16 * wt;
         const int k = 16 * u + 4 * s + e;
         float v = 0.0f;
-        if (feat < L.N && k < L.K) {
+        if (L.transpose) {
+            if (feat < L.N && k < L.K)
+                v = L.fold ? ws[L.fold_tmp + k * L.src_ld + L.col_off + feat] : params[L.src_w + k * L.src_ld + L.col_off + feat];
+        } else if (feat < L.N && k < L.K) {
             const int sk = (k < L.K - L.tshift) ? k + L.tshift : k - (L.K - L.tshift);
             v = L.fold ? ws[L.fold_tmp + feat * L.K + sk] : params[L.src_w + feat * L.K + sk];
         }
@@ -121,6 +127,7 @@ struct MfmaArgs {
     float* ys;
     float* traj;
     float* dW_out;
+    float* act_save;   // (N, NSAVE, B, H) or null
     int64_t row_offset;
     uint64_t seed;
     int32_t B, L, C, N, T, method, no;
@@ -217,6 +224,7 @@ struct Cfg {
     static constexpr int NLAYER = (EMB && !FOLD ? 3 : 1) + NHID + 1;   // bias rows: [init, in, emb] | [first], hid.., out
     static constexpr int XI = (M * 16 * KUX + NT - 1) / NT;           // spline items per thread
     static constexpr int EPT = FL ? 1 : 4;                            // owned state elements per lane per tile
+    static constexpr int NSAVE = NHID + 2;                            // saved activations per step: z0, hidden.., zout
     static constexpr int ZB = FL ? 4 : 1;                             // Philox calls generated together per element
     static constexpr int ROWCH = 128;                                 // step-table rows staged in LDS per chunk
     static constexpr int ZSTASH = PHX ? 4 * ZB * 64 * EPT : 0;        // floats per wave
@@ -354,7 +362,8 @@ __global__ void __launch_bounds__(CF::NT, CF::WPS) snsde_mfma_kernel(MfmaArgs a)
     const uint32_t grow = (uint32_t)(a.row_offset + row);
 
     // store one layer output fragment (bias came in through the accumulator init) as 16 B per lane
-    auto store_frag = [&](float* buf, int ld, int col0, f32x4 v, bool relu) {
+    int save_step = 0;   // current step, for the optional activation save
+    auto store_frag = [&](float* buf, int ld, int col0, f32x4 v, bool relu, int save_slot = -1) {
         if constexpr (FL) {
 #pragma unroll
             for (int i = 0; i < 4; ++i) v[i] = row_ror_add(v[i]);
@@ -363,7 +372,12 @@ __global__ void __launch_bounds__(CF::NT, CF::WPS) snsde_mfma_kernel(MfmaArgs a)
 #pragma unroll
             for (int i = 0; i < 4; ++i) v[i] = fmaxf(v[i], 0.0f);
         }
-        if (writer) *reinterpret_cast<f32x4*>(buf + r * ld + col0 + fsub) = v;
+        if (writer) {
+            *reinterpret_cast<f32x4*>(buf + r * ld + col0 + fsub) = v;
+            if (save_slot >= 0 && a.act_save && row_ok)
+                *reinterpret_cast<f32x4*>(a.act_save + (((size_t)save_step * CF::NSAVE + save_slot) * B + row) * H +
+                                          wave * 16 + fsub) = v;
+        }
     };
     auto bias_frag = [&](int layer, int t) {
         f32x4 v = *reinterpret_cast<const f32x4*>(bias + layer * H + (wave * TPW + t) * 16 + fsub);
@@ -396,6 +410,7 @@ __global__ void __launch_bounds__(CF::NT, CF::WPS) snsde_mfma_kernel(MfmaArgs a)
     for (int n = 0; n < a.N; ++n) {
         TRACE(0)
         const bool more = n + 1 < a.N;
+        save_step = n;
         const int rbase = (n / CF::ROWCH) * CF::ROWCH;
         if (n > 0 && n == rbase) {       // next chunk (every wave is past the previous step's closing barrier)
             fill_rows(rbase);
@@ -469,7 +484,7 @@ __global__ void __launch_bounds__(CF::NT, CF::WPS) snsde_mfma_kernel(MfmaArgs a)
             sum_acc();
             TRACE(2)
 #pragma unroll
-            for (int t = 0; t < TPW; ++t) store_frag(bufA, LDA, (wave * TPW + t) * 16, acc[t], true);
+            for (int t = 0; t < TPW; ++t) store_frag(bufA, LDA, (wave * TPW + t) * 16, acc[t], true, 0);
             ++layer;
             TRACE(3)
             __syncthreads();
@@ -488,7 +503,7 @@ __global__ void __launch_bounds__(CF::NT, CF::WPS) snsde_mfma_kernel(MfmaArgs a)
             gemm<FL, KUY, TPW>(wy, yrow, acc, acc2);
             sum_acc();
 #pragma unroll
-            for (int t = 0; t < TPW; ++t) store_frag(cat, LDC, (wave * TPW + t) * 16, acc[t], !CF::EMB);
+            for (int t = 0; t < TPW; ++t) store_frag(cat, LDC, (wave * TPW + t) * 16, acc[t], !CF::EMB, CF::EMB ? -1 : 0);
             ++layer;
             __syncthreads();
             cur = crow;
@@ -497,7 +512,7 @@ __global__ void __launch_bounds__(CF::NT, CF::WPS) snsde_mfma_kernel(MfmaArgs a)
                 gemm<FL, KUE, TPW>(we, crow, acc, acc2);
                 sum_acc();
 #pragma unroll
-                for (int t = 0; t < TPW; ++t) store_frag(bufA, LDA, (wave * TPW + t) * 16, acc[t], true);
+                for (int t = 0; t < TPW; ++t) store_frag(bufA, LDA, (wave * TPW + t) * 16, acc[t], true, 0);
                 ++layer;
                 __syncthreads();
                 cur = arow;
@@ -512,7 +527,7 @@ __global__ void __launch_bounds__(CF::NT, CF::WPS) snsde_mfma_kernel(MfmaArgs a)
             sum_acc();
             TRACE(5)
 #pragma unroll
-            for (int t = 0; t < TPW; ++t) store_frag(toB ? bufB : bufA, LDA, (wave * TPW + t) * 16, acc[t], true);
+            for (int t = 0; t < TPW; ++t) store_frag(toB ? bufB : bufA, LDA, (wave * TPW + t) * 16, acc[t], true, 1 + l);
             ++layer;
             __syncthreads();
             TRACE(6)
@@ -531,11 +546,12 @@ __global__ void __launch_bounds__(CF::NT, CF::WPS) snsde_mfma_kernel(MfmaArgs a)
 #pragma unroll
                 for (int i = 0; i < 4; ++i) zv[i] = row_ror_add(zv[i]);
             }
-            float ynew[EPT], yold[EPT];
+            float ynew[EPT], yold[EPT], zsave[EPT];
 #pragma unroll
             for (int e = 0; e < EPT; ++e) {
                 float z = zv[FL ? 0 : e];
                 if constexpr (FL) { z = s1 ? zv[1] : z; z = s2 ? zv[2] : z; z = s3 ? zv[3] : z; }
+                zsave[e] = z;
                 const float y = yv[t][e];
                 if constexpr (CF::GEO) z *= fast_tanh(y);
                 const float f = fast_tanh(z);
@@ -551,6 +567,11 @@ __global__ void __launch_bounds__(CF::NT, CF::WPS) snsde_mfma_kernel(MfmaArgs a)
                 yold[e] = y; ynew[e] = yn; yv[t][e] = yn;
             }
             const size_t goff = (size_t)row * H + fcol[t];
+            if (a.act_save && row_ok) {
+                float* zp = a.act_save + (((size_t)n * CF::NSAVE + CF::NSAVE - 1) * B) * H + goff;
+                if constexpr (FL) zp[0] = zsave[0];
+                else *reinterpret_cast<f32x4*>(zp) = f32x4{zsave[0], zsave[1], zsave[2], zsave[3]};
+            }
             if constexpr (FL) {
                 ybuf[r * LDY + fcol[t]] = ynew[0];
                 if (row_ok) {
@@ -606,6 +627,187 @@ int launch_cfg(const MfmaArgs& a, hipStream_t stream) {
     }
     const int grid = (a.B + CF::M - 1) / CF::M;
     hipLaunchKernelGGL(snsde_mfma_kernel<CF>, dim3(grid), dim3(CF::NT), lds_bytes, stream, a);
+    return hipGetLastError() == hipSuccess ? SNSDE_OK : SNSDE_ERR_LAUNCH;
+}
+
+// =====================================================================================================
+// Backward: adjoint recursion of the Euler scheme over the saved trajectory (include/snsde.h, snsde_backward).
+// Same skeleton as the forward kernel (persistent row tiles, one 16-feature tile per wave, register-stationary
+// weights, transposed f32 MFMA chain), run on the TRANSPOSED matrices:
+//     dzout -> out^T -> [z_hid > 0] -> hid^T .. -> [z0 > 0] -> first_y^T -> dy
+// where first_y = (emb o linear_in)[:, y columns] (or linear_in[:, y columns] without emb).  relu masks and the
+// pre-tanh drift come from the forward's act_save; f, g and their derivatives are recomputed elementwise.
+// =====================================================================================================
+template <int H_, int NHID_, int GEO_, int FL_>
+struct CfgR {
+    static constexpr int H = H_, NHID = NHID_, FL = FL_;
+    static constexpr bool GEO = GEO_ != 0;
+    static constexpr int TPW = 1;
+    static constexpr int NW = H / 16;
+    static constexpr int NT = NW * 64;
+    static constexpr int WPS = NW >= 4 ? NW / 4 : 1;
+    static constexpr int M = FL ? 4 : 16;
+    static constexpr int KUH = H / 16;
+    static constexpr int PAD = FL ? 16 : 8;
+    static constexpr int LDA = ld_for(16 * KUH, PAD);
+    static constexpr int NG = NHID + 2;          // transposed GEMMs per step = LDS buffers
+    static constexpr int NSAVE = NHID + 2;
+    static constexpr int EPT = FL ? 1 : 4;
+    static constexpr int ROWCH = 128;
+    static constexpr int LDS_FLOATS = NG * M * LDA + (ROWCH + 1) * SNSDE_STEP_STRIDE;
+};
+
+struct RevArgs {
+    const float* params;
+    const float* ws;        // backward workspace: packed transposed weights
+    const float* gt;        // time-only diffusion table (N, H) of the forward workspace, or null
+    const float* step_tab;
+    const float* out_w;
+    const float* traj;
+    const float* act;
+    const float* dW;
+    const float* grad_ys;
+    float* adj;
+    int32_t B, N, T, no, off_theta;
+    int32_t w_off[MAXL];
+};
+
+template <class CF>
+__global__ void __launch_bounds__(CF::NT, CF::WPS) snsde_mfma_reverse_kernel(RevArgs a) {
+    constexpr int H = CF::H, TPW = 1, FL = CF::FL, M = CF::M, NT = CF::NT, NHID = CF::NHID, NG = CF::NG;
+    constexpr int KUH = CF::KUH, EPT = CF::EPT, LDA = CF::LDA, NSAVE = CF::NSAVE;
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    float* rowtab = lds + NG * M * LDA;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int r = FL ? (lane & 3) : (lane & 15);
+    const int s = FL ? ((lane >> 2) & 3) : (lane >> 4);
+    const int fsub = FL ? 4 * (lane >> 4) : 4 * s;
+    const int row0 = blockIdx.x * M, B = a.B;
+    const int row = row0 + r, rowc = row < B ? row : B - 1;
+    const bool row_ok = row < B;
+    const size_t BH = (size_t)B * H;
+    const bool writer = FL ? (s == 0) : true;
+    const bool s1 = (s == 1), s2 = (s == 2), s3 = (s == 3);
+    const int fcol = wave * 16 + fsub + (FL ? s : 0);
+    const size_t goff = (size_t)rowc * H + fcol;
+
+    float wt[NG][TPW][KUH * 4];
+#pragma unroll
+    for (int g = 0; g < NG; ++g) load_weights<KUH, TPW>(wt[g], a.ws + a.w_off[g], wave, lane);
+    for (int i = tid; i < NG * M * LDA; i += NT) lds[i] = 0.0f;
+
+    const float sig_theta = snsde_sigmoid(a.params[a.off_theta]);
+    const bool mul_y = (a.no == 13 || a.no == 17);
+
+    auto fill_rows = [&](int base) {
+        for (int i = tid; i < (CF::ROWCH + 1) * SNSDE_STEP_STRIDE; i += NT) {
+            const int rr = base + i / SNSDE_STEP_STRIDE;
+            rowtab[i] = a.step_tab[(size_t)(rr < a.N ? rr : a.N - 1) * SNSDE_STEP_STRIDE + i % SNSDE_STEP_STRIDE];
+        }
+    };
+
+    // adjoint of y_N (owned elements)
+    float adj[EPT];
+#pragma unroll
+    for (int e = 0; e < EPT; ++e) adj[e] = 0.0f;
+    int rbase = -1;
+
+    for (int n = a.N - 1; n >= 0; --n) {
+        const int nb = (n / CF::ROWCH) * CF::ROWCH;
+        if (nb != rbase) {           // (re)stage the step-table chunk; previous step's readers are past its last barrier
+            __syncthreads();
+            rbase = nb;
+            fill_rows(rbase);
+            __syncthreads();
+        }
+        const float* st = rowtab + (n - rbase) * SNSDE_STEP_STRIDE;
+        const float h = st[1];
+        const int nout = __float_as_int(st[8]), kfirst = __float_as_int(st[9]);
+
+        // outputs emitted after step n: ys[k+1] = y_{n+1}  or  w0 y_n + w1 y_{n+1}
+        float carry[EPT];
+#pragma unroll
+        for (int e = 0; e < EPT; ++e) carry[e] = 0.0f;
+        for (int k = kfirst; k < kfirst + nout; ++k) {
+            const float w0 = a.out_w[2 * k], w1 = a.out_w[2 * k + 1];
+#pragma unroll
+            for (int e = 0; e < EPT; ++e) {
+                const float gk = a.grad_ys[(size_t)(k + 1) * BH + goff + e];
+                if (w0 == 0.0f) adj[e] += gk;
+                else { adj[e] = fmaf(w1, gk, adj[e]); carry[e] = fmaf(w0, gk, carry[e]); }
+            }
+        }
+        if (row_ok) {
+#pragma unroll
+            for (int e = 0; e < EPT; ++e) a.adj[(size_t)(n + 1) * BH + goff + e] = adj[e];
+        }
+        // ---- elementwise: d(f h + g dW)/d(zout, y) applied to the adjoint ----
+        float ay[EPT], dz[EPT];
+#pragma unroll
+        for (int e = 0; e < EPT; ++e) {
+            const float y = a.traj[(size_t)n * BH + goff + e];
+            const float z = a.act[(((size_t)n * NSAVE + NSAVE - 1) * B) * H + goff + e];
+            const float dw = a.dW[(size_t)n * BH + goff + e];
+            const float gq = a.gt ? a.gt[(size_t)n * H + fcol + e] : 0.0f;
+            const float av = adj[e];
+            float ty = 1.0f, zt = z;
+            if constexpr (CF::GEO) { ty = fast_tanh(y); zt = z * ty; }
+            const float f = fast_tanh(zt);
+            const float dzt = av * h * (1.0f - f * f);
+            float acc_y = av;
+            if constexpr (CF::GEO) { dz[e] = dzt * ty; acc_y = fmaf(dzt * z, 1.0f - ty * ty, acc_y); }
+            else dz[e] = dzt;
+            const float raw = mul_y ? gq * y : gq;
+            const float g = fast_tanh(sig_theta * snsde_nan_to_num(raw));
+            if (mul_y && (raw - raw == 0.0f)) acc_y = fmaf(av * dw * (1.0f - g * g) * sig_theta, gq, acc_y);
+            ay[e] = acc_y;
+        }
+        float* buf = lds;   // buffer g holds the input of transposed GEMM g
+        if constexpr (FL) buf[r * LDA + fcol] = dz[0];
+        else *reinterpret_cast<f32x4*>(buf + r * LDA + fcol) = f32x4{dz[0], dz[1], dz[2], dz[3]};
+        __syncthreads();
+        f32x4 acc[TPW], acc2[TPW];
+#pragma unroll
+        for (int g = 0; g < NG; ++g) {
+            acc[0] = acc2[0] = f32x4{0.f, 0.f, 0.f, 0.f};
+            gemm<FL, KUH, TPW>(wt[g], lds + g * M * LDA + r * LDA + 4 * s, acc, acc2);
+            f32x4 v = acc[0] + acc2[0];
+            if constexpr (FL) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) v[i] = row_ror_add(v[i]);
+            }
+            if (g < NG - 1) {
+                // relu mask of the forward activation that produced this gradient's input: slot NHID - g
+                if (writer) {
+                    const f32x4 zsv = *reinterpret_cast<const f32x4*>(
+                        a.act + (((size_t)n * NSAVE + (NHID - g)) * B + rowc) * H + wave * 16 + fsub);
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) v[i] = zsv[i] > 0.0f ? v[i] : 0.0f;
+                    *reinterpret_cast<f32x4*>(lds + (g + 1) * M * LDA + r * LDA + wave * 16 + fsub) = v;
+                }
+                __syncthreads();
+            } else {
+#pragma unroll
+                for (int e = 0; e < EPT; ++e) {
+                    float d = v[FL ? 0 : e];
+                    if constexpr (FL) { d = s1 ? v[1] : d; d = s2 ? v[2] : d; d = s3 ? v[3] : d; }
+                    adj[e] = ay[e] + d + carry[e];
+                }
+            }
+        }
+    }
+    if (row_ok) {     // ys[0] = y0
+#pragma unroll
+        for (int e = 0; e < EPT; ++e) a.adj[goff + e] = adj[e] + a.grad_ys[goff + e];
+    }
+}
+
+template <class CF>
+int launch_rev(const RevArgs& a, hipStream_t stream) {
+    const size_t lds_bytes = (size_t)CF::LDS_FLOATS * sizeof(float);
+    const int grid = (a.B + CF::M - 1) / CF::M;
+    hipLaunchKernelGGL(snsde_mfma_reverse_kernel<CF>, dim3(grid), dim3(CF::NT), lds_bytes, stream, a);
     return hipGetLastError() == hipSuccess ? SNSDE_OK : SNSDE_ERR_LAUNCH;
 }
 
@@ -750,6 +952,7 @@ int snsde_mfma_launch(const snsde_solve* s, const SnsdeNet& net, hipStream_t str
     MfmaArgs a{};
     a.params = s->params; a.ws = ws; a.coeffs = s->coeffs; a.step_tab = s->step_tab; a.out_step = s->out_step;
     a.out_w = s->out_w; a.y0 = s->y0; a.dW = s->dW; a.ys = s->ys; a.traj = s->traj; a.dW_out = s->dW_out;
+    a.act_save = s->act_save;
     a.row_offset = s->row_offset; a.seed = s->seed;
     a.B = s->batch; a.L = s->knots; a.C = s->model.input_channels; a.N = s->n_steps; a.T = s->n_out;
     a.method = s->method; a.no = s->model.noise_option;
@@ -758,5 +961,95 @@ int snsde_mfma_launch(const snsde_solve* s, const SnsdeNet& net, hipStream_t str
     if (p.H == 128) return p.FL ? dispatch_io<128, 1>(p, a, stream) : dispatch_io<128, 0>(p, a, stream);
     if (p.H == 64) return p.FL ? dispatch_io<64, 1>(p, a, stream) : dispatch_io<64, 0>(p, a, stream);
     if (p.H == 32) return p.FL ? dispatch_io<32, 1>(p, a, stream) : dispatch_io<32, 0>(p, a, stream);
+    return SNSDE_ERR_UNSUPPORTED;
+}
+
+
+// ---- backward host side ---------------------------------------------------------------------------------
+namespace {
+
+struct RevPlan {
+    bool ok;
+    int H, NHID, GEO, FL, NW, n_layers, fold_tmp, total_floats, emb;
+    MfmaLayerPack layer[MAXL];
+};
+
+RevPlan make_rev_plan(const snsde_solve* s, const SnsdeNet& net, const MfmaPlan& fp) {
+    RevPlan p{};
+    p.ok = false;
+    if (!fp.ok || s->method != SNSDE_EULER) return p;
+    const int H = fp.H, io = fp.IO;
+    p.H = H; p.NHID = fp.NHID; p.GEO = (io == 5 || io == 6) ? 1 : 0; p.FL = fp.FL; p.NW = fp.NW;
+    p.emb = (io == 2 || io == 4 || io == 6) ? 1 : 0;
+    int off = 0, n = 0;
+    auto add_t = [&](const SnsdeLayer& L, int col_off, int fold_tmp) {
+        MfmaLayerPack& q = p.layer[n++];
+        q = MfmaLayerPack{};
+        q.src_w = L.src_w; q.src_b = L.src_b; q.K = H; q.N = H; q.KU = H / 16; q.dst = off; q.tshift = 0;
+        q.transpose = 1; q.src_ld = L.K; q.col_off = col_off; q.bias_row = -1;
+        q.fold = fold_tmp >= 0 ? 1 : 0; q.fold_tmp = fold_tmp;
+        off += p.NW * (H / 16) * 256;
+    };
+    // fold temp first (so its offset is known to the pack job)
+    int fold_tmp = -1;
+    const int packed = (p.NHID + 2) * p.NW * (H / 16) * 256;
+    if (p.emb) fold_tmp = packed;
+    add_t(net.out, 0, -1);
+    for (int l = p.NHID - 1; l >= 0; --l) add_t(net.hid[l], 0, -1);
+    add_t(net.in, net.in.tshift, fold_tmp);
+    p.n_layers = n;
+    p.fold_tmp = fold_tmp;
+    p.total_floats = packed + (p.emb ? H * net.in.K + H : 0) + 16;
+    p.ok = true;
+    return p;
+}
+
+template <int H, int FL>
+int dispatch_rev(const RevPlan& p, const RevArgs& a, hipStream_t st) {
+    if (p.NHID == 1) return p.GEO ? launch_rev<CfgR<H, 1, 1, FL>>(a, st) : launch_rev<CfgR<H, 1, 0, FL>>(a, st);
+    if (p.NHID == 0) return p.GEO ? launch_rev<CfgR<H, 0, 1, FL>>(a, st) : launch_rev<CfgR<H, 0, 0, FL>>(a, st);
+    return SNSDE_ERR_UNSUPPORTED;
+}
+
+}  // namespace
+
+bool snsde_mfma_backward_supported(const snsde_solve* s, const SnsdeNet& net) {
+    return make_rev_plan(s, net, make_plan(s, net, -1)).ok;
+}
+
+size_t snsde_mfma_backward_workspace_floats(const snsde_solve* s, const SnsdeNet& net) {
+    RevPlan p = make_rev_plan(s, net, make_plan(s, net, -1));
+    return p.ok ? (size_t)p.total_floats : 0;
+}
+
+int snsde_mfma_backward_launch(const snsde_backward* b, const SnsdeNet& net, hipStream_t stream) {
+    const snsde_solve* s = &b->fwd;
+    const int hint = s->kernel == SNSDE_KERNEL_MFMA_M16 ? 0 : (s->kernel == SNSDE_KERNEL_MFMA_M4 ? 1 : -1);
+    MfmaPlan fp = make_plan(s, net, hint);
+    RevPlan p = make_rev_plan(s, net, fp);
+    if (!p.ok) return SNSDE_ERR_UNSUPPORTED;
+    float* ws = static_cast<float*>(b->workspace);
+    if (p.emb) {   // first_y = emb[:, 0:H] . linear_in  (all columns; the pack step picks the y columns)
+        FoldJob fj{};
+        fj.emb_w = net.emb.src_w; fj.H = p.H; fj.n_pieces = 1;
+        fj.src_w[0] = net.in.src_w; fj.K[0] = net.in.K; fj.col[0] = 0; fj.tmp[0] = p.fold_tmp;
+        fj.b_in = net.in.src_b; fj.b_init = net.init.src_b; fj.b_emb = net.emb.src_b;
+        fj.bias_tmp = p.fold_tmp + p.H * net.in.K;
+        hipLaunchKernelGGL(snsde_fold_kernel, dim3(p.H, 1), dim3(256), 2 * p.H * sizeof(float), stream, s->params, ws, fj);
+    }
+    MfmaPackJob job{};
+    for (int i = 0; i < p.n_layers; ++i) job.layer[i] = p.layer[i];
+    job.n_layers = p.n_layers; job.flavor = p.FL; job.TPW = 1; job.NW = p.NW; job.bias_off = 0; job.H = p.H;
+    hipLaunchKernelGGL(snsde_mfma_pack_kernel, dim3(16, p.n_layers), dim3(256), 0, stream, s->params, ws, job);
+    RevArgs a{};
+    a.params = s->params; a.ws = ws;
+    a.gt = fp.gt_off >= 0 ? static_cast<const float*>(s->workspace) + fp.gt_off : nullptr;
+    a.step_tab = s->step_tab; a.out_w = s->out_w; a.traj = s->traj; a.act = s->act_save; a.dW = s->dW_out;
+    a.grad_ys = b->grad_ys; a.adj = b->adj;
+    a.B = s->batch; a.N = s->n_steps; a.T = s->n_out; a.no = s->model.noise_option; a.off_theta = net.off_theta;
+    for (int i = 0; i < p.n_layers; ++i) a.w_off[i] = p.layer[i].dst;
+    if (p.H == 128) return p.FL ? dispatch_rev<128, 1>(p, a, stream) : dispatch_rev<128, 0>(p, a, stream);
+    if (p.H == 64) return p.FL ? dispatch_rev<64, 1>(p, a, stream) : dispatch_rev<64, 0>(p, a, stream);
+    if (p.H == 32) return p.FL ? dispatch_rev<32, 1>(p, a, stream) : dispatch_rev<32, 0>(p, a, stream);
     return SNSDE_ERR_UNSUPPORTED;
 }

@@ -121,7 +121,7 @@ class SolveCall:
     launch itself is one C call that only enqueues kernels (hipGraph-capturable)."""
 
     def __init__(self, model, flat_params, coeffs, grid, y0, dW=None, method='euler', seed=0, row_offset=0,
-                 kernel='auto', save_traj=False, save_dW=False, exact_order=False):
+                 kernel='auto', save_traj=False, save_dW=False, exact_order=False, save_act=False):
         B, H = y0.shape
         C_ = model.input_channels
         L = coeffs.shape[1] + 1
@@ -136,6 +136,11 @@ class SolveCall:
         self.ys = torch.empty((grid.T, B, H), device=dev, dtype=torch.float32)
         self.traj = torch.empty((grid.N + 1, B, H), device=dev, dtype=torch.float32) if save_traj else None
         self.dW_out = torch.empty((grid.N, B, H), device=dev, dtype=torch.float32) if save_dW else None
+        self.act_save = None
+        if save_act:
+            slots = _lib.lib().snsde_act_slots(C.byref(model))
+            _lib.check(min(slots, 0), 'snsde_act_slots')
+            self.act_save = torch.empty((grid.N, slots, B, H), device=dev, dtype=torch.float32)
         s = _lib.Solve()
         s.model = model
         s.batch, s.knots, s.n_steps, s.n_out = B, L, grid.N, grid.T
@@ -149,6 +154,7 @@ class SolveCall:
         s.step_tab, s.out_step, s.out_w = _ptr(grid.d_step_tab), _ptr(grid.d_out_step), _ptr(grid.d_out_w)
         s.y0, s.dW, s.ys = _ptr(y0), _ptr(dW), _ptr(self.ys)
         s.traj, s.dW_out = _ptr(self.traj), _ptr(self.dW_out)
+        s.act_save = _ptr(self.act_save)
         nbytes = _lib.lib().snsde_workspace_bytes(C.byref(s))
         self.workspace = torch.empty(max(nbytes, 256), device=dev, dtype=torch.uint8)
         s.workspace = _ptr(self.workspace)
@@ -163,6 +169,30 @@ class SolveCall:
         _lib.check(_lib.lib().snsde_solve_forward(C.byref(self.desc), C.c_void_p(stream.cuda_stream)),
                    'snsde_solve_forward')
         return self.ys
+
+
+def backward_supported(call):
+    return bool(_lib.lib().snsde_backward_supported(C.byref(call.desc)))
+
+
+def solve_backward(call, grad_ys, stream=None):
+    """Adjoint recursion over a finished training-mode solve (SolveCall with save_traj/save_dW/save_act):
+    returns adj (N+1, B, H), adj[n] = dL/dy_n; adj[0] is the gradient w.r.t. y0."""
+    if call.traj is None or call.dW_out is None or call.act_save is None:
+        raise ValueError('backward needs a solve run with save_traj, save_dW and save_act')
+    _check_f32('grad_ys', grad_ys, tuple(call.ys.shape))
+    b = _lib.Backward()
+    b.fwd = call.desc
+    b.fwd.flags = call.base_flags
+    adj = torch.empty_like(call.traj)
+    b.grad_ys, b.adj = _ptr(grad_ys), _ptr(adj)
+    nbytes = _lib.lib().snsde_backward_workspace_bytes(C.byref(b))
+    ws = torch.empty(max(nbytes, 256), device=adj.device, dtype=torch.uint8)
+    b.workspace, b.workspace_bytes = _ptr(ws), ws.numel()
+    stream = torch.cuda.current_stream(adj.device) if stream is None else stream
+    _lib.check(_lib.lib().snsde_solve_backward(C.byref(b), C.c_void_p(stream.cuda_stream)), 'snsde_solve_backward')
+    call.keep_bwd = (ws, grad_ys)
+    return adj
 
 
 def eval_fg(model, flat_params, coeffs, times_host, t, y, kernel='auto'):

@@ -44,6 +44,66 @@ def prepare_sde_solver_kwargs(times, kwargs, *, default_method, respect_euler_gr
 _prepare_sde_solver_kwargs = prepare_sde_solver_kwargs
 
 
+def _lin(P, name, x):
+    return torch.nn.functional.linear(x, P[name + '.weight'], P[name + '.bias'])
+
+
+def drift_rows(P, io, tau, y, Xraw):
+    """Drift f of Diffusion_model for rows with their own time features `tau` (rows, 2) and control value
+    `Xraw` (rows, C): the reference's f (neuralsde.py:295-302) written over a name->tensor dict so it serves the
+    module, foreign modules honouring the same parameter names, and the batched parameter-gradient pass."""
+    Xt = _lin(P, 'initial_network', Xraw) if io in (0,) + _CONTROL_EMB else None
+    if io == 0:
+        z = Xt
+    else:
+        z = _lin(P, 'linear_in', torch.cat([tau, y], dim=-1) if io in _TIME_IN else y)
+        if io in _CONTROL_EMB:
+            z = _lin(P, 'emb', torch.cat([z, Xt], dim=-1))
+    z = z.relu()
+    i = 0
+    while f'linears.{i}.weight' in P:
+        z = _lin(P, f'linears.{i}', z).relu()
+        i += 1
+    z = _lin(P, 'linear_out', z)
+    if io in _GEOMETRIC:
+        z = z * y.tanh()
+    return z.tanh()
+
+
+def raw_diffusion_rows(P, no, col, tau, y):
+    """Un-clipped diffusion (neuralsde.py:233-288) for rows with time column `col` (rows,1) / features `tau`."""
+    if no == 0:
+        return torch.zeros_like(y)
+    if no <= 6:
+        scale = (P['sigma'] if no <= 3 else P['sigma_diag']).exp().expand_as(y)
+        kind = (no - 1) % 3
+        return scale if kind == 0 else (scale * col if kind == 1 else scale * y)
+    if no == 7:
+        return y.sqrt()
+    if no == 8:
+        return y ** 3
+    if no == 9:
+        return y.sigmoid()
+    if no == 10:
+        return y.relu()
+    if no == 11:
+        return col * y
+    time_only = no in (12, 13, 16, 17)
+    x = tau if time_only else torch.cat([tau, y], dim=-1)
+    name = 'noise_t' if time_only else 'noise_y'
+    if name + '.0.weight' in P:
+        out = _lin(P, name + '.2', _lin(P, name + '.0', x).relu())
+    else:
+        out = _lin(P, name, x)
+    if no >= 16:
+        out = out.relu()
+    return out * y if no % 2 == 1 else out
+
+
+def diffusion_rows(P, no, col, tau, y):
+    return (P['theta'].sigmoid() * torch.nan_to_num(raw_diffusion_rows(P, no, col, tau, y))).tanh()
+
+
 class Diffusion_model(nn.Module):
     def __init__(self, input_channels, hidden_channels, hidden_hidden_channels, num_hidden_layers, theta=1.0,
                  sigma=1.0, input_option=0, noise_option=0):
@@ -106,45 +166,12 @@ class Diffusion_model(nn.Module):
 
     def _drift(self, t, y):
         io = self.input_option
-        Xt = self.initial_network(self.X.evaluate(t)) if io in (0,) + _CONTROL_EMB else None
-        if io == 0:
-            z = Xt
-        else:
-            inp = torch.cat([self._tau(t, y)[1], y], dim=-1) if io in _TIME_IN else y
-            z = self.linear_in(inp)
-            if io in _CONTROL_EMB:
-                z = self.emb(torch.cat([z, Xt], dim=-1))
-        z = z.relu()
-        for layer in self.linears:
-            z = layer(z).relu()
-        z = self.linear_out(z)
-        if io in _GEOMETRIC:
-            z = z * y.tanh()
-        return z.tanh()
+        Xraw = self.X.evaluate(t) if io in (0,) + _CONTROL_EMB else None
+        return drift_rows(dict(self.named_parameters()), io, self._tau(t, y)[1], y, Xraw)
 
     def _raw_diffusion(self, t, y):
-        no = self.noise_option
         col, tau = self._tau(t, y)
-        if no == 0:
-            return torch.zeros_like(y)
-        if no <= 6:
-            scale = (self.sigma if no <= 3 else self.sigma_diag).exp().expand_as(y)
-            return scale * (1, col, y)[(no - 1) % 3] if (no - 1) % 3 else scale
-        if no == 7:
-            return y.sqrt()
-        if no == 8:
-            return y ** 3
-        if no == 9:
-            return y.sigmoid()
-        if no == 10:
-            return y.relu()
-        if no == 11:
-            return col * y
-        net_in = tau if no in (12, 13, 16, 17) else torch.cat([tau, y], dim=-1)
-        out = (self.noise_t if no in (12, 13, 16, 17) else self.noise_y)(net_in)
-        if no >= 16:
-            out = out.relu()
-        return out * y if no % 2 == 1 else out
+        return raw_diffusion_rows(dict(self.named_parameters()), self.noise_option, col, tau, y)
 
     def f(self, t, y):
         if self._fused_ok(y):

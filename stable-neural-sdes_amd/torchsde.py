@@ -98,11 +98,7 @@ def sdeint(sde, y0, ts, bm=None, method=None, dt=1e-3, adaptive=False, rtol=1e-5
 
 def _sdeint_hip(sde, rec, y0, ts, bm, method, dt, options):
     model, layout, numel = rec
-    if torch.is_grad_enabled() and (y0.requires_grad or any(p.requires_grad for p in sde.parameters())):
-        raise NotImplementedError(
-            "backward through the fused HIP solve is not implemented in this round: call under "
-            "torch.no_grad(), or pass options={'backend': 'torch'} to differentiate through the unfused "
-            "tensor-op loop")
+    needs_grad = torch.is_grad_enabled() and (y0.requires_grad or any(p.requires_grad for p in sde.parameters()))
     dev = y0.device
     coeffs = sde.coeffs
     if coeffs.dim() != 3 or coeffs.shape[0] != y0.shape[0]:
@@ -120,13 +116,97 @@ def _sdeint_hip(sde, rec, y0, ts, bm, method, dt, options):
         dW = torch.stack([bm(t0[n], t1[n]).to(device=dev, dtype=torch.float32) for n in range(grid.N)]).contiguous()
     seed = options.get('seed')
     seed = _fresh_seed() if seed is None else int(seed)
+    if needs_grad:
+        return _FusedEulerSolve.apply(sde, rec, coeffs, grid, times_host, dW, method, seed, options, y0,
+                                      *[p for _, p in sde.named_parameters()])
     call = engine.SolveCall(model, flat, coeffs, grid, y0c, dW=dW, method=method, seed=seed,
                             row_offset=int(options.get('row_offset', 0)), kernel=options.get('kernel', 'auto'),
-                            save_traj=bool(options.get('save_traj', False)))
+                            save_traj=bool(options.get('save_traj', False)),
+                            exact_order=bool(options.get('exact_order', False)))
     ys = call.launch()
     if options.get('save_traj', False):
         sde.last_trajectory = call.traj
     return ys.to(y0.dtype)
+
+
+class _FusedEulerSolve(torch.autograd.Function):
+    """Differentiable fused solve.  forward = the HIP solve in training mode (keeps every state, the increments
+    used and the per-step activations); backward = the HIP adjoint recursion (snsde_solve_backward) for dL/dy0
+    and every adjoint a_n, then ONE batched evaluation of a_{n+1} . (f h + g dW) over all (step, row) pairs
+    whose autograd (plain library GEMMs) yields the parameter gradients.  This replaces autograd through the
+    ~25 x N nodes of the unrolled loop (benchmark_classification/common_sde.py:158-160)."""
+
+    @staticmethod
+    def forward(ctx, sde, rec, coeffs, grid, times_host, dW, method, seed, options, y0, *params):
+        model, layout, numel = rec
+        if method != 'euler':
+            raise NotImplementedError("gradients through the fused solve are implemented for method='euler' only")
+        flat = engine.flatten_params(sde, layout, numel, y0.device)
+        call = engine.SolveCall(model, flat, coeffs, grid, y0.detach().to(torch.float32).contiguous(), dW=dW,
+                                method=method, seed=seed, row_offset=int(options.get('row_offset', 0)),
+                                kernel=options.get('kernel', 'auto'), save_traj=True, save_dW=True, save_act=True,
+                                exact_order=bool(options.get('exact_order', False)))
+        if not engine.backward_supported(call):
+            raise NotImplementedError(
+                "backward of the fused solve covers the MFMA fast-path configurations (H in {32,64,128}, "
+                "input_option 1..6, noise_option in {0,12,13,16,17}, at most one hidden layer, C <= 32); pass "
+                "options={'backend': 'torch'} to differentiate other configurations through the tensor-op loop")
+        ys = call.launch()
+        ctx.call, ctx.sde, ctx.grid, ctx.times_host = call, sde, grid, times_host
+        ctx.names = [n for n, _ in sde.named_parameters()]
+        ctx.y0_dtype = y0.dtype
+        return ys.to(y0.dtype)
+
+    @staticmethod
+    def backward(ctx, grad_ys):
+        call, sde, grid = ctx.call, ctx.sde, ctx.grid
+        adj = engine.solve_backward(call, grad_ys.to(torch.float32).contiguous())
+        grads = _parameter_gradients(sde, call, grid, adj)
+        return (None,) * 9 + (adj[0].to(ctx.y0_dtype),) + tuple(grads)
+
+
+def _parameter_gradients(sde, call, grid, adj, max_rows=1 << 19):
+    """sum over steps n and rows of  a_{n+1} . d(f(t_n, y_n) h_n + g(t_n, y_n) dW_n)/d theta  with y_n, a_{n+1}, dW_n
+    constants: one batched forward of the vector field over (step, row) pairs + autograd (library GEMMs)."""
+    from . import modules
+    params = list(sde.parameters())
+    P = dict(sde.named_parameters())
+    io, no = sde.input_option, sde.noise_option
+    N, B, H = call.dW_out.shape
+    dev = adj.device
+    t0 = torch.from_numpy(grid.step_tab[:, 0].copy()).to(dev)
+    hh = torch.from_numpy(grid.step_tab[:, 1].copy()).to(dev)
+    idx = torch.from_numpy(grid.step_tab[:, 5].copy().view('int32').astype('int64')).to(dev)
+    frac = torch.from_numpy(grid.step_tab[:, 4].copy()).to(dev)
+    coeffs = call.keep[1]
+    Cn = coeffs.shape[-1] // 4
+    uses_x = io in (0, 2, 4, 6)
+    total = [torch.zeros_like(p) for p in params]
+    steps_per_chunk = max(1, max_rows // B)
+    with torch.enable_grad():
+        for lo in range(0, N, steps_per_chunk):
+            hi = min(N, lo + steps_per_chunk)
+            n = hi - lo
+            Y = call.traj[lo:hi].reshape(n * B, H)
+            A = adj[lo + 1:hi + 1].reshape(n * B, H)
+            DW = call.dW_out[lo:hi].reshape(n * B, H)
+            col = t0[lo:hi].repeat_interleave(B).unsqueeze(-1)
+            hcol = hh[lo:hi].repeat_interleave(B).unsqueeze(-1)
+            tau = torch.cat([col.sin(), col.cos()], dim=-1)
+            Xraw = None
+            if uses_x:
+                rows = coeffs[:, idx[lo:hi], :].permute(1, 0, 2)                      # (n, B, 4C)
+                fr = frac[lo:hi].view(n, 1, 1)
+                a_, b_, c2, d3 = (rows[..., k * Cn:(k + 1) * Cn] for k in range(4))
+                Xraw = (a_ + (b_ + (0.5 * c2 + d3 * fr / 3) * fr) * fr).reshape(n * B, Cn)
+            f = modules.drift_rows(P, io, tau, Y, Xraw)
+            g = modules.diffusion_rows(P, no, col, tau, Y)
+            surrogate = (A * (f * hcol + g * DW)).sum()
+            gs = torch.autograd.grad(surrogate, params, allow_unused=True)
+            for acc, gpart in zip(total, gs):
+                if gpart is not None:
+                    acc.add_(gpart)
+    return total
 
 
 def _call(sde, names, key, default):

@@ -455,3 +455,101 @@ def test_k5_milstein_h256_forecast_shaped():
     cpu32, _ = oracle_solve(pr, ts, dt, dW, 'milstein', np.float32)
     assert ys.shape == (50, B, H)
     print('K5', assert_parity(ys, ref64, cpu32, what='K5'))
+
+
+# ---- backward (adjoint) of the fused solve --------------------------------------------------------------
+BWD_CASES = [
+    # io, no, NL, B, H, C, L, ts, dt
+    (4, 17, 2, 21, 32, 5, 9, [0, 8], 1.0),
+    (4, 17, 2, 37, 128, 21, 13, [0, 5, 12], 1.0),
+    (6, 17, 2, 18, 64, 7, 9, [0, 3, 8], 1.0),
+    (2, 16, 1, 9, 32, 2, 12, None, 0.05),          # interpolated outputs at every knot
+    (1, 0, 2, 11, 64, 3, 8, [0, 2.5, 7], 1.0),
+    (3, 13, 2, 11, 32, 3, 8, [0, 7], 0.5),
+    (5, 12, 1, 8, 128, 3, 8, [0, 7], 1.0),
+]
+
+
+@pytest.mark.parametrize('kernel', ['mfma4', 'mfma16'])
+@pytest.mark.parametrize('ci', range(len(BWD_CASES)))
+def test_backward_matches_fp64_autograd_through_the_unrolled_loop(ci, kernel):
+    """dL/dy0 and dL/dtheta from the HIP adjoint + batched parameter pass vs float64 autograd through the unfused
+    tensor-op loop (the reference's way of differentiating, common_sde.py:158-160) on identical increments."""
+    io, no, NL, B, H, C, L, ts, dt = BWD_CASES[ci]
+    times = np.linspace(0, 1, L).astype(np.float32) if ts is None else None
+    pr = make_problem(500 + ci, io, no, NL, B, H, C, L, times=times)
+    ts = pr['times'] if ts is None else np.asarray(ts, np.float32)
+    dW = draw_dW(500 + ci, ts, dt, B, H)
+    wsum = np.random.default_rng(ci).standard_normal((len(ts), B, H)).astype(np.float32)
+
+    def build(dtype, device):
+        m = S.Diffusion_model(C, H, H, NL, input_option=io, noise_option=no)
+        m.load_state_dict({k: torch.from_numpy(v.copy()) for k, v in pr['params'].items()})
+        m = m.to(device=device, dtype=dtype)
+        m.set_X(torch.from_numpy(pr['coeffs']).to(device=device, dtype=dtype), torch.from_numpy(pr['times']).to(device))
+        y0 = torch.from_numpy(pr['y0']).to(device=device, dtype=dtype).requires_grad_(True)
+        return m, y0
+
+    m_ref, y0_ref = build(torch.float64, 'cpu')
+    ys_ref = S.sdeint(m_ref, y0_ref, torch.from_numpy(ts), bm=_ReplayBM(torch.from_numpy(dW).double()), method='euler',
+                      dt=dt, options={'backend': 'torch'})
+    (ys_ref * torch.from_numpy(wsum).double()).sum().backward()
+
+    m, y0 = build(torch.float32, DEV)
+    ys = S.sdeint(m, y0, torch.from_numpy(ts).to(DEV), bm=_ReplayBM(torch.from_numpy(dW).to(DEV)), method='euler', dt=dt,
+                  options={'kernel': kernel})
+    (ys * torch.from_numpy(wsum).to(DEV)).sum().backward()
+
+    def close(got, ref, name):
+        ref = ref.numpy()
+        scale = np.abs(ref).max() + 1e-12
+        err = np.abs(got.cpu().numpy().astype(np.float64) - ref).max() / scale
+        assert err < 2e-3, (name, err, scale)
+
+    close(y0.grad, y0_ref.grad, 'y0')
+    ref_grads = dict(m_ref.named_parameters())
+    for name, p in m.named_parameters():
+        gref = ref_grads[name].grad
+        if gref is None or float(gref.abs().max()) == 0.0:
+            assert p.grad is None or float(p.grad.abs().max()) < 1e-6, name
+            continue
+        close(p.grad, gref, name)
+
+
+def test_backward_unsupported_configurations_raise():
+    pr = make_problem(9, 1, 18, 2, 8, 64, 3, 5)
+    m = S.Diffusion_model(3, 64, 64, 2, input_option=1, noise_option=18).to(DEV)
+    m.set_X(torch.from_numpy(pr['coeffs']).to(DEV), torch.from_numpy(pr['times']).to(DEV))
+    y0 = torch.from_numpy(pr['y0']).to(DEV).requires_grad_(True)
+    with pytest.raises(NotImplementedError):
+        S.sdeint(m, y0, torch.tensor([0., 4.], device=DEV), method='euler', dt=1.0)
+    m2 = S.Diffusion_model(3, 64, 64, 2, input_option=4, noise_option=17).to(DEV)
+    m2.set_X(torch.from_numpy(pr['coeffs']).to(DEV), torch.from_numpy(pr['times']).to(DEV))
+    with pytest.raises(NotImplementedError):
+        S.sdeint(m2, y0, torch.tensor([0., 4.], device=DEV), method='milstein', dt=1.0)
+
+
+def test_neuralsde_training_step_on_cuda():
+    """One optimizer step of the reference's training recipe (Adam, BCE-with-logits) through the fused path."""
+    pr = make_problem(23, 4, 17, 2, 64, 32, 5, 9)
+    torch.manual_seed(1)
+    model, field = S.make_sde_model('neurallnsde', 5, 1, 32, 32, 2, initial=True)
+    model = model.to(DEV).train()
+    opt = torch.optim.Adam(model.parameters(), lr=1e-3)
+    times = torch.from_numpy(pr['times']).to(DEV)
+    coeffs = torch.from_numpy(pr['coeffs']).to(DEV)
+    fi = torch.randint(0, 9, (64,), device=DEV)
+    target = (torch.rand(64, device=DEV) > 0.5).float()
+    before = {k: v.detach().clone() for k, v in model.state_dict().items() if v.dtype.is_floating_point}
+    losses = []
+    for _ in range(3):
+        pred = model(times, [coeffs], fi, options={'seed': 11}).squeeze(-1)
+        loss = torch.nn.functional.binary_cross_entropy_with_logits(pred, target)
+        opt.zero_grad()
+        loss.backward()
+        opt.step()
+        losses.append(float(loss))
+    assert all(np.isfinite(losses))
+    moved = [k for k, v in model.state_dict().items() if k in before and not torch.equal(v, before[k])]
+    assert any(k.startswith('func.linear_in') for k in moved) and any(k.startswith('func.noise_t') for k in moved)
+    assert any(k.startswith('initial_network') for k in moved)
