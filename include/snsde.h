@@ -154,6 +154,9 @@ typedef struct snsde_backward {
     snsde_solve  fwd;        /* the forward descriptor (traj, dW_out, act_save filled by the forward)      */
     const float* grad_ys;    /* device (T, B, H): dL/d ys                                                 */
     float*       adj;        /* device (N+1, B, H) out: adjoint of every solver state                     */
+    float*       delta_save; /* optional device (N, snsde_act_slots, B, H) out: per step, slot 0 = dL/d zout and */
+                             /* slot g = dL/d(pre-activation of hidden layer slots-1-g): the left factors of    */
+                             /* the weight-gradient GEMMs  dW_layer = sum delta^T . layer_input                  */
     void*        workspace;  /* device scratch >= snsde_backward_workspace_bytes (separate from fwd's)    */
     size_t       workspace_bytes;
 } snsde_backward;

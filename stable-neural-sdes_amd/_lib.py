@@ -35,7 +35,8 @@ class Solve(C.Structure):
 
 
 class Backward(C.Structure):
-    _fields_ = [('fwd', Solve), ('grad_ys', C.c_void_p), ('adj', C.c_void_p), ('workspace', C.c_void_p),
+    _fields_ = [('fwd', Solve), ('grad_ys', C.c_void_p), ('adj', C.c_void_p), ('delta_save', C.c_void_p),
+                ('workspace', C.c_void_p),
                 ('workspace_bytes', C.c_size_t)]
 
 

@@ -668,6 +668,7 @@ struct RevArgs {
     const float* dW;
     const float* grad_ys;
     float* adj;
+    float* delta;      // (N, NG, B, H) or null
     int32_t B, N, T, no, off_theta;
     int32_t w_off[MAXL];
 };
@@ -766,6 +767,11 @@ __global__ void __launch_bounds__(CF::NT, CF::WPS) snsde_mfma_reverse_kernel(Rev
         float* buf = lds;   // buffer g holds the input of transposed GEMM g
         if constexpr (FL) buf[r * LDA + fcol] = dz[0];
         else *reinterpret_cast<f32x4*>(buf + r * LDA + fcol) = f32x4{dz[0], dz[1], dz[2], dz[3]};
+        if (a.delta && row_ok) {
+            float* dp = a.delta + ((size_t)n * NG * B) * H + goff;
+            if constexpr (FL) dp[0] = dz[0];
+            else *reinterpret_cast<f32x4*>(dp) = f32x4{dz[0], dz[1], dz[2], dz[3]};
+        }
         __syncthreads();
         f32x4 acc[TPW], acc2[TPW];
 #pragma unroll
@@ -785,6 +791,8 @@ __global__ void __launch_bounds__(CF::NT, CF::WPS) snsde_mfma_reverse_kernel(Rev
 #pragma unroll
                     for (int i = 0; i < 4; ++i) v[i] = zsv[i] > 0.0f ? v[i] : 0.0f;
                     *reinterpret_cast<f32x4*>(lds + (g + 1) * M * LDA + r * LDA + wave * 16 + fsub) = v;
+                    if (a.delta && row_ok)
+                        *reinterpret_cast<f32x4*>(a.delta + (((size_t)n * NG + g + 1) * B + row) * H + wave * 16 + fsub) = v;
                 }
                 __syncthreads();
             } else {
@@ -1045,7 +1053,7 @@ int snsde_mfma_backward_launch(const snsde_backward* b, const SnsdeNet& net, hip
     a.params = s->params; a.ws = ws;
     a.gt = fp.gt_off >= 0 ? static_cast<const float*>(s->workspace) + fp.gt_off : nullptr;
     a.step_tab = s->step_tab; a.out_w = s->out_w; a.traj = s->traj; a.act = s->act_save; a.dW = s->dW_out;
-    a.grad_ys = b->grad_ys; a.adj = b->adj;
+    a.grad_ys = b->grad_ys; a.adj = b->adj; a.delta = b->delta_save;
     a.B = s->batch; a.N = s->n_steps; a.T = s->n_out; a.no = s->model.noise_option; a.off_theta = net.off_theta;
     for (int i = 0; i < p.n_layers; ++i) a.w_off[i] = p.layer[i].dst;
     if (p.H == 128) return p.FL ? dispatch_rev<128, 1>(p, a, stream) : dispatch_rev<128, 0>(p, a, stream);

@@ -175,7 +175,7 @@ def backward_supported(call):
     return bool(_lib.lib().snsde_backward_supported(C.byref(call.desc)))
 
 
-def solve_backward(call, grad_ys, stream=None):
+def solve_backward(call, grad_ys, stream=None, save_delta=False):
     """Adjoint recursion over a finished training-mode solve (SolveCall with save_traj/save_dW/save_act):
     returns adj (N+1, B, H), adj[n] = dL/dy_n; adj[0] is the gradient w.r.t. y0."""
     if call.traj is None or call.dW_out is None or call.act_save is None:
@@ -185,14 +185,15 @@ def solve_backward(call, grad_ys, stream=None):
     b.fwd = call.desc
     b.fwd.flags = call.base_flags
     adj = torch.empty_like(call.traj)
-    b.grad_ys, b.adj = _ptr(grad_ys), _ptr(adj)
+    delta = torch.empty_like(call.act_save) if save_delta else None
+    b.grad_ys, b.adj, b.delta_save = _ptr(grad_ys), _ptr(adj), _ptr(delta)
     nbytes = _lib.lib().snsde_backward_workspace_bytes(C.byref(b))
     ws = torch.empty(max(nbytes, 256), device=adj.device, dtype=torch.uint8)
     b.workspace, b.workspace_bytes = _ptr(ws), ws.numel()
     stream = torch.cuda.current_stream(adj.device) if stream is None else stream
     _lib.check(_lib.lib().snsde_solve_backward(C.byref(b), C.c_void_p(stream.cuda_stream)), 'snsde_solve_backward')
     call.keep_bwd = (ws, grad_ys)
-    return adj
+    return (adj, delta) if save_delta else adj
 
 
 def eval_fg(model, flat_params, coeffs, times_host, t, y, kernel='auto'):

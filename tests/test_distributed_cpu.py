@@ -81,3 +81,73 @@ def test_shard_rows_partition():
         assert max(sizes) - min(sizes) <= 1
     with pytest.raises(ValueError):
         S.sharding.shard_rows(8, 2, 2)
+
+
+def _ddp_worker(rank, world, port, out_q):
+    sys.path.insert(0, ROOT)
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        import stable_neural_sdes_amd as S
+        from tests.helpers import make_problem
+        from tests.test_host_cpu import _ReplayBM
+        B = 8
+        pr = make_problem(91, 4, 17, 2, B, 8, 3, 7)
+        torch.manual_seed(5)
+        model, field = S.make_sde_model('neurallnsde', 3, 1, 8, 8, 2, initial=True)
+        model.linear[1] = torch.nn.Identity()          # BatchNorm keeps per-rank statistics under DP; drop it here
+        model.eval()                                     # (no dropout) so both runs are deterministic
+        ddp = torch.nn.parallel.DistributedDataParallel(model)
+        lo, hi = S.sharding.shard_rows(B, world, rank)
+        times = torch.from_numpy(pr['times'])
+        coeffs = torch.from_numpy(pr['coeffs'][lo:hi])
+        fi = torch.tensor([6, 3, 3, 5, 1, 6, 2, 4])[lo:hi]
+        from oracle import sde_oracle as O
+        t0, t1, *_ = O.step_grid(np.array([0, 1, 2, 3, 4, 5, 6], np.float32), 1.0)
+        dW = torch.from_numpy(O.philox_dW(7, lo, hi - lo, 8, t0, t1))   # global-row stream for this shard
+        pred = ddp(times, [coeffs], fi, bm=_ReplayBM(dW))
+        target = torch.arange(B, dtype=torch.float32)[lo:hi].unsqueeze(-1) / B
+        loss = ((pred - target) ** 2).sum() / B * world      # DDP averages gradients over ranks
+        loss.backward()
+        g = torch.cat([p.grad.reshape(-1) for p in model.parameters()])
+        if rank == 0:
+            out_q.put(g.numpy())
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()
+
+
+def test_ddp_gradient_allreduce_equals_full_batch_gradient():
+    """Batch-DP training step: rows sharded over two ranks, gradients all-reduced by DDP (gloo here, RCCL on GPUs);
+    the averaged gradient equals the single-process full-batch gradient."""
+    sys.path.insert(0, ROOT)
+    import stable_neural_sdes_amd as S
+    from oracle import sde_oracle as O
+    from tests.helpers import make_problem
+    from tests.test_host_cpu import _ReplayBM
+    world = 2
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_ddp_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    g_ddp = q.get(timeout=240)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    B = 8
+    pr = make_problem(91, 4, 17, 2, B, 8, 3, 7)
+    torch.manual_seed(5)
+    model, field = S.make_sde_model('neurallnsde', 3, 1, 8, 8, 2, initial=True)
+    model.linear[1] = torch.nn.Identity()
+    model.eval()
+    t0, t1, *_ = O.step_grid(np.array([0, 1, 2, 3, 4, 5, 6], np.float32), 1.0)
+    dW = torch.from_numpy(O.philox_dW(7, 0, B, 8, t0, t1))
+    pred = model(torch.from_numpy(pr['times']), [torch.from_numpy(pr['coeffs'])], torch.tensor([6, 3, 3, 5, 1, 6, 2, 4]),
+                 bm=_ReplayBM(dW))
+    target = torch.arange(B, dtype=torch.float32).unsqueeze(-1) / B
+    (((pred - target) ** 2).sum() / B).backward()
+    g_full = torch.cat([p.grad.reshape(-1) for p in model.parameters()]).numpy()
+    np.testing.assert_allclose(g_ddp, g_full, rtol=1e-4, atol=1e-6)
