@@ -245,9 +245,11 @@ def test_sdeint_drop_in_on_cuda_dispatches_to_hip():
                       options={'dt': 1.0}, bm=_ReplayBM(torch.from_numpy(dW).to(DEV)))
     ref64, _ = oracle_solve(pr, [0, 3, 8], 1.0, dW, 'euler', np.float64)
     assert_parity(ys.cpu().numpy(), ref64, what='sdeint')
-    # grads requested -> loud error, never a silent unfused fallback
-    with pytest.raises(NotImplementedError):
-        S.sdeint(sde=m, y0=torch.from_numpy(pr['y0']).to(DEV), ts=ts, dt=1.0, method='euler')
+    # with grads enabled the same call goes through the differentiable fused solve (HIP forward + HIP adjoint)
+    ys_g = S.sdeint(sde=m, y0=torch.from_numpy(pr['y0']).to(DEV), ts=ts, dt=1.0, method='euler',
+                    bm=_ReplayBM(torch.from_numpy(dW).to(DEV)))
+    assert ys_g.requires_grad and ys_g.grad_fn is not None
+    np.testing.assert_allclose(ys_g.detach().cpu().numpy(), ys.cpu().numpy(), rtol=1e-6, atol=1e-6)
     # vector-field probes go through the HIP kernel too
     with torch.no_grad():
         f = m.f(torch.tensor(2.0), torch.from_numpy(pr['y0']).to(DEV)).cpu().numpy()
