@@ -405,6 +405,7 @@ __global__ void __launch_bounds__(CF::NT, CF::WPS) snsde_mfma_kernel(MfmaArgs a)
     };
     fill_rows(0);
     __syncthreads();
+    if (__builtin_amdgcn_readfirstlane(tid) >= NT / 2 && CF::NW >= 8) __builtin_amdgcn_s_setprio(1);   // younger half
 
     TRACE_DECL
     for (int n = 0; n < a.N; ++n) {
@@ -423,47 +424,58 @@ __global__ void __launch_bounds__(CF::NT, CF::WPS) snsde_mfma_kernel(MfmaArgs a)
         if constexpr (CF::EMB) { if (more) load_coeffs(n_idx); }   // prefetch next interval's cubic pieces
         const float h = cur_row.h, sqh = cur_row.sqh;
 
-        // Brownian increments for the owned elements: one Philox call per (row, 4-step block, column) gives the
-        // element's normals for 4 consecutive steps (snsde_philox_normal4), regenerated every 4th step
-        static_assert(TPW == 1, "one 16-feature tile per wave");
+        // y-independent work of the step (Brownian increments, diffusion table row, next step's X(t) and time
+        // features) is done by the two waves of a SIMD at DIFFERENT points of the layer chain (older waves before
+        // the hidden GEMM, younger waves after it), so one wave's VALU work runs under the other's MFMAs.
         float dw[TPW][EPT];
-        if constexpr (CF::PHX) {
-            // ZB independent Philox calls (ZB blocks of 4 steps) are generated together (their round chains interleave)
-            // and parked in this wave's private LDS stash [4*ZB steps][64 lanes][EPT]; each step reads back one entry.
-            constexpr int ZB = CF::ZB;
-            const int k = n % (4 * ZB);
-            if (k == 0) {
-                float zq[EPT][4 * ZB];
-#pragma unroll
-                for (int e = 0; e < EPT; ++e)
-#pragma unroll
-                    for (int bb = 0; bb < ZB; ++bb)
-                        snsde_philox_normal4(a.seed, grow, (uint32_t)((n >> 2) + bb), (uint32_t)(fcol[0] + e), &zq[e][4 * bb]);
-#pragma unroll
-                for (int i = 0; i < 4 * ZB; ++i) {
-                    if constexpr (FL) zstash[i * 64 + lane] = zq[0][i];
-                    else *reinterpret_cast<f32x4*>(zstash + (i * 64 + lane) * 4) = f32x4{zq[0][i], zq[1][i], zq[2][i], zq[3][i]};
+        float gtv[TPW][EPT];
+        auto prep = [&]() {
+            // Brownian increments for the owned elements: one Philox call per (row, 4-step block, column) gives the
+            // element's normals for 4 consecutive steps (snsde_philox_normal4), regenerated every 4th step
+            static_assert(TPW == 1, "one 16-feature tile per wave");
+            if constexpr (CF::PHX) {
+                // ZB independent Philox calls (ZB blocks of 4 steps) are generated together (their round chains interleave)
+                // and parked in this wave's private LDS stash [4*ZB steps][64 lanes][EPT]; each step reads back one entry.
+                constexpr int ZB = CF::ZB;
+                const int k = n % (4 * ZB);
+                if (k == 0) {
+                    float zq[EPT][4 * ZB];
+    #pragma unroll
+                    for (int e = 0; e < EPT; ++e)
+    #pragma unroll
+                        for (int bb = 0; bb < ZB; ++bb)
+                            snsde_philox_normal4(a.seed, grow, (uint32_t)((n >> 2) + bb), (uint32_t)(fcol[0] + e), &zq[e][4 * bb]);
+    #pragma unroll
+                    for (int i = 0; i < 4 * ZB; ++i) {
+                        if constexpr (FL) zstash[i * 64 + lane] = zq[0][i];
+                        else *reinterpret_cast<f32x4*>(zstash + (i * 64 + lane) * 4) = f32x4{zq[0][i], zq[1][i], zq[2][i], zq[3][i]};
+                    }
+                }
+                if constexpr (FL) dw[0][0] = zstash[k * 64 + lane] * sqh;
+                else {
+                    const f32x4 v = *reinterpret_cast<const f32x4*>(zstash + (k * 64 + lane) * 4);
+                    dw[0][0] = v[0] * sqh; dw[0][1] = v[1] * sqh; dw[0][2] = v[2] * sqh; dw[0][3] = v[3] * sqh;
+                }
+            } else {
+                if constexpr (FL) dw[0][0] = a.dW[(size_t)n * BH + (size_t)rowc * H + fcol[0]];
+                else {
+                    const f32x4 v = *reinterpret_cast<const f32x4*>(a.dW + (size_t)n * BH + (size_t)rowc * H + fcol[0]);
+                    dw[0][0] = v[0]; dw[0][1] = v[1]; dw[0][2] = v[2]; dw[0][3] = v[3];
                 }
             }
-            if constexpr (FL) dw[0][0] = zstash[k * 64 + lane] * sqh;
-            else {
-                const f32x4 v = *reinterpret_cast<const f32x4*>(zstash + (k * 64 + lane) * 4);
-                dw[0][0] = v[0] * sqh; dw[0][1] = v[1] * sqh; dw[0][2] = v[2] * sqh; dw[0][3] = v[3] * sqh;
-            }
-        } else {
-            if constexpr (FL) dw[0][0] = a.dW[(size_t)n * BH + (size_t)rowc * H + fcol[0]];
-            else {
-                const f32x4 v = *reinterpret_cast<const f32x4*>(a.dW + (size_t)n * BH + (size_t)rowc * H + fcol[0]);
-                dw[0][0] = v[0]; dw[0][1] = v[1]; dw[0][2] = v[2]; dw[0][3] = v[3];
-            }
-        }
-        // time-only diffusion table row (noise_option 12/13/16/17)
-        float gtv[TPW][EPT];
-#pragma unroll
-        for (int t = 0; t < TPW; ++t)
-#pragma unroll
-            for (int e = 0; e < EPT; ++e) gtv[t][e] = (a.gt_off >= 0) ? gt[(size_t)n * H + fcol[t] + e] : 0.0f;
+            // time-only diffusion table row (noise_option 12/13/16/17)
+    #pragma unroll
+            for (int t = 0; t < TPW; ++t)
+    #pragma unroll
+                for (int e = 0; e < EPT; ++e) gtv[t][e] = (a.gt_off >= 0) ? gt[(size_t)n * H + fcol[t] + e] : 0.0f;
 
+
+            if (more) {
+                if constexpr (CF::EMB) store_x(n_frac);
+                if (CF::TIME && tid < M) { ybuf[tid * LDY + H] = n_sin; ybuf[tid * LDY + H + 1] = n_cos; }
+            }
+        };
+        const bool early = wave < (CF::NW + 1) / 2;
         TRACE(1)
         f32x4 acc[TPW], acc2[TPW];
         int layer = 0;
@@ -518,6 +530,7 @@ __global__ void __launch_bounds__(CF::NT, CF::WPS) snsde_mfma_kernel(MfmaArgs a)
                 cur = arow;
             }
         }
+        if (early) prep();
 #pragma unroll
         for (int l = 0; l < NHID; ++l) {
             // ping-pong: (emb|fold) -> A -> B -> A ... ; no-emb: cat -> A -> B ...
@@ -533,6 +546,7 @@ __global__ void __launch_bounds__(CF::NT, CF::WPS) snsde_mfma_kernel(MfmaArgs a)
             TRACE(6)
             cur = toB ? brow : arow;
         }
+        if (!early) prep();
         init_acc(layer);
         gemm<FL, KUH, TPW>(wo, cur, acc, acc2);
         sum_acc();
@@ -598,11 +612,6 @@ __global__ void __launch_bounds__(CF::NT, CF::WPS) snsde_mfma_kernel(MfmaArgs a)
                     }
                 }
             }
-        }
-        // inputs of the next step
-        if (more) {
-            if constexpr (CF::EMB) store_x(n_frac);
-            if (CF::TIME && tid < M) { ybuf[tid * LDY + H] = n_sin; ybuf[tid * LDY + H + 1] = n_cos; }
         }
         TRACE(8)
         __syncthreads();
