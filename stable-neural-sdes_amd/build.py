@@ -25,20 +25,42 @@ def needs_build():
     return any(os.path.getmtime(s) > t for s in srcs)
 
 
-def build(force=False, verbose=False):
-    if not force and not needs_build():
-        return OUT
+def build(force=False, verbose=False, defines=(), out=None):
+    """Compile every csrc/*.hip to an object file (in parallel: the MFMA kernels are split by hidden size) and
+    link libsnsde.so."""
+    from concurrent.futures import ThreadPoolExecutor
+    out = out or OUT
+    if not force and out == OUT and not needs_build():
+        return out
     srcs = sorted(glob.glob(os.path.join(CSRC, '*.hip')))
-    cmd = [hipcc(), '--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-shared', '-I', INCLUDE, '-I', CSRC,
-           '-o', OUT + '.tmp'] + srcs
-    if verbose:
-        print(' '.join(cmd))
+    objdir = os.path.join(HERE, 'build_' + ('_'.join(d.strip('-D') for d in defines) or 'obj'))
+    os.makedirs(objdir, exist_ok=True)
+    cc = hipcc()
+    base = [cc, '--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-I', INCLUDE, '-I', CSRC] + list(defines)
+
+    def compile_one(src):
+        obj = os.path.join(objdir, os.path.basename(src)[:-4] + '.o')
+        cmd = base + ['-c', src, '-o', obj]
+        if verbose:
+            print(' '.join(cmd))
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError('hipcc failed for ' + src + ':\n' + r.stdout + r.stderr)
+        return obj
+
+    with ThreadPoolExecutor(max_workers=min(8, len(srcs))) as ex:
+        objs = list(ex.map(compile_one, srcs))
+    cmd = [cc, '--offload-arch=gfx950', '-shared', '-fPIC', '-o', out + '.tmp'] + objs
     r = subprocess.run(cmd, capture_output=True, text=True)
     if r.returncode != 0:
-        raise RuntimeError('hipcc failed:\n' + r.stdout + r.stderr)
-    os.replace(OUT + '.tmp', OUT)
-    return OUT
+        raise RuntimeError('link failed:\n' + r.stdout + r.stderr)
+    os.replace(out + '.tmp', out)
+    return out
 
 
 if __name__ == '__main__':
-    print(build(force=True, verbose=True))
+    import sys
+    if len(sys.argv) > 1 and sys.argv[1] == 'trace':
+        print(build(force=True, defines=('-DSNSDE_TRACE',), out=os.path.join(HERE, 'libsnsde_trace.so')))
+    else:
+        print(build(force=True, verbose=True))

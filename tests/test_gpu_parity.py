@@ -314,6 +314,16 @@ MFMA_CASES = [
     (5, 16, 1, 11, 128, 3, 8, [0, 7], 0.5, 'euler'),
     (1, 13, 2, 11, 128, 3, 8, [0, 7], 0.5, 'milstein'),
     (3, 0, 1, 40, 64, 3, 8, [0, 7], 1.0, 'euler'),
+    (4, 17, 3, 13, 128, 21, 9, [0, 8], 1.0, 'euler'),          # NL = 3, 4: more hidden `linears`
+    (6, 17, 4, 13, 128, 5, 9, [0, 3.5, 8], 1.0, 'euler'),
+    (2, 16, 4, 9, 64, 3, 9, [0, 8], 1.0, 'milstein'),
+    (4, 17, 2, 21, 16, 3, 9, [0, 8], 1.0, 'euler'),            # H = 16
+    (1, 0, 3, 7, 16, 3, 9, [0, 8], 0.5, 'euler'),
+    (1, 18, 2, 19, 64, 3, 8, [0, 7], 1.0, 'euler'),            # naivesde: diffusion net on [t, y]
+    (3, 18, 2, 23, 64, 69, 8, [0, 3, 7], 1.0, 'euler'),        # K4 model (C = 69 is unused by input_option 3)
+    (3, 19, 1, 9, 128, 3, 8, [0, 7], 0.5, 'euler'),
+    (1, 14, 2, 9, 32, 3, 8, [0, 7], 1.0, 'euler'),
+    (3, 15, 3, 9, 16, 3, 8, [0, 7], 1.0, 'euler'),
 ]
 
 
@@ -336,7 +346,7 @@ def test_mfma_trajectory_vs_oracle(ci, kernel):
 
 
 def test_mfma_unsupported_configuration_is_refused_not_silently_rerouted():
-    pr = make_problem(1, 1, 18, 2, 8, 64, 3, 5)
+    pr = make_problem(1, 2, 18, 2, 8, 64, 3, 5)      # diffusion net together with a control embedding: generic only
     with pytest.raises(S._lib.SnsdeError) as e:
         hip_solve(pr, [0, 4], 1.0, dW=draw_dW(1, [0, 4], 1.0, 8, 64), kernel='mfma')
     assert e.value.code == -4
@@ -439,11 +449,12 @@ def test_k4_sepsis_shaped_nsde_full_size():
     ts = np.concatenate([times[:1], times[uniq], times[-1:]])
     dt = 1.0
     dW = draw_dW(4004, ts, dt, B, H)
-    ys, _ = hip_solve(pr, ts, dt, dW=dW)
     ref64, _ = oracle_solve(pr, ts, dt, dW, 'euler', np.float64)
     cpu32, _ = oracle_solve(pr, ts, dt, dW, 'euler', np.float32)
-    assert ys.shape[0] == len(ts)
-    print('K4', assert_parity(ys, ref64, cpu32, what='K4'))
+    for kernel in ('mfma4', 'mfma16', 'generic'):
+        ys, _ = hip_solve(pr, ts, dt, dW=dW, kernel=kernel)
+        assert ys.shape[0] == len(ts)
+        print('K4', kernel, assert_parity(ys, ref64, cpu32, what='K4 ' + kernel))
 
 
 def test_k5_milstein_h256_forecast_shaped():
@@ -469,6 +480,8 @@ BWD_CASES = [
     (1, 0, 2, 11, 64, 3, 8, [0, 2.5, 7], 1.0),
     (3, 13, 2, 11, 32, 3, 8, [0, 7], 0.5),
     (5, 12, 1, 8, 128, 3, 8, [0, 7], 1.0),
+    (4, 17, 4, 9, 64, 5, 9, [0, 8], 1.0),
+    (6, 17, 3, 9, 16, 3, 9, [0, 8], 1.0),
 ]
 
 
@@ -519,7 +532,7 @@ def test_backward_matches_fp64_autograd_through_the_unrolled_loop(ci, kernel):
 
 
 def test_backward_unsupported_configurations_raise():
-    pr = make_problem(9, 1, 18, 2, 8, 64, 3, 5)
+    pr = make_problem(9, 1, 18, 2, 8, 64, 3, 5)       # diffusion nets have no fused backward yet
     m = S.Diffusion_model(3, 64, 64, 2, input_option=1, noise_option=18).to(DEV)
     m.set_X(torch.from_numpy(pr['coeffs']).to(DEV), torch.from_numpy(pr['times']).to(DEV))
     y0 = torch.from_numpy(pr['y0']).to(DEV).requires_grad_(True)
