@@ -45,7 +45,7 @@ enum {
     SNSDE_ERR_INDEX = -9         /* index out of range                                          */
 };
 
-enum { SNSDE_EULER = 0, SNSDE_MILSTEIN = 1 };
+enum { SNSDE_EULER = 0, SNSDE_MILSTEIN = 1, SNSDE_SRK = 2 /* SRID2, strong order 1.5, diagonal noise */ };
 
 /* kernel selection (for tests / benchmarking); 0 lets the library choose */
 enum {
@@ -105,6 +105,11 @@ int     snsde_param_info(const snsde_model* m, int index, char* name, int name_c
 int snsde_grid_count(const float* ts, int32_t n_out, double dt, int32_t* n_steps);
 int snsde_grid_build(const float* ts, int32_t n_out, double dt, const float* times, int32_t knots,
                      int32_t n_steps, float* step_tab, int32_t* out_step, float* out_w);
+/* Stage times of the SRK scheme: per solver step the four evaluation times t0 + c*h, c = 0, 1/4, 1/2, 1
+ * (float32 arithmetic as torchsde's `t0 + c * dt`), each as SNSDE_SRK_STRIDE floats:
+ * t, sin t, cos t, frac, idx (int32 bits), 0, 0, 0.   srk_tab is (n_steps, 4, SNSDE_SRK_STRIDE). */
+#define SNSDE_SRK_STRIDE 8
+int snsde_grid_srk_build(const float* step_tab, int32_t n_steps, const float* times, int32_t knots, float* srk_tab);
 
 /* ---- the solve --------------------------------------------------------------------------------
  * Replaces torchsde.sdeint(sde=Diffusion_model, y0, ts, dt, method) (neuralsde.py:78-82):
@@ -133,6 +138,10 @@ typedef struct snsde_solve {
     float*         ys;        /* device (T, B, H) out; ys[0] = y0                                */
     float*         traj;      /* optional device (N+1, B, H): every solver state                 */
     float*         dW_out;    /* optional device (N, B, H): the increments actually used         */
+    const float*   srk_tab;   /* device (N, 4, SNSDE_SRK_STRIDE), method SNSDE_SRK only              */
+    const float*   dU;        /* device (N, B, H) supplied space-time Levy integrals I_k0 (SRK with   */
+                              /* supplied dW), or NULL: h*(dW/2 + sqrt(h/12) xi), xi from Philox      */
+    float*         dU_out;    /* optional device (N, B, H): the I_k0 actually used                    */
     float*         act_save;  /* optional device (N, snsde_act_slots, B, H): per-step activations */
                               /* the backward pass needs (MFMA path only, see snsde_solve_backward)*/
     void*          workspace; /* device scratch, >= snsde_workspace_bytes()                      */

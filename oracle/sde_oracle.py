@@ -460,7 +460,44 @@ def step_grid(ts, dt):
             np.array(w0, f32), np.array(w1, f32))
 
 
-def integrate(f, g, y0, ts, dt, dW, method='euler', gdg=None):
+# SRID2 tableau (Roessler 2010, strong order 1.5 for diagonal noise) as used by torchsde 0.2.5 `method='srk'`
+# (restated from the published scheme; torchsde's source is not in the reference tree: parity unpinned, guarded by
+# the strong-order test in tests/test_oracle_analytic.py).
+SRK_C0 = (0.0, 1.0, 0.5, 0.0)
+SRK_C1 = (0.0, 0.25, 1.0, 0.25)
+SRK_A0 = ((), (1.0,), (0.25, 0.25), (0.0, 0.0, 0.0))
+SRK_A1 = ((), (0.25,), (1.0, 0.0), (0.0, 0.0, 0.25))
+SRK_B0 = ((), (0.0,), (1.0, 0.5), (0.0, 0.0, 0.0))
+SRK_B1 = ((), (0.5,), (-1.0, 0.0), (-5.0, 3.0, 0.5))
+SRK_ALPHA = (1 / 6, 1 / 6, 2 / 3, 0.0)
+SRK_BETA1 = (-1.0, 4 / 3, 2 / 3, 0.0)
+SRK_BETA2 = (-1.0, 4 / 3, -1 / 3, 0.0)
+SRK_BETA3 = (2.0, -4 / 3, -2 / 3, 0.0)
+SRK_BETA4 = (-2.0, 5 / 3, -2 / 3, 1.0)
+
+
+def srk_step(f, g, t0, h, y, I_k, I_k0):
+    """One SRID2 step.  I_k = W(t1) - W(t0);  I_k0 = int_{t0}^{t1} (W(s) - W(t0)) ds (space-time Levy integral)."""
+    dt = y.dtype.type
+    rdt = np.sqrt(h)
+    I_kk = (I_k * I_k - h) / dt(2)
+    I_kkk = (I_k * I_k * I_k - dt(3) * h * I_k) / dt(6)
+    fs, gs = [], []
+    y1 = y
+    for s in range(4):
+        H0, H1 = y, y
+        for j in range(s):
+            H0 = H0 + dt(SRK_A0[s][j]) * fs[j] * h + dt(SRK_B0[s][j]) * gs[j] * I_k0 / h
+            H1 = H1 + dt(SRK_A1[s][j]) * fs[j] * h + dt(SRK_B1[s][j]) * gs[j] * rdt
+        fs.append(f(t0 + dt(SRK_C0[s]) * h, H0))
+        gs.append(g(t0 + dt(SRK_C1[s]) * h, H1))
+        gw = (dt(SRK_BETA1[s]) * I_k + dt(SRK_BETA2[s]) * I_kk / rdt + dt(SRK_BETA3[s]) * I_k0 / h
+              + dt(SRK_BETA4[s]) * I_kkk / h)
+        y1 = y1 + dt(SRK_ALPHA[s]) * fs[s] * h + gw * gs[s]
+    return y1
+
+
+def integrate(f, g, y0, ts, dt, dW, method='euler', gdg=None, dU=None):
     """Fixed-step Ito integration with supplied increments.
 
     f(t, y), g(t, y) -> (B, H);  dW (N, B, H) = bm(t0_n, t1_n) for the steps of ``step_grid``.
@@ -487,6 +524,8 @@ def integrate(f, g, y0, ts, dt, dW, method='euler', gdg=None):
         elif method == 'milstein':
             gv, dg = gdg(t, y)
             y = y + f(t, y) * h + gv * I + dtype.type(0.5) * (gv * dg) * (I * I - h)
+        elif method == 'srk':
+            y = srk_step(f, g, t, h, y, I, dU[n].astype(dtype))
         else:
             raise ValueError(method)
         traj.append(y.copy())
@@ -497,7 +536,7 @@ def integrate(f, g, y0, ts, dt, dW, method='euler', gdg=None):
     return np.stack(ys, 0), np.stack(traj, 0)
 
 
-def solve_diffusion_model(p, io, no, coeffs, times, y0, ts, dt, dW, method='euler', dtype=np.float64):
+def solve_diffusion_model(p, io, no, coeffs, times, y0, ts, dt, dW, method='euler', dtype=np.float64, dU=None):
     """Whole hot path for a ``Diffusion_model`` parameter dict: spline -> f/g -> integrate."""
     p = cast_params(p, dtype)
     coeffs = np.asarray(coeffs, dtype=dtype)
@@ -514,7 +553,7 @@ def solve_diffusion_model(p, io, no, coeffs, times, y0, ts, dt, dW, method='eule
     def gdg(t, y):
         return diffusion_g_dgdy(p, no, t, y)
 
-    return integrate(f, g, y0, ts, dt, np.asarray(dW), method=method, gdg=gdg)
+    return integrate(f, g, y0, ts, dt, np.asarray(dW), method=method, gdg=gdg, dU=None if dU is None else np.asarray(dU))
 
 
 # --------------------------------------------------------------------------------------
@@ -545,19 +584,19 @@ def philox4x32_10(c0, c1, c2, c3, k0, k1):
     return c0, c1, c2, c3
 
 
-def philox_normals(seed, rows, step, H):
+def philox_normals(seed, rows, step, H, stream=0):
     """Standard normals Z[row, col] for global row indices ``rows`` at solver step ``step``.
 
     One Philox call per (row, block of 4 steps, column): counter = (row, step >> 2, col, 0),
     key = (seed & 0xffffffff, seed >> 32); the four 32-bit outputs x0..x3 are that element's normals for
-    steps 4b..4b+3 by two Box-Muller pairs:
+    steps 4b..4b+3 by two Box-Muller pairs (`stream` = 4th counter word: 0 for dW, 1 for the SRK Levy-area normal):
         u = ((x >> 9) + 0.5) * 2^-23  (exact in fp32);  r = sqrt(-2 ln u_a);
         (z0, z1) = r(x0) (cos, sin)(2 pi u(x1)),  (z2, z3) = r(x2) (cos, sin)(2 pi u(x3));  Z = z[step & 3]
     Computed in float64 and rounded to float32 (the kernel's fp32 result agrees to a few ulp).
     """
     rows = np.asarray(rows, dtype=np.uint32)[:, None]
     cols = np.arange(H, dtype=np.uint32)[None, :]
-    x0, x1, x2, x3 = philox4x32_10(rows, np.uint32(step >> 2), cols, np.uint32(0),
+    x0, x1, x2, x3 = philox4x32_10(rows, np.uint32(step >> 2), cols, np.uint32(stream),
                                    seed & 0xFFFFFFFF, (seed >> 32) & 0xFFFFFFFF)
 
     def u(x):
@@ -578,4 +617,15 @@ def philox_dW(seed, row_offset, B, H, t0s, t1s):
     for n in range(t0s.shape[0]):
         h = np.float32(t1s[n]) - np.float32(t0s[n])
         out[n] = philox_normals(seed, rows, n, H) * np.sqrt(h, dtype=np.float32)
+    return out
+
+
+def philox_dU(seed, row_offset, B, H, t0s, t1s, dW):
+    """Space-time Levy integrals I_k0 = h (dW/2 + Hs), Hs = sqrt(h/12) * xi with xi from Philox stream 1."""
+    rows = np.arange(row_offset, row_offset + B)
+    out = np.empty_like(dW)
+    for n in range(t0s.shape[0]):
+        h = np.float32(t1s[n]) - np.float32(t0s[n])
+        xi = philox_normals(seed, rows, n, H, stream=1)
+        out[n] = h * (np.float32(0.5) * dW[n] + np.sqrt(h / np.float32(12), dtype=np.float32) * xi)
     return out

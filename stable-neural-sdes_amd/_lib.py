@@ -10,7 +10,8 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get('SNSDE_LIB', os.path.join(_HERE, 'libsnsde.so'))   # SNSDE_LIB: debug/trace builds
 
 SNSDE_STEP_STRIDE = 12
-EULER, MILSTEIN = 0, 1
+EULER, MILSTEIN, SRK = 0, 1, 2
+SNSDE_SRK_STRIDE = 8
 KERNEL_AUTO, KERNEL_GENERIC, KERNEL_MFMA = 0, 1, 2
 FLAG_REUSE_PREPARED = 1
 FLAG_EXACT_ORDER = 2
@@ -30,7 +31,8 @@ class Solve(C.Structure):
                 ('row_offset', C.c_int64), ('seed', C.c_uint64),
                 ('params', C.c_void_p), ('coeffs', C.c_void_p), ('step_tab', C.c_void_p),
                 ('out_step', C.c_void_p), ('out_w', C.c_void_p), ('y0', C.c_void_p), ('dW', C.c_void_p),
-                ('ys', C.c_void_p), ('traj', C.c_void_p), ('dW_out', C.c_void_p), ('act_save', C.c_void_p),
+                ('ys', C.c_void_p), ('traj', C.c_void_p), ('dW_out', C.c_void_p), ('srk_tab', C.c_void_p), ('dU', C.c_void_p),
+                ('dU_out', C.c_void_p), ('act_save', C.c_void_p),
                 ('workspace', C.c_void_p), ('workspace_bytes', C.c_size_t)]
 
 
@@ -50,7 +52,7 @@ class SnsdeError(RuntimeError):
 _lib = None
 
 EXPORTS = ('snsde_version', 'snsde_strerror', 'snsde_param_count', 'snsde_param_numel', 'snsde_param_info',
-           'snsde_grid_count', 'snsde_grid_build', 'snsde_workspace_bytes', 'snsde_solve_forward',
+           'snsde_grid_count', 'snsde_grid_build', 'snsde_grid_srk_build', 'snsde_workspace_bytes', 'snsde_solve_forward',
            'snsde_spline_evaluate', 'snsde_eval_fg', 'snsde_act_slots', 'snsde_backward_supported',
            'snsde_backward_workspace_bytes', 'snsde_solve_backward')
 
@@ -76,6 +78,7 @@ def lib():
     L.snsde_grid_count.argtypes = [C.c_void_p, C.c_int32, C.c_double, C.POINTER(C.c_int32)]
     L.snsde_grid_build.argtypes = [C.c_void_p, C.c_int32, C.c_double, C.c_void_p, C.c_int32, C.c_int32,
                                    C.c_void_p, C.c_void_p, C.c_void_p]
+    L.snsde_grid_srk_build.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_void_p]
     L.snsde_workspace_bytes.argtypes = [C.POINTER(Solve)]
     L.snsde_workspace_bytes.restype = C.c_size_t
     L.snsde_solve_forward.argtypes = [C.POINTER(Solve), C.c_void_p]

@@ -270,6 +270,30 @@ int snsde_grid_build(const float* ts, int32_t n_out, double dt, const float* tim
     return n == n_steps ? SNSDE_OK : SNSDE_ERR_DIMS;
 }
 
+int snsde_grid_srk_build(const float* step_tab, int32_t n_steps, const float* times, int32_t knots, float* srk_tab) {
+    if (!step_tab || !times || !srk_tab) return SNSDE_ERR_NULL;
+    if (n_steps <= 0 || knots < 2) return SNSDE_ERR_DIMS;
+    const float cs[4] = {0.0f, 0.25f, 0.5f, 1.0f};
+    for (int n = 0; n < n_steps; ++n) {
+        const float t0 = step_tab[(size_t)n * SNSDE_STEP_STRIDE], h = step_tab[(size_t)n * SNSDE_STEP_STRIDE + 1];
+        for (int c = 0; c < 4; ++c) {
+            volatile float ch = cs[c] * h;
+            volatile float t = t0 + ch;
+            float* r = srk_tab + ((size_t)n * 4 + c) * SNSDE_SRK_STRIDE;
+            int cnt = 0;
+            for (int j = 0; j < knots; ++j) cnt += (t > times[j]) ? 1 : 0;
+            int idx = cnt - 1;
+            if (idx < 0) idx = 0;
+            if (idx > knots - 2) idx = knots - 2;
+            volatile float fr = t - times[idx];
+            r[0] = t; r[1] = sinf(t); r[2] = cosf(t); r[3] = fr;
+            memcpy(&r[4], &idx, sizeof(float));
+            r[5] = r[6] = r[7] = 0.0f;
+        }
+    }
+    return SNSDE_OK;
+}
+
 static int validate_solve(const snsde_solve* s, bool eval) {
     if (!s) return SNSDE_ERR_NULL;
     int rc = validate_model(&s->model);
@@ -279,7 +303,9 @@ static int validate_solve(const snsde_solve* s, bool eval) {
     if (!eval) {
         if (s->n_steps <= 0 || s->n_out < 2) return SNSDE_ERR_DIMS;
         if (!s->step_tab || !s->out_step || !s->out_w || !s->y0 || !s->ys) return SNSDE_ERR_NULL;
-        if (s->method != SNSDE_EULER && s->method != SNSDE_MILSTEIN) return SNSDE_ERR_OPTION;
+        if (s->method != SNSDE_EULER && s->method != SNSDE_MILSTEIN && s->method != SNSDE_SRK) return SNSDE_ERR_OPTION;
+        if (s->method == SNSDE_SRK && !s->srk_tab) return SNSDE_ERR_NULL;
+        if (s->method == SNSDE_SRK && s->dW && !s->dU) return SNSDE_ERR_NULL;   // supplied dW needs its Levy integral
         const int no = s->model.noise_option;
         // Milstein needs dg_i/dy_i in closed form: g_i may depend on y only through y_i
         if (s->method == SNSDE_MILSTEIN && (no == 7 || no == 14 || no == 15 || no == 18 || no == 19))
@@ -309,6 +335,10 @@ int snsde_solve_forward(const snsde_solve* s, void* hip_stream) {
     rc = snsde_build_net(s->model, s->n_steps, &net);
     if (rc) return rc;
     hipStream_t st = static_cast<hipStream_t>(hip_stream);
+    if (s->method == SNSDE_SRK) {   // SRK runs on the generic (all-options) kernel family
+        if (s->kernel != SNSDE_KERNEL_AUTO && s->kernel != SNSDE_KERNEL_GENERIC) return SNSDE_ERR_UNSUPPORTED;
+        return snsde_srk_launch(s, net, st);
+    }
     switch (s->kernel) {
         case SNSDE_KERNEL_AUTO:
             if (snsde_mfma_supported(s, net)) return snsde_mfma_launch(s, net, st, -1);

@@ -41,10 +41,11 @@ __global__ void snsde_pack_kernel(const float* __restrict__ params, float* __res
 // every batch row, so it is evaluated once per solver step: gt[n][j] = noise_t(tau_n)[j]
 // (relu applied for 16/17).
 __global__ void snsde_time_table_kernel(const float* __restrict__ params, const float* __restrict__ step_tab,
-                                        float* __restrict__ gt, SnsdeLayer nt0, SnsdeLayer nt1, int H, int no) {
+                                        float* __restrict__ gt, SnsdeLayer nt0, SnsdeLayer nt1, int H, int no,
+                                        int row_stride, int sin_col) {
     extern __shared__ float hbuf[];
-    const int n = blockIdx.x;
-    const float sn = step_tab[n * SNSDE_STEP_STRIDE + 2], cs = step_tab[n * SNSDE_STEP_STRIDE + 3];
+    const int n = blockIdx.x;   // one block per table row (a solver step, or an SRK stage time)
+    const float sn = step_tab[(size_t)n * row_stride + sin_col], cs = step_tab[(size_t)n * row_stride + sin_col + 1];
     const bool two = (no == 16 || no == 17);
     for (int j = threadIdx.x; j < H; j += blockDim.x) {
         const float v = fmaf(cs, params[nt0.src_w + 2 * j + 1], sn * params[nt0.src_w + 2 * j]) + params[nt0.src_b + j];
@@ -290,6 +291,242 @@ __global__ void __launch_bounds__(GT) snsde_generic_kernel(GenericArgs a) {
     }
 }
 
+// =====================================================================================================
+// SRK (SRID2, strong order 1.5 for diagonal noise; torchsde `method='srk'`, the torch_ists default
+// nsde_model.py:67): per step three drift evaluations f(t0,y), f(t0+h,H0_1), f(t0+h/2,H0_2) and four diffusion
+// evaluations g(t0,y), g(t0+h/4,H1_1), g(t0+h,H1_2), g(t0+h/4,H1_3), combined with the increments
+// I_k, I_k0 (space-time Levy integral), I_kk=(I_k^2-h)/2, I_kkk=(I_k^3-3hI_k)/6.  Tableau: oracle/sde_oracle.py.
+// Same tile structure as the generic Euler kernel; every option pair (input_option, noise_option).
+// =====================================================================================================
+struct SrkArgs {
+    GenericArgs g;
+    const float* srk_tab;   // (N, 4, SNSDE_SRK_STRIDE): stage times c = 0, 1/4, 1/2, 1
+    const float* dU;
+    float* dU_out;
+    int32_t ldf;
+};
+
+__global__ void __launch_bounds__(GT) snsde_generic_srk_kernel(SrkArgs sa) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const GenericArgs& a = sa.g;
+    const SnsdeDims& d = a.d;
+    const SnsdeNet& net = a.net;
+    const int H = d.H, C = d.C, B = d.B, io = d.io, no = d.no;
+    const int ldy = a.ldy, ldw = a.ldw, ldx = a.ldx, ldf = sa.ldf;
+    float* Y = lds;                       // state y_n
+    float* S0 = Y + GR * ldy;             // drift stage state (+ time features)
+    float* S1 = S0 + GR * ldy;            // diffusion stage state (+ time features)
+    float* bufA = S1 + GR * ldy;
+    float* bufB = bufA + GR * ldw;
+    float* bufC = bufB + GR * ldw;
+    float* xbuf = bufC + GR * ldw;
+    float* V = xbuf + GR * ldx;           // 8 value planes [GR][ldf]: f0 f1 f2 g0 g1 g2 dW dU
+    const int plane = GR * ldf;
+    float* F0 = V; float* F1 = V + plane; float* F2 = V + 2 * plane;
+    float* G0 = V + 3 * plane; float* G1 = V + 4 * plane; float* G2 = V + 5 * plane;
+    float* DW = V + 6 * plane; float* DU = V + 7 * plane;
+    const int lds_floats = GR * (3 * ldy + 3 * ldw + ldx + 8 * ldf);
+    const int tid = threadIdx.x, row0 = blockIdx.x * GR;
+    for (int i = tid; i < lds_floats; i += GT) lds[i] = 0.0f;
+    __syncthreads();
+    for (int i = tid; i < GR * H; i += GT) {
+        const int r = i / H, j = i - r * H, row = row0 + r;
+        if (row < B) {
+            const float v = a.y0[(size_t)row * H + j];
+            Y[r * ldy + j] = v;
+            a.ys[(size_t)row * H + j] = v;
+            if (a.traj) a.traj[(size_t)row * H + j] = v;
+        }
+    }
+    const float sig_theta = snsde_sigmoid(a.params[net.off_theta]);
+    const float exp_sigma = (net.off_sigma >= 0) ? expf(a.params[net.off_sigma]) : 0.0f;
+    const bool uses_x = (io == 0 || io == 2 || io == 4 || io == 6);
+    const bool uses_emb = (io == 2 || io == 4 || io == 6);
+    const bool noise_net = (no == 14 || no == 15 || no == 18 || no == 19);
+    const float* gt = a.ws + (net.gt_tab >= 0 ? net.gt_tab : 0);
+    const size_t BH = (size_t)B * H;
+    int kout = 0;
+    __syncthreads();
+
+    auto for_elems = [&](auto&& fn) {
+        for (int i = tid; i < GR * H; i += GT) {
+            const int r = i / H, j = i - r * H;
+            fn(r, j, row0 + r);
+        }
+        __syncthreads();
+    };
+    // f(tp, state in sbuf) -> fout plane
+    auto drift = [&](float* sbuf, const float* tp, float* fout) {
+        const float frac = tp[3];
+        const int idx = __float_as_int(tp[4]);
+        if (tid < GR) { sbuf[tid * ldy + H] = tp[1]; sbuf[tid * ldy + H + 1] = tp[2]; }
+        if (uses_x) {
+            for (int i = tid; i < GR * C; i += GT) {
+                const int r = i / C, c = i - r * C, row = row0 + r;
+                float v = 0.0f;
+                if (row < B) {
+                    const float* cp = a.coeffs + ((size_t)row * (d.L - 1) + idx) * (4 * C) + c;
+                    v = snsde_spline_eval(cp[0], cp[C], cp[2 * C], cp[3 * C], frac);
+                }
+                xbuf[r * ldx + c] = v;
+            }
+        }
+        __syncthreads();
+        float* cur;
+        float* oth;
+        if (io == 0) {
+            dense(a.params, a.ws, net.init, xbuf, ldx, bufA, ldw, true);
+            cur = bufA; oth = bufB;
+        } else if (!uses_emb) {
+            dense(a.params, a.ws, net.in, sbuf, ldy, bufA, ldw, true);
+            cur = bufA; oth = bufB;
+        } else {
+            dense(a.params, a.ws, net.in, sbuf, ldy, bufA, ldw, false);
+            dense(a.params, a.ws, net.init, xbuf, ldx, bufA + H, ldw, false);
+            __syncthreads();
+            dense(a.params, a.ws, net.emb, bufA, ldw, bufB, ldw, true);
+            cur = bufB; oth = bufA;
+        }
+        __syncthreads();
+        for (int l = 0; l < net.n_hid; ++l) {
+            dense(a.params, a.ws, net.hid[l], cur, ldw, oth, ldw, true);
+            float* t = cur; cur = oth; oth = t;
+            __syncthreads();
+        }
+        dense(a.params, a.ws, net.out, cur, ldw, oth, ldw, false);
+        __syncthreads();
+        for_elems([&](int r, int j, int) {
+            float z = oth[r * ldw + j];
+            if (io == 5 || io == 6) z *= tanhf(sbuf[r * ldy + j]);
+            fout[r * ldf + j] = tanhf(z);
+        });
+    };
+    // diffusion-net output buffer for the state in sbuf at stage time tp (noise_option 14/15/18/19)
+    auto diffusion_net = [&](float* sbuf, const float* tp) -> const float* {
+        if (!noise_net) return bufC;
+        if (tid < GR) { sbuf[tid * ldy + H] = tp[1]; sbuf[tid * ldy + H + 1] = tp[2]; }
+        __syncthreads();
+        dense(a.params, a.ws, net.ny0, sbuf, ldy, bufA, ldw, no >= 18);
+        __syncthreads();
+        if (no < 18) return bufA;
+        dense(a.params, a.ws, net.ny1, bufA, ldw, bufC, ldw, true);
+        __syncthreads();
+        return bufC;
+    };
+    auto g_elem = [&](float y, float t, int n, int slot, int r, int j, const float* nb) {
+        float raw = 0.0f;
+        switch (no) {
+            case 0: break;
+            case 1: raw = exp_sigma; break;
+            case 2: raw = exp_sigma * t; break;
+            case 3: raw = exp_sigma * y; break;
+            case 4: raw = expf(a.params[net.off_sigma_diag + j]); break;
+            case 5: raw = expf(a.params[net.off_sigma_diag + j]) * t; break;
+            case 6: raw = expf(a.params[net.off_sigma_diag + j]) * y; break;
+            case 7: raw = sqrtf(y); break;
+            case 8: raw = y * y * y; break;
+            case 9: raw = snsde_sigmoid(y); break;
+            case 10: raw = fmaxf(y, 0.0f); break;
+            case 11: raw = t * y; break;
+            case 12: case 16: raw = gt[((size_t)n * 4 + slot) * H + j]; break;
+            case 13: case 17: raw = gt[((size_t)n * 4 + slot) * H + j] * y; break;
+            case 14: case 18: raw = nb[r * ldw + j]; break;
+            case 15: case 19: raw = nb[r * ldw + j] * y; break;
+        }
+        return tanhf(sig_theta * snsde_nan_to_num(raw));
+    };
+    auto diffusion = [&](float* sbuf, const float* tp, int n, int slot, float* gout) {
+        const float* nb = diffusion_net(sbuf, tp);
+        const float t = tp[0];
+        for_elems([&](int r, int j, int) { gout[r * ldf + j] = g_elem(sbuf[r * ldy + j], t, n, slot, r, j, nb); });
+    };
+
+    for (int n = 0; n < d.N; ++n) {
+        const float* st = a.step_tab + (size_t)n * SNSDE_STEP_STRIDE;
+        const float h = st[1], rdt = st[6];
+        const float* tp0 = sa.srk_tab + (size_t)n * 4 * SNSDE_SRK_STRIDE;   // t0
+        const float* tpq = tp0 + SNSDE_SRK_STRIDE;                          // t0 + h/4
+        const float* tph = tp0 + 2 * SNSDE_SRK_STRIDE;                      // t0 + h/2
+        const float* tp1 = tp0 + 3 * SNSDE_SRK_STRIDE;                      // t0 + h
+        // increments of the step
+        for_elems([&](int r, int j, int row) {
+            float dw = 0.0f, du = 0.0f;
+            if (row < B) {
+                const size_t off = (size_t)n * BH + (size_t)row * H + j;
+                if (a.dW) { dw = a.dW[off]; du = sa.dU[off]; }
+                else {
+                    float z4[4], x4[4];
+                    snsde_philox_normal4(a.seed, (uint32_t)(a.row_offset + row), (uint32_t)(n >> 2), (uint32_t)j, z4, 0u);
+                    snsde_philox_normal4(a.seed, (uint32_t)(a.row_offset + row), (uint32_t)(n >> 2), (uint32_t)j, x4, 1u);
+                    const int k = n & 3;
+                    dw = (k == 0 ? z4[0] : k == 1 ? z4[1] : k == 2 ? z4[2] : z4[3]) * rdt;
+                    const float xi = k == 0 ? x4[0] : k == 1 ? x4[1] : k == 2 ? x4[2] : x4[3];
+                    du = h * fmaf(sqrtf(h / 12.0f), xi, 0.5f * dw);
+                }
+                if (a.dW_out) a.dW_out[off] = dw;
+                if (sa.dU_out) sa.dU_out[off] = du;
+            }
+            DW[r * ldf + j] = dw;
+            DU[r * ldf + j] = du;
+            S0[r * ldy + j] = Y[r * ldy + j];
+            S1[r * ldy + j] = Y[r * ldy + j];
+        });
+        // stage 0
+        drift(S0, tp0, F0);
+        diffusion(S1, tp0, n, 0, G0);
+        // stage 1: H0 = y + f0 h ; H1 = y + f0 h/4 + g0 sqrt(h)/2
+        for_elems([&](int r, int j, int) {
+            const float y = Y[r * ldy + j], f0 = F0[r * ldf + j], g0 = G0[r * ldf + j];
+            S0[r * ldy + j] = y + f0 * h;
+            S1[r * ldy + j] = y + 0.25f * f0 * h + 0.5f * g0 * rdt;
+        });
+        drift(S0, tp1, F1);
+        diffusion(S1, tpq, n, 1, G1);
+        // stage 2: H0 = y + (f0 + f1) h/4 + (g0 + g1/2) I_k0/h ; H1 = y + f0 h - g0 sqrt(h)
+        for_elems([&](int r, int j, int) {
+            const float y = Y[r * ldy + j], f0 = F0[r * ldf + j], f1 = F1[r * ldf + j];
+            const float g0 = G0[r * ldf + j], g1 = G1[r * ldf + j], du = DU[r * ldf + j];
+            S0[r * ldy + j] = y + 0.25f * f0 * h + 0.25f * f1 * h + g0 * du / h + 0.5f * g1 * du / h;
+            S1[r * ldy + j] = y + f0 * h - g0 * rdt;
+        });
+        drift(S0, tph, F2);
+        diffusion(S1, tp1, n, 3, G2);
+        // stage 3: H1 = y + f2 h/4 + (-5 g0 + 3 g1 + g2/2) sqrt(h)  (its drift has weight 0)
+        for_elems([&](int r, int j, int) {
+            const float y = Y[r * ldy + j];
+            S1[r * ldy + j] = y + 0.25f * F2[r * ldf + j] * h +
+                              (-5.0f * G0[r * ldf + j] + 3.0f * G1[r * ldf + j] + 0.5f * G2[r * ldf + j]) * rdt;
+        });
+        const float* nb3 = diffusion_net(S1, tpq);
+        // combination
+        int kend = kout;
+        while (kend < d.T - 1 && a.out_step[kend] == n) ++kend;
+        for_elems([&](int r, int j, int row) {
+            const float y = Y[r * ldy + j];
+            const float ik = DW[r * ldf + j], ik0 = DU[r * ldf + j];
+            const float ikk = 0.5f * (ik * ik - h);
+            const float ikkk = (ik * ik * ik - 3.0f * h * ik) / 6.0f;
+            const float g3 = g_elem(S1[r * ldy + j], tpq[0], n, 1, r, j, nb3);
+            const float a1 = ik, a2 = ikk / rdt, a3 = ik0 / h, a4 = ikkk / h;
+            const float w0 = -a1 - a2 + 2.0f * a3 - 2.0f * a4;
+            const float w1 = (4.0f / 3.0f) * a1 + (4.0f / 3.0f) * a2 - (4.0f / 3.0f) * a3 + (5.0f / 3.0f) * a4;
+            const float w2 = (2.0f / 3.0f) * a1 - (1.0f / 3.0f) * a2 - (2.0f / 3.0f) * a3 - (2.0f / 3.0f) * a4;
+            const float w3 = a4;
+            float ynew = y + (F0[r * ldf + j] + F1[r * ldf + j]) * (h / 6.0f) + F2[r * ldf + j] * (2.0f * h / 3.0f);
+            ynew += w0 * G0[r * ldf + j] + w1 * G1[r * ldf + j] + w2 * G2[r * ldf + j] + w3 * g3;
+            Y[r * ldy + j] = ynew;
+            if (row < B) {
+                if (a.traj) a.traj[(size_t)(n + 1) * BH + (size_t)row * H + j] = ynew;
+                for (int k = kout; k < kend; ++k) {
+                    const float c0 = a.out_w[2 * k], c1 = a.out_w[2 * k + 1];
+                    a.ys[(size_t)(k + 1) * BH + (size_t)row * H + j] = (c0 == 0.0f) ? ynew : c0 * y + c1 * ynew;
+                }
+            }
+        });
+        kout = kend;
+    }
+}
+
 __global__ void snsde_spline_kernel(const float* __restrict__ coeffs, int B, int L, int C, int index, float frac,
                                     int derivative, float* __restrict__ out) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -307,13 +544,13 @@ inline int round4(int x) { return (x + 3) & ~3; }
 int snsde_time_table_launch(const float* params, const float* step_tab, float* gt, const SnsdeLayer& nt0,
                             const SnsdeLayer& nt1, int H, int no, int n_steps, hipStream_t stream) {
     hipLaunchKernelGGL(snsde_time_table_kernel, dim3(n_steps), dim3(128), H * sizeof(float), stream, params, step_tab,
-                       gt, nt0, nt1, H, no);
+                       gt, nt0, nt1, H, no, SNSDE_STEP_STRIDE, 2);
     return hipGetLastError() == hipSuccess ? SNSDE_OK : SNSDE_ERR_LAUNCH;
 }
 
 int snsde_generic_workspace_floats(const snsde_solve* s, const SnsdeNet& net, size_t* floats) {
     size_t f = (size_t)net.packed_floats;
-    if (net.gt_tab >= 0) f = (size_t)net.gt_tab + (size_t)s->n_steps * s->model.hidden_channels;
+    if (net.gt_tab >= 0) f = (size_t)net.gt_tab + (size_t)s->n_steps * s->model.hidden_channels * (s->method == SNSDE_SRK ? 4 : 1);
     *floats = f;
     return SNSDE_OK;
 }
@@ -339,7 +576,8 @@ int snsde_generic_launch(const snsde_solve* s, const SnsdeNet& net, hipStream_t 
     const int n_steps = eval_mode ? 1 : s->n_steps;
     if (net.gt_tab >= 0 && prepare) {
         hipLaunchKernelGGL(snsde_time_table_kernel, dim3(n_steps), dim3(128), m.hidden_channels * sizeof(float), stream,
-                           s->params, step_tab, ws + net.gt_tab, net.nt0, net.nt1, m.hidden_channels, no);
+                           s->params, step_tab, ws + net.gt_tab, net.nt0, net.nt1, m.hidden_channels, no,
+                           SNSDE_STEP_STRIDE, 2);
     }
     // 3. the fused solve
     GenericArgs a;
@@ -376,6 +614,46 @@ int snsde_generic_launch(const snsde_solve* s, const SnsdeNet& net, hipStream_t 
     }
     const int grid = (s->batch + GR - 1) / GR;
     hipLaunchKernelGGL(snsde_generic_kernel, dim3(grid), dim3(GT), lds_bytes, stream, a);
+    return hipGetLastError() == hipSuccess ? SNSDE_OK : SNSDE_ERR_LAUNCH;
+}
+
+int snsde_srk_launch(const snsde_solve* s, const SnsdeNet& net, hipStream_t stream) {
+    const snsde_model& m = s->model;
+    float* ws = static_cast<float*>(s->workspace);
+    if (!(s->flags & SNSDE_FLAG_REUSE_PREPARED)) {
+        PackJob job;
+        job.n = 0;
+        auto add = [&](const SnsdeLayer& L) { if (L.present && L.w >= 0) job.layer[job.n++] = L; };
+        add(net.init); add(net.in); add(net.emb);
+        for (int i = 0; i < net.n_hid; ++i) add(net.hid[i]);
+        add(net.out); add(net.ny0); add(net.ny1);
+        if (job.n > 0) hipLaunchKernelGGL(snsde_pack_kernel, dim3(32, job.n), dim3(256), 0, stream, s->params, ws, job);
+        if (net.gt_tab >= 0)   // time-only diffusion at the 4 stage times of every step: gt[(n*4 + slot)][H]
+            hipLaunchKernelGGL(snsde_time_table_kernel, dim3(s->n_steps * 4), dim3(128), m.hidden_channels * sizeof(float),
+                               stream, s->params, s->srk_tab, ws + net.gt_tab, net.nt0, net.nt1, m.hidden_channels,
+                               m.noise_option, SNSDE_SRK_STRIDE, 1);
+    }
+    SrkArgs sa;
+    GenericArgs& a = sa.g;
+    a.d = SnsdeDims{s->batch, m.hidden_channels, m.hidden_hidden_channels, m.input_channels, s->knots,
+                    m.num_hidden_layers, m.input_option, m.noise_option, s->n_steps, s->n_out, s->method};
+    a.net = net;
+    a.params = s->params; a.ws = ws; a.coeffs = s->coeffs; a.step_tab = s->step_tab; a.out_step = s->out_step;
+    a.out_w = s->out_w; a.y0 = s->y0; a.dW = s->dW; a.ys = s->ys; a.traj = s->traj; a.dW_out = s->dW_out;
+    a.row_offset = s->row_offset; a.seed = s->seed; a.eval_mode = 0; a.eval_f = nullptr; a.eval_g = nullptr;
+    const int H = m.hidden_channels, HH = m.hidden_hidden_channels;
+    a.ldy = round4(H + 2);
+    const int wmax = 2 * H > HH ? 2 * H : HH;
+    a.ldw = round4(wmax) + 4;
+    a.ldx = round4(m.input_channels);
+    sa.srk_tab = s->srk_tab; sa.dU = s->dU; sa.dU_out = s->dU_out; sa.ldf = round4(H);
+    const size_t lds_bytes = (size_t)GR * (3 * a.ldy + 3 * a.ldw + a.ldx + 8 * sa.ldf) * sizeof(float);
+    if (lds_bytes > 160 * 1024) return SNSDE_ERR_LDS;
+    if (lds_bytes > 64 * 1024 &&
+        hipFuncSetAttribute(reinterpret_cast<const void*>(snsde_generic_srk_kernel),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes) != hipSuccess)
+        return SNSDE_ERR_LDS;
+    hipLaunchKernelGGL(snsde_generic_srk_kernel, dim3((s->batch + GR - 1) / GR), dim3(GT), lds_bytes, stream, sa);
     return hipGetLastError() == hipSuccess ? SNSDE_OK : SNSDE_ERR_LAUNCH;
 }
 

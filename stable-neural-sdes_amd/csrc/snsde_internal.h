@@ -50,6 +50,7 @@ int snsde_build_net(const snsde_model& m, int32_t n_steps, SnsdeNet* net);
 int snsde_generic_workspace_floats(const snsde_solve* s, const SnsdeNet& net, size_t* floats);
 int snsde_generic_launch(const snsde_solve* s, const SnsdeNet& net, hipStream_t stream, int eval_mode,
                          const float* eval_y, float* eval_f, float* eval_g, const float* step_row_dev);
+int snsde_srk_launch(const snsde_solve* s, const SnsdeNet& net, hipStream_t stream);
 int snsde_time_table_launch(const float* params, const float* step_tab, float* gt, const SnsdeLayer& nt0,
                             const SnsdeLayer& nt1, int H, int no, int n_steps, hipStream_t stream);
 // launchers (snsde_mfma.hip)
@@ -115,9 +116,10 @@ __device__ __forceinline__ void snsde_philox4x32_10(uint32_t c0, uint32_t c1, ui
 // Every state element is owned by exactly one lane in every kernel, so no lane recomputes another's call.
 // Specification: oracle/sde_oracle.py philox_normals.
 __device__ __forceinline__ void snsde_philox_normal4(uint64_t seed, uint32_t row, uint32_t step_block, uint32_t col,
-                                                     float z[4]) {
+                                                     float z[4], uint32_t stream = 0u) {
+    // stream = 4th counter word: 0 = Brownian increments, 1 = the independent normal of the SRK space-time Levy area
     uint32_t x[4];
-    snsde_philox4x32_10(row, step_block, col, 0u, (uint32_t)seed, (uint32_t)(seed >> 32), x);
+    snsde_philox4x32_10(row, step_block, col, stream, (uint32_t)seed, (uint32_t)(seed >> 32), x);
     const float s = 1.1920928955078125e-07f;  // 2^-23
     const float ua = ((float)(x[0] >> 9) + 0.5f) * s, ub = ((float)(x[1] >> 9) + 0.5f) * s;
     const float uc = ((float)(x[2] >> 9) + 0.5f) * s, ud = ((float)(x[3] >> 9) + 0.5f) * s;

@@ -97,6 +97,7 @@ MfmaPlan make_plan(const snsde_solve* s, const SnsdeNet& net, int flavor_hint) {
     const int H = m.hidden_channels, io = m.input_option, no = m.noise_option;
     p.ok = false;
     if (m.hidden_hidden_channels != H) return p;
+    if (s->method == SNSDE_SRK) return p;
     if (!(H == 128 || H == 64 || H == 32 || H == 16)) return p;
     if (!(io >= 1 && io <= 6)) return p;
     const bool noise_net = (no == 14 || no == 15 || no == 18 || no == 19);

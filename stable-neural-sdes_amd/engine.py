@@ -82,6 +82,8 @@ class StepGrid:
         _lib.check(L.snsde_grid_build(ts32.ctypes.data, self.T, float(dt), times32.ctypes.data, times32.shape[0],
                                       self.N, self.step_tab.ctypes.data, self.out_step.ctypes.data,
                                       self.out_w.ctypes.data), 'snsde_grid_build')
+        self._times32 = times32
+        self._d_srk = None
         self.t0 = self.step_tab[:, 0].copy()
         self.t1 = self.step_tab[:, 7].copy()
         self.device = device
@@ -89,6 +91,17 @@ class StepGrid:
             self.d_step_tab = torch.from_numpy(self.step_tab).to(device)
             self.d_out_step = torch.from_numpy(self.out_step).to(device)
             self.d_out_w = torch.from_numpy(self.out_w).to(device)
+
+
+def srk_table(grid):
+    """Device (N, 4, SNSDE_SRK_STRIDE) stage-time table of a StepGrid (built on first use)."""
+    if grid._d_srk is None:
+        tab = np.zeros((grid.N, 4, _lib.SNSDE_SRK_STRIDE), dtype=np.float32)
+        _lib.check(_lib.lib().snsde_grid_srk_build(grid.step_tab.ctypes.data, grid.N, grid._times32.ctypes.data,
+                                                   grid._times32.shape[0], tab.ctypes.data), 'snsde_grid_srk_build')
+        grid.srk_host = tab
+        grid._d_srk = torch.from_numpy(tab).to(grid.device)
+    return grid._d_srk
 
 
 def step_grid(ts_host, dt, times_host, device):
@@ -121,7 +134,7 @@ class SolveCall:
     launch itself is one C call that only enqueues kernels (hipGraph-capturable)."""
 
     def __init__(self, model, flat_params, coeffs, grid, y0, dW=None, method='euler', seed=0, row_offset=0,
-                 kernel='auto', save_traj=False, save_dW=False, exact_order=False, save_act=False):
+                 kernel='auto', save_traj=False, save_dW=False, exact_order=False, save_act=False, dU=None):
         B, H = y0.shape
         C_ = model.input_channels
         L = coeffs.shape[1] + 1
@@ -132,7 +145,9 @@ class SolveCall:
         if dW is not None:
             _check_f32('dW', dW, (grid.N, B, H))
         self.model, self.grid = model, grid
-        self.keep = (flat_params, coeffs, y0, dW, grid)
+        if dU is not None:
+            _check_f32('dU', dU, (grid.N, B, H))
+        self.keep = (flat_params, coeffs, y0, dW, grid, dU)
         self.ys = torch.empty((grid.T, B, H), device=dev, dtype=torch.float32)
         self.traj = torch.empty((grid.N + 1, B, H), device=dev, dtype=torch.float32) if save_traj else None
         self.dW_out = torch.empty((grid.N, B, H), device=dev, dtype=torch.float32) if save_dW else None
@@ -144,7 +159,12 @@ class SolveCall:
         s = _lib.Solve()
         s.model = model
         s.batch, s.knots, s.n_steps, s.n_out = B, L, grid.N, grid.T
-        s.method = {'euler': _lib.EULER, 'milstein': _lib.MILSTEIN}[method]
+        s.method = {'euler': _lib.EULER, 'milstein': _lib.MILSTEIN, 'srk': _lib.SRK}[method]
+        if method == 'srk':
+            s.srk_tab = _ptr(srk_table(grid))
+            s.dU = _ptr(dU)
+            self.dU_out = torch.empty((grid.N, B, H), device=dev, dtype=torch.float32) if save_dW else None
+            s.dU_out = _ptr(self.dU_out)
         s.kernel = _lib.KERNELS[kernel]
         self.base_flags = _lib.FLAG_EXACT_ORDER if exact_order else 0
         s.flags = self.base_flags

@@ -40,10 +40,17 @@ class BrownianIncrements:
         self.generator = torch.Generator(device=device if device is not None else 'cpu')
         self.generator.manual_seed(int(entropy) if entropy is not None else int(torch.empty((), dtype=torch.int64).random_().item()))
 
-    def __call__(self, ta, tb=None, **kwargs):
-        h = torch.as_tensor(tb, dtype=self.dtype) - torch.as_tensor(ta, dtype=self.dtype)
+    levy_area_approximation = 'space-time'
+
+    def __call__(self, ta, tb=None, return_U=False, **kwargs):
+        h = (torch.as_tensor(tb, dtype=self.dtype) - torch.as_tensor(ta, dtype=self.dtype))
         z = torch.randn(self.shape, dtype=self.dtype, device=self.device, generator=self.generator)
-        return z * h.to(z.device).sqrt()
+        h = h.to(z.device)
+        W = z * h.sqrt()
+        if not return_U:
+            return W
+        xi = torch.randn(self.shape, dtype=self.dtype, device=self.device, generator=self.generator)
+        return W, h * (0.5 * W + (h / 12).sqrt() * xi)     # U = int_ta^tb (W_s - W_ta) ds
 
 
 def _as_ts(ts, y0):
@@ -77,8 +84,6 @@ def sdeint(sde, y0, ts, bm=None, method=None, dt=1e-3, adaptive=False, rtol=1e-5
         method = 'srk'   # torchsde's default for Ito / diagonal noise
     if method not in METHODS:
         raise ValueError(f"Expected method in {METHODS}, but found {method}.")
-    if method == 'srk':
-        raise NotImplementedError("method='srk' (SRID2) is not implemented yet; use 'euler' or 'milstein'")
     if not (float(dt) > 0):
         raise ValueError("`dt` must be positive.")
     backend = options.get('backend', 'auto')
@@ -109,20 +114,28 @@ def _sdeint_hip(sde, rec, y0, ts, bm, method, dt, options):
     ts_host = ts.detach().to('cpu', torch.float32).numpy()
     grid = engine.step_grid(ts_host, dt, times_host, dev)
     flat = engine.flatten_params(sde, layout, numel, dev)
-    dW = None
+    dW = dU = None
     if bm is not None:
         t0 = torch.from_numpy(grid.t0)
         t1 = torch.from_numpy(grid.t1)
-        dW = torch.stack([bm(t0[n], t1[n]).to(device=dev, dtype=torch.float32) for n in range(grid.N)]).contiguous()
+        if method == 'srk':   # torchsde: I_k, I_k0 = bm(t0, t1, return_U=True)
+            pairs = [bm(t0[n], t1[n], return_U=True) for n in range(grid.N)]
+            dW = torch.stack([p[0].to(device=dev, dtype=torch.float32) for p in pairs]).contiguous()
+            dU = torch.stack([p[1].to(device=dev, dtype=torch.float32) for p in pairs]).contiguous()
+        else:
+            dW = torch.stack([bm(t0[n], t1[n]).to(device=dev, dtype=torch.float32) for n in range(grid.N)]).contiguous()
     seed = options.get('seed')
     seed = _fresh_seed() if seed is None else int(seed)
+    if needs_grad and method == 'srk':
+        raise NotImplementedError("gradients through the fused SRK solve are not implemented; use method='euler' "
+                                  "or options={'backend': 'torch'}")
     if needs_grad:
         return _FusedEulerSolve.apply(sde, rec, coeffs, grid, times_host, dW, method, seed, options, y0,
                                       *[p for _, p in sde.named_parameters()])
     call = engine.SolveCall(model, flat, coeffs, grid, y0c, dW=dW, method=method, seed=seed,
                             row_offset=int(options.get('row_offset', 0)), kernel=options.get('kernel', 'auto'),
                             save_traj=bool(options.get('save_traj', False)),
-                            exact_order=bool(options.get('exact_order', False)))
+                            exact_order=bool(options.get('exact_order', False)), dU=dU)
     ys = call.launch()
     if options.get('save_traj', False):
         sde.last_trajectory = call.traj
@@ -291,6 +304,33 @@ def _call(sde, names, key, default):
     return getattr(sde, (names or {}).get(key, default))
 
 
+# SRID2 (Roessler 2010; torchsde 0.2.5 `srk` for diagonal noise), restated - see oracle/sde_oracle.py
+_SRK = dict(C0=(0.0, 1.0, 0.5, 0.0), C1=(0.0, 0.25, 1.0, 0.25),
+            A0=((), (1.0,), (0.25, 0.25), (0.0, 0.0, 0.0)), A1=((), (0.25,), (1.0, 0.0), (0.0, 0.0, 0.25)),
+            B0=((), (0.0,), (1.0, 0.5), (0.0, 0.0, 0.0)), B1=((), (0.5,), (-1.0, 0.0), (-5.0, 3.0, 0.5)),
+            alpha=(1 / 6, 1 / 6, 2 / 3, 0.0), beta1=(-1.0, 4 / 3, 2 / 3, 0.0), beta2=(-1.0, 4 / 3, -1 / 3, 0.0),
+            beta3=(2.0, -4 / 3, -2 / 3, 0.0), beta4=(-2.0, 5 / 3, -2 / 3, 1.0))
+
+
+def _srk_step(f, g, t0, h, y, I_k, I_k0):
+    T = _SRK
+    rdt = h.sqrt()
+    I_kk = (I_k * I_k - h) / 2
+    I_kkk = (I_k ** 3 - 3 * h * I_k) / 6
+    fs, gs = [], []
+    y1 = y
+    for s in range(4):
+        H0, H1 = y, y
+        for j in range(s):
+            H0 = H0 + T['A0'][s][j] * fs[j] * h + T['B0'][s][j] * gs[j] * I_k0 / h
+            H1 = H1 + T['A1'][s][j] * fs[j] * h + T['B1'][s][j] * gs[j] * rdt
+        fs.append(f(t0 + T['C0'][s] * h, H0))
+        gs.append(g(t0 + T['C1'][s] * h, H1))
+        gw = T['beta1'][s] * I_k + T['beta2'][s] * I_kk / rdt + T['beta3'][s] * I_k0 / h + T['beta4'][s] * I_kkk / h
+        y1 = y1 + T['alpha'][s] * fs[s] * h + gw * gs[s]
+    return y1
+
+
 def _sdeint_torch(sde, y0, ts, bm, method, dt, options, names):
     """Unfused scheme on tensor ops (arbitrary sde, CPU plumbing, autograd)."""
     f = _call(sde, names, 'drift', 'f')
@@ -312,11 +352,15 @@ def _sdeint_torch(sde, y0, ts, bm, method, dt, options, names):
     for n in range(grid.N):
         t0, t1 = t0s[n], t1s[n]
         h = (t1 - t0).to(y0.dtype)
-        I = bm(t0, t1)
         prev = y
-        if method == 'euler':
+        if method == 'srk':
+            I, I0 = bm(t0, t1, return_U=True)
+            y = _srk_step(f, g, t0, h, y, I, I0)
+        elif method == 'euler':
+            I = bm(t0, t1)
             y = y + f(t0, y) * h + g(t0, y) * I
         else:
+            I = bm(t0, t1)
             v = I * I - h
             with torch.enable_grad():
                 yy = y if y.requires_grad else y.detach().requires_grad_(True)

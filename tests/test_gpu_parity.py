@@ -22,7 +22,7 @@ def flat_params(p, io, no, NL, C, H):
 
 
 def hip_solve(pr, ts, dt, dW=None, method='euler', seed=0, row_offset=0, kernel='auto', rows=None, save_traj=False,
-              save_dW=False):
+              save_dW=False, dU=None):
     exact = kernel.endswith('x')          # 'mfma4x' = MFMA path keeping the reference's unfused emb order
     kernel = kernel[:-1] if exact else kernel
     io, no, NL, C, H = pr['io'], pr['no'], pr['NL'], pr['C'], pr['H']
@@ -33,8 +33,9 @@ def hip_solve(pr, ts, dt, dW=None, method='euler', seed=0, row_offset=0, kernel=
     y0 = torch.from_numpy(np.ascontiguousarray(pr['y0'][sl])).to(DEV)
     grid = S.engine.step_grid(np.asarray(ts, np.float32), dt, pr['times'], torch.device(DEV))
     dWd = None if dW is None else torch.from_numpy(np.ascontiguousarray(dW[:, sl])).to(DEV)
+    dUd = None if dU is None else torch.from_numpy(np.ascontiguousarray(dU[:, sl])).to(DEV)
     call = S.engine.SolveCall(model, flat, coeffs, grid, y0, dW=dWd, method=method, seed=seed, row_offset=row_offset,
-                              kernel=kernel, save_traj=save_traj, save_dW=save_dW, exact_order=exact)
+                              kernel=kernel, save_traj=save_traj, save_dW=save_dW, exact_order=exact, dU=dUd)
     ys = call.launch()
     torch.cuda.synchronize()
     return ys.cpu().numpy(), call
@@ -568,3 +569,71 @@ def test_neuralsde_training_step_on_cuda():
     moved = [k for k, v in model.state_dict().items() if k in before and not torch.equal(v, before[k])]
     assert any(k.startswith('func.linear_in') for k in moved) and any(k.startswith('func.noise_t') for k in moved)
     assert any(k.startswith('initial_network') for k in moved)
+
+
+# ---- SRK (SRID2) ---------------------------------------------------------------------------------------
+SRK_CASES = [
+    # io, no, NL, B, H, C, L, ts, dt
+    (6, 17, 2, 19, 32, 5, 9, [0, 2.5, 8], 0.5),      # torch_ists / tutorial GSDE-SRK flavour
+    (4, 17, 2, 37, 128, 21, 13, [0, 12], 1.0),
+    (2, 16, 1, 9, 16, 2, 12, None, None),            # ts = times = linspace(0,1,12): interpolated outputs
+    (1, 18, 2, 8, 24, 3, 8, [0, 7], 0.5),
+    (3, 15, 3, 8, 16, 4, 8, [0, 7], 1.0),
+    (0, 5, 2, 8, 12, 3, 8, [0, 7], 1.0),
+    (5, 8, 2, 8, 10, 3, 8, [0, 3.5, 7], 0.25),
+    (1, 0, 2, 5, 8, 3, 8, [0, 7], 1.0),
+]
+
+
+def _draw_dU(seed, dW, ts, dt):
+    t0, t1, *_ = O.step_grid(np.asarray(ts, np.float32), dt)
+    h = (t1 - t0).astype(np.float32)[:, None, None]
+    xi = np.random.default_rng(seed + 7).standard_normal(dW.shape).astype(np.float32)
+    return (h * (0.5 * dW + np.sqrt(h / 12) * xi)).astype(np.float32)
+
+
+@pytest.mark.parametrize('ci', range(len(SRK_CASES)))
+def test_srk_trajectory_vs_oracle(ci):
+    io, no, NL, B, H, C, L, ts, dt = SRK_CASES[ci]
+    times = np.linspace(0, 1, L).astype(np.float32) if ts is None else None
+    pr = make_problem(700 + ci, io, no, NL, B, H, C, L, times=times)
+    if ts is None:
+        ts = pr['times']
+        dt = max(float(np.diff(pr['times']).min()), 1e-3) / 2      # torch_ists tutorial: dt = min gap / 2
+    dW = draw_dW(700 + ci, ts, dt, B, H)
+    dU = _draw_dU(700 + ci, dW, ts, dt)
+    ys, call = hip_solve(pr, ts, dt, dW=dW, dU=dU, method='srk', save_traj=True)
+    ref64, traj64 = O.solve_diffusion_model(pr['params'], io, no, pr['coeffs'], pr['times'], pr['y0'],
+                                            np.asarray(ts, np.float32), dt, dW, method='srk', dtype=np.float64, dU=dU)
+    cpu32, _ = O.solve_diffusion_model(pr['params'], io, no, pr['coeffs'], pr['times'], pr['y0'],
+                                       np.asarray(ts, np.float32), dt, dW, method='srk', dtype=np.float32, dU=dU)
+    assert_parity(ys, ref64, cpu32, what=f'srk case {ci}')
+    assert_parity(call.traj.cpu().numpy(), traj64, what=f'srk traj {ci}')
+
+
+def test_srk_philox_levy_area_matches_specification_and_shards():
+    pr = make_problem(41, 6, 17, 2, 24, 32, 5, 9)
+    ts, dt = [0, 8], 0.5
+    ys, call = hip_solve(pr, ts, dt, method='srk', seed=99, row_offset=64, save_dW=True)
+    t0, t1, *_ = O.step_grid(np.asarray(ts, np.float32), dt)
+    dW = call.dW_out.cpu().numpy()
+    dU = call.dU_out.cpu().numpy()
+    exp_dW = O.philox_dW(99, 64, 24, 32, t0, t1)
+    np.testing.assert_allclose(dW, exp_dW, rtol=2e-6, atol=2e-7)
+    np.testing.assert_allclose(dU, O.philox_dU(99, 64, 24, 32, t0, t1, dW), rtol=1e-5, atol=1e-6)
+    ref64, _ = O.solve_diffusion_model(pr['params'], 6, 17, pr['coeffs'], pr['times'], pr['y0'], np.asarray(ts, np.float32),
+                                       dt, dW, method='srk', dtype=np.float64, dU=dU)
+    assert_parity(ys, ref64, what='srk philox')
+    halves = [hip_solve(pr, ts, dt, method='srk', seed=99, row_offset=64 + o, rows=slice(o, o + 12))[0] for o in (0, 12)]
+    np.testing.assert_array_equal(np.concatenate(halves, axis=1), ys)
+
+
+def test_ists_neuralsde_default_srk_on_cuda():
+    """torch_ists wrapper: default method srk, ts = times, dt = min gap (nsde_model.py:63-84)."""
+    pr = make_problem(42, 6, 17, 2, 10, 16, 3, 9, times=np.linspace(0, 1, 9).astype(np.float32))
+    torch.manual_seed(0)
+    func = S.Diffusion_model(3, 16, 16, 2, input_option=6, noise_option=17)
+    model = S.IstsNeuralSDE(func, 3, 16, 2, initial=True).to(DEV).eval()
+    with torch.no_grad():
+        out, z = model(torch.from_numpy(pr['coeffs']).to(DEV), torch.from_numpy(pr['times']).to(DEV), options={'seed': 3})
+    assert out.shape == (10, 9, 2) and z.shape == (10, 9, 16) and torch.isfinite(z).all()

@@ -301,8 +301,8 @@ def test_sdeint_argument_errors():
         S.sdeint(m, y0, torch.tensor([0., 1.]), method='euler', dt=0.0)
     with pytest.raises(NotImplementedError):
         S.sdeint(m, y0, torch.tensor([0., 1.]), method='euler', dt=1.0, adaptive=True)
-    with pytest.raises(NotImplementedError):
-        S.sdeint(m, y0, torch.tensor([0., 1.]), dt=1.0)   # default method srk
+    with torch.no_grad():                                  # default method = srk (torchsde's default for Ito/diagonal)
+        assert S.sdeint(m, y0, torch.tensor([0., 1.]), dt=0.5).shape == (2, 2, 8)
     with pytest.raises(ValueError):   # HIP engine requested on CPU tensors: loud, no fallback
         with torch.no_grad():
             S.sdeint(m, y0, torch.tensor([0., 1.]), method='euler', dt=1.0, options={'backend': 'hip'})
@@ -322,3 +322,34 @@ def test_install_registers_shims():
             sys.modules.pop(k, None)
             if v is not None:
                 sys.modules[k] = v
+
+
+class _ReplayBMU:
+    """bm(ta, tb, return_U=True) -> (dW_n, dU_n) replayed from arrays (SRK)."""
+    levy_area_approximation = 'space-time'
+
+    def __init__(self, dW, dU):
+        self.dW, self.dU, self.n = dW, dU, 0
+
+    def __call__(self, ta, tb, return_U=False):
+        out = (self.dW[self.n], self.dU[self.n]) if return_U else self.dW[self.n]
+        self.n += 1
+        return out
+
+
+@pytest.mark.parametrize('io,no', [(4, 17), (6, 17), (2, 16), (1, 18), (3, 8), (0, 5)])
+def test_sdeint_srk_tensor_loop_vs_oracle(io, no):
+    from tests.helpers import draw_dW, make_problem
+    pr = make_problem(60 + io, io, no, 2, 5, 8, 3, 9)
+    ts, dt = np.array([0., 2.5, 8.], np.float32), 0.5
+    dW = draw_dW(60, ts, dt, 5, 8)
+    dU = (0.5 * dt * dW + dt * np.sqrt(dt / 12) * np.random.default_rng(1).standard_normal(dW.shape)).astype(np.float32)
+    m = S.Diffusion_model(3, 8, 8, 2, input_option=io, noise_option=no)
+    m.load_state_dict({k: torch.from_numpy(v.copy()) for k, v in pr['params'].items()})
+    m.set_X(torch.from_numpy(pr['coeffs']), torch.from_numpy(pr['times']))
+    with torch.no_grad():
+        ys = S.sdeint(m, torch.from_numpy(pr['y0']), torch.from_numpy(ts), bm=_ReplayBMU(torch.from_numpy(dW), torch.from_numpy(dU)),
+                      method='srk', dt=dt)
+    ref, _ = O.solve_diffusion_model(pr['params'], io, no, pr['coeffs'], pr['times'], pr['y0'], ts, dt, dW, method='srk',
+                                     dtype=np.float64, dU=dU)
+    np.testing.assert_allclose(ys.numpy(), ref, rtol=2e-4, atol=2e-5)

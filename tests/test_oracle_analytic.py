@@ -173,3 +173,27 @@ def test_milstein_closed_form_matches_autograd_style_fd():
             np.testing.assert_allclose(dg[mask], fd[mask], rtol=1e-5, atol=1e-7)
         else:
             np.testing.assert_allclose(dg, fd, rtol=1e-5, atol=1e-7, err_msg=str(no))
+
+
+def test_srk_strong_order_one_and_a_half_on_gbm():
+    """SRID2 with exact (I_k, I_k0) pairs: strong order ~1.5 on geometric Brownian motion, far below Milstein's error."""
+    mu, sig, T, paths, fine = 0.5, 0.8, 1.0, 4000, 2 ** 10
+    rng = np.random.default_rng(11)
+    hf = T / fine
+    dWf = rng.standard_normal((fine, paths, 1)) * np.sqrt(hf)
+    dUf = hf * (0.5 * dWf + np.sqrt(hf / 12) * rng.standard_normal((fine, paths, 1)))   # int (W_s - W_t0) ds on fine cells
+    exact = np.exp((mu - 0.5 * sig ** 2) * T + sig * dWf.sum(0))
+    errs = []
+    for N in (8, 32, 128):
+        m = fine // N
+        dWc = dWf.reshape(N, m, paths, 1)
+        dW = dWc.sum(1)
+        # coarse I_k0 = sum_i [ dU_i + (W_i - W_0) hf ]  over the fine cells of the coarse step
+        Wpre = np.cumsum(dWc, axis=1) - dWc
+        dU = (dUf.reshape(N, m, paths, 1) + Wpre * hf).sum(1)
+        ts = np.array([0., T], np.float32)
+        ys, _ = O.integrate(lambda t, y: mu * y, lambda t, y: sig * y, np.ones((paths, 1)), ts, T / N, dW, method='srk', dU=dU)
+        errs.append(np.mean(np.abs(ys[-1] - exact)))
+    order = np.log(errs[0] / errs[-1]) / np.log(16)
+    assert 1.25 < order < 1.9, (order, errs)
+    assert errs[1] < 0.2 * _gbm_strong_error('milstein', 32, rng_seed=11)
