@@ -182,6 +182,16 @@ int    snsde_solve_backward(const snsde_backward* b, void* hip_stream);
 int snsde_spline_evaluate(const float* coeffs, int32_t batch, int32_t knots, int32_t channels,
                           int32_t index, float frac, int32_t derivative, float* out, void* hip_stream);
 
+/* ---- spline coefficient construction (A11 / A12; offline preprocessing in the reference) ------------
+ * natural: controldiffeq.natural_cubic_spline_coeffs (interpolate.py:161-228) incl. its missing-value handling;
+ * hermite: torchcde.hermite_cubic_coefficients_with_backward_differences (datasets/common.py:82-84).
+ * times (L) and X (B, L, C) device float32, NaN = missing; coeffs (B, L-1, 4C) = cat[a, b, two_c, three_d] out. */
+size_t snsde_spline_workspace_bytes(int32_t batch, int32_t knots, int32_t channels);
+int snsde_natural_cubic_coeffs(const float* times, const float* X, int32_t batch, int32_t knots, int32_t channels,
+                               float* coeffs, void* workspace, size_t workspace_bytes, void* hip_stream);
+int snsde_hermite_coeffs(const float* times, const float* X, int32_t batch, int32_t knots, int32_t channels,
+                         float* coeffs, void* hip_stream);
+
 /* vector-field probe: one evaluation of f(t,y) and g(t,y) (neuralsde.py:295-307) through the same
  * device code the solver uses.  `step_row` = one step_tab row (device, SNSDE_STEP_STRIDE floats)
  * describing t; y, f_out, g_out are device (B, H).  Uses s->model/batch/knots/params/coeffs/

@@ -54,7 +54,8 @@ _lib = None
 EXPORTS = ('snsde_version', 'snsde_strerror', 'snsde_param_count', 'snsde_param_numel', 'snsde_param_info',
            'snsde_grid_count', 'snsde_grid_build', 'snsde_grid_srk_build', 'snsde_workspace_bytes', 'snsde_solve_forward',
            'snsde_spline_evaluate', 'snsde_eval_fg', 'snsde_act_slots', 'snsde_backward_supported',
-           'snsde_backward_workspace_bytes', 'snsde_solve_backward')
+           'snsde_backward_workspace_bytes', 'snsde_solve_backward', 'snsde_spline_workspace_bytes',
+           'snsde_natural_cubic_coeffs', 'snsde_hermite_coeffs')
 
 
 def lib():
@@ -85,6 +86,11 @@ def lib():
     L.snsde_spline_evaluate.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_float,
                                         C.c_int32, C.c_void_p, C.c_void_p]
     L.snsde_eval_fg.argtypes = [C.POINTER(Solve), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+    L.snsde_spline_workspace_bytes.argtypes = [C.c_int32, C.c_int32, C.c_int32]
+    L.snsde_spline_workspace_bytes.restype = C.c_size_t
+    L.snsde_natural_cubic_coeffs.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p,
+                                             C.c_size_t, C.c_void_p]
+    L.snsde_hermite_coeffs.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p]
     L.snsde_act_slots.argtypes = [C.POINTER(Model)]
     L.snsde_backward_supported.argtypes = [C.POINTER(Solve)]
     L.snsde_backward_workspace_bytes.argtypes = [C.POINTER(Backward)]

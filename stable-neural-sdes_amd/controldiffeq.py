@@ -101,6 +101,10 @@ def natural_cubic_spline_coeffs(t, X):
         raise ValueError("Must have a time dimension of size at least 2.")
     L, Cn = X.shape[-2], X.shape[-1]
     lead = X.shape[:-2]
+    if X.is_cuda and X.dtype == torch.float32 and not X.requires_grad:     # HIP construction kernel
+        packed = engine.spline_coeffs(t.to(device=X.device, dtype=torch.float32).contiguous(),
+                                      X.reshape(-1, L, Cn).contiguous(), 'natural')
+        return tuple(packed[..., k * Cn:(k + 1) * Cn].reshape(*lead, L - 1, Cn).contiguous() for k in range(4))
     series = X.transpose(-1, -2).reshape(-1, L)
     outs = _series_coeffs(t.to(X.dtype), series)
     return tuple(o.reshape(*lead, Cn, L - 1).transpose(-1, -2).contiguous() for o in outs)

@@ -241,6 +241,24 @@ def eval_fg(model, flat_params, coeffs, times_host, t, y, kernel='auto'):
     return f, gg
 
 
+def spline_coeffs(times, X, kind='natural'):
+    """Packed spline coefficients (B, L-1, 4C) on the GPU; times (L,), X (B, L, C) CUDA float32 with NaN = missing."""
+    _check_f32('X', X)
+    _check_f32('times', times)
+    B, L, Cn = X.shape
+    out = torch.empty((B, L - 1, 4 * Cn), device=X.device, dtype=torch.float32)
+    stream = C.c_void_p(torch.cuda.current_stream(X.device).cuda_stream)
+    lib = _lib.lib()
+    if kind == 'natural':
+        ws = torch.empty(lib.snsde_spline_workspace_bytes(B, L, Cn), device=X.device, dtype=torch.uint8)
+        _lib.check(lib.snsde_natural_cubic_coeffs(_ptr(times), _ptr(X), B, L, Cn, _ptr(out), _ptr(ws), ws.numel(), stream),
+                   'snsde_natural_cubic_coeffs')
+        torch.cuda.current_stream(X.device).synchronize()    # workspace is released on return
+    else:
+        _lib.check(lib.snsde_hermite_coeffs(_ptr(times), _ptr(X), B, L, Cn, _ptr(out), stream), 'snsde_hermite_coeffs')
+    return out
+
+
 def spline_evaluate(coeffs, index, frac, derivative=False):
     B, Lm1, C4 = coeffs.shape
     _check_f32('coeffs', coeffs)

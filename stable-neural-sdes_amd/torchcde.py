@@ -72,6 +72,11 @@ def hermite_cubic_coefficients_with_backward_differences(x, t=None):
         raise ValueError("t must be one dimensional with the same length as the time dimension of x.")
     if L < 2:
         raise ValueError("Must have a time dimension of size at least 2.")
+    if x.is_cuda and x.dtype == torch.float32 and not x.requires_grad:     # HIP construction kernel
+        from . import engine
+        lead = x.shape[:-2]
+        out = engine.spline_coeffs(t.to(device=x.device).contiguous(), x.reshape(-1, L, Cn).contiguous(), 'hermite')
+        return out.reshape(*lead, L - 1, 4 * Cn)
     if bool(torch.isnan(x).any()):
         lead = x.shape[:-2]
         series = x.transpose(-1, -2).reshape(-1, L)

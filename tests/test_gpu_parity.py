@@ -637,3 +637,33 @@ def test_ists_neuralsde_default_srk_on_cuda():
     with torch.no_grad():
         out, z = model(torch.from_numpy(pr['coeffs']).to(DEV), torch.from_numpy(pr['times']).to(DEV), options={'seed': 3})
     assert out.shape == (10, 9, 2) and z.shape == (10, 9, 16) and torch.isfinite(z).all()
+
+
+# ---- spline coefficient construction on the GPU (A11 / A12) -----------------------------------------------
+@pytest.mark.parametrize('case', G1_CASES)
+def test_natural_spline_coeffs_hip_vs_reference_golden(case):
+    g = group(SPL, f'G1/{case}/f32')
+    out = S.controldiffeq.natural_cubic_spline_coeffs(torch.from_numpy(g['times']).to(DEV), torch.from_numpy(g['X']).to(DEV))
+    for got, name in zip(out, ('a', 'b', 'two_c', 'three_d')):
+        assert got.shape == g[name].shape
+        np.testing.assert_allclose(got.cpu().numpy(), g[name], rtol=2e-5, atol=2e-5, err_msg=name)
+
+
+def test_spline_construction_hip_vs_oracle_large():
+    rng = np.random.default_rng(8)
+    B, L, C = 257, 72, 9
+    times = np.cumsum(rng.uniform(0.5, 1.5, L)).astype(np.float32)
+    X = (rng.standard_normal((B, L, C)) * 0.3).cumsum(1).astype(np.float32)
+    X[rng.random((B, L, C)) < 0.35] = np.nan
+    X[0, :, 0] = np.nan
+    X[1, 1:, 1] = np.nan
+    Xd, td = torch.from_numpy(X).to(DEV), torch.from_numpy(times).to(DEV)
+    nat = torch.cat(S.controldiffeq.natural_cubic_spline_coeffs(td, Xd), dim=-1).cpu().numpy()
+    ref = np.concatenate(O.natural_cubic_spline_coeffs(times.astype(np.float64), X.astype(np.float64)), axis=-1)
+    np.testing.assert_allclose(nat, ref, rtol=2e-4, atol=2e-4)
+    her = S.torchcde.hermite_cubic_coefficients_with_backward_differences(Xd, td).cpu().numpy()
+    ref_h = O.hermite_cubic_coefficients_with_backward_differences(X.astype(np.float64), times.astype(np.float64))
+    np.testing.assert_allclose(her, ref_h, rtol=2e-4, atol=2e-4)
+    # the CPU tensor-op construction (host path for CPU tensors) agrees too
+    nat_cpu = torch.cat(S.controldiffeq.natural_cubic_spline_coeffs(torch.from_numpy(times), torch.from_numpy(X)), dim=-1)
+    np.testing.assert_allclose(nat, nat_cpu.numpy(), rtol=2e-4, atol=2e-4)
