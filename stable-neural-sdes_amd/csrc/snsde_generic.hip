@@ -46,20 +46,7 @@ __global__ void snsde_time_table_kernel(const float* __restrict__ params, const 
     extern __shared__ float hbuf[];
     const int n = blockIdx.x;   // one block per table row (a solver step, or an SRK stage time)
     const float sn = step_tab[(size_t)n * row_stride + sin_col], cs = step_tab[(size_t)n * row_stride + sin_col + 1];
-    const bool two = (no == 16 || no == 17);
-    for (int j = threadIdx.x; j < H; j += blockDim.x) {
-        const float v = fmaf(cs, params[nt0.src_w + 2 * j + 1], sn * params[nt0.src_w + 2 * j]) + params[nt0.src_b + j];
-        if (two) hbuf[j] = fmaxf(v, 0.0f);
-        else gt[n * H + j] = v;
-    }
-    if (!two) return;
-    __syncthreads();
-    for (int j = threadIdx.x; j < H; j += blockDim.x) {
-        float acc = 0.0f;
-        const float* w = params + nt1.src_w + (size_t)j * H;
-        for (int k = 0; k < H; ++k) acc = fmaf(hbuf[k], w[k], acc);
-        gt[n * H + j] = fmaxf(acc + params[nt1.src_b + j], 0.0f);
-    }
+    snsde_time_table_row(params, sn, cs, gt + (size_t)n * H, nt0, nt1, H, no, hbuf);
 }
 
 struct GenericArgs {

@@ -131,4 +131,25 @@ __device__ __forceinline__ void snsde_philox_normal4(uint64_t seed, uint32_t row
     z[2] = rb * __builtin_amdgcn_cosf(ud); z[3] = rb * __builtin_amdgcn_sinf(ud);
 }
 
+// Time-only part of the diffusion for noise_option 12,13,16,17 (neuralsde.py:266-277), one table row:
+// gt[j] = noise_t([sn, cs])[j] (relu applied for 16/17).  Block-cooperative; hbuf = H floats of LDS.
+__device__ __forceinline__ void snsde_time_table_row(const float* __restrict__ params, float sn, float cs,
+                                                     float* __restrict__ gt, const SnsdeLayer& nt0, const SnsdeLayer& nt1,
+                                                     int H, int no, float* hbuf) {
+    const bool two = (no == 16 || no == 17);
+    for (int j = threadIdx.x; j < H; j += blockDim.x) {
+        const float v = fmaf(cs, params[nt0.src_w + 2 * j + 1], sn * params[nt0.src_w + 2 * j]) + params[nt0.src_b + j];
+        if (two) hbuf[j] = fmaxf(v, 0.0f);
+        else gt[j] = v;
+    }
+    if (!two) return;
+    __syncthreads();
+    for (int j = threadIdx.x; j < H; j += blockDim.x) {
+        float acc = 0.0f;
+        const float* w = params + nt1.src_w + (size_t)j * H;
+        for (int k = 0; k < H; ++k) acc = fmaf(hbuf[k], w[k], acc);
+        gt[j] = fmaxf(acc + params[nt1.src_b + j], 0.0f);
+    }
+}
+
 #endif  // __HIPCC__

@@ -67,9 +67,21 @@ __global__ void snsde_mfma_pack_kernel(const float* __restrict__ params, float* 
     }
 }
 
+// One "prepare" launch: blockIdx.y in {0,1} = the two folded products F = E[:, col:col+H] . W (one block per
+// output row f, lanes over the K columns, coalesced reads of W rows), blockIdx.y == 2 = the time-only diffusion
+// table (one block per solver step).
 __global__ void snsde_fold_kernel(const float* __restrict__ params, float* __restrict__ ws, FoldJob job) {
     extern __shared__ float erow[];
-    const int f = blockIdx.x, pc = blockIdx.y, H = job.H;
+    const int pc = blockIdx.y, H = job.H;
+    if (pc == 2) {
+        const int n = blockIdx.x;
+        if (!job.tab_on || n >= job.n_steps) return;
+        const float sn = job.step_tab[(size_t)n * SNSDE_STEP_STRIDE + 2], cs = job.step_tab[(size_t)n * SNSDE_STEP_STRIDE + 3];
+        snsde_time_table_row(params, sn, cs, ws + job.tab_off + (size_t)n * H, job.nt0, job.nt1, H, job.no, erow);
+        return;
+    }
+    const int f = blockIdx.x;
+    if (!job.fold_on || f >= H || pc >= job.n_pieces) return;
     const float* e = params + job.emb_w + (size_t)f * 2 * H;
     for (int j = threadIdx.x; j < 2 * H; j += blockDim.x) erow[j] = e[j];
     __syncthreads();
@@ -77,9 +89,16 @@ __global__ void snsde_fold_kernel(const float* __restrict__ params, float* __res
     const int K = job.K[pc];
     const float* ec = erow + job.col[pc];
     for (int k = threadIdx.x; k < K; k += blockDim.x) {
-        float acc = 0.0f;
-        for (int j = 0; j < H; ++j) acc = fmaf(ec[j], W[(size_t)j * K + k], acc);
-        ws[job.tmp[pc] + f * K + k] = acc;
+        float a0 = 0.0f, a1 = 0.0f, a2 = 0.0f, a3 = 0.0f;   // four independent chains hide the load latency
+        int j = 0;
+        for (; j + 3 < H; j += 4) {
+            a0 = fmaf(ec[j], W[(size_t)j * K + k], a0);
+            a1 = fmaf(ec[j + 1], W[(size_t)(j + 1) * K + k], a1);
+            a2 = fmaf(ec[j + 2], W[(size_t)(j + 2) * K + k], a2);
+            a3 = fmaf(ec[j + 3], W[(size_t)(j + 3) * K + k], a3);
+        }
+        for (; j < H; ++j) a0 = fmaf(ec[j], W[(size_t)j * K + k], a0);
+        ws[job.tmp[pc] + f * K + k] = (a0 + a1) + (a2 + a3);
     }
     if (pc == 0 && threadIdx.x < 64) {   // folded bias: b_emb + E1 b_in + E2 b_init (one wave, shuffle reduction)
         float acc = 0.0f;
@@ -215,21 +234,24 @@ int snsde_mfma_launch(const snsde_solve* s, const SnsdeNet& net, hipStream_t str
         job.fold_b_in = p.fold_b_in; job.fold_b_init = p.fold_b_init; job.fold_b_emb = p.fold_b_emb;
         job.fold_emb_w = p.fold_emb_w;
         job.fold_bias_tmp = p.fold_bias_tmp;
-        if (p.FOLD) {
+        if (p.FOLD || p.gt_off >= 0) {   // folded products + time-only diffusion table in ONE launch
             FoldJob fj{};
-            fj.emb_w = p.fold_emb_w; fj.H = p.H; fj.n_pieces = 2;
-            for (int i = 0; i < 2; ++i) {
-                fj.src_w[i] = p.layer[i].src_w; fj.K[i] = p.layer[i].K; fj.col[i] = p.layer[i].fold_col;
-                fj.tmp[i] = p.layer[i].fold_tmp;
+            fj.fold_on = p.FOLD; fj.H = p.H; fj.n_pieces = 2;
+            if (p.FOLD) {
+                fj.emb_w = p.fold_emb_w;
+                for (int i = 0; i < 2; ++i) {
+                    fj.src_w[i] = p.layer[i].src_w; fj.K[i] = p.layer[i].K; fj.col[i] = p.layer[i].fold_col;
+                    fj.tmp[i] = p.layer[i].fold_tmp;
+                }
+                fj.b_in = p.fold_b_in; fj.b_init = p.fold_b_init; fj.b_emb = p.fold_b_emb; fj.bias_tmp = p.fold_bias_tmp;
             }
-            fj.b_in = p.fold_b_in; fj.b_init = p.fold_b_init; fj.b_emb = p.fold_b_emb; fj.bias_tmp = p.fold_bias_tmp;
-            hipLaunchKernelGGL(snsde_fold_kernel, dim3(p.H, 2), dim3(256), 2 * p.H * sizeof(float), stream, s->params,
-                               ws, fj);
+            fj.tab_on = p.gt_off >= 0; fj.tab_off = p.gt_off; fj.n_steps = s->n_steps; fj.no = s->model.noise_option;
+            fj.nt0 = net.nt0; fj.nt1 = net.nt1; fj.step_tab = s->step_tab;
+            const int gx = fj.tab_on && s->n_steps > p.H ? s->n_steps : p.H;
+            hipLaunchKernelGGL(snsde_fold_kernel, dim3(gx, fj.tab_on ? 3 : 2), dim3(256), 2 * p.H * sizeof(float), stream,
+                               s->params, ws, fj);
         }
         hipLaunchKernelGGL(snsde_mfma_pack_kernel, dim3(16, p.n_layers), dim3(256), 0, stream, s->params, ws, job);
-        if (p.gt_off >= 0)
-            snsde_time_table_launch(s->params, s->step_tab, ws + p.gt_off, net.nt0, net.nt1, p.H, s->model.noise_option,
-                                    s->n_steps, stream);
     }
     MfmaArgs a{};
     a.params = s->params; a.ws = ws; a.coeffs = s->coeffs; a.step_tab = s->step_tab; a.out_step = s->out_step;
@@ -268,7 +290,7 @@ int snsde_mfma_backward_launch(const snsde_backward* b, const SnsdeNet& net, hip
     float* ws = static_cast<float*>(b->workspace);
     if (p.emb) {   // first_y = emb[:, 0:H] . linear_in  (all columns; the pack step picks the y columns)
         FoldJob fj{};
-        fj.emb_w = net.emb.src_w; fj.H = p.H; fj.n_pieces = 1;
+        fj.emb_w = net.emb.src_w; fj.H = p.H; fj.n_pieces = 1; fj.fold_on = 1;
         fj.src_w[0] = net.in.src_w; fj.K[0] = net.in.K; fj.col[0] = 0; fj.tmp[0] = p.fold_tmp;
         fj.b_in = net.in.src_b; fj.b_init = net.init.src_b; fj.b_emb = net.emb.src_b;
         fj.bias_tmp = p.fold_tmp + p.H * net.in.K;

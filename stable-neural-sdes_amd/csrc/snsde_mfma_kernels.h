@@ -56,6 +56,10 @@ struct FoldJob {
     int32_t emb_w, H, n_pieces;
     int32_t src_w[2], K[2], col[2], tmp[2];
     int32_t b_in, b_init, b_emb, bias_tmp;
+    // time-only diffusion table built by the same launch (blockIdx.y == 2): gt[n][H] for n < n_steps
+    int32_t tab_on, tab_off, n_steps, no, fold_on;
+    SnsdeLayer nt0, nt1;
+    const float* step_tab;
 };
 
 struct MfmaArgs {
