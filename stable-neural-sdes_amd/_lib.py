@@ -105,8 +105,15 @@ def check(code, what=''):
         raise SnsdeError(code, what)
 
 
+_LAYOUT_CACHE = {}
+
+
 def param_layout(model):
-    """[(name, offset, shape)] of the flat parameter block, in state_dict order."""
+    """[(name, offset, shape)] of the flat parameter block, in state_dict order (memoised per model shape)."""
+    key = (model.input_channels, model.hidden_channels, model.hidden_hidden_channels, model.num_hidden_layers,
+           model.input_option, model.noise_option)
+    if key in _LAYOUT_CACHE:
+        return _LAYOUT_CACHE[key]
     L = lib()
     n = L.snsde_param_count(C.byref(model))
     check(min(n, 0), 'snsde_param_count')
@@ -118,4 +125,5 @@ def param_layout(model):
         name = buf.value.decode()
         shape = (rows.value, cols.value) if cols.value > 0 else (rows.value,)
         out.append((name, off.value, shape))
-    return out, int(L.snsde_param_numel(C.byref(model)))
+    _LAYOUT_CACHE[key] = (out, int(L.snsde_param_numel(C.byref(model))))
+    return _LAYOUT_CACHE[key]

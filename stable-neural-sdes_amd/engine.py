@@ -28,6 +28,20 @@ def recognise(sde):
     need = ('input_option', 'noise_option', 'hidden_channels', 'input_channels', 'coeffs', 'times')
     if not all(hasattr(sde, a) for a in need) or not hasattr(sde, 'named_parameters'):
         return None
+    cached = getattr(sde, '_snsde_rec', None)     # (key, result): parameter names/shapes are fixed after construction
+    key = (sde.input_option, sde.noise_option, sde.hidden_channels, sde.input_channels, len(sde._parameters),
+           len(sde._modules))
+    if cached is not None and cached[0] == key:
+        return cached[1]
+    result = _recognise(sde)
+    try:
+        object.__setattr__(sde, '_snsde_rec', (key, result))
+    except Exception:
+        pass
+    return result
+
+
+def _recognise(sde):
     if getattr(sde, 'sde_type', 'ito') != 'ito' or getattr(sde, 'noise_type', 'diagonal') != 'diagonal':
         return None
     params = dict(sde.named_parameters())

@@ -198,17 +198,24 @@ def _parameter_gradients_gemm(sde, call, grid, adj, delta):
     hh = torch.from_numpy(grid.step_tab[:, 1].copy()).to(dev)
     Y = call.traj[:-1]
     # ---- drift side -----------------------------------------------------------------------------------
-    d_out = delta[:, 0].reshape(NB, H)
-    grads['linear_out.weight'] = d_out.t() @ act[:, nhid].reshape(NB, H)
-    grads['linear_out.bias'] = d_out.sum(0)
+    def wgrad(d3, x3):
+        # sum_{n,b} d[n,b,:]^T x[n,b,:] as a batched GEMM over the steps (K = B per batch entry) + a small sum:
+        # ~5x faster than one (H x N*B)(N*B x K) GEMM, whose reduction dimension is 1e5 long
+        return torch.bmm(d3.transpose(1, 2), x3).sum(0)
+
+    d_out = delta[:, 0]
+    grads['linear_out.weight'] = wgrad(d_out, act[:, nhid])
+    grads['linear_out.bias'] = d_out.sum((0, 1))
     for l in range(nhid):
-        d_l = delta[:, nhid - l].reshape(NB, H)
-        grads[f'linears.{l}.weight'] = d_l.t() @ act[:, l].reshape(NB, H)
-        grads[f'linears.{l}.bias'] = d_l.sum(0)
-    d0 = delta[:, nhid + 1].reshape(NB, H)            # w.r.t. the pre-activation of z0
-    col = t0.repeat_interleave(B).unsqueeze(-1)
-    tau = torch.cat([col.sin(), col.cos()], dim=-1)
-    yin = torch.cat([tau, Y.reshape(NB, H)], dim=-1) if io in (3, 4, 5, 6) else Y.reshape(NB, H)
+        d_l = delta[:, nhid - l]
+        grads[f'linears.{l}.weight'] = wgrad(d_l, act[:, l])
+        grads[f'linears.{l}.bias'] = d_l.sum((0, 1))
+    d0 = delta[:, nhid + 1]                           # (N, B, H) w.r.t. the pre-activation of z0
+    if io in (3, 4, 5, 6):
+        tau = torch.stack([t0.sin(), t0.cos()], dim=-1).unsqueeze(1).expand(N, B, 2)
+        yin = torch.cat([tau, Y], dim=-1)
+    else:
+        yin = Y
     if io in (2, 4, 6):
         idx = torch.from_numpy(grid.step_tab[:, 5].copy().view('int32').astype('int64')).to(dev)
         frac = torch.from_numpy(grid.step_tab[:, 4].copy()).to(dev).view(N, 1, 1)
@@ -216,19 +223,19 @@ def _parameter_gradients_gemm(sde, call, grid, adj, delta):
         Cn = coeffs.shape[-1] // 4
         rows = coeffs[:, idx, :].permute(1, 0, 2)
         a_, b_, c2, d3 = (rows[..., k * Cn:(k + 1) * Cn] for k in range(4))
-        Xraw = (a_ + (b_ + (0.5 * c2 + d3 * frac / 3) * frac) * frac).reshape(NB, Cn)
-        yy = torch.addmm(P['linear_in.bias'], yin, P['linear_in.weight'].t())
-        Xt = torch.addmm(P['initial_network.bias'], Xraw, P['initial_network.weight'].t())
-        grads['emb.weight'] = torch.cat([d0.t() @ yy, d0.t() @ Xt], dim=1)
-        grads['emb.bias'] = d0.sum(0)
-        dcat = d0 @ P['emb.weight']
-        d_in, d_x = dcat[:, :H], dcat[:, H:]
-        grads['initial_network.weight'] = d_x.t() @ Xraw
-        grads['initial_network.bias'] = d_x.sum(0)
+        Xraw = a_ + (b_ + (0.5 * c2 + d3 * frac / 3) * frac) * frac                     # (N, B, C)
+        yy = torch.baddbmm(P['linear_in.bias'], yin, P['linear_in.weight'].t().expand(N, -1, -1))
+        Xt = torch.baddbmm(P['initial_network.bias'], Xraw, P['initial_network.weight'].t().expand(N, -1, -1))
+        grads['emb.weight'] = torch.cat([wgrad(d0, yy), wgrad(d0, Xt)], dim=1)
+        grads['emb.bias'] = d0.sum((0, 1))
+        dcat = torch.matmul(d0, P['emb.weight'])
+        d_in, d_x = dcat[..., :H], dcat[..., H:]
+        grads['initial_network.weight'] = wgrad(d_x, Xraw)
+        grads['initial_network.bias'] = d_x.sum((0, 1))
     else:
         d_in = d0
-    grads['linear_in.weight'] = d_in.t() @ yin
-    grads['linear_in.bias'] = d_in.sum(0)
+    grads['linear_in.weight'] = wgrad(d_in, yin)
+    grads['linear_in.bias'] = d_in.sum((0, 1))
     # ---- diffusion side: g = tanh(sigmoid(theta) * nan_to_num(raw)), raw = s_n (no 12,16) or s_n * y (13,17) ----
     if no in (12, 13, 16, 17):
         sig = P['theta'].sigmoid()
