@@ -158,7 +158,9 @@ int    snsde_solve_forward(const snsde_solve* s, void* hip_stream);
  * trajectory and writes EVERY a_n (adj[0] = dL/dy0).  Parameter gradients are the batched reduction
  * sum_{n,rows} a_{n+1} . d(f h + g dW)/d theta over (traj, adj, dW_used), a plain GEMM-shaped job done by the host
  * (engine.py) with library GEMMs.  Forward must have been run with traj, dW_out and act_save set.
- * Euler only; covered configurations = the MFMA fast path (snsde_backward_supported). */
+ * snsde_backward_supported: 1 = MFMA adjoint kernel (forward on the MFMA path with act_save; Euler; fills delta_save),
+ * 2 = generic adjoint kernel (forward on SNSDE_KERNEL_GENERIC, traj + dW_out only; Euler and Milstein, any dims,
+ * noise_option 0..13, 16, 17; delta_save must be NULL), 0 = none. */
 typedef struct snsde_backward {
     snsde_solve  fwd;        /* the forward descriptor (traj, dW_out, act_save filled by the forward)      */
     const float* grad_ys;    /* device (T, B, H): dL/d ys                                                 */
@@ -171,7 +173,7 @@ typedef struct snsde_backward {
 } snsde_backward;
 
 int    snsde_act_slots(const snsde_model* m);             /* activation tensors saved per step, or <0     */
-int    snsde_backward_supported(const snsde_solve* s);    /* 1 / 0                                         */
+int    snsde_backward_supported(const snsde_solve* s);    /* 1 / 2 / 0, see above                          */
 size_t snsde_backward_workspace_bytes(const snsde_backward* b);
 int    snsde_solve_backward(const snsde_backward* b, void* hip_stream);
 

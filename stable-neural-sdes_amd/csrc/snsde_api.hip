@@ -379,7 +379,10 @@ int snsde_backward_supported(const snsde_solve* s) {
     if (!s || validate_model(&s->model)) return 0;
     SnsdeNet net;
     if (snsde_build_net(s->model, s->n_steps, &net)) return 0;
-    return snsde_mfma_backward_supported(s, net) ? 1 : 0;
+    // 1: MFMA adjoint kernel (forward on the MFMA path with act_save); 2: generic adjoint kernel (forward on the
+    // generic kernel, traj + dW_out only); 0: no fused backward for this configuration
+    if (snsde_mfma_backward_supported(s, net) && s->kernel != SNSDE_KERNEL_GENERIC) return 1;
+    return snsde_generic_backward_supported(s) ? 2 : 0;
 }
 
 size_t snsde_backward_workspace_bytes(const snsde_backward* b) {
@@ -393,12 +396,17 @@ int snsde_solve_backward(const snsde_backward* b, void* hip_stream) {
     if (!b) return SNSDE_ERR_NULL;
     int rc = validate_solve(&b->fwd, false);
     if (rc) return rc;
-    if (!b->grad_ys || !b->adj || !b->workspace || !b->fwd.traj || !b->fwd.dW_out || !b->fwd.act_save)
-        return SNSDE_ERR_NULL;
+    if (!b->grad_ys || !b->adj || !b->workspace || !b->fwd.traj || !b->fwd.dW_out) return SNSDE_ERR_NULL;
     SnsdeNet net;
     rc = snsde_build_net(b->fwd.model, b->fwd.n_steps, &net);
     if (rc) return rc;
-    if (!snsde_mfma_backward_supported(&b->fwd, net)) return SNSDE_ERR_UNSUPPORTED;
+    const int mode = snsde_backward_supported(&b->fwd);
+    if (mode == 0) return SNSDE_ERR_UNSUPPORTED;
+    if (mode == 2) {
+        if (b->delta_save) return SNSDE_ERR_UNSUPPORTED;    // the generic adjoint writes adjoints only
+        return snsde_generic_backward_launch(b, net, static_cast<hipStream_t>(hip_stream));
+    }
+    if (!b->fwd.act_save) return SNSDE_ERR_NULL;
     if (b->workspace_bytes < snsde_backward_workspace_bytes(b)) return SNSDE_ERR_WORKSPACE;
     return snsde_mfma_backward_launch(b, net, static_cast<hipStream_t>(hip_stream));
 }

@@ -514,6 +514,214 @@ __global__ void __launch_bounds__(GT) snsde_generic_srk_kernel(SrkArgs sa) {
     }
 }
 
+// =====================================================================================================
+// Generic adjoint (backward) kernel: discretise-then-optimise adjoint of the Euler / Milstein step for every
+// input_option and every noise_option whose diffusion is elementwise in y (0..13, 16, 17), any H / HH / C / NL.
+// Per step (last to first) a workgroup re-evaluates the drift chain on its GR rows from the saved state y_n
+// (activations stay in LDS: one buffer per layer), applies the elementwise derivatives of f, g and the Milstein
+// term to the adjoint, and walks the chain backwards with the ORIGINAL (out, in) weight layout
+// (delta_in[k] = sum_n W[n][k] delta_out[n]: lanes over k read W rows coalesced).  Output: every adjoint a_n.
+// =====================================================================================================
+struct AdjArgs {
+    GenericArgs g;          // params, packed forward weights (ws), coeffs, step table, dims
+    const float* traj;      // (N+1, B, H)
+    const float* dW_used;   // (N, B, H)
+    const float* grad_ys;   // (T, B, H)
+    float* adj;             // (N+1, B, H)
+    int32_t nbuf;           // activation buffers: n_hid + 1
+};
+
+// out[r][k] (+)= sum_n W[n][k] * in[r][n]  for k in [k0, k0 + Kn): W row-major (N, ldk)
+__device__ void dense_T(const float* __restrict__ W, int ldk, int k0, int Kn, int N, const float* in, int ldin, float* out,
+                        int ldout) {
+    for (int k = threadIdx.x; k < Kn; k += GT) {
+        float acc[GR];
+#pragma unroll
+        for (int r = 0; r < GR; ++r) acc[r] = 0.0f;
+        const float* wp = W + k0 + k;
+        for (int n = 0; n < N; ++n) {
+            const float w = wp[(size_t)n * ldk];
+#pragma unroll
+            for (int r = 0; r < GR; ++r) acc[r] = fmaf(in[r * ldin + n], w, acc[r]);
+        }
+#pragma unroll
+        for (int r = 0; r < GR; ++r) out[r * ldout + k] = acc[r];
+    }
+}
+
+__global__ void __launch_bounds__(GT) snsde_generic_adjoint_kernel(AdjArgs aa) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const GenericArgs& a = aa.g;
+    const SnsdeDims& d = a.d;
+    const SnsdeNet& net = a.net;
+    const int H = d.H, C = d.C, B = d.B, io = d.io, no = d.no;
+    const int ldy = a.ldy, ldw = a.ldw, ldx = a.ldx;
+    const int nact = net.n_hid + 1;                 // z0, hidden outputs (post-relu)
+    float* ybuf = lds;                              // y_n | sin, cos
+    float* xbuf = ybuf + GR * ldy;
+    float* cat = xbuf + GR * ldx;                   // [yy | Xt] (emb) / scratch
+    float* act = cat + GR * ldw;                    // act[l][GR][ldw], l < nact
+    float* zo = act + (size_t)nact * GR * ldw;      // zout, later delta ping
+    float* dl = zo + GR * ldw;                      // delta pong
+    float* abuf = dl + GR * ldw;                    // adjoint a (GR x ldy)
+    float* ayb = abuf + GR * ldy;                   // a_y accumulator
+    const int lds_floats = GR * (3 * ldy + ldx + (3 + nact) * ldw);
+    const int tid = threadIdx.x, row0 = blockIdx.x * GR;
+    for (int i = tid; i < lds_floats; i += GT) lds[i] = 0.0f;
+    __syncthreads();
+    const float sig_theta = snsde_sigmoid(a.params[net.off_theta]);
+    const float exp_sigma = (net.off_sigma >= 0) ? expf(a.params[net.off_sigma]) : 0.0f;
+    const bool uses_x = (io == 0 || io == 2 || io == 4 || io == 6);
+    const bool uses_emb = (io == 2 || io == 4 || io == 6);
+    const bool geo = (io == 5 || io == 6);
+    const float* gt = a.ws + (net.gt_tab >= 0 ? net.gt_tab : 0);
+    const size_t BH = (size_t)B * H;
+    const float mil = (d.method == SNSDE_MILSTEIN) ? 0.5f : 0.0f;
+
+    auto for_elems = [&](auto&& fn) {
+        for (int i = tid; i < GR * H; i += GT) {
+            const int r = i / H, j = i - r * H;
+            fn(r, j, row0 + r);
+        }
+        __syncthreads();
+    };
+
+    for (int n = d.N - 1; n >= 0; --n) {
+        const float* st = a.step_tab + (size_t)n * SNSDE_STEP_STRIDE;
+        const float t0 = st[0], h = st[1], frac = st[4];
+        const int idx = __float_as_int(st[5]);
+        const int nout = __float_as_int(st[8]), kfirst = __float_as_int(st[9]);
+        // adjoint of y_{n+1}: add the output gradients emitted after step n; keep the y_n share in ayb
+        for_elems([&](int r, int j, int row) {
+            float av = abuf[r * ldy + j], carry = 0.0f;
+            if (row < B) {
+                for (int k = kfirst; k < kfirst + nout; ++k) {
+                    const float w0 = a.out_w[2 * k], w1 = a.out_w[2 * k + 1];
+                    const float gk = aa.grad_ys[(size_t)(k + 1) * BH + (size_t)row * H + j];
+                    if (w0 == 0.0f) av += gk; else { av = fmaf(w1, gk, av); carry = fmaf(w0, gk, carry); }
+                }
+                aa.adj[(size_t)(n + 1) * BH + (size_t)row * H + j] = av;
+                ybuf[r * ldy + j] = aa.traj[(size_t)n * BH + (size_t)row * H + j];
+            }
+            abuf[r * ldy + j] = av;
+            ayb[r * ldy + j] = carry;
+        });
+        if (tid < GR) { ybuf[tid * ldy + H] = st[2]; ybuf[tid * ldy + H + 1] = st[3]; }
+        if (uses_x) {
+            for (int i = tid; i < GR * C; i += GT) {
+                const int r = i / C, c = i - r * C, row = row0 + r;
+                float v = 0.0f;
+                if (row < B) {
+                    const float* cp = a.coeffs + ((size_t)row * (d.L - 1) + idx) * (4 * C) + c;
+                    v = snsde_spline_eval(cp[0], cp[C], cp[2 * C], cp[3 * C], frac);
+                }
+                xbuf[r * ldx + c] = v;
+            }
+        }
+        __syncthreads();
+        // ---- forward re-evaluation, activations kept ----
+        float* z0 = act;
+        if (io == 0) dense(a.params, a.ws, net.init, xbuf, ldx, z0, ldw, true);
+        else if (!uses_emb) dense(a.params, a.ws, net.in, ybuf, ldy, z0, ldw, true);
+        else {
+            dense(a.params, a.ws, net.in, ybuf, ldy, cat, ldw, false);
+            dense(a.params, a.ws, net.init, xbuf, ldx, cat + H, ldw, false);
+            __syncthreads();
+            dense(a.params, a.ws, net.emb, cat, ldw, z0, ldw, true);
+        }
+        __syncthreads();
+        for (int l = 0; l < net.n_hid; ++l) {
+            dense(a.params, a.ws, net.hid[l], act + (size_t)l * GR * ldw, ldw, act + (size_t)(l + 1) * GR * ldw, ldw, true);
+            __syncthreads();
+        }
+        dense(a.params, a.ws, net.out, act + (size_t)net.n_hid * GR * ldw, ldw, zo, ldw, false);
+        __syncthreads();
+        // ---- elementwise derivatives: delta_zout -> zo (in place), direct y terms -> ayb ----
+        for_elems([&](int r, int j, int row) {
+            const float y = ybuf[r * ldy + j], z = zo[r * ldw + j], av = abuf[r * ldy + j];
+            const float dw = (row < B) ? aa.dW_used[(size_t)n * BH + (size_t)row * H + j] : 0.0f;
+            float ty = 1.0f, zt = z;
+            if (geo) { ty = tanhf(y); zt = z * ty; }
+            const float f = tanhf(zt);
+            const float dzt = av * h * (1.0f - f * f);
+            float accy = ayb[r * ldy + j] + av;
+            float dz = dzt;
+            if (geo) { dz = dzt * ty; accy = fmaf(dzt * z, 1.0f - ty * ty, accy); }
+            // diffusion: raw(y), raw', raw''
+            float raw = 0.0f, r1 = 0.0f, r2 = 0.0f;
+            switch (no) {
+                case 0: break;
+                case 1: raw = exp_sigma; break;
+                case 2: raw = exp_sigma * t0; break;
+                case 3: raw = exp_sigma * y; r1 = exp_sigma; break;
+                case 4: raw = expf(a.params[net.off_sigma_diag + j]); break;
+                case 5: raw = expf(a.params[net.off_sigma_diag + j]) * t0; break;
+                case 6: r1 = expf(a.params[net.off_sigma_diag + j]); raw = r1 * y; break;
+                case 7: raw = sqrtf(y); r1 = 0.5f / raw; r2 = -0.25f / (raw * y); break;
+                case 8: raw = y * y * y; r1 = 3.0f * y * y; r2 = 6.0f * y; break;
+                case 9: raw = snsde_sigmoid(y); r1 = raw * (1.0f - raw); r2 = r1 * (1.0f - 2.0f * raw); break;
+                case 10: raw = fmaxf(y, 0.0f); r1 = y > 0.0f ? 1.0f : 0.0f; break;
+                case 11: raw = t0 * y; r1 = t0; break;
+                case 12: case 16: raw = gt[(size_t)n * H + j]; break;
+                case 13: case 17: r1 = gt[(size_t)n * H + j]; raw = r1 * y; break;
+                default: break;
+            }
+            const bool fin = (raw - raw == 0.0f);
+            const float g = tanhf(sig_theta * snsde_nan_to_num(raw));
+            if (fin) {
+                const float sech = 1.0f - g * g;
+                const float g1 = sech * sig_theta * r1;
+                accy = fmaf(av * dw, g1, accy);
+                if (mil != 0.0f) {
+                    const float g2 = sech * sig_theta * r2 - 2.0f * g * g1 * sig_theta * r1;
+                    accy = fmaf(av * mil * (g1 * g1 + g * g2), dw * dw - h, accy);
+                }
+            }
+            zo[r * ldw + j] = dz;
+            ayb[r * ldy + j] = accy;
+        });
+        // ---- transposed chain ----
+        float* cur = zo;
+        float* oth = dl;
+        dense_T(a.params + net.out.src_w, net.out.K, 0, net.out.K, net.out.N, cur, ldw, oth, ldw);
+        __syncthreads();
+        for (int l = net.n_hid; l >= 0; --l) {
+            // oth holds dL/d(post-relu z_l): mask with z_l > 0, then move one layer down
+            const float* zl = act + (size_t)l * GR * ldw;
+            const int width = (l == 0 && io != 0) ? net.in.N : (l == 0 ? H : net.hid[l - 1].N);
+            for (int i = tid; i < GR * width; i += GT) {
+                const int r = i / width, j = i - r * width;
+                if (!(zl[r * ldw + j] > 0.0f)) oth[r * ldw + j] = 0.0f;
+            }
+            __syncthreads();
+            float* t = cur; cur = oth; oth = t;     // cur = dL/d(pre-activation z_l)
+            if (l > 0) {
+                dense_T(a.params + net.hid[l - 1].src_w, net.hid[l - 1].K, 0, net.hid[l - 1].K, net.hid[l - 1].N, cur, ldw, oth, ldw);
+                __syncthreads();
+            }
+        }
+        // first stage: cur = dL/d(pre-activation of z0)
+        if (io != 0) {
+            const float* din = cur;
+            if (uses_emb) {   // through emb to the yy half of the concatenation
+                dense_T(a.params + net.emb.src_w, net.emb.K, 0, H, net.emb.N, cur, ldw, oth, ldw);
+                __syncthreads();
+                din = oth;
+            }
+            float* dst = (din == oth) ? cur : oth;
+            dense_T(a.params + net.in.src_w, net.in.K, net.in.tshift, H, net.in.N, din, ldw, dst, ldw);
+            __syncthreads();
+            for_elems([&](int r, int j, int) { abuf[r * ldy + j] = ayb[r * ldy + j] + dst[r * ldw + j]; });
+        } else {
+            for_elems([&](int r, int j, int) { abuf[r * ldy + j] = ayb[r * ldy + j]; });
+        }
+    }
+    for (int i = tid; i < GR * H; i += GT) {      // ys[0] = y0
+        const int r = i / H, j = i - r * H, row = row0 + r;
+        if (row < B) aa.adj[(size_t)row * H + j] = abuf[r * ldy + j] + aa.grad_ys[(size_t)row * H + j];
+    }
+}
+
 __global__ void snsde_spline_kernel(const float* __restrict__ coeffs, int B, int L, int C, int index, float frac,
                                     int derivative, float* __restrict__ out) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -601,6 +809,43 @@ int snsde_generic_launch(const snsde_solve* s, const SnsdeNet& net, hipStream_t 
     }
     const int grid = (s->batch + GR - 1) / GR;
     hipLaunchKernelGGL(snsde_generic_kernel, dim3(grid), dim3(GT), lds_bytes, stream, a);
+    return hipGetLastError() == hipSuccess ? SNSDE_OK : SNSDE_ERR_LAUNCH;
+}
+
+bool snsde_generic_backward_supported(const snsde_solve* s) {
+    const int no = s->model.noise_option;
+    if (s->method != SNSDE_EULER && s->method != SNSDE_MILSTEIN) return false;
+    if (no == 14 || no == 15 || no == 18 || no == 19) return false;        // dense diffusion Jacobian: not yet
+    if (s->method == SNSDE_MILSTEIN && no == 7) return false;
+    return true;
+}
+
+// The adjoint kernel re-uses the packed forward weights and the time-only diffusion table of the FORWARD workspace.
+int snsde_generic_backward_launch(const snsde_backward* b, const SnsdeNet& net, hipStream_t stream) {
+    const snsde_solve* s = &b->fwd;
+    const snsde_model& m = s->model;
+    AdjArgs aa;
+    GenericArgs& a = aa.g;
+    a.d = SnsdeDims{s->batch, m.hidden_channels, m.hidden_hidden_channels, m.input_channels, s->knots,
+                    m.num_hidden_layers, m.input_option, m.noise_option, s->n_steps, s->n_out, s->method};
+    a.net = net;
+    a.params = s->params; a.ws = static_cast<const float*>(s->workspace); a.coeffs = s->coeffs;
+    a.step_tab = s->step_tab; a.out_step = s->out_step; a.out_w = s->out_w; a.y0 = s->y0; a.dW = nullptr;
+    a.ys = nullptr; a.traj = nullptr; a.dW_out = nullptr; a.row_offset = 0; a.seed = 0; a.eval_mode = 0;
+    a.eval_f = nullptr; a.eval_g = nullptr;
+    const int H = m.hidden_channels, HH = m.hidden_hidden_channels;
+    a.ldy = round4(H + 2);
+    const int wmax = 2 * H > HH ? 2 * H : HH;
+    a.ldw = round4(wmax) + 4;
+    a.ldx = round4(m.input_channels);
+    aa.traj = s->traj; aa.dW_used = s->dW_out; aa.grad_ys = b->grad_ys; aa.adj = b->adj; aa.nbuf = net.n_hid + 1;
+    const size_t lds_bytes = (size_t)GR * (3 * a.ldy + a.ldx + (3 + net.n_hid + 1) * a.ldw) * sizeof(float);
+    if (lds_bytes > 160 * 1024) return SNSDE_ERR_LDS;
+    if (lds_bytes > 64 * 1024 &&
+        hipFuncSetAttribute(reinterpret_cast<const void*>(snsde_generic_adjoint_kernel),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes) != hipSuccess)
+        return SNSDE_ERR_LDS;
+    hipLaunchKernelGGL(snsde_generic_adjoint_kernel, dim3((s->batch + GR - 1) / GR), dim3(GT), lds_bytes, stream, aa);
     return hipGetLastError() == hipSuccess ? SNSDE_OK : SNSDE_ERR_LAUNCH;
 }
 

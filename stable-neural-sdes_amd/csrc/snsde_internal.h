@@ -50,6 +50,8 @@ int snsde_build_net(const snsde_model& m, int32_t n_steps, SnsdeNet* net);
 int snsde_generic_workspace_floats(const snsde_solve* s, const SnsdeNet& net, size_t* floats);
 int snsde_generic_launch(const snsde_solve* s, const SnsdeNet& net, hipStream_t stream, int eval_mode,
                          const float* eval_y, float* eval_f, float* eval_g, const float* step_row_dev);
+bool snsde_generic_backward_supported(const snsde_solve* s);
+int snsde_generic_backward_launch(const snsde_backward* b, const SnsdeNet& net, hipStream_t stream);
 int snsde_srk_launch(const snsde_solve* s, const SnsdeNet& net, hipStream_t stream);
 int snsde_time_table_launch(const float* params, const float* step_tab, float* gt, const SnsdeLayer& nt0,
                             const SnsdeLayer& nt1, int H, int no, int n_steps, hipStream_t stream);

@@ -206,20 +206,22 @@ class SolveCall:
 
 
 def backward_supported(call):
-    return bool(_lib.lib().snsde_backward_supported(C.byref(call.desc)))
+    """0 = no fused backward; 1 = MFMA adjoint kernel (needs save_act); 2 = generic adjoint kernel (forward must run
+    on the generic kernel; needs traj + dW_out only)."""
+    return int(_lib.lib().snsde_backward_supported(C.byref(call.desc)))
 
 
 def solve_backward(call, grad_ys, stream=None, save_delta=False):
     """Adjoint recursion over a finished training-mode solve (SolveCall with save_traj/save_dW/save_act):
     returns adj (N+1, B, H), adj[n] = dL/dy_n; adj[0] is the gradient w.r.t. y0."""
-    if call.traj is None or call.dW_out is None or call.act_save is None:
-        raise ValueError('backward needs a solve run with save_traj, save_dW and save_act')
+    if call.traj is None or call.dW_out is None:
+        raise ValueError('backward needs a solve run with save_traj and save_dW (and save_act on the MFMA path)')
     _check_f32('grad_ys', grad_ys, tuple(call.ys.shape))
     b = _lib.Backward()
     b.fwd = call.desc
     b.fwd.flags = call.base_flags
     adj = torch.empty_like(call.traj)
-    delta = torch.empty_like(call.act_save) if save_delta else None
+    delta = torch.empty_like(call.act_save) if (save_delta and call.act_save is not None) else None
     b.grad_ys, b.adj, b.delta_save = _ptr(grad_ys), _ptr(adj), _ptr(delta)
     nbytes = _lib.lib().snsde_backward_workspace_bytes(C.byref(b))
     ws = torch.empty(max(nbytes, 256), device=adj.device, dtype=torch.uint8)

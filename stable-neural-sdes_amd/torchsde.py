@@ -130,7 +130,7 @@ def _sdeint_hip(sde, rec, y0, ts, bm, method, dt, options):
         raise NotImplementedError("gradients through the fused SRK solve are not implemented; use method='euler' "
                                   "or options={'backend': 'torch'}")
     if needs_grad:
-        return _FusedEulerSolve.apply(sde, rec, coeffs, grid, times_host, dW, method, seed, options, y0,
+        return _FusedSolve.apply(sde, rec, coeffs, grid, times_host, dW, method, seed, options, y0,
                                       *[p for _, p in sde.named_parameters()])
     call = engine.SolveCall(model, flat, coeffs, grid, y0c, dW=dW, method=method, seed=seed,
                             row_offset=int(options.get('row_offset', 0)), kernel=options.get('kernel', 'auto'),
@@ -142,7 +142,7 @@ def _sdeint_hip(sde, rec, y0, ts, bm, method, dt, options):
     return ys.to(y0.dtype)
 
 
-class _FusedEulerSolve(torch.autograd.Function):
+class _FusedSolve(torch.autograd.Function):
     """Differentiable fused solve.  forward = the HIP solve in training mode (keeps every state, the increments
     used and the per-step activations); backward = the HIP adjoint recursion (snsde_solve_backward) for dL/dy0
     and every adjoint a_n, then ONE batched evaluation of a_{n+1} . (f h + g dW) over all (step, row) pairs
@@ -152,18 +152,22 @@ class _FusedEulerSolve(torch.autograd.Function):
     @staticmethod
     def forward(ctx, sde, rec, coeffs, grid, times_host, dW, method, seed, options, y0, *params):
         model, layout, numel = rec
-        if method != 'euler':
-            raise NotImplementedError("gradients through the fused solve are implemented for method='euler' only")
         flat = engine.flatten_params(sde, layout, numel, y0.device)
-        call = engine.SolveCall(model, flat, coeffs, grid, y0.detach().to(torch.float32).contiguous(), dW=dW,
-                                method=method, seed=seed, row_offset=int(options.get('row_offset', 0)),
-                                kernel=options.get('kernel', 'auto'), save_traj=True, save_dW=True, save_act=True,
-                                exact_order=bool(options.get('exact_order', False)))
-        if not engine.backward_supported(call):
+        y0c = y0.detach().to(torch.float32).contiguous()
+
+        def make(kernel, save_act):
+            return engine.SolveCall(model, flat, coeffs, grid, y0c, dW=dW, method=method, seed=seed,
+                                    row_offset=int(options.get('row_offset', 0)), kernel=kernel, save_traj=True,
+                                    save_dW=True, save_act=save_act, exact_order=bool(options.get('exact_order', False)))
+        call = make(options.get('kernel', 'auto'), False)
+        mode = engine.backward_supported(call)
+        if mode == 0:
             raise NotImplementedError(
-                "backward of the fused solve covers the MFMA fast-path configurations (H in {32,64,128}, "
-                "input_option 1..6, noise_option in {0,12,13,16,17}, at most one hidden layer, C <= 32); pass "
-                "options={'backend': 'torch'} to differentiate other configurations through the tensor-op loop")
+                "the fused backward covers method 'euler'/'milstein' with a diffusion that is elementwise in y "
+                "(noise_option 0..13, 16, 17); pass options={'backend': 'torch'} to differentiate this configuration "
+                "through the tensor-op loop")
+        call = make(options.get('kernel', 'auto'), True) if mode == 1 else make('generic', False)
+        ctx.mode, ctx.method = mode, method
         ys = call.launch()
         ctx.call, ctx.sde, ctx.grid, ctx.times_host = call, sde, grid, times_host
         ctx.names = [n for n, _ in sde.named_parameters()]
@@ -173,8 +177,12 @@ class _FusedEulerSolve(torch.autograd.Function):
     @staticmethod
     def backward(ctx, grad_ys):
         call, sde, grid = ctx.call, ctx.sde, ctx.grid
-        adj, delta = engine.solve_backward(call, grad_ys.to(torch.float32).contiguous(), save_delta=True)
-        grads = _parameter_gradients_gemm(sde, call, grid, adj, delta)
+        if ctx.mode == 1:     # MFMA adjoint kernel + GEMMs on the saved activations / deltas
+            adj, delta = engine.solve_backward(call, grad_ys.to(torch.float32).contiguous(), save_delta=True)
+            grads = _parameter_gradients_gemm(sde, call, grid, adj, delta)
+        else:                 # generic adjoint kernel (any dims, Euler / Milstein) + batched autograd parameter pass
+            adj = engine.solve_backward(call, grad_ys.to(torch.float32).contiguous())
+            grads = _parameter_gradients(sde, call, grid, adj, method=ctx.method)
         return (None,) * 9 + (adj[0].to(ctx.y0_dtype),) + tuple(grads)
 
 
@@ -263,7 +271,7 @@ def _parameter_gradients_gemm(sde, call, grid, adj, delta):
     return [grads[k] if grads[k] is not None else torch.zeros_like(P[k]) for k in P]
 
 
-def _parameter_gradients(sde, call, grid, adj, max_rows=1 << 19):
+def _parameter_gradients(sde, call, grid, adj, max_rows=1 << 19, method='euler'):
     """sum over steps n and rows of  a_{n+1} . d(f(t_n, y_n) h_n + g(t_n, y_n) dW_n)/d theta  with y_n, a_{n+1}, dW_n
     constants: one batched forward of the vector field over (step, row) pairs + autograd (library GEMMs)."""
     from . import modules
@@ -298,8 +306,14 @@ def _parameter_gradients(sde, call, grid, adj, max_rows=1 << 19):
                 a_, b_, c2, d3 = (rows[..., k * Cn:(k + 1) * Cn] for k in range(4))
                 Xraw = (a_ + (b_ + (0.5 * c2 + d3 * fr / 3) * fr) * fr).reshape(n * B, Cn)
             f = modules.drift_rows(P, io, tau, Y, Xraw)
-            g = modules.diffusion_rows(P, no, col, tau, Y)
-            surrogate = (A * (f * hcol + g * DW)).sum()
+            if method == 'milstein':   # + 1/2 g dg/dy (dW^2 - h); g is elementwise in y for the supported options
+                Yg = Y.detach().requires_grad_(True)
+                g = modules.diffusion_rows(P, no, col, tau, Yg)
+                dg, = torch.autograd.grad(g.sum(), Yg, create_graph=True)
+                surrogate = (A * (f * hcol + g * DW + 0.5 * g * dg * (DW * DW - hcol))).sum()
+            else:
+                g = modules.diffusion_rows(P, no, col, tau, Y)
+                surrogate = (A * (f * hcol + g * DW)).sum()
             gs = torch.autograd.grad(surrogate, params, allow_unused=True)
             for acc, gpart in zip(total, gs):
                 if gpart is not None:
@@ -369,12 +383,16 @@ def _sdeint_torch(sde, y0, ts, bm, method, dt, options, names):
         else:
             I = bm(t0, t1)
             v = I * I - h
+            # g * dg/dy * v for diagonal noise; when differentiating, the cotangent keeps its dependence on y so that
+            # autograd through this loop is the exact gradient of the discrete scheme (what the fused adjoint computes)
+            diff = torch.is_grad_enabled() and (y.requires_grad or any(
+                p.requires_grad for p in getattr(sde, 'parameters', lambda: [])()))
             with torch.enable_grad():
                 yy = y if y.requires_grad else y.detach().requires_grad_(True)
                 gv = g(t0, yy)
-                gdg, = torch.autograd.grad(gv, yy, grad_outputs=gv.detach() * v, allow_unused=True,
-                                           create_graph=torch.is_grad_enabled() and y.requires_grad)
-            gv = gv if y.requires_grad else gv.detach()
+                gdg, = torch.autograd.grad(gv, yy, grad_outputs=(gv if diff else gv.detach()) * v, allow_unused=True,
+                                           create_graph=diff)
+            gv = gv if diff else gv.detach()
             gdg = torch.zeros_like(y) if gdg is None else gdg
             y = y + f(t0, y) * h + gv * I + 0.5 * gdg
         while k < grid.T - 1 and grid.out_step[k] == n:

@@ -486,16 +486,43 @@ BWD_CASES = [
 ]
 
 
+GEN_BWD_CASES = [
+    # io, no, NL, B, H, C, L, ts, dt, method    (generic adjoint kernel: any dims, Euler and Milstein)
+    (4, 17, 2, 11, 24, 5, 9, [0, 3, 8], 1.0, 'euler'),
+    (4, 17, 2, 9, 256, 14, 8, None, None, 'milstein'),        # K5 shape: H = 256, Milstein, ts = times
+    (6, 17, 3, 9, 40, 3, 9, [0, 8], 1.0, 'milstein'),
+    (2, 16, 1, 9, 20, 2, 12, None, 0.05, 'euler'),
+    (0, 6, 2, 9, 12, 3, 8, [0, 7], 1.0, 'milstein'),
+    (1, 8, 2, 9, 12, 3, 8, [0, 2.5, 7], 0.5, 'milstein'),
+    (3, 9, 5, 9, 12, 3, 8, [0, 7], 0.5, 'milstein'),
+    (5, 11, 2, 9, 12, 3, 8, [0, 7], 0.5, 'milstein'),
+    (3, 3, 2, 9, 12, 3, 8, [0, 7], 0.5, 'euler'),
+    (1, 10, 2, 9, 12, 3, 8, [0, 7], 0.5, 'euler'),
+]
+
+
+@pytest.mark.parametrize('ci', range(len(GEN_BWD_CASES)))
+def test_generic_backward_matches_fp64_autograd(ci):
+    io, no, NL, B, H, C, L, ts, dt, method = GEN_BWD_CASES[ci]
+    _check_backward(900 + ci, io, no, NL, B, H, C, L, ts, dt, method, 'generic')
+
+
 @pytest.mark.parametrize('kernel', ['mfma4', 'mfma16'])
 @pytest.mark.parametrize('ci', range(len(BWD_CASES)))
 def test_backward_matches_fp64_autograd_through_the_unrolled_loop(ci, kernel):
     """dL/dy0 and dL/dtheta from the HIP adjoint + batched parameter pass vs float64 autograd through the unfused
     tensor-op loop (the reference's way of differentiating, common_sde.py:158-160) on identical increments."""
     io, no, NL, B, H, C, L, ts, dt = BWD_CASES[ci]
+    _check_backward(500 + ci, io, no, NL, B, H, C, L, ts, dt, 'euler', kernel)
+
+
+def _check_backward(seed, io, no, NL, B, H, C, L, ts, dt, method, kernel):
     times = np.linspace(0, 1, L).astype(np.float32) if ts is None else None
-    pr = make_problem(500 + ci, io, no, NL, B, H, C, L, times=times)
+    pr = make_problem(seed, io, no, NL, B, H, C, L, times=times)
     ts = pr['times'] if ts is None else np.asarray(ts, np.float32)
-    dW = draw_dW(500 + ci, ts, dt, B, H)
+    dt = dt or max(float(np.diff(pr['times']).min()), 1e-3)
+    dW = draw_dW(seed, ts, dt, B, H)
+    ci = seed
     wsum = np.random.default_rng(ci).standard_normal((len(ts), B, H)).astype(np.float32)
 
     def build(dtype, device):
@@ -507,12 +534,12 @@ def test_backward_matches_fp64_autograd_through_the_unrolled_loop(ci, kernel):
         return m, y0
 
     m_ref, y0_ref = build(torch.float64, 'cpu')
-    ys_ref = S.sdeint(m_ref, y0_ref, torch.from_numpy(ts), bm=_ReplayBM(torch.from_numpy(dW).double()), method='euler',
+    ys_ref = S.sdeint(m_ref, y0_ref, torch.from_numpy(ts), bm=_ReplayBM(torch.from_numpy(dW).double()), method=method,
                       dt=dt, options={'backend': 'torch'})
     (ys_ref * torch.from_numpy(wsum).double()).sum().backward()
 
     m, y0 = build(torch.float32, DEV)
-    ys = S.sdeint(m, y0, torch.from_numpy(ts).to(DEV), bm=_ReplayBM(torch.from_numpy(dW).to(DEV)), method='euler', dt=dt,
+    ys = S.sdeint(m, y0, torch.from_numpy(ts).to(DEV), bm=_ReplayBM(torch.from_numpy(dW).to(DEV)), method=method, dt=dt,
                   options={'kernel': kernel})
     (ys * torch.from_numpy(wsum).to(DEV)).sum().backward()
 
@@ -542,7 +569,7 @@ def test_backward_unsupported_configurations_raise():
     m2 = S.Diffusion_model(3, 64, 64, 2, input_option=4, noise_option=17).to(DEV)
     m2.set_X(torch.from_numpy(pr['coeffs']).to(DEV), torch.from_numpy(pr['times']).to(DEV))
     with pytest.raises(NotImplementedError):
-        S.sdeint(m2, y0, torch.tensor([0., 4.], device=DEV), method='milstein', dt=1.0)
+        S.sdeint(m2, y0, torch.tensor([0., 4.], device=DEV), method='srk', dt=1.0)
 
 
 def test_neuralsde_training_step_on_cuda():
