@@ -117,7 +117,7 @@ MfmaPlan make_plan(const snsde_solve* s, const SnsdeNet& net, int flavor_hint) {
     p.ok = false;
     if (m.hidden_hidden_channels != H) return p;
     if (s->method == SNSDE_SRK) return p;
-    if (!(H == 128 || H == 64 || H == 32 || H == 16)) return p;
+    if (!(H == 256 || H == 128 || H == 64 || H == 32 || H == 16)) return p;
     if (!(io >= 1 && io <= 6)) return p;
     const bool noise_net = (no == 14 || no == 15 || no == 18 || no == 19);
     if (!(no == 0 || no == 12 || no == 13 || no == 16 || no == 17 || noise_net)) return p;
@@ -182,7 +182,7 @@ MfmaPlan make_plan(const snsde_solve* s, const SnsdeNet& net, int flavor_hint) {
 RevPlan make_rev_plan(const snsde_solve* s, const SnsdeNet& net, const MfmaPlan& fp) {
     RevPlan p{};
     p.ok = false;
-    if (!fp.ok || s->method != SNSDE_EULER || fp.NN != 0) return p;
+    if (!fp.ok || (s->method != SNSDE_EULER && s->method != SNSDE_MILSTEIN) || fp.NN != 0) return p;
     const int H = fp.H, io = fp.IO;
     p.H = H; p.NHID = fp.NHID; p.GEO = (io == 5 || io == 6) ? 1 : 0; p.FL = fp.FL; p.NW = fp.NW;
     p.emb = (io == 2 || io == 4 || io == 6) ? 1 : 0;
@@ -262,6 +262,7 @@ int snsde_mfma_launch(const snsde_solve* s, const SnsdeNet& net, hipStream_t str
     a.method = s->method; a.no = s->model.noise_option;
     a.off_theta = net.off_theta; a.gt_off = p.gt_off; a.bias_off = p.bias_off;
     for (int i = 0; i < p.n_layers; ++i) a.w_off[i] = p.layer[i].dst;
+    if (p.H == 256) return dispatch_fwd_h256(p, a, stream);
     if (p.H == 128) return dispatch_fwd_h128(p, a, stream);
     if (p.H == 64) return dispatch_fwd_h64(p, a, stream);
     if (p.H == 32) return dispatch_fwd_h32(p, a, stream);
@@ -305,8 +306,9 @@ int snsde_mfma_backward_launch(const snsde_backward* b, const SnsdeNet& net, hip
     a.gt = fp.gt_off >= 0 ? static_cast<const float*>(s->workspace) + fp.gt_off : nullptr;
     a.step_tab = s->step_tab; a.out_w = s->out_w; a.traj = s->traj; a.act = s->act_save; a.dW = s->dW_out;
     a.grad_ys = b->grad_ys; a.adj = b->adj; a.delta = b->delta_save;
-    a.B = s->batch; a.N = s->n_steps; a.T = s->n_out; a.no = s->model.noise_option; a.off_theta = net.off_theta;
+    a.B = s->batch; a.N = s->n_steps; a.T = s->n_out; a.no = s->model.noise_option; a.off_theta = net.off_theta; a.method = s->method;
     for (int i = 0; i < p.n_layers; ++i) a.w_off[i] = p.layer[i].dst;
+    if (p.H == 256) return dispatch_rev_h256(p, a, stream);
     if (p.H == 128) return dispatch_rev_h128(p, a, stream);
     if (p.H == 64) return dispatch_rev_h64(p, a, stream);
     if (p.H == 32) return dispatch_rev_h32(p, a, stream);

@@ -144,6 +144,50 @@ __device__ __forceinline__ void gemm(const float (&w)[TPW][KU * 4], const float*
             }
 }
 
+// Where a wave's weight slice lives: registers for the whole solve (the default), or streamed from the packed
+// workspace (L2-resident) every use when the matrices exceed the register file (H = 256).
+template <bool STREAM, int KU, int TPW> struct Wt;
+template <int KU, int TPW> struct Wt<false, KU, TPW> {
+    float v[TPW][KU * 4];
+    __device__ __forceinline__ void load(const float* __restrict__ g, int wave, int lane) { load_weights<KU, TPW>(v, g, wave, lane); }
+};
+template <int KU, int TPW> struct Wt<true, KU, TPW> {
+    const float* p;   // this lane's first float4 of the wave's packed block
+    __device__ __forceinline__ void load(const float* __restrict__ g, int wave, int lane) {
+        p = g + (size_t)wave * TPW * KU * 256 + lane * 4;
+    }
+};
+
+template <int FL, int KU, int TPW>
+__device__ __forceinline__ void gemm(const Wt<false, KU, TPW>& w, const float* in, f32x4 (&acc)[TPW], f32x4 (&acc2)[TPW]) {
+    gemm<FL, KU, TPW>(w.v, in, acc, acc2);
+}
+
+// streamed variant: per 16-wide k-block one coalesced 1 KiB global load (float4 per lane) feeds four MFMAs
+template <int FL, int KU, int TPW>
+__device__ __forceinline__ void gemm(const Wt<true, KU, TPW>& w, const float* in, f32x4 (&acc)[TPW], f32x4 (&acc2)[TPW]) {
+    static_assert(TPW == 1, "streamed weights: one tile per wave");
+    constexpr int CH = 4;   // k-blocks in flight
+#pragma unroll
+    for (int c0 = 0; c0 < KU; c0 += CH) {
+        f32x4 wv[CH], bv[CH];
+#pragma unroll
+        for (int i = 0; i < CH; ++i)
+            if (c0 + i < KU) {
+                wv[i] = *reinterpret_cast<const f32x4*>(w.p + (size_t)(c0 + i) * 256);
+                bv[i] = *reinterpret_cast<const f32x4*>(in + 16 * (c0 + i));
+            }
+#pragma unroll
+        for (int i = 0; i < CH; ++i)
+            if (c0 + i < KU) {
+                acc[0] = mfma<FL>(wv[i][0], bv[i][0], acc[0]);
+                acc2[0] = mfma<FL>(wv[i][1], bv[i][1], acc2[0]);
+                acc[0] = mfma<FL>(wv[i][2], bv[i][2], acc[0]);
+                acc2[0] = mfma<FL>(wv[i][3], bv[i][3], acc2[0]);
+            }
+    }
+}
+
 template <int H_, int KUX_, int NHID_, int IO_, int FL_, int PHX_, int FOLD_, int NN_ = 0>
 struct Cfg {
     static constexpr int H = H_, KUX = KUX_, NHID = NHID_, IO = IO_, FL = FL_;
@@ -161,6 +205,7 @@ struct Cfg {
     static constexpr bool YTIME = TIME || NN > 0;   // ybuf carries the [sin t, cos t] columns
     static constexpr bool EMB = (IO == 2 || IO == 4 || IO == 6);
     static constexpr bool GEO = (IO == 5 || IO == 6);
+    static constexpr bool STREAM = H > 128;   // weights streamed from L2 instead of register-resident
     static constexpr bool FOLD = EMB && FOLD_ != 0;   // emb o (linear_in, initial_network) pre-multiplied
     static constexpr int KUH = H / 16;
     static constexpr int KUY = KUH + (TIME ? 1 : 0);
@@ -169,13 +214,13 @@ struct Cfg {
     static constexpr int KUN = KUH + 1;       // noise net input = [y, sin t, cos t]
     static constexpr int LDY = ld_for(16 * (YTIME ? KUH + 1 : KUH), PAD);
     static constexpr int LDX = ld_for(16 * KUX, PAD);
-    static constexpr int LDC = ld_for(EMB ? 32 * KUH : 16 * KUH, PAD);
+    static constexpr int LDC = FOLD ? 0 : ld_for(EMB ? 32 * KUH : 16 * KUH, PAD);   // folded first layer needs no concat buffer
     static constexpr int LDA = ld_for(16 * KUH, PAD);
     static constexpr int NLAYER = (EMB && !FOLD ? 3 : 1) + NHID + 1 + NN;   // bias rows: [init, in, emb] | [first], hid.., out, noise..
     static constexpr int XI = (M * 16 * KUX + NT - 1) / NT;           // spline items per thread
     static constexpr int EPT = FL ? 1 : 4;                            // owned state elements per lane per tile
     static constexpr int NSAVE = NHID + 2;                            // saved activations per step: z0, hidden.., zout
-    static constexpr int ZB = FL ? 4 : 1;                             // Philox calls generated together per element
+    static constexpr int ZB = (FL && !STREAM) ? 4 : 1;                             // Philox calls generated together per element
     static constexpr int ROWCH = 128;                                 // step-table rows staged in LDS per chunk
     static constexpr int ZSTASH = PHX ? 4 * ZB * 64 * EPT : 0;        // floats per wave
     static constexpr int LDS_FLOATS = M * (LDY + LDX + LDC + 3 * LDA) + NLAYER * H + (ROWCH + 1) * SNSDE_STEP_STRIDE + NW * ZSTASH;
@@ -223,21 +268,21 @@ __global__ void __launch_bounds__(CF::NT, CF::WPS) snsde_mfma_kernel(MfmaArgs a)
 
     // ---- resident weights ----------------------------------------------------------------------
     int li = 0;
-    float wx[TPW][CF::EMB ? KUX * 4 : 4];
-    float wy[TPW][KUY * 4];
-    float we[TPW][(CF::EMB && !CF::FOLD) ? KUE * 4 : 4];
-    float wh[NHID > 0 ? NHID : 1][TPW][KUH * 4];
-    float wo[TPW][KUH * 4];
-    float wn0[TPW][CF::NN > 0 ? CF::KUN * 4 : 4];
-    float wn1[TPW][CF::NN > 1 ? KUH * 4 : 4];
-    if constexpr (CF::EMB) load_weights<KUX, TPW>(wx, a.ws + a.w_off[li++], wave, lane);
-    load_weights<KUY, TPW>(wy, a.ws + a.w_off[li++], wave, lane);
-    if constexpr (CF::EMB && !CF::FOLD) load_weights<KUE, TPW>(we, a.ws + a.w_off[li++], wave, lane);
+    Wt<CF::STREAM, CF::EMB ? KUX : 1, TPW> wx;
+    Wt<CF::STREAM, KUY, TPW> wy;
+    Wt<CF::STREAM, (CF::EMB && !CF::FOLD) ? KUE : 1, TPW> we;
+    Wt<CF::STREAM, KUH, TPW> wh[(NHID > 0) ? NHID : 1];
+    Wt<CF::STREAM, KUH, TPW> wo;
+    Wt<CF::STREAM, (CF::NN > 0) ? CF::KUN : 1, TPW> wn0;
+    Wt<CF::STREAM, (CF::NN > 1) ? KUH : 1, TPW> wn1;
+    if constexpr (CF::EMB) wx.load(a.ws + a.w_off[li++], wave, lane);
+    wy.load(a.ws + a.w_off[li++], wave, lane);
+    if constexpr (CF::EMB && !CF::FOLD) we.load(a.ws + a.w_off[li++], wave, lane);
 #pragma unroll
-    for (int l = 0; l < NHID; ++l) load_weights<KUH, TPW>(wh[l], a.ws + a.w_off[li++], wave, lane);
-    load_weights<KUH, TPW>(wo, a.ws + a.w_off[li++], wave, lane);
-    if constexpr (CF::NN > 0) load_weights<CF::KUN, TPW>(wn0, a.ws + a.w_off[li++], wave, lane);
-    if constexpr (CF::NN > 1) load_weights<KUH, TPW>(wn1, a.ws + a.w_off[li++], wave, lane);
+    for (int l = 0; l < NHID; ++l) wh[l].load(a.ws + a.w_off[li++], wave, lane);
+    wo.load(a.ws + a.w_off[li++], wave, lane);
+    if constexpr (CF::NN > 0) wn0.load(a.ws + a.w_off[li++], wave, lane);
+    if constexpr (CF::NN > 1) wn1.load(a.ws + a.w_off[li++], wave, lane);
 
     // ---- LDS init ------------------------------------------------------------------------------
     for (int i = tid; i < M * (LDY + LDX + LDC + 3 * LDA); i += NT) lds[i] = 0.0f;
@@ -448,7 +493,7 @@ __global__ void __launch_bounds__(CF::NT, CF::WPS) snsde_mfma_kernel(MfmaArgs a)
         if constexpr (CF::FOLD) {
             init_acc(layer);
             gemm<FL, KUY, TPW>(wy, yrow, acc, acc2);
-            gemm<FL, KUX, TPW>(wx, xrow, acc, acc2);
+            gemm<FL, CF::EMB ? KUX : 1, TPW>(wx, xrow, acc, acc2);
             sum_acc();
             TRACE(2)
 #pragma unroll
@@ -461,7 +506,7 @@ __global__ void __launch_bounds__(CF::NT, CF::WPS) snsde_mfma_kernel(MfmaArgs a)
         } else {
             if constexpr (CF::EMB) {
                 init_acc(layer);
-                gemm<FL, KUX, TPW>(wx, xrow, acc, acc2);
+                gemm<FL, CF::EMB ? KUX : 1, TPW>(wx, xrow, acc, acc2);
                 sum_acc();
 #pragma unroll
                 for (int t = 0; t < TPW; ++t) store_frag(cat, LDC, H + (wave * TPW + t) * 16, acc[t], false);
@@ -476,7 +521,7 @@ __global__ void __launch_bounds__(CF::NT, CF::WPS) snsde_mfma_kernel(MfmaArgs a)
             if constexpr (CF::NN > 0) {   // diffusion net, first layer, on the same [y, sin t, cos t] rows
                 constexpr int NROW = CF::NLAYER - CF::NN;
                 init_acc(NROW);
-                gemm<FL, CF::KUN, TPW>(wn0, yrow, acc, acc2);
+                gemm<FL, (CF::NN > 0) ? CF::KUN : 1, TPW>(wn0, yrow, acc, acc2);
                 sum_acc();
                 if constexpr (CF::NN == 2) store_frag(nbuf, LDA, wave * 16, acc[0], true);
                 else {
@@ -490,7 +535,7 @@ __global__ void __launch_bounds__(CF::NT, CF::WPS) snsde_mfma_kernel(MfmaArgs a)
             __syncthreads();
             if constexpr (CF::NN == 2) {   // second layer of the diffusion net (relu'd raw value, neuralsde.py:278-281)
                 init_acc(CF::NLAYER - 1);
-                gemm<FL, KUH, TPW>(wn1, nbuf + r * LDA + 4 * s, acc, acc2);
+                gemm<FL, (CF::NN > 1) ? KUH : 1, TPW>(wn1, nbuf + r * LDA + 4 * s, acc, acc2);
                 sum_acc();
                 gnv = acc[0];
 #pragma unroll
@@ -502,7 +547,7 @@ __global__ void __launch_bounds__(CF::NT, CF::WPS) snsde_mfma_kernel(MfmaArgs a)
             cur = crow;
             if constexpr (CF::EMB) {
                 init_acc(layer);
-                gemm<FL, KUE, TPW>(we, crow, acc, acc2);
+                gemm<FL, (CF::EMB && !CF::FOLD) ? KUE : 1, TPW>(we, crow, acc, acc2);
                 sum_acc();
 #pragma unroll
                 for (int t = 0; t < TPW; ++t) store_frag(bufA, LDA, (wave * TPW + t) * 16, acc[t], true, 0);
@@ -648,6 +693,7 @@ struct CfgR {
     static constexpr int NSAVE = NHID + 2;
     static constexpr int EPT = FL ? 1 : 4;
     static constexpr int ROWCH = 128;
+    static constexpr bool STREAM = H > 128;
     static constexpr int LDS_FLOATS = NG * M * LDA + (ROWCH + 1) * SNSDE_STEP_STRIDE;
 };
 
@@ -663,7 +709,7 @@ struct RevArgs {
     const float* grad_ys;
     float* adj;
     float* delta;      // (N, NG, B, H) or null
-    int32_t B, N, T, no, off_theta;
+    int32_t B, N, T, no, off_theta, method;
     int32_t w_off[MAXL];
 };
 
@@ -687,13 +733,14 @@ __global__ void __launch_bounds__(CF::NT, CF::WPS) snsde_mfma_reverse_kernel(Rev
     const int fcol = wave * 16 + fsub + (FL ? s : 0);
     const size_t goff = (size_t)rowc * H + fcol;
 
-    float wt[NG][TPW][KUH * 4];
+    Wt<CF::STREAM, KUH, TPW> wt[NG];
 #pragma unroll
-    for (int g = 0; g < NG; ++g) load_weights<KUH, TPW>(wt[g], a.ws + a.w_off[g], wave, lane);
+    for (int g = 0; g < NG; ++g) wt[g].load(a.ws + a.w_off[g], wave, lane);
     for (int i = tid; i < NG * M * LDA; i += NT) lds[i] = 0.0f;
 
     const float sig_theta = snsde_sigmoid(a.params[a.off_theta]);
     const bool mul_y = (a.no == 13 || a.no == 17);
+    const float mil = (a.method == SNSDE_MILSTEIN) ? 0.5f : 0.0f;
 
     auto fill_rows = [&](int base) {
         for (int i = tid; i < (CF::ROWCH + 1) * SNSDE_STEP_STRIDE; i += NT) {
@@ -755,7 +802,12 @@ __global__ void __launch_bounds__(CF::NT, CF::WPS) snsde_mfma_reverse_kernel(Rev
             else dz[e] = dzt;
             const float raw = mul_y ? gq * y : gq;
             const float g = fast_tanh(sig_theta * snsde_nan_to_num(raw));
-            if (mul_y && (raw - raw == 0.0f)) acc_y = fmaf(av * dw * (1.0f - g * g) * sig_theta, gq, acc_y);
+            if (mul_y && (raw - raw == 0.0f)) {
+                // d/dy [g dW + mil (dW^2 - h) g g'],  g' = (1 - g^2) c,  (g g')' = c^2 (1 - g^2)(1 - 3 g^2),  c = sigmoid(theta) s_n
+                const float c = sig_theta * gq, om = 1.0f - g * g;
+                const float dm = mil * fmaf(dw, dw, -h) * c * fmaf(-3.0f * g, g, 1.0f);
+                acc_y = fmaf(av * om * c, dw + dm, acc_y);
+            }
             ay[e] = acc_y;
         }
         float* buf = lds;   // buffer g holds the input of transposed GEMM g
@@ -884,5 +936,7 @@ int dispatch_fwd_h64(const MfmaPlan& p, const MfmaArgs& a, hipStream_t st);
 int dispatch_rev_h64(const RevPlan& p, const RevArgs& a, hipStream_t st);
 int dispatch_fwd_h128(const MfmaPlan& p, const MfmaArgs& a, hipStream_t st);
 int dispatch_rev_h128(const RevPlan& p, const RevArgs& a, hipStream_t st);
+int dispatch_fwd_h256(const MfmaPlan& p, const MfmaArgs& a, hipStream_t st);
+int dispatch_rev_h256(const RevPlan& p, const RevArgs& a, hipStream_t st);
 
 }  // namespace snsde_mfma

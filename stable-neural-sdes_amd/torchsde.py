@@ -179,7 +179,7 @@ class _FusedSolve(torch.autograd.Function):
         call, sde, grid = ctx.call, ctx.sde, ctx.grid
         if ctx.mode == 1:     # MFMA adjoint kernel + GEMMs on the saved activations / deltas
             adj, delta = engine.solve_backward(call, grad_ys.to(torch.float32).contiguous(), save_delta=True)
-            grads = _parameter_gradients_gemm(sde, call, grid, adj, delta)
+            grads = _parameter_gradients_gemm(sde, call, grid, adj, delta, method=ctx.method)
         else:                 # generic adjoint kernel (any dims, Euler / Milstein) + batched autograd parameter pass
             adj = engine.solve_backward(call, grad_ys.to(torch.float32).contiguous())
             grads = _parameter_gradients(sde, call, grid, adj, method=ctx.method)
@@ -187,7 +187,7 @@ class _FusedSolve(torch.autograd.Function):
 
 
 @torch.no_grad()
-def _parameter_gradients_gemm(sde, call, grid, adj, delta):
+def _parameter_gradients_gemm(sde, call, grid, adj, delta, method='euler'):
     """Parameter gradients from the tensors the two kernels left in HBM, as plain library GEMMs:
         d layer.weight = sum_{step,row} delta_layer^T . layer_input,   d layer.bias = sum delta_layer
     (delta from the adjoint kernel, layer inputs from the forward's act_save / trajectory), plus the elementwise
@@ -259,9 +259,17 @@ def _parameter_gradients_gemm(sde, call, grid, adj, delta):
         rc = torch.nan_to_num(raw)
         g = (sig * rc).tanh()
         du = adj[1:] * call.dW_out * (1 - g * g)
-        grads['theta'] = ((du * rc).sum() * sig * (1 - sig)).reshape(1, 1)
+        dtheta = (du * rc).sum()
         ds = du * sig * finite
         ds = (ds * Y).sum(1) if no in (13, 17) else ds.sum(1)                           # (N, H)
+        if method == 'milstein' and no in (13, 17):
+            # + a . d/dc [1/2 (dW^2 - h) g g'],  g' = (1 - g^2) c,  c = sigmoid(theta) s_n   (zero for y-independent g)
+            c = sig * sd
+            q = call.dW_out * call.dW_out - hh.view(N, 1, 1)
+            ex = adj[1:] * (1 - g * g) * (0.5 * q) * ((1 - 3 * g * g) * c * Y + g) * finite
+            dtheta = dtheta + (ex * sd).sum()
+            ds = ds + (ex * sig).sum(1)
+        grads['theta'] = (dtheta * sig * (1 - sig)).reshape(1, 1)
         net_params = [p for p in net.parameters()]
         gs = torch.autograd.grad(s_n, net_params, grad_outputs=ds)
         for (name, _), gval in zip(net.named_parameters(), gs):

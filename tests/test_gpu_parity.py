@@ -325,6 +325,9 @@ MFMA_CASES = [
     (3, 19, 1, 9, 128, 3, 8, [0, 7], 0.5, 'euler'),
     (1, 14, 2, 9, 32, 3, 8, [0, 7], 1.0, 'euler'),
     (3, 15, 3, 9, 16, 3, 8, [0, 7], 1.0, 'euler'),
+    (4, 17, 2, 21, 256, 14, 11, [0, 4.5, 10], 1.0, 'milstein'),   # H = 256: weights streamed from L2 (K5 model)
+    (6, 17, 1, 9, 256, 5, 9, [0, 8], 1.0, 'euler'),
+    (1, 18, 2, 9, 256, 3, 8, [0, 7], 1.0, 'euler'),
 ]
 
 
@@ -464,11 +467,12 @@ def test_k5_milstein_h256_forecast_shaped():
     pr = make_problem(5005, 4, 17, 2, B, H, C, L, nan_frac=0.3)
     ts, dt = pr['times'], 1.0
     dW = draw_dW(5005, ts, dt, B, H)
-    ys, _ = hip_solve(pr, ts, dt, dW=dW, method='milstein')
     ref64, _ = oracle_solve(pr, ts, dt, dW, 'milstein', np.float64)
     cpu32, _ = oracle_solve(pr, ts, dt, dW, 'milstein', np.float32)
-    assert ys.shape == (50, B, H)
-    print('K5', assert_parity(ys, ref64, cpu32, what='K5'))
+    for kernel in ('mfma4', 'mfma16', 'generic'):
+        ys, _ = hip_solve(pr, ts, dt, dW=dW, method='milstein', kernel=kernel)
+        assert ys.shape == (50, B, H)
+        print('K5', kernel, assert_parity(ys, ref64, cpu32, what='K5 ' + kernel))
 
 
 # ---- backward (adjoint) of the fused solve --------------------------------------------------------------
@@ -483,6 +487,12 @@ BWD_CASES = [
     (5, 12, 1, 8, 128, 3, 8, [0, 7], 1.0),
     (4, 17, 4, 9, 64, 5, 9, [0, 8], 1.0),
     (6, 17, 3, 9, 16, 3, 9, [0, 8], 1.0),
+    (4, 17, 2, 9, 256, 14, 9, [0, 3, 8], 1.0),
+    (4, 17, 2, 9, 256, 14, 8, None, None, 'milstein'),        # K5 shape: H = 256, Milstein, ts = times
+    (4, 17, 2, 21, 128, 5, 9, [0, 3.5, 8], 0.5, 'milstein'),
+    (6, 17, 3, 9, 64, 3, 9, [0, 8], 1.0, 'milstein'),
+    (3, 13, 2, 11, 32, 3, 8, [0, 7], 0.5, 'milstein'),
+    (2, 16, 1, 9, 32, 2, 12, None, 0.05, 'milstein'),         # y-independent diffusion: Milstein term vanishes
 ]
 
 
@@ -512,8 +522,9 @@ def test_generic_backward_matches_fp64_autograd(ci):
 def test_backward_matches_fp64_autograd_through_the_unrolled_loop(ci, kernel):
     """dL/dy0 and dL/dtheta from the HIP adjoint + batched parameter pass vs float64 autograd through the unfused
     tensor-op loop (the reference's way of differentiating, common_sde.py:158-160) on identical increments."""
-    io, no, NL, B, H, C, L, ts, dt = BWD_CASES[ci]
-    _check_backward(500 + ci, io, no, NL, B, H, C, L, ts, dt, 'euler', kernel)
+    io, no, NL, B, H, C, L, ts, dt = BWD_CASES[ci][:9]
+    method = BWD_CASES[ci][9] if len(BWD_CASES[ci]) > 9 else 'euler'
+    _check_backward(500 + ci, io, no, NL, B, H, C, L, ts, dt, method, kernel)
 
 
 def _check_backward(seed, io, no, NL, B, H, C, L, ts, dt, method, kernel):

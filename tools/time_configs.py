@@ -1,0 +1,47 @@
+#!/usr/bin/env python3
+"""Forward (and where supported fwd+bwd) timings of the BASELINE.json configurations on one GPU."""
+import os, sys, time
+import numpy as np, torch
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import stable_neural_sdes_amd as S
+from tests.helpers import make_problem
+dev = torch.device('cuda:0')
+
+def timeit(fn, n=10):
+    for _ in range(3): fn()
+    torch.cuda.synchronize(); t = time.perf_counter()
+    for _ in range(n): fn()
+    torch.cuda.synchronize(); return (time.perf_counter() - t) / n * 1e3
+
+CFG = [  # name, io, no, NL, B, H, C, L, method, ts_all
+    ('K1 LSDE tutorial-shaped', 2, 16, 1, 256, 32, 2, 51, 'euler', True),
+    ('K2 LNSDE', 4, 17, 2, 1024, 128, 21, 101, 'euler', False),
+    ('K3 GSDE per-GPU shard', 6, 17, 2, 512, 128, 21, 201, 'euler', False),
+    ('K4 NSDE sepsis-shaped', 3, 18, 2, 2048, 64, 69, 72, 'euler', False),
+    ('K5 LNSDE Milstein per-GPU shard', 4, 17, 2, 128, 256, 14, 50, 'milstein', True),
+    ('K5 LNSDE Milstein B=1024', 4, 17, 2, 1024, 256, 14, 50, 'milstein', True),
+]
+for name, io, no, NL, B, H, C, L, method, ts_all in CFG:
+    pr = make_problem(7, io, no, NL, B, H, C, L, nan_frac=0.2)
+    m = S.Diffusion_model(C, H, H, NL, input_option=io, noise_option=no)
+    m.load_state_dict({k: torch.from_numpy(v.copy()) for k, v in pr['params'].items()})
+    m = m.to(dev)
+    times = torch.from_numpy(pr['times']).to(dev)
+    m.set_X(torch.from_numpy(pr['coeffs']).to(dev), times)
+    ts = times if ts_all else times[[0, -1]]
+    y0 = torch.from_numpy(pr['y0']).to(dev)
+    N = L - 1
+    def fwd():
+        with torch.no_grad():
+            return S.sdeint(m, y0, ts, method=method, dt=1.0, options={'seed': 1})
+    def fwd_bwd():
+        yy = y0.clone().requires_grad_(True)
+        S.sdeint(m, yy, ts, method=method, dt=1.0, options={'seed': 1})[-1].square().mean().backward()
+    tf = min(timeit(fwd), timeit(fwd))
+    try:
+        tb = timeit(fwd_bwd, 5)
+        tb = f'{tb:8.3f} ms'
+    except NotImplementedError:
+        tb = '   n/a'
+    print(f'{name:34s} B={B:5d} H={H:3d} N={N:3d} {method:8s} sdeint fwd {tf:7.3f} ms = {B * N / (tf * 1e-3):9.3e} row-steps/s | fwd+bwd {tb}')
