@@ -177,6 +177,17 @@ int    snsde_backward_supported(const snsde_solve* s);    /* 1 / 2 / 0, see abov
 size_t snsde_backward_workspace_bytes(const snsde_backward* b);
 int    snsde_solve_backward(const snsde_backward* b, void* hip_stream);
 
+/* Parameter gradients of the fused solve (mode 1 = MFMA path only): after snsde_solve_forward (traj, dW_out, act_save
+ * kept; fwd.workspace untouched since) and snsde_solve_backward (adj, delta_save; b->workspace still the buffer that
+ * call used — it holds the adjoint kernel's per-workgroup diffusion-side sums), writes dL/d params into
+ * grad_params (device, snsde_param_numel floats, same flat layout as `params`, overwritten) — what autograd
+ * accumulates through the unrolled loop (benchmark_classification/common_sde.py:158-160): split-R MFMA GEMMs
+ * sum_r delta^T . input with per-workgroup partials and one deterministic reduction, the elementwise diffusion
+ * reductions (theta, the time-only noise MLP; Euler and Milstein) and the first-layer/emb algebra. */
+size_t snsde_param_gradients_workspace_bytes(const snsde_backward* b);
+int    snsde_param_gradients(const snsde_backward* b, float* grad_params, void* workspace, size_t workspace_bytes,
+                             void* hip_stream);
+
 /* ---- cubic spline evaluation (A10) -----------------------------------------------------------
  * out[b, c] = a + (b + (0.5*two_c + three_d*frac/3)*frac)*frac   on interval `index`
  * (derivative != 0: b + (two_c + three_d*frac)*frac), operation order as

@@ -111,7 +111,9 @@ def natural_cubic_spline_coeffs(t, X):
 
 
 class _HostTimes:
-    """Host copy of the knot grid (one device->host copy per distinct `times` tensor version)."""
+    """Host copy of a small device vector (knot grid, output times): one device->host copy — a stream sync — per
+    distinct tensor version.  The cache keeps the tensor alive, so its address cannot be recycled for different
+    values while the entry exists; in-place edits bump `_version`."""
     _cache = {}
 
     @classmethod
@@ -120,14 +122,14 @@ class _HostTimes:
             return torch.as_tensor(times, dtype=torch.float32).numpy()
         if times.device.type == 'cpu':
             return times.detach().to(torch.float32).numpy()
-        key = (times.data_ptr(), times._version, times.numel(), str(times.device))
+        key = (times.data_ptr(), times._version, tuple(times.shape), times.stride(), times.dtype, str(times.device))
         hit = cls._cache.get(key)
         if hit is None:
             if len(cls._cache) > 64:
                 cls._cache.clear()
-            hit = times.detach().to('cpu', torch.float32).numpy()
+            hit = (times.detach().to('cpu', torch.float32).numpy(), times)
             cls._cache[key] = hit
-        return hit
+        return hit[0]
 
 
 class NaturalCubicSpline:

@@ -411,6 +411,30 @@ int snsde_solve_backward(const snsde_backward* b, void* hip_stream) {
     return snsde_mfma_backward_launch(b, net, static_cast<hipStream_t>(hip_stream));
 }
 
+size_t snsde_param_gradients_workspace_bytes(const snsde_backward* b) {
+    if (!b) return 0;
+    SnsdeNet net;
+    if (snsde_build_net(b->fwd.model, b->fwd.n_steps, &net)) return 0;
+    if (snsde_backward_supported(&b->fwd) != 1) return 0;
+    return snsde_wgrad_workspace_floats(b, net) * sizeof(float);
+}
+
+int snsde_param_gradients(const snsde_backward* b, float* grad_params, void* workspace, size_t workspace_bytes,
+                          void* hip_stream) {
+    if (!b || !grad_params || !workspace) return SNSDE_ERR_NULL;
+    int rc = validate_solve(&b->fwd, false);
+    if (rc) return rc;
+    if (!b->adj || !b->delta_save || !b->fwd.traj || !b->fwd.dW_out || !b->fwd.act_save || !b->fwd.workspace)
+        return SNSDE_ERR_NULL;
+    SnsdeNet net;
+    rc = snsde_build_net(b->fwd.model, b->fwd.n_steps, &net);
+    if (rc) return rc;
+    if (snsde_backward_supported(&b->fwd) != 1) return SNSDE_ERR_UNSUPPORTED;
+    if (workspace_bytes < snsde_param_gradients_workspace_bytes(b)) return SNSDE_ERR_WORKSPACE;
+    return snsde_wgrad_launch(b, net, grad_params, (int32_t)snsde_param_numel(&b->fwd.model), static_cast<float*>(workspace),
+                              static_cast<hipStream_t>(hip_stream));
+}
+
 int snsde_spline_evaluate(const float* coeffs, int32_t batch, int32_t knots, int32_t channels, int32_t index,
                           float frac, int32_t derivative, float* out, void* hip_stream) {
     if (!coeffs || !out) return SNSDE_ERR_NULL;

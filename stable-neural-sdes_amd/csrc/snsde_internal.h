@@ -62,6 +62,13 @@ int snsde_mfma_launch(const snsde_solve* s, const SnsdeNet& net, hipStream_t str
 bool snsde_mfma_backward_supported(const snsde_solve* s, const SnsdeNet& net);
 size_t snsde_mfma_backward_workspace_floats(const snsde_solve* s, const SnsdeNet& net);
 int snsde_mfma_backward_launch(const snsde_backward* b, const SnsdeNet& net, hipStream_t stream);
+const float* snsde_mfma_gt_table(const snsde_solve* s, const SnsdeNet& net);
+bool snsde_mfma_backward_partials(const snsde_solve* s, const SnsdeNet& net, int* nwg, int* waves, size_t* ds_off,
+                                  size_t* dth_off);
+// launchers (snsde_wgrad.hip)
+size_t snsde_wgrad_workspace_floats(const snsde_backward* b, const SnsdeNet& net);
+int snsde_wgrad_launch(const snsde_backward* b, const SnsdeNet& net, float* grad_params, int32_t n_params, float* ws,
+                       hipStream_t stream);
 int snsde_spline_launch(const float* coeffs, int32_t B, int32_t L, int32_t C, int32_t index, float frac,
                         int32_t derivative, float* out, hipStream_t stream);
 

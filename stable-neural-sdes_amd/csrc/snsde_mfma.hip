@@ -205,6 +205,15 @@ RevPlan make_rev_plan(const snsde_solve* s, const SnsdeNet& net, const MfmaPlan&
     p.n_layers = n;
     p.fold_tmp = fold_tmp;
     p.total_floats = packed + (p.emb ? H * net.in.K + H : 0) + 16;
+    p.nwg = (s->batch + (p.FL ? 4 : 16) - 1) / (p.FL ? 4 : 16);
+    p.ds_off = p.dth_off = 0;
+    if (fp.gt_off >= 0) {     // time-only diffusion table present: the adjoint kernel also leaves the parameter-side sums
+        size_t o = ((size_t)p.total_floats + 3) & ~(size_t)3;
+        p.ds_off = o; o += (size_t)p.nwg * s->n_steps * H;
+        p.dth_off = o; o += (size_t)p.nwg * p.NW;
+        if (o + 16 > 0x7fffffff) return p;
+        p.total_floats = (int)(o + 16);
+    }
     p.ok = true;
     return p;
 }
@@ -273,12 +282,29 @@ int snsde_mfma_launch(const snsde_solve* s, const SnsdeNet& net, hipStream_t str
 
 // ---- backward host side ---------------------------------------------------------------------------------
 
+const float* snsde_mfma_gt_table(const snsde_solve* s, const SnsdeNet& net) {
+    MfmaPlan p = make_plan(s, net, -1);
+    return (p.ok && p.gt_off >= 0 && s->workspace) ? static_cast<const float*>(s->workspace) + p.gt_off : nullptr;
+}
+
 bool snsde_mfma_backward_supported(const snsde_solve* s, const SnsdeNet& net) {
     return make_rev_plan(s, net, make_plan(s, net, -1)).ok;
 }
 
+static int flavor_hint_of(const snsde_solve* s) {
+    return s->kernel == SNSDE_KERNEL_MFMA_M16 ? 0 : (s->kernel == SNSDE_KERNEL_MFMA_M4 ? 1 : -1);
+}
+
+bool snsde_mfma_backward_partials(const snsde_solve* s, const SnsdeNet& net, int* nwg, int* waves, size_t* ds_off,
+                                  size_t* dth_off) {
+    RevPlan p = make_rev_plan(s, net, make_plan(s, net, flavor_hint_of(s)));
+    if (!p.ok || p.ds_off == 0) return false;
+    *nwg = p.nwg; *waves = p.NW; *ds_off = p.ds_off; *dth_off = p.dth_off;
+    return true;
+}
+
 size_t snsde_mfma_backward_workspace_floats(const snsde_solve* s, const SnsdeNet& net) {
-    RevPlan p = make_rev_plan(s, net, make_plan(s, net, -1));
+    RevPlan p = make_rev_plan(s, net, make_plan(s, net, flavor_hint_of(s)));
     return p.ok ? (size_t)p.total_floats : 0;
 }
 
@@ -306,6 +332,8 @@ int snsde_mfma_backward_launch(const snsde_backward* b, const SnsdeNet& net, hip
     a.gt = fp.gt_off >= 0 ? static_cast<const float*>(s->workspace) + fp.gt_off : nullptr;
     a.step_tab = s->step_tab; a.out_w = s->out_w; a.traj = s->traj; a.act = s->act_save; a.dW = s->dW_out;
     a.grad_ys = b->grad_ys; a.adj = b->adj; a.delta = b->delta_save;
+    a.ds_part = p.ds_off ? ws + p.ds_off : nullptr;
+    a.dth_part = p.ds_off ? ws + p.dth_off : nullptr;
     a.B = s->batch; a.N = s->n_steps; a.T = s->n_out; a.no = s->model.noise_option; a.off_theta = net.off_theta; a.method = s->method;
     for (int i = 0; i < p.n_layers; ++i) a.w_off[i] = p.layer[i].dst;
     if (p.H == 256) return dispatch_rev_h256(p, a, stream);

@@ -709,6 +709,8 @@ struct RevArgs {
     const float* grad_ys;
     float* adj;
     float* delta;      // (N, NG, B, H) or null
+    float* ds_part;    // (workgroups, N, H) per-tile sums of dL/d s_n (time-only diffusion table), or null
+    float* dth_part;   // (workgroups, waves) partial sums of dL/d sigmoid(theta), or null
     int32_t B, N, T, no, off_theta, method;
     int32_t w_off[MAXL];
 };
@@ -754,6 +756,9 @@ __global__ void __launch_bounds__(CF::NT, CF::WPS) snsde_mfma_reverse_kernel(Rev
 #pragma unroll
     for (int e = 0; e < EPT; ++e) adj[e] = 0.0f;
     int rbase = -1;
+    const bool dsum = a.ds_part != nullptr && a.gt != nullptr;   // diffusion-side parameter sums wanted
+    const float rowf = row_ok ? 1.0f : 0.0f;                     // padding rows replicate the last row: excluded
+    float th_acc = 0.0f;
 
     for (int n = a.N - 1; n >= 0; --n) {
         const int nb = (n / CF::ROWCH) * CF::ROWCH;
@@ -785,9 +790,10 @@ __global__ void __launch_bounds__(CF::NT, CF::WPS) snsde_mfma_reverse_kernel(Rev
             for (int e = 0; e < EPT; ++e) a.adj[(size_t)(n + 1) * BH + goff + e] = adj[e];
         }
         // ---- elementwise: d(f h + g dW)/d(zout, y) applied to the adjoint ----
-        float ay[EPT], dz[EPT];
+        float ay[EPT], dz[EPT], dsv[EPT];
 #pragma unroll
         for (int e = 0; e < EPT; ++e) {
+            dsv[e] = 0.0f;
             const float y = a.traj[(size_t)n * BH + goff + e];
             const float z = a.act[(((size_t)n * NSAVE + NSAVE - 1) * B) * H + goff + e];
             const float dw = a.dW[(size_t)n * BH + goff + e];
@@ -801,14 +807,50 @@ __global__ void __launch_bounds__(CF::NT, CF::WPS) snsde_mfma_reverse_kernel(Rev
             if constexpr (CF::GEO) { dz[e] = dzt * ty; acc_y = fmaf(dzt * z, 1.0f - ty * ty, acc_y); }
             else dz[e] = dzt;
             const float raw = mul_y ? gq * y : gq;
-            const float g = fast_tanh(sig_theta * snsde_nan_to_num(raw));
-            if (mul_y && (raw - raw == 0.0f)) {
+            const float rcv = snsde_nan_to_num(raw);
+            const float g = fast_tanh(sig_theta * rcv);
+            const bool finite = (raw - raw == 0.0f);
+            const float om = 1.0f - g * g;
+            if (mul_y && finite) {
                 // d/dy [g dW + mil (dW^2 - h) g g'],  g' = (1 - g^2) c,  (g g')' = c^2 (1 - g^2)(1 - 3 g^2),  c = sigmoid(theta) s_n
-                const float c = sig_theta * gq, om = 1.0f - g * g;
+                const float c = sig_theta * gq;
                 const float dm = mil * fmaf(dw, dw, -h) * c * fmaf(-3.0f * g, g, 1.0f);
                 acc_y = fmaf(av * om * c, dw + dm, acc_y);
             }
             ay[e] = acc_y;
+            if (dsum) {
+                // parameter side of the same term:  d/d sigmoid(theta) and d/d s_n of  g dW + mil (dW^2 - h) g g'
+                const float du = av * dw * om * rowf;
+                th_acc = fmaf(du, rcv, th_acc);
+                float d = finite ? du * sig_theta * (mul_y ? y : 1.0f) : 0.0f;
+                if (mul_y && finite && mil != 0.0f) {
+                    const float c = sig_theta * gq;
+                    const float ex = av * rowf * om * (mil * fmaf(dw, dw, -h)) * fmaf(fmaf(-3.0f * g, g, 1.0f) * c, y, g);
+                    th_acc = fmaf(ex, gq, th_acc);
+                    d = fmaf(ex, sig_theta, d);
+                }
+                dsv[e] = d;
+            }
+        }
+        if (dsum) {     // sum over the tile's rows, one writer lane per feature
+            float* dp = a.ds_part + ((size_t)blockIdx.x * a.N + n) * H + fcol;
+            if constexpr (FL) {     // rows = lane & 3
+                float v = dsv[0];
+                v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xf, 0xf, false));
+                v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xf, 0xf, false));
+                if (r == 0) dp[0] = v;
+            } else {                // rows = lane & 15
+#pragma unroll
+                for (int e = 0; e < EPT; ++e) {
+                    float v = dsv[e];
+                    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x128, 0xf, 0xf, false));
+                    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x124, 0xf, 0xf, false));
+                    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x122, 0xf, 0xf, false));
+                    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x121, 0xf, 0xf, false));
+                    dsv[e] = v;
+                }
+                if (r == 0) *reinterpret_cast<f32x4*>(dp) = f32x4{dsv[0], dsv[1], dsv[2], dsv[3]};
+            }
         }
         float* buf = lds;   // buffer g holds the input of transposed GEMM g
         if constexpr (FL) buf[r * LDA + fcol] = dz[0];
@@ -855,6 +897,11 @@ __global__ void __launch_bounds__(CF::NT, CF::WPS) snsde_mfma_reverse_kernel(Rev
 #pragma unroll
         for (int e = 0; e < EPT; ++e) a.adj[goff + e] = adj[e] + a.grad_ys[goff + e];
     }
+    if (dsum && a.dth_part) {
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) th_acc += __shfl_down(th_acc, off, 64);
+        if (lane == 0) a.dth_part[blockIdx.x * CF::NW + wave] = th_acc;
+    }
 }
 
 template <class CF>
@@ -878,6 +925,8 @@ struct MfmaPlan {
 struct RevPlan {
     bool ok;
     int H, NHID, GEO, FL, NW, n_layers, fold_tmp, total_floats, emb;
+    int nwg;                    // workgroups of the adjoint launch
+    size_t ds_off, dth_off;     // diffusion-side partial sums inside the backward workspace (0 = none)
     MfmaLayerPack layer[MAXL];
 };
 

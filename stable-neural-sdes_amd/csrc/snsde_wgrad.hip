@@ -1,0 +1,553 @@
+// Parameter gradients of the fused solve (include/snsde.h: snsde_param_gradients), gfx950.
+//
+// After the forward (act_save, traj, dW_out) and the MFMA adjoint kernel (adj, delta_save) every parameter gradient
+// of the discretised scheme is a reduction over the R = N*B (step, row) pairs:
+//     d layer.weight = sum_r delta_layer[r]^T . layer_input[r]        d layer.bias = sum_r delta_layer[r]
+// (what autograd accumulates node by node through the unrolled loop, benchmark_classification/common_sde.py:158-160).
+// They are computed here as split-R MFMA GEMMs with per-workgroup partials and ONE deterministic reduction:
+//   1. snsde_wgrad_kernel      : per (128 x 128 output tile, R-split) partial sums  D^T X  on v_mfma_f32_16x16x4_f32,
+//                                operands staged through LDS, bias sums from a ones-column MFMA;
+//                                the first layer's inputs [y | sin t, cos t, X(t)] are built on the fly (spline rows).
+//   2. snsde_wgrad_reduce_kernel: sum of the partials into dense per-job matrices.
+//   3. snsde_dsum_reduce_kernel: the diffusion-side sums (d theta, d s_n; Euler and Milstein) were left per workgroup
+//                                by the adjoint kernel, which has every factor in registers; this adds them up.
+//   4. snsde_noise_hidden_kernel, snsde_assemble_kernel, snsde_small_gemm_kernel: tiny epilogue that maps the sums
+//      to the flat parameter layout.  The folded first layer uses linearity: with S = sum d0^T [yin | X], s0 = sum d0,
+//         d emb.weight = [S_y W_in^T + s0 b_in^T | S_x W_init^T + s0 b_init^T],  d linear_in.weight = E_y^T S_y, ...
+//      so no (N, B, .) intermediate of the un-folded first layer is ever materialised; the time-only noise MLP is
+//      back-propagated over its N inputs the same way.
+#include "snsde_internal.h"
+
+namespace {
+
+constexpr int RC = 32;        // reduction rows per LDS chunk
+constexpr int LD = 144;       // LDS row stride in floats (== 16 mod 64: the four r-groups of an operand read hit distinct banks)
+constexpr int NT = 512;       // 8 waves: one 16-row strip of the 128 x 128 tile each
+constexpr int TILE = 128;
+constexpr int TILE_FLOATS = TILE * TILE + TILE;   // sums + bias column
+constexpr int MAX_TILES = 40;
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+struct WTile {
+    int32_t d_slot;   // delta slot of the left factor D
+    int32_t h0;       // first D feature (output row) of this tile
+    int32_t x_kind;   // 0 = act_save slot, 1 = trajectory y, 2 = control-path columns [sin t, cos t][X(t) channels] (xaux)
+    int32_t x_slot;
+    int32_t k0;       // first X column of this tile
+    int32_t ncols;    // valid X columns in this tile
+    int32_t out;      // float offset (in the sums block) of the dense job matrix
+    int32_t ldo;      // its row stride
+    int32_t bias;     // float offset of the job's bias sums, or -1 (only the k0 == 0 tile of a job carries it)
+    int32_t nsplit;   // R-splits of this tile (proportional to its MFMA work, so all workgroups finish together)
+    int32_t rows_per_split;
+    int32_t part;     // index of its first partial tile
+    int32_t cls;      // 2 * log2(8 / sub-tiles) + (no bias): selects the kernel body
+    int32_t csplit;   // destination column remap: tile columns >= csplit land cshift further right (the aux tile's
+    int32_t cshift;   // [sin t, cos t | X(t)] columns straddle the y block of the first layer's dense sums)
+};
+
+struct WArgs {
+    const float* delta; const float* act; const float* traj; const float* xaux;
+    float* part;       // [tile][split][TILE_FLOATS]
+    float* sums;       // dense job matrices
+    int32_t B, H, N, NG, NSAVE, ldx, R, ntiles;
+    WTile tile[MAX_TILES];
+};
+
+// control-path columns of the first layer's input, one row per (step, batch row): [sin t, cos t][X_c(t_n)], zero padded
+struct XArgs { const float* coeffs; const float* step_tab; float* xaux; int32_t B, C, Lm1, time_cols, naux, ldx, R; };
+
+__global__ void __launch_bounds__(256) snsde_xaux_kernel(XArgs a) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= (size_t)a.R * a.ldx) return;
+    const int r = (int)(i / a.ldx), j = (int)(i - (size_t)r * a.ldx);
+    const int n = r / a.B, b = r - n * a.B;
+    const float* st = a.step_tab + (size_t)n * SNSDE_STEP_STRIDE;
+    float val = 0.0f;
+    if (j < a.time_cols) val = st[2 + j];
+    else if (j < a.naux) {
+        const int c = j - a.time_cols;
+        const float* cr = a.coeffs + ((size_t)b * a.Lm1 + __float_as_int(st[5])) * 4 * a.C;
+        val = snsde_spline_eval(cr[c], cr[a.C + c], cr[2 * a.C + c], cr[3 * a.C + c], st[4]);
+    }
+    a.xaux[i] = val;
+}
+
+// NKT = 16-column sub-tiles of X per wave (compile time: the MFMA chain is branch-free); BIAS: also the column sums of D
+template <int NKT, bool BIAS>
+__device__ __forceinline__ void wgrad_body(const WArgs& a, const WTile& t, float* lds) {
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int split = blockIdx.x;
+    const int r_begin = split * t.rows_per_split;
+    const int r_end = min(a.R, r_begin + t.rows_per_split);
+    const int B = a.B, H = a.H;
+
+    // staging assignment: rows (tid >> 5) and (tid >> 5) + 16 of the chunk, float4 column 4 * (tid & 31), for D and X
+    const int c4 = (tid & 31) * 4;
+    const bool dcol = t.h0 + c4 < H, xcol = c4 < t.ncols;
+    float4 dreg[2], xreg[2];
+    float4 bsum = make_float4(0.f, 0.f, 0.f, 0.f);
+    auto fetch = [&](int r0) {
+#pragma unroll
+        for (int p = 0; p < 2; ++p) {
+            const int r = r0 + (tid >> 5) + 16 * p;
+            float4 dv = make_float4(0.f, 0.f, 0.f, 0.f), xv = dv;
+            if (r < r_end) {
+                const int n = r / B, b = r - n * B;
+                if (dcol) dv = *reinterpret_cast<const float4*>(a.delta + (((size_t)n * a.NG + t.d_slot) * B + b) * H + t.h0 + c4);
+                if (xcol) {
+                    if (t.x_kind == 0)
+                        xv = *reinterpret_cast<const float4*>(a.act + (((size_t)n * a.NSAVE + t.x_slot) * B + b) * H + t.k0 + c4);
+                    else if (t.x_kind == 1)
+                        xv = *reinterpret_cast<const float4*>(a.traj + ((size_t)n * B + b) * H + t.k0 + c4);
+                    else
+                        xv = *reinterpret_cast<const float4*>(a.xaux + (size_t)r * a.ldx + t.k0 + c4);
+                }
+            }
+            dreg[p] = dv; xreg[p] = xv;
+        }
+    };
+    auto stash = [&](int buf) {
+        float* Dl = lds + buf * (2 * RC * LD);
+        float* Xl = Dl + RC * LD;
+#pragma unroll
+        for (int p = 0; p < 2; ++p) {
+            const int rr = (tid >> 5) + 16 * p;
+            *reinterpret_cast<float4*>(Dl + rr * LD + c4) = dreg[p];
+            *reinterpret_cast<float4*>(Xl + rr * LD + c4) = xreg[p];
+            if constexpr (BIAS) {
+                bsum.x += dreg[p].x; bsum.y += dreg[p].y; bsum.z += dreg[p].z; bsum.w += dreg[p].w;
+            }
+        }
+    };
+
+    f32x4 acc[NKT];
+#pragma unroll
+    for (int i = 0; i < NKT; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const bool active = t.h0 + 16 * wave < H;
+    const int li = lane & 15, lq = lane >> 4;
+
+    int buf = 0;
+    if (r_begin < r_end) { fetch(r_begin); stash(0); }
+    __syncthreads();
+    for (int r0 = r_begin; r0 < r_end; r0 += RC) {
+        const bool more = r0 + RC < r_end;
+        if (more) fetch(r0 + RC);
+        if (active) {
+            const float* Dl = lds + buf * (2 * RC * LD);
+            const float* Xl = Dl + RC * LD;
+#pragma unroll
+            for (int q = 0; q < RC / 4; ++q) {
+                const int rr = 4 * q + lq;
+                const float av = Dl[rr * LD + 16 * wave + li];
+                float bv[NKT];
+#pragma unroll
+                for (int i = 0; i < NKT; ++i) bv[i] = Xl[rr * LD + 16 * i + li];
+#pragma unroll
+                for (int i = 0; i < NKT; ++i) acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv[i], acc[i], 0, 0, 0);
+            }
+        }
+        if (more) stash(buf ^ 1);
+        __syncthreads();
+        buf ^= 1;
+    }
+    // partial tile out: rows 16*wave + 4*lq + v, columns 16*i + li
+    float* out = a.part + (size_t)(t.part + split) * TILE_FLOATS;
+#pragma unroll
+    for (int i = 0; i < NKT; ++i)
+#pragma unroll
+        for (int v = 0; v < 4; ++v) out[(16 * wave + 4 * lq + v) * TILE + 16 * i + li] = acc[i][v];
+    if constexpr (BIAS) {      // column sums of D: 16 row-threads per float4 column, summed through LDS
+        float* red = lds;      // all MFMA reads of the buffers are behind the loop's last barrier
+        *reinterpret_cast<float4*>(red + (tid >> 5) * TILE + c4) = bsum;
+        __syncthreads();
+        if (tid < TILE) {
+            float sacc = 0.0f;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) sacc += red[i * TILE + tid];
+            out[TILE * TILE + tid] = sacc;
+        }
+    }
+}
+
+__global__ void __launch_bounds__(NT, 4) snsde_wgrad_kernel(WArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];   // [2 buffers][D | X][RC][LD]
+    const WTile t = a.tile[blockIdx.y];
+    if ((int)blockIdx.x >= t.nsplit) return;
+    switch (t.cls) {     // uniform per workgroup
+        case 0: wgrad_body<8, true>(a, t, lds); break;
+        case 1: wgrad_body<8, false>(a, t, lds); break;
+        case 2: wgrad_body<4, true>(a, t, lds); break;
+        case 3: wgrad_body<4, false>(a, t, lds); break;
+        case 4: wgrad_body<2, true>(a, t, lds); break;
+        case 5: wgrad_body<2, false>(a, t, lds); break;
+        case 6: wgrad_body<1, true>(a, t, lds); break;
+        default: wgrad_body<1, false>(a, t, lds); break;
+    }
+}
+
+// sums[job matrix] = sum over splits of the partial tiles (fixed order: deterministic)
+__global__ void __launch_bounds__(256) snsde_wgrad_reduce_kernel(WArgs a) {
+    const WTile t = a.tile[blockIdx.y];
+    const int e = blockIdx.x * 256 + threadIdx.x;
+    if (e >= TILE_FLOATS) return;
+    if (e < TILE * TILE ? (e % TILE >= t.ncols) : (t.bias < 0)) return;    // never written by the GEMM kernel
+    const float* p = a.part + (size_t)t.part * TILE_FLOATS + e;
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    int s = 0;
+    for (; s + 3 < t.nsplit; s += 4) {
+        s0 += p[(size_t)s * TILE_FLOATS]; s1 += p[(size_t)(s + 1) * TILE_FLOATS];
+        s2 += p[(size_t)(s + 2) * TILE_FLOATS]; s3 += p[(size_t)(s + 3) * TILE_FLOATS];
+    }
+    for (; s < t.nsplit; ++s) s0 += p[(size_t)s * TILE_FLOATS];
+    const float v = (s0 + s1) + (s2 + s3);
+    if (e < TILE * TILE) {
+        const int hl = e / TILE, kl = e % TILE;
+        const int col = t.k0 + kl + (kl >= t.csplit ? t.cshift : 0);
+        if (t.h0 + hl < a.H) a.sums[t.out + (size_t)(t.h0 + hl) * t.ldo + col] = v;
+    } else {
+        const int hl = e - TILE * TILE;
+        if (t.h0 + hl < a.H) a.sums[t.bias + t.h0 + hl] = v;
+    }
+}
+
+// ---- diffusion side: per-workgroup sums of the adjoint kernel -> ds (N, H), dth (1) ---------------------------------
+struct DArgs {
+    const float* ds_part; const float* dth_part;
+    float* ds; float* dth;
+    int32_t nwg, n_dth, NH;
+};
+
+__global__ void __launch_bounds__(256) snsde_dsum_reduce_kernel(DArgs a) {
+    __shared__ float red[256];
+    const int tid = threadIdx.x;
+    if (blockIdx.x == gridDim.x - 1) {          // last block: the theta partials
+        float s = 0.0f;
+        for (int i = tid; i < a.n_dth; i += 256) s += a.dth_part[i];
+        red[tid] = s;
+        __syncthreads();
+        for (int o = 128; o > 0; o >>= 1) {
+            if (tid < o) red[tid] += red[tid + o];
+            __syncthreads();
+        }
+        if (tid == 0) a.dth[0] = red[0];
+        return;
+    }
+    // 64 (n, h) elements per block, four workgroup ranges summed in parallel
+    const int e = blockIdx.x * 64 + (tid & 63), q = tid >> 6;
+    float s0 = 0.f, s1 = 0.f;
+    if (e < a.NH) {
+        const float* p = a.ds_part + e;
+        int w = q;
+        for (; w + 4 < a.nwg; w += 8) { s0 += p[(size_t)w * a.NH]; s1 += p[(size_t)(w + 4) * a.NH]; }
+        if (w < a.nwg) s0 += p[(size_t)w * a.NH];
+    }
+    red[tid] = s0 + s1;
+    __syncthreads();
+    if (q == 0 && e < a.NH) a.ds[e] = (red[tid] + red[tid + 64]) + (red[tid + 128] + red[tid + 192]);
+}
+
+// ---- epilogue -------------------------------------------------------------------------------------------------
+struct GJob {     // C (M x N) = A . B^T (trans 0: A (M, K), B (N, K)) or A^T . B (trans 1: A (K, M), B (K, N); B null = ones)
+    const float* A; const float* B; float* C; const float* u; const float* v;   // + u v^T when u != null
+    int32_t M, N, K, lda, ldb, ldc, trans;
+};
+constexpr int MAX_GJOBS = 10;
+
+struct AArgs {
+    const float* params; const float* sums; const float* ds; const float* dth; const float* gt; const float* step_tab;
+    float* dz1;       // (N, H) scratch: gradient at the hidden pre-activation of the time-only noise MLP
+    float* dz2;       // (N, H) scratch: gradient at its output pre-activation
+    float* a1;        // (N, H) scratch: its hidden activation
+    float* grad;      // flat parameter gradients out
+    SnsdeNet net;
+    int32_t H, C, N, io, no, nhid, P, has_dth;
+    int32_t o_out, b_out, o_hid[SNSDE_MAX_HIDDEN], b_hid[SNSDE_MAX_HIDDEN], o_first, ld_first, b_first;   // offsets in sums
+    int32_t n_jobs;
+    GJob job[MAX_GJOBS];
+};
+
+// noise_option 16/17, s_n = relu(W2 relu(W1 tau_n + b1) + b2):  a1, dz2 = ds * [s_n > 0], dz1 = [a1 > 0] W2^T dz2
+__global__ void snsde_noise_hidden_kernel(AArgs a) {
+    extern __shared__ float dz2s[];
+    const int n = blockIdx.x, H = a.H;
+    for (int h = threadIdx.x; h < H; h += blockDim.x) {
+        const float v = a.gt[(size_t)n * H + h] > 0.0f ? a.ds[(size_t)n * H + h] : 0.0f;
+        dz2s[h] = v;
+        a.dz2[(size_t)n * H + h] = v;
+    }
+    __syncthreads();
+    const float* st = a.step_tab + (size_t)n * SNSDE_STEP_STRIDE;
+    const float* W1 = a.params + a.net.nt0.src_w;
+    const float* b1 = a.params + a.net.nt0.src_b;
+    const float* W2 = a.params + a.net.nt1.src_w;
+    for (int k = threadIdx.x; k < H; k += blockDim.x) {
+        const float z1 = fmaf(W1[2 * k], st[2], fmaf(W1[2 * k + 1], st[3], b1[k]));
+        float s = 0.0f;
+        for (int h = 0; h < H; ++h) s = fmaf(W2[(size_t)h * H + k], dz2s[h], s);
+        a.a1[(size_t)n * H + k] = fmaxf(z1, 0.0f);
+        a.dz1[(size_t)n * H + k] = z1 > 0.0f ? s : 0.0f;
+    }
+}
+
+// dense sums -> flat layout for the parameters that need no further algebra; everything else starts at zero
+__global__ void __launch_bounds__(256) snsde_assemble_kernel(AArgs a) {
+    const int p = blockIdx.x * 256 + threadIdx.x;
+    if (p >= a.P) return;
+    const SnsdeNet& net = a.net;
+    const int H = a.H;
+    const bool emb = (a.io == 2 || a.io == 4 || a.io == 6);
+    const int Kin = net.in.K;
+    float val = 0.0f;
+    auto inside = [&](int off, int count, int& rel) { rel = p - off; return off >= 0 && rel >= 0 && rel < count; };
+    int rel;
+    if (inside(net.out.src_w, H * H, rel)) val = a.sums[a.o_out + rel];
+    else if (inside(net.out.src_b, H, rel)) val = a.sums[a.b_out + rel];
+    else if (!emb && inside(net.in.src_w, H * Kin, rel)) val = a.sums[a.o_first + (size_t)(rel / Kin) * a.ld_first + rel % Kin];
+    else if (!emb && inside(net.in.src_b, H, rel)) val = a.sums[a.b_first + rel];
+    else if (emb && inside(net.emb.src_b, H, rel)) val = a.sums[a.b_first + rel];
+    else if (inside(net.off_theta, 1, rel)) {
+        if (a.has_dth) {
+            const float sg = snsde_sigmoid(a.params[net.off_theta]);
+            val = a.dth[0] * sg * (1.0f - sg);
+        }
+    } else {
+        for (int l = 0; l < a.nhid; ++l) {
+            if (inside(net.hid[l].src_w, H * H, rel)) { val = a.sums[a.o_hid[l] + rel]; break; }
+            if (inside(net.hid[l].src_b, H, rel)) { val = a.sums[a.b_hid[l] + rel]; break; }
+        }
+    }
+    a.grad[p] = val;
+}
+
+// the small products of the epilogue (K, M, N of a few hundred): 32 x 32 output tiles, operands staged through LDS
+__global__ void __launch_bounds__(256) snsde_small_gemm_kernel(AArgs a) {
+    __shared__ float As[32][33], Bs[32][33];
+    const GJob j = a.job[blockIdx.z];
+    const int m0 = blockIdx.y * 32, n0 = blockIdx.x * 32;
+    if (m0 >= j.M || n0 >= j.N) return;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;     // 32 x 8
+    float acc[4] = {0.f, 0.f, 0.f, 0.f};                        // rows ty + 8 i, column tx
+    for (int k0 = 0; k0 < j.K; k0 += 32) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int rr = ty + 8 * i;
+            if (j.trans == 0) {      // As[m][k], Bs[n][k]: k contiguous in memory
+                As[rr][tx] = (m0 + rr < j.M && k0 + tx < j.K) ? j.A[(size_t)(m0 + rr) * j.lda + k0 + tx] : 0.0f;
+                Bs[rr][tx] = (n0 + rr < j.N && k0 + tx < j.K) ? j.B[(size_t)(n0 + rr) * j.ldb + k0 + tx] : 0.0f;
+            } else {                 // As[k][m], Bs[k][n]: m / n contiguous in memory
+                As[rr][tx] = (k0 + rr < j.K && m0 + tx < j.M) ? j.A[(size_t)(k0 + rr) * j.lda + m0 + tx] : 0.0f;
+                Bs[rr][tx] = (k0 + rr < j.K && n0 + tx < j.N) ? (j.B ? j.B[(size_t)(k0 + rr) * j.ldb + n0 + tx] : 1.0f) : 0.0f;
+            }
+        }
+        __syncthreads();
+        if (j.trans == 0) {
+#pragma unroll 8
+            for (int k = 0; k < 32; ++k) {
+                const float b = Bs[tx][k];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) acc[i] = fmaf(As[ty + 8 * i][k], b, acc[i]);
+            }
+        } else {
+#pragma unroll 8
+            for (int k = 0; k < 32; ++k) {
+                const float b = Bs[k][tx];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) acc[i] = fmaf(As[k][ty + 8 * i], b, acc[i]);
+            }
+        }
+        __syncthreads();
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int m = m0 + ty + 8 * i, n = n0 + tx;
+        if (m < j.M && n < j.N) j.C[(size_t)m * j.ldc + n] = acc[i] + (j.u ? j.u[m] * j.v[n] : 0.0f);
+    }
+}
+
+struct WPlan {
+    int ntiles, max_split, naux, ldx;
+    size_t part_floats, sums_floats, ds_off, dth_off, dz1_off, dz2_off, a1_off, xaux_off, total_floats;
+    bool tnoise;
+    AArgs aa;
+    WTile tile[MAX_TILES];
+};
+
+int nkt_class(int ncols) { return ncols > 64 ? 8 : (ncols > 32 ? 4 : (ncols > 16 ? 2 : 1)); }
+
+bool make_wplan(const snsde_backward* b, const SnsdeNet& net, WPlan* w) {
+    const snsde_solve& s = b->fwd;
+    const int H = s.model.hidden_channels, C = s.model.input_channels, io = s.model.input_option, no = s.model.noise_option;
+    const int nhid = s.model.num_hidden_layers - 1;
+    const bool emb = (io == 2 || io == 4 || io == 6), timef = io >= 3;
+    const int ts = timef ? 2 : 0, naux = ts + (emb ? C : 0);
+    const int R = s.n_steps * s.batch;
+    AArgs& aa = w->aa;
+    aa = AArgs{};
+    int nt = 0;
+    size_t off = 0;
+    const int ht = (H + TILE - 1) / TILE;
+    auto add_tiles = [&](int d_slot, int x_kind, int x_slot, int ncols_total, int o_mat, int ldo, int o_bias, int csplit,
+                         int cshift) {
+        for (int hi = 0; hi < ht; ++hi)
+            for (int k0 = 0; k0 < ncols_total; k0 += TILE) {
+                if (nt >= MAX_TILES) return false;
+                WTile& t = w->tile[nt++];
+                t = WTile{};
+                t.d_slot = d_slot; t.h0 = hi * TILE; t.x_kind = x_kind; t.x_slot = x_slot; t.k0 = k0;
+                t.ncols = ncols_total - k0 < TILE ? ncols_total - k0 : TILE;
+                t.out = o_mat; t.ldo = ldo; t.bias = (o_bias >= 0 && k0 == 0) ? o_bias : -1;
+                t.csplit = csplit; t.cshift = cshift;
+            }
+        return true;
+    };
+    auto alloc = [&](size_t n) { const int o = (int)off; off += n; return o; };
+    aa.o_out = alloc((size_t)H * H); aa.b_out = alloc(H);
+    bool ok = add_tiles(0, 0, nhid, H, aa.o_out, H, aa.b_out, 1 << 30, 0);
+    for (int l = 0; l < nhid && ok; ++l) {
+        aa.o_hid[l] = alloc((size_t)H * H); aa.b_hid[l] = alloc(H);
+        ok = add_tiles(nhid - l, 0, l, H, aa.o_hid[l], H, aa.b_hid[l], 1 << 30, 0);
+    }
+    // first layer: dense sums in linear_in's column order followed by the control channels: [sin t, cos t | y | X(t)]
+    aa.ld_first = ts + H + (emb ? C : 0);
+    aa.o_first = alloc((size_t)H * aa.ld_first); aa.b_first = alloc(H);
+    ok = ok && add_tiles(nhid + 1, 1, 0, H, aa.o_first + ts, aa.ld_first, aa.b_first, 1 << 30, 0);
+    if (ok && naux > 0) ok = add_tiles(nhid + 1, 2, 0, naux, aa.o_first, aa.ld_first, -1, ts, H);
+    if (!ok) return false;
+    w->ntiles = nt;
+    // R-splits per tile proportional to its work (MFMAs per slab + staging), ~2 workgroups per CU in total
+    const int chunks = (R + RC - 1) / RC;
+    int wsum = 0;
+    for (int i = 0; i < nt; ++i) wsum += nkt_class(w->tile[i].ncols) + 4;
+    int nparts = 0;
+    w->max_split = 1;
+    for (int i = 0; i < nt; ++i) {
+        WTile& t = w->tile[i];
+        const int nk = nkt_class(t.ncols);
+        t.cls = (nk == 8 ? 0 : (nk == 4 ? 2 : (nk == 2 ? 4 : 6))) + (t.bias >= 0 ? 0 : 1);
+        int ns = (512 * (nk + 4) + wsum / 2) / wsum;
+        if (ns < 1) ns = 1;
+        if (ns > chunks) ns = chunks;
+        t.rows_per_split = ((chunks + ns - 1) / ns) * RC;
+        t.nsplit = (R + t.rows_per_split - 1) / t.rows_per_split;
+        t.part = nparts;
+        nparts += t.nsplit;
+        if (t.nsplit > w->max_split) w->max_split = t.nsplit;
+    }
+    w->sums_floats = (off + 3) & ~(size_t)3;
+    w->part_floats = (size_t)nparts * TILE_FLOATS;
+    w->tnoise = (no == 12 || no == 13 || no == 16 || no == 17);
+    const bool two = (no == 16 || no == 17);
+    size_t o = w->sums_floats + w->part_floats;
+    const size_t NH = (size_t)s.n_steps * H;
+    w->ds_off = o; o += w->tnoise ? NH : 0;
+    w->dth_off = o; o += 4;
+    w->dz1_off = o; o += two ? NH : 0;
+    w->dz2_off = o; o += two ? NH : 0;
+    w->a1_off = o; o += two ? NH : 0;
+    o = (o + 3) & ~(size_t)3;
+    w->naux = naux; w->ldx = (naux + 3) & ~3;
+    w->xaux_off = o; o += (size_t)R * w->ldx;
+    w->total_floats = o + 16;
+    aa.net = net; aa.H = H; aa.C = C; aa.N = s.n_steps; aa.io = io; aa.no = no; aa.nhid = nhid; aa.has_dth = w->tnoise ? 1 : 0;
+    return true;
+}
+
+}  // namespace
+
+size_t snsde_wgrad_workspace_floats(const snsde_backward* b, const SnsdeNet& net) {
+    WPlan w;
+    return make_wplan(b, net, &w) ? w.total_floats : 0;
+}
+
+int snsde_wgrad_launch(const snsde_backward* b, const SnsdeNet& net, float* grad_params, int32_t n_params, float* ws,
+                       hipStream_t stream) {
+    WPlan plan;
+    WPlan* wp = &plan;
+    if (!make_wplan(b, net, wp)) return SNSDE_ERR_UNSUPPORTED;
+    const snsde_solve& s = b->fwd;
+    const int H = s.model.hidden_channels, C = s.model.input_channels, io = s.model.input_option, no = s.model.noise_option;
+    WArgs a{};
+    a.delta = b->delta_save; a.act = s.act_save; a.traj = s.traj; a.xaux = ws + wp->xaux_off;
+    a.sums = ws; a.part = ws + wp->sums_floats;
+    a.B = s.batch; a.H = H; a.N = s.n_steps; a.NG = s.model.num_hidden_layers + 1; a.NSAVE = s.model.num_hidden_layers + 1;
+    a.ldx = wp->ldx; a.R = s.n_steps * s.batch; a.ntiles = wp->ntiles;
+    for (int i = 0; i < wp->ntiles; ++i) a.tile[i] = wp->tile[i];
+    if (wp->naux > 0) {
+        XArgs x{};
+        x.coeffs = s.coeffs; x.step_tab = s.step_tab; x.xaux = ws + wp->xaux_off;
+        x.B = s.batch; x.C = C; x.Lm1 = s.knots - 1; x.time_cols = io >= 3 ? 2 : 0; x.naux = wp->naux; x.ldx = wp->ldx; x.R = a.R;
+        const size_t total = (size_t)a.R * wp->ldx;
+        hipLaunchKernelGGL(snsde_xaux_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, x);
+    }
+    const size_t lds_bytes = (size_t)2 * 2 * RC * LD * sizeof(float);
+    static bool attr_done = false;
+    if (!attr_done) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(snsde_wgrad_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                (int)lds_bytes) != hipSuccess) return SNSDE_ERR_LDS;
+        attr_done = true;
+    }
+    hipLaunchKernelGGL(snsde_wgrad_kernel, dim3(wp->max_split, wp->ntiles), dim3(NT), lds_bytes, stream, a);
+    hipLaunchKernelGGL(snsde_wgrad_reduce_kernel, dim3((TILE_FLOATS + 255) / 256, wp->ntiles), dim3(256), 0, stream, a);
+
+    AArgs aa = wp->aa;
+    const float* gt = snsde_mfma_gt_table(&s, net);
+    float* ds = ws + wp->ds_off;
+    aa.params = s.params; aa.sums = ws; aa.ds = ds; aa.dth = ws + wp->dth_off;
+    aa.dz1 = ws + wp->dz1_off; aa.dz2 = ws + wp->dz2_off; aa.a1 = ws + wp->a1_off;
+    aa.gt = gt; aa.step_tab = s.step_tab; aa.grad = grad_params; aa.P = n_params;
+    const bool two = (no == 16 || no == 17);
+    if (wp->tnoise) {
+        int nwg = 0, waves = 0; size_t ds_off = 0, dth_off = 0;
+        if (!gt || !b->workspace || !snsde_mfma_backward_partials(&s, net, &nwg, &waves, &ds_off, &dth_off))
+            return SNSDE_ERR_UNSUPPORTED;
+        const float* bws = static_cast<const float*>(b->workspace);
+        DArgs d{};
+        d.ds_part = bws + ds_off; d.dth_part = bws + dth_off; d.ds = ds; d.dth = ws + wp->dth_off;
+        d.nwg = nwg; d.n_dth = nwg * waves; d.NH = s.n_steps * H;
+        hipLaunchKernelGGL(snsde_dsum_reduce_kernel, dim3((d.NH + 63) / 64 + 1), dim3(256), 0, stream, d);
+        if (two)
+            hipLaunchKernelGGL(snsde_noise_hidden_kernel, dim3(s.n_steps), dim3(H < 256 ? H : 256), H * sizeof(float), stream, aa);
+    }
+    // small products straight into the flat gradient (after the assemble kernel has written every other entry)
+    int nj = 0;
+    auto add_job = [&](const float* A, int lda, const float* B, int ldb, float* Cm, int ldc, int M, int N, int K, int trans,
+                       const float* u, const float* v) {
+        GJob& j = aa.job[nj++];
+        j.A = A; j.B = B; j.C = Cm; j.u = u; j.v = v; j.M = M; j.N = N; j.K = K; j.lda = lda; j.ldb = ldb; j.ldc = ldc; j.trans = trans;
+    };
+    const bool emb = (io == 2 || io == 4 || io == 6);
+    int maxM = 1, maxN = 1;
+    if (emb) {
+        const int Kin = net.in.K, Kf = aa.ld_first;
+        const float* Sf = ws + aa.o_first;            // (H, Kf): [linear_in's columns | control channels]
+        const float* s0 = ws + aa.b_first;
+        const float* E = s.params + net.emb.src_w;    // (H, 2H)
+        float* gE = grad_params + net.emb.src_w;
+        add_job(Sf, Kf, s.params + net.in.src_w, Kin, gE, 2 * H, H, H, Kin, 0, s0, s.params + net.in.src_b);
+        add_job(Sf + Kin, Kf, s.params + net.init.src_w, C, gE + H, 2 * H, H, H, C, 0, s0, s.params + net.init.src_b);
+        add_job(E, 2 * H, Sf, Kf, grad_params + net.in.src_w, Kin, H, Kin, H, 1, nullptr, nullptr);
+        add_job(E + H, 2 * H, Sf + Kin, Kf, grad_params + net.init.src_w, C, H, C, H, 1, nullptr, nullptr);
+        add_job(E, 2 * H, s0, 1, grad_params + net.in.src_b, 1, H, 1, H, 1, nullptr, nullptr);
+        add_job(E + H, 2 * H, s0, 1, grad_params + net.init.src_b, 1, H, 1, H, 1, nullptr, nullptr);
+        maxM = H; maxN = Kin > H ? Kin : H;
+    }
+    if (wp->tnoise) {
+        const float* tau = s.step_tab + 2;
+        const float* src = two ? aa.dz1 : ds;          // gradient at the output of noise_t(.0)
+        add_job(src, H, tau, SNSDE_STEP_STRIDE, grad_params + net.nt0.src_w, 2, H, 2, s.n_steps, 1, nullptr, nullptr);
+        add_job(src, H, nullptr, 0, grad_params + net.nt0.src_b, 1, H, 1, s.n_steps, 1, nullptr, nullptr);
+        if (two) {
+            add_job(aa.dz2, H, aa.a1, H, grad_params + net.nt1.src_w, H, H, H, s.n_steps, 1, nullptr, nullptr);
+            add_job(aa.dz2, H, nullptr, 0, grad_params + net.nt1.src_b, 1, H, 1, s.n_steps, 1, nullptr, nullptr);
+        }
+        if (H > maxM) maxM = H;
+        if (H > maxN) maxN = H;
+    }
+    aa.n_jobs = nj;
+    hipLaunchKernelGGL(snsde_assemble_kernel, dim3((n_params + 255) / 256), dim3(256), 0, stream, aa);
+    if (nj > 0)
+        hipLaunchKernelGGL(snsde_small_gemm_kernel, dim3((maxN + 31) / 32, (maxM + 31) / 32, nj), dim3(256), 0, stream, aa);
+    return hipGetLastError() == hipSuccess ? SNSDE_OK : SNSDE_ERR_LAUNCH;
+}

@@ -3,6 +3,7 @@
 PyTorch is used only for device memory and streams; all arithmetic of the hot path runs in
 libsnsde.so (HIP).  Nothing here falls back to CPU math.
 """
+import os
 import ctypes as C
 from collections import OrderedDict
 
@@ -65,11 +66,29 @@ def _recognise(sde):
 
 
 def flatten_params(sde, layout, numel, device):
-    """One float32 device buffer in the C ABI's layout (state_dict order)."""
+    """One float32 device buffer in the C ABI's layout (state_dict order).
+
+    The first call concatenates the parameters and (when they are float32 tensors on `device`) re-points every
+    `param.data` at its slice of that buffer, so later calls — including after in-place optimizer steps, which now
+    write straight into the buffer — return it without launching anything.  Anything that re-allocates a parameter
+    (`.to()`, `.double()`, a new nn.Parameter) is detected by the address check and triggers a fresh flatten."""
     params = dict(sde.named_parameters())
-    flat = torch.cat([params[name].detach().reshape(-1).to(device=device, dtype=torch.float32)
-                      for name, _, _ in layout])
+    plist = [params[name] for name, _, _ in layout]
+    arena = getattr(sde, '_snsde_flat', None)
+    if arena is not None and arena.device == device:
+        base = arena.data_ptr()
+        if all(p.data_ptr() == base + 4 * off and p.dtype == torch.float32 for p, (_, off, _) in zip(plist, layout)):
+            return arena
+    flat = torch.cat([p.detach().reshape(-1).to(device=device, dtype=torch.float32) for p in plist])
     assert flat.numel() == numel
+    if all(p.dtype == torch.float32 and p.device == device for p in plist) and os.environ.get('SNSDE_NO_PARAM_ARENA') != '1':
+        with torch.no_grad():
+            for p, (_, off, shape) in zip(plist, layout):
+                p.data = flat[off:off + p.numel()].view(shape)
+        try:
+            object.__setattr__(sde, '_snsde_flat', flat)
+        except Exception:
+            pass
     return flat
 
 
@@ -211,6 +230,26 @@ def backward_supported(call):
     return int(_lib.lib().snsde_backward_supported(C.byref(call.desc)))
 
 
+_MODE_CACHE = {}
+
+
+def backward_mode(model, batch, knots, grid, method, kernel='auto', exact_order=False):
+    """backward_supported for a solve that has not been allocated yet (memoised per configuration)."""
+    key = (model.input_channels, model.hidden_channels, model.hidden_hidden_channels, model.num_hidden_layers,
+           model.input_option, model.noise_option, batch, knots, grid.N, grid.T, method, kernel, exact_order)
+    hit = _MODE_CACHE.get(key)
+    if hit is None:
+        s = _lib.Solve()
+        s.model = model
+        s.batch, s.knots, s.n_steps, s.n_out = batch, knots, grid.N, grid.T
+        s.method = {'euler': _lib.EULER, 'milstein': _lib.MILSTEIN, 'srk': _lib.SRK}[method]
+        s.kernel = _lib.KERNELS[kernel]
+        s.flags = _lib.FLAG_EXACT_ORDER if exact_order else 0
+        hit = int(_lib.lib().snsde_backward_supported(C.byref(s)))
+        _MODE_CACHE[key] = hit
+    return hit
+
+
 def solve_backward(call, grad_ys, stream=None, save_delta=False):
     """Adjoint recursion over a finished training-mode solve (SolveCall with save_traj/save_dW/save_act):
     returns adj (N+1, B, H), adj[n] = dL/dy_n; adj[0] is the gradient w.r.t. y0."""
@@ -229,7 +268,30 @@ def solve_backward(call, grad_ys, stream=None, save_delta=False):
     stream = torch.cuda.current_stream(adj.device) if stream is None else stream
     _lib.check(_lib.lib().snsde_solve_backward(C.byref(b), C.c_void_p(stream.cuda_stream)), 'snsde_solve_backward')
     call.keep_bwd = (ws, grad_ys)
+    call.bwd_desc = b
     return (adj, delta) if save_delta else adj
+
+
+def param_gradients(call, adj, delta, stream=None):
+    """Flat parameter gradient (the C ABI's layout) of a finished MFMA-path solve + adjoint: snsde_param_gradients
+    (split-R MFMA weight-gradient GEMMs, diffusion reductions, first-layer algebra), all on the device."""
+    b = _lib.Backward()
+    b.fwd = call.desc
+    b.fwd.flags = call.base_flags
+    b.adj, b.delta_save = _ptr(adj), _ptr(delta)
+    bws = call.keep_bwd[0]          # the adjoint's workspace: holds its per-workgroup diffusion-side sums
+    b.workspace, b.workspace_bytes = _ptr(bws), bws.numel()
+    L = _lib.lib()
+    nbytes = L.snsde_param_gradients_workspace_bytes(C.byref(b))
+    if nbytes == 0:
+        raise NotImplementedError('snsde_param_gradients covers the MFMA-path configurations only')
+    ws = torch.empty(nbytes, device=adj.device, dtype=torch.uint8)
+    grad = torch.empty(call.keep[0].numel(), device=adj.device, dtype=torch.float32)
+    stream = torch.cuda.current_stream(adj.device) if stream is None else stream
+    _lib.check(L.snsde_param_gradients(C.byref(b), _ptr(grad), _ptr(ws), ws.numel(), C.c_void_p(stream.cuda_stream)),
+               'snsde_param_gradients')
+    call.keep_pg = (ws, adj, delta)
+    return grad
 
 
 def eval_fg(model, flat_params, coeffs, times_host, t, y, kernel='auto'):

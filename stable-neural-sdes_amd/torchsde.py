@@ -111,9 +111,8 @@ def _sdeint_hip(sde, rec, y0, ts, bm, method, dt, options):
     coeffs = coeffs.detach().to(device=dev, dtype=torch.float32).contiguous()
     y0c = y0.detach().to(torch.float32).contiguous()
     times_host = _HostTimes.get(sde.times)
-    ts_host = ts.detach().to('cpu', torch.float32).numpy()
+    ts_host = _HostTimes.get(ts)
     grid = engine.step_grid(ts_host, dt, times_host, dev)
-    flat = engine.flatten_params(sde, layout, numel, dev)
     dW = dU = None
     if bm is not None:
         t0 = torch.from_numpy(grid.t0)
@@ -132,6 +131,7 @@ def _sdeint_hip(sde, rec, y0, ts, bm, method, dt, options):
     if needs_grad:
         return _FusedSolve.apply(sde, rec, coeffs, grid, times_host, dW, method, seed, options, y0,
                                       *[p for _, p in sde.named_parameters()])
+    flat = engine.flatten_params(sde, layout, numel, dev)
     call = engine.SolveCall(model, flat, coeffs, grid, y0c, dW=dW, method=method, seed=seed,
                             row_offset=int(options.get('row_offset', 0)), kernel=options.get('kernel', 'auto'),
                             save_traj=bool(options.get('save_traj', False)),
@@ -159,8 +159,8 @@ class _FusedSolve(torch.autograd.Function):
             return engine.SolveCall(model, flat, coeffs, grid, y0c, dW=dW, method=method, seed=seed,
                                     row_offset=int(options.get('row_offset', 0)), kernel=kernel, save_traj=True,
                                     save_dW=True, save_act=save_act, exact_order=bool(options.get('exact_order', False)))
-        call = make(options.get('kernel', 'auto'), False)
-        mode = engine.backward_supported(call)
+        mode = engine.backward_mode(model, y0c.shape[0], coeffs.shape[1] + 1, grid, method, options.get('kernel', 'auto'),
+                                    bool(options.get('exact_order', False)))
         if mode == 0:
             raise NotImplementedError(
                 "the fused backward covers method 'euler'/'milstein' with a diffusion that is elementwise in y "
@@ -168,6 +168,8 @@ class _FusedSolve(torch.autograd.Function):
                 "through the tensor-op loop")
         call = make(options.get('kernel', 'auto'), True) if mode == 1 else make('generic', False)
         ctx.mode, ctx.method = mode, method
+        ctx.param_pass = options.get('param_pass', 'hip')
+        ctx.layout = (layout, numel)
         ys = call.launch()
         ctx.call, ctx.sde, ctx.grid, ctx.times_host = call, sde, grid, times_host
         ctx.names = [n for n, _ in sde.named_parameters()]
@@ -179,7 +181,16 @@ class _FusedSolve(torch.autograd.Function):
         call, sde, grid = ctx.call, ctx.sde, ctx.grid
         if ctx.mode == 1:     # MFMA adjoint kernel + GEMMs on the saved activations / deltas
             adj, delta = engine.solve_backward(call, grad_ys.to(torch.float32).contiguous(), save_delta=True)
-            grads = _parameter_gradients_gemm(sde, call, grid, adj, delta, method=ctx.method)
+            if ctx.param_pass == 'torch':     # library-GEMM cross-check of the native pass
+                grads = _parameter_gradients_gemm(sde, call, grid, adj, delta, method=ctx.method)
+            else:
+                flat = engine.param_gradients(call, adj, delta)
+                layout, _ = ctx.layout
+                offs = {name: (off, shape) for name, off, shape in layout}
+                grads = []
+                for name, p in sde.named_parameters():
+                    off, shape = offs[name]
+                    grads.append(flat[off:off + p.numel()].view_as(p).to(p.dtype))
         else:                 # generic adjoint kernel (any dims, Euler / Milstein) + batched autograd parameter pass
             adj = engine.solve_backward(call, grad_ys.to(torch.float32).contiguous())
             grads = _parameter_gradients(sde, call, grid, adj, method=ctx.method)
@@ -368,7 +379,7 @@ def _sdeint_torch(sde, y0, ts, bm, method, dt, options, names):
         raise NotImplementedError("only diagonal noise is implemented")
     if getattr(sde, 'sde_type', 'ito') != 'ito':
         raise NotImplementedError("only Ito SDEs are implemented")
-    ts_host = ts.detach().to('cpu', torch.float32).numpy()
+    ts_host = _HostTimes.get(ts)
     grid = engine.StepGrid(ts_host, dt, np.array([0.0, 1.0], dtype=np.float32), None)
     if bm is None:
         bm = BrownianIncrements(size=tuple(y0.shape), dtype=y0.dtype, device=y0.device, entropy=options.get('seed'))

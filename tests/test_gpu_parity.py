@@ -570,6 +570,37 @@ def _check_backward(seed, io, no, NL, B, H, C, L, ts, dt, method, kernel):
         close(p.grad, gref, name)
 
 
+@pytest.mark.parametrize('case', [(4, 17, 2, 300, 128, 21, 13, 'euler'), (6, 17, 3, 70, 64, 7, 9, 'milstein'),
+                                  (3, 13, 2, 45, 32, 3, 8, 'milstein'), (1, 0, 1, 33, 16, 3, 8, 'euler'),
+                                  (5, 12, 4, 40, 128, 3, 8, 'euler'), (2, 16, 2, 130, 256, 14, 9, 'milstein')])
+def test_native_parameter_pass_matches_library_gemm_pass(case):
+    """snsde_param_gradients (split-R MFMA GEMMs + reductions + first-layer algebra) against the same sums formed with
+    library GEMMs / elementwise torch ops from the identical saved tensors."""
+    io, no, NL, B, H, C, L, method = case
+    pr = make_problem(77, io, no, NL, B, H, C, L)
+    ts = np.asarray([0, (L - 1) / 2, L - 1], np.float32)
+    dW = draw_dW(77, ts, 1.0, B, H)
+    wsum = torch.from_numpy(np.random.default_rng(7).standard_normal((len(ts), B, H)).astype(np.float32)).to(DEV)
+    out = {}
+    for mode in ('hip', 'torch'):
+        m = S.Diffusion_model(C, H, H, NL, input_option=io, noise_option=no)
+        m.load_state_dict({k: torch.from_numpy(v.copy()) for k, v in pr['params'].items()})
+        m = m.to(DEV)
+        m.set_X(torch.from_numpy(pr['coeffs']).to(DEV), torch.from_numpy(pr['times']).to(DEV))
+        y0 = torch.from_numpy(pr['y0']).to(DEV).requires_grad_(True)
+        ys = S.sdeint(m, y0, torch.from_numpy(ts).to(DEV), bm=_ReplayBM(torch.from_numpy(dW).to(DEV)), method=method, dt=1.0,
+                      options={'param_pass': mode})
+        (ys * wsum).sum().backward()
+        out[mode] = {k: (None if p.grad is None else p.grad.detach().cpu().numpy()) for k, p in m.named_parameters()}
+    for k, ref in out['torch'].items():
+        got = out['hip'][k]
+        if ref is None or np.abs(ref).max() == 0.0:
+            assert got is None or np.abs(got).max() < 1e-6, k
+            continue
+        scale = np.abs(ref).max()
+        assert np.abs(got - ref).max() / scale < 2e-4, (k, np.abs(got - ref).max() / scale)
+
+
 def test_backward_unsupported_configurations_raise():
     pr = make_problem(9, 1, 18, 2, 8, 64, 3, 5)       # diffusion nets have no fused backward yet
     m = S.Diffusion_model(3, 64, 64, 2, input_option=1, noise_option=18).to(DEV)

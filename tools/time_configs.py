@@ -41,6 +41,12 @@ for name, io, no, NL, B, H, C, L, method, ts_all in CFG:
     tf = min(timeit(fwd), timeit(fwd))
     try:
         tb = timeit(fwd_bwd, 5)
+        if '-v' in sys.argv:
+            per = []
+            for _ in range(12):
+                torch.cuda.synchronize(); t = time.perf_counter(); fwd_bwd(); torch.cuda.synchronize()
+                per.append((time.perf_counter() - t) * 1e3)
+            print('   per-iteration fwd+bwd ms:', ' '.join(f'{x:.2f}' for x in per))
         tb = f'{tb:8.3f} ms'
     except NotImplementedError:
         tb = '   n/a'

@@ -45,6 +45,7 @@ from stable_neural_sdes_amd.torchsde import _parameter_gradients
 print('parameter-gradient pass (batched, torch):      %.3f ms' % timeit(lambda: _parameter_gradients(m, call, grid, adj), 5))
 from stable_neural_sdes_amd.torchsde import _parameter_gradients_gemm
 print('parameter-gradient pass (GEMMs on saved tensors): %.3f ms' % timeit(lambda: _parameter_gradients_gemm(m, call, grid, adj, delta), 5))
+print('parameter-gradient pass (native snsde_param_gradients): %.3f ms' % timeit(lambda: S.engine.param_gradients(call, adj, delta), 10))
 ga = _parameter_gradients(m, call, grid, adj); gb = _parameter_gradients_gemm(m, call, grid, adj, delta)
 for (nm, _), x, y in zip(m.named_parameters(), ga, gb):
     print(f'  {nm:28s} rel diff {float((x - y).abs().max() / (x.abs().max() + 1e-20)):.2e}')
