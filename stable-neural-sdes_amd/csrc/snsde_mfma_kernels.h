@@ -760,7 +760,34 @@ __global__ void __launch_bounds__(CF::NT, CF::WPS) snsde_mfma_reverse_kernel(Rev
     const float rowf = row_ok ? 1.0f : 0.0f;                     // padding rows replicate the last row: excluded
     float th_acc = 0.0f;
 
+    // per-step inputs from HBM are fetched one step ahead, so their latency hides behind the previous step's GEMM chain
+    struct StepIn { float y[EPT], z[EPT], dw[EPT], gq[EPT]; f32x4 mask[NG - 1]; };
+    auto prefetch = [&](int n, StepIn& p) {
+#pragma unroll
+        for (int e = 0; e < EPT; ++e) {
+            p.y[e] = a.traj[(size_t)n * BH + goff + e];
+            p.z[e] = a.act[(((size_t)n * NSAVE + NSAVE - 1) * B) * H + goff + e];
+            p.dw[e] = a.dW[(size_t)n * BH + goff + e];
+            p.gq[e] = a.gt ? a.gt[(size_t)n * H + fcol + e] : 0.0f;
+        }
+        if (writer) {
+#pragma unroll
+            for (int g = 0; g < NG - 1; ++g)     // relu mask of the forward activation feeding transposed GEMM g + 1
+                p.mask[g] = *reinterpret_cast<const f32x4*>(
+                    a.act + (((size_t)n * NSAVE + (NHID - g)) * B + rowc) * H + wave * 16 + fsub);
+        }
+    };
+    constexpr bool AHEAD = !CF::STREAM;   // the streamed-weight variant (H = 256) has no registers to spare for it
+    StepIn cur, nxt;
+    if constexpr (AHEAD) prefetch(a.N - 1, cur);
+
     for (int n = a.N - 1; n >= 0; --n) {
+        if constexpr (AHEAD) {
+            nxt = cur;
+            if (n > 0) prefetch(n - 1, nxt);
+        } else {
+            prefetch(n, cur);
+        }
         const int nb = (n / CF::ROWCH) * CF::ROWCH;
         if (nb != rbase) {           // (re)stage the step-table chunk; previous step's readers are past its last barrier
             __syncthreads();
@@ -794,10 +821,7 @@ __global__ void __launch_bounds__(CF::NT, CF::WPS) snsde_mfma_reverse_kernel(Rev
 #pragma unroll
         for (int e = 0; e < EPT; ++e) {
             dsv[e] = 0.0f;
-            const float y = a.traj[(size_t)n * BH + goff + e];
-            const float z = a.act[(((size_t)n * NSAVE + NSAVE - 1) * B) * H + goff + e];
-            const float dw = a.dW[(size_t)n * BH + goff + e];
-            const float gq = a.gt ? a.gt[(size_t)n * H + fcol + e] : 0.0f;
+            const float y = cur.y[e], z = cur.z[e], dw = cur.dw[e], gq = cur.gq[e];
             const float av = adj[e];
             float ty = 1.0f, zt = z;
             if constexpr (CF::GEO) { ty = fast_tanh(y); zt = z * ty; }
@@ -874,8 +898,7 @@ __global__ void __launch_bounds__(CF::NT, CF::WPS) snsde_mfma_reverse_kernel(Rev
             if (g < NG - 1) {
                 // relu mask of the forward activation that produced this gradient's input: slot NHID - g
                 if (writer) {
-                    const f32x4 zsv = *reinterpret_cast<const f32x4*>(
-                        a.act + (((size_t)n * NSAVE + (NHID - g)) * B + rowc) * H + wave * 16 + fsub);
+                    const f32x4 zsv = cur.mask[g];
 #pragma unroll
                     for (int i = 0; i < 4; ++i) v[i] = zsv[i] > 0.0f ? v[i] : 0.0f;
                     *reinterpret_cast<f32x4*>(lds + (g + 1) * M * LDA + r * LDA + wave * 16 + fsub) = v;
@@ -892,6 +915,7 @@ __global__ void __launch_bounds__(CF::NT, CF::WPS) snsde_mfma_reverse_kernel(Rev
                 }
             }
         }
+        if constexpr (AHEAD) cur = nxt;
     }
     if (row_ok) {     // ys[0] = y0
 #pragma unroll

@@ -269,25 +269,33 @@ struct AArgs {
 };
 
 // noise_option 16/17, s_n = relu(W2 relu(W1 tau_n + b1) + b2):  a1, dz2 = ds * [s_n > 0], dz1 = [a1 > 0] W2^T dz2
-__global__ void snsde_noise_hidden_kernel(AArgs a) {
-    extern __shared__ float dz2s[];
-    const int n = blockIdx.x, H = a.H;
-    for (int h = threadIdx.x; h < H; h += blockDim.x) {
+__global__ void __launch_bounds__(256) snsde_noise_hidden_kernel(AArgs a) {
+    extern __shared__ float sm[];      // dz2 (H) | partial sums (4 x 64)
+    float* dz2s = sm;
+    float* red = sm + a.H;
+    const int n = blockIdx.x, H = a.H, tid = threadIdx.x;
+    for (int h = tid; h < H; h += 256) {
         const float v = a.gt[(size_t)n * H + h] > 0.0f ? a.ds[(size_t)n * H + h] : 0.0f;
         dz2s[h] = v;
-        a.dz2[(size_t)n * H + h] = v;
+        if (blockIdx.y == 0) a.dz2[(size_t)n * H + h] = v;
     }
     __syncthreads();
-    const float* st = a.step_tab + (size_t)n * SNSDE_STEP_STRIDE;
-    const float* W1 = a.params + a.net.nt0.src_w;
-    const float* b1 = a.params + a.net.nt0.src_b;
+    const int kl = tid & 63, hq = tid >> 6, k = blockIdx.y * 64 + kl;
     const float* W2 = a.params + a.net.nt1.src_w;
-    for (int k = threadIdx.x; k < H; k += blockDim.x) {
-        const float z1 = fmaf(W1[2 * k], st[2], fmaf(W1[2 * k + 1], st[3], b1[k]));
-        float s = 0.0f;
-        for (int h = 0; h < H; ++h) s = fmaf(W2[(size_t)h * H + k], dz2s[h], s);
+    float s = 0.0f;
+    if (k < H) {
+        const int hb = (H + 3) / 4, h0 = hq * hb, h1 = min(H, h0 + hb);
+        for (int h = h0; h < h1; ++h) s = fmaf(W2[(size_t)h * H + k], dz2s[h], s);
+    }
+    red[tid] = s;
+    __syncthreads();
+    if (hq == 0 && k < H) {
+        const float* st = a.step_tab + (size_t)n * SNSDE_STEP_STRIDE;
+        const float* W1 = a.params + a.net.nt0.src_w;
+        const float z1 = fmaf(W1[2 * k], st[2], fmaf(W1[2 * k + 1], st[3], a.params[a.net.nt0.src_b + k]));
+        const float tot = (red[kl] + red[kl + 64]) + (red[kl + 128] + red[kl + 192]);
         a.a1[(size_t)n * H + k] = fmaxf(z1, 0.0f);
-        a.dz1[(size_t)n * H + k] = z1 > 0.0f ? s : 0.0f;
+        a.dz1[(size_t)n * H + k] = z1 > 0.0f ? tot : 0.0f;
     }
 }
 
@@ -329,19 +337,26 @@ __global__ void __launch_bounds__(256) snsde_small_gemm_kernel(AArgs a) {
     if (m0 >= j.M || n0 >= j.N) return;
     const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;     // 32 x 8
     float acc[4] = {0.f, 0.f, 0.f, 0.f};                        // rows ty + 8 i, column tx
-    for (int k0 = 0; k0 < j.K; k0 += 32) {
+    float ra[4], rb[4];
+    auto gload = [&](int k0) {                                  // next K-chunk into registers (overlaps the FMAs)
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const int rr = ty + 8 * i;
             if (j.trans == 0) {      // As[m][k], Bs[n][k]: k contiguous in memory
-                As[rr][tx] = (m0 + rr < j.M && k0 + tx < j.K) ? j.A[(size_t)(m0 + rr) * j.lda + k0 + tx] : 0.0f;
-                Bs[rr][tx] = (n0 + rr < j.N && k0 + tx < j.K) ? j.B[(size_t)(n0 + rr) * j.ldb + k0 + tx] : 0.0f;
+                ra[i] = (m0 + rr < j.M && k0 + tx < j.K) ? j.A[(size_t)(m0 + rr) * j.lda + k0 + tx] : 0.0f;
+                rb[i] = (n0 + rr < j.N && k0 + tx < j.K) ? j.B[(size_t)(n0 + rr) * j.ldb + k0 + tx] : 0.0f;
             } else {                 // As[k][m], Bs[k][n]: m / n contiguous in memory
-                As[rr][tx] = (k0 + rr < j.K && m0 + tx < j.M) ? j.A[(size_t)(k0 + rr) * j.lda + m0 + tx] : 0.0f;
-                Bs[rr][tx] = (k0 + rr < j.K && n0 + tx < j.N) ? (j.B ? j.B[(size_t)(k0 + rr) * j.ldb + n0 + tx] : 1.0f) : 0.0f;
+                ra[i] = (k0 + rr < j.K && m0 + tx < j.M) ? j.A[(size_t)(k0 + rr) * j.lda + m0 + tx] : 0.0f;
+                rb[i] = (k0 + rr < j.K && n0 + tx < j.N) ? (j.B ? j.B[(size_t)(k0 + rr) * j.ldb + n0 + tx] : 1.0f) : 0.0f;
             }
         }
+    };
+    gload(0);
+    for (int k0 = 0; k0 < j.K; k0 += 32) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { As[ty + 8 * i][tx] = ra[i]; Bs[ty + 8 * i][tx] = rb[i]; }
         __syncthreads();
+        if (k0 + 32 < j.K) gload(k0 + 32);
         if (j.trans == 0) {
 #pragma unroll 8
             for (int k = 0; k < 32; ++k) {
@@ -508,7 +523,8 @@ int snsde_wgrad_launch(const snsde_backward* b, const SnsdeNet& net, float* grad
         d.nwg = nwg; d.n_dth = nwg * waves; d.NH = s.n_steps * H;
         hipLaunchKernelGGL(snsde_dsum_reduce_kernel, dim3((d.NH + 63) / 64 + 1), dim3(256), 0, stream, d);
         if (two)
-            hipLaunchKernelGGL(snsde_noise_hidden_kernel, dim3(s.n_steps), dim3(H < 256 ? H : 256), H * sizeof(float), stream, aa);
+            hipLaunchKernelGGL(snsde_noise_hidden_kernel, dim3(s.n_steps, (H + 63) / 64), dim3(256), (H + 256) * sizeof(float),
+                               stream, aa);
     }
     // small products straight into the flat gradient (after the assemble kernel has written every other entry)
     int nj = 0;

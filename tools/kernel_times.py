@@ -9,7 +9,7 @@ agg = collections.defaultdict(list)
 for r in csv.DictReader(open(f)):
     n = r['Kernel_Name']
     if pat in n:
-        m = re.search(r'(snsde_\w+)(<[^>]*>)?', n)
+        m = re.search(r'(snsde_\w*kernel)(<[^>]*>+)?', n)
         key = (m.group(0) if m else n[:60]) + ' grid=' + r['Grid_Size_X'] + 'x' + r['Grid_Size_Y'] + 'x' + r['Grid_Size_Z']
         agg[key].append((int(r['End_Timestamp']) - int(r['Start_Timestamp'])) / 1e3)
 for k, v in sorted(agg.items(), key=lambda kv: -sum(kv[1])):
