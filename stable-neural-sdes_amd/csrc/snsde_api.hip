@@ -372,7 +372,9 @@ int snsde_eval_fg(const snsde_solve* s, const float* step_row, const float* y, f
 
 int snsde_act_slots(const snsde_model* m) {
     int rc = validate_model(m);
-    return rc ? rc : m->num_hidden_layers + 1;   // z0, hidden.., zout
+    if (rc) return rc;
+    const int no = m->noise_option;   // + the diffusion net's activations (hidden for 18/19, output)
+    return m->num_hidden_layers + 1 + ((no == 18 || no == 19) ? 2 : ((no == 14 || no == 15) ? 1 : 0));
 }
 
 int snsde_backward_supported(const snsde_solve* s) {

@@ -182,9 +182,10 @@ MfmaPlan make_plan(const snsde_solve* s, const SnsdeNet& net, int flavor_hint) {
 RevPlan make_rev_plan(const snsde_solve* s, const SnsdeNet& net, const MfmaPlan& fp) {
     RevPlan p{};
     p.ok = false;
-    if (!fp.ok || (s->method != SNSDE_EULER && s->method != SNSDE_MILSTEIN) || fp.NN != 0) return p;
+    if (!fp.ok || (s->method != SNSDE_EULER && s->method != SNSDE_MILSTEIN)) return p;
+    if (fp.NN != 0 && s->method != SNSDE_EULER) return p;
     const int H = fp.H, io = fp.IO;
-    p.H = H; p.NHID = fp.NHID; p.GEO = (io == 5 || io == 6) ? 1 : 0; p.FL = fp.FL; p.NW = fp.NW;
+    p.H = H; p.NHID = fp.NHID; p.GEO = (io == 5 || io == 6) ? 1 : 0; p.FL = fp.FL; p.NW = fp.NW; p.NN = fp.NN;
     p.emb = (io == 2 || io == 4 || io == 6) ? 1 : 0;
     int off = 0, n = 0;
     auto add_t = [&](const SnsdeLayer& L, int col_off, int fold_tmp) {
@@ -197,20 +198,22 @@ RevPlan make_rev_plan(const snsde_solve* s, const SnsdeNet& net, const MfmaPlan&
     };
     // fold temp first (so its offset is known to the pack job)
     int fold_tmp = -1;
-    const int packed = (p.NHID + 2) * p.NW * (H / 16) * 256;
+    const int packed = (p.NHID + 2 + p.NN) * p.NW * (H / 16) * 256;
     if (p.emb) fold_tmp = packed;
     add_t(net.out, 0, -1);
     for (int l = p.NHID - 1; l >= 0; --l) add_t(net.hid[l], 0, -1);
     add_t(net.in, net.in.tshift, fold_tmp);
+    if (p.NN == 2) add_t(net.ny1, 0, -1);                   // diffusion net, output layer first
+    if (p.NN >= 1) add_t(net.ny0, net.ny0.tshift, -1);      // its y columns
     p.n_layers = n;
     p.fold_tmp = fold_tmp;
     p.total_floats = packed + (p.emb ? H * net.in.K + H : 0) + 16;
     p.nwg = (s->batch + (p.FL ? 4 : 16) - 1) / (p.FL ? 4 : 16);
     p.ds_off = p.dth_off = 0;
-    if (fp.gt_off >= 0) {     // time-only diffusion table present: the adjoint kernel also leaves the parameter-side sums
+    if (fp.gt_off >= 0 || p.NN > 0) {     // the adjoint kernel also leaves the diffusion-side parameter sums
         size_t o = ((size_t)p.total_floats + 3) & ~(size_t)3;
-        p.ds_off = o; o += (size_t)p.nwg * s->n_steps * H;
-        p.dth_off = o; o += (size_t)p.nwg * p.NW;
+        if (fp.gt_off >= 0) { p.ds_off = o; o += (size_t)p.nwg * s->n_steps * H; }   // time-only noise MLP: d/d s_n
+        p.dth_off = o; o += (size_t)p.nwg * p.NW;                                    // d/d sigmoid(theta)
         if (o + 16 > 0x7fffffff) return p;
         p.total_floats = (int)(o + 16);
     }
@@ -298,7 +301,7 @@ static int flavor_hint_of(const snsde_solve* s) {
 bool snsde_mfma_backward_partials(const snsde_solve* s, const SnsdeNet& net, int* nwg, int* waves, size_t* ds_off,
                                   size_t* dth_off) {
     RevPlan p = make_rev_plan(s, net, make_plan(s, net, flavor_hint_of(s)));
-    if (!p.ok || p.ds_off == 0) return false;
+    if (!p.ok || p.dth_off == 0) return false;
     *nwg = p.nwg; *waves = p.NW; *ds_off = p.ds_off; *dth_off = p.dth_off;
     return true;
 }
@@ -333,7 +336,7 @@ int snsde_mfma_backward_launch(const snsde_backward* b, const SnsdeNet& net, hip
     a.step_tab = s->step_tab; a.out_w = s->out_w; a.traj = s->traj; a.act = s->act_save; a.dW = s->dW_out;
     a.grad_ys = b->grad_ys; a.adj = b->adj; a.delta = b->delta_save;
     a.ds_part = p.ds_off ? ws + p.ds_off : nullptr;
-    a.dth_part = p.ds_off ? ws + p.dth_off : nullptr;
+    a.dth_part = p.dth_off ? ws + p.dth_off : nullptr;
     a.B = s->batch; a.N = s->n_steps; a.T = s->n_out; a.no = s->model.noise_option; a.off_theta = net.off_theta; a.method = s->method;
     for (int i = 0; i < p.n_layers; ++i) a.w_off[i] = p.layer[i].dst;
     if (p.H == 256) return dispatch_rev_h256(p, a, stream);

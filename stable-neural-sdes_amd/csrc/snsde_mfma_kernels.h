@@ -219,7 +219,8 @@ struct Cfg {
     static constexpr int NLAYER = (EMB && !FOLD ? 3 : 1) + NHID + 1 + NN;   // bias rows: [init, in, emb] | [first], hid.., out, noise..
     static constexpr int XI = (M * 16 * KUX + NT - 1) / NT;           // spline items per thread
     static constexpr int EPT = FL ? 1 : 4;                            // owned state elements per lane per tile
-    static constexpr int NSAVE = NHID + 2;                            // saved activations per step: z0, hidden.., zout
+    static constexpr int NSAVE = NHID + 2 + NN;                       // saved activations per step: z0, hidden.., zout, [noise-net hidden], [noise-net output]
+    static constexpr int ZSLOT = NHID + 1;                            // slot of the pre-tanh drift
     static constexpr int ZB = (FL && !STREAM) ? 4 : 1;                             // Philox calls generated together per element
     static constexpr int ROWCH = 128;                                 // step-table rows staged in LDS per chunk
     static constexpr int ZSTASH = PHX ? 4 * ZB * 64 * EPT : 0;        // floats per wave
@@ -523,13 +524,15 @@ __global__ void __launch_bounds__(CF::NT, CF::WPS) snsde_mfma_kernel(MfmaArgs a)
                 init_acc(NROW);
                 gemm<FL, (CF::NN > 0) ? CF::KUN : 1, TPW>(wn0, yrow, acc, acc2);
                 sum_acc();
-                if constexpr (CF::NN == 2) store_frag(nbuf, LDA, wave * 16, acc[0], true);
+                if constexpr (CF::NN == 2) store_frag(nbuf, LDA, wave * 16, acc[0], true, CF::ZSLOT + 1);
                 else {
                     gnv = acc[0];
                     if constexpr (FL) {
 #pragma unroll
                         for (int i = 0; i < 4; ++i) gnv[i] = row_ror_add(gnv[i]);
                     }
+                    if (writer && a.act_save && row_ok)
+                        *reinterpret_cast<f32x4*>(a.act_save + (((size_t)n * CF::NSAVE + CF::ZSLOT + 1) * B + row) * H + wave * 16 + fsub) = gnv;
                 }
             }
             __syncthreads();
@@ -543,6 +546,8 @@ __global__ void __launch_bounds__(CF::NT, CF::WPS) snsde_mfma_kernel(MfmaArgs a)
                     if constexpr (FL) gnv[i] = row_ror_add(gnv[i]);
                     gnv[i] = fmaxf(gnv[i], 0.0f);
                 }
+                if (writer && a.act_save && row_ok)
+                    *reinterpret_cast<f32x4*>(a.act_save + (((size_t)n * CF::NSAVE + CF::ZSLOT + 2) * B + row) * H + wave * 16 + fsub) = gnv;
             }
             cur = crow;
             if constexpr (CF::EMB) {
@@ -612,7 +617,7 @@ __global__ void __launch_bounds__(CF::NT, CF::WPS) snsde_mfma_kernel(MfmaArgs a)
             }
             const size_t goff = (size_t)row * H + fcol[t];
             if (a.act_save && row_ok) {
-                float* zp = a.act_save + (((size_t)n * CF::NSAVE + CF::NSAVE - 1) * B) * H + goff;
+                float* zp = a.act_save + (((size_t)n * CF::NSAVE + CF::ZSLOT) * B) * H + goff;
                 if constexpr (FL) zp[0] = zsave[0];
                 else *reinterpret_cast<f32x4*>(zp) = f32x4{zsave[0], zsave[1], zsave[2], zsave[3]};
             }
@@ -677,9 +682,9 @@ int launch_cfg(const MfmaArgs& a, hipStream_t stream) {
 // where first_y = (emb o linear_in)[:, y columns] (or linear_in[:, y columns] without emb).  relu masks and the
 // pre-tanh drift come from the forward's act_save; f, g and their derivatives are recomputed elementwise.
 // =====================================================================================================
-template <int H_, int NHID_, int GEO_, int FL_>
+template <int H_, int NHID_, int GEO_, int FL_, int NN_ = 0>
 struct CfgR {
-    static constexpr int H = H_, NHID = NHID_, FL = FL_;
+    static constexpr int H = H_, NHID = NHID_, FL = FL_, NN = NN_;   // NN: layers of the diffusion net on [tau, y] (noise_option 14/15: 1, 18/19: 2)
     static constexpr bool GEO = GEO_ != 0;
     static constexpr int TPW = 1;
     static constexpr int NW = H / 16;
@@ -689,8 +694,10 @@ struct CfgR {
     static constexpr int KUH = H / 16;
     static constexpr int PAD = FL ? 16 : 8;
     static constexpr int LDA = ld_for(16 * KUH, PAD);
-    static constexpr int NG = NHID + 2;          // transposed GEMMs per step = LDS buffers
-    static constexpr int NSAVE = NHID + 2;
+    static constexpr int ND = NHID + 2;          // transposed GEMMs of the drift chain
+    static constexpr int NG = ND + NN;           // + the diffusion net's = LDS buffers = delta slots
+    static constexpr int NSAVE = NHID + 2 + NN;
+    static constexpr int ZSLOT = NHID + 1;
     static constexpr int EPT = FL ? 1 : 4;
     static constexpr int ROWCH = 128;
     static constexpr bool STREAM = H > 128;
@@ -718,7 +725,7 @@ struct RevArgs {
 template <class CF>
 __global__ void __launch_bounds__(CF::NT, CF::WPS) snsde_mfma_reverse_kernel(RevArgs a) {
     constexpr int H = CF::H, TPW = 1, FL = CF::FL, M = CF::M, NT = CF::NT, NHID = CF::NHID, NG = CF::NG;
-    constexpr int KUH = CF::KUH, EPT = CF::EPT, LDA = CF::LDA, NSAVE = CF::NSAVE;
+    constexpr int KUH = CF::KUH, EPT = CF::EPT, LDA = CF::LDA, NSAVE = CF::NSAVE, ND = CF::ND, NN = CF::NN;
     extern __shared__ __attribute__((aligned(16))) float lds[];
     float* rowtab = lds + NG * M * LDA;
     const int tid = threadIdx.x, lane = tid & 63;
@@ -741,7 +748,7 @@ __global__ void __launch_bounds__(CF::NT, CF::WPS) snsde_mfma_reverse_kernel(Rev
     for (int i = tid; i < NG * M * LDA; i += NT) lds[i] = 0.0f;
 
     const float sig_theta = snsde_sigmoid(a.params[a.off_theta]);
-    const bool mul_y = (a.no == 13 || a.no == 17);
+    const bool mul_y = (a.no == 13 || a.no == 17 || a.no == 15 || a.no == 19);
     const float mil = (a.method == SNSDE_MILSTEIN) ? 0.5f : 0.0f;
 
     auto fill_rows = [&](int base) {
@@ -756,25 +763,29 @@ __global__ void __launch_bounds__(CF::NT, CF::WPS) snsde_mfma_reverse_kernel(Rev
 #pragma unroll
     for (int e = 0; e < EPT; ++e) adj[e] = 0.0f;
     int rbase = -1;
-    const bool dsum = a.ds_part != nullptr && a.gt != nullptr;   // diffusion-side parameter sums wanted
+    const bool dsum = a.ds_part != nullptr && a.gt != nullptr;   // diffusion-side parameter sums wanted (time-only noise MLP)
     const float rowf = row_ok ? 1.0f : 0.0f;                     // padding rows replicate the last row: excluded
     float th_acc = 0.0f;
 
     // per-step inputs from HBM are fetched one step ahead, so their latency hides behind the previous step's GEMM chain
-    struct StepIn { float y[EPT], z[EPT], dw[EPT], gq[EPT]; f32x4 mask[NG - 1]; };
+    struct StepIn { float y[EPT], z[EPT], dw[EPT], gq[EPT]; f32x4 mask[ND - 1]; f32x4 nmask; };
     auto prefetch = [&](int n, StepIn& p) {
 #pragma unroll
         for (int e = 0; e < EPT; ++e) {
             p.y[e] = a.traj[(size_t)n * BH + goff + e];
-            p.z[e] = a.act[(((size_t)n * NSAVE + NSAVE - 1) * B) * H + goff + e];
+            p.z[e] = a.act[(((size_t)n * NSAVE + CF::ZSLOT) * B) * H + goff + e];
             p.dw[e] = a.dW[(size_t)n * BH + goff + e];
-            p.gq[e] = a.gt ? a.gt[(size_t)n * H + fcol + e] : 0.0f;
+            if constexpr (NN > 0) p.gq[e] = a.act[(((size_t)n * NSAVE + NSAVE - 1) * B) * H + goff + e];   // diffusion-net output
+            else p.gq[e] = a.gt ? a.gt[(size_t)n * H + fcol + e] : 0.0f;
         }
         if (writer) {
 #pragma unroll
-            for (int g = 0; g < NG - 1; ++g)     // relu mask of the forward activation feeding transposed GEMM g + 1
+            for (int g = 0; g < ND - 1; ++g)     // relu mask of the forward activation feeding transposed GEMM g + 1
                 p.mask[g] = *reinterpret_cast<const f32x4*>(
                     a.act + (((size_t)n * NSAVE + (NHID - g)) * B + rowc) * H + wave * 16 + fsub);
+            if constexpr (NN == 2)               // hidden activation of the diffusion net
+                p.nmask = *reinterpret_cast<const f32x4*>(
+                    a.act + (((size_t)n * NSAVE + CF::ZSLOT + 1) * B + rowc) * H + wave * 16 + fsub);
         }
     };
     constexpr bool AHEAD = !CF::STREAM;   // the streamed-weight variant (H = 256) has no registers to spare for it
@@ -817,10 +828,10 @@ __global__ void __launch_bounds__(CF::NT, CF::WPS) snsde_mfma_reverse_kernel(Rev
             for (int e = 0; e < EPT; ++e) a.adj[(size_t)(n + 1) * BH + goff + e] = adj[e];
         }
         // ---- elementwise: d(f h + g dW)/d(zout, y) applied to the adjoint ----
-        float ay[EPT], dz[EPT], dsv[EPT];
+        float ay[EPT], dz[EPT], dsv[EPT], dq[EPT];
 #pragma unroll
         for (int e = 0; e < EPT; ++e) {
-            dsv[e] = 0.0f;
+            dsv[e] = 0.0f; dq[e] = 0.0f;
             const float y = cur.y[e], z = cur.z[e], dw = cur.dw[e], gq = cur.gq[e];
             const float av = adj[e];
             float ty = 1.0f, zt = z;
@@ -840,6 +851,14 @@ __global__ void __launch_bounds__(CF::NT, CF::WPS) snsde_mfma_reverse_kernel(Rev
                 const float c = sig_theta * gq;
                 const float dm = mil * fmaf(dw, dw, -h) * c * fmaf(-3.0f * g, g, 1.0f);
                 acc_y = fmaf(av * om * c, dw + dm, acc_y);
+            }
+            if constexpr (NN > 0) {
+                // raw = q (14, 18) or q * y (15, 19), q = the diffusion net's output (relu'd for 18/19): Euler term g dW
+                const float dr = finite ? av * dw * om * sig_theta : 0.0f;
+                float d = mul_y ? dr * y : dr;
+                if constexpr (NN == 2) d = gq > 0.0f ? d : 0.0f;
+                dq[e] = d;
+                th_acc = fmaf(av * dw * om * rowf, rcv, th_acc);
             }
             ay[e] = acc_y;
             if (dsum) {
@@ -884,6 +903,16 @@ __global__ void __launch_bounds__(CF::NT, CF::WPS) snsde_mfma_reverse_kernel(Rev
             if constexpr (FL) dp[0] = dz[0];
             else *reinterpret_cast<f32x4*>(dp) = f32x4{dz[0], dz[1], dz[2], dz[3]};
         }
+        if constexpr (NN > 0) {     // input of the diffusion net's transposed chain (buffer / delta slot ND)
+            float* nb = lds + ND * M * LDA;
+            if constexpr (FL) nb[r * LDA + fcol] = dq[0];
+            else *reinterpret_cast<f32x4*>(nb + r * LDA + fcol) = f32x4{dq[0], dq[1], dq[2], dq[3]};
+            if (a.delta && row_ok) {
+                float* dp = a.delta + (((size_t)n * NG + ND) * B) * H + goff;
+                if constexpr (FL) dp[0] = dq[0];
+                else *reinterpret_cast<f32x4*>(dp) = f32x4{dq[0], dq[1], dq[2], dq[3]};
+            }
+        }
         __syncthreads();
         f32x4 acc[TPW], acc2[TPW];
 #pragma unroll
@@ -895,10 +924,11 @@ __global__ void __launch_bounds__(CF::NT, CF::WPS) snsde_mfma_reverse_kernel(Rev
 #pragma unroll
                 for (int i = 0; i < 4; ++i) v[i] = row_ror_add(v[i]);
             }
-            if (g < NG - 1) {
-                // relu mask of the forward activation that produced this gradient's input: slot NHID - g
+            if (g != ND - 1 && g != NG - 1) {
+                // relu mask of the forward activation that produced this gradient's input: slot NHID - g (drift chain),
+                // the diffusion net's hidden activation (g == ND, noise_option 18/19)
                 if (writer) {
-                    const f32x4 zsv = cur.mask[g];
+                    const f32x4 zsv = g < ND ? cur.mask[g < ND - 1 ? g : 0] : cur.nmask;
 #pragma unroll
                     for (int i = 0; i < 4; ++i) v[i] = zsv[i] > 0.0f ? v[i] : 0.0f;
                     *reinterpret_cast<f32x4*>(lds + (g + 1) * M * LDA + r * LDA + wave * 16 + fsub) = v;
@@ -911,7 +941,8 @@ __global__ void __launch_bounds__(CF::NT, CF::WPS) snsde_mfma_reverse_kernel(Rev
                 for (int e = 0; e < EPT; ++e) {
                     float d = v[FL ? 0 : e];
                     if constexpr (FL) { d = s1 ? v[1] : d; d = s2 ? v[2] : d; d = s3 ? v[3] : d; }
-                    adj[e] = ay[e] + d + carry[e];
+                    if (g == ND - 1) adj[e] = ay[e] + d + carry[e];      // end of the drift chain
+                    else adj[e] += d;                                    // end of the diffusion net's chain
                 }
             }
         }
@@ -921,7 +952,7 @@ __global__ void __launch_bounds__(CF::NT, CF::WPS) snsde_mfma_reverse_kernel(Rev
 #pragma unroll
         for (int e = 0; e < EPT; ++e) a.adj[goff + e] = adj[e] + a.grad_ys[goff + e];
     }
-    if (dsum && a.dth_part) {
+    if ((dsum || NN > 0) && a.dth_part) {
 #pragma unroll
         for (int off = 32; off > 0; off >>= 1) th_acc += __shfl_down(th_acc, off, 64);
         if (lane == 0) a.dth_part[blockIdx.x * CF::NW + wave] = th_acc;
@@ -948,7 +979,7 @@ struct MfmaPlan {
 
 struct RevPlan {
     bool ok;
-    int H, NHID, GEO, FL, NW, n_layers, fold_tmp, total_floats, emb;
+    int H, NHID, GEO, FL, NW, NN, n_layers, fold_tmp, total_floats, emb;
     int nwg;                    // workgroups of the adjoint launch
     size_t ds_off, dth_off;     // diffusion-side partial sums inside the backward workspace (0 = none)
     MfmaLayerPack layer[MAXL];
@@ -993,7 +1024,10 @@ int dispatch_rev(const RevPlan& p, const RevArgs& a, hipStream_t st) {
     if (p.NHID == 1 && !p.GEO) return launch_rev<CfgR<H, 1, 0, FL>>(a, st);
     return SNSDE_ERR_UNSUPPORTED;
 #else
-#define SNSDE_RCASE(NH_) if (p.NHID == NH_) return p.GEO ? launch_rev<CfgR<H, NH_, 1, FL>>(a, st) : launch_rev<CfgR<H, NH_, 0, FL>>(a, st);
+#define SNSDE_RCASE(NH_) if (p.NHID == NH_) { \
+        if (p.NN == 1) return launch_rev<CfgR<H, NH_, 0, FL, 1>>(a, st); \
+        if (p.NN == 2) return launch_rev<CfgR<H, NH_, 0, FL, 2>>(a, st); \
+        return p.GEO ? launch_rev<CfgR<H, NH_, 1, FL>>(a, st) : launch_rev<CfgR<H, NH_, 0, FL>>(a, st); }
     SNSDE_RCASE(0) SNSDE_RCASE(1) SNSDE_RCASE(2) SNSDE_RCASE(3)
 #undef SNSDE_RCASE
     return SNSDE_ERR_UNSUPPORTED;

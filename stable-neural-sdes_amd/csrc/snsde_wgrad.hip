@@ -264,6 +264,7 @@ struct AArgs {
     SnsdeNet net;
     int32_t H, C, N, io, no, nhid, P, has_dth;
     int32_t o_out, b_out, o_hid[SNSDE_MAX_HIDDEN], b_hid[SNSDE_MAX_HIDDEN], o_first, ld_first, b_first;   // offsets in sums
+    int32_t o_ny0, b_ny0, o_ny1, b_ny1, nn;   // diffusion net on [tau, y] (noise_option 14/15/18/19), dense sums in the parameters' own layout
     int32_t n_jobs;
     GJob job[MAX_GJOBS];
 };
@@ -320,7 +321,11 @@ __global__ void __launch_bounds__(256) snsde_assemble_kernel(AArgs a) {
             const float sg = snsde_sigmoid(a.params[net.off_theta]);
             val = a.dth[0] * sg * (1.0f - sg);
         }
-    } else {
+    } else if (a.nn >= 1 && inside(net.ny0.src_w, H * (H + 2), rel)) val = a.sums[a.o_ny0 + rel];
+    else if (a.nn >= 1 && inside(net.ny0.src_b, H, rel)) val = a.sums[a.b_ny0 + rel];
+    else if (a.nn == 2 && inside(net.ny1.src_w, H * H, rel)) val = a.sums[a.o_ny1 + rel];
+    else if (a.nn == 2 && inside(net.ny1.src_b, H, rel)) val = a.sums[a.b_ny1 + rel];
+    else {
         for (int l = 0; l < a.nhid; ++l) {
             if (inside(net.hid[l].src_w, H * H, rel)) { val = a.sums[a.o_hid[l] + rel]; break; }
             if (inside(net.hid[l].src_b, H, rel)) { val = a.sums[a.b_hid[l] + rel]; break; }
@@ -384,7 +389,8 @@ __global__ void __launch_bounds__(256) snsde_small_gemm_kernel(AArgs a) {
 struct WPlan {
     int ntiles, max_split, naux, ldx;
     size_t part_floats, sums_floats, ds_off, dth_off, dz1_off, dz2_off, a1_off, xaux_off, total_floats;
-    bool tnoise;
+    bool tnoise, has_dth;
+    int nact, xt;
     AArgs aa;
     WTile tile[MAX_TILES];
 };
@@ -396,7 +402,11 @@ bool make_wplan(const snsde_backward* b, const SnsdeNet& net, WPlan* w) {
     const int H = s.model.hidden_channels, C = s.model.input_channels, io = s.model.input_option, no = s.model.noise_option;
     const int nhid = s.model.num_hidden_layers - 1;
     const bool emb = (io == 2 || io == 4 || io == 6), timef = io >= 3;
-    const int ts = timef ? 2 : 0, naux = ts + (emb ? C : 0);
+    const int nn = (no == 18 || no == 19) ? 2 : ((no == 14 || no == 15) ? 1 : 0);
+    const int ts = timef ? 2 : 0;
+    const int xt = (timef || nn > 0) ? 2 : 0;          // time columns present in the xaux rows
+    const int naux = xt + (emb ? C : 0);
+    const int nd = nhid + 2;                           // delta slots of the drift chain
     const int R = s.n_steps * s.batch;
     AArgs& aa = w->aa;
     aa = AArgs{};
@@ -428,7 +438,18 @@ bool make_wplan(const snsde_backward* b, const SnsdeNet& net, WPlan* w) {
     aa.ld_first = ts + H + (emb ? C : 0);
     aa.o_first = alloc((size_t)H * aa.ld_first); aa.b_first = alloc(H);
     ok = ok && add_tiles(nhid + 1, 1, 0, H, aa.o_first + ts, aa.ld_first, aa.b_first, 1 << 30, 0);
-    if (ok && naux > 0) ok = add_tiles(nhid + 1, 2, 0, naux, aa.o_first, aa.ld_first, -1, ts, H);
+    if (ok && ts + (emb ? C : 0) > 0) ok = add_tiles(nhid + 1, 2, 0, naux, aa.o_first, aa.ld_first, -1, ts, H);
+    aa.nn = nn;
+    if (ok && nn > 0) {     // diffusion net: first layer on [sin t, cos t | y] (delta slot nd + nn - 1), output layer on its hidden
+        const int d0n = nd + nn - 1;
+        aa.o_ny0 = alloc((size_t)H * (H + 2)); aa.b_ny0 = alloc(H);
+        ok = add_tiles(d0n, 1, 0, H, aa.o_ny0 + 2, H + 2, aa.b_ny0, 1 << 30, 0)
+             && add_tiles(d0n, 2, 0, 2, aa.o_ny0, H + 2, -1, 1 << 30, 0);
+        if (ok && nn == 2) {
+            aa.o_ny1 = alloc((size_t)H * H); aa.b_ny1 = alloc(H);
+            ok = add_tiles(nd, 0, nhid + 2, H, aa.o_ny1, H, aa.b_ny1, 1 << 30, 0);
+        }
+    }
     if (!ok) return false;
     w->ntiles = nt;
     // R-splits per tile proportional to its work (MFMAs per slab + staging), ~2 workgroups per CU in total
@@ -457,6 +478,9 @@ bool make_wplan(const snsde_backward* b, const SnsdeNet& net, WPlan* w) {
     size_t o = w->sums_floats + w->part_floats;
     const size_t NH = (size_t)s.n_steps * H;
     w->ds_off = o; o += w->tnoise ? NH : 0;
+    w->has_dth = w->tnoise || nn > 0;
+    w->nact = nhid + 2 + nn;
+    w->xt = xt;
     w->dth_off = o; o += 4;
     w->dz1_off = o; o += two ? NH : 0;
     w->dz2_off = o; o += two ? NH : 0;
@@ -465,7 +489,7 @@ bool make_wplan(const snsde_backward* b, const SnsdeNet& net, WPlan* w) {
     w->naux = naux; w->ldx = (naux + 3) & ~3;
     w->xaux_off = o; o += (size_t)R * w->ldx;
     w->total_floats = o + 16;
-    aa.net = net; aa.H = H; aa.C = C; aa.N = s.n_steps; aa.io = io; aa.no = no; aa.nhid = nhid; aa.has_dth = w->tnoise ? 1 : 0;
+    aa.net = net; aa.H = H; aa.C = C; aa.N = s.n_steps; aa.io = io; aa.no = no; aa.nhid = nhid; aa.has_dth = w->has_dth ? 1 : 0;
     return true;
 }
 
@@ -486,13 +510,13 @@ int snsde_wgrad_launch(const snsde_backward* b, const SnsdeNet& net, float* grad
     WArgs a{};
     a.delta = b->delta_save; a.act = s.act_save; a.traj = s.traj; a.xaux = ws + wp->xaux_off;
     a.sums = ws; a.part = ws + wp->sums_floats;
-    a.B = s.batch; a.H = H; a.N = s.n_steps; a.NG = s.model.num_hidden_layers + 1; a.NSAVE = s.model.num_hidden_layers + 1;
+    a.B = s.batch; a.H = H; a.N = s.n_steps; a.NG = wp->nact; a.NSAVE = wp->nact;
     a.ldx = wp->ldx; a.R = s.n_steps * s.batch; a.ntiles = wp->ntiles;
     for (int i = 0; i < wp->ntiles; ++i) a.tile[i] = wp->tile[i];
     if (wp->naux > 0) {
         XArgs x{};
         x.coeffs = s.coeffs; x.step_tab = s.step_tab; x.xaux = ws + wp->xaux_off;
-        x.B = s.batch; x.C = C; x.Lm1 = s.knots - 1; x.time_cols = io >= 3 ? 2 : 0; x.naux = wp->naux; x.ldx = wp->ldx; x.R = a.R;
+        x.B = s.batch; x.C = C; x.Lm1 = s.knots - 1; x.time_cols = wp->xt; x.naux = wp->naux; x.ldx = wp->ldx; x.R = a.R;
         const size_t total = (size_t)a.R * wp->ldx;
         hipLaunchKernelGGL(snsde_xaux_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, x);
     }
@@ -513,14 +537,14 @@ int snsde_wgrad_launch(const snsde_backward* b, const SnsdeNet& net, float* grad
     aa.dz1 = ws + wp->dz1_off; aa.dz2 = ws + wp->dz2_off; aa.a1 = ws + wp->a1_off;
     aa.gt = gt; aa.step_tab = s.step_tab; aa.grad = grad_params; aa.P = n_params;
     const bool two = (no == 16 || no == 17);
-    if (wp->tnoise) {
+    if (wp->has_dth) {
         int nwg = 0, waves = 0; size_t ds_off = 0, dth_off = 0;
-        if (!gt || !b->workspace || !snsde_mfma_backward_partials(&s, net, &nwg, &waves, &ds_off, &dth_off))
+        if ((wp->tnoise && !gt) || !b->workspace || !snsde_mfma_backward_partials(&s, net, &nwg, &waves, &ds_off, &dth_off))
             return SNSDE_ERR_UNSUPPORTED;
         const float* bws = static_cast<const float*>(b->workspace);
         DArgs d{};
         d.ds_part = bws + ds_off; d.dth_part = bws + dth_off; d.ds = ds; d.dth = ws + wp->dth_off;
-        d.nwg = nwg; d.n_dth = nwg * waves; d.NH = s.n_steps * H;
+        d.nwg = nwg; d.n_dth = nwg * waves; d.NH = wp->tnoise ? s.n_steps * H : 0;
         hipLaunchKernelGGL(snsde_dsum_reduce_kernel, dim3((d.NH + 63) / 64 + 1), dim3(256), 0, stream, d);
         if (two)
             hipLaunchKernelGGL(snsde_noise_hidden_kernel, dim3(s.n_steps, (H + 63) / 64), dim3(256), (H + 256) * sizeof(float),

@@ -493,6 +493,11 @@ BWD_CASES = [
     (6, 17, 3, 9, 64, 3, 9, [0, 8], 1.0, 'milstein'),
     (3, 13, 2, 11, 32, 3, 8, [0, 7], 0.5, 'milstein'),
     (2, 16, 1, 9, 32, 2, 12, None, 0.05, 'milstein'),         # y-independent diffusion: Milstein term vanishes
+    (3, 18, 2, 21, 64, 5, 9, [0, 3.5, 8], 1.0, 'euler'),      # diffusion nets on [tau, y] (BASELINE config 4's model)
+    (1, 14, 2, 9, 32, 3, 8, [0, 7], 1.0, 'euler'),
+    (3, 15, 1, 11, 128, 3, 8, [0, 7], 0.5, 'euler'),
+    (1, 19, 3, 9, 16, 3, 8, [0, 2.5, 7], 1.0, 'euler'),
+    (3, 19, 2, 9, 128, 3, 8, [0, 7], 1.0, 'euler'),
 ]
 
 
@@ -602,8 +607,8 @@ def test_native_parameter_pass_matches_library_gemm_pass(case):
 
 
 def test_backward_unsupported_configurations_raise():
-    pr = make_problem(9, 1, 18, 2, 8, 64, 3, 5)       # diffusion nets have no fused backward yet
-    m = S.Diffusion_model(3, 64, 64, 2, input_option=1, noise_option=18).to(DEV)
+    pr = make_problem(9, 4, 18, 2, 8, 64, 3, 5)       # diffusion nets behind a control embedding: no fused backward yet
+    m = S.Diffusion_model(3, 64, 64, 2, input_option=4, noise_option=18).to(DEV)
     m.set_X(torch.from_numpy(pr['coeffs']).to(DEV), torch.from_numpy(pr['times']).to(DEV))
     y0 = torch.from_numpy(pr['y0']).to(DEV).requires_grad_(True)
     with pytest.raises(NotImplementedError):
