@@ -143,6 +143,9 @@ typedef struct snsde_solve {
                               /* supplied dW), or NULL: h*(dW/2 + sqrt(h/12) xi), xi from Philox      */
     float*         dU_out;    /* optional device (N, B, H): the I_k0 actually used                    */
     float*         act_save;  /* optional device (N, snsde_act_slots, B, H): per-step activations */
+    const int32_t* row_out;   /* optional device (B): per-row output selection (the gather of NeuralSDE.forward,  */
+                              /* neuralsde.py:115-116).  When set, ys is (B, H) with ys[b] = the solution at      */
+                              /* ts[row_out[b]] (0 <= row_out[b] < n_out), and the backward's grad_ys is (B, H).  */
                               /* the backward pass needs (MFMA path only, see snsde_solve_backward)*/
     void*          workspace; /* device scratch, >= snsde_workspace_bytes()                      */
     size_t         workspace_bytes;

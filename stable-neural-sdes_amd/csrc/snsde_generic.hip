@@ -63,6 +63,7 @@ struct GenericArgs {
     float* ys;
     float* traj;
     float* dW_out;
+    const int32_t* row_out;   // (B) per-row output slot (ys / grad_ys are then (B, H)) or null
     int64_t row_offset;
     uint64_t seed;
     int32_t eval_mode;
@@ -266,7 +267,9 @@ __global__ void __launch_bounds__(GT) snsde_generic_kernel(GenericArgs a) {
                 int k = kout;
                 while (k < d.T - 1 && a.out_step[k] == n) {
                     const float w0 = a.out_w[2 * k], w1 = a.out_w[2 * k + 1];
-                    a.ys[(size_t)(k + 1) * BH + (size_t)row * H + j] = (w0 == 0.0f) ? ynew : w0 * y + w1 * ynew;
+                    const float o = (w0 == 0.0f) ? ynew : w0 * y + w1 * ynew;
+                    if (!a.row_out) a.ys[(size_t)(k + 1) * BH + (size_t)row * H + j] = o;
+                    else if (a.row_out[row] == k + 1) a.ys[(size_t)row * H + j] = o;
                     ++k;
                 }
             }
@@ -506,7 +509,9 @@ __global__ void __launch_bounds__(GT) snsde_generic_srk_kernel(SrkArgs sa) {
                 if (a.traj) a.traj[(size_t)(n + 1) * BH + (size_t)row * H + j] = ynew;
                 for (int k = kout; k < kend; ++k) {
                     const float c0 = a.out_w[2 * k], c1 = a.out_w[2 * k + 1];
-                    a.ys[(size_t)(k + 1) * BH + (size_t)row * H + j] = (c0 == 0.0f) ? ynew : c0 * y + c1 * ynew;
+                    const float o = (c0 == 0.0f) ? ynew : c0 * y + c1 * ynew;
+                    if (!a.row_out) a.ys[(size_t)(k + 1) * BH + (size_t)row * H + j] = o;
+                    else if (a.row_out[row] == k + 1) a.ys[(size_t)row * H + j] = o;
                 }
             }
         });
@@ -597,7 +602,8 @@ __global__ void __launch_bounds__(GT) snsde_generic_adjoint_kernel(AdjArgs aa) {
             if (row < B) {
                 for (int k = kfirst; k < kfirst + nout; ++k) {
                     const float w0 = a.out_w[2 * k], w1 = a.out_w[2 * k + 1];
-                    const float gk = aa.grad_ys[(size_t)(k + 1) * BH + (size_t)row * H + j];
+                    const float gk = a.row_out ? (a.row_out[row] == k + 1 ? aa.grad_ys[(size_t)row * H + j] : 0.0f)
+                                               : aa.grad_ys[(size_t)(k + 1) * BH + (size_t)row * H + j];
                     if (w0 == 0.0f) av += gk; else { av = fmaf(w1, gk, av); carry = fmaf(w0, gk, carry); }
                 }
                 aa.adj[(size_t)(n + 1) * BH + (size_t)row * H + j] = av;
@@ -718,7 +724,8 @@ __global__ void __launch_bounds__(GT) snsde_generic_adjoint_kernel(AdjArgs aa) {
     }
     for (int i = tid; i < GR * H; i += GT) {      // ys[0] = y0
         const int r = i / H, j = i - r * H, row = row0 + r;
-        if (row < B) aa.adj[(size_t)row * H + j] = abuf[r * ldy + j] + aa.grad_ys[(size_t)row * H + j];
+        if (row < B) aa.adj[(size_t)row * H + j] = abuf[r * ldy + j] +
+            ((!a.row_out || a.row_out[row] == 0) ? aa.grad_ys[(size_t)row * H + j] : 0.0f);
     }
 }
 
@@ -790,6 +797,7 @@ int snsde_generic_launch(const snsde_solve* s, const SnsdeNet& net, hipStream_t 
     a.ys = s->ys;
     a.traj = s->traj;
     a.dW_out = s->dW_out;
+    a.row_out = eval_mode ? nullptr : s->row_out;
     a.row_offset = s->row_offset;
     a.seed = s->seed;
     a.eval_mode = eval_mode;
@@ -831,7 +839,7 @@ int snsde_generic_backward_launch(const snsde_backward* b, const SnsdeNet& net, 
     a.net = net;
     a.params = s->params; a.ws = static_cast<const float*>(s->workspace); a.coeffs = s->coeffs;
     a.step_tab = s->step_tab; a.out_step = s->out_step; a.out_w = s->out_w; a.y0 = s->y0; a.dW = nullptr;
-    a.ys = nullptr; a.traj = nullptr; a.dW_out = nullptr; a.row_offset = 0; a.seed = 0; a.eval_mode = 0;
+    a.ys = nullptr; a.traj = nullptr; a.dW_out = nullptr; a.row_out = s->row_out; a.row_offset = 0; a.seed = 0; a.eval_mode = 0;
     a.eval_f = nullptr; a.eval_g = nullptr;
     const int H = m.hidden_channels, HH = m.hidden_hidden_channels;
     a.ldy = round4(H + 2);
@@ -872,7 +880,7 @@ int snsde_srk_launch(const snsde_solve* s, const SnsdeNet& net, hipStream_t stre
     a.net = net;
     a.params = s->params; a.ws = ws; a.coeffs = s->coeffs; a.step_tab = s->step_tab; a.out_step = s->out_step;
     a.out_w = s->out_w; a.y0 = s->y0; a.dW = s->dW; a.ys = s->ys; a.traj = s->traj; a.dW_out = s->dW_out;
-    a.row_offset = s->row_offset; a.seed = s->seed; a.eval_mode = 0; a.eval_f = nullptr; a.eval_g = nullptr;
+    a.row_out = s->row_out; a.row_offset = s->row_offset; a.seed = s->seed; a.eval_mode = 0; a.eval_f = nullptr; a.eval_g = nullptr;
     const int H = m.hidden_channels, HH = m.hidden_hidden_channels;
     a.ldy = round4(H + 2);
     const int wmax = 2 * H > HH ? 2 * H : HH;

@@ -75,6 +75,7 @@ struct MfmaArgs {
     float* traj;
     float* dW_out;
     float* act_save;   // (N, NSAVE, B, H) or null
+    const int32_t* row_out;   // (B) per-row output slot (ys is then (B, H)) or null
     int64_t row_offset;
     uint64_t seed;
     int32_t B, L, C, N, T, method, no;
@@ -361,6 +362,7 @@ __global__ void __launch_bounds__(CF::NT, CF::WPS) snsde_mfma_kernel(MfmaArgs a)
     const bool s1 = (s == 1), s2 = (s == 2), s3 = (s == 3);
     const float mil = (a.method == SNSDE_MILSTEIN) ? 0.5f : 0.0f;
     const uint32_t grow = (uint32_t)(a.row_offset + row);
+    const int rslot = a.row_out ? a.row_out[rowc] : -1;     // per-row output selection (ys is (B, H))
 
     // store one layer output fragment (bias came in through the accumulator init) as 16 B per lane
     int save_step = 0;   // current step, for the optional activation save
@@ -628,7 +630,9 @@ __global__ void __launch_bounds__(CF::NT, CF::WPS) snsde_mfma_kernel(MfmaArgs a)
                     if (a.dW_out) a.dW_out[(size_t)n * BH + goff] = dw[t][0];
                     for (int k = c_kfirst; k < c_kfirst + c_nout; ++k) {
                         const float w0 = a.out_w[2 * k], w1 = a.out_w[2 * k + 1];
-                        a.ys[(size_t)(k + 1) * BH + goff] = (w0 == 0.0f) ? ynew[0] : w0 * yold[0] + w1 * ynew[0];
+                        const float o = (w0 == 0.0f) ? ynew[0] : w0 * yold[0] + w1 * ynew[0];
+                        if (!a.row_out) a.ys[(size_t)(k + 1) * BH + goff] = o;
+                        else if (rslot == k + 1) a.ys[goff] = o;
                     }
                 }
             } else {
@@ -643,7 +647,8 @@ __global__ void __launch_bounds__(CF::NT, CF::WPS) snsde_mfma_kernel(MfmaArgs a)
                         f32x4 o;
 #pragma unroll
                         for (int e = 0; e < 4; ++e) o[e] = (w0 == 0.0f) ? ynew[e] : w0 * yold[e] + w1 * ynew[e];
-                        *reinterpret_cast<f32x4*>(a.ys + (size_t)(k + 1) * BH + goff) = o;
+                        if (!a.row_out) *reinterpret_cast<f32x4*>(a.ys + (size_t)(k + 1) * BH + goff) = o;
+                        else if (rslot == k + 1) *reinterpret_cast<f32x4*>(a.ys + goff) = o;
                     }
                 }
             }
@@ -716,6 +721,7 @@ struct RevArgs {
     const float* grad_ys;
     float* adj;
     float* delta;      // (N, NG, B, H) or null
+    const int32_t* row_out;   // (B) per-row output slot (grad_ys is then (B, H)) or null
     float* ds_part;    // (workgroups, N, H) per-tile sums of dL/d s_n (time-only diffusion table), or null
     float* dth_part;   // (workgroups, waves) partial sums of dL/d sigmoid(theta), or null
     int32_t B, N, T, no, off_theta, method;
@@ -759,9 +765,10 @@ __global__ void __launch_bounds__(CF::NT, CF::WPS) snsde_mfma_reverse_kernel(Rev
     };
 
     // adjoint of y_N (owned elements)
-    float adj[EPT];
+    float adj[EPT], gfin[EPT];
+    const int rslot = a.row_out ? a.row_out[rowc] : -1;     // per-row output selection: the row's single output gradient
 #pragma unroll
-    for (int e = 0; e < EPT; ++e) adj[e] = 0.0f;
+    for (int e = 0; e < EPT; ++e) { adj[e] = 0.0f; gfin[e] = a.row_out ? a.grad_ys[goff + e] : 0.0f; }
     int rbase = -1;
     const bool dsum = a.ds_part != nullptr && a.gt != nullptr;   // diffusion-side parameter sums wanted (time-only noise MLP)
     const float rowf = row_ok ? 1.0f : 0.0f;                     // padding rows replicate the last row: excluded
@@ -818,7 +825,7 @@ __global__ void __launch_bounds__(CF::NT, CF::WPS) snsde_mfma_reverse_kernel(Rev
             const float w0 = a.out_w[2 * k], w1 = a.out_w[2 * k + 1];
 #pragma unroll
             for (int e = 0; e < EPT; ++e) {
-                const float gk = a.grad_ys[(size_t)(k + 1) * BH + goff + e];
+                const float gk = a.row_out ? (rslot == k + 1 ? gfin[e] : 0.0f) : a.grad_ys[(size_t)(k + 1) * BH + goff + e];
                 if (w0 == 0.0f) adj[e] += gk;
                 else { adj[e] = fmaf(w1, gk, adj[e]); carry[e] = fmaf(w0, gk, carry[e]); }
             }
@@ -950,7 +957,7 @@ __global__ void __launch_bounds__(CF::NT, CF::WPS) snsde_mfma_reverse_kernel(Rev
     }
     if (row_ok) {     // ys[0] = y0
 #pragma unroll
-        for (int e = 0; e < EPT; ++e) a.adj[goff + e] = adj[e] + a.grad_ys[goff + e];
+        for (int e = 0; e < EPT; ++e) a.adj[goff + e] = adj[e] + (a.row_out ? (rslot == 0 ? gfin[e] : 0.0f) : a.grad_ys[goff + e]);
     }
     if ((dsum || NN > 0) && a.dth_part) {
 #pragma unroll

@@ -167,7 +167,7 @@ class SolveCall:
     launch itself is one C call that only enqueues kernels (hipGraph-capturable)."""
 
     def __init__(self, model, flat_params, coeffs, grid, y0, dW=None, method='euler', seed=0, row_offset=0,
-                 kernel='auto', save_traj=False, save_dW=False, exact_order=False, save_act=False, dU=None):
+                 kernel='auto', save_traj=False, save_dW=False, exact_order=False, save_act=False, dU=None, row_out=None):
         B, H = y0.shape
         C_ = model.input_channels
         L = coeffs.shape[1] + 1
@@ -180,8 +180,12 @@ class SolveCall:
         self.model, self.grid = model, grid
         if dU is not None:
             _check_f32('dU', dU, (grid.N, B, H))
-        self.keep = (flat_params, coeffs, y0, dW, grid, dU)
-        self.ys = torch.empty((grid.T, B, H), device=dev, dtype=torch.float32)
+        if row_out is not None:
+            if row_out.dtype != torch.int32 or not row_out.is_cuda or not row_out.is_contiguous() or tuple(row_out.shape) != (B,):
+                raise ValueError('row_out must be a contiguous int32 CUDA tensor of shape (batch,)')
+        self.keep = (flat_params, coeffs, y0, dW, grid, dU, row_out)
+        # per-row output selection: one state per row instead of one plane per output time
+        self.ys = torch.empty((B, H) if row_out is not None else (grid.T, B, H), device=dev, dtype=torch.float32)
         self.traj = torch.empty((grid.N + 1, B, H), device=dev, dtype=torch.float32) if save_traj else None
         self.dW_out = torch.empty((grid.N, B, H), device=dev, dtype=torch.float32) if save_dW else None
         self.act_save = None
@@ -208,6 +212,7 @@ class SolveCall:
         s.y0, s.dW, s.ys = _ptr(y0), _ptr(dW), _ptr(self.ys)
         s.traj, s.dW_out = _ptr(self.traj), _ptr(self.dW_out)
         s.act_save = _ptr(self.act_save)
+        s.row_out = _ptr(row_out)
         nbytes = _lib.lib().snsde_workspace_bytes(C.byref(s))
         self.workspace = torch.empty(max(nbytes, 256), device=dev, dtype=torch.uint8)
         s.workspace = _ptr(self.workspace)

@@ -230,15 +230,20 @@ class NeuralSDE(_SDEHead):
         self.func.set_X(*coeffs, times)
         z0 = self._prepare_initial_state(times, z0)
         if stream:
-            ts, row_slot = times, None
-        else:
-            ts, row_slot = self.output_times(times, final_index)
+            return self.linear(self._solve_sde_path(times, times, z0, kwargs).movedim(0, -2))
+        if z0.is_cuda and engine.recognise(self.func) is not None:
+            # Fused solve: output grid = every knot, and each row's own state is selected INSIDE the solve
+            # (options['row_out']; ys comes back as (B, H)).  The step grid depends only on ts[0], dt and ts[-1], and
+            # each output is the interpolation of the two solver states around it, so the selected states are
+            # bit-identical to solving on the reference's `unique(final_index)` grid and gathering
+            # (neuralsde.py:91-116) — without its two device->host syncs and without the (T, B, H) round trip.
+            kwargs = dict(kwargs)
+            kwargs['options'] = dict(kwargs.get('options') or {}, row_out=final_index)
+            return self.linear(self._solve_sde_path(times, times, z0, kwargs))
+        ts, row_slot = self.output_times(times, final_index)
         z_t = self._solve_sde_path(times, ts, z0, kwargs)
-        if stream:
-            z = z_t.movedim(0, -2)
-        else:
-            idx = row_slot.reshape(1, -1, 1).expand(1, z_t.shape[1], z_t.shape[2])
-            z = z_t.gather(0, idx).squeeze(0)
+        idx = row_slot.reshape(1, -1, 1).expand(1, z_t.shape[1], z_t.shape[2])
+        z = z_t.gather(0, idx).squeeze(0)
         return self.linear(z)
 
 

@@ -125,6 +125,10 @@ def _sdeint_hip(sde, rec, y0, ts, bm, method, dt, options):
             dW = torch.stack([bm(t0[n], t1[n]).to(device=dev, dtype=torch.float32) for n in range(grid.N)]).contiguous()
     seed = options.get('seed')
     seed = _fresh_seed() if seed is None else int(seed)
+    row_out = options.get('row_out')
+    if row_out is not None:     # per-row output selection fused into the solve: the result is (B, H)
+        row_out = row_out.to(device=dev, dtype=torch.int32).contiguous()
+        options = dict(options, row_out=row_out)
     if needs_grad and method == 'srk':
         raise NotImplementedError("gradients through the fused SRK solve are not implemented; use method='euler' "
                                   "or options={'backend': 'torch'}")
@@ -135,7 +139,7 @@ def _sdeint_hip(sde, rec, y0, ts, bm, method, dt, options):
     call = engine.SolveCall(model, flat, coeffs, grid, y0c, dW=dW, method=method, seed=seed,
                             row_offset=int(options.get('row_offset', 0)), kernel=options.get('kernel', 'auto'),
                             save_traj=bool(options.get('save_traj', False)),
-                            exact_order=bool(options.get('exact_order', False)), dU=dU)
+                            exact_order=bool(options.get('exact_order', False)), dU=dU, row_out=row_out)
     ys = call.launch()
     if options.get('save_traj', False):
         sde.last_trajectory = call.traj
@@ -158,7 +162,8 @@ class _FusedSolve(torch.autograd.Function):
         def make(kernel, save_act):
             return engine.SolveCall(model, flat, coeffs, grid, y0c, dW=dW, method=method, seed=seed,
                                     row_offset=int(options.get('row_offset', 0)), kernel=kernel, save_traj=True,
-                                    save_dW=True, save_act=save_act, exact_order=bool(options.get('exact_order', False)))
+                                    save_dW=True, save_act=save_act, exact_order=bool(options.get('exact_order', False)),
+                                    row_out=options.get('row_out'))
         mode = engine.backward_mode(model, y0c.shape[0], coeffs.shape[1] + 1, grid, method, options.get('kernel', 'auto'),
                                     bool(options.get('exact_order', False)))
         if mode == 0:
@@ -419,4 +424,9 @@ def _sdeint_torch(sde, y0, ts, bm, method, dt, options, names):
         while k < grid.T - 1 and grid.out_step[k] == n:
             ys.append(y if grid.out_w[k, 0] == 0 else w[k, 0] * prev + w[k, 1] * y)
             k += 1
-    return torch.stack(ys, dim=0)
+    ys = torch.stack(ys, dim=0)
+    row_out = (options or {}).get('row_out')
+    if row_out is not None:     # same contract as the fused path: each row's own output state, (B, H)
+        idx = row_out.to(device=ys.device, dtype=torch.int64).reshape(1, -1, 1).expand(1, ys.shape[1], ys.shape[2])
+        ys = ys.gather(0, idx).squeeze(0)
+    return ys

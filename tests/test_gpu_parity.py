@@ -619,6 +619,63 @@ def test_backward_unsupported_configurations_raise():
         S.sdeint(m2, y0, torch.tensor([0., 4.], device=DEV), method='srk', dt=1.0)
 
 
+@pytest.mark.parametrize('kernel,method,io,no', [('mfma4', 'euler', 4, 17), ('mfma16', 'milstein', 6, 17), ('generic', 'euler', 2, 7),
+                                                  ('generic', 'srk', 4, 17), ('mfma4', 'euler', 3, 18)])
+def test_per_row_output_selection_equals_gather(kernel, method, io, no):
+    """options['row_out'] (per-row output slot, fused into the solve) == solving for every output and gathering
+    (the per-row selection of NeuralSDE.forward, neuralsde.py:115-116), forward and backward, bit for bit."""
+    B, H, C, L = 37, 64, 5, 12
+    pr = make_problem(41, io, no, 2, B, H, C, L)
+    ts = torch.tensor([0., 2.5, 4., 7., 11.], device=DEV)       # includes an interpolated output
+    slot = torch.randint(0, 5, (B,), device=DEV)
+    wsum = torch.randn(B, H, device=DEV)
+    res = {}
+    for mode in ('fused', 'gather'):
+        m = S.Diffusion_model(C, H, H, 2, input_option=io, noise_option=no)
+        m.load_state_dict({k: torch.from_numpy(v.copy()) for k, v in pr['params'].items()})
+        m = m.to(DEV)
+        m.set_X(torch.from_numpy(pr['coeffs']).to(DEV), torch.from_numpy(pr['times']).to(DEV))
+        grad = method != 'srk'
+        y0 = torch.from_numpy(pr['y0']).to(DEV).requires_grad_(grad)
+        opts = {'seed': 9, 'kernel': kernel}
+        with torch.set_grad_enabled(grad):
+            if mode == 'fused':
+                z = S.sdeint(m, y0, ts, method=method, dt=1.0, options=dict(opts, row_out=slot))
+            else:
+                zt = S.sdeint(m, y0, ts, method=method, dt=1.0, options=opts)
+                z = zt.gather(0, slot.reshape(1, -1, 1).expand(1, B, H)).squeeze(0)
+            assert z.shape == (B, H)
+            if grad:
+                (z * wsum).sum().backward()
+        res[mode] = (z.detach(), y0.grad, [p.grad for p in m.parameters()] if grad else [])
+    assert torch.equal(res['fused'][0], res['gather'][0])
+    if res['fused'][1] is not None:
+        assert torch.equal(res['fused'][1], res['gather'][1])
+        for a, b in zip(res['fused'][2], res['gather'][2]):
+            assert (a is None and b is None) or torch.equal(a, b)
+
+
+def test_neuralsde_wrapper_all_knot_outputs_equal_reference_output_time_selection():
+    """NeuralSDE.forward on CUDA emits every knot and gathers each row's state; the reference solves on
+    ts = [t0, times[unique(final_index)], t_end] (neuralsde.py:91-116).  Same grid, same interpolation: identical bits."""
+    B, H, C, L = 96, 64, 5, 17
+    pr = make_problem(31, 4, 17, 2, B, H, C, L)
+    torch.manual_seed(3)
+    model, field = S.make_sde_model('neurallnsde', C, 2, H, H, 2, initial=True)
+    model = model.to(DEV).eval()
+    times = torch.from_numpy(pr['times']).to(DEV)
+    coeffs = torch.from_numpy(pr['coeffs']).to(DEV)
+    fi = torch.randint(0, L, (B,), device=DEV)
+    with torch.no_grad():
+        got = model(times, [coeffs], fi, options={'seed': 5})
+        field.set_X(coeffs, times)
+        z0 = model.initial_network(field.X.evaluate(times[0]))
+        ts, slot = model.output_times(times, fi)
+        z_t = S.sdeint(field, z0, ts, method='euler', dt=1.0, options={'seed': 5})
+        want = model.linear(z_t.gather(0, slot.reshape(1, -1, 1).expand(1, B, H)).squeeze(0))
+    assert torch.equal(got, want)
+
+
 def test_neuralsde_training_step_on_cuda():
     """One optimizer step of the reference's training recipe (Adam, BCE-with-logits) through the fused path."""
     pr = make_problem(23, 4, 17, 2, 64, 32, 5, 9)
