@@ -143,6 +143,9 @@ typedef struct snsde_solve {
                               /* supplied dW), or NULL: h*(dW/2 + sqrt(h/12) xi), xi from Philox      */
     float*         dU_out;    /* optional device (N, B, H): the I_k0 actually used                    */
     float*         act_save;  /* optional device (N, snsde_act_slots, B, H): per-step activations */
+    const uint64_t* seed_dev; /* optional device pointer to the Philox key: read when the kernel starts and used  */
+                              /* instead of `seed`, so a captured hipGraph draws fresh increments on every replay */
+                              /* (the owner updates the value in-stream between replays).                         */
     const int32_t* row_out;   /* optional device (B): per-row output selection (the gather of NeuralSDE.forward,  */
                               /* neuralsde.py:115-116).  When set, ys is (B, H) with ys[b] = the solution at      */
                               /* ts[row_out[b]] (0 <= row_out[b] < n_out), and the backward's grad_ys is (B, H).  */

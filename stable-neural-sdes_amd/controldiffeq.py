@@ -131,6 +131,24 @@ class _HostTimes:
             cls._cache[key] = hit
         return hit[0]
 
+    @classmethod
+    def scalar(cls, t):
+        """float(t) without a stream sync when `t` is an element of a device vector whose host copy is cached (the
+        usual `X.evaluate(times[0])` of the reference's models, neuralsde.py:66): the value is read from the host copy
+        at the view's storage offset.  Anything else falls back to float(t)."""
+        if torch.is_tensor(t) and t.is_cuda and t.numel() == 1:
+            try:
+                base = t.untyped_storage().data_ptr()
+            except Exception:
+                return float(t)
+            for (ptr, version, shape, stride, dtype, dev), (host, ref) in cls._cache.items():
+                if (ref.untyped_storage().data_ptr() == base and version == t._version and dtype == t.dtype
+                        and len(shape) == 1 and str(t.device) == dev):
+                    k, rem = divmod(t.storage_offset() - ref.storage_offset(), stride[0] if stride[0] else 1)
+                    if rem == 0 and 0 <= k < shape[0]:
+                        return float(host[k])
+        return float(t)
+
 
 class NaturalCubicSpline:
     """``NaturalCubicSpline(times, (a, b, two_c, three_d))`` with ``evaluate(t)`` / ``derivative(t)``
@@ -152,8 +170,7 @@ class NaturalCubicSpline:
 
     def _interpret_t(self, t):
         times = _HostTimes.get(self._times)
-        tv = float(t)
-        import numpy as np
+        tv = _HostTimes.scalar(t)
         t32 = times.dtype.type(tv)
         idx = int((t32 > times).sum()) - 1
         idx = min(max(idx, 0), times.shape[0] - 2)

@@ -66,6 +66,7 @@ struct GenericArgs {
     const int32_t* row_out;   // (B) per-row output slot (ys / grad_ys are then (B, H)) or null
     int64_t row_offset;
     uint64_t seed;
+    const uint64_t* seed_dev;   // device-resident key (overrides seed) or null
     int32_t eval_mode;
     float* eval_f;
     float* eval_g;
@@ -217,7 +218,7 @@ __global__ void __launch_bounds__(GT) snsde_generic_kernel(GenericArgs a) {
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     float z4[4];
-                    snsde_philox_normal4(a.seed, (uint32_t)(a.row_offset + row), (uint32_t)(n >> 2), (uint32_t)(4 * q + e), z4);
+                    snsde_philox_normal4(a.seed_dev ? *a.seed_dev : a.seed, (uint32_t)(a.row_offset + row), (uint32_t)(n >> 2), (uint32_t)(4 * q + e), z4);
                     zn[e] = (n & 3) == 0 ? z4[0] : (n & 3) == 1 ? z4[1] : (n & 3) == 2 ? z4[2] : z4[3];
                 }
             }
@@ -446,8 +447,8 @@ __global__ void __launch_bounds__(GT) snsde_generic_srk_kernel(SrkArgs sa) {
                 if (a.dW) { dw = a.dW[off]; du = sa.dU[off]; }
                 else {
                     float z4[4], x4[4];
-                    snsde_philox_normal4(a.seed, (uint32_t)(a.row_offset + row), (uint32_t)(n >> 2), (uint32_t)j, z4, 0u);
-                    snsde_philox_normal4(a.seed, (uint32_t)(a.row_offset + row), (uint32_t)(n >> 2), (uint32_t)j, x4, 1u);
+                    snsde_philox_normal4(a.seed_dev ? *a.seed_dev : a.seed, (uint32_t)(a.row_offset + row), (uint32_t)(n >> 2), (uint32_t)j, z4, 0u);
+                    snsde_philox_normal4(a.seed_dev ? *a.seed_dev : a.seed, (uint32_t)(a.row_offset + row), (uint32_t)(n >> 2), (uint32_t)j, x4, 1u);
                     const int k = n & 3;
                     dw = (k == 0 ? z4[0] : k == 1 ? z4[1] : k == 2 ? z4[2] : z4[3]) * rdt;
                     const float xi = k == 0 ? x4[0] : k == 1 ? x4[1] : k == 2 ? x4[2] : x4[3];
@@ -799,7 +800,7 @@ int snsde_generic_launch(const snsde_solve* s, const SnsdeNet& net, hipStream_t 
     a.dW_out = s->dW_out;
     a.row_out = eval_mode ? nullptr : s->row_out;
     a.row_offset = s->row_offset;
-    a.seed = s->seed;
+    a.seed = s->seed; a.seed_dev = s->seed_dev;
     a.eval_mode = eval_mode;
     a.eval_f = eval_f;
     a.eval_g = eval_g;
@@ -839,7 +840,7 @@ int snsde_generic_backward_launch(const snsde_backward* b, const SnsdeNet& net, 
     a.net = net;
     a.params = s->params; a.ws = static_cast<const float*>(s->workspace); a.coeffs = s->coeffs;
     a.step_tab = s->step_tab; a.out_step = s->out_step; a.out_w = s->out_w; a.y0 = s->y0; a.dW = nullptr;
-    a.ys = nullptr; a.traj = nullptr; a.dW_out = nullptr; a.row_out = s->row_out; a.row_offset = 0; a.seed = 0; a.eval_mode = 0;
+    a.ys = nullptr; a.traj = nullptr; a.dW_out = nullptr; a.row_out = s->row_out; a.row_offset = 0; a.seed = 0; a.seed_dev = nullptr; a.eval_mode = 0;
     a.eval_f = nullptr; a.eval_g = nullptr;
     const int H = m.hidden_channels, HH = m.hidden_hidden_channels;
     a.ldy = round4(H + 2);
@@ -880,7 +881,7 @@ int snsde_srk_launch(const snsde_solve* s, const SnsdeNet& net, hipStream_t stre
     a.net = net;
     a.params = s->params; a.ws = ws; a.coeffs = s->coeffs; a.step_tab = s->step_tab; a.out_step = s->out_step;
     a.out_w = s->out_w; a.y0 = s->y0; a.dW = s->dW; a.ys = s->ys; a.traj = s->traj; a.dW_out = s->dW_out;
-    a.row_out = s->row_out; a.row_offset = s->row_offset; a.seed = s->seed; a.eval_mode = 0; a.eval_f = nullptr; a.eval_g = nullptr;
+    a.row_out = s->row_out; a.row_offset = s->row_offset; a.seed = s->seed; a.seed_dev = s->seed_dev; a.eval_mode = 0; a.eval_f = nullptr; a.eval_g = nullptr;
     const int H = m.hidden_channels, HH = m.hidden_hidden_channels;
     a.ldy = round4(H + 2);
     const int wmax = 2 * H > HH ? 2 * H : HH;

@@ -269,7 +269,7 @@ int snsde_mfma_launch(const snsde_solve* s, const SnsdeNet& net, hipStream_t str
     a.params = s->params; a.ws = ws; a.coeffs = s->coeffs; a.step_tab = s->step_tab; a.out_step = s->out_step;
     a.out_w = s->out_w; a.y0 = s->y0; a.dW = s->dW; a.ys = s->ys; a.traj = s->traj; a.dW_out = s->dW_out;
     a.act_save = s->act_save; a.row_out = s->row_out;
-    a.row_offset = s->row_offset; a.seed = s->seed;
+    a.row_offset = s->row_offset; a.seed = s->seed; a.seed_dev = s->seed_dev;
     a.B = s->batch; a.L = s->knots; a.C = s->model.input_channels; a.N = s->n_steps; a.T = s->n_out;
     a.method = s->method; a.no = s->model.noise_option;
     a.off_theta = net.off_theta; a.gt_off = p.gt_off; a.bias_off = p.bias_off;

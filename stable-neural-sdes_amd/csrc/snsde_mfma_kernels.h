@@ -78,6 +78,7 @@ struct MfmaArgs {
     const int32_t* row_out;   // (B) per-row output slot (ys is then (B, H)) or null
     int64_t row_offset;
     uint64_t seed;
+    const uint64_t* seed_dev;   // device-resident key (overrides seed) or null
     int32_t B, L, C, N, T, method, no;
     int32_t off_theta, gt_off, bias_off;
     int32_t w_off[MAXL];
@@ -362,6 +363,7 @@ __global__ void __launch_bounds__(CF::NT, CF::WPS) snsde_mfma_kernel(MfmaArgs a)
     const bool s1 = (s == 1), s2 = (s == 2), s3 = (s == 3);
     const float mil = (a.method == SNSDE_MILSTEIN) ? 0.5f : 0.0f;
     const uint32_t grow = (uint32_t)(a.row_offset + row);
+    const uint64_t seed = a.seed_dev ? *a.seed_dev : a.seed;
     const int rslot = a.row_out ? a.row_out[rowc] : -1;     // per-row output selection (ys is (B, H))
 
     // store one layer output fragment (bias came in through the accumulator init) as 16 B per lane
@@ -447,7 +449,7 @@ __global__ void __launch_bounds__(CF::NT, CF::WPS) snsde_mfma_kernel(MfmaArgs a)
                     for (int e = 0; e < EPT; ++e)
     #pragma unroll
                         for (int bb = 0; bb < ZB; ++bb)
-                            snsde_philox_normal4(a.seed, grow, (uint32_t)((n >> 2) + bb), (uint32_t)(fcol[0] + e), &zq[e][4 * bb]);
+                            snsde_philox_normal4(seed, grow, (uint32_t)((n >> 2) + bb), (uint32_t)(fcol[0] + e), &zq[e][4 * bb]);
     #pragma unroll
                     for (int i = 0; i < 4 * ZB; ++i) {
                         if constexpr (FL) zstash[i * 64 + lane] = zq[0][i];

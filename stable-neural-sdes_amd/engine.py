@@ -206,7 +206,13 @@ class SolveCall:
         self.base_flags = _lib.FLAG_EXACT_ORDER if exact_order else 0
         s.flags = self.base_flags
         s.row_offset = int(row_offset)
-        s.seed = int(seed) & 0xFFFFFFFFFFFFFFFF
+        if torch.is_tensor(seed):     # device-resident key: re-read by every launch / graph replay
+            if seed.dtype != torch.int64 or not seed.is_cuda or seed.numel() != 1:
+                raise ValueError('a tensor seed must be a one-element int64 CUDA tensor')
+            self.keep = self.keep + (seed,)
+            s.seed_dev = _ptr(seed)
+        else:
+            s.seed = int(seed) & 0xFFFFFFFFFFFFFFFF
         s.params, s.coeffs = _ptr(flat_params), _ptr(coeffs)
         s.step_tab, s.out_step, s.out_w = _ptr(grid.d_step_tab), _ptr(grid.d_out_step), _ptr(grid.d_out_w)
         s.y0, s.dW, s.ys = _ptr(y0), _ptr(dW), _ptr(self.ys)

@@ -68,6 +68,35 @@ def _fresh_seed():
     return int(torch.empty((), dtype=torch.int64).random_().item())
 
 
+_CAPTURE_SEEDS = {}
+
+
+def _dev_key(device):
+    device = torch.device(device)
+    return device.index if device.index is not None else torch.cuda.current_device()
+
+
+def _capture_seed(device):
+    """Device-resident Philox key for solves recorded into a hipGraph: the increment is part of the graph, so every
+    replay integrates against fresh Brownian increments (a host-drawn seed would be frozen into the recording)."""
+    state = _CAPTURE_SEEDS.get(_dev_key(device))
+    if state is None:
+        raise RuntimeError("sdeint without options['seed'] inside a CUDA graph capture: call "
+                           "stable_neural_sdes_amd.torchsde.prepare_graph_capture(device) before capturing")
+    state.add_(1)
+    return state
+
+
+def prepare_graph_capture(device):
+    """Allocate the device-resident seed used by solves that are recorded into a CUDA/HIP graph (call once, outside
+    the capture).  The key is drawn from torch's CPU generator, so torch.manual_seed makes replays reproducible."""
+    key = _dev_key(device)
+    if key not in _CAPTURE_SEEDS:
+        _CAPTURE_SEEDS[key] = torch.tensor([_fresh_seed() & 0x3FFFFFFFFFFFFFFF], dtype=torch.int64,
+                                           device=torch.device('cuda', key))
+    return _CAPTURE_SEEDS[key]
+
+
 def sdeint(sde, y0, ts, bm=None, method=None, dt=1e-3, adaptive=False, rtol=1e-5, atol=1e-4, dt_min=1e-5,
            options=None, names=None, logqp=False, extra=False, extra_solver_state=None, **unused_kwargs):
     if unused_kwargs:
@@ -124,7 +153,10 @@ def _sdeint_hip(sde, rec, y0, ts, bm, method, dt, options):
         else:
             dW = torch.stack([bm(t0[n], t1[n]).to(device=dev, dtype=torch.float32) for n in range(grid.N)]).contiguous()
     seed = options.get('seed')
-    seed = _fresh_seed() if seed is None else int(seed)
+    if seed is None:
+        seed = _capture_seed(dev) if torch.cuda.is_current_stream_capturing() else _fresh_seed()
+    elif not torch.is_tensor(seed):
+        seed = int(seed)
     row_out = options.get('row_out')
     if row_out is not None:     # per-row output selection fused into the solve: the result is (B, H)
         row_out = row_out.to(device=dev, dtype=torch.int32).contiguous()

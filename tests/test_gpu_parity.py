@@ -676,6 +676,62 @@ def test_neuralsde_wrapper_all_knot_outputs_equal_reference_output_time_selectio
     assert torch.equal(got, want)
 
 
+def test_training_step_recorded_into_a_graph_draws_fresh_noise_and_matches_eager():
+    """A whole training step (NeuralSDE forward, fused solve + adjoint + parameter pass, Adam) recorded into one
+    CUDA/HIP graph: every replay must integrate against fresh increments (device-resident Philox key) and leave the
+    parameters exactly where the same steps run eagerly with those keys leave them."""
+    from stable_neural_sdes_amd import torchsde as T
+    B, H, C, L = 64, 32, 5, 9
+    pr = make_problem(23, 4, 17, 2, B, H, C, L)
+    times = torch.from_numpy(pr['times']).to(DEV)
+    coeffs = torch.from_numpy(pr['coeffs']).to(DEV)
+    fi = torch.randint(1, L, (B,), device=DEV)
+    target = (torch.rand(B, device=DEV) > 0.5).float()
+
+    def make():
+        torch.manual_seed(1)
+        model, _ = S.make_sde_model('neurallnsde', C, 1, H, H, 2, initial=True)
+        model = model.to(DEV).train()
+        model.linear[3].p = 0.0          # dropout off: its generator state is not part of this comparison
+        return model, torch.optim.Adam(model.parameters(), lr=1e-3, capturable=True)
+
+    def step(model, opt, seed=None):
+        opts = {} if seed is None else {'seed': seed}
+        pred = model(times, [coeffs], fi, options=opts).squeeze(-1)
+        loss = torch.nn.functional.binary_cross_entropy_with_logits(pred, target)
+        opt.zero_grad(set_to_none=True)
+        loss.backward()
+        opt.step()
+        return loss
+
+    state = T.prepare_graph_capture(DEV)
+    mg, og = make()
+    me, oe = make()
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        for k in range(3):
+            step(mg, og, seed=100 + k)
+    torch.cuda.current_stream().wait_stream(side)
+    for k in range(3):
+        step(me, oe, seed=100 + k)
+    torch.cuda.synchronize()
+    base = int(state.item())
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        static_loss = step(mg, og)
+    losses = []
+    for _ in range(3):
+        g.replay()
+        losses.append(float(static_loss))
+    assert int(state.item()) == base + 3
+    assert len(set(losses)) == 3 and all(np.isfinite(losses))
+    eager = [float(step(me, oe, seed=base + 1 + k)) for k in range(3)]
+    assert losses == eager
+    for (n1, p1), (n2, p2) in zip(mg.named_parameters(), me.named_parameters()):
+        assert torch.equal(p1, p2), n1
+
+
 def test_neuralsde_training_step_on_cuda():
     """One optimizer step of the reference's training recipe (Adam, BCE-with-logits) through the fused path."""
     pr = make_problem(23, 4, 17, 2, 64, 32, 5, 9)

@@ -15,21 +15,47 @@ def timeit(fn, n=20):
     for _ in range(n): fn()
     torch.cuda.synchronize(); return (time.perf_counter() - t) / n * 1e3
 
+from stable_neural_sdes_amd import torchsde as T
+T.prepare_graph_capture(dev)
+
 for name, B, H, C, L in (('neurallnsde', 1024, 128, 21, 101), ('naivesde', 2048, 64, 69, 72), ('neuralgsde', 512, 128, 21, 201)):
     pr = make_problem(5, 4, 17, 2, B, H, C, L, nan_frac=0.2)
-    torch.manual_seed(0)
-    model, field = S.make_sde_model(name, C, 1, H, H, 2, initial=True)
-    model = model.to(dev).train()
-    opt = torch.optim.Adam(model.parameters(), lr=1e-3)
     times = torch.from_numpy(pr['times']).to(dev)
     coeffs = torch.from_numpy(pr['coeffs']).to(dev)
     fi = torch.randint(2, L, (B,), device=dev)
     target = (torch.rand(B, device=dev) > 0.5).float()
-    def train_step():
-        pred = model(times, [coeffs], fi).squeeze(-1)
-        loss = torch.nn.functional.binary_cross_entropy_with_logits(pred, target)
-        opt.zero_grad(); loss.backward(); opt.step()
+
+    def build(capturable):
+        torch.manual_seed(0)
+        model, _ = S.make_sde_model(name, C, 1, H, H, 2, initial=True)
+        model = model.to(dev).train()
+        return model, torch.optim.Adam(model.parameters(), lr=1e-3, capturable=capturable)
+
+    def make_step(model, opt):
+        def train_step():
+            pred = model(times, [coeffs], fi).squeeze(-1)
+            loss = torch.nn.functional.binary_cross_entropy_with_logits(pred, target)
+            opt.zero_grad(set_to_none=True); loss.backward(); opt.step()
+        return train_step
+
+    # (1) the training step recorded into one CUDA/HIP graph (device-resident Philox key => fresh noise per replay);
+    #     first use of this model is on the side stream, as torch's capture recipe requires
+    mg, og = build(True)
+    cap_step = make_step(mg, og)
+    side = torch.cuda.Stream(); side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        for _ in range(3): cap_step()
+    torch.cuda.current_stream().wait_stream(side); torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        cap_step()
+    t_graph = timeit(g.replay)
+    # (2) eager
+    model, opt = build(False)
+    train_step = make_step(model, opt)
     def infer():
         with torch.no_grad():
             model(times, [coeffs], fi)
-    print(f'{name:12s} B={B} H={H} L={L}: inference {timeit(infer):.3f} ms, training step {timeit(train_step):.3f} ms')
+    t_train, t_inf = timeit(train_step), timeit(infer)
+    print(f'{name:12s} B={B} H={H} L={L}: inference {t_inf:.3f} ms, training step {t_train:.3f} ms, '
+          f'graph-replayed training step {t_graph:.3f} ms')
