@@ -730,6 +730,316 @@ __global__ void __launch_bounds__(GT) snsde_generic_adjoint_kernel(AdjArgs aa) {
     }
 }
 
+
+// =====================================================================================================
+// SRK adjoint: discretise-then-optimise backward of the SRID2 step above (elementwise diffusions, any dims).
+// Per step (last to first) the workgroup re-evaluates the three drift stages from the saved state y_n and the saved
+// increments (I_k, I_k0), then walks the stage graph backwards:
+//     Fbar_s, Gbar_s  <-  a (alpha_s h, w_s)  +  the H0/H1 combinations of later stages
+//     H1bar_s = Gbar_s * dg/dy(t1_s, H1_s)            (elementwise)
+//     H0bar_s = J_f(t0_s, H0_s)^T Fbar_s              (transposed dense chain, as in the Euler adjoint)
+// The activations of the LAST forward drift evaluation (stage 2) are reused by its VJP; stages 1 and 0 are
+// re-evaluated right before theirs: 5 drift forwards + 3 VJPs per step.
+// =====================================================================================================
+struct SrkAdjArgs {
+    GenericArgs g;
+    const float* srk_tab;
+    const float* traj;      // (N+1, B, H)
+    const float* dW_used;   // (N, B, H)  I_k
+    const float* dU_used;   // (N, B, H)  I_k0
+    const float* grad_ys;
+    float* adj;             // (N+1, B, H)
+    int32_t ldf;
+};
+
+__global__ void __launch_bounds__(GT) snsde_generic_srk_adjoint_kernel(SrkAdjArgs aa) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const GenericArgs& a = aa.g;
+    const SnsdeDims& d = a.d;
+    const SnsdeNet& net = a.net;
+    const int H = d.H, C = d.C, B = d.B, io = d.io, no = d.no;
+    const int ldy = a.ldy, ldw = a.ldw, ldx = a.ldx, ldf = aa.ldf;
+    const int nact = net.n_hid + 1;
+    float* Y = lds;                                 // y_n
+    float* S0 = Y + GR * ldy;                       // drift stage state | sin, cos
+    float* xbuf = S0 + GR * ldy;
+    float* cat = xbuf + GR * ldx;
+    float* act = cat + GR * ldw;                    // act[l][GR][ldw]
+    float* zo = act + (size_t)nact * GR * ldw;
+    float* dl = zo + GR * ldw;
+    float* V = dl + GR * ldw;                       // 16 planes [GR][ldf]
+    const int plane = GR * ldf;
+    float* F0 = V; float* F1 = V + plane; float* F2 = V + 2 * plane;
+    float* G0 = V + 3 * plane; float* G1 = V + 4 * plane; float* G2 = V + 5 * plane;
+    float* FB0 = V + 6 * plane; float* FB1 = V + 7 * plane; float* FB2 = V + 8 * plane;
+    float* GB0 = V + 9 * plane; float* GB1 = V + 10 * plane; float* GB2 = V + 11 * plane;
+    float* YB = V + 12 * plane; float* AV = V + 13 * plane; float* DW = V + 14 * plane; float* DU = V + 15 * plane;
+    const int lds_floats = GR * (2 * ldy + ldx + (3 + nact) * ldw + 16 * ldf);
+    const int tid = threadIdx.x, row0 = blockIdx.x * GR;
+    for (int i = tid; i < lds_floats; i += GT) lds[i] = 0.0f;
+    __syncthreads();
+    const float sig_theta = snsde_sigmoid(a.params[net.off_theta]);
+    const float exp_sigma = (net.off_sigma >= 0) ? expf(a.params[net.off_sigma]) : 0.0f;
+    const bool uses_x = (io == 0 || io == 2 || io == 4 || io == 6);
+    const bool uses_emb = (io == 2 || io == 4 || io == 6);
+    const bool geo = (io == 5 || io == 6);
+    const float* gt = a.ws + (net.gt_tab >= 0 ? net.gt_tab : 0);
+    const size_t BH = (size_t)B * H;
+
+    auto for_elems = [&](auto&& fn) {
+        for (int i = tid; i < GR * H; i += GT) {
+            const int r = i / H, j = i - r * H;
+            fn(r, j, row0 + r);
+        }
+        __syncthreads();
+    };
+    // drift forward at (stage time tp, state in S0), activations kept in act[] / zo
+    auto fwd_chain = [&](const float* tp) {
+        const float frac = tp[3];
+        const int idx = __float_as_int(tp[4]);
+        if (tid < GR) { S0[tid * ldy + H] = tp[1]; S0[tid * ldy + H + 1] = tp[2]; }
+        if (uses_x) {
+            for (int i = tid; i < GR * C; i += GT) {
+                const int r = i / C, c = i - r * C, row = row0 + r;
+                float v = 0.0f;
+                if (row < B) {
+                    const float* cp = a.coeffs + ((size_t)row * (d.L - 1) + idx) * (4 * C) + c;
+                    v = snsde_spline_eval(cp[0], cp[C], cp[2 * C], cp[3 * C], frac);
+                }
+                xbuf[r * ldx + c] = v;
+            }
+        }
+        __syncthreads();
+        float* z0 = act;
+        if (io == 0) dense(a.params, a.ws, net.init, xbuf, ldx, z0, ldw, true);
+        else if (!uses_emb) dense(a.params, a.ws, net.in, S0, ldy, z0, ldw, true);
+        else {
+            dense(a.params, a.ws, net.in, S0, ldy, cat, ldw, false);
+            dense(a.params, a.ws, net.init, xbuf, ldx, cat + H, ldw, false);
+            __syncthreads();
+            dense(a.params, a.ws, net.emb, cat, ldw, z0, ldw, true);
+        }
+        __syncthreads();
+        for (int l = 0; l < net.n_hid; ++l) {
+            dense(a.params, a.ws, net.hid[l], act + (size_t)l * GR * ldw, ldw, act + (size_t)(l + 1) * GR * ldw, ldw, true);
+            __syncthreads();
+        }
+        dense(a.params, a.ws, net.out, act + (size_t)net.n_hid * GR * ldw, ldw, zo, ldw, false);
+        __syncthreads();
+    };
+    auto f_value = [&](float* fout) {
+        for_elems([&](int r, int j, int) {
+            float z = zo[r * ldw + j];
+            if (geo) z *= tanhf(S0[r * ldy + j]);
+            fout[r * ldf + j] = tanhf(z);
+        });
+    };
+    // g(t, y) and dg/dy for the elementwise diffusions
+    auto g_and_prime = [&](float y, float t, int n, int slot, int j, float& g1) {
+        float raw = 0.0f, r1 = 0.0f;
+        switch (no) {
+            case 0: break;
+            case 1: raw = exp_sigma; break;
+            case 2: raw = exp_sigma * t; break;
+            case 3: raw = exp_sigma * y; r1 = exp_sigma; break;
+            case 4: raw = expf(a.params[net.off_sigma_diag + j]); break;
+            case 5: raw = expf(a.params[net.off_sigma_diag + j]) * t; break;
+            case 6: r1 = expf(a.params[net.off_sigma_diag + j]); raw = r1 * y; break;
+            case 7: raw = sqrtf(y); r1 = 0.5f / raw; break;
+            case 8: raw = y * y * y; r1 = 3.0f * y * y; break;
+            case 9: raw = snsde_sigmoid(y); r1 = raw * (1.0f - raw); break;
+            case 10: raw = fmaxf(y, 0.0f); r1 = y > 0.0f ? 1.0f : 0.0f; break;
+            case 11: raw = t * y; r1 = t; break;
+            case 12: case 16: raw = gt[((size_t)n * 4 + slot) * H + j]; break;
+            case 13: case 17: r1 = gt[((size_t)n * 4 + slot) * H + j]; raw = r1 * y; break;
+            default: break;
+        }
+        const float g = tanhf(sig_theta * snsde_nan_to_num(raw));
+        g1 = (raw - raw == 0.0f) ? (1.0f - g * g) * sig_theta * r1 : 0.0f;
+        return g;
+    };
+    // J_f(stage)^T FB for the stage whose activations are in act[] / zo and whose state is in S0:
+    // result added to YB; returns the buffer holding dL/dH0 (ldw stride) for the caller's combinations
+    auto vjp = [&](const float* FB) -> const float* {
+        for_elems([&](int r, int j, int) {
+            const float z = zo[r * ldw + j], v = FB[r * ldf + j];
+            float ty = 1.0f, zt = z;
+            if (geo) { ty = tanhf(S0[r * ldy + j]); zt = z * ty; }
+            const float f = tanhf(zt);
+            const float dzt = v * (1.0f - f * f);
+            zo[r * ldw + j] = geo ? dzt * ty : dzt;
+            cat[r * ldw + j] = geo ? dzt * z * (1.0f - ty * ty) : 0.0f;     // direct y term of the tanh(y) gate
+        });
+        float* cur = zo;
+        float* oth = dl;
+        dense_T(a.params + net.out.src_w, net.out.K, 0, net.out.K, net.out.N, cur, ldw, oth, ldw);
+        __syncthreads();
+        for (int l = net.n_hid; l >= 0; --l) {
+            const float* zl = act + (size_t)l * GR * ldw;
+            const int width = (l == 0 && io != 0) ? net.in.N : (l == 0 ? H : net.hid[l - 1].N);
+            for (int i = tid; i < GR * width; i += GT) {
+                const int r = i / width, j = i - r * width;
+                if (!(zl[r * ldw + j] > 0.0f)) oth[r * ldw + j] = 0.0f;
+            }
+            __syncthreads();
+            float* t = cur; cur = oth; oth = t;
+            if (l > 0) {
+                dense_T(a.params + net.hid[l - 1].src_w, net.hid[l - 1].K, 0, net.hid[l - 1].K, net.hid[l - 1].N, cur, ldw, oth, ldw);
+                __syncthreads();
+            }
+        }
+        float* dst = oth;
+        if (io != 0) {
+            const float* din = cur;
+            if (uses_emb) {
+                dense_T(a.params + net.emb.src_w, net.emb.K, 0, H, net.emb.N, cur, ldw, oth, ldw);
+                __syncthreads();
+                din = oth;
+            }
+            dst = (din == oth) ? cur : oth;
+            dense_T(a.params + net.in.src_w, net.in.K, net.in.tshift, H, net.in.N, din, ldw, dst, ldw);
+            __syncthreads();
+            for_elems([&](int r, int j, int) { dst[r * ldw + j] += cat[r * ldw + j]; });
+        } else {
+            for_elems([&](int r, int j, int) { dst[r * ldw + j] = cat[r * ldw + j]; });
+        }
+        return dst;
+    };
+
+    for (int n = d.N - 1; n >= 0; --n) {
+        const float* st = a.step_tab + (size_t)n * SNSDE_STEP_STRIDE;
+        const float h = st[1], rdt = st[6];
+        const int nout = __float_as_int(st[8]), kfirst = __float_as_int(st[9]);
+        const float* tp0 = aa.srk_tab + (size_t)n * 4 * SNSDE_SRK_STRIDE;
+        const float* tpq = tp0 + SNSDE_SRK_STRIDE;
+        const float* tph = tp0 + 2 * SNSDE_SRK_STRIDE;
+        const float* tp1 = tp0 + 3 * SNSDE_SRK_STRIDE;
+        // adjoint of y_{n+1} (+ output gradients), saved state and increments of the step
+        for_elems([&](int r, int j, int row) {
+            float av = AV[r * ldf + j], carry = 0.0f, y = 0.0f, dw = 0.0f, du = 0.0f;
+            if (row < B) {
+                for (int k = kfirst; k < kfirst + nout; ++k) {
+                    const float w0 = a.out_w[2 * k], w1 = a.out_w[2 * k + 1];
+                    const float gk = a.row_out ? (a.row_out[row] == k + 1 ? aa.grad_ys[(size_t)row * H + j] : 0.0f)
+                                               : aa.grad_ys[(size_t)(k + 1) * BH + (size_t)row * H + j];
+                    if (w0 == 0.0f) av += gk; else { av = fmaf(w1, gk, av); carry = fmaf(w0, gk, carry); }
+                }
+                const size_t off = (size_t)n * BH + (size_t)row * H + j;
+                aa.adj[off + BH] = av;
+                y = aa.traj[off]; dw = aa.dW_used[off]; du = aa.dU_used[off];
+            }
+            AV[r * ldf + j] = av;
+            YB[r * ldf + j] = carry + av;
+            Y[r * ldy + j] = y; S0[r * ldy + j] = y;
+            DW[r * ldf + j] = dw; DU[r * ldf + j] = du;
+        });
+        // ---- forward stages ----
+        fwd_chain(tp0);
+        f_value(F0);
+        for_elems([&](int r, int j, int) {
+            const float y = Y[r * ldy + j];
+            float g1;
+            const float g0 = g_and_prime(y, tp0[0], n, 0, j, g1);
+            G0[r * ldf + j] = g0;
+            S0[r * ldy + j] = y + F0[r * ldf + j] * h;                                   // H0_1
+        });
+        fwd_chain(tp1);
+        f_value(F1);
+        for_elems([&](int r, int j, int) {
+            const float y = Y[r * ldy + j], f0 = F0[r * ldf + j], f1 = F1[r * ldf + j], g0 = G0[r * ldf + j];
+            const float du = DU[r * ldf + j];
+            float g1p;
+            const float g1 = g_and_prime(y + 0.25f * f0 * h + 0.5f * g0 * rdt, tpq[0], n, 1, j, g1p);   // at H1_1
+            G1[r * ldf + j] = g1;
+            S0[r * ldy + j] = y + 0.25f * f0 * h + 0.25f * f1 * h + g0 * du / h + 0.5f * g1 * du / h;  // H0_2
+        });
+        fwd_chain(tph);        // activations of this evaluation feed the first VJP below
+        f_value(F2);
+        // ---- backward: stage 3 and the diffusion half of stage 2 (elementwise) ----
+        for_elems([&](int r, int j, int) {
+            const float y = Y[r * ldy + j], av = AV[r * ldf + j];
+            const float f0 = F0[r * ldf + j], f2 = F2[r * ldf + j], g0 = G0[r * ldf + j], g1 = G1[r * ldf + j];
+            const float ik = DW[r * ldf + j], ik0 = DU[r * ldf + j];
+            float gp;
+            const float h12 = y + f0 * h - g0 * rdt;
+            const float g2 = g_and_prime(h12, tp1[0], n, 3, j, gp);
+            const float g2p = gp;
+            const float ikk = 0.5f * (ik * ik - h);
+            const float ikkk = (ik * ik * ik - 3.0f * h * ik) / 6.0f;
+            const float a1 = ik, a2 = ikk / rdt, a3 = ik0 / h, a4 = ikkk / h;
+            const float w0 = -a1 - a2 + 2.0f * a3 - 2.0f * a4;
+            const float w1 = (4.0f / 3.0f) * a1 + (4.0f / 3.0f) * a2 - (4.0f / 3.0f) * a3 + (5.0f / 3.0f) * a4;
+            const float w2 = (2.0f / 3.0f) * a1 - (1.0f / 3.0f) * a2 - (2.0f / 3.0f) * a3 - (2.0f / 3.0f) * a4;
+            const float w3 = a4;
+            float fb0 = av * (h / 6.0f), fb1 = fb0, fb2 = av * (2.0f * h / 3.0f);
+            float gb0 = w0 * av, gb1 = w1 * av, gb2 = w2 * av, yb = YB[r * ldf + j];
+            // stage 3: H1_3 = y + f2 h/4 + (-5 g0 + 3 g1 + g2/2) sqrt(h), evaluated at t0 + h/4
+            const float h13 = y + 0.25f * f2 * h + (-5.0f * g0 + 3.0f * g1 + 0.5f * g2) * rdt;
+            g_and_prime(h13, tpq[0], n, 1, j, gp);
+            float hb = w3 * av * gp;
+            yb += hb; fb2 = fmaf(0.25f * h, hb, fb2);
+            gb0 = fmaf(-5.0f * rdt, hb, gb0); gb1 = fmaf(3.0f * rdt, hb, gb1); gb2 = fmaf(0.5f * rdt, hb, gb2);
+            // stage 2, diffusion half: H1_2 = y + f0 h - g0 sqrt(h)
+            hb = gb2 * g2p;
+            yb += hb; fb0 = fmaf(h, hb, fb0); gb0 = fmaf(-rdt, hb, gb0);
+            FB0[r * ldf + j] = fb0; FB1[r * ldf + j] = fb1; FB2[r * ldf + j] = fb2;
+            GB0[r * ldf + j] = gb0; GB1[r * ldf + j] = gb1; GB2[r * ldf + j] = gb2;
+            G2[r * ldf + j] = g2;
+            YB[r * ldf + j] = yb;
+        });
+        // stage 2, drift half: H0_2 = y + (f0 + f1) h/4 + (g0 + g1/2) I_k0/h
+        {
+            const float* dH = vjp(FB2);
+            for_elems([&](int r, int j, int) {
+                const float dv = dH[r * ldw + j], du = DU[r * ldf + j];
+                YB[r * ldf + j] += dv;
+                FB0[r * ldf + j] = fmaf(0.25f * h, dv, FB0[r * ldf + j]);
+                FB1[r * ldf + j] = fmaf(0.25f * h, dv, FB1[r * ldf + j]);
+                GB0[r * ldf + j] = fmaf(du / h, dv, GB0[r * ldf + j]);
+                GB1[r * ldf + j] = fmaf(0.5f * du / h, dv, GB1[r * ldf + j]);
+            });
+        }
+        // stage 1: H1_1 = y + f0 h/4 + g0 sqrt(h)/2 (diffusion at t0 + h/4), H0_1 = y + f0 h (drift at t0 + h)
+        for_elems([&](int r, int j, int) {
+            const float y = Y[r * ldy + j], f0 = F0[r * ldf + j], g0 = G0[r * ldf + j];
+            float gp;
+            g_and_prime(y + 0.25f * f0 * h + 0.5f * g0 * rdt, tpq[0], n, 1, j, gp);
+            const float hb = GB1[r * ldf + j] * gp;
+            YB[r * ldf + j] += hb;
+            FB0[r * ldf + j] = fmaf(0.25f * h, hb, FB0[r * ldf + j]);
+            GB0[r * ldf + j] = fmaf(0.5f * rdt, hb, GB0[r * ldf + j]);
+            S0[r * ldy + j] = y + f0 * h;
+        });
+        fwd_chain(tp1);
+        {
+            const float* dH = vjp(FB1);
+            for_elems([&](int r, int j, int) {
+                const float dv = dH[r * ldw + j];
+                YB[r * ldf + j] += dv;
+                FB0[r * ldf + j] = fmaf(h, dv, FB0[r * ldf + j]);
+            });
+        }
+        // stage 0: both evaluated at (t0, y)
+        for_elems([&](int r, int j, int) {
+            const float y = Y[r * ldy + j];
+            float gp;
+            g_and_prime(y, tp0[0], n, 0, j, gp);
+            YB[r * ldf + j] = fmaf(GB0[r * ldf + j], gp, YB[r * ldf + j]);
+            S0[r * ldy + j] = y;
+        });
+        fwd_chain(tp0);
+        {
+            const float* dH = vjp(FB0);
+            for_elems([&](int r, int j, int) { AV[r * ldf + j] = YB[r * ldf + j] + dH[r * ldw + j]; });
+        }
+    }
+    for (int i = tid; i < GR * H; i += GT) {      // ys[0] = y0
+        const int r = i / H, j = i - r * H, row = row0 + r;
+        if (row < B) aa.adj[(size_t)row * H + j] = AV[r * ldf + j] +
+            ((!a.row_out || a.row_out[row] == 0) ? aa.grad_ys[(size_t)row * H + j] : 0.0f);
+    }
+}
+
 __global__ void snsde_spline_kernel(const float* __restrict__ coeffs, int B, int L, int C, int index, float frac,
                                     int derivative, float* __restrict__ out) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -823,8 +1133,15 @@ int snsde_generic_launch(const snsde_solve* s, const SnsdeNet& net, hipStream_t 
 
 bool snsde_generic_backward_supported(const snsde_solve* s) {
     const int no = s->model.noise_option;
-    if (s->method != SNSDE_EULER && s->method != SNSDE_MILSTEIN) return false;
     if (no == 14 || no == 15 || no == 18 || no == 19) return false;        // dense diffusion Jacobian: not yet
+    if (s->method == SNSDE_SRK) {     // SRK adjoint: bounded by its LDS planes
+        const int H = s->model.hidden_channels, HH = s->model.hidden_hidden_channels;
+        const int wmax = 2 * H > HH ? 2 * H : HH;
+        const size_t fl = (size_t)GR * (2 * round4(H + 2) + round4(s->model.input_channels) +
+                                        (3 + s->model.num_hidden_layers) * (round4(wmax) + 4) + 16 * round4(H));
+        return fl * sizeof(float) <= 160 * 1024;
+    }
+    if (s->method != SNSDE_EULER && s->method != SNSDE_MILSTEIN) return false;
     if (s->method == SNSDE_MILSTEIN && no == 7) return false;
     return true;
 }
@@ -847,6 +1164,21 @@ int snsde_generic_backward_launch(const snsde_backward* b, const SnsdeNet& net, 
     const int wmax = 2 * H > HH ? 2 * H : HH;
     a.ldw = round4(wmax) + 4;
     a.ldx = round4(m.input_channels);
+    if (s->method == SNSDE_SRK) {
+        if (!s->dU_out || !s->srk_tab) return SNSDE_ERR_NULL;
+        SrkAdjArgs sa;
+        sa.g = a;
+        sa.srk_tab = s->srk_tab; sa.traj = s->traj; sa.dW_used = s->dW_out; sa.dU_used = s->dU_out;
+        sa.grad_ys = b->grad_ys; sa.adj = b->adj; sa.ldf = round4(H);
+        const size_t bytes = (size_t)GR * (2 * a.ldy + a.ldx + (3 + net.n_hid + 1) * a.ldw + 16 * sa.ldf) * sizeof(float);
+        if (bytes > 160 * 1024) return SNSDE_ERR_LDS;
+        if (bytes > 64 * 1024 &&
+            hipFuncSetAttribute(reinterpret_cast<const void*>(snsde_generic_srk_adjoint_kernel),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes) != hipSuccess)
+            return SNSDE_ERR_LDS;
+        hipLaunchKernelGGL(snsde_generic_srk_adjoint_kernel, dim3((s->batch + GR - 1) / GR), dim3(GT), bytes, stream, sa);
+        return hipGetLastError() == hipSuccess ? SNSDE_OK : SNSDE_ERR_LAUNCH;
+    }
     aa.traj = s->traj; aa.dW_used = s->dW_out; aa.grad_ys = b->grad_ys; aa.adj = b->adj; aa.nbuf = net.n_hid + 1;
     const size_t lds_bytes = (size_t)GR * (3 * a.ldy + a.ldx + (3 + net.n_hid + 1) * a.ldw) * sizeof(float);
     if (lds_bytes > 160 * 1024) return SNSDE_ERR_LDS;

@@ -161,11 +161,8 @@ def _sdeint_hip(sde, rec, y0, ts, bm, method, dt, options):
     if row_out is not None:     # per-row output selection fused into the solve: the result is (B, H)
         row_out = row_out.to(device=dev, dtype=torch.int32).contiguous()
         options = dict(options, row_out=row_out)
-    if needs_grad and method == 'srk':
-        raise NotImplementedError("gradients through the fused SRK solve are not implemented; use method='euler' "
-                                  "or options={'backend': 'torch'}")
     if needs_grad:
-        return _FusedSolve.apply(sde, rec, coeffs, grid, times_host, dW, method, seed, options, y0,
+        return _FusedSolve.apply(sde, rec, coeffs, grid, times_host, (dW, dU), method, seed, options, y0,
                                       *[p for _, p in sde.named_parameters()])
     flat = engine.flatten_params(sde, layout, numel, dev)
     call = engine.SolveCall(model, flat, coeffs, grid, y0c, dW=dW, method=method, seed=seed,
@@ -186,8 +183,9 @@ class _FusedSolve(torch.autograd.Function):
     ~25 x N nodes of the unrolled loop (benchmark_classification/common_sde.py:158-160)."""
 
     @staticmethod
-    def forward(ctx, sde, rec, coeffs, grid, times_host, dW, method, seed, options, y0, *params):
+    def forward(ctx, sde, rec, coeffs, grid, times_host, increments, method, seed, options, y0, *params):
         model, layout, numel = rec
+        dW, dU = increments
         flat = engine.flatten_params(sde, layout, numel, y0.device)
         y0c = y0.detach().to(torch.float32).contiguous()
 
@@ -195,14 +193,14 @@ class _FusedSolve(torch.autograd.Function):
             return engine.SolveCall(model, flat, coeffs, grid, y0c, dW=dW, method=method, seed=seed,
                                     row_offset=int(options.get('row_offset', 0)), kernel=kernel, save_traj=True,
                                     save_dW=True, save_act=save_act, exact_order=bool(options.get('exact_order', False)),
-                                    row_out=options.get('row_out'))
+                                    row_out=options.get('row_out'), dU=dU)
         mode = engine.backward_mode(model, y0c.shape[0], coeffs.shape[1] + 1, grid, method, options.get('kernel', 'auto'),
                                     bool(options.get('exact_order', False)))
         if mode == 0:
             raise NotImplementedError(
-                "the fused backward covers method 'euler'/'milstein' with a diffusion that is elementwise in y "
-                "(noise_option 0..13, 16, 17); pass options={'backend': 'torch'} to differentiate this configuration "
-                "through the tensor-op loop")
+                "the fused backward covers 'euler'/'milstein'/'srk' with a diffusion that is elementwise in y "
+                "(noise_option 0..13, 16, 17) and 'euler' with the diffusion nets on input_option 1/3; pass "
+                "options={'backend': 'torch'} to differentiate this configuration through the tensor-op loop")
         call = make(options.get('kernel', 'auto'), True) if mode == 1 else make('generic', False)
         ctx.mode, ctx.method = mode, method
         ctx.param_pass = options.get('param_pass', 'hip')
@@ -363,6 +361,14 @@ def _parameter_gradients(sde, call, grid, adj, max_rows=1 << 19, method='euler')
                 fr = frac[lo:hi].view(n, 1, 1)
                 a_, b_, c2, d3 = (rows[..., k * Cn:(k + 1) * Cn] for k in range(4))
                 Xraw = (a_ + (b_ + (0.5 * c2 + d3 * fr / 3) * fr) * fr).reshape(n * B, Cn)
+            if method == 'srk':
+                surrogate = (A * _srk_rows(P, io, no, grid, lo, hi, B, Y, DW, call.dU_out[lo:hi].reshape(n * B, H), coeffs,
+                                           hcol)).sum()
+                gs = torch.autograd.grad(surrogate, params, allow_unused=True)
+                for acc, gpart in zip(total, gs):
+                    if gpart is not None:
+                        acc.add_(gpart)
+                continue
             f = modules.drift_rows(P, io, tau, Y, Xraw)
             if method == 'milstein':   # + 1/2 g dg/dy (dW^2 - h); g is elementwise in y for the supported options
                 Yg = Y.detach().requires_grad_(True)
@@ -377,6 +383,58 @@ def _parameter_gradients(sde, call, grid, adj, max_rows=1 << 19, method='euler')
                 if gpart is not None:
                     acc.add_(gpart)
     return total
+
+
+def _srk_rows(P, io, no, grid, lo, hi, B, Y, I_k, I_k0, coeffs, hcol):
+    """One SRID2 step of every (step, row) pair of steps lo..hi-1 as a differentiable function of the parameters
+    (states, increments constant): the stage times / spline intervals come from the solver's stage table."""
+    from . import modules
+    tab = engine.srk_table(grid)[lo:hi]   # (n, 4, stride): t, sin t, cos t, frac, interval index
+    n = hi - lo
+    Cn = coeffs.shape[-1] // 4
+    uses_x = io in (0, 2, 4, 6)
+
+    def at(slot):
+        t = tab[:, slot, 0].repeat_interleave(B).unsqueeze(-1)
+        tau = torch.stack([tab[:, slot, 1], tab[:, slot, 2]], dim=-1).repeat_interleave(B, dim=0)
+        Xraw = None
+        if uses_x:
+            idx = tab[:, slot, 4].contiguous().view(torch.int32).to(torch.int64)
+            fr = tab[:, slot, 3].view(n, 1, 1)
+            rows = coeffs[:, idx, :].permute(1, 0, 2)
+            a_, b_, c2, d3 = (rows[..., k * Cn:(k + 1) * Cn] for k in range(4))
+            Xraw = (a_ + (b_ + (0.5 * c2 + d3 * fr / 3) * fr) * fr).reshape(n * B, Cn)
+        return t, tau, Xraw
+
+    slots_f = (0, 3, 2, 0)      # C0 = 0, 1, 1/2, 0  -> stage-table slots (0, 1/4, 1/2, 1)
+    slots_g = (0, 1, 3, 1)      # C1 = 0, 1/4, 1, 1/4
+
+    def f(stage, y):
+        t, tau, Xraw = at(slots_f[stage])
+        return modules.drift_rows(P, io, tau, y, Xraw)
+
+    def g(stage, y):
+        t, tau, _ = at(slots_g[stage])
+        return modules.diffusion_rows(P, no, t, tau, y)
+
+    T = _SRK
+    h = hcol
+    rdt = h.sqrt()
+    I_kk = (I_k * I_k - h) / 2
+    I_kkk = (I_k ** 3 - 3 * h * I_k) / 6
+    fs, gs = [], []
+    y1 = Y
+    for s in range(4):
+        H0, H1 = Y, Y
+        for j in range(s):
+            H0 = H0 + T['A0'][s][j] * fs[j] * h + T['B0'][s][j] * gs[j] * I_k0 / h
+            H1 = H1 + T['A1'][s][j] * fs[j] * h + T['B1'][s][j] * gs[j] * rdt
+        fs.append(f(s, H0) if T['alpha'][s] != 0.0 or any(T['A0'][k][s] != 0.0 or T['A1'][k][s] != 0.0 for k in range(s + 1, 4))
+                  else torch.zeros_like(Y))
+        gs.append(g(s, H1))
+        gw = T['beta1'][s] * I_k + T['beta2'][s] * I_kk / rdt + T['beta3'][s] * I_k0 / h + T['beta4'][s] * I_kkk / h
+        y1 = y1 + T['alpha'][s] * fs[s] * h + gw * gs[s]
+    return y1
 
 
 def _call(sde, names, key, default):

@@ -224,13 +224,14 @@ def test_batch_shards_reproduce_the_global_solve_bitwise():
 
 # ---- drop-in API ------------------------------------------------------------------------------------
 class _ReplayBM:
-    def __init__(self, dW):
-        self.dW, self.n = dW, 0
+    def __init__(self, dW, dU=None):
+        self.dW, self.dU, self.n = dW, dU, 0
 
-    def __call__(self, ta, tb):
+    def __call__(self, ta, tb, return_U=False):
         out = self.dW[self.n]
+        u = self.dU[self.n] if self.dU is not None else None
         self.n += 1
-        return out
+        return (out, u) if return_U else out
 
 
 def test_sdeint_drop_in_on_cuda_dispatches_to_hip():
@@ -513,6 +514,12 @@ GEN_BWD_CASES = [
     (5, 11, 2, 9, 12, 3, 8, [0, 7], 0.5, 'milstein'),
     (3, 3, 2, 9, 12, 3, 8, [0, 7], 0.5, 'euler'),
     (1, 10, 2, 9, 12, 3, 8, [0, 7], 0.5, 'euler'),
+    (4, 17, 2, 11, 24, 5, 9, [0, 3.5, 8], 1.0, 'srk'),       # SRID2 adjoint (torch_ists default method)
+    (6, 17, 3, 9, 40, 3, 9, [0, 8], 0.5, 'srk'),
+    (2, 16, 1, 9, 20, 2, 12, None, 0.05, 'srk'),
+    (1, 8, 2, 9, 12, 3, 8, [0, 2.5, 7], 0.5, 'srk'),
+    (3, 13, 2, 10, 64, 3, 8, [0, 7], 1.0, 'srk'),
+    (0, 6, 2, 9, 12, 3, 8, [0, 7], 1.0, 'srk'),
 ]
 
 
@@ -540,6 +547,12 @@ def _check_backward(seed, io, no, NL, B, H, C, L, ts, dt, method, kernel):
     dW = draw_dW(seed, ts, dt, B, H)
     ci = seed
     wsum = np.random.default_rng(ci).standard_normal((len(ts), B, H)).astype(np.float32)
+    dU = None
+    if method == 'srk':      # space-time Levy integrals consistent in scale with the increments
+        g0, g1 = O.step_grid(ts, dt)[:2]
+        hh = (g1 - g0).astype(np.float32).reshape(-1, 1, 1)
+        xi = np.random.default_rng(ci + 1).standard_normal(dW.shape).astype(np.float32)
+        dU = (hh * (0.5 * dW + np.sqrt(hh / 12) * xi)).astype(np.float32)
 
     def build(dtype, device):
         m = S.Diffusion_model(C, H, H, NL, input_option=io, noise_option=no)
@@ -550,13 +563,15 @@ def _check_backward(seed, io, no, NL, B, H, C, L, ts, dt, method, kernel):
         return m, y0
 
     m_ref, y0_ref = build(torch.float64, 'cpu')
-    ys_ref = S.sdeint(m_ref, y0_ref, torch.from_numpy(ts), bm=_ReplayBM(torch.from_numpy(dW).double()), method=method,
-                      dt=dt, options={'backend': 'torch'})
+    ys_ref = S.sdeint(m_ref, y0_ref, torch.from_numpy(ts),
+                      bm=_ReplayBM(torch.from_numpy(dW).double(), None if dU is None else torch.from_numpy(dU).double()),
+                      method=method, dt=dt, options={'backend': 'torch'})
     (ys_ref * torch.from_numpy(wsum).double()).sum().backward()
 
     m, y0 = build(torch.float32, DEV)
-    ys = S.sdeint(m, y0, torch.from_numpy(ts).to(DEV), bm=_ReplayBM(torch.from_numpy(dW).to(DEV)), method=method, dt=dt,
-                  options={'kernel': kernel})
+    ys = S.sdeint(m, y0, torch.from_numpy(ts).to(DEV),
+                  bm=_ReplayBM(torch.from_numpy(dW).to(DEV), None if dU is None else torch.from_numpy(dU).to(DEV)),
+                  method=method, dt=dt, options={'kernel': kernel})
     (ys * torch.from_numpy(wsum).to(DEV)).sum().backward()
 
     def close(got, ref, name):
@@ -613,7 +628,7 @@ def test_backward_unsupported_configurations_raise():
     y0 = torch.from_numpy(pr['y0']).to(DEV).requires_grad_(True)
     with pytest.raises(NotImplementedError):
         S.sdeint(m, y0, torch.tensor([0., 4.], device=DEV), method='euler', dt=1.0)
-    m2 = S.Diffusion_model(3, 64, 64, 2, input_option=4, noise_option=17).to(DEV)
+    m2 = S.Diffusion_model(3, 64, 64, 2, input_option=1, noise_option=14).to(DEV)     # SRK through a diffusion net
     m2.set_X(torch.from_numpy(pr['coeffs']).to(DEV), torch.from_numpy(pr['times']).to(DEV))
     with pytest.raises(NotImplementedError):
         S.sdeint(m2, y0, torch.tensor([0., 4.], device=DEV), method='srk', dt=1.0)
@@ -730,6 +745,29 @@ def test_training_step_recorded_into_a_graph_draws_fresh_noise_and_matches_eager
     assert losses == eager
     for (n1, p1), (n2, p2) in zip(mg.named_parameters(), me.named_parameters()):
         assert torch.equal(p1, p2), n1
+
+
+def test_ists_neuralsde_trains_with_its_default_srk_method_on_the_fused_path():
+    """torch_ists flavour (nsde_model.py:63-84): forward(coeffs, times) with the default method 'srk'; loss.backward()
+    runs the fused SRK forward + SRK adjoint kernel + batched parameter pass (no tensor-op loop)."""
+    B, H, C, L = 24, 32, 4, 9
+    pr = make_problem(29, 4, 17, 2, B, H, C, L)
+    torch.manual_seed(2)
+    field = S.Diffusion_model(C, H, H, 2, input_option=4, noise_option=17)
+    model = S.IstsNeuralSDE(field, C, H, 3).to(DEV).train()
+    opt = torch.optim.Adam(model.parameters(), lr=1e-3)
+    times = torch.from_numpy(pr['times']).to(DEV)
+    coeffs = torch.from_numpy(pr['coeffs']).to(DEV)
+    target = torch.randn(B, L, 3, device=DEV)
+    before = field.linear_out.weight.detach().clone()
+    for _ in range(2):
+        out, z = model(coeffs, times, options={'seed': 3})
+        assert out.shape == (B, L, 3) and z.shape == (B, L, H)
+        loss = (out - target).square().mean()
+        opt.zero_grad(); loss.backward(); opt.step()
+    assert np.isfinite(float(loss.detach()))
+    assert all(p.grad is not None and torch.isfinite(p.grad).all() for p in field.parameters() if p.requires_grad)
+    assert not torch.equal(before, field.linear_out.weight.detach())
 
 
 def test_neuralsde_training_step_on_cuda():
