@@ -395,12 +395,12 @@ def _srk_rows(P, io, no, grid, lo, hi, B, Y, I_k, I_k0, coeffs, hcol):
     uses_x = io in (0, 2, 4, 6)
 
     def at(slot):
-        t = tab[:, slot, 0].repeat_interleave(B).unsqueeze(-1)
-        tau = torch.stack([tab[:, slot, 1], tab[:, slot, 2]], dim=-1).repeat_interleave(B, dim=0)
+        t = tab[:, slot, 0].to(Y.dtype).repeat_interleave(B).unsqueeze(-1)
+        tau = torch.stack([tab[:, slot, 1], tab[:, slot, 2]], dim=-1).to(Y.dtype).repeat_interleave(B, dim=0)
         Xraw = None
         if uses_x:
             idx = tab[:, slot, 4].contiguous().view(torch.int32).to(torch.int64)
-            fr = tab[:, slot, 3].view(n, 1, 1)
+            fr = tab[:, slot, 3].to(Y.dtype).view(n, 1, 1)
             rows = coeffs[:, idx, :].permute(1, 0, 2)
             a_, b_, c2, d3 = (rows[..., k * Cn:(k + 1) * Cn] for k in range(4))
             Xraw = (a_ + (b_ + (0.5 * c2 + d3 * fr / 3) * fr) * fr).reshape(n * B, Cn)

@@ -353,3 +353,96 @@ def test_sdeint_srk_tensor_loop_vs_oracle(io, no):
     ref, _ = O.solve_diffusion_model(pr['params'], io, no, pr['coeffs'], pr['times'], pr['y0'], ts, dt, dW, method='srk',
                                      dtype=np.float64, dU=dU)
     np.testing.assert_allclose(ys.numpy(), ref, rtol=2e-4, atol=2e-5)
+
+
+# ---- host logic added with the fused training path -------------------------------------------------------
+def _small_model(io=4, no=17, B=6, H=8, C_=3, L=7, seed=0):
+    torch.manual_seed(seed)
+    m = S.Diffusion_model(C_, H, H, 2, input_option=io, noise_option=no)
+    times = torch.arange(L, dtype=torch.float32)
+    m.set_X(torch.randn(B, L - 1, 4 * C_) * 0.1, times)
+    return m, times, torch.randn(B, H)
+
+
+def test_row_out_option_of_the_tensor_loop_equals_gather():
+    """options['row_out'] has the same contract on every backend: (B, H), row b = the state at ts[row_out[b]]."""
+    m, times, y0 = _small_model()
+    ts = torch.tensor([0., 1.5, 3., 6.])
+    slot = torch.tensor([0, 3, 1, 2, 3, 1])
+    dW = torch.randn(6, 6, 8)
+    with torch.no_grad():
+        full = S.sdeint(m, y0, ts, bm=_ReplayBM(dW), method='euler', dt=1.0)
+        sel = S.sdeint(m, y0, ts, bm=_ReplayBM(dW), method='euler', dt=1.0, options={'row_out': slot})
+    assert sel.shape == (6, 8)
+    assert torch.equal(sel, full.gather(0, slot.reshape(1, -1, 1).expand(1, 6, 8)).squeeze(0))
+
+
+def test_neuralsde_forward_on_cpu_keeps_the_reference_output_time_selection():
+    """CPU tensors take the reference's unique(final_index) route (neuralsde.py:91-116), CUDA tensors the fused
+    row_out route; both must return the same rows (checked on GPU in test_gpu_parity)."""
+    torch.manual_seed(1)
+    model, field = S.make_sde_model('neurallnsde', 3, 2, 8, 8, 2, initial=True)
+    model.eval()
+    times = torch.arange(7, dtype=torch.float32)
+    coeffs = torch.randn(5, 6, 12) * 0.1
+    fi = torch.tensor([6, 2, 2, 0, 4])
+    ts, slot = model.output_times(times, fi)
+    assert ts.tolist() == [0.0, 2.0, 4.0, 6.0] and slot.tolist() == [3, 1, 1, 0, 2]
+    with torch.no_grad():
+        out = model(times, [coeffs], fi, options={'seed': 3})
+    assert out.shape == (5, 2) and torch.isfinite(out).all()
+
+
+def test_flatten_params_arena_tracks_in_place_updates_and_reallocation():
+    from stable_neural_sdes_amd import engine
+    m, _, _ = _small_model()
+    model, layout, numel = engine.recognise(m)
+    dev = torch.device('cpu')
+    flat = engine.flatten_params(m, layout, numel, dev)
+    assert flat.numel() == numel
+    assert engine.flatten_params(m, layout, numel, dev) is flat          # no new buffer
+    with torch.no_grad():
+        m.linear_out.weight.add_(1.0)                                     # optimizer-style in-place step
+    off = {n: o for n, o, _ in layout}['linear_out.weight']
+    assert torch.equal(flat[off:off + m.linear_out.weight.numel()].view_as(m.linear_out.weight), m.linear_out.weight)
+    sd = {k: v.clone() for k, v in m.state_dict().items()}
+    m.linear_out.weight = torch.nn.Parameter(torch.zeros_like(m.linear_out.weight))   # re-allocated parameter
+    flat2 = engine.flatten_params(m, layout, numel, dev)
+    assert flat2 is not flat and float(flat2[off:off + 4].abs().sum()) == 0.0
+    m.load_state_dict(sd)                                                 # copy_ into the (new) arena
+    assert torch.equal(engine.flatten_params(m, layout, numel, dev)[off:off + 4], sd['linear_out.weight'].reshape(-1)[:4])
+
+
+def test_host_time_cache_scalar_lookup():
+    from stable_neural_sdes_amd.controldiffeq import _HostTimes
+    t = torch.linspace(0, 1, 6)
+    assert _HostTimes.scalar(t[3]) == float(t[3]) and _HostTimes.scalar(0.25) == 0.25
+    assert np.array_equal(_HostTimes.get(t), t.numpy())
+
+
+def test_srk_rows_step_equals_the_loop_step():
+    """The batched SRID2 step used by the SRK parameter pass == the per-step scheme of the tensor-op loop."""
+    from stable_neural_sdes_amd import engine, torchsde as T
+    if not os.path.exists(_lib.LIB_PATH):
+        pytest.skip('libsnsde.so not built')
+    m, times, y0 = _small_model(io=4, no=17)
+    m = m.double()
+    m.set_X(m.coeffs.double(), times)
+    B, H = y0.shape
+    grid = engine.StepGrid(np.array([0., 6.], np.float32), 1.0, times.numpy(), None)
+    grid.device = torch.device('cpu')
+    tab = np.zeros((grid.N, 4, _lib.SNSDE_SRK_STRIDE), dtype=np.float32)
+    _lib.check(_lib.lib().snsde_grid_srk_build(grid.step_tab.ctypes.data, grid.N, grid._times32.ctypes.data,
+                                               grid._times32.shape[0], tab.ctypes.data), 'snsde_grid_srk_build')
+    grid._d_srk = torch.from_numpy(tab)
+    P = dict(m.named_parameters())
+    n = 2
+    Y = torch.randn(B, H, dtype=torch.float64)
+    I_k = torch.randn(B, H, dtype=torch.float64)
+    I_k0 = 0.5 * I_k + 0.1 * torch.randn(B, H, dtype=torch.float64)
+    h = torch.ones(B, 1, dtype=torch.float64)
+    with torch.no_grad():
+        got = T._srk_rows(P, 4, 17, grid, n, n + 1, B, Y, I_k, I_k0, m.coeffs, h)
+        want = T._srk_step(m.f, m.g, torch.tensor(float(grid.t0[n]), dtype=torch.float64), torch.tensor(1.0, dtype=torch.float64),
+                           Y, I_k, I_k0)
+    assert torch.allclose(got, want, rtol=1e-6, atol=1e-7)
