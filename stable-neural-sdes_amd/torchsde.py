@@ -373,7 +373,11 @@ def _parameter_gradients(sde, call, grid, adj, max_rows=1 << 19, method='euler')
             if method == 'milstein':   # + 1/2 g dg/dy (dW^2 - h); g is elementwise in y for the supported options
                 Yg = Y.detach().requires_grad_(True)
                 g = modules.diffusion_rows(P, no, col, tau, Yg)
-                dg, = torch.autograd.grad(g.sum(), Yg, create_graph=True)
+                if g.requires_grad and g.grad_fn is not None:
+                    dg, = torch.autograd.grad(g.sum(), Yg, create_graph=True, allow_unused=True)
+                else:
+                    dg = None
+                dg = torch.zeros_like(Yg) if dg is None else dg       # diffusion independent of y: no Milstein term
                 surrogate = (A * (f * hcol + g * DW + 0.5 * g * dg * (DW * DW - hcol))).sum()
             else:
                 g = modules.diffusion_rows(P, no, col, tau, Y)

@@ -539,6 +539,25 @@ def test_backward_matches_fp64_autograd_through_the_unrolled_loop(ci, kernel):
     _check_backward(500 + ci, io, no, NL, B, H, C, L, ts, dt, method, kernel)
 
 
+@pytest.mark.parametrize('io', [1, 2, 3, 4, 5, 6])
+@pytest.mark.parametrize('no', [0, 12, 13, 16, 17])
+def test_backward_sweep_mfma_options(io, no):
+    """Every (input_option, elementwise noise_option) pair of the MFMA path: adjoint kernel + native parameter pass vs
+    float64 autograd, alternating depth, flavour and method."""
+    k = io * 7 + no
+    _check_backward(2000 + k, io, no, 1 + k % 3, 9, 16 if k % 2 else 32, 3, 7, [0, 2.5, 6], 1.0,
+                    'milstein' if k % 3 == 0 else 'euler', 'mfma16' if k % 4 == 0 else 'mfma4')
+
+
+@pytest.mark.parametrize('io', [0, 1, 2, 3, 4, 5, 6])
+@pytest.mark.parametrize('no', [0, 1, 2, 3, 4, 5, 6, 8, 9, 10, 11, 12, 13, 16, 17])
+def test_backward_sweep_generic_options(io, no):
+    """Every input_option x elementwise noise_option on the generic adjoint kernels (Euler / Milstein / SRK in turn)."""
+    k = io * 5 + no
+    method = ('euler', 'milstein', 'srk')[k % 3]
+    _check_backward(3000 + k, io, no, 1 + k % 2, 7, 12, 3, 6, [0, 5], 1.0 if k % 2 else 0.5, method, 'generic')
+
+
 def _check_backward(seed, io, no, NL, B, H, C, L, ts, dt, method, kernel):
     times = np.linspace(0, 1, L).astype(np.float32) if ts is None else None
     pr = make_problem(seed, io, no, NL, B, H, C, L, times=times)
