@@ -132,8 +132,14 @@ MfmaPlan make_plan(const snsde_solve* s, const SnsdeNet& net, int flavor_hint) {
     p.KUX = emb ? 2 : 1;
     p.TPW = 1;
     p.NW = H / (16 * p.TPW);
-    // flavour: M4 fills the chip when the batch is small (256 CUs); M16 has 4x less overhead per row
-    p.FL = flavor_hint >= 0 ? flavor_hint : ((s->batch + 15) / 16 >= 256 ? 0 : 1);
+    // flavour: a solve costs (rounds of resident workgroups) x (steps) x (step latency); an M16 step takes ~2.2x an
+    // M4 step (measured at H=128: 4.9 vs 2.2 us) but carries 4x the rows, so M16 wins as soon as M4 needs more than
+    // two rounds per M16 round.  Narrow models (H <= 64: 4 or fewer waves per workgroup) co-reside on a CU.
+    {
+        const int slots = 256 * (p.NW <= 4 ? 8 / (p.NW < 2 ? 2 : p.NW) : 1);
+        const long r4 = ((s->batch + 3) / 4 + slots - 1) / slots, r16 = ((s->batch + 15) / 16 + slots - 1) / slots;
+        p.FL = flavor_hint >= 0 ? flavor_hint : (10 * r4 > 22 * r16 ? 0 : 1);
+    }
     p.FOLD = (emb && (nhid > 1 || !(s->flags & SNSDE_FLAG_EXACT_ORDER))) ? 1 : 0;   // exact order: NL <= 2 only
     int off = 0, n = 0, rows = 0;
     auto add = [&](const SnsdeLayer& L, int KU, int fold_col, bool bias) {

@@ -13,12 +13,12 @@ pr = make_problem(1234, IO, NO, NL, 1024, H, C, L, nan_frac=0.3)
 flat = torch.from_numpy(np.concatenate([pr['params'][n].reshape(-1) for n, _ in param_spec(IO, NO, NL, C, H)])).to(dev)
 model = S.engine.model_struct(C, H, H, NL, IO, NO)
 grid = S.engine.step_grid(np.array([0.0, 100.0], np.float32), 1.0, pr['times'], dev)
-for B in (256, 512, 1024, 2048, 4096, 16384, 65536):
+for B in (256, 512, 1024, 2048, 2304, 3072, 4096, 16384, 65536):
     reps = max(1, B // 1024)
     coeffs = torch.from_numpy(np.tile(pr['coeffs'], (reps, 1, 1))[:B]).to(dev) if B >= 1024 else torch.from_numpy(pr['coeffs'][:B]).to(dev)
     y0 = torch.from_numpy(np.tile(pr['y0'], (reps, 1))[:B]).to(dev) if B >= 1024 else torch.from_numpy(pr['y0'][:B]).to(dev)
     line = f'B={B:6d}'
-    for kern in ('mfma4', 'mfma16'):
+    for kern in ('mfma4', 'mfma16', 'auto'):
         call = S.engine.SolveCall(model, flat, coeffs, grid, y0, seed=1, kernel=kern)
         for _ in range(3): call.launch()
         ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(10)]
@@ -27,5 +27,5 @@ for B in (256, 512, 1024, 2048, 4096, 16384, 65536):
         torch.cuda.synchronize()
         ms = float(np.median([a.elapsed_time(b) for a, b in ev]))
         rs = B * 100 / (ms * 1e-3)
-        line += f'  {kern}: {ms:8.3f} ms {rs:10.3e} row-steps/s ({rs * 169728 / 157.3e12 * 100:5.1f}% fp32 roof)'
+        line += f'  {kern}: {ms:7.3f} ms {rs:9.3e} r-s/s ({rs * 169728 / 157.3e12 * 100:4.1f}%)'
     print(line)
