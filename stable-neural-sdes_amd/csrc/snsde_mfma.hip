@@ -127,9 +127,9 @@ MfmaPlan make_plan(const snsde_solve* s, const SnsdeNet& net, int flavor_hint) {
     const int nhid = m.num_hidden_layers - 1;
     if (nhid > 3) return p;
     p.NN = noise_net ? (no >= 18 ? 2 : 1) : 0;
-    if (emb && m.input_channels > 32) return p;
+    if (emb && m.input_channels > 80) return p;
     p.H = H; p.IO = io; p.NHID = nhid;
-    p.KUX = emb ? 2 : 1;
+    p.KUX = emb ? (m.input_channels > 32 ? 5 : 2) : 1;    // 16-wide k-blocks of the control channels (C <= 32 / <= 80)
     p.TPW = 1;
     p.NW = H / (16 * p.TPW);
     // flavour: a solve costs (rounds of resident workgroups) x (steps) x (step latency); an M16 step takes ~2.2x an
@@ -140,7 +140,7 @@ MfmaPlan make_plan(const snsde_solve* s, const SnsdeNet& net, int flavor_hint) {
         const long r4 = ((s->batch + 3) / 4 + slots - 1) / slots, r16 = ((s->batch + 15) / 16 + slots - 1) / slots;
         p.FL = flavor_hint >= 0 ? flavor_hint : (10 * r4 > 22 * r16 ? 0 : 1);
     }
-    p.FOLD = (emb && (nhid > 1 || !(s->flags & SNSDE_FLAG_EXACT_ORDER))) ? 1 : 0;   // exact order: NL <= 2 only
+    p.FOLD = (emb && (nhid > 1 || p.KUX > 2 || !(s->flags & SNSDE_FLAG_EXACT_ORDER))) ? 1 : 0;   // exact order: NL <= 2, C <= 32 only
     int off = 0, n = 0, rows = 0;
     auto add = [&](const SnsdeLayer& L, int KU, int fold_col, bool bias) {
         MfmaLayerPack& q = p.layer[n++];

@@ -1007,7 +1007,8 @@ int dispatch_var(const MfmaPlan& p, const MfmaArgs& a, hipStream_t st) {
     return SNSDE_ERR_UNSUPPORTED;
 }
 
-// Instantiated configurations: input_option 1..6, up to 3 hidden `linears` (NL <= 4), C <= 32 (two 16-wide k-blocks),
+// Instantiated configurations: input_option 1..6, up to 3 hidden `linears` (NL <= 4), C <= 32 (two 16-wide k-blocks) or
+// C <= 80 (five, folded first layer),
 // diffusion nets (noise_option 14/15/18/19) for the latent-only drifts (input_option 1, 3).
 template <int H, int FL>
 int dispatch_io(const MfmaPlan& p, const MfmaArgs& a, hipStream_t st) {
@@ -1015,6 +1016,16 @@ int dispatch_io(const MfmaPlan& p, const MfmaArgs& a, hipStream_t st) {
     if (p.IO == 4 && p.NHID == 1 && p.NN == 0) return dispatch_var<H, 2, 1, 4, FL, 0>(p, a, st);
     return SNSDE_ERR_UNSUPPORTED;
 #else
+#define SNSDE_WIDE(IO_, NHID_) \
+    if (p.IO == IO_ && p.NHID == NHID_) return a.dW ? launch_cfg<Cfg<H, 5, NHID_, IO_, FL, 0, 1, 0>>(a, st) \
+                                                    : launch_cfg<Cfg<H, 5, NHID_, IO_, FL, 1, 1, 0>>(a, st);
+    if (p.KUX == 5) {      // wide control paths (32 < C <= 80, e.g. the sepsis channels): folded first layer only
+        SNSDE_WIDE(2, 0) SNSDE_WIDE(2, 1) SNSDE_WIDE(2, 2) SNSDE_WIDE(2, 3)
+        SNSDE_WIDE(4, 0) SNSDE_WIDE(4, 1) SNSDE_WIDE(4, 2) SNSDE_WIDE(4, 3)
+        SNSDE_WIDE(6, 0) SNSDE_WIDE(6, 1) SNSDE_WIDE(6, 2) SNSDE_WIDE(6, 3)
+        return SNSDE_ERR_UNSUPPORTED;
+    }
+#undef SNSDE_WIDE
 #define SNSDE_CASE(IO_, NHID_, NN_) \
     if (p.IO == IO_ && p.NHID == NHID_ && p.NN == NN_) return dispatch_var<H, (IO_ % 2 == 0 ? 2 : 1), NHID_, IO_, FL, NN_>(p, a, st);
 #define SNSDE_CASES(IO_, NN_) SNSDE_CASE(IO_, 0, NN_) SNSDE_CASE(IO_, 1, NN_) SNSDE_CASE(IO_, 2, NN_) SNSDE_CASE(IO_, 3, NN_)

@@ -326,6 +326,9 @@ MFMA_CASES = [
     (3, 19, 1, 9, 128, 3, 8, [0, 7], 0.5, 'euler'),
     (1, 14, 2, 9, 32, 3, 8, [0, 7], 1.0, 'euler'),
     (3, 15, 3, 9, 16, 3, 8, [0, 7], 1.0, 'euler'),
+    (4, 17, 2, 37, 128, 69, 9, [0, 3.5, 8], 1.0, 'euler'),        # wide control path (sepsis channel counts): 5 k-blocks
+    (2, 16, 1, 21, 64, 35, 9, [0, 8], 1.0, 'milstein'),
+    (6, 17, 3, 9, 32, 80, 7, [0, 6], 0.5, 'euler'),
     (4, 17, 2, 21, 256, 14, 11, [0, 4.5, 10], 1.0, 'milstein'),   # H = 256: weights streamed from L2 (K5 model)
     (6, 17, 1, 9, 256, 5, 9, [0, 8], 1.0, 'euler'),
     (1, 18, 2, 9, 256, 3, 8, [0, 7], 1.0, 'euler'),
@@ -494,6 +497,8 @@ BWD_CASES = [
     (6, 17, 3, 9, 64, 3, 9, [0, 8], 1.0, 'milstein'),
     (3, 13, 2, 11, 32, 3, 8, [0, 7], 0.5, 'milstein'),
     (2, 16, 1, 9, 32, 2, 12, None, 0.05, 'milstein'),         # y-independent diffusion: Milstein term vanishes
+    (4, 17, 2, 13, 64, 69, 9, [0, 3.5, 8], 1.0, 'euler'),     # wide control path (C = 69)
+    (6, 17, 2, 9, 32, 35, 8, [0, 7], 1.0, 'milstein'),
     (3, 18, 2, 21, 64, 5, 9, [0, 3.5, 8], 1.0, 'euler'),      # diffusion nets on [tau, y] (BASELINE config 4's model)
     (1, 14, 2, 9, 32, 3, 8, [0, 7], 1.0, 'euler'),
     (3, 15, 1, 11, 128, 3, 8, [0, 7], 0.5, 'euler'),

@@ -21,6 +21,7 @@ CFG = [  # name, io, no, NL, B, H, C, L, method, ts_all
     ('K4 NSDE sepsis-shaped', 3, 18, 2, 2048, 64, 69, 72, 'euler', False),
     ('K5 LNSDE Milstein per-GPU shard', 4, 17, 2, 128, 256, 14, 50, 'milstein', True),
     ('K5 LNSDE Milstein B=1024', 4, 17, 2, 1024, 256, 14, 50, 'milstein', True),
+    ('sepsis-shaped LNSDE (C=69)', 4, 17, 2, 1024, 128, 69, 72, 'euler', False),
 ]
 for name, io, no, NL, B, H, C, L, method, ts_all in CFG:
     pr = make_problem(7, io, no, NL, B, H, C, L, nan_frac=0.2)
