@@ -335,8 +335,11 @@ int snsde_solve_forward(const snsde_solve* s, void* hip_stream) {
     rc = snsde_build_net(s->model, s->n_steps, &net);
     if (rc) return rc;
     hipStream_t st = static_cast<hipStream_t>(hip_stream);
-    if (s->method == SNSDE_SRK) {   // SRK runs on the generic (all-options) kernel family
-        if (s->kernel != SNSDE_KERNEL_AUTO && s->kernel != SNSDE_KERNEL_GENERIC) return SNSDE_ERR_UNSUPPORTED;
+    if (s->method == SNSDE_SRK) {   // SRK: MFMA variant (M4 tiles) where instantiated, else the generic (all-options) family
+        if (s->kernel == SNSDE_KERNEL_MFMA_M16) return SNSDE_ERR_UNSUPPORTED;
+        if (s->kernel == SNSDE_KERNEL_MFMA || s->kernel == SNSDE_KERNEL_MFMA_M4) return snsde_mfma_launch(s, net, st, 1);
+        if (s->kernel == SNSDE_KERNEL_AUTO && snsde_mfma_supported(s, net)) return snsde_mfma_launch(s, net, st, -1);
+        if (s->kernel != SNSDE_KERNEL_AUTO && s->kernel != SNSDE_KERNEL_GENERIC) return SNSDE_ERR_OPTION;
         return snsde_srk_launch(s, net, st);
     }
     switch (s->kernel) {
@@ -391,7 +394,9 @@ size_t snsde_backward_workspace_bytes(const snsde_backward* b) {
     if (!b) return 0;
     SnsdeNet net;
     if (snsde_build_net(b->fwd.model, b->fwd.n_steps, &net)) return 0;
-    return (snsde_mfma_backward_workspace_floats(&b->fwd, net) + 64) * sizeof(float);
+    size_t f = snsde_mfma_backward_workspace_floats(&b->fwd, net), g = 0;
+    snsde_generic_workspace_floats(&b->fwd, net, &g);      // the generic adjoints pack their own weights / tables
+    return ((f > g ? f : g) + 64) * sizeof(float);
 }
 
 int snsde_solve_backward(const snsde_backward* b, void* hip_stream) {
@@ -406,6 +411,7 @@ int snsde_solve_backward(const snsde_backward* b, void* hip_stream) {
     if (mode == 0) return SNSDE_ERR_UNSUPPORTED;
     if (mode == 2) {
         if (b->delta_save) return SNSDE_ERR_UNSUPPORTED;    // the generic adjoint writes adjoints only
+        if (b->workspace_bytes < snsde_backward_workspace_bytes(b)) return SNSDE_ERR_WORKSPACE;
         return snsde_generic_backward_launch(b, net, static_cast<hipStream_t>(hip_stream));
     }
     if (!b->fwd.act_save) return SNSDE_ERR_NULL;

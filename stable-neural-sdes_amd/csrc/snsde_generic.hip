@@ -1061,6 +1061,14 @@ int snsde_time_table_launch(const float* params, const float* step_tab, float* g
     return hipGetLastError() == hipSuccess ? SNSDE_OK : SNSDE_ERR_LAUNCH;
 }
 
+int snsde_time_table_srk_launch(const float* params, const float* srk_tab, float* gt, const SnsdeLayer& nt0,
+                                const SnsdeLayer& nt1, int H, int no, int n_rows, hipStream_t stream) {
+    // time-only diffusion at the stage times of every step: gt[(n*4 + slot)][H], rows of the SRK stage table
+    hipLaunchKernelGGL(snsde_time_table_kernel, dim3(n_rows), dim3(128), H * sizeof(float), stream, params, srk_tab,
+                       gt, nt0, nt1, H, no, SNSDE_SRK_STRIDE, 1);
+    return hipGetLastError() == hipSuccess ? SNSDE_OK : SNSDE_ERR_LAUNCH;
+}
+
 int snsde_generic_workspace_floats(const snsde_solve* s, const SnsdeNet& net, size_t* floats) {
     size_t f = (size_t)net.packed_floats;
     if (net.gt_tab >= 0) f = (size_t)net.gt_tab + (size_t)s->n_steps * s->model.hidden_channels * (s->method == SNSDE_SRK ? 4 : 1);
@@ -1146,16 +1154,42 @@ bool snsde_generic_backward_supported(const snsde_solve* s) {
     return true;
 }
 
-// The adjoint kernel re-uses the packed forward weights and the time-only diffusion table of the FORWARD workspace.
+// The adjoint kernels need the generic packed weights and the time-only diffusion table: prepared here in the
+// BACKWARD workspace, so the forward may have run on any kernel family (e.g. the MFMA SRK variant).
 int snsde_generic_backward_launch(const snsde_backward* b, const SnsdeNet& net, hipStream_t stream) {
     const snsde_solve* s = &b->fwd;
     const snsde_model& m = s->model;
+    size_t need = 0;
+    snsde_generic_workspace_floats(s, net, &need);
+    if (!b->workspace || b->workspace_bytes < need * sizeof(float)) return SNSDE_ERR_WORKSPACE;
+    float* bws = static_cast<float*>(b->workspace);
+    {
+        PackJob job;
+        job.n = 0;
+        auto add = [&](const SnsdeLayer& L) { if (L.present && L.w >= 0) job.layer[job.n++] = L; };
+        add(net.init); add(net.in); add(net.emb);
+        for (int i = 0; i < net.n_hid; ++i) add(net.hid[i]);
+        add(net.out); add(net.ny0); add(net.ny1);
+        if (job.n > 0) hipLaunchKernelGGL(snsde_pack_kernel, dim3(32, job.n), dim3(256), 0, stream, s->params, bws, job);
+        if (net.gt_tab >= 0) {
+            if (s->method == SNSDE_SRK) {
+                if (!s->srk_tab) return SNSDE_ERR_NULL;
+                hipLaunchKernelGGL(snsde_time_table_kernel, dim3(s->n_steps * 4), dim3(128), m.hidden_channels * sizeof(float),
+                                   stream, s->params, s->srk_tab, bws + net.gt_tab, net.nt0, net.nt1, m.hidden_channels,
+                                   m.noise_option, SNSDE_SRK_STRIDE, 1);
+            } else {
+                hipLaunchKernelGGL(snsde_time_table_kernel, dim3(s->n_steps), dim3(128), m.hidden_channels * sizeof(float),
+                                   stream, s->params, s->step_tab, bws + net.gt_tab, net.nt0, net.nt1, m.hidden_channels,
+                                   m.noise_option, SNSDE_STEP_STRIDE, 2);
+            }
+        }
+    }
     AdjArgs aa;
     GenericArgs& a = aa.g;
     a.d = SnsdeDims{s->batch, m.hidden_channels, m.hidden_hidden_channels, m.input_channels, s->knots,
                     m.num_hidden_layers, m.input_option, m.noise_option, s->n_steps, s->n_out, s->method};
     a.net = net;
-    a.params = s->params; a.ws = static_cast<const float*>(s->workspace); a.coeffs = s->coeffs;
+    a.params = s->params; a.ws = bws; a.coeffs = s->coeffs;
     a.step_tab = s->step_tab; a.out_step = s->out_step; a.out_w = s->out_w; a.y0 = s->y0; a.dW = nullptr;
     a.ys = nullptr; a.traj = nullptr; a.dW_out = nullptr; a.row_out = s->row_out; a.row_offset = 0; a.seed = 0; a.seed_dev = nullptr; a.eval_mode = 0;
     a.eval_f = nullptr; a.eval_g = nullptr;

@@ -55,6 +55,8 @@ int snsde_generic_backward_launch(const snsde_backward* b, const SnsdeNet& net, 
 int snsde_srk_launch(const snsde_solve* s, const SnsdeNet& net, hipStream_t stream);
 int snsde_time_table_launch(const float* params, const float* step_tab, float* gt, const SnsdeLayer& nt0,
                             const SnsdeLayer& nt1, int H, int no, int n_steps, hipStream_t stream);
+int snsde_time_table_srk_launch(const float* params, const float* srk_tab, float* gt, const SnsdeLayer& nt0,
+                                const SnsdeLayer& nt1, int H, int no, int n_rows, hipStream_t stream);
 // launchers (snsde_mfma.hip)
 bool snsde_mfma_supported(const snsde_solve* s, const SnsdeNet& net);
 size_t snsde_mfma_workspace_floats(const snsde_solve* s, const SnsdeNet& net);

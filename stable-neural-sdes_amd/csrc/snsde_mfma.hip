@@ -109,6 +109,21 @@ __global__ void snsde_fold_kernel(const float* __restrict__ params, float* __res
     }
 }
 
+// SRK variant: one step-table row per drift pass (stage times t0, t0 + h, t0 + h/2 = slots 0, 3, 2 of the stage table);
+// outputs are emitted after the last pass of a step only.
+__global__ void snsde_srk_expand_kernel(const float* __restrict__ step_tab, const float* __restrict__ srk_tab,
+                                        float* __restrict__ out, int n_steps) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= 3 * n_steps) return;
+    const int n = i / 3, stg = i - 3 * n;
+    const int slot = stg == 0 ? 0 : (stg == 1 ? 3 : 2);
+    const float* st = step_tab + (size_t)n * SNSDE_STEP_STRIDE;
+    const float* tp = srk_tab + ((size_t)n * 4 + slot) * SNSDE_SRK_STRIDE;
+    float* o = out + (size_t)i * SNSDE_STEP_STRIDE;
+    o[0] = tp[0]; o[1] = st[1]; o[2] = tp[1]; o[3] = tp[2]; o[4] = tp[3]; o[5] = tp[4]; o[6] = st[6]; o[7] = st[7];
+    o[8] = stg == 2 ? st[8] : __int_as_float(0); o[9] = st[9]; o[10] = 0.0f; o[11] = 0.0f;
+}
+
 // Which configurations the fast path is instantiated for.
 MfmaPlan make_plan(const snsde_solve* s, const SnsdeNet& net, int flavor_hint) {
     MfmaPlan p{};
@@ -116,13 +131,15 @@ MfmaPlan make_plan(const snsde_solve* s, const SnsdeNet& net, int flavor_hint) {
     const int H = m.hidden_channels, io = m.input_option, no = m.noise_option;
     p.ok = false;
     if (m.hidden_hidden_channels != H) return p;
-    if (s->method == SNSDE_SRK) return p;
+    const bool srk = s->method == SNSDE_SRK;
+    if (srk && (H > 128 || s->act_save || flavor_hint == 0)) return p;      // SRK variant: M4 tiles, no activation save
     if (!(H == 256 || H == 128 || H == 64 || H == 32 || H == 16)) return p;
     if (!(io >= 1 && io <= 6)) return p;
     const bool noise_net = (no == 14 || no == 15 || no == 18 || no == 19);
     if (!(no == 0 || no == 12 || no == 13 || no == 16 || no == 17 || noise_net)) return p;
     if (noise_net && !(io == 1 || io == 3)) return p;
     if (noise_net && s->method != SNSDE_EULER) return p;
+    if (srk && (m.input_channels > 32 && (io == 2 || io == 4 || io == 6))) return p;
     const bool emb = (io == 2 || io == 4 || io == 6);
     const int nhid = m.num_hidden_layers - 1;
     if (nhid > 3) return p;
@@ -140,7 +157,9 @@ MfmaPlan make_plan(const snsde_solve* s, const SnsdeNet& net, int flavor_hint) {
         const long r4 = ((s->batch + 3) / 4 + slots - 1) / slots, r16 = ((s->batch + 15) / 16 + slots - 1) / slots;
         p.FL = flavor_hint >= 0 ? flavor_hint : (10 * r4 > 22 * r16 ? 0 : 1);
     }
-    p.FOLD = (emb && (nhid > 1 || p.KUX > 2 || !(s->flags & SNSDE_FLAG_EXACT_ORDER))) ? 1 : 0;   // exact order: NL <= 2, C <= 32 only
+    p.SRK = srk ? 1 : 0;
+    if (srk) p.FL = 1;
+    p.FOLD = (emb && (nhid > 1 || p.KUX > 2 || srk || !(s->flags & SNSDE_FLAG_EXACT_ORDER))) ? 1 : 0;   // exact order: NL <= 2, C <= 32 only
     int off = 0, n = 0, rows = 0;
     auto add = [&](const SnsdeLayer& L, int KU, int fold_col, bool bias) {
         MfmaLayerPack& q = p.layer[n++];
@@ -174,7 +193,9 @@ MfmaPlan make_plan(const snsde_solve* s, const SnsdeNet& net, int flavor_hint) {
     off += rows * H;
     off = (off + 3) & ~3;
     p.gt_off = (no == 12 || no == 13 || no == 16 || no == 17) ? off : -1;
-    if (p.gt_off >= 0) off += s->n_steps * H;
+    if (p.gt_off >= 0) off += s->n_steps * H * (srk ? 4 : 1);     // SRK: the four stage times of every step
+    p.srk_tab_off = -1;
+    if (srk) { p.srk_tab_off = off; off += 3 * s->n_steps * SNSDE_STEP_STRIDE; }
     if (p.FOLD) {   // temps for the folded products
         for (int i = 0; i < 2; ++i) { p.layer[i].fold_tmp = off; off += H * p.layer[i].K; }
         p.fold_bias_tmp = off; off += H;
@@ -252,7 +273,7 @@ int snsde_mfma_launch(const snsde_solve* s, const SnsdeNet& net, hipStream_t str
         job.fold_b_in = p.fold_b_in; job.fold_b_init = p.fold_b_init; job.fold_b_emb = p.fold_b_emb;
         job.fold_emb_w = p.fold_emb_w;
         job.fold_bias_tmp = p.fold_bias_tmp;
-        if (p.FOLD || p.gt_off >= 0) {   // folded products + time-only diffusion table in ONE launch
+        if (p.FOLD || (p.gt_off >= 0 && !p.SRK)) {   // folded products + time-only diffusion table in ONE launch
             FoldJob fj{};
             fj.fold_on = p.FOLD; fj.H = p.H; fj.n_pieces = 2;
             if (p.FOLD) {
@@ -263,18 +284,32 @@ int snsde_mfma_launch(const snsde_solve* s, const SnsdeNet& net, hipStream_t str
                 }
                 fj.b_in = p.fold_b_in; fj.b_init = p.fold_b_init; fj.b_emb = p.fold_b_emb; fj.bias_tmp = p.fold_bias_tmp;
             }
-            fj.tab_on = p.gt_off >= 0; fj.tab_off = p.gt_off; fj.n_steps = s->n_steps; fj.no = s->model.noise_option;
+            fj.tab_on = p.gt_off >= 0 && !p.SRK; fj.tab_off = p.gt_off; fj.n_steps = s->n_steps; fj.no = s->model.noise_option;
             fj.nt0 = net.nt0; fj.nt1 = net.nt1; fj.step_tab = s->step_tab;
             const int gx = fj.tab_on && s->n_steps > p.H ? s->n_steps : p.H;
             hipLaunchKernelGGL(snsde_fold_kernel, dim3(gx, fj.tab_on ? 3 : 2), dim3(256), 2 * p.H * sizeof(float), stream,
                                s->params, ws, fj);
         }
         hipLaunchKernelGGL(snsde_mfma_pack_kernel, dim3(16, p.n_layers), dim3(256), 0, stream, s->params, ws, job);
+        if (p.SRK) {
+            if (!s->srk_tab) return SNSDE_ERR_NULL;
+            hipLaunchKernelGGL(snsde_srk_expand_kernel, dim3((3 * s->n_steps + 127) / 128), dim3(128), 0, stream, s->step_tab,
+                               s->srk_tab, ws + p.srk_tab_off, s->n_steps);
+            if (p.gt_off >= 0) {
+                const int rc = snsde_time_table_srk_launch(s->params, s->srk_tab, ws + p.gt_off, net.nt0, net.nt1, p.H,
+                                                           s->model.noise_option, s->n_steps * 4, stream);
+                if (rc) return rc;
+            }
+        }
     }
     MfmaArgs a{};
     a.params = s->params; a.ws = ws; a.coeffs = s->coeffs; a.step_tab = s->step_tab; a.out_step = s->out_step;
     a.out_w = s->out_w; a.y0 = s->y0; a.dW = s->dW; a.ys = s->ys; a.traj = s->traj; a.dW_out = s->dW_out;
     a.act_save = s->act_save; a.row_out = s->row_out;
+    if (p.SRK) {
+        if (s->dW && !s->dU) return SNSDE_ERR_NULL;
+        a.step_tab = ws + p.srk_tab_off; a.dU = s->dU; a.dU_out = s->dU_out;
+    }
     a.row_offset = s->row_offset; a.seed = s->seed; a.seed_dev = s->seed_dev;
     a.B = s->batch; a.L = s->knots; a.C = s->model.input_channels; a.N = s->n_steps; a.T = s->n_out;
     a.method = s->method; a.no = s->model.noise_option;

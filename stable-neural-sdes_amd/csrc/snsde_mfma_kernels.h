@@ -71,6 +71,8 @@ struct MfmaArgs {
     const float* out_w;
     const float* y0;
     const float* dW;
+    const float* dU;   // SRK: supplied space-time Levy integrals I_k0 (with dW) or null
+    float* dU_out;     // SRK: I_k0 used, or null
     float* ys;
     float* traj;
     float* dW_out;
@@ -190,8 +192,9 @@ __device__ __forceinline__ void gemm(const Wt<true, KU, TPW>& w, const float* in
     }
 }
 
-template <int H_, int KUX_, int NHID_, int IO_, int FL_, int PHX_, int FOLD_, int NN_ = 0>
+template <int H_, int KUX_, int NHID_, int IO_, int FL_, int PHX_, int FOLD_, int NN_ = 0, int SRK_ = 0>
 struct Cfg {
+    static constexpr bool SRK = SRK_ != 0;   // SRID2 stepper: three drift passes (pseudo-steps) per solver step
     static constexpr int H = H_, KUX = KUX_, NHID = NHID_, IO = IO_, FL = FL_;
     static constexpr bool PHX = PHX_ != 0;   // in-kernel Philox increments (else supplied dW)
     // one 16-feature tile per wave: H/16 waves per workgroup (8 at H=128 = two waves per SIMD, so one wave's
@@ -223,9 +226,9 @@ struct Cfg {
     static constexpr int EPT = FL ? 1 : 4;                            // owned state elements per lane per tile
     static constexpr int NSAVE = NHID + 2 + NN;                       // saved activations per step: z0, hidden.., zout, [noise-net hidden], [noise-net output]
     static constexpr int ZSLOT = NHID + 1;                            // slot of the pre-tanh drift
-    static constexpr int ZB = (FL && !STREAM) ? 4 : 1;                             // Philox calls generated together per element
+    static constexpr int ZB = (FL && !STREAM && !SRK) ? 4 : 1;                     // Philox calls generated together per element
     static constexpr int ROWCH = 128;                                 // step-table rows staged in LDS per chunk
-    static constexpr int ZSTASH = PHX ? 4 * ZB * 64 * EPT : 0;        // floats per wave
+    static constexpr int ZSTASH = (PHX && !SRK) ? 4 * ZB * 64 * EPT : 0;  // floats per wave
     static constexpr int LDS_FLOATS = M * (LDY + LDX + LDC + 3 * LDA) + NLAYER * H + (ROWCH + 1) * SNSDE_STEP_STRIDE + NW * ZSTASH;
 };
 
@@ -396,7 +399,8 @@ __global__ void __launch_bounds__(CF::NT, CF::WPS) snsde_mfma_kernel(MfmaArgs a)
     auto fill_rows = [&](int base) {
         for (int i = tid; i < (CF::ROWCH + 1) * SNSDE_STEP_STRIDE; i += NT) {
             const int rr = base + i / SNSDE_STEP_STRIDE;
-            rowtab[i] = a.step_tab[(size_t)(rr < a.N ? rr : a.N - 1) * SNSDE_STEP_STRIDE + i % SNSDE_STEP_STRIDE];
+            const int last = (CF::SRK ? 3 * a.N : a.N) - 1;
+            rowtab[i] = a.step_tab[(size_t)(rr < last ? rr : last) * SNSDE_STEP_STRIDE + i % SNSDE_STEP_STRIDE];
         }
     };
     auto get_row = [&](int i, int base) {
@@ -412,10 +416,25 @@ __global__ void __launch_bounds__(CF::NT, CF::WPS) snsde_mfma_kernel(MfmaArgs a)
     __syncthreads();
     if (__builtin_amdgcn_readfirstlane(tid) >= NT / 2 && CF::NW >= 8) __builtin_amdgcn_s_setprio(1);   // younger half
 
+    // SRK (SRID2): every solver step is three pseudo-steps of this loop (one drift pass each: stage times t0, t0 + h,
+    // t0 + h/2 from the expanded step table); the stage combinations are elementwise in the D layout.
+    float sk_y[EPT], sk_f0[EPT], sk_f1[EPT], sk_g0[EPT], sk_g1[EPT], sk_dw[EPT], sk_du[EPT];
+    float sk_t0[EPT], sk_t1[EPT], sk_t3[EPT], sk_z[EPT][4], sk_x[EPT][4];
+#pragma unroll
+    for (int e = 0; e < EPT; ++e) {
+        sk_y[e] = yv[0][e]; sk_f0[e] = sk_f1[e] = sk_g0[e] = sk_g1[e] = sk_dw[e] = sk_du[e] = 0.0f;
+        sk_t0[e] = sk_t1[e] = sk_t3[e] = 0.0f;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { sk_z[e][i] = 0.0f; sk_x[e][i] = 0.0f; }
+    }
+    const int n_loop = CF::SRK ? 3 * a.N : a.N;
+
     TRACE_DECL
-    for (int n = 0; n < a.N; ++n) {
+    for (int n = 0; n < n_loop; ++n) {
         TRACE(0)
-        const bool more = n + 1 < a.N;
+        const bool more = n + 1 < n_loop;
+        const int stage = CF::SRK ? n % 3 : 0;     // pseudo-step -> (solver step ns, stage)
+        const int ns = CF::SRK ? n / 3 : n;
         save_step = n;
         const int rbase = (n / CF::ROWCH) * CF::ROWCH;
         if (n > 0 && n == rbase) {       // next chunk (every wave is past the previous step's closing barrier)
@@ -438,7 +457,32 @@ __global__ void __launch_bounds__(CF::NT, CF::WPS) snsde_mfma_kernel(MfmaArgs a)
             // Brownian increments for the owned elements: one Philox call per (row, 4-step block, column) gives the
             // element's normals for 4 consecutive steps (snsde_philox_normal4), regenerated every 4th step
             static_assert(TPW == 1, "one 16-feature tile per wave");
-            if constexpr (CF::PHX) {
+            if constexpr (CF::SRK) {
+                if (stage == 0) {      // increments (I_k, I_k0) and the diffusion table rows of the step's three stage times
+#pragma unroll
+                    for (int e = 0; e < EPT; ++e) {
+                        if constexpr (CF::PHX) {
+                            if ((ns & 3) == 0) {
+                                snsde_philox_normal4(seed, grow, (uint32_t)(ns >> 2), (uint32_t)(fcol[0] + e), sk_z[e], 0u);
+                                snsde_philox_normal4(seed, grow, (uint32_t)(ns >> 2), (uint32_t)(fcol[0] + e), sk_x[e], 1u);
+                            }
+                            const int k = ns & 3;
+                            const float z = k == 0 ? sk_z[e][0] : (k == 1 ? sk_z[e][1] : (k == 2 ? sk_z[e][2] : sk_z[e][3]));
+                            const float xi = k == 0 ? sk_x[e][0] : (k == 1 ? sk_x[e][1] : (k == 2 ? sk_x[e][2] : sk_x[e][3]));
+                            sk_dw[e] = z * sqh;
+                            sk_du[e] = h * fmaf(sqrtf(h / 12.0f), xi, 0.5f * sk_dw[e]);
+                        } else {
+                            const size_t off = (size_t)ns * BH + (size_t)rowc * H + fcol[0] + e;
+                            sk_dw[e] = a.dW[off];
+                            sk_du[e] = a.dU[off];
+                        }
+                        if (a.gt_off >= 0) {
+                            const float* gp = gt + (size_t)ns * 4 * H + fcol[0] + e;
+                            sk_t0[e] = gp[0]; sk_t1[e] = gp[H]; sk_t3[e] = gp[3 * H];
+                        }
+                    }
+                }
+            } else if constexpr (CF::PHX) {
                 // ZB independent Philox calls (ZB blocks of 4 steps) are generated together (their round chains interleave)
                 // and parked in this wave's private LDS stash [4*ZB steps][64 lanes][EPT]; each step reads back one entry.
                 constexpr int ZB = CF::ZB;
@@ -469,10 +513,12 @@ __global__ void __launch_bounds__(CF::NT, CF::WPS) snsde_mfma_kernel(MfmaArgs a)
                 }
             }
             // time-only diffusion table row (noise_option 12/13/16/17)
+            if constexpr (!CF::SRK) {
     #pragma unroll
-            for (int t = 0; t < TPW; ++t)
+                for (int t = 0; t < TPW; ++t)
     #pragma unroll
-                for (int e = 0; e < EPT; ++e) gtv[t][e] = (a.gt_off >= 0) ? gt[(size_t)n * H + fcol[t] + e] : 0.0f;
+                    for (int e = 0; e < EPT; ++e) gtv[t][e] = (a.gt_off >= 0) ? gt[(size_t)n * H + fcol[t] + e] : 0.0f;
+            }
 
 
             if (more) {
@@ -604,6 +650,43 @@ __global__ void __launch_bounds__(CF::NT, CF::WPS) snsde_mfma_kernel(MfmaArgs a)
                 const float y = yv[t][e];
                 if constexpr (CF::GEO) z *= fast_tanh(y);
                 const float f = fast_tanh(z);
+                if constexpr (CF::SRK) {
+                    auto gfun = [&](float gq, float yy) {
+                        const float raw = mul_y ? gq * yy : gq;
+                        return fast_tanh(sig_theta * snsde_nan_to_num(raw));
+                    };
+                    const float yb = sk_y[e], f0 = sk_f0[e], g0 = sk_g0[e];
+                    float yin;
+                    yold[e] = yb;
+                    if (stage == 0) {            // F0, G0 at (t0, y);  H0_1 = y + f0 h
+                        sk_f0[e] = f;
+                        sk_g0[e] = gfun(sk_t0[e], yb);
+                        yin = yb + f * h;
+                    } else if (stage == 1) {     // F1 at (t0 + h, H0_1), G1 at (t0 + h/4, H1_1);  H0_2
+                        sk_f1[e] = f;
+                        const float g1 = gfun(sk_t1[e], yb + 0.25f * f0 * h + 0.5f * g0 * sqh);
+                        sk_g1[e] = g1;
+                        const float du = sk_du[e];
+                        yin = yb + 0.25f * f0 * h + 0.25f * f * h + g0 * du / h + 0.5f * g1 * du / h;
+                    } else {                     // F2 at (t0 + h/2, H0_2), G2 at (t0 + h, H1_2), G3 at (t0 + h/4, H1_3): combine
+                        const float f1 = sk_f1[e], g1 = sk_g1[e], ik = sk_dw[e], ik0 = sk_du[e];
+                        const float g2 = gfun(sk_t3[e], yb + f0 * h - g0 * sqh);
+                        const float g3 = gfun(sk_t1[e], yb + 0.25f * f * h + (-5.0f * g0 + 3.0f * g1 + 0.5f * g2) * sqh);
+                        const float ikk = 0.5f * (ik * ik - h);
+                        const float ikkk = (ik * ik * ik - 3.0f * h * ik) / 6.0f;
+                        const float a1 = ik, a2 = ikk / sqh, a3 = ik0 / h, a4 = ikkk / h;
+                        const float w0 = -a1 - a2 + 2.0f * a3 - 2.0f * a4;
+                        const float w1 = (4.0f / 3.0f) * a1 + (4.0f / 3.0f) * a2 - (4.0f / 3.0f) * a3 + (5.0f / 3.0f) * a4;
+                        const float w2 = (2.0f / 3.0f) * a1 - (1.0f / 3.0f) * a2 - (2.0f / 3.0f) * a3 - (2.0f / 3.0f) * a4;
+                        float yn1 = yb + (f0 + f1) * (h / 6.0f) + f * (2.0f * h / 3.0f);
+                        yn1 += w0 * g0 + w1 * g1 + w2 * g2 + a4 * g3;
+                        sk_y[e] = yn1;
+                        yin = yn1;
+                    }
+                    ynew[e] = yin; yv[t][e] = yin;
+                    dw[t][e] = sk_dw[e];
+                    continue;
+                }
                 float gq = gtv[t][e];
                 if constexpr (CF::NN > 0) {
                     gq = gnv[FL ? 0 : e];
@@ -627,9 +710,10 @@ __global__ void __launch_bounds__(CF::NT, CF::WPS) snsde_mfma_kernel(MfmaArgs a)
             }
             if constexpr (FL) {
                 ybuf[r * LDY + fcol[t]] = ynew[0];
-                if (row_ok) {
-                    if (a.traj) a.traj[(size_t)(n + 1) * BH + goff] = ynew[0];
-                    if (a.dW_out) a.dW_out[(size_t)n * BH + goff] = dw[t][0];
+                if (row_ok && (!CF::SRK || stage == 2)) {
+                    if (a.traj) a.traj[(size_t)(ns + 1) * BH + goff] = ynew[0];
+                    if (a.dW_out) a.dW_out[(size_t)ns * BH + goff] = dw[t][0];
+                    if constexpr (CF::SRK) { if (a.dU_out) a.dU_out[(size_t)ns * BH + goff] = sk_du[0]; }
                     for (int k = c_kfirst; k < c_kfirst + c_nout; ++k) {
                         const float w0 = a.out_w[2 * k], w1 = a.out_w[2 * k + 1];
                         const float o = (w0 == 0.0f) ? ynew[0] : w0 * yold[0] + w1 * ynew[0];
@@ -640,10 +724,14 @@ __global__ void __launch_bounds__(CF::NT, CF::WPS) snsde_mfma_kernel(MfmaArgs a)
             } else {
                 const f32x4 vn = {ynew[0], ynew[1], ynew[2], ynew[3]};
                 *reinterpret_cast<f32x4*>(ybuf + r * LDY + fcol[t]) = vn;
-                if (row_ok) {
-                    if (a.traj) *reinterpret_cast<f32x4*>(a.traj + (size_t)(n + 1) * BH + goff) = vn;
-                    if (a.dW_out) *reinterpret_cast<f32x4*>(a.dW_out + (size_t)n * BH + goff) =
+                if (row_ok && (!CF::SRK || stage == 2)) {
+                    if (a.traj) *reinterpret_cast<f32x4*>(a.traj + (size_t)(ns + 1) * BH + goff) = vn;
+                    if (a.dW_out) *reinterpret_cast<f32x4*>(a.dW_out + (size_t)ns * BH + goff) =
                         f32x4{dw[t][0], dw[t][1], dw[t][2], dw[t][3]};
+                    if constexpr (CF::SRK) {
+                        if (a.dU_out) *reinterpret_cast<f32x4*>(a.dU_out + (size_t)ns * BH + goff) =
+                            f32x4{sk_du[0], sk_du[EPT > 1 ? 1 : 0], sk_du[EPT > 2 ? 2 : 0], sk_du[EPT > 3 ? 3 : 0]};
+                    }
                     for (int k = c_kfirst; k < c_kfirst + c_nout; ++k) {
                         const float w0 = a.out_w[2 * k], w1 = a.out_w[2 * k + 1];
                         f32x4 o;
@@ -978,7 +1066,8 @@ int launch_rev(const RevArgs& a, hipStream_t stream) {
 
 struct MfmaPlan {
     bool ok;
-    int H, KUX, NHID, IO, FL, TPW, NW, FOLD, NN;
+    int H, KUX, NHID, IO, FL, TPW, NW, FOLD, NN, SRK;
+    int srk_tab_off;   // expanded (3N-row) step table of the SRK variant inside the workspace
     int n_bias_rows;
     int fold_b_in, fold_b_init, fold_b_emb, fold_emb_w, fold_bias_tmp;
     int n_layers;
@@ -1016,6 +1105,18 @@ int dispatch_io(const MfmaPlan& p, const MfmaArgs& a, hipStream_t st) {
     if (p.IO == 4 && p.NHID == 1 && p.NN == 0) return dispatch_var<H, 2, 1, 4, FL, 0>(p, a, st);
     return SNSDE_ERR_UNSUPPORTED;
 #else
+    if (p.SRK) {           // SRID2 stepper: M4 tiles, folded first layer, C <= 32, elementwise diffusions
+        if constexpr (FL == 1) {
+#define SNSDE_SRKC(IO_, NHID_) \
+    if (p.IO == IO_ && p.NHID == NHID_) return a.dW ? launch_cfg<Cfg<H, (IO_ % 2 == 0 ? 2 : 1), NHID_, IO_, 1, 0, 1, 0, 1>>(a, st) \
+                                                    : launch_cfg<Cfg<H, (IO_ % 2 == 0 ? 2 : 1), NHID_, IO_, 1, 1, 1, 0, 1>>(a, st);
+#define SNSDE_SRKS(IO_) SNSDE_SRKC(IO_, 0) SNSDE_SRKC(IO_, 1) SNSDE_SRKC(IO_, 2) SNSDE_SRKC(IO_, 3)
+            SNSDE_SRKS(1) SNSDE_SRKS(2) SNSDE_SRKS(3) SNSDE_SRKS(4) SNSDE_SRKS(5) SNSDE_SRKS(6)
+#undef SNSDE_SRKS
+#undef SNSDE_SRKC
+        }
+        return SNSDE_ERR_UNSUPPORTED;
+    }
 #define SNSDE_WIDE(IO_, NHID_) \
     if (p.IO == IO_ && p.NHID == NHID_) return a.dW ? launch_cfg<Cfg<H, 5, NHID_, IO_, FL, 0, 1, 0>>(a, st) \
                                                     : launch_cfg<Cfg<H, 5, NHID_, IO_, FL, 1, 1, 0>>(a, st);

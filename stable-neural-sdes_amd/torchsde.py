@@ -201,7 +201,8 @@ class _FusedSolve(torch.autograd.Function):
                 "the fused backward covers 'euler'/'milstein'/'srk' with a diffusion that is elementwise in y "
                 "(noise_option 0..13, 16, 17) and 'euler' with the diffusion nets on input_option 1/3; pass "
                 "options={'backend': 'torch'} to differentiate this configuration through the tensor-op loop")
-        call = make(options.get('kernel', 'auto'), True) if mode == 1 else make('generic', False)
+        # mode 2: the generic adjoint prepares its own weights, so the forward takes whatever kernel is fastest
+        call = make(options.get('kernel', 'auto'), mode == 1)
         ctx.mode, ctx.method = mode, method
         ctx.param_pass = options.get('param_pass', 'hip')
         ctx.layout = (layout, numel)

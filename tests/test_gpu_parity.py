@@ -831,6 +831,11 @@ SRK_CASES = [
     (0, 5, 2, 8, 12, 3, 8, [0, 7], 1.0),
     (5, 8, 2, 8, 10, 3, 8, [0, 3.5, 7], 0.25),
     (1, 0, 2, 5, 8, 3, 8, [0, 7], 1.0),
+    (1, 12, 1, 9, 64, 3, 8, [0, 2.5, 7], 1.0),       # MFMA SRK variant: every drift family, H = 16 .. 128, NL 1 .. 4
+    (3, 13, 3, 21, 32, 3, 9, [0, 8], 0.5),
+    (5, 17, 2, 13, 16, 3, 8, [0, 7], 1.0),
+    (4, 16, 4, 9, 64, 21, 9, [0, 4, 8], 1.0),
+    (2, 0, 2, 7, 128, 32, 8, [0, 7], 1.0),
 ]
 
 
@@ -841,8 +846,9 @@ def _draw_dU(seed, dW, ts, dt):
     return (h * (0.5 * dW + np.sqrt(h / 12) * xi)).astype(np.float32)
 
 
+@pytest.mark.parametrize('kernel', ['auto', 'generic'])
 @pytest.mark.parametrize('ci', range(len(SRK_CASES)))
-def test_srk_trajectory_vs_oracle(ci):
+def test_srk_trajectory_vs_oracle(ci, kernel):
     io, no, NL, B, H, C, L, ts, dt = SRK_CASES[ci]
     times = np.linspace(0, 1, L).astype(np.float32) if ts is None else None
     pr = make_problem(700 + ci, io, no, NL, B, H, C, L, times=times)
@@ -851,7 +857,7 @@ def test_srk_trajectory_vs_oracle(ci):
         dt = max(float(np.diff(pr['times']).min()), 1e-3) / 2      # torch_ists tutorial: dt = min gap / 2
     dW = draw_dW(700 + ci, ts, dt, B, H)
     dU = _draw_dU(700 + ci, dW, ts, dt)
-    ys, call = hip_solve(pr, ts, dt, dW=dW, dU=dU, method='srk', save_traj=True)
+    ys, call = hip_solve(pr, ts, dt, dW=dW, dU=dU, method='srk', save_traj=True, kernel=kernel)
     ref64, traj64 = O.solve_diffusion_model(pr['params'], io, no, pr['coeffs'], pr['times'], pr['y0'],
                                             np.asarray(ts, np.float32), dt, dW, method='srk', dtype=np.float64, dU=dU)
     cpu32, _ = O.solve_diffusion_model(pr['params'], io, no, pr['coeffs'], pr['times'], pr['y0'],
