@@ -143,6 +143,8 @@ typedef struct snsde_solve {
                               /* supplied dW), or NULL: h*(dW/2 + sqrt(h/12) xi), xi from Philox      */
     float*         dU_out;    /* optional device (N, B, H): the I_k0 actually used                    */
     float*         act_save;  /* optional device (N, snsde_act_slots, B, H): per-step activations */
+    float*         stage_save;/* SRK training on the MFMA path: optional device (3N + 1, B, H), the input state of every   */
+                              /* drift pass (act_save / delta_save are then indexed by pass, 3N of them)                */
     const uint64_t* seed_dev; /* optional device pointer to the Philox key: read when the kernel starts and used  */
                               /* instead of `seed`, so a captured hipGraph draws fresh increments on every replay */
                               /* (the owner updates the value in-stream between replays).                         */

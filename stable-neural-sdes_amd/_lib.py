@@ -32,7 +32,7 @@ class Solve(C.Structure):
                 ('params', C.c_void_p), ('coeffs', C.c_void_p), ('step_tab', C.c_void_p),
                 ('out_step', C.c_void_p), ('out_w', C.c_void_p), ('y0', C.c_void_p), ('dW', C.c_void_p),
                 ('ys', C.c_void_p), ('traj', C.c_void_p), ('dW_out', C.c_void_p), ('srk_tab', C.c_void_p), ('dU', C.c_void_p),
-                ('dU_out', C.c_void_p), ('act_save', C.c_void_p), ('seed_dev', C.c_void_p), ('row_out', C.c_void_p),
+                ('dU_out', C.c_void_p), ('act_save', C.c_void_p), ('stage_save', C.c_void_p), ('seed_dev', C.c_void_p), ('row_out', C.c_void_p),
                 ('workspace', C.c_void_p), ('workspace_bytes', C.c_size_t)]
 
 

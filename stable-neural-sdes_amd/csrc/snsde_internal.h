@@ -65,6 +65,7 @@ bool snsde_mfma_backward_supported(const snsde_solve* s, const SnsdeNet& net);
 size_t snsde_mfma_backward_workspace_floats(const snsde_solve* s, const SnsdeNet& net);
 int snsde_mfma_backward_launch(const snsde_backward* b, const SnsdeNet& net, hipStream_t stream);
 const float* snsde_mfma_gt_table(const snsde_solve* s, const SnsdeNet& net);
+const float* snsde_mfma_srk_pass_table(const snsde_solve* s, const SnsdeNet& net);   // (3N, SNSDE_STEP_STRIDE) or null
 bool snsde_mfma_backward_partials(const snsde_solve* s, const SnsdeNet& net, int* nwg, int* waves, size_t* ds_off,
                                   size_t* dth_off);
 // launchers (snsde_wgrad.hip)

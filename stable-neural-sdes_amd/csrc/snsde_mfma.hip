@@ -132,7 +132,7 @@ MfmaPlan make_plan(const snsde_solve* s, const SnsdeNet& net, int flavor_hint) {
     p.ok = false;
     if (m.hidden_hidden_channels != H) return p;
     const bool srk = s->method == SNSDE_SRK;
-    if (srk && (H > 128 || s->act_save || flavor_hint == 0)) return p;      // SRK variant: M4 tiles, no activation save
+    if (srk && (H > 128 || flavor_hint == 0)) return p;      // SRK variant: M4 tiles
     if (!(H == 256 || H == 128 || H == 64 || H == 32 || H == 16)) return p;
     if (!(io >= 1 && io <= 6)) return p;
     const bool noise_net = (no == 14 || no == 15 || no == 18 || no == 19);
@@ -209,8 +209,9 @@ MfmaPlan make_plan(const snsde_solve* s, const SnsdeNet& net, int flavor_hint) {
 RevPlan make_rev_plan(const snsde_solve* s, const SnsdeNet& net, const MfmaPlan& fp) {
     RevPlan p{};
     p.ok = false;
-    if (!fp.ok || (s->method != SNSDE_EULER && s->method != SNSDE_MILSTEIN)) return p;
+    if (!fp.ok || (s->method != SNSDE_EULER && s->method != SNSDE_MILSTEIN && s->method != SNSDE_SRK)) return p;
     if (fp.NN != 0 && s->method != SNSDE_EULER) return p;
+    p.SRK = fp.SRK;
     const int H = fp.H, io = fp.IO;
     p.H = H; p.NHID = fp.NHID; p.GEO = (io == 5 || io == 6) ? 1 : 0; p.FL = fp.FL; p.NW = fp.NW; p.NN = fp.NN;
     p.emb = (io == 2 || io == 4 || io == 6) ? 1 : 0;
@@ -239,7 +240,7 @@ RevPlan make_rev_plan(const snsde_solve* s, const SnsdeNet& net, const MfmaPlan&
     p.ds_off = p.dth_off = 0;
     if (fp.gt_off >= 0 || p.NN > 0) {     // the adjoint kernel also leaves the diffusion-side parameter sums
         size_t o = ((size_t)p.total_floats + 3) & ~(size_t)3;
-        if (fp.gt_off >= 0) { p.ds_off = o; o += (size_t)p.nwg * s->n_steps * H; }   // time-only noise MLP: d/d s_n
+        if (fp.gt_off >= 0) { p.ds_off = o; o += (size_t)p.nwg * s->n_steps * H * (p.SRK ? 4 : 1); }   // time-only noise MLP: d/d s_n
         p.dth_off = o; o += (size_t)p.nwg * p.NW;                                    // d/d sigmoid(theta)
         if (o + 16 > 0x7fffffff) return p;
         p.total_floats = (int)(o + 16);
@@ -306,6 +307,7 @@ int snsde_mfma_launch(const snsde_solve* s, const SnsdeNet& net, hipStream_t str
     a.params = s->params; a.ws = ws; a.coeffs = s->coeffs; a.step_tab = s->step_tab; a.out_step = s->out_step;
     a.out_w = s->out_w; a.y0 = s->y0; a.dW = s->dW; a.ys = s->ys; a.traj = s->traj; a.dW_out = s->dW_out;
     a.act_save = s->act_save; a.row_out = s->row_out;
+    a.stage_save = p.SRK ? s->stage_save : nullptr;
     if (p.SRK) {
         if (s->dW && !s->dU) return SNSDE_ERR_NULL;
         a.step_tab = ws + p.srk_tab_off; a.dU = s->dU; a.dU_out = s->dU_out;
@@ -325,6 +327,11 @@ int snsde_mfma_launch(const snsde_solve* s, const SnsdeNet& net, hipStream_t str
 
 
 // ---- backward host side ---------------------------------------------------------------------------------
+
+const float* snsde_mfma_srk_pass_table(const snsde_solve* s, const SnsdeNet& net) {
+    MfmaPlan p = make_plan(s, net, -1);
+    return (p.ok && p.SRK && s->workspace) ? static_cast<const float*>(s->workspace) + p.srk_tab_off : nullptr;
+}
 
 const float* snsde_mfma_gt_table(const snsde_solve* s, const SnsdeNet& net) {
     MfmaPlan p = make_plan(s, net, -1);
@@ -376,6 +383,10 @@ int snsde_mfma_backward_launch(const snsde_backward* b, const SnsdeNet& net, hip
     a.gt = fp.gt_off >= 0 ? static_cast<const float*>(s->workspace) + fp.gt_off : nullptr;
     a.step_tab = s->step_tab; a.out_w = s->out_w; a.traj = s->traj; a.act = s->act_save; a.dW = s->dW_out;
     a.grad_ys = b->grad_ys; a.adj = b->adj; a.delta = b->delta_save; a.row_out = s->row_out;
+    if (p.SRK) {
+        if (!s->dU_out) return SNSDE_ERR_NULL;
+        a.dU = s->dU_out;
+    }
     a.ds_part = p.ds_off ? ws + p.ds_off : nullptr;
     a.dth_part = p.dth_off ? ws + p.dth_off : nullptr;
     a.B = s->batch; a.N = s->n_steps; a.T = s->n_out; a.no = s->model.noise_option; a.off_theta = net.off_theta; a.method = s->method;

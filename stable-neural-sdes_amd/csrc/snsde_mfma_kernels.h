@@ -77,6 +77,7 @@ struct MfmaArgs {
     float* traj;
     float* dW_out;
     float* act_save;   // (N, NSAVE, B, H) or null
+    float* stage_save; // SRK training: (3N + 1, B, H) input state of every drift pass, or null
     const int32_t* row_out;   // (B) per-row output slot (ys is then (B, H)) or null
     int64_t row_offset;
     uint64_t seed;
@@ -311,6 +312,7 @@ __global__ void __launch_bounds__(CF::NT, CF::WPS) snsde_mfma_kernel(MfmaArgs a)
             if (row_ok) {
                 a.ys[(size_t)row * H + fcol[t]] = yv[t][0];
                 if (a.traj) a.traj[(size_t)row * H + fcol[t]] = yv[t][0];
+                if constexpr (CF::SRK) { if (a.stage_save) a.stage_save[(size_t)row * H + fcol[t]] = yv[t][0]; }
             }
         } else {
             const f32x4 v = *reinterpret_cast<const f32x4*>(a.y0 + (size_t)rowc * H + fcol[t]);
@@ -710,6 +712,7 @@ __global__ void __launch_bounds__(CF::NT, CF::WPS) snsde_mfma_kernel(MfmaArgs a)
             }
             if constexpr (FL) {
                 ybuf[r * LDY + fcol[t]] = ynew[0];
+                if constexpr (CF::SRK) { if (a.stage_save && row_ok) a.stage_save[(size_t)(n + 1) * BH + goff] = ynew[0]; }
                 if (row_ok && (!CF::SRK || stage == 2)) {
                     if (a.traj) a.traj[(size_t)(ns + 1) * BH + goff] = ynew[0];
                     if (a.dW_out) a.dW_out[(size_t)ns * BH + goff] = dw[t][0];
@@ -808,6 +811,7 @@ struct RevArgs {
     const float* traj;
     const float* act;
     const float* dW;
+    const float* dU;   // SRK: the space-time Levy integrals used by the forward
     const float* grad_ys;
     float* adj;
     float* delta;      // (N, NG, B, H) or null
@@ -1064,6 +1068,214 @@ int launch_rev(const RevArgs& a, hipStream_t stream) {
     return hipGetLastError() == hipSuccess ? SNSDE_OK : SNSDE_ERR_LAUNCH;
 }
 
+
+// =====================================================================================================
+// SRK (SRID2) adjoint on the MFMA path, M4 tiles.  The forward ran every solver step as three drift passes and saved,
+// per pass p = 3n + s, the layer activations (act_save[p]) — so the backward of a step is three transposed chains
+// (stage 2, 1, 0: same register-stationary chain as the Euler adjoint, relu masks and deltas indexed by pass) glued by
+// the elementwise reverse of the stage combinations:
+//     Fbar_s, Gbar_s <- a (alpha_s h, w_s) + the H0/H1 combinations of later stages,
+//     H1bar_s = Gbar_s dg/dy(t1_s, H1_s),   H0bar_s = J_f^T Fbar_s (the chain).
+// F_s, G_s, H0_s, H1_s are recomputed per lane from y_n, the saved pre-tanh drifts and (I_k, I_k0).  The diffusion-side
+// parameter sums (d/d sigmoid(theta), d/d s(t) at the stage times: rows 4n + slot) are left per workgroup as in the
+// Euler adjoint.
+// =====================================================================================================
+template <class CF>
+__global__ void __launch_bounds__(CF::NT, CF::WPS) snsde_mfma_srk_reverse_kernel(RevArgs a) {
+    static_assert(CF::FL == 1 && CF::NN == 0, "SRK adjoint: M4 tiles, elementwise diffusions");
+    constexpr int H = CF::H, TPW = 1, M = CF::M, NT = CF::NT, NHID = CF::NHID, NG = CF::NG;
+    constexpr int KUH = CF::KUH, LDA = CF::LDA, NSAVE = CF::NSAVE;
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int r = lane & 3, s = (lane >> 2) & 3, fsub = 4 * (lane >> 4);
+    const int row0 = blockIdx.x * M, B = a.B;
+    const int row = row0 + r, rowc = row < B ? row : B - 1;
+    const bool row_ok = row < B;
+    const size_t BH = (size_t)B * H;
+    const bool writer = (s == 0);
+    const bool s1 = (s == 1), s2 = (s == 2), s3 = (s == 3);
+    const int fcol = wave * 16 + fsub + s;
+    const size_t goff = (size_t)rowc * H + fcol;
+
+    Wt<CF::STREAM, KUH, TPW> wt[NG];
+#pragma unroll
+    for (int g = 0; g < NG; ++g) wt[g].load(a.ws + a.w_off[g], wave, lane);
+    for (int i = tid; i < NG * M * LDA; i += NT) lds[i] = 0.0f;
+
+    const float sig_theta = snsde_sigmoid(a.params[a.off_theta]);
+    const bool mul_y = (a.no == 13 || a.no == 17);
+    const bool dsum = a.ds_part != nullptr && a.gt != nullptr;
+    const float rowf = row_ok ? 1.0f : 0.0f;
+    const int rslot = a.row_out ? a.row_out[rowc] : -1;
+    const float gfin = a.row_out ? a.grad_ys[goff] : 0.0f;
+    float adj = 0.0f, th_acc = 0.0f;
+
+    // g = tanh(sigmoid(theta) nan_to_num(raw)), raw = s(t) or s(t) y;  returns g, sets dg/dy, the clipped raw and its finiteness
+    auto gfun = [&](float tv, float yy, float& gp, float& rc, bool& fin) {
+        const float raw = mul_y ? tv * yy : tv;
+        fin = (raw - raw == 0.0f);
+        rc = snsde_nan_to_num(raw);
+        const float g = fast_tanh(sig_theta * rc);
+        gp = (mul_y && fin) ? (1.0f - g * g) * sig_theta * tv : 0.0f;
+        return g;
+    };
+    auto quad_sum = [&](float v) {      // over the four rows of the tile (lanes differing in bits 0-1)
+        v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xf, 0xf, false));
+        v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xf, 0xf, false));
+        return v;
+    };
+    // one transposed chain: cotangent `cot` w.r.t. F of pass p (F = tanh(z * (GEO ? tanh(hin) : 1))); returns J_f^T cot for
+    // the own element (the tanh(y) gate's direct term included)
+    auto chain = [&](int p, float cot, float hin, float z, float F) {
+        float ty = 1.0f;
+        if constexpr (CF::GEO) ty = fast_tanh(hin);
+        const float dzt = cot * (1.0f - F * F);
+        const float dz = dzt * ty;
+        float direct = 0.0f;
+        if constexpr (CF::GEO) direct = dzt * z * (1.0f - ty * ty);
+        lds[r * LDA + fcol] = dz;
+        if (a.delta && row_ok) a.delta[((size_t)p * NG * B) * H + goff] = dz;
+        __syncthreads();
+        float d = 0.0f;
+        f32x4 acc[TPW], acc2[TPW];
+#pragma unroll
+        for (int g = 0; g < NG; ++g) {
+            acc[0] = acc2[0] = f32x4{0.f, 0.f, 0.f, 0.f};
+            gemm<1, KUH, TPW>(wt[g], lds + g * M * LDA + r * LDA + 4 * s, acc, acc2);
+            f32x4 v = acc[0] + acc2[0];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) v[i] = row_ror_add(v[i]);
+            if (g < NG - 1) {
+                if (writer) {
+                    const f32x4 zsv = *reinterpret_cast<const f32x4*>(
+                        a.act + (((size_t)p * NSAVE + (NHID - g)) * B + rowc) * H + wave * 16 + fsub);
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) v[i] = zsv[i] > 0.0f ? v[i] : 0.0f;
+                    *reinterpret_cast<f32x4*>(lds + (g + 1) * M * LDA + r * LDA + wave * 16 + fsub) = v;
+                    if (a.delta && row_ok)
+                        *reinterpret_cast<f32x4*>(a.delta + (((size_t)p * NG + g + 1) * B + row) * H + wave * 16 + fsub) = v;
+                }
+                __syncthreads();
+            } else {
+                d = v[0];
+                d = s1 ? v[1] : d; d = s2 ? v[2] : d; d = s3 ? v[3] : d;
+            }
+        }
+        return d + direct;
+    };
+
+    for (int n = a.N - 1; n >= 0; --n) {
+        const float* st = a.step_tab + (size_t)n * SNSDE_STEP_STRIDE;
+        const float h = st[1], rdt = st[6];
+        const int nout = __float_as_int(st[8]), kfirst = __float_as_int(st[9]);
+        float carry = 0.0f;
+        for (int k = kfirst; k < kfirst + nout; ++k) {
+            const float w0 = a.out_w[2 * k], w1 = a.out_w[2 * k + 1];
+            const float gk = a.row_out ? (rslot == k + 1 ? gfin : 0.0f) : a.grad_ys[(size_t)(k + 1) * BH + goff];
+            if (w0 == 0.0f) adj += gk;
+            else { adj = fmaf(w1, gk, adj); carry = fmaf(w0, gk, carry); }
+        }
+        if (row_ok) a.adj[(size_t)(n + 1) * BH + goff] = adj;
+        // ---- recompute the stage values of the step for the own element ----
+        const size_t so = (size_t)n * BH + goff;
+        const float y = a.traj[so], ik = a.dW[so], ik0 = a.dU[so];
+        const float z0 = a.act[(((size_t)(3 * n) * NSAVE + CF::ZSLOT) * B) * H + goff];
+        const float z1 = a.act[(((size_t)(3 * n + 1) * NSAVE + CF::ZSLOT) * B) * H + goff];
+        const float z2 = a.act[(((size_t)(3 * n + 2) * NSAVE + CF::ZSLOT) * B) * H + goff];
+        float t0v = 0.0f, t1v = 0.0f, t3v = 0.0f;
+        if (a.gt) {
+            const float* gp = a.gt + (size_t)n * 4 * H + fcol;
+            t0v = gp[0]; t1v = gp[H]; t3v = gp[3 * H];
+        }
+        auto gate = [&](float hv) { return CF::GEO ? fast_tanh(hv) : 1.0f; };
+        float g0p, g1p, g2p, g3p, rc0, rc1, rc2, rc3;
+        bool fi0, fi1, fi2, fi3;
+        const float f0 = fast_tanh(z0 * gate(y));
+        const float g0 = gfun(t0v, y, g0p, rc0, fi0);
+        const float h01 = y + f0 * h;
+        const float f1 = fast_tanh(z1 * gate(h01));
+        const float h11 = y + 0.25f * f0 * h + 0.5f * g0 * rdt;
+        const float g1 = gfun(t1v, h11, g1p, rc1, fi1);
+        const float h02 = y + 0.25f * f0 * h + 0.25f * f1 * h + g0 * ik0 / h + 0.5f * g1 * ik0 / h;
+        const float f2 = fast_tanh(z2 * gate(h02));
+        const float h12 = y + f0 * h - g0 * rdt;
+        const float g2 = gfun(t3v, h12, g2p, rc2, fi2);
+        const float h13 = y + 0.25f * f2 * h + (-5.0f * g0 + 3.0f * g1 + 0.5f * g2) * rdt;
+        const float g3 = gfun(t1v, h13, g3p, rc3, fi3);
+        // ---- reverse of the combination and of stage 3 / the diffusion half of stage 2 ----
+        const float av = adj;
+        const float ikk = 0.5f * (ik * ik - h);
+        const float ikkk = (ik * ik * ik - 3.0f * h * ik) / 6.0f;
+        const float a1 = ik, a2 = ikk / rdt, a3 = ik0 / h, a4 = ikkk / h;
+        const float w0 = -a1 - a2 + 2.0f * a3 - 2.0f * a4;
+        const float w1 = (4.0f / 3.0f) * a1 + (4.0f / 3.0f) * a2 - (4.0f / 3.0f) * a3 + (5.0f / 3.0f) * a4;
+        const float w2 = (2.0f / 3.0f) * a1 - (1.0f / 3.0f) * a2 - (2.0f / 3.0f) * a3 - (2.0f / 3.0f) * a4;
+        float yb = carry + av;
+        float fb0 = av * (h / 6.0f), fb1 = fb0, fb2 = av * (2.0f * h / 3.0f);
+        float gb0 = w0 * av, gb1 = w1 * av, gb2 = w2 * av;
+        const float gb3 = a4 * av;
+        float hb = gb3 * g3p;
+        yb += hb; fb2 = fmaf(0.25f * h, hb, fb2);
+        gb0 = fmaf(-5.0f * rdt, hb, gb0); gb1 = fmaf(3.0f * rdt, hb, gb1); gb2 = fmaf(0.5f * rdt, hb, gb2);
+        hb = gb2 * g2p;
+        yb += hb; fb0 = fmaf(h, hb, fb0); gb0 = fmaf(-rdt, hb, gb0);
+        // parameter side of G3 (slot 1, completed below with G1) and G2 (slot 3)
+        float ds1 = 0.0f;
+        if (dsum) {
+            const float c3 = gb3 * (1.0f - g3 * g3) * rowf, c2 = gb2 * (1.0f - g2 * g2) * rowf;
+            th_acc = fmaf(c3, rc3, fmaf(c2, rc2, th_acc));
+            ds1 = fi3 ? c3 * sig_theta * (mul_y ? h13 : 1.0f) : 0.0f;
+            const float ds3 = quad_sum(fi2 ? c2 * sig_theta * (mul_y ? h12 : 1.0f) : 0.0f);
+            if (r == 0) a.ds_part[((size_t)blockIdx.x * 4 * a.N + 4 * n + 3) * H + fcol] = ds3;
+        }
+        // ---- stage 2: drift at (t0 + h/2, H0_2) ----
+        float d = chain(3 * n + 2, fb2, h02, z2, f2);
+        yb += d;
+        fb0 = fmaf(0.25f * h, d, fb0); fb1 = fmaf(0.25f * h, d, fb1);
+        gb0 = fmaf(ik0 / h, d, gb0); gb1 = fmaf(0.5f * ik0 / h, d, gb1);
+        // ---- stage 1: diffusion at (t0 + h/4, H1_1), drift at (t0 + h, H0_1) ----
+        hb = gb1 * g1p;
+        yb += hb; fb0 = fmaf(0.25f * h, hb, fb0); gb0 = fmaf(0.5f * rdt, hb, gb0);
+        if (dsum) {
+            const float c1 = gb1 * (1.0f - g1 * g1) * rowf;
+            th_acc = fmaf(c1, rc1, th_acc);
+            ds1 += fi1 ? c1 * sig_theta * (mul_y ? h11 : 1.0f) : 0.0f;
+            ds1 = quad_sum(ds1);
+            if (r == 0) a.ds_part[((size_t)blockIdx.x * 4 * a.N + 4 * n + 1) * H + fcol] = ds1;
+        }
+        d = chain(3 * n + 1, fb1, h01, z1, f1);
+        yb += d; fb0 = fmaf(h, d, fb0);
+        // ---- stage 0: both at (t0, y) ----
+        yb = fmaf(gb0, g0p, yb);
+        if (dsum) {
+            const float c0 = gb0 * (1.0f - g0 * g0) * rowf;
+            th_acc = fmaf(c0, rc0, th_acc);
+            const float ds0 = quad_sum(fi0 ? c0 * sig_theta * (mul_y ? y : 1.0f) : 0.0f);
+            if (r == 0) {
+                a.ds_part[((size_t)blockIdx.x * 4 * a.N + 4 * n) * H + fcol] = ds0;
+                a.ds_part[((size_t)blockIdx.x * 4 * a.N + 4 * n + 2) * H + fcol] = 0.0f;   // slot t0 + h/2: no diffusion evaluation
+            }
+        }
+        d = chain(3 * n, fb0, y, z0, f0);
+        adj = yb + d;
+    }
+    if (row_ok) a.adj[goff] = adj + (a.row_out ? (rslot == 0 ? gfin : 0.0f) : a.grad_ys[goff]);
+    if (dsum && a.dth_part) {
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) th_acc += __shfl_down(th_acc, off, 64);
+        if (lane == 0) a.dth_part[blockIdx.x * CF::NW + wave] = th_acc;
+    }
+}
+
+template <class CF>
+int launch_rev_srk(const RevArgs& a, hipStream_t stream) {
+    const size_t lds_bytes = (size_t)CF::LDS_FLOATS * sizeof(float);
+    const int grid = (a.B + CF::M - 1) / CF::M;
+    hipLaunchKernelGGL(snsde_mfma_srk_reverse_kernel<CF>, dim3(grid), dim3(CF::NT), lds_bytes, stream, a);
+    return hipGetLastError() == hipSuccess ? SNSDE_OK : SNSDE_ERR_LAUNCH;
+}
+
 struct MfmaPlan {
     bool ok;
     int H, KUX, NHID, IO, FL, TPW, NW, FOLD, NN, SRK;
@@ -1077,7 +1289,7 @@ struct MfmaPlan {
 
 struct RevPlan {
     bool ok;
-    int H, NHID, GEO, FL, NW, NN, n_layers, fold_tmp, total_floats, emb;
+    int H, NHID, GEO, FL, NW, NN, SRK, n_layers, fold_tmp, total_floats, emb;
     int nwg;                    // workgroups of the adjoint launch
     size_t ds_off, dth_off;     // diffusion-side partial sums inside the backward workspace (0 = none)
     MfmaLayerPack layer[MAXL];
@@ -1145,6 +1357,14 @@ int dispatch_rev(const RevPlan& p, const RevArgs& a, hipStream_t st) {
     if (p.NHID == 1 && !p.GEO) return launch_rev<CfgR<H, 1, 0, FL>>(a, st);
     return SNSDE_ERR_UNSUPPORTED;
 #else
+    if (p.SRK) {
+        if constexpr (FL == 1) {
+#define SNSDE_RSRK(NH_) if (p.NHID == NH_) return p.GEO ? launch_rev_srk<CfgR<H, NH_, 1, 1>>(a, st) : launch_rev_srk<CfgR<H, NH_, 0, 1>>(a, st);
+            SNSDE_RSRK(0) SNSDE_RSRK(1) SNSDE_RSRK(2) SNSDE_RSRK(3)
+#undef SNSDE_RSRK
+        }
+        return SNSDE_ERR_UNSUPPORTED;
+    }
 #define SNSDE_RCASE(NH_) if (p.NHID == NH_) { \
         if (p.NN == 1) return launch_rev<CfgR<H, NH_, 0, FL, 1>>(a, st); \
         if (p.NN == 2) return launch_rev<CfgR<H, NH_, 0, FL, 2>>(a, st); \

@@ -256,7 +256,9 @@ struct GJob {     // C (M x N) = A . B^T (trans 0: A (M, K), B (N, K)) or A^T . 
 constexpr int MAX_GJOBS = 10;
 
 struct AArgs {
-    const float* params; const float* sums; const float* ds; const float* dth; const float* gt; const float* step_tab;
+    const float* params; const float* sums; const float* ds; const float* dth; const float* gt;
+    const float* tau;       // [sin t, cos t] of the rows of the time-only diffusion table: tau[row * tau_stride + {0, 1}]
+    int32_t tau_stride;
     float* dz1;       // (N, H) scratch: gradient at the hidden pre-activation of the time-only noise MLP
     float* dz2;       // (N, H) scratch: gradient at its output pre-activation
     float* a1;        // (N, H) scratch: its hidden activation
@@ -291,9 +293,9 @@ __global__ void __launch_bounds__(256) snsde_noise_hidden_kernel(AArgs a) {
     red[tid] = s;
     __syncthreads();
     if (hq == 0 && k < H) {
-        const float* st = a.step_tab + (size_t)n * SNSDE_STEP_STRIDE;
+        const float* st = a.tau + (size_t)n * a.tau_stride;
         const float* W1 = a.params + a.net.nt0.src_w;
-        const float z1 = fmaf(W1[2 * k], st[2], fmaf(W1[2 * k + 1], st[3], a.params[a.net.nt0.src_b + k]));
+        const float z1 = fmaf(W1[2 * k], st[0], fmaf(W1[2 * k + 1], st[1], a.params[a.net.nt0.src_b + k]));
         const float tot = (red[kl] + red[kl + 64]) + (red[kl + 128] + red[kl + 192]);
         a.a1[(size_t)n * H + k] = fmaxf(z1, 0.0f);
         a.dz1[(size_t)n * H + k] = z1 > 0.0f ? tot : 0.0f;
@@ -387,7 +389,7 @@ __global__ void __launch_bounds__(256) snsde_small_gemm_kernel(AArgs a) {
 }
 
 struct WPlan {
-    int ntiles, max_split, naux, ldx;
+    int ntiles, max_split, naux, ldx, n_pass, n_trow;
     size_t part_floats, sums_floats, ds_off, dth_off, dz1_off, dz2_off, a1_off, xaux_off, total_floats;
     bool tnoise, has_dth;
     int nact, xt;
@@ -407,7 +409,10 @@ bool make_wplan(const snsde_backward* b, const SnsdeNet& net, WPlan* w) {
     const int xt = (timef || nn > 0) ? 2 : 0;          // time columns present in the xaux rows
     const int naux = xt + (emb ? C : 0);
     const int nd = nhid + 2;                           // delta slots of the drift chain
-    const int R = s.n_steps * s.batch;
+    const bool srk = s.method == SNSDE_SRK;
+    const int n_pass = s.n_steps * (srk ? 3 : 1);      // drift passes (one per step, three for SRK): rows of act / delta
+    const int n_trow = s.n_steps * (srk ? 4 : 1);      // rows of the time-only diffusion table
+    const int R = n_pass * s.batch;
     AArgs& aa = w->aa;
     aa = AArgs{};
     int nt = 0;
@@ -476,7 +481,8 @@ bool make_wplan(const snsde_backward* b, const SnsdeNet& net, WPlan* w) {
     w->tnoise = (no == 12 || no == 13 || no == 16 || no == 17);
     const bool two = (no == 16 || no == 17);
     size_t o = w->sums_floats + w->part_floats;
-    const size_t NH = (size_t)s.n_steps * H;
+    const size_t NH = (size_t)n_trow * H;
+    w->n_pass = n_pass; w->n_trow = n_trow;
     w->ds_off = o; o += w->tnoise ? NH : 0;
     w->has_dth = w->tnoise || nn > 0;
     w->nact = nhid + 2 + nn;
@@ -489,7 +495,7 @@ bool make_wplan(const snsde_backward* b, const SnsdeNet& net, WPlan* w) {
     w->naux = naux; w->ldx = (naux + 3) & ~3;
     w->xaux_off = o; o += (size_t)R * w->ldx;
     w->total_floats = o + 16;
-    aa.net = net; aa.H = H; aa.C = C; aa.N = s.n_steps; aa.io = io; aa.no = no; aa.nhid = nhid; aa.has_dth = w->has_dth ? 1 : 0;
+    aa.net = net; aa.H = H; aa.C = C; aa.N = n_trow; aa.io = io; aa.no = no; aa.nhid = nhid; aa.has_dth = w->has_dth ? 1 : 0;
     return true;
 }
 
@@ -510,12 +516,19 @@ int snsde_wgrad_launch(const snsde_backward* b, const SnsdeNet& net, float* grad
     WArgs a{};
     a.delta = b->delta_save; a.act = s.act_save; a.traj = s.traj; a.xaux = ws + wp->xaux_off;
     a.sums = ws; a.part = ws + wp->sums_floats;
-    a.B = s.batch; a.H = H; a.N = s.n_steps; a.NG = wp->nact; a.NSAVE = wp->nact;
-    a.ldx = wp->ldx; a.R = s.n_steps * s.batch; a.ntiles = wp->ntiles;
+    const bool srk = s.method == SNSDE_SRK;
+    const float* pass_tab = s.step_tab;            // one row per drift pass: time features and spline interval
+    if (srk) {
+        pass_tab = snsde_mfma_srk_pass_table(&s, net);
+        if (!pass_tab || !s.stage_save || !s.srk_tab) return SNSDE_ERR_NULL;
+        a.traj = s.stage_save;                     // first-layer inputs = the stage states
+    }
+    a.B = s.batch; a.H = H; a.N = wp->n_pass; a.NG = wp->nact; a.NSAVE = wp->nact;
+    a.ldx = wp->ldx; a.R = wp->n_pass * s.batch; a.ntiles = wp->ntiles;
     for (int i = 0; i < wp->ntiles; ++i) a.tile[i] = wp->tile[i];
     if (wp->naux > 0) {
         XArgs x{};
-        x.coeffs = s.coeffs; x.step_tab = s.step_tab; x.xaux = ws + wp->xaux_off;
+        x.coeffs = s.coeffs; x.step_tab = pass_tab; x.xaux = ws + wp->xaux_off;
         x.B = s.batch; x.C = C; x.Lm1 = s.knots - 1; x.time_cols = wp->xt; x.naux = wp->naux; x.ldx = wp->ldx; x.R = a.R;
         const size_t total = (size_t)a.R * wp->ldx;
         hipLaunchKernelGGL(snsde_xaux_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, x);
@@ -535,7 +548,9 @@ int snsde_wgrad_launch(const snsde_backward* b, const SnsdeNet& net, float* grad
     float* ds = ws + wp->ds_off;
     aa.params = s.params; aa.sums = ws; aa.ds = ds; aa.dth = ws + wp->dth_off;
     aa.dz1 = ws + wp->dz1_off; aa.dz2 = ws + wp->dz2_off; aa.a1 = ws + wp->a1_off;
-    aa.gt = gt; aa.step_tab = s.step_tab; aa.grad = grad_params; aa.P = n_params;
+    aa.gt = gt; aa.grad = grad_params; aa.P = n_params;
+    aa.tau = srk ? s.srk_tab + 1 : s.step_tab + 2;
+    aa.tau_stride = srk ? SNSDE_SRK_STRIDE : SNSDE_STEP_STRIDE;
     const bool two = (no == 16 || no == 17);
     if (wp->has_dth) {
         int nwg = 0, waves = 0; size_t ds_off = 0, dth_off = 0;
@@ -544,10 +559,10 @@ int snsde_wgrad_launch(const snsde_backward* b, const SnsdeNet& net, float* grad
         const float* bws = static_cast<const float*>(b->workspace);
         DArgs d{};
         d.ds_part = bws + ds_off; d.dth_part = bws + dth_off; d.ds = ds; d.dth = ws + wp->dth_off;
-        d.nwg = nwg; d.n_dth = nwg * waves; d.NH = wp->tnoise ? s.n_steps * H : 0;
+        d.nwg = nwg; d.n_dth = nwg * waves; d.NH = wp->tnoise ? wp->n_trow * H : 0;
         hipLaunchKernelGGL(snsde_dsum_reduce_kernel, dim3((d.NH + 63) / 64 + 1), dim3(256), 0, stream, d);
         if (two)
-            hipLaunchKernelGGL(snsde_noise_hidden_kernel, dim3(s.n_steps, (H + 63) / 64), dim3(256), (H + 256) * sizeof(float),
+            hipLaunchKernelGGL(snsde_noise_hidden_kernel, dim3(wp->n_trow, (H + 63) / 64), dim3(256), (H + 256) * sizeof(float),
                                stream, aa);
     }
     // small products straight into the flat gradient (after the assemble kernel has written every other entry)
@@ -574,13 +589,13 @@ int snsde_wgrad_launch(const snsde_backward* b, const SnsdeNet& net, float* grad
         maxM = H; maxN = Kin > H ? Kin : H;
     }
     if (wp->tnoise) {
-        const float* tau = s.step_tab + 2;
+        const float* tau = aa.tau;
         const float* src = two ? aa.dz1 : ds;          // gradient at the output of noise_t(.0)
-        add_job(src, H, tau, SNSDE_STEP_STRIDE, grad_params + net.nt0.src_w, 2, H, 2, s.n_steps, 1, nullptr, nullptr);
-        add_job(src, H, nullptr, 0, grad_params + net.nt0.src_b, 1, H, 1, s.n_steps, 1, nullptr, nullptr);
+        add_job(src, H, tau, aa.tau_stride, grad_params + net.nt0.src_w, 2, H, 2, wp->n_trow, 1, nullptr, nullptr);
+        add_job(src, H, nullptr, 0, grad_params + net.nt0.src_b, 1, H, 1, wp->n_trow, 1, nullptr, nullptr);
         if (two) {
-            add_job(aa.dz2, H, aa.a1, H, grad_params + net.nt1.src_w, H, H, H, s.n_steps, 1, nullptr, nullptr);
-            add_job(aa.dz2, H, nullptr, 0, grad_params + net.nt1.src_b, 1, H, 1, s.n_steps, 1, nullptr, nullptr);
+            add_job(aa.dz2, H, aa.a1, H, grad_params + net.nt1.src_w, H, H, H, wp->n_trow, 1, nullptr, nullptr);
+            add_job(aa.dz2, H, nullptr, 0, grad_params + net.nt1.src_b, 1, H, 1, wp->n_trow, 1, nullptr, nullptr);
         }
         if (H > maxM) maxM = H;
         if (H > maxN) maxN = H;

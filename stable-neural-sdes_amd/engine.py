@@ -188,11 +188,14 @@ class SolveCall:
         self.ys = torch.empty((B, H) if row_out is not None else (grid.T, B, H), device=dev, dtype=torch.float32)
         self.traj = torch.empty((grid.N + 1, B, H), device=dev, dtype=torch.float32) if save_traj else None
         self.dW_out = torch.empty((grid.N, B, H), device=dev, dtype=torch.float32) if save_dW else None
-        self.act_save = None
+        self.act_save = self.stage_save = None
         if save_act:
             slots = _lib.lib().snsde_act_slots(C.byref(model))
             _lib.check(min(slots, 0), 'snsde_act_slots')
-            self.act_save = torch.empty((grid.N, slots, B, H), device=dev, dtype=torch.float32)
+            passes = 3 * grid.N if method == 'srk' else grid.N      # SRK: three drift passes per step
+            self.act_save = torch.empty((passes, slots, B, H), device=dev, dtype=torch.float32)
+            if method == 'srk':
+                self.stage_save = torch.empty((passes + 1, B, H), device=dev, dtype=torch.float32)
         s = _lib.Solve()
         s.model = model
         s.batch, s.knots, s.n_steps, s.n_out = B, L, grid.N, grid.T
@@ -218,6 +221,7 @@ class SolveCall:
         s.y0, s.dW, s.ys = _ptr(y0), _ptr(dW), _ptr(self.ys)
         s.traj, s.dW_out = _ptr(self.traj), _ptr(self.dW_out)
         s.act_save = _ptr(self.act_save)
+        s.stage_save = _ptr(self.stage_save)
         s.row_out = _ptr(row_out)
         nbytes = _lib.lib().snsde_workspace_bytes(C.byref(s))
         self.workspace = torch.empty(max(nbytes, 256), device=dev, dtype=torch.uint8)

@@ -544,6 +544,25 @@ def test_backward_matches_fp64_autograd_through_the_unrolled_loop(ci, kernel):
     _check_backward(500 + ci, io, no, NL, B, H, C, L, ts, dt, method, kernel)
 
 
+SRK_BWD_CASES = [
+    # io, no, NL, B, H, C, L, ts, dt     (MFMA SRK forward + MFMA SRK adjoint + native parameter pass)
+    (4, 17, 2, 11, 32, 5, 9, [0, 3.5, 8], 1.0),
+    (6, 17, 3, 9, 64, 3, 9, [0, 8], 0.5),
+    (2, 16, 1, 9, 16, 2, 12, None, 0.05),
+    (1, 0, 2, 7, 32, 3, 8, [0, 7], 1.0),
+    (3, 13, 2, 10, 64, 3, 8, [0, 2.5, 7], 1.0),
+    (5, 12, 4, 6, 128, 3, 7, [0, 6], 1.0),
+    (4, 17, 2, 21, 128, 21, 9, [0, 8], 1.0),
+]
+
+
+@pytest.mark.parametrize('kernel', ['mfma4', 'auto'])
+@pytest.mark.parametrize('ci', range(len(SRK_BWD_CASES)))
+def test_srk_backward_on_the_mfma_path(ci, kernel):
+    io, no, NL, B, H, C, L, ts, dt = SRK_BWD_CASES[ci]
+    _check_backward(4000 + ci, io, no, NL, B, H, C, L, ts, dt, 'srk', kernel)
+
+
 @pytest.mark.parametrize('io', [1, 2, 3, 4, 5, 6])
 @pytest.mark.parametrize('no', [0, 12, 13, 16, 17])
 def test_backward_sweep_mfma_options(io, no):
