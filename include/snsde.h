@@ -121,7 +121,7 @@ typedef struct snsde_solve {
     int32_t  knots;        /* L: len(times); coeffs has L-1 intervals                            */
     int32_t  n_steps;      /* N (snsde_grid_count)                                               */
     int32_t  n_out;        /* T = len(ts)                                                        */
-    int32_t  method;       /* SNSDE_EULER | SNSDE_MILSTEIN                                       */
+    int32_t  method;       /* SNSDE_EULER | SNSDE_MILSTEIN | SNSDE_SRK                           */
     int32_t  kernel;       /* SNSDE_KERNEL_*                                                     */
     int32_t  flags;        /* SNSDE_FLAG_*                                                       */
     int32_t  reserved;     /* must be 0                                                          */
@@ -142,7 +142,8 @@ typedef struct snsde_solve {
     const float*   dU;        /* device (N, B, H) supplied space-time Levy integrals I_k0 (SRK with   */
                               /* supplied dW), or NULL: h*(dW/2 + sqrt(h/12) xi), xi from Philox      */
     float*         dU_out;    /* optional device (N, B, H): the I_k0 actually used                    */
-    float*         act_save;  /* optional device (N, snsde_act_slots, B, H): per-step activations */
+    float*         act_save;  /* optional device (N, snsde_act_slots, B, H): per-step activations the MFMA adjoint */
+                              /* needs (training mode; see snsde_solve_backward)                                   */
     float*         stage_save;/* SRK training on the MFMA path: optional device (3N + 1, B, H), the input state of every   */
                               /* drift pass (act_save / delta_save are then indexed by pass, 3N of them)                */
     const uint64_t* seed_dev; /* optional device pointer to the Philox key: read when the kernel starts and used  */
@@ -151,7 +152,6 @@ typedef struct snsde_solve {
     const int32_t* row_out;   /* optional device (B): per-row output selection (the gather of NeuralSDE.forward,  */
                               /* neuralsde.py:115-116).  When set, ys is (B, H) with ys[b] = the solution at      */
                               /* ts[row_out[b]] (0 <= row_out[b] < n_out), and the backward's grad_ys is (B, H).  */
-                              /* the backward pass needs (MFMA path only, see snsde_solve_backward)*/
     void*          workspace; /* device scratch, >= snsde_workspace_bytes()                      */
     size_t         workspace_bytes;
 } snsde_solve;
