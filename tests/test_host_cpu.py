@@ -446,3 +446,20 @@ def test_srk_rows_step_equals_the_loop_step():
         want = T._srk_step(m.f, m.g, torch.tensor(float(grid.t0[n]), dtype=torch.float64), torch.tensor(1.0, dtype=torch.float64),
                            Y, I_k, I_k0)
     assert torch.allclose(got, want, rtol=1e-6, atol=1e-7)
+
+
+def test_ctypes_structs_follow_the_header_field_order():
+    """_lib.Solve / _lib.Backward and the stub printed in INTEGRATION.md must list the fields of the C structs in order."""
+    hdr = open(os.path.join(ROOT, 'include', 'snsde.h')).read()
+
+    def fields(struct):
+        body = re.search(r'typedef struct %s \{(.*?)\} %s;' % (struct, struct), hdr, re.S).group(1)
+        body = re.sub(r'/\*.*?\*/', '', body, flags=re.S)
+        return [re.search(r'(\w+)\s*$', line.strip().rstrip(';')).group(1) for line in body.split('\n') if line.strip().endswith(';')]
+
+    assert fields('snsde_solve') == [n for n, _ in _lib.Solve._fields_]
+    assert fields('snsde_backward') == [n for n, _ in _lib.Backward._fields_]
+    assert fields('snsde_model') == [n for n, _ in _lib.Model._fields_]
+    doc = open(os.path.join(ROOT, 'INTEGRATION.md')).read()
+    stub = re.findall(r'"(\w+)"', re.search(r'\("params".*?"workspace"\)', doc, re.S).group(0))
+    assert stub == [n for n, t in _lib.Solve._fields_ if t is C.c_void_p]
