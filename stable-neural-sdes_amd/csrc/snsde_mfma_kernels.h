@@ -1127,7 +1127,19 @@ __global__ void __launch_bounds__(CF::NT, CF::WPS) snsde_mfma_srk_reverse_kernel
     };
     // one transposed chain: cotangent `cot` w.r.t. F of pass p (F = tanh(z * (GEO ? tanh(hin) : 1))); returns J_f^T cot for
     // the own element (the tanh(y) gate's direct term included)
+    // relu masks of a pass are fetched while the previous chain runs (their HBM latency would otherwise sit between
+    // the GEMMs of every chain)
+    f32x4 mk[NG - 1], mk_next[NG - 1];
+    auto load_masks = [&](int p, f32x4 (&dst)[NG - 1]) {
+        if (writer) {
+#pragma unroll
+            for (int g = 0; g < NG - 1; ++g)
+                dst[g] = *reinterpret_cast<const f32x4*>(a.act + (((size_t)p * NSAVE + (NHID - g)) * B + rowc) * H + wave * 16 + fsub);
+        }
+    };
+    load_masks(3 * a.N - 1, mk);
     auto chain = [&](int p, float cot, float hin, float z, float F) {
+        if (p > 0) load_masks(p - 1, mk_next);
         float ty = 1.0f;
         if constexpr (CF::GEO) ty = fast_tanh(hin);
         const float dzt = cot * (1.0f - F * F);
@@ -1148,8 +1160,7 @@ __global__ void __launch_bounds__(CF::NT, CF::WPS) snsde_mfma_srk_reverse_kernel
             for (int i = 0; i < 4; ++i) v[i] = row_ror_add(v[i]);
             if (g < NG - 1) {
                 if (writer) {
-                    const f32x4 zsv = *reinterpret_cast<const f32x4*>(
-                        a.act + (((size_t)p * NSAVE + (NHID - g)) * B + rowc) * H + wave * 16 + fsub);
+                    const f32x4 zsv = mk[g];
 #pragma unroll
                     for (int i = 0; i < 4; ++i) v[i] = zsv[i] > 0.0f ? v[i] : 0.0f;
                     *reinterpret_cast<f32x4*>(lds + (g + 1) * M * LDA + r * LDA + wave * 16 + fsub) = v;
@@ -1162,10 +1173,31 @@ __global__ void __launch_bounds__(CF::NT, CF::WPS) snsde_mfma_srk_reverse_kernel
                 d = s1 ? v[1] : d; d = s2 ? v[2] : d; d = s3 ? v[3] : d;
             }
         }
+#pragma unroll
+        for (int g = 0; g < NG - 1; ++g) mk[g] = mk_next[g];
         return d + direct;
     };
 
+    // per-step inputs (state, increments, saved pre-tanh drifts, table rows) are fetched one step ahead
+    struct SrkIn { float y, ik, ik0, z0, z1, z2, t0v, t1v, t3v; };
+    auto fetch = [&](int n, SrkIn& q) {
+        const size_t so = (size_t)n * BH + goff;
+        q.y = a.traj[so]; q.ik = a.dW[so]; q.ik0 = a.dU[so];
+        q.z0 = a.act[(((size_t)(3 * n) * NSAVE + CF::ZSLOT) * B) * H + goff];
+        q.z1 = a.act[(((size_t)(3 * n + 1) * NSAVE + CF::ZSLOT) * B) * H + goff];
+        q.z2 = a.act[(((size_t)(3 * n + 2) * NSAVE + CF::ZSLOT) * B) * H + goff];
+        q.t0v = q.t1v = q.t3v = 0.0f;
+        if (a.gt) {
+            const float* gp = a.gt + (size_t)n * 4 * H + fcol;
+            q.t0v = gp[0]; q.t1v = gp[H]; q.t3v = gp[3 * H];
+        }
+    };
+    SrkIn cur, nxt;
+    fetch(a.N - 1, cur);
+
     for (int n = a.N - 1; n >= 0; --n) {
+        nxt = cur;
+        if (n > 0) fetch(n - 1, nxt);
         const float* st = a.step_tab + (size_t)n * SNSDE_STEP_STRIDE;
         const float h = st[1], rdt = st[6];
         const int nout = __float_as_int(st[8]), kfirst = __float_as_int(st[9]);
@@ -1178,16 +1210,8 @@ __global__ void __launch_bounds__(CF::NT, CF::WPS) snsde_mfma_srk_reverse_kernel
         }
         if (row_ok) a.adj[(size_t)(n + 1) * BH + goff] = adj;
         // ---- recompute the stage values of the step for the own element ----
-        const size_t so = (size_t)n * BH + goff;
-        const float y = a.traj[so], ik = a.dW[so], ik0 = a.dU[so];
-        const float z0 = a.act[(((size_t)(3 * n) * NSAVE + CF::ZSLOT) * B) * H + goff];
-        const float z1 = a.act[(((size_t)(3 * n + 1) * NSAVE + CF::ZSLOT) * B) * H + goff];
-        const float z2 = a.act[(((size_t)(3 * n + 2) * NSAVE + CF::ZSLOT) * B) * H + goff];
-        float t0v = 0.0f, t1v = 0.0f, t3v = 0.0f;
-        if (a.gt) {
-            const float* gp = a.gt + (size_t)n * 4 * H + fcol;
-            t0v = gp[0]; t1v = gp[H]; t3v = gp[3 * H];
-        }
+        const float y = cur.y, ik = cur.ik, ik0 = cur.ik0, z0 = cur.z0, z1 = cur.z1, z2 = cur.z2;
+        const float t0v = cur.t0v, t1v = cur.t1v, t3v = cur.t3v;
         auto gate = [&](float hv) { return CF::GEO ? fast_tanh(hv) : 1.0f; };
         float g0p, g1p, g2p, g3p, rc0, rc1, rc2, rc3;
         bool fi0, fi1, fi2, fi3;
@@ -1259,6 +1283,7 @@ __global__ void __launch_bounds__(CF::NT, CF::WPS) snsde_mfma_srk_reverse_kernel
         }
         d = chain(3 * n, fb0, y, z0, f0);
         adj = yb + d;
+        cur = nxt;
     }
     if (row_ok) a.adj[goff] = adj + (a.row_out ? (rslot == 0 ? gfin : 0.0f) : a.grad_ys[goff]);
     if (dsum && a.dth_part) {
