@@ -678,7 +678,8 @@ def test_backward_unsupported_configurations_raise():
 
 
 @pytest.mark.parametrize('kernel,method,io,no', [('mfma4', 'euler', 4, 17), ('mfma16', 'milstein', 6, 17), ('generic', 'euler', 2, 7),
-                                                  ('generic', 'srk', 4, 17), ('mfma4', 'euler', 3, 18)])
+                                                  ('generic', 'srk', 4, 17), ('mfma4', 'euler', 3, 18),
+                                                  ('mfma4', 'srk', 6, 17), ('auto', 'srk', 2, 16)])
 def test_per_row_output_selection_equals_gather(kernel, method, io, no):
     """options['row_out'] (per-row output slot, fused into the solve) == solving for every output and gathering
     (the per-row selection of NeuralSDE.forward, neuralsde.py:115-116), forward and backward, bit for bit."""
@@ -693,7 +694,7 @@ def test_per_row_output_selection_equals_gather(kernel, method, io, no):
         m.load_state_dict({k: torch.from_numpy(v.copy()) for k, v in pr['params'].items()})
         m = m.to(DEV)
         m.set_X(torch.from_numpy(pr['coeffs']).to(DEV), torch.from_numpy(pr['times']).to(DEV))
-        grad = method != 'srk'
+        grad = True
         y0 = torch.from_numpy(pr['y0']).to(DEV).requires_grad_(grad)
         opts = {'seed': 9, 'kernel': kernel}
         with torch.set_grad_enabled(grad):
