@@ -42,11 +42,12 @@ __global__ void snsde_pack_kernel(const float* __restrict__ params, float* __res
 // (relu applied for 16/17).
 __global__ void snsde_time_table_kernel(const float* __restrict__ params, const float* __restrict__ step_tab,
                                         float* __restrict__ gt, SnsdeLayer nt0, SnsdeLayer nt1, int H, int no,
-                                        int row_stride, int sin_col) {
+                                        int row_stride, int sin_col, int off_sigma = -1, int off_sigma_diag = -1) {
     extern __shared__ float hbuf[];
     const int n = blockIdx.x;   // one block per table row (a solver step, or an SRK stage time)
-    const float sn = step_tab[(size_t)n * row_stride + sin_col], cs = step_tab[(size_t)n * row_stride + sin_col + 1];
-    snsde_time_table_row(params, sn, cs, gt + (size_t)n * H, nt0, nt1, H, no, hbuf);
+    const float* st = step_tab + (size_t)n * row_stride;
+    snsde_time_table_row(params, st[0], st[sin_col], st[sin_col + 1], gt + (size_t)n * H, nt0, nt1, H, no, hbuf, off_sigma,
+                         off_sigma_diag);
 }
 
 struct GenericArgs {
@@ -1061,11 +1062,11 @@ int snsde_time_table_launch(const float* params, const float* step_tab, float* g
     return hipGetLastError() == hipSuccess ? SNSDE_OK : SNSDE_ERR_LAUNCH;
 }
 
-int snsde_time_table_srk_launch(const float* params, const float* srk_tab, float* gt, const SnsdeLayer& nt0,
-                                const SnsdeLayer& nt1, int H, int no, int n_rows, hipStream_t stream) {
+int snsde_time_table_srk_launch(const float* params, const float* srk_tab, float* gt, const SnsdeNet& net, int H, int no,
+                                int n_rows, hipStream_t stream) {
     // time-only diffusion at the stage times of every step: gt[(n*4 + slot)][H], rows of the SRK stage table
     hipLaunchKernelGGL(snsde_time_table_kernel, dim3(n_rows), dim3(128), H * sizeof(float), stream, params, srk_tab,
-                       gt, nt0, nt1, H, no, SNSDE_SRK_STRIDE, 1);
+                       gt, net.nt0, net.nt1, H, no, SNSDE_SRK_STRIDE, 1, net.off_sigma, net.off_sigma_diag);
     return hipGetLastError() == hipSuccess ? SNSDE_OK : SNSDE_ERR_LAUNCH;
 }
 

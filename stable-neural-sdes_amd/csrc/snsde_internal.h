@@ -55,8 +55,8 @@ int snsde_generic_backward_launch(const snsde_backward* b, const SnsdeNet& net, 
 int snsde_srk_launch(const snsde_solve* s, const SnsdeNet& net, hipStream_t stream);
 int snsde_time_table_launch(const float* params, const float* step_tab, float* gt, const SnsdeLayer& nt0,
                             const SnsdeLayer& nt1, int H, int no, int n_steps, hipStream_t stream);
-int snsde_time_table_srk_launch(const float* params, const float* srk_tab, float* gt, const SnsdeLayer& nt0,
-                                const SnsdeLayer& nt1, int H, int no, int n_rows, hipStream_t stream);
+int snsde_time_table_srk_launch(const float* params, const float* srk_tab, float* gt, const SnsdeNet& net, int H, int no,
+                                int n_rows, hipStream_t stream);
 // launchers (snsde_mfma.hip)
 bool snsde_mfma_supported(const snsde_solve* s, const SnsdeNet& net);
 size_t snsde_mfma_workspace_floats(const snsde_solve* s, const SnsdeNet& net);
@@ -145,9 +145,22 @@ __device__ __forceinline__ void snsde_philox_normal4(uint64_t seed, uint32_t row
 
 // Time-only part of the diffusion for noise_option 12,13,16,17 (neuralsde.py:266-277), one table row:
 // gt[j] = noise_t([sn, cs])[j] (relu applied for 16/17).  Block-cooperative; hbuf = H floats of LDS.
-__device__ __forceinline__ void snsde_time_table_row(const float* __restrict__ params, float sn, float cs,
+// Row n of the time-only diffusion table: the part of `raw` (neuralsde.py:233-288) that does not depend on y —
+// noise_t(tau_n) for 12/13/16/17, and for the closed forms that are (function of t) x {1, y}:
+//   1/2/3: exp(sigma) {1, t, 1}   4/5/6: exp(sigma_diag[j]) {1, t, 1}   11: t      (3, 6, 11 multiply by y in the kernel)
+__device__ __forceinline__ void snsde_time_table_row(const float* __restrict__ params, float t, float sn, float cs,
                                                      float* __restrict__ gt, const SnsdeLayer& nt0, const SnsdeLayer& nt1,
-                                                     int H, int no, float* hbuf) {
+                                                     int H, int no, float* hbuf, int off_sigma, int off_sigma_diag) {
+    if (no <= 11) {
+        for (int j = threadIdx.x; j < H; j += blockDim.x) {
+            float v = 1.0f;
+            if (no >= 1 && no <= 3) v = expf(params[off_sigma]);
+            else if (no >= 4 && no <= 6) v = expf(params[off_sigma_diag + j]);
+            if (no == 2 || no == 5 || no == 11) v *= t;
+            gt[j] = v;
+        }
+        return;
+    }
     const bool two = (no == 16 || no == 17);
     for (int j = threadIdx.x; j < H; j += blockDim.x) {
         const float v = fmaf(cs, params[nt0.src_w + 2 * j + 1], sn * params[nt0.src_w + 2 * j]) + params[nt0.src_b + j];

@@ -76,8 +76,9 @@ __global__ void snsde_fold_kernel(const float* __restrict__ params, float* __res
     if (pc == 2) {
         const int n = blockIdx.x;
         if (!job.tab_on || n >= job.n_steps) return;
-        const float sn = job.step_tab[(size_t)n * SNSDE_STEP_STRIDE + 2], cs = job.step_tab[(size_t)n * SNSDE_STEP_STRIDE + 3];
-        snsde_time_table_row(params, sn, cs, ws + job.tab_off + (size_t)n * H, job.nt0, job.nt1, H, job.no, erow);
+        const float* st = job.step_tab + (size_t)n * SNSDE_STEP_STRIDE;
+        snsde_time_table_row(params, st[0], st[2], st[3], ws + job.tab_off + (size_t)n * H, job.nt0, job.nt1, H, job.no, erow,
+                             job.off_sigma, job.off_sigma_diag);
         return;
     }
     const int f = blockIdx.x;
@@ -136,7 +137,9 @@ MfmaPlan make_plan(const snsde_solve* s, const SnsdeNet& net, int flavor_hint) {
     if (!(H == 256 || H == 128 || H == 64 || H == 32 || H == 16)) return p;
     if (!(io >= 1 && io <= 6)) return p;
     const bool noise_net = (no == 14 || no == 15 || no == 18 || no == 19);
-    if (!(no == 0 || no == 12 || no == 13 || no == 16 || no == 17 || noise_net)) return p;
+    // table noise: raw = (row of a per-step table) x {1, y}: the time-only noise MLPs and the closed forms in t, sigma
+    const bool tab_noise = (no >= 1 && no <= 6) || no == 11 || no == 12 || no == 13 || no == 16 || no == 17;
+    if (!(no == 0 || tab_noise || noise_net)) return p;
     if (noise_net && !(io == 1 || io == 3)) return p;
     if (noise_net && s->method != SNSDE_EULER) return p;
     if (srk && (m.input_channels > 32 && (io == 2 || io == 4 || io == 6))) return p;
@@ -192,7 +195,7 @@ MfmaPlan make_plan(const snsde_solve* s, const SnsdeNet& net, int flavor_hint) {
     p.bias_off = off;
     off += rows * H;
     off = (off + 3) & ~3;
-    p.gt_off = (no == 12 || no == 13 || no == 16 || no == 17) ? off : -1;
+    p.gt_off = tab_noise ? off : -1;
     if (p.gt_off >= 0) off += s->n_steps * H * (srk ? 4 : 1);     // SRK: the four stage times of every step
     p.srk_tab_off = -1;
     if (srk) { p.srk_tab_off = off; off += 3 * s->n_steps * SNSDE_STEP_STRIDE; }
@@ -287,6 +290,7 @@ int snsde_mfma_launch(const snsde_solve* s, const SnsdeNet& net, hipStream_t str
             }
             fj.tab_on = p.gt_off >= 0 && !p.SRK; fj.tab_off = p.gt_off; fj.n_steps = s->n_steps; fj.no = s->model.noise_option;
             fj.nt0 = net.nt0; fj.nt1 = net.nt1; fj.step_tab = s->step_tab;
+            fj.off_sigma = net.off_sigma; fj.off_sigma_diag = net.off_sigma_diag;
             const int gx = fj.tab_on && s->n_steps > p.H ? s->n_steps : p.H;
             hipLaunchKernelGGL(snsde_fold_kernel, dim3(gx, fj.tab_on ? 3 : 2), dim3(256), 2 * p.H * sizeof(float), stream,
                                s->params, ws, fj);
@@ -297,7 +301,7 @@ int snsde_mfma_launch(const snsde_solve* s, const SnsdeNet& net, hipStream_t str
             hipLaunchKernelGGL(snsde_srk_expand_kernel, dim3((3 * s->n_steps + 127) / 128), dim3(128), 0, stream, s->step_tab,
                                s->srk_tab, ws + p.srk_tab_off, s->n_steps);
             if (p.gt_off >= 0) {
-                const int rc = snsde_time_table_srk_launch(s->params, s->srk_tab, ws + p.gt_off, net.nt0, net.nt1, p.H,
+                const int rc = snsde_time_table_srk_launch(s->params, s->srk_tab, ws + p.gt_off, net, p.H,
                                                            s->model.noise_option, s->n_steps * 4, stream);
                 if (rc) return rc;
             }

@@ -57,7 +57,7 @@ struct FoldJob {
     int32_t src_w[2], K[2], col[2], tmp[2];
     int32_t b_in, b_init, b_emb, bias_tmp;
     // time-only diffusion table built by the same launch (blockIdx.y == 2): gt[n][H] for n < n_steps
-    int32_t tab_on, tab_off, n_steps, no, fold_on;
+    int32_t tab_on, tab_off, n_steps, no, fold_on, off_sigma, off_sigma_diag;
     SnsdeLayer nt0, nt1;
     const float* step_tab;
 };
@@ -364,7 +364,7 @@ __global__ void __launch_bounds__(CF::NT, CF::WPS) snsde_mfma_kernel(MfmaArgs a)
     const float* arow = bufA + r * LDA + 4 * s;
     const float* brow = bufB + r * LDA + 4 * s;
     const bool writer = FL ? (s == 0) : true;
-    const bool mul_y = (no == 13 || no == 17 || no == 15 || no == 19);
+    const bool mul_y = (no == 13 || no == 17 || no == 15 || no == 19 || no == 3 || no == 6 || no == 11);
     const bool s1 = (s == 1), s2 = (s == 2), s3 = (s == 3);
     const float mil = (a.method == SNSDE_MILSTEIN) ? 0.5f : 0.0f;
     const uint32_t grow = (uint32_t)(a.row_offset + row);
@@ -848,7 +848,7 @@ __global__ void __launch_bounds__(CF::NT, CF::WPS) snsde_mfma_reverse_kernel(Rev
     for (int i = tid; i < NG * M * LDA; i += NT) lds[i] = 0.0f;
 
     const float sig_theta = snsde_sigmoid(a.params[a.off_theta]);
-    const bool mul_y = (a.no == 13 || a.no == 17 || a.no == 15 || a.no == 19);
+    const bool mul_y = (a.no == 13 || a.no == 17 || a.no == 15 || a.no == 19 || a.no == 3 || a.no == 6 || a.no == 11);
     const float mil = (a.method == SNSDE_MILSTEIN) ? 0.5f : 0.0f;
 
     auto fill_rows = [&](int base) {
@@ -1104,7 +1104,7 @@ __global__ void __launch_bounds__(CF::NT, CF::WPS) snsde_mfma_srk_reverse_kernel
     for (int i = tid; i < NG * M * LDA; i += NT) lds[i] = 0.0f;
 
     const float sig_theta = snsde_sigmoid(a.params[a.off_theta]);
-    const bool mul_y = (a.no == 13 || a.no == 17);
+    const bool mul_y = (a.no == 13 || a.no == 17 || a.no == 3 || a.no == 6 || a.no == 11);
     const bool dsum = a.ds_part != nullptr && a.gt != nullptr;
     const float rowf = row_ok ? 1.0f : 0.0f;
     const int rslot = a.row_out ? a.row_out[rowc] : -1;

@@ -248,6 +248,35 @@ __global__ void __launch_bounds__(256) snsde_dsum_reduce_kernel(DArgs a) {
     if (q == 0 && e < a.NH) a.ds[e] = (red[tid] + red[tid + 64]) + (red[tid + 128] + red[tid + 192]);
 }
 
+// closed-form table noise (noise_option 1..6): table[n][f] = exp(sigma) {1, t_n} or exp(sigma_diag[f]) {1, t_n}, so
+// d/d sigma = sum_{n,f} ds table (1..3),  d/d sigma_diag[f] = sum_n ds table (4..6)
+struct SArgs { const float* ds; const float* gt; float* grad; int32_t rows, H, off_sigma, off_sigma_diag, no; };
+
+__global__ void __launch_bounds__(256) snsde_sigma_grad_kernel(SArgs a) {
+    __shared__ float red[256];
+    const int tid = threadIdx.x;
+    if (a.no <= 3) {             // scalar sigma: one block over every (row, feature)
+        float s = 0.0f;
+        const int total = a.rows * a.H;
+        for (int i = tid; i < total; i += 256) s = fmaf(a.ds[i], a.gt[i], s);
+        red[tid] = s;
+        __syncthreads();
+        for (int o = 128; o > 0; o >>= 1) {
+            if (tid < o) red[tid] += red[tid + o];
+            __syncthreads();
+        }
+        if (tid == 0) a.grad[a.off_sigma] = red[0];
+        return;
+    }
+    const int f = blockIdx.x * 64 + (tid & 63), q = tid >> 6;     // 64 features per block, four row ranges
+    float s = 0.0f;
+    if (f < a.H)
+        for (int n = q; n < a.rows; n += 4) s = fmaf(a.ds[(size_t)n * a.H + f], a.gt[(size_t)n * a.H + f], s);
+    red[tid] = s;
+    __syncthreads();
+    if (q == 0 && f < a.H) a.grad[a.off_sigma_diag + f] = (red[tid] + red[tid + 64]) + (red[tid + 128] + red[tid + 192]);
+}
+
 // ---- epilogue -------------------------------------------------------------------------------------------------
 struct GJob {     // C (M x N) = A . B^T (trans 0: A (M, K), B (N, K)) or A^T . B (trans 1: A (K, M), B (K, N); B null = ones)
     const float* A; const float* B; float* C; const float* u; const float* v;   // + u v^T when u != null
@@ -478,7 +507,7 @@ bool make_wplan(const snsde_backward* b, const SnsdeNet& net, WPlan* w) {
     }
     w->sums_floats = (off + 3) & ~(size_t)3;
     w->part_floats = (size_t)nparts * TILE_FLOATS;
-    w->tnoise = (no == 12 || no == 13 || no == 16 || no == 17);
+    w->tnoise = (no >= 1 && no <= 6) || no == 11 || no == 12 || no == 13 || no == 16 || no == 17;   // table noise: ds wanted
     const bool two = (no == 16 || no == 17);
     size_t o = w->sums_floats + w->part_floats;
     const size_t NH = (size_t)n_trow * H;
@@ -561,7 +590,7 @@ int snsde_wgrad_launch(const snsde_backward* b, const SnsdeNet& net, float* grad
         d.ds_part = bws + ds_off; d.dth_part = bws + dth_off; d.ds = ds; d.dth = ws + wp->dth_off;
         d.nwg = nwg; d.n_dth = nwg * waves; d.NH = wp->tnoise ? wp->n_trow * H : 0;
         hipLaunchKernelGGL(snsde_dsum_reduce_kernel, dim3((d.NH + 63) / 64 + 1), dim3(256), 0, stream, d);
-        if (two)
+        if (two)      // (two implies the noise MLP of 16/17)
             hipLaunchKernelGGL(snsde_noise_hidden_kernel, dim3(wp->n_trow, (H + 63) / 64), dim3(256), (H + 256) * sizeof(float),
                                stream, aa);
     }
@@ -588,7 +617,8 @@ int snsde_wgrad_launch(const snsde_backward* b, const SnsdeNet& net, float* grad
         add_job(E + H, 2 * H, s0, 1, grad_params + net.init.src_b, 1, H, 1, H, 1, nullptr, nullptr);
         maxM = H; maxN = Kin > H ? Kin : H;
     }
-    if (wp->tnoise) {
+    const bool mlp = (no == 12 || no == 13 || no == 16 || no == 17);
+    if (mlp) {
         const float* tau = aa.tau;
         const float* src = two ? aa.dz1 : ds;          // gradient at the output of noise_t(.0)
         add_job(src, H, tau, aa.tau_stride, grad_params + net.nt0.src_w, 2, H, 2, wp->n_trow, 1, nullptr, nullptr);
@@ -602,6 +632,13 @@ int snsde_wgrad_launch(const snsde_backward* b, const SnsdeNet& net, float* grad
     }
     aa.n_jobs = nj;
     hipLaunchKernelGGL(snsde_assemble_kernel, dim3((n_params + 255) / 256), dim3(256), 0, stream, aa);
+    if (no >= 1 && no <= 6) {     // after the assemble kernel (which zero-fills sigma / sigma_diag)
+        SArgs sg{};
+        sg.ds = ds; sg.gt = gt; sg.grad = grad_params; sg.rows = wp->n_trow; sg.H = H; sg.no = no;
+        sg.off_sigma = net.off_sigma; sg.off_sigma_diag = net.off_sigma_diag;
+        if ((no <= 3 ? net.off_sigma : net.off_sigma_diag) < 0) return SNSDE_ERR_UNSUPPORTED;
+        hipLaunchKernelGGL(snsde_sigma_grad_kernel, dim3(no <= 3 ? 1 : (H + 63) / 64), dim3(256), 0, stream, sg);
+    }
     if (nj > 0)
         hipLaunchKernelGGL(snsde_small_gemm_kernel, dim3((maxN + 31) / 32, (maxM + 31) / 32, nj), dim3(256), 0, stream, aa);
     return hipGetLastError() == hipSuccess ? SNSDE_OK : SNSDE_ERR_LAUNCH;

@@ -242,8 +242,8 @@ def _parameter_gradients_gemm(sde, call, grid, adj, delta, method='euler'):
     (kept as the autograd cross-check) at a fraction of the memory traffic."""
     P = dict(sde.named_parameters())
     io, no = sde.input_option, sde.noise_option
-    if no in (14, 15, 18, 19):
-        raise NotImplementedError("the library-GEMM cross-check pass does not cover the diffusion nets; use param_pass='hip'")
+    if no not in (0, 12, 13, 16, 17):
+        raise NotImplementedError("the library-GEMM cross-check pass covers noise_option 0/12/13/16/17 only; use param_pass='hip'")
     N, B, H = call.dW_out.shape
     dev = adj.device
     NB = N * B

@@ -326,6 +326,13 @@ MFMA_CASES = [
     (3, 19, 1, 9, 128, 3, 8, [0, 7], 0.5, 'euler'),
     (1, 14, 2, 9, 32, 3, 8, [0, 7], 1.0, 'euler'),
     (3, 15, 3, 9, 16, 3, 8, [0, 7], 1.0, 'euler'),
+    (4, 3, 2, 21, 64, 5, 9, [0, 3.5, 8], 1.0, 'milstein'),        # closed-form table noise: exp(sigma) y
+    (2, 5, 1, 9, 32, 3, 8, [0, 7], 0.5, 'euler'),                 # exp(sigma_diag) t
+    (6, 11, 2, 13, 128, 5, 9, [0, 8], 1.0, 'milstein'),           # t y
+    (1, 1, 2, 9, 16, 3, 8, [0, 7], 1.0, 'euler'),
+    (3, 6, 3, 9, 64, 3, 8, [0, 2.5, 7], 1.0, 'milstein'),
+    (5, 2, 2, 9, 32, 3, 8, [0, 7], 0.5, 'euler'),
+    (4, 4, 2, 9, 32, 3, 8, [0, 7], 1.0, 'euler'),
     (4, 17, 2, 37, 128, 69, 9, [0, 3.5, 8], 1.0, 'euler'),        # wide control path (sepsis channel counts): 5 k-blocks
     (2, 16, 1, 21, 64, 35, 9, [0, 8], 1.0, 'milstein'),
     (6, 17, 3, 9, 32, 80, 7, [0, 6], 0.5, 'euler'),
@@ -553,6 +560,10 @@ SRK_BWD_CASES = [
     (3, 13, 2, 10, 64, 3, 8, [0, 2.5, 7], 1.0),
     (5, 12, 4, 6, 128, 3, 7, [0, 6], 1.0),
     (4, 17, 2, 21, 128, 21, 9, [0, 8], 1.0),
+    (2, 3, 2, 9, 32, 3, 8, [0, 7], 1.0),             # closed-form table noise under SRK
+    (6, 5, 1, 9, 64, 3, 8, [0, 3, 7], 0.5),
+    (3, 11, 2, 9, 16, 3, 8, [0, 7], 1.0),
+    (4, 1, 2, 9, 32, 5, 8, [0, 7], 1.0),
 ]
 
 
@@ -564,7 +575,7 @@ def test_srk_backward_on_the_mfma_path(ci, kernel):
 
 
 @pytest.mark.parametrize('io', [1, 2, 3, 4, 5, 6])
-@pytest.mark.parametrize('no', [0, 12, 13, 16, 17])
+@pytest.mark.parametrize('no', [0, 1, 2, 3, 4, 5, 6, 11, 12, 13, 16, 17])
 def test_backward_sweep_mfma_options(io, no):
     """Every (input_option, elementwise noise_option) pair of the MFMA path: adjoint kernel + native parameter pass vs
     float64 autograd, alternating depth, flavour and method."""
@@ -856,6 +867,8 @@ SRK_CASES = [
     (5, 17, 2, 13, 16, 3, 8, [0, 7], 1.0),
     (4, 16, 4, 9, 64, 21, 9, [0, 4, 8], 1.0),
     (2, 0, 2, 7, 128, 32, 8, [0, 7], 1.0),
+    (4, 6, 2, 9, 32, 5, 8, [0, 7], 1.0),
+    (1, 2, 2, 9, 64, 3, 8, [0, 3, 7], 0.5),
 ]
 
 
