@@ -139,7 +139,8 @@ MfmaPlan make_plan(const snsde_solve* s, const SnsdeNet& net, int flavor_hint) {
     const bool noise_net = (no == 14 || no == 15 || no == 18 || no == 19);
     // table noise: raw = (row of a per-step table) x {1, y}: the time-only noise MLPs and the closed forms in t, sigma
     const bool tab_noise = (no >= 1 && no <= 6) || no == 11 || no == 12 || no == 13 || no == 16 || no == 17;
-    if (!(no == 0 || tab_noise || noise_net)) return p;
+    const bool y_noise = (no >= 7 && no <= 10);      // raw = phi(y): sqrt y, y^3, sigmoid y, relu y
+    if (!(no == 0 || tab_noise || y_noise || noise_net)) return p;
     if (noise_net && !(io == 1 || io == 3)) return p;
     if (noise_net && s->method != SNSDE_EULER) return p;
     if (srk && (m.input_channels > 32 && (io == 2 || io == 4 || io == 6))) return p;
@@ -241,7 +242,8 @@ RevPlan make_rev_plan(const snsde_solve* s, const SnsdeNet& net, const MfmaPlan&
     p.total_floats = packed + (p.emb ? H * net.in.K + H : 0) + 16;
     p.nwg = (s->batch + (p.FL ? 4 : 16) - 1) / (p.FL ? 4 : 16);
     p.ds_off = p.dth_off = 0;
-    if (fp.gt_off >= 0 || p.NN > 0) {     // the adjoint kernel also leaves the diffusion-side parameter sums
+    const int no_ = s->model.noise_option;
+    if (fp.gt_off >= 0 || p.NN > 0 || (no_ >= 7 && no_ <= 10)) {     // the adjoint kernel also leaves the diffusion-side parameter sums
         size_t o = ((size_t)p.total_floats + 3) & ~(size_t)3;
         if (fp.gt_off >= 0) { p.ds_off = o; o += (size_t)p.nwg * s->n_steps * H * (p.SRK ? 4 : 1); }   // time-only noise MLP: d/d s_n
         p.dth_off = o; o += (size_t)p.nwg * p.NW;                                    // d/d sigmoid(theta)

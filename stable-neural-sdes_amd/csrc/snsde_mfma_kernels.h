@@ -102,6 +102,15 @@ __device__ __forceinline__ float row_ror_add(float x) {
     return x + b;
 }
 
+// y-only closed-form diffusions (noise_option 7..10, neuralsde.py:250-261): raw = phi(y) with its first two derivatives
+__device__ __forceinline__ float snsde_phi(int no, float y, float& r1, float& r2) {
+    if (no == 7) { const float q = sqrtf(y); r1 = 0.5f / q; r2 = -0.25f / (q * y); return q; }
+    if (no == 8) { r1 = 3.0f * y * y; r2 = 6.0f * y; return y * y * y; }
+    if (no == 9) { const float q = snsde_sigmoid(y); r1 = q * (1.0f - q); r2 = r1 * (1.0f - 2.0f * q); return q; }
+    r1 = y > 0.0f ? 1.0f : 0.0f; r2 = 0.0f;
+    return fmaxf(y, 0.0f);
+}
+
 // tanh on the hardware exp2 / rcp units, branch-free:
 //   |x| <  0.25 : odd Taylor polynomial to x^11 (truncation < 3e-10 relative)
 //   |x| >= 0.25 : (1 - t) / (1 + t), t = 2^(-2 log2(e) |x|) in (0, 0.61]: no cancellation in 1 - t, the result
@@ -365,6 +374,7 @@ __global__ void __launch_bounds__(CF::NT, CF::WPS) snsde_mfma_kernel(MfmaArgs a)
     const float* brow = bufB + r * LDA + 4 * s;
     const bool writer = FL ? (s == 0) : true;
     const bool mul_y = (no == 13 || no == 17 || no == 15 || no == 19 || no == 3 || no == 6 || no == 11);
+    const bool yfun = (no >= 7 && no <= 10);     // raw = phi(y)
     const bool s1 = (s == 1), s2 = (s == 2), s3 = (s == 3);
     const float mil = (a.method == SNSDE_MILSTEIN) ? 0.5f : 0.0f;
     const uint32_t grow = (uint32_t)(a.row_offset + row);
@@ -654,7 +664,8 @@ __global__ void __launch_bounds__(CF::NT, CF::WPS) snsde_mfma_kernel(MfmaArgs a)
                 const float f = fast_tanh(z);
                 if constexpr (CF::SRK) {
                     auto gfun = [&](float gq, float yy) {
-                        const float raw = mul_y ? gq * yy : gq;
+                        float q1, q2;
+                        const float raw = yfun ? snsde_phi(no, yy, q1, q2) : (mul_y ? gq * yy : gq);
                         return fast_tanh(sig_theta * snsde_nan_to_num(raw));
                     };
                     const float yb = sk_y[e], f0 = sk_f0[e], g0 = sk_g0[e];
@@ -694,12 +705,13 @@ __global__ void __launch_bounds__(CF::NT, CF::WPS) snsde_mfma_kernel(MfmaArgs a)
                     gq = gnv[FL ? 0 : e];
                     if constexpr (FL) { gq = s1 ? gnv[1] : gq; gq = s2 ? gnv[2] : gq; gq = s3 ? gnv[3] : gq; }
                 }
-                const float raw = mul_y ? gq * y : gq;
+                float q1 = 0.0f, q2 = 0.0f;
+                const float raw = yfun ? snsde_phi(no, y, q1, q2) : (mul_y ? gq * y : gq);
                 const float g = fast_tanh(sig_theta * snsde_nan_to_num(raw));
                 float yn = fmaf(g, dw[t][e], fmaf(f, h, y));
                 // Milstein: + 0.5 g dg/dy (dW^2 - h), dg/dy = (1 - g^2) sigmoid(theta) d raw/dy (raw finite)
                 if (mil != 0.0f) {
-                    const float draw = (mul_y && (raw - raw == 0.0f)) ? gq : 0.0f;
+                    const float draw = (raw - raw == 0.0f) ? (yfun ? q1 : (mul_y ? gq : 0.0f)) : 0.0f;
                     yn = fmaf(mil * (g * ((1.0f - g * g) * sig_theta * draw)), fmaf(dw[t][e], dw[t][e], -h), yn);
                 }
                 yold[e] = y; ynew[e] = yn; yv[t][e] = yn;
@@ -849,6 +861,7 @@ __global__ void __launch_bounds__(CF::NT, CF::WPS) snsde_mfma_reverse_kernel(Rev
 
     const float sig_theta = snsde_sigmoid(a.params[a.off_theta]);
     const bool mul_y = (a.no == 13 || a.no == 17 || a.no == 15 || a.no == 19 || a.no == 3 || a.no == 6 || a.no == 11);
+    const bool yfun = (a.no >= 7 && a.no <= 10);     // raw = phi(y): no table, theta is the only diffusion parameter
     const float mil = (a.method == SNSDE_MILSTEIN) ? 0.5f : 0.0f;
 
     auto fill_rows = [&](int base) {
@@ -942,12 +955,25 @@ __global__ void __launch_bounds__(CF::NT, CF::WPS) snsde_mfma_reverse_kernel(Rev
             float acc_y = av;
             if constexpr (CF::GEO) { dz[e] = dzt * ty; acc_y = fmaf(dzt * z, 1.0f - ty * ty, acc_y); }
             else dz[e] = dzt;
-            const float raw = mul_y ? gq * y : gq;
+            float q1 = 0.0f, q2 = 0.0f;
+            const float raw = yfun ? snsde_phi(a.no, y, q1, q2) : (mul_y ? gq * y : gq);
             const float rcv = snsde_nan_to_num(raw);
             const float g = fast_tanh(sig_theta * rcv);
             const bool finite = (raw - raw == 0.0f);
             const float om = 1.0f - g * g;
-            if (mul_y && finite) {
+            if (yfun) {
+                if (finite) {
+                    // g' = (1 - g^2) s r1,  g'' = (1 - g^2) s r2 - 2 g g' s r1  (s = sigmoid(theta));  d/dy [g dW + mil (dW^2 - h) g g']
+                    const float g1 = om * sig_theta * q1;
+                    const float g2 = om * sig_theta * q2 - 2.0f * g * g1 * sig_theta * q1;
+                    const float qq = mil * fmaf(dw, dw, -h);
+                    acc_y = fmaf(av, fmaf(qq, fmaf(g1, g1, g * g2), dw * g1), acc_y);
+                    // d/d sigmoid(theta): (1 - g^2) rc dW + mil (dW^2 - h)(1 - g^2) r1 [s rc (1 - 3 g^2) + g]
+                    th_acc = fmaf(av * rowf * om, fmaf(qq * q1, fmaf(sig_theta * rcv, fmaf(-3.0f * g, g, 1.0f), g), dw * rcv), th_acc);
+                } else {
+                    th_acc = fmaf(av * rowf * om * dw, rcv, th_acc);
+                }
+            } else if (mul_y && finite) {
                 // d/dy [g dW + mil (dW^2 - h) g g'],  g' = (1 - g^2) c,  (g g')' = c^2 (1 - g^2)(1 - 3 g^2),  c = sigmoid(theta) s_n
                 const float c = sig_theta * gq;
                 const float dm = mil * fmaf(dw, dw, -h) * c * fmaf(-3.0f * g, g, 1.0f);
@@ -1053,7 +1079,7 @@ __global__ void __launch_bounds__(CF::NT, CF::WPS) snsde_mfma_reverse_kernel(Rev
 #pragma unroll
         for (int e = 0; e < EPT; ++e) a.adj[goff + e] = adj[e] + (a.row_out ? (rslot == 0 ? gfin[e] : 0.0f) : a.grad_ys[goff + e]);
     }
-    if ((dsum || NN > 0) && a.dth_part) {
+    if ((dsum || NN > 0 || yfun) && a.dth_part) {
 #pragma unroll
         for (int off = 32; off > 0; off >>= 1) th_acc += __shfl_down(th_acc, off, 64);
         if (lane == 0) a.dth_part[blockIdx.x * CF::NW + wave] = th_acc;
@@ -1105,7 +1131,9 @@ __global__ void __launch_bounds__(CF::NT, CF::WPS) snsde_mfma_srk_reverse_kernel
 
     const float sig_theta = snsde_sigmoid(a.params[a.off_theta]);
     const bool mul_y = (a.no == 13 || a.no == 17 || a.no == 3 || a.no == 6 || a.no == 11);
+    const bool yfun = (a.no >= 7 && a.no <= 10);
     const bool dsum = a.ds_part != nullptr && a.gt != nullptr;
+    const bool tsum = dsum || yfun;       // d/d sigmoid(theta) wanted
     const float rowf = row_ok ? 1.0f : 0.0f;
     const int rslot = a.row_out ? a.row_out[rowc] : -1;
     const float gfin = a.row_out ? a.grad_ys[goff] : 0.0f;
@@ -1113,11 +1141,12 @@ __global__ void __launch_bounds__(CF::NT, CF::WPS) snsde_mfma_srk_reverse_kernel
 
     // g = tanh(sigmoid(theta) nan_to_num(raw)), raw = s(t) or s(t) y;  returns g, sets dg/dy, the clipped raw and its finiteness
     auto gfun = [&](float tv, float yy, float& gp, float& rc, bool& fin) {
-        const float raw = mul_y ? tv * yy : tv;
+        float q1 = mul_y ? tv : 0.0f, q2 = 0.0f;
+        const float raw = yfun ? snsde_phi(a.no, yy, q1, q2) : (mul_y ? tv * yy : tv);
         fin = (raw - raw == 0.0f);
         rc = snsde_nan_to_num(raw);
         const float g = fast_tanh(sig_theta * rc);
-        gp = (mul_y && fin) ? (1.0f - g * g) * sig_theta * tv : 0.0f;
+        gp = fin ? (1.0f - g * g) * sig_theta * q1 : 0.0f;
         return g;
     };
     auto quad_sum = [&](float v) {      // over the four rows of the tile (lanes differing in bits 0-1)
@@ -1246,12 +1275,14 @@ __global__ void __launch_bounds__(CF::NT, CF::WPS) snsde_mfma_srk_reverse_kernel
         yb += hb; fb0 = fmaf(h, hb, fb0); gb0 = fmaf(-rdt, hb, gb0);
         // parameter side of G3 (slot 1, completed below with G1) and G2 (slot 3)
         float ds1 = 0.0f;
-        if (dsum) {
+        if (tsum) {
             const float c3 = gb3 * (1.0f - g3 * g3) * rowf, c2 = gb2 * (1.0f - g2 * g2) * rowf;
             th_acc = fmaf(c3, rc3, fmaf(c2, rc2, th_acc));
-            ds1 = fi3 ? c3 * sig_theta * (mul_y ? h13 : 1.0f) : 0.0f;
-            const float ds3 = quad_sum(fi2 ? c2 * sig_theta * (mul_y ? h12 : 1.0f) : 0.0f);
-            if (r == 0) a.ds_part[((size_t)blockIdx.x * 4 * a.N + 4 * n + 3) * H + fcol] = ds3;
+            if (dsum) {
+                ds1 = fi3 ? c3 * sig_theta * (mul_y ? h13 : 1.0f) : 0.0f;
+                const float ds3 = quad_sum(fi2 ? c2 * sig_theta * (mul_y ? h12 : 1.0f) : 0.0f);
+                if (r == 0) a.ds_part[((size_t)blockIdx.x * 4 * a.N + 4 * n + 3) * H + fcol] = ds3;
+            }
         }
         // ---- stage 2: drift at (t0 + h/2, H0_2) ----
         float d = chain(3 * n + 2, fb2, h02, z2, f2);
@@ -1261,22 +1292,24 @@ __global__ void __launch_bounds__(CF::NT, CF::WPS) snsde_mfma_srk_reverse_kernel
         // ---- stage 1: diffusion at (t0 + h/4, H1_1), drift at (t0 + h, H0_1) ----
         hb = gb1 * g1p;
         yb += hb; fb0 = fmaf(0.25f * h, hb, fb0); gb0 = fmaf(0.5f * rdt, hb, gb0);
-        if (dsum) {
+        if (tsum) {
             const float c1 = gb1 * (1.0f - g1 * g1) * rowf;
             th_acc = fmaf(c1, rc1, th_acc);
-            ds1 += fi1 ? c1 * sig_theta * (mul_y ? h11 : 1.0f) : 0.0f;
-            ds1 = quad_sum(ds1);
-            if (r == 0) a.ds_part[((size_t)blockIdx.x * 4 * a.N + 4 * n + 1) * H + fcol] = ds1;
+            if (dsum) {
+                ds1 += fi1 ? c1 * sig_theta * (mul_y ? h11 : 1.0f) : 0.0f;
+                ds1 = quad_sum(ds1);
+                if (r == 0) a.ds_part[((size_t)blockIdx.x * 4 * a.N + 4 * n + 1) * H + fcol] = ds1;
+            }
         }
         d = chain(3 * n + 1, fb1, h01, z1, f1);
         yb += d; fb0 = fmaf(h, d, fb0);
         // ---- stage 0: both at (t0, y) ----
         yb = fmaf(gb0, g0p, yb);
-        if (dsum) {
+        if (tsum) {
             const float c0 = gb0 * (1.0f - g0 * g0) * rowf;
             th_acc = fmaf(c0, rc0, th_acc);
-            const float ds0 = quad_sum(fi0 ? c0 * sig_theta * (mul_y ? y : 1.0f) : 0.0f);
-            if (r == 0) {
+            const float ds0 = dsum ? quad_sum(fi0 ? c0 * sig_theta * (mul_y ? y : 1.0f) : 0.0f) : 0.0f;
+            if (dsum && r == 0) {
                 a.ds_part[((size_t)blockIdx.x * 4 * a.N + 4 * n) * H + fcol] = ds0;
                 a.ds_part[((size_t)blockIdx.x * 4 * a.N + 4 * n + 2) * H + fcol] = 0.0f;   // slot t0 + h/2: no diffusion evaluation
             }
@@ -1286,7 +1319,7 @@ __global__ void __launch_bounds__(CF::NT, CF::WPS) snsde_mfma_srk_reverse_kernel
         cur = nxt;
     }
     if (row_ok) a.adj[goff] = adj + (a.row_out ? (rslot == 0 ? gfin : 0.0f) : a.grad_ys[goff]);
-    if (dsum && a.dth_part) {
+    if (tsum && a.dth_part) {
 #pragma unroll
         for (int off = 32; off > 0; off >>= 1) th_acc += __shfl_down(th_acc, off, 64);
         if (lane == 0) a.dth_part[blockIdx.x * CF::NW + wave] = th_acc;

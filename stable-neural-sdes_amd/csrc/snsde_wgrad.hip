@@ -513,7 +513,7 @@ bool make_wplan(const snsde_backward* b, const SnsdeNet& net, WPlan* w) {
     const size_t NH = (size_t)n_trow * H;
     w->n_pass = n_pass; w->n_trow = n_trow;
     w->ds_off = o; o += w->tnoise ? NH : 0;
-    w->has_dth = w->tnoise || nn > 0;
+    w->has_dth = w->tnoise || nn > 0 || (no >= 7 && no <= 10);
     w->nact = nhid + 2 + nn;
     w->xt = xt;
     w->dth_off = o; o += 4;

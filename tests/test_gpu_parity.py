@@ -333,6 +333,10 @@ MFMA_CASES = [
     (3, 6, 3, 9, 64, 3, 8, [0, 2.5, 7], 1.0, 'milstein'),
     (5, 2, 2, 9, 32, 3, 8, [0, 7], 0.5, 'euler'),
     (4, 4, 2, 9, 32, 3, 8, [0, 7], 1.0, 'euler'),
+    (4, 7, 2, 9, 32, 3, 8, [0, 7], 1.0, 'euler'),                 # y-only closed forms: sqrt y (NaN -> 0 for y < 0)
+    (2, 8, 2, 9, 64, 3, 8, [0, 3, 7], 0.5, 'milstein'),           # y^3
+    (6, 9, 1, 13, 128, 5, 8, [0, 7], 1.0, 'milstein'),            # sigmoid y
+    (3, 10, 3, 9, 16, 3, 8, [0, 7], 1.0, 'euler'),                # relu y
     (4, 17, 2, 37, 128, 69, 9, [0, 3.5, 8], 1.0, 'euler'),        # wide control path (sepsis channel counts): 5 k-blocks
     (2, 16, 1, 21, 64, 35, 9, [0, 8], 1.0, 'milstein'),
     (6, 17, 3, 9, 32, 80, 7, [0, 6], 0.5, 'euler'),
@@ -564,6 +568,9 @@ SRK_BWD_CASES = [
     (6, 5, 1, 9, 64, 3, 8, [0, 3, 7], 0.5),
     (3, 11, 2, 9, 16, 3, 8, [0, 7], 1.0),
     (4, 1, 2, 9, 32, 5, 8, [0, 7], 1.0),
+    (4, 9, 2, 9, 32, 5, 8, [0, 7], 1.0),             # y-only closed forms under SRK
+    (1, 8, 2, 9, 16, 3, 8, [0, 3, 7], 0.5),
+    (6, 10, 1, 9, 64, 3, 8, [0, 7], 1.0),
 ]
 
 
@@ -575,7 +582,7 @@ def test_srk_backward_on_the_mfma_path(ci, kernel):
 
 
 @pytest.mark.parametrize('io', [1, 2, 3, 4, 5, 6])
-@pytest.mark.parametrize('no', [0, 1, 2, 3, 4, 5, 6, 11, 12, 13, 16, 17])
+@pytest.mark.parametrize('no', [0, 1, 2, 3, 4, 5, 6, 8, 9, 10, 11, 12, 13, 16, 17])   # 7 (sqrt y): autograd's own gradient is NaN for y < 0
 def test_backward_sweep_mfma_options(io, no):
     """Every (input_option, elementwise noise_option) pair of the MFMA path: adjoint kernel + native parameter pass vs
     float64 autograd, alternating depth, flavour and method."""
@@ -869,6 +876,8 @@ SRK_CASES = [
     (2, 0, 2, 7, 128, 32, 8, [0, 7], 1.0),
     (4, 6, 2, 9, 32, 5, 8, [0, 7], 1.0),
     (1, 2, 2, 9, 64, 3, 8, [0, 3, 7], 0.5),
+    (2, 9, 2, 9, 32, 3, 8, [0, 7], 1.0),
+    (5, 7, 2, 9, 16, 3, 8, [0, 7], 0.5),
 ]
 
 
