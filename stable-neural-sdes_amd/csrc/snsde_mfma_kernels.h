@@ -1368,7 +1368,7 @@ int dispatch_var(const MfmaPlan& p, const MfmaArgs& a, hipStream_t st) {
 
 // Instantiated configurations: input_option 1..6, up to 3 hidden `linears` (NL <= 4), C <= 32 (two 16-wide k-blocks) or
 // C <= 80 (five, folded first layer),
-// diffusion nets (noise_option 14/15/18/19) for the latent-only drifts (input_option 1, 3).
+// diffusion nets (noise_option 14/15/18/19) for the latent-only drifts (input_option 1, 3, 5).
 template <int H, int FL>
 int dispatch_io(const MfmaPlan& p, const MfmaArgs& a, hipStream_t st) {
 #ifdef SNSDE_DEV_SUBSET   // development builds: the headline configuration only
@@ -1402,7 +1402,7 @@ int dispatch_io(const MfmaPlan& p, const MfmaArgs& a, hipStream_t st) {
 #define SNSDE_CASES(IO_, NN_) SNSDE_CASE(IO_, 0, NN_) SNSDE_CASE(IO_, 1, NN_) SNSDE_CASE(IO_, 2, NN_) SNSDE_CASE(IO_, 3, NN_)
     SNSDE_CASES(2, 0) SNSDE_CASES(4, 0) SNSDE_CASES(6, 0)
     SNSDE_CASES(1, 0) SNSDE_CASES(3, 0) SNSDE_CASES(5, 0)
-    SNSDE_CASES(1, 1) SNSDE_CASES(3, 1) SNSDE_CASES(1, 2) SNSDE_CASES(3, 2)
+    SNSDE_CASES(1, 1) SNSDE_CASES(3, 1) SNSDE_CASES(5, 1) SNSDE_CASES(1, 2) SNSDE_CASES(3, 2) SNSDE_CASES(5, 2)
 #undef SNSDE_CASES
 #undef SNSDE_CASE
     return SNSDE_ERR_UNSUPPORTED;
@@ -1424,8 +1424,8 @@ int dispatch_rev(const RevPlan& p, const RevArgs& a, hipStream_t st) {
         return SNSDE_ERR_UNSUPPORTED;
     }
 #define SNSDE_RCASE(NH_) if (p.NHID == NH_) { \
-        if (p.NN == 1) return launch_rev<CfgR<H, NH_, 0, FL, 1>>(a, st); \
-        if (p.NN == 2) return launch_rev<CfgR<H, NH_, 0, FL, 2>>(a, st); \
+        if (p.NN == 1) return p.GEO ? launch_rev<CfgR<H, NH_, 1, FL, 1>>(a, st) : launch_rev<CfgR<H, NH_, 0, FL, 1>>(a, st); \
+        if (p.NN == 2) return p.GEO ? launch_rev<CfgR<H, NH_, 1, FL, 2>>(a, st) : launch_rev<CfgR<H, NH_, 0, FL, 2>>(a, st); \
         return p.GEO ? launch_rev<CfgR<H, NH_, 1, FL>>(a, st) : launch_rev<CfgR<H, NH_, 0, FL>>(a, st); }
     SNSDE_RCASE(0) SNSDE_RCASE(1) SNSDE_RCASE(2) SNSDE_RCASE(3)
 #undef SNSDE_RCASE

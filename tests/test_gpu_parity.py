@@ -333,6 +333,8 @@ MFMA_CASES = [
     (3, 6, 3, 9, 64, 3, 8, [0, 2.5, 7], 1.0, 'milstein'),
     (5, 2, 2, 9, 32, 3, 8, [0, 7], 0.5, 'euler'),
     (4, 4, 2, 9, 32, 3, 8, [0, 7], 1.0, 'euler'),
+    (5, 18, 2, 13, 64, 3, 8, [0, 7], 1.0, 'euler'),               # diffusion nets on the geometric drift
+    (5, 14, 1, 9, 32, 3, 8, [0, 3, 7], 1.0, 'euler'),
     (4, 7, 2, 9, 32, 3, 8, [0, 7], 1.0, 'euler'),                 # y-only closed forms: sqrt y (NaN -> 0 for y < 0)
     (2, 8, 2, 9, 64, 3, 8, [0, 3, 7], 0.5, 'milstein'),           # y^3
     (6, 9, 1, 13, 128, 5, 8, [0, 7], 1.0, 'milstein'),            # sigmoid y
@@ -515,6 +517,8 @@ BWD_CASES = [
     (3, 15, 1, 11, 128, 3, 8, [0, 7], 0.5, 'euler'),
     (1, 19, 3, 9, 16, 3, 8, [0, 2.5, 7], 1.0, 'euler'),
     (3, 19, 2, 9, 128, 3, 8, [0, 7], 1.0, 'euler'),
+    (5, 18, 2, 9, 64, 3, 8, [0, 7], 1.0, 'euler'),            # geometric drift (tanh(y) gate) with a diffusion net
+    (5, 15, 1, 9, 32, 3, 8, [0, 3, 7], 1.0, 'euler'),
 ]
 
 
