@@ -1055,13 +1055,6 @@ inline int round4(int x) { return (x + 3) & ~3; }
 
 }  // namespace
 
-int snsde_time_table_launch(const float* params, const float* step_tab, float* gt, const SnsdeLayer& nt0,
-                            const SnsdeLayer& nt1, int H, int no, int n_steps, hipStream_t stream) {
-    hipLaunchKernelGGL(snsde_time_table_kernel, dim3(n_steps), dim3(128), H * sizeof(float), stream, params, step_tab,
-                       gt, nt0, nt1, H, no, SNSDE_STEP_STRIDE, 2);
-    return hipGetLastError() == hipSuccess ? SNSDE_OK : SNSDE_ERR_LAUNCH;
-}
-
 int snsde_time_table_srk_launch(const float* params, const float* srk_tab, float* gt, const SnsdeNet& net, int H, int no,
                                 int n_rows, hipStream_t stream) {
     // time-only diffusion at the stage times of every step: gt[(n*4 + slot)][H], rows of the SRK stage table

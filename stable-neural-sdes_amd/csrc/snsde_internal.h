@@ -53,8 +53,6 @@ int snsde_generic_launch(const snsde_solve* s, const SnsdeNet& net, hipStream_t 
 bool snsde_generic_backward_supported(const snsde_solve* s);
 int snsde_generic_backward_launch(const snsde_backward* b, const SnsdeNet& net, hipStream_t stream);
 int snsde_srk_launch(const snsde_solve* s, const SnsdeNet& net, hipStream_t stream);
-int snsde_time_table_launch(const float* params, const float* step_tab, float* gt, const SnsdeLayer& nt0,
-                            const SnsdeLayer& nt1, int H, int no, int n_steps, hipStream_t stream);
 int snsde_time_table_srk_launch(const float* params, const float* srk_tab, float* gt, const SnsdeNet& net, int H, int no,
                                 int n_rows, hipStream_t stream);
 // launchers (snsde_mfma.hip)

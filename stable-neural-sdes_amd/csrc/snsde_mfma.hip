@@ -258,8 +258,6 @@ RevPlan make_rev_plan(const snsde_solve* s, const SnsdeNet& net, const MfmaPlan&
 
 
 // time table kernel lives in snsde_generic.hip
-int snsde_time_table_launch(const float* params, const float* step_tab, float* gt, const SnsdeLayer& nt0,
-                            const SnsdeLayer& nt1, int H, int no, int n_steps, hipStream_t stream);
 
 bool snsde_mfma_supported(const snsde_solve* s, const SnsdeNet& net) { return make_plan(s, net, -1).ok; }
 
