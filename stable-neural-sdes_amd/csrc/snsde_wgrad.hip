@@ -631,6 +631,10 @@ int snsde_wgrad_launch(const snsde_backward* b, const SnsdeNet& net, float* grad
         if (H > maxN) maxN = H;
     }
     aa.n_jobs = nj;
+    for (int i = 0; i < nj; ++i) {      // the launch grid must cover the largest job (e.g. C > H columns of initial_network)
+        if (aa.job[i].M > maxM) maxM = aa.job[i].M;
+        if (aa.job[i].N > maxN) maxN = aa.job[i].N;
+    }
     hipLaunchKernelGGL(snsde_assemble_kernel, dim3((n_params + 255) / 256), dim3(256), 0, stream, aa);
     if (no >= 1 && no <= 6) {     // after the assemble kernel (which zero-fills sigma / sigma_diag)
         SArgs sg{};

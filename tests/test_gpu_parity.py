@@ -968,3 +968,69 @@ def test_spline_construction_hip_vs_oracle_large():
     # the CPU tensor-op construction (host path for CPU tensors) agrees too
     nat_cpu = torch.cat(S.controldiffeq.natural_cubic_spline_coeffs(torch.from_numpy(times), torch.from_numpy(X)), dim=-1)
     np.testing.assert_allclose(nat, nat_cpu.numpy(), rtol=2e-4, atol=2e-4)
+
+
+# ---- randomized cross-checks between the kernel families ------------------------------------------------
+def _fuzz_configs(n, seed):
+    rng = np.random.default_rng(seed)
+    out = []
+    while len(out) < n:
+        io = int(rng.integers(1, 7))
+        # (11 = t*y is left to the option sweeps: with t up to 10 its dynamics amplify float32 round-off beyond a fixed tolerance)
+        no = int(rng.choice([0, 1, 2, 3, 4, 5, 6, 8, 9, 10, 12, 13, 16, 17, 14, 15, 18, 19]))
+        if no in (14, 15, 18, 19) and io not in (1, 3, 5):
+            continue
+        method = str(rng.choice(['euler', 'milstein', 'srk']))
+        if no in (14, 15, 18, 19) and method != 'euler':
+            continue
+        H = int(rng.choice([16, 32, 64, 128]))
+        C = int(rng.choice([2, 5, 21, 33, 40])) if method != 'srk' else int(rng.choice([2, 5, 21]))
+        out.append((io, no, int(rng.integers(1, 5)), int(rng.integers(3, 40)), H, C, int(rng.integers(5, 12)), method))
+    return out
+
+
+@pytest.mark.parametrize('cfg', _fuzz_configs(120, 2026))
+def test_fuzz_mfma_forward_matches_generic_forward(cfg):
+    """Random supported configurations: the MFMA kernels (both tile flavours where instantiated) against the generic
+    all-options kernel on identical increments — two independent implementations of the same scheme."""
+    io, no, NL, B, H, C, L, method = cfg
+    sd = sum(int(v) * (i + 3) for i, v in enumerate(cfg[:7]))       # deterministic across processes
+    pr = make_problem(sd, io, no, NL, B, H, C, L)
+    ts = [0, (L - 1) / 2 + 0.25, L - 1]
+    dW = draw_dW(sd % 1000, ts, 1.0, B, H)
+    dU = _draw_dU(sd % 1000, dW, ts, 1.0) if method == 'srk' else None
+    ref, _ = hip_solve(pr, ts, 1.0, dW=dW, dU=dU, method=method, kernel='generic')
+    for kern in (('mfma4',) if method == 'srk' else ('mfma4', 'mfma16')):
+        ys, _ = hip_solve(pr, ts, 1.0, dW=dW, dU=dU, method=method, kernel=kern)
+        err = np.abs(ys - ref) / (1.0 + np.abs(ref))
+        assert np.isfinite(ys).all() and err.max() < 5e-4 and err.mean() < 2e-6, (cfg, kern, err.max(), err.mean())
+
+
+@pytest.mark.parametrize('cfg', [c for c in _fuzz_configs(120, 7) if c[1] not in (14, 15, 18, 19)][:72])
+def test_fuzz_mfma_backward_matches_generic_backward(cfg):
+    """Random configurations with an elementwise diffusion: gradients from the MFMA adjoint + native parameter pass against
+    the generic adjoint + batched autograd pass (both fused paths, different kernels and different parameter passes)."""
+    io, no, NL, B, H, C, L, method = cfg
+    sd = sum(int(v) * (i + 5) for i, v in enumerate(cfg[:7]))
+    pr = make_problem(sd, io, no, NL, B, H, C, L)
+    ts = np.asarray([0, (L - 1) / 2 + 0.25, L - 1], np.float32)
+    dW = draw_dW(sd % 1000, ts, 1.0, B, H)
+    dU = _draw_dU(sd % 1000, dW, ts, 1.0) if method == 'srk' else None
+    wsum = torch.from_numpy(np.random.default_rng(3).standard_normal((3, B, H)).astype(np.float32)).to(DEV)
+    res = {}
+    for kern in ('mfma4', 'generic'):
+        m = S.Diffusion_model(C, H, H, NL, input_option=io, noise_option=no)
+        m.load_state_dict({k: torch.from_numpy(v.copy()) for k, v in pr['params'].items()})
+        m = m.to(DEV)
+        m.set_X(torch.from_numpy(pr['coeffs']).to(DEV), torch.from_numpy(pr['times']).to(DEV))
+        y0 = torch.from_numpy(pr['y0']).to(DEV).requires_grad_(True)
+        bm = _ReplayBM(torch.from_numpy(dW).to(DEV), None if dU is None else torch.from_numpy(dU).to(DEV))
+        ys = S.sdeint(m, y0, torch.from_numpy(ts).to(DEV), bm=bm, method=method, dt=1.0, options={'kernel': kern})
+        (ys * wsum).sum().backward()
+        res[kern] = [y0.grad] + [p.grad for p in m.parameters()]
+    for a, b in zip(res['mfma4'], res['generic']):
+        if b is None or float(b.abs().max()) == 0.0:
+            assert a is None or float(a.abs().max()) < 1e-6
+            continue
+        scale = float(b.abs().max())
+        assert float((a - b).abs().max()) / scale < 2e-3, (cfg, float((a - b).abs().max()) / scale)
