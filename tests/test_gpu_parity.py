@@ -1034,3 +1034,53 @@ def test_fuzz_mfma_backward_matches_generic_backward(cfg):
             continue
         scale = float(b.abs().max())
         assert float((a - b).abs().max()) / scale < 2e-3, (cfg, float((a - b).abs().max()) / scale)
+
+
+LONG_CASES = [
+    # io, no, NL, B, H, C, L, method, dt      long grids: several step-table chunks (128 rows each), many outputs
+    (4, 17, 2, 19, 64, 5, 150, 'euler', 1.0),
+    (6, 17, 2, 9, 32, 3, 135, 'milstein', 1.0),
+    (2, 16, 1, 13, 128, 21, 141, 'euler', 0.5),
+    (4, 17, 2, 11, 32, 5, 60, 'srk', 1.0),          # 180 drift passes
+    (3, 13, 3, 7, 64, 3, 101, 'srk', 1.0),
+    (1, 18, 2, 9, 64, 3, 135, 'euler', 1.0),
+]
+
+
+@pytest.mark.parametrize('case', LONG_CASES)
+@pytest.mark.parametrize('outputs', ['ends', 'knots', 'rows'])
+def test_long_grids_mfma_vs_generic_forward_and_backward(case, outputs):
+    """Grids longer than one LDS step-table chunk, with final-only / every-knot / per-row outputs: MFMA kernels against the
+    generic kernels (forward on Philox increments from the same key; gradients where both adjoints exist)."""
+    io, no, NL, B, H, C, L, method, dt = case
+    pr = make_problem(L * 7 + io, io, no, NL, B, H, C, L)
+    times = torch.from_numpy(pr['times']).to(DEV)
+    ts = times if outputs != 'ends' else times[[0, L - 1]]
+    opts = {'seed': 77}
+    if outputs == 'rows':
+        opts['row_out'] = torch.randint(0, L, (B,), device=DEV)
+    wsum = None
+    res = {}
+    for kern in ('mfma4', 'generic'):
+        m = S.Diffusion_model(C, H, H, NL, input_option=io, noise_option=no)
+        m.load_state_dict({k: torch.from_numpy(v.copy()) for k, v in pr['params'].items()})
+        m = m.to(DEV)
+        m.set_X(torch.from_numpy(pr['coeffs']).to(DEV), times)
+        grad = no not in (14, 15, 18, 19)          # the generic adjoint has no diffusion nets
+        y0 = torch.from_numpy(pr['y0']).to(DEV).requires_grad_(grad)
+        with torch.set_grad_enabled(grad):
+            ys = S.sdeint(m, y0, ts, method=method, dt=dt, options=dict(opts, kernel=kern))
+            if wsum is None:
+                wsum = torch.randn_like(ys)
+            if grad:
+                (ys * wsum).sum().backward()
+        res[kern] = (ys.detach(), [y0.grad] + [p.grad for p in m.parameters()] if grad else [])
+    a, b = res['mfma4'][0], res['generic'][0]
+    err = (a - b).abs() / (1.0 + b.abs())
+    assert torch.isfinite(a).all() and float(err.max()) < 2e-3 and float(err.mean()) < 1e-5, (float(err.max()), float(err.mean()))
+    for ga, gb in zip(res['mfma4'][1], res['generic'][1]):
+        if gb is None or float(gb.abs().max()) == 0.0:
+            assert ga is None or float(ga.abs().max()) < 1e-5
+            continue
+        assert torch.isfinite(gb).all() and torch.isfinite(ga).all()
+        assert float((ga - gb).abs().max()) / float(gb.abs().max()) < 5e-3
