@@ -1084,3 +1084,35 @@ def test_long_grids_mfma_vs_generic_forward_and_backward(case, outputs):
             continue
         assert torch.isfinite(gb).all() and torch.isfinite(ga).all()
         assert float((ga - gb).abs().max()) / float(gb.abs().max()) < 5e-3
+
+
+@pytest.mark.parametrize('case', [(4, 17, 2, 2500, 128, 21, 12, 'euler'), (6, 17, 2, 1100, 64, 5, 10, 'milstein'),
+                                  (2, 16, 3, 3000, 32, 3, 9, 'euler'), (4, 17, 2, 700, 256, 14, 8, 'milstein'),
+                                  (4, 17, 2, 1300, 64, 5, 9, 'srk')])
+def test_wide_batches_auto_selection_vs_generic(case):
+    """Batches beyond one round of workgroups (automatic M4 / M16 choice, many R-splits in the weight-gradient pass):
+    forward and gradients against the generic kernels."""
+    io, no, NL, B, H, C, L, method = case
+    pr = make_problem(B + L, io, no, NL, B, H, C, L)
+    times = torch.from_numpy(pr['times']).to(DEV)
+    ts = times[[0, L // 2, L - 1]]
+    res = {}
+    wsum = None
+    for kern in ('auto', 'generic'):
+        m = S.Diffusion_model(C, H, H, NL, input_option=io, noise_option=no)
+        m.load_state_dict({k: torch.from_numpy(v.copy()) for k, v in pr['params'].items()})
+        m = m.to(DEV)
+        m.set_X(torch.from_numpy(pr['coeffs']).to(DEV), times)
+        y0 = torch.from_numpy(pr['y0']).to(DEV).requires_grad_(True)
+        ys = S.sdeint(m, y0, ts, method=method, dt=1.0, options={'seed': 5, 'kernel': kern})
+        wsum = torch.randn_like(ys) if wsum is None else wsum
+        (ys * wsum).sum().backward()
+        res[kern] = (ys.detach(), [y0.grad] + [p.grad for p in m.parameters()])
+    a, b = res['auto'][0], res['generic'][0]
+    err = (a - b).abs() / (1.0 + b.abs())
+    assert float(err.max()) < 2e-3 and float(err.mean()) < 1e-5
+    for ga, gb in zip(res['auto'][1], res['generic'][1]):
+        if gb is None or float(gb.abs().max()) == 0.0:
+            assert ga is None or float(ga.abs().max()) < 1e-4
+            continue
+        assert float((ga - gb).abs().max()) / float(gb.abs().max()) < 5e-3
