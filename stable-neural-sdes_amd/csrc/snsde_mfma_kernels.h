@@ -562,9 +562,38 @@ __global__ void __launch_bounds__(CF::NT, CF::WPS) snsde_mfma_kernel(MfmaArgs a)
 #pragma unroll
             for (int t = 0; t < TPW; ++t) store_frag(bufA, LDA, (wave * TPW + t) * 16, acc[t], true, 0);
             ++layer;
+            if constexpr (CF::NN > 0) {   // diffusion net, first layer, on the same [y, sin t, cos t] rows
+                constexpr int NROW = CF::NLAYER - CF::NN;
+                init_acc(NROW);
+                gemm<FL, (CF::NN > 0) ? CF::KUN : 1, TPW>(wn0, yrow, acc, acc2);
+                sum_acc();
+                if constexpr (CF::NN == 2) store_frag(nbuf, LDA, wave * 16, acc[0], true, CF::ZSLOT + 1);
+                else {
+                    gnv = acc[0];
+                    if constexpr (FL) {
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) gnv[i] = row_ror_add(gnv[i]);
+                    }
+                    if (writer && a.act_save && row_ok)
+                        *reinterpret_cast<f32x4*>(a.act_save + (((size_t)n * CF::NSAVE + CF::ZSLOT + 1) * B + row) * H + wave * 16 + fsub) = gnv;
+                }
+            }
             TRACE(3)
             __syncthreads();
             TRACE(4)
+            if constexpr (CF::NN == 2) {   // second layer of the diffusion net (relu'd raw value, neuralsde.py:278-281)
+                init_acc(CF::NLAYER - 1);
+                gemm<FL, (CF::NN > 1) ? KUH : 1, TPW>(wn1, nbuf + r * LDA + 4 * s, acc, acc2);
+                sum_acc();
+                gnv = acc[0];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    if constexpr (FL) gnv[i] = row_ror_add(gnv[i]);
+                    gnv[i] = fmaxf(gnv[i], 0.0f);
+                }
+                if (writer && a.act_save && row_ok)
+                    *reinterpret_cast<f32x4*>(a.act_save + (((size_t)n * CF::NSAVE + CF::ZSLOT + 2) * B + row) * H + wave * 16 + fsub) = gnv;
+            }
             cur = arow;
         } else {
             if constexpr (CF::EMB) {
@@ -1357,11 +1386,12 @@ template <int H, int KUX, int NHID, int IO, int FL, int NN>
 int dispatch_var(const MfmaPlan& p, const MfmaArgs& a, hipStream_t st) {
     constexpr bool emb = (IO == 2 || IO == 4 || IO == 6);
     if constexpr (emb) {
-        if (p.FOLD) return a.dW ? launch_cfg<Cfg<H, KUX, NHID, IO, FL, 0, 1, 0>>(a, st)
-                                : launch_cfg<Cfg<H, KUX, NHID, IO, FL, 1, 1, 0>>(a, st);
+        if (p.FOLD) return a.dW ? launch_cfg<Cfg<H, KUX, NHID, IO, FL, 0, 1, NN>>(a, st)
+                                : launch_cfg<Cfg<H, KUX, NHID, IO, FL, 1, 1, NN>>(a, st);
+        if constexpr (NN > 0) return SNSDE_ERR_UNSUPPORTED;   // diffusion nets behind a control embedding: folded layer only
         if constexpr (NHID > 1) return SNSDE_ERR_UNSUPPORTED;   // exact-order variant: diagnostic, NL <= 2 only
     }
-    if constexpr (!emb || NHID <= 1)
+    if constexpr (!emb || (NHID <= 1 && NN == 0))
         return a.dW ? launch_cfg<Cfg<H, KUX, NHID, IO, FL, 0, 0, NN>>(a, st) : launch_cfg<Cfg<H, KUX, NHID, IO, FL, 1, 0, NN>>(a, st);
     return SNSDE_ERR_UNSUPPORTED;
 }
@@ -1403,6 +1433,7 @@ int dispatch_io(const MfmaPlan& p, const MfmaArgs& a, hipStream_t st) {
     SNSDE_CASES(2, 0) SNSDE_CASES(4, 0) SNSDE_CASES(6, 0)
     SNSDE_CASES(1, 0) SNSDE_CASES(3, 0) SNSDE_CASES(5, 0)
     SNSDE_CASES(1, 1) SNSDE_CASES(3, 1) SNSDE_CASES(5, 1) SNSDE_CASES(1, 2) SNSDE_CASES(3, 2) SNSDE_CASES(5, 2)
+    SNSDE_CASES(4, 1) SNSDE_CASES(6, 1) SNSDE_CASES(4, 2) SNSDE_CASES(6, 2)
 #undef SNSDE_CASES
 #undef SNSDE_CASE
     return SNSDE_ERR_UNSUPPORTED;
