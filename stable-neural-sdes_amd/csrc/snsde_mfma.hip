@@ -141,8 +141,7 @@ MfmaPlan make_plan(const snsde_solve* s, const SnsdeNet& net, int flavor_hint) {
     const bool tab_noise = (no >= 1 && no <= 6) || no == 11 || no == 12 || no == 13 || no == 16 || no == 17;
     const bool y_noise = (no >= 7 && no <= 10);      // raw = phi(y): sqrt y, y^3, sigmoid y, relu y
     if (!(no == 0 || tab_noise || y_noise || noise_net)) return p;
-    if (noise_net && io == 2) return p;     // diffusion nets: every drift that carries time features, and the plain latent drift
-    if (noise_net && (io == 4 || io == 6) && m.input_channels > 32) return p;
+    if (noise_net && (io == 2 || io == 4 || io == 6) && m.input_channels > 32) return p;   // nets + wide control: generic
     if (noise_net && s->method != SNSDE_EULER) return p;
     if (srk && (m.input_channels > 32 && (io == 2 || io == 4 || io == 6))) return p;
     const bool emb = (io == 2 || io == 4 || io == 6);

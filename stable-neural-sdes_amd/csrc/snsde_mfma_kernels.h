@@ -1433,7 +1433,7 @@ int dispatch_io(const MfmaPlan& p, const MfmaArgs& a, hipStream_t st) {
     SNSDE_CASES(2, 0) SNSDE_CASES(4, 0) SNSDE_CASES(6, 0)
     SNSDE_CASES(1, 0) SNSDE_CASES(3, 0) SNSDE_CASES(5, 0)
     SNSDE_CASES(1, 1) SNSDE_CASES(3, 1) SNSDE_CASES(5, 1) SNSDE_CASES(1, 2) SNSDE_CASES(3, 2) SNSDE_CASES(5, 2)
-    SNSDE_CASES(4, 1) SNSDE_CASES(6, 1) SNSDE_CASES(4, 2) SNSDE_CASES(6, 2)
+    SNSDE_CASES(2, 1) SNSDE_CASES(4, 1) SNSDE_CASES(6, 1) SNSDE_CASES(2, 2) SNSDE_CASES(4, 2) SNSDE_CASES(6, 2)
 #undef SNSDE_CASES
 #undef SNSDE_CASE
     return SNSDE_ERR_UNSUPPORTED;

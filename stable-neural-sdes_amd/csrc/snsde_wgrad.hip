@@ -34,7 +34,8 @@ struct WTile {
     int32_t h0;       // first D feature (output row) of this tile
     int32_t x_kind;   // 0 = act_save slot, 1 = trajectory y, 2 = control-path columns [sin t, cos t][X(t) channels] (xaux)
     int32_t x_slot;
-    int32_t k0;       // first X column of this tile
+    int32_t k0;       // first X column of this tile (source)
+    int32_t kd;       // first destination column of this tile in the job matrix
     int32_t ncols;    // valid X columns in this tile
     int32_t out;      // float offset (in the sums block) of the dense job matrix
     int32_t ldo;      // its row stride
@@ -56,7 +57,7 @@ struct WArgs {
 };
 
 // control-path columns of the first layer's input, one row per (step, batch row): [sin t, cos t][X_c(t_n)], zero padded
-struct XArgs { const float* coeffs; const float* step_tab; float* xaux; int32_t B, C, Lm1, time_cols, naux, ldx, R; };
+struct XArgs { const float* coeffs; const float* step_tab; float* xaux; int32_t B, C, Lm1, t_col0, t_cols, x_col0, x_cols, ldx, R; };
 
 __global__ void __launch_bounds__(256) snsde_xaux_kernel(XArgs a) {
     const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
@@ -65,9 +66,9 @@ __global__ void __launch_bounds__(256) snsde_xaux_kernel(XArgs a) {
     const int n = r / a.B, b = r - n * a.B;
     const float* st = a.step_tab + (size_t)n * SNSDE_STEP_STRIDE;
     float val = 0.0f;
-    if (j < a.time_cols) val = st[2 + j];
-    else if (j < a.naux) {
-        const int c = j - a.time_cols;
+    if (j >= a.t_col0 && j < a.t_col0 + a.t_cols) val = st[2 + j - a.t_col0];
+    else if (j >= a.x_col0 && j < a.x_col0 + a.x_cols) {
+        const int c = j - a.x_col0;
         const float* cr = a.coeffs + ((size_t)b * a.Lm1 + __float_as_int(st[5])) * 4 * a.C;
         val = snsde_spline_eval(cr[c], cr[a.C + c], cr[2 * a.C + c], cr[3 * a.C + c], st[4]);
     }
@@ -204,7 +205,7 @@ __global__ void __launch_bounds__(256) snsde_wgrad_reduce_kernel(WArgs a) {
     const float v = (s0 + s1) + (s2 + s3);
     if (e < TILE * TILE) {
         const int hl = e / TILE, kl = e % TILE;
-        const int col = t.k0 + kl + (kl >= t.csplit ? t.cshift : 0);
+        const int col = t.kd + kl + (kl >= t.csplit ? t.cshift : 0);
         if (t.h0 + hl < a.H) a.sums[t.out + (size_t)(t.h0 + hl) * t.ldo + col] = v;
     } else {
         const int hl = e - TILE * TILE;
@@ -421,7 +422,7 @@ struct WPlan {
     int ntiles, max_split, naux, ldx, n_pass, n_trow;
     size_t part_floats, sums_floats, ds_off, dth_off, dz1_off, dz2_off, a1_off, xaux_off, total_floats;
     bool tnoise, has_dth;
-    int nact, xt;
+    int nact, xt, t_col0, x_col0, x_cols;
     AArgs aa;
     WTile tile[MAX_TILES];
 };
@@ -436,7 +437,11 @@ bool make_wplan(const snsde_backward* b, const SnsdeNet& net, WPlan* w) {
     const int nn = (no == 18 || no == 19) ? 2 : ((no == 14 || no == 15) ? 1 : 0);
     const int ts = timef ? 2 : 0;
     const int xt = (timef || nn > 0) ? 2 : 0;          // time columns present in the xaux rows
-    const int naux = xt + (emb ? C : 0);
+    // xaux row = [sin t, cos t | X(t)] in the drift's order; a time-free embedded drift with a diffusion net (input_option 2)
+    // keeps its X block first and the net's time columns after it (at a 16-byte aligned column)
+    const bool tau_last = emb && !timef && nn > 0;
+    const int t_col0 = tau_last ? ((C + 3) & ~3) : 0, x_col0 = tau_last ? 0 : xt;
+    const int naux = tau_last ? t_col0 + 2 : xt + (emb ? C : 0);
     const int nd = nhid + 2;                           // delta slots of the drift chain
     const bool srk = s.method == SNSDE_SRK;
     const int n_pass = s.n_steps * (srk ? 3 : 1);      // drift passes (one per step, three for SRK): rows of act / delta
@@ -448,13 +453,13 @@ bool make_wplan(const snsde_backward* b, const SnsdeNet& net, WPlan* w) {
     size_t off = 0;
     const int ht = (H + TILE - 1) / TILE;
     auto add_tiles = [&](int d_slot, int x_kind, int x_slot, int ncols_total, int o_mat, int ldo, int o_bias, int csplit,
-                         int cshift) {
+                         int cshift, int src0 = 0) {
         for (int hi = 0; hi < ht; ++hi)
             for (int k0 = 0; k0 < ncols_total; k0 += TILE) {
                 if (nt >= MAX_TILES) return false;
                 WTile& t = w->tile[nt++];
                 t = WTile{};
-                t.d_slot = d_slot; t.h0 = hi * TILE; t.x_kind = x_kind; t.x_slot = x_slot; t.k0 = k0;
+                t.d_slot = d_slot; t.h0 = hi * TILE; t.x_kind = x_kind; t.x_slot = x_slot; t.k0 = src0 + k0; t.kd = k0;
                 t.ncols = ncols_total - k0 < TILE ? ncols_total - k0 : TILE;
                 t.out = o_mat; t.ldo = ldo; t.bias = (o_bias >= 0 && k0 == 0) ? o_bias : -1;
                 t.csplit = csplit; t.cshift = cshift;
@@ -472,13 +477,13 @@ bool make_wplan(const snsde_backward* b, const SnsdeNet& net, WPlan* w) {
     aa.ld_first = ts + H + (emb ? C : 0);
     aa.o_first = alloc((size_t)H * aa.ld_first); aa.b_first = alloc(H);
     ok = ok && add_tiles(nhid + 1, 1, 0, H, aa.o_first + ts, aa.ld_first, aa.b_first, 1 << 30, 0);
-    if (ok && ts + (emb ? C : 0) > 0) ok = add_tiles(nhid + 1, 2, 0, naux, aa.o_first, aa.ld_first, -1, ts, H);
+    if (ok && ts + (emb ? C : 0) > 0) ok = add_tiles(nhid + 1, 2, 0, ts + (emb ? C : 0), aa.o_first, aa.ld_first, -1, ts, H, 0);
     aa.nn = nn;
     if (ok && nn > 0) {     // diffusion net: first layer on [sin t, cos t | y] (delta slot nd + nn - 1), output layer on its hidden
         const int d0n = nd + nn - 1;
         aa.o_ny0 = alloc((size_t)H * (H + 2)); aa.b_ny0 = alloc(H);
         ok = add_tiles(d0n, 1, 0, H, aa.o_ny0 + 2, H + 2, aa.b_ny0, 1 << 30, 0)
-             && add_tiles(d0n, 2, 0, 2, aa.o_ny0, H + 2, -1, 1 << 30, 0);
+             && add_tiles(d0n, 2, 0, 2, aa.o_ny0, H + 2, -1, 1 << 30, 0, t_col0);
         if (ok && nn == 2) {
             aa.o_ny1 = alloc((size_t)H * H); aa.b_ny1 = alloc(H);
             ok = add_tiles(nd, 0, nhid + 2, H, aa.o_ny1, H, aa.b_ny1, 1 << 30, 0);
@@ -514,6 +519,7 @@ bool make_wplan(const snsde_backward* b, const SnsdeNet& net, WPlan* w) {
     w->n_pass = n_pass; w->n_trow = n_trow;
     w->ds_off = o; o += w->tnoise ? NH : 0;
     w->has_dth = w->tnoise || nn > 0 || (no >= 7 && no <= 10);
+    w->t_col0 = t_col0; w->x_col0 = x_col0; w->x_cols = emb ? C : 0;
     w->nact = nhid + 2 + nn;
     w->xt = xt;
     w->dth_off = o; o += 4;
@@ -558,7 +564,8 @@ int snsde_wgrad_launch(const snsde_backward* b, const SnsdeNet& net, float* grad
     if (wp->naux > 0) {
         XArgs x{};
         x.coeffs = s.coeffs; x.step_tab = pass_tab; x.xaux = ws + wp->xaux_off;
-        x.B = s.batch; x.C = C; x.Lm1 = s.knots - 1; x.time_cols = wp->xt; x.naux = wp->naux; x.ldx = wp->ldx; x.R = a.R;
+        x.B = s.batch; x.C = C; x.Lm1 = s.knots - 1; x.t_col0 = wp->t_col0; x.t_cols = wp->xt; x.x_col0 = wp->x_col0;
+        x.x_cols = wp->x_cols; x.ldx = wp->ldx; x.R = a.R;
         const size_t total = (size_t)a.R * wp->ldx;
         hipLaunchKernelGGL(snsde_xaux_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, x);
     }

@@ -333,6 +333,8 @@ MFMA_CASES = [
     (3, 6, 3, 9, 64, 3, 8, [0, 2.5, 7], 1.0, 'milstein'),
     (5, 2, 2, 9, 32, 3, 8, [0, 7], 0.5, 'euler'),
     (4, 4, 2, 9, 32, 3, 8, [0, 7], 1.0, 'euler'),
+    (2, 18, 2, 13, 64, 5, 8, [0, 7], 1.0, 'euler'),               # ... and on the time-free embedded drift
+    (2, 15, 1, 9, 32, 3, 8, [0, 3, 7], 1.0, 'euler'),
     (4, 18, 2, 13, 64, 5, 8, [0, 7], 1.0, 'euler'),               # diffusion nets behind the control embedding (folded layer)
     (6, 15, 1, 9, 32, 3, 8, [0, 3, 7], 1.0, 'euler'),
     (4, 14, 3, 9, 128, 21, 8, [0, 7], 1.0, 'euler'),
@@ -371,7 +373,7 @@ def test_mfma_trajectory_vs_oracle(ci, kernel):
 
 
 def test_mfma_unsupported_configuration_is_refused_not_silently_rerouted():
-    pr = make_problem(1, 2, 18, 2, 8, 64, 3, 5)      # diffusion net together with a control embedding: generic only
+    pr = make_problem(1, 0, 18, 2, 8, 64, 3, 5)      # the y-free drift (input_option 0): generic only
     with pytest.raises(S._lib.SnsdeError) as e:
         hip_solve(pr, [0, 4], 1.0, dW=draw_dW(1, [0, 4], 1.0, 8, 64), kernel='mfma')
     assert e.value.code == -4
@@ -521,6 +523,8 @@ BWD_CASES = [
     (3, 15, 1, 11, 128, 3, 8, [0, 7], 0.5, 'euler'),
     (1, 19, 3, 9, 16, 3, 8, [0, 2.5, 7], 1.0, 'euler'),
     (3, 19, 2, 9, 128, 3, 8, [0, 7], 1.0, 'euler'),
+    (2, 18, 2, 9, 64, 5, 8, [0, 7], 1.0, 'euler'),            # time-free embedded drift + net: xaux keeps X first, tau after
+    (2, 14, 1, 9, 32, 6, 8, [0, 3, 7], 1.0, 'euler'),
     (4, 18, 2, 9, 64, 5, 8, [0, 7], 1.0, 'euler'),            # diffusion nets behind the control embedding
     (6, 19, 2, 9, 32, 3, 8, [0, 3, 7], 1.0, 'euler'),
     (4, 15, 1, 9, 128, 21, 8, [0, 7], 0.5, 'euler'),
@@ -695,8 +699,8 @@ def test_native_parameter_pass_matches_library_gemm_pass(case):
 
 
 def test_backward_unsupported_configurations_raise():
-    pr = make_problem(9, 2, 18, 2, 8, 64, 3, 5)       # a diffusion net on the time-free embedded drift: no fused backward
-    m = S.Diffusion_model(3, 64, 64, 2, input_option=2, noise_option=18).to(DEV)
+    pr = make_problem(9, 0, 18, 2, 8, 64, 3, 5)       # a diffusion net on the y-free drift (input_option 0): no fused backward
+    m = S.Diffusion_model(3, 64, 64, 2, input_option=0, noise_option=18).to(DEV)
     m.set_X(torch.from_numpy(pr['coeffs']).to(DEV), torch.from_numpy(pr['times']).to(DEV))
     y0 = torch.from_numpy(pr['y0']).to(DEV).requires_grad_(True)
     with pytest.raises(NotImplementedError):
@@ -986,14 +990,12 @@ def _fuzz_configs(n, seed):
         io = int(rng.integers(1, 7))
         # (11 = t*y is left to the option sweeps: with t up to 10 its dynamics amplify float32 round-off beyond a fixed tolerance)
         no = int(rng.choice([0, 1, 2, 3, 4, 5, 6, 8, 9, 10, 12, 13, 16, 17, 14, 15, 18, 19]))
-        if no in (14, 15, 18, 19) and io == 2:
-            continue
         method = str(rng.choice(['euler', 'milstein', 'srk']))
         if no in (14, 15, 18, 19) and method != 'euler':
             continue
         H = int(rng.choice([16, 32, 64, 128]))
         C = int(rng.choice([2, 5, 21, 33, 40])) if method != 'srk' else int(rng.choice([2, 5, 21]))
-        if no in (14, 15, 18, 19) and io in (4, 6) and C > 32:
+        if no in (14, 15, 18, 19) and io in (2, 4, 6) and C > 32:
             continue
         out.append((io, no, int(rng.integers(1, 5)), int(rng.integers(3, 40)), H, C, int(rng.integers(5, 12)), method))
     return out
