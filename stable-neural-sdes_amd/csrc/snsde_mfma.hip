@@ -135,22 +135,23 @@ MfmaPlan make_plan(const snsde_solve* s, const SnsdeNet& net, int flavor_hint) {
     const bool srk = s->method == SNSDE_SRK;
     if (srk && (H > 128 || flavor_hint == 0)) return p;      // SRK variant: M4 tiles
     if (!(H == 256 || H == 128 || H == 64 || H == 32 || H == 16)) return p;
-    if (!(io >= 1 && io <= 6)) return p;
+    if (!(io >= 0 && io <= 6)) return p;
+    if (io == 0 && srk) return p;                     // the y-free drift under SRK stays on the generic kernels
     const bool noise_net = (no == 14 || no == 15 || no == 18 || no == 19);
     // table noise: raw = (row of a per-step table) x {1, y}: the time-only noise MLPs and the closed forms in t, sigma
     const bool tab_noise = (no >= 1 && no <= 6) || no == 11 || no == 12 || no == 13 || no == 16 || no == 17;
     const bool y_noise = (no >= 7 && no <= 10);      // raw = phi(y): sqrt y, y^3, sigmoid y, relu y
     if (!(no == 0 || tab_noise || y_noise || noise_net)) return p;
-    if (noise_net && (io == 2 || io == 4 || io == 6) && m.input_channels > 32) return p;   // nets + wide control: generic
+    if (noise_net && (io == 0 || io == 2 || io == 4 || io == 6) && m.input_channels > 32) return p;   // nets + wide control: generic
     if (noise_net && s->method != SNSDE_EULER) return p;
     if (srk && (m.input_channels > 32 && (io == 2 || io == 4 || io == 6))) return p;
     const bool emb = (io == 2 || io == 4 || io == 6);
     const int nhid = m.num_hidden_layers - 1;
     if (nhid > 3) return p;
     p.NN = noise_net ? (no >= 18 ? 2 : 1) : 0;
-    if (emb && m.input_channels > 80) return p;
+    if ((emb || io == 0) && m.input_channels > 80) return p;
     p.H = H; p.IO = io; p.NHID = nhid;
-    p.KUX = emb ? (m.input_channels > 32 ? 5 : 2) : 1;    // 16-wide k-blocks of the control channels (C <= 32 / <= 80)
+    p.KUX = (emb || io == 0) ? (m.input_channels > 32 ? 5 : 2) : 1;    // 16-wide k-blocks of the control channels (C <= 32 / <= 80)
     p.TPW = 1;
     p.NW = H / (16 * p.TPW);
     // flavour: a solve costs (rounds of resident workgroups) x (steps) x (step latency); an M16 step takes ~2.2x an
@@ -182,6 +183,8 @@ MfmaPlan make_plan(const snsde_solve* s, const SnsdeNet& net, int flavor_hint) {
         add(net.in, KUYv, 0, true);
         p.fold_b_in = net.in.src_b; p.fold_b_init = net.init.src_b; p.fold_b_emb = net.emb.src_b;
         p.fold_emb_w = net.emb.src_w;
+    } else if (io == 0) {
+        add(net.init, p.KUX, -1, true);                  // z0 = initial_network(X(t))
     } else {
         if (emb) add(net.init, p.KUX, -1, true);
         add(net.in, KUYv, -1, true);
@@ -219,6 +222,7 @@ RevPlan make_rev_plan(const snsde_solve* s, const SnsdeNet& net, const MfmaPlan&
     const int H = fp.H, io = fp.IO;
     p.H = H; p.NHID = fp.NHID; p.GEO = (io == 5 || io == 6) ? 1 : 0; p.FL = fp.FL; p.NW = fp.NW; p.NN = fp.NN;
     p.emb = (io == 2 || io == 4 || io == 6) ? 1 : 0;
+    p.IO0 = io == 0 ? 1 : 0;
     int off = 0, n = 0;
     auto add_t = [&](const SnsdeLayer& L, int col_off, int fold_tmp) {
         MfmaLayerPack& q = p.layer[n++];
@@ -234,7 +238,7 @@ RevPlan make_rev_plan(const snsde_solve* s, const SnsdeNet& net, const MfmaPlan&
     if (p.emb) fold_tmp = packed;
     add_t(net.out, 0, -1);
     for (int l = p.NHID - 1; l >= 0; --l) add_t(net.hid[l], 0, -1);
-    add_t(net.in, net.in.tshift, fold_tmp);
+    if (!p.IO0) add_t(net.in, net.in.tshift, fold_tmp);      // the y-free drift has no first_y^T
     if (p.NN == 2) add_t(net.ny1, 0, -1);                   // diffusion net, output layer first
     if (p.NN >= 1) add_t(net.ny0, net.ny0.tshift, -1);      // its y columns
     p.n_layers = n;

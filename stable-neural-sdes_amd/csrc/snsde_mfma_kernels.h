@@ -219,6 +219,8 @@ struct Cfg {
     static constexpr int NN = NN_;            // diffusion net on [tau, y]: 0 none, 1 = noise_y Linear (no 14/15), 2 = two layers (18/19)
     static constexpr bool YTIME = TIME || NN > 0;   // ybuf carries the [sin t, cos t] columns
     static constexpr bool EMB = (IO == 2 || IO == 4 || IO == 6);
+    static constexpr bool IO0 = (IO == 0);            // drift on the control path only: z = initial_network(X(t))
+    static constexpr bool USEX = EMB || IO0;          // the spline value X(t) is an input of the first layer
     static constexpr bool GEO = (IO == 5 || IO == 6);
     static constexpr bool STREAM = H > 128;   // weights streamed from L2 instead of register-resident
     static constexpr bool FOLD = EMB && FOLD_ != 0;   // emb o (linear_in, initial_network) pre-multiplied
@@ -284,15 +286,15 @@ __global__ void __launch_bounds__(CF::NT, CF::WPS) snsde_mfma_kernel(MfmaArgs a)
 
     // ---- resident weights ----------------------------------------------------------------------
     int li = 0;
-    Wt<CF::STREAM, CF::EMB ? KUX : 1, TPW> wx;
+    Wt<CF::STREAM, CF::USEX ? KUX : 1, TPW> wx;
     Wt<CF::STREAM, KUY, TPW> wy;
     Wt<CF::STREAM, (CF::EMB && !CF::FOLD) ? KUE : 1, TPW> we;
     Wt<CF::STREAM, KUH, TPW> wh[(NHID > 0) ? NHID : 1];
     Wt<CF::STREAM, KUH, TPW> wo;
     Wt<CF::STREAM, (CF::NN > 0) ? CF::KUN : 1, TPW> wn0;
     Wt<CF::STREAM, (CF::NN > 1) ? KUH : 1, TPW> wn1;
-    if constexpr (CF::EMB) wx.load(a.ws + a.w_off[li++], wave, lane);
-    wy.load(a.ws + a.w_off[li++], wave, lane);
+    if constexpr (CF::USEX) wx.load(a.ws + a.w_off[li++], wave, lane);
+    if constexpr (!CF::IO0) wy.load(a.ws + a.w_off[li++], wave, lane);
     if constexpr (CF::EMB && !CF::FOLD) we.load(a.ws + a.w_off[li++], wave, lane);
 #pragma unroll
     for (int l = 0; l < NHID; ++l) wh[l].load(a.ws + a.w_off[li++], wave, lane);
@@ -342,7 +344,7 @@ __global__ void __launch_bounds__(CF::NT, CF::WPS) snsde_mfma_kernel(MfmaArgs a)
     for (int i = 0; i < CF::XI; ++i) {
         const int it = tid + i * NT;
         xr[i] = it / C; xc[i] = it - xr[i] * C;
-        xok[i] = CF::EMB && it < M * C;
+        xok[i] = CF::USEX && it < M * C;
         if (!xok[i]) { xr[i] = 0; xc[i] = 0; }
     }
     auto load_coeffs = [&](int idx) {
@@ -362,7 +364,7 @@ __global__ void __launch_bounds__(CF::NT, CF::WPS) snsde_mfma_kernel(MfmaArgs a)
     };
     {   // step 0 inputs
         const float* st = a.step_tab;
-        if constexpr (CF::EMB) { load_coeffs(__float_as_int(st[5])); store_x(st[4]); }
+        if constexpr (CF::USEX) { load_coeffs(__float_as_int(st[5])); store_x(st[4]); }
         if (CF::YTIME && tid < M) { ybuf[tid * LDY + H] = st[2]; ybuf[tid * LDY + H + 1] = st[3]; }
     }
     __syncthreads();
@@ -457,7 +459,7 @@ __global__ void __launch_bounds__(CF::NT, CF::WPS) snsde_mfma_kernel(MfmaArgs a)
         const float n_sin = nxt.sn, n_cos = nxt.cs, n_frac = nxt.frac;
         const int n_idx = nxt.idx;
         const int c_nout = cur_row.nout, c_kfirst = cur_row.kfirst;
-        if constexpr (CF::EMB) { if (more) load_coeffs(n_idx); }   // prefetch next interval's cubic pieces
+        if constexpr (CF::USEX) { if (more) load_coeffs(n_idx); }   // prefetch next interval's cubic pieces
         const float h = cur_row.h, sqh = cur_row.sqh;
 
         // y-independent work of the step (Brownian increments, diffusion table row, next step's X(t) and time
@@ -534,7 +536,7 @@ __global__ void __launch_bounds__(CF::NT, CF::WPS) snsde_mfma_kernel(MfmaArgs a)
 
 
             if (more) {
-                if constexpr (CF::EMB) store_x(n_frac);
+                if constexpr (CF::USEX) store_x(n_frac);
                 if (CF::YTIME && tid < M) { ybuf[tid * LDY + H] = n_sin; ybuf[tid * LDY + H + 1] = n_cos; }
             }
         };
@@ -605,7 +607,8 @@ __global__ void __launch_bounds__(CF::NT, CF::WPS) snsde_mfma_kernel(MfmaArgs a)
                 ++layer;
             }
             init_acc(layer);
-            gemm<FL, KUY, TPW>(wy, yrow, acc, acc2);
+            if constexpr (CF::IO0) gemm<FL, CF::USEX ? KUX : 1, TPW>(wx, xrow, acc, acc2);      // z0 = initial_network(X(t))
+            else gemm<FL, KUY, TPW>(wy, yrow, acc, acc2);
             sum_acc();
 #pragma unroll
             for (int t = 0; t < TPW; ++t) store_frag(cat, LDC, (wave * TPW + t) * 16, acc[t], !CF::EMB, CF::EMB ? -1 : 0);
@@ -821,9 +824,10 @@ int launch_cfg(const MfmaArgs& a, hipStream_t stream) {
 // where first_y = (emb o linear_in)[:, y columns] (or linear_in[:, y columns] without emb).  relu masks and the
 // pre-tanh drift come from the forward's act_save; f, g and their derivatives are recomputed elementwise.
 // =====================================================================================================
-template <int H_, int NHID_, int GEO_, int FL_, int NN_ = 0>
+template <int H_, int NHID_, int GEO_, int FL_, int NN_ = 0, int IO0_ = 0>
 struct CfgR {
-    static constexpr int H = H_, NHID = NHID_, FL = FL_, NN = NN_;   // NN: layers of the diffusion net on [tau, y] (noise_option 14/15: 1, 18/19: 2)
+    static constexpr int H = H_, NHID = NHID_, FL = FL_, NN = NN_;
+    static constexpr bool IO0 = IO0_ != 0;       // y-free drift (input_option 0): its chain ends at the first layer's delta   // NN: layers of the diffusion net on [tau, y] (noise_option 14/15: 1, 18/19: 2)
     static constexpr bool GEO = GEO_ != 0;
     static constexpr int TPW = 1;
     static constexpr int NW = H / 16;
@@ -833,14 +837,15 @@ struct CfgR {
     static constexpr int KUH = H / 16;
     static constexpr int PAD = FL ? 16 : 8;
     static constexpr int LDA = ld_for(16 * KUH, PAD);
-    static constexpr int ND = NHID + 2;          // transposed GEMMs of the drift chain
-    static constexpr int NG = ND + NN;           // + the diffusion net's = LDS buffers = delta slots
+    static constexpr int ND = NHID + (IO0 ? 1 : 2);   // transposed GEMMs of the drift chain
+    static constexpr int NG = ND + NN;           // + the diffusion net's
+    static constexpr int NBUF = NHID + 2 + NN;   // LDS buffers = delta slots
     static constexpr int NSAVE = NHID + 2 + NN;
     static constexpr int ZSLOT = NHID + 1;
     static constexpr int EPT = FL ? 1 : 4;
     static constexpr int ROWCH = 128;
     static constexpr bool STREAM = H > 128;
-    static constexpr int LDS_FLOATS = NG * M * LDA + (ROWCH + 1) * SNSDE_STEP_STRIDE;
+    static constexpr int LDS_FLOATS = NBUF * M * LDA + (ROWCH + 1) * SNSDE_STEP_STRIDE;
 };
 
 struct RevArgs {
@@ -866,9 +871,13 @@ struct RevArgs {
 template <class CF>
 __global__ void __launch_bounds__(CF::NT, CF::WPS) snsde_mfma_reverse_kernel(RevArgs a) {
     constexpr int H = CF::H, TPW = 1, FL = CF::FL, M = CF::M, NT = CF::NT, NHID = CF::NHID, NG = CF::NG;
+    constexpr int NS = CF::NBUF;                 // LDS buffers = delta slots: z_out, hidden.., first layer, [diffusion net]
+    constexpr int NB0 = NHID + 2;                // first buffer / slot of the diffusion net's chain
+    constexpr bool IO0 = CF::IO0;
+    constexpr int NM = IO0 ? CF::ND : CF::ND - 1;   // relu masks of the drift chain
     constexpr int KUH = CF::KUH, EPT = CF::EPT, LDA = CF::LDA, NSAVE = CF::NSAVE, ND = CF::ND, NN = CF::NN;
     extern __shared__ __attribute__((aligned(16))) float lds[];
-    float* rowtab = lds + NG * M * LDA;
+    float* rowtab = lds + NS * M * LDA;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int r = FL ? (lane & 3) : (lane & 15);
@@ -886,7 +895,7 @@ __global__ void __launch_bounds__(CF::NT, CF::WPS) snsde_mfma_reverse_kernel(Rev
     Wt<CF::STREAM, KUH, TPW> wt[NG];
 #pragma unroll
     for (int g = 0; g < NG; ++g) wt[g].load(a.ws + a.w_off[g], wave, lane);
-    for (int i = tid; i < NG * M * LDA; i += NT) lds[i] = 0.0f;
+    for (int i = tid; i < NS * M * LDA; i += NT) lds[i] = 0.0f;
 
     const float sig_theta = snsde_sigmoid(a.params[a.off_theta]);
     const bool mul_y = (a.no == 13 || a.no == 17 || a.no == 15 || a.no == 19 || a.no == 3 || a.no == 6 || a.no == 11);
@@ -911,7 +920,7 @@ __global__ void __launch_bounds__(CF::NT, CF::WPS) snsde_mfma_reverse_kernel(Rev
     float th_acc = 0.0f;
 
     // per-step inputs from HBM are fetched one step ahead, so their latency hides behind the previous step's GEMM chain
-    struct StepIn { float y[EPT], z[EPT], dw[EPT], gq[EPT]; f32x4 mask[ND - 1]; f32x4 nmask; };
+    struct StepIn { float y[EPT], z[EPT], dw[EPT], gq[EPT]; f32x4 mask[NM > 0 ? NM : 1]; f32x4 nmask; };
     auto prefetch = [&](int n, StepIn& p) {
 #pragma unroll
         for (int e = 0; e < EPT; ++e) {
@@ -923,7 +932,7 @@ __global__ void __launch_bounds__(CF::NT, CF::WPS) snsde_mfma_reverse_kernel(Rev
         }
         if (writer) {
 #pragma unroll
-            for (int g = 0; g < ND - 1; ++g)     // relu mask of the forward activation feeding transposed GEMM g + 1
+            for (int g = 0; g < NM; ++g)     // relu mask of the forward activation feeding transposed GEMM g + 1
                 p.mask[g] = *reinterpret_cast<const f32x4*>(
                     a.act + (((size_t)n * NSAVE + (NHID - g)) * B + rowc) * H + wave * 16 + fsub);
             if constexpr (NN == 2)               // hidden activation of the diffusion net
@@ -1055,41 +1064,47 @@ __global__ void __launch_bounds__(CF::NT, CF::WPS) snsde_mfma_reverse_kernel(Rev
         if constexpr (FL) buf[r * LDA + fcol] = dz[0];
         else *reinterpret_cast<f32x4*>(buf + r * LDA + fcol) = f32x4{dz[0], dz[1], dz[2], dz[3]};
         if (a.delta && row_ok) {
-            float* dp = a.delta + ((size_t)n * NG * B) * H + goff;
+            float* dp = a.delta + ((size_t)n * NS * B) * H + goff;
             if constexpr (FL) dp[0] = dz[0];
             else *reinterpret_cast<f32x4*>(dp) = f32x4{dz[0], dz[1], dz[2], dz[3]};
         }
-        if constexpr (NN > 0) {     // input of the diffusion net's transposed chain (buffer / delta slot ND)
-            float* nb = lds + ND * M * LDA;
+        if constexpr (NN > 0) {     // input of the diffusion net's transposed chain (buffer / delta slot NB0)
+            float* nb = lds + NB0 * M * LDA;
             if constexpr (FL) nb[r * LDA + fcol] = dq[0];
             else *reinterpret_cast<f32x4*>(nb + r * LDA + fcol) = f32x4{dq[0], dq[1], dq[2], dq[3]};
             if (a.delta && row_ok) {
-                float* dp = a.delta + (((size_t)n * NG + ND) * B) * H + goff;
+                float* dp = a.delta + (((size_t)n * NS + NB0) * B) * H + goff;
                 if constexpr (FL) dp[0] = dq[0];
                 else *reinterpret_cast<f32x4*>(dp) = f32x4{dq[0], dq[1], dq[2], dq[3]};
             }
+        }
+        if constexpr (IO0) {        // the drift does not see y: its chain only produces the layer deltas
+#pragma unroll
+            for (int e = 0; e < EPT; ++e) adj[e] = ay[e] + carry[e];
         }
         __syncthreads();
         f32x4 acc[TPW], acc2[TPW];
 #pragma unroll
         for (int g = 0; g < NG; ++g) {
+            const int bi = g < ND ? g : NB0 + (g - ND);     // LDS buffer / delta slot holding this GEMM's input
+            const bool mid = (g < ND - 1) || (g == ND - 1 && IO0) || (g >= ND && g != NG - 1);
             acc[0] = acc2[0] = f32x4{0.f, 0.f, 0.f, 0.f};
-            gemm<FL, KUH, TPW>(wt[g], lds + g * M * LDA + r * LDA + 4 * s, acc, acc2);
+            gemm<FL, KUH, TPW>(wt[g], lds + bi * M * LDA + r * LDA + 4 * s, acc, acc2);
             f32x4 v = acc[0] + acc2[0];
             if constexpr (FL) {
 #pragma unroll
                 for (int i = 0; i < 4; ++i) v[i] = row_ror_add(v[i]);
             }
-            if (g != ND - 1 && g != NG - 1) {
+            if (mid) {
                 // relu mask of the forward activation that produced this gradient's input: slot NHID - g (drift chain),
-                // the diffusion net's hidden activation (g == ND, noise_option 18/19)
+                // the diffusion net's hidden activation (first GEMM of its chain, noise_option 18/19)
                 if (writer) {
-                    const f32x4 zsv = g < ND ? cur.mask[g < ND - 1 ? g : 0] : cur.nmask;
+                    const f32x4 zsv = g < ND ? cur.mask[g < NM ? g : 0] : cur.nmask;
 #pragma unroll
                     for (int i = 0; i < 4; ++i) v[i] = zsv[i] > 0.0f ? v[i] : 0.0f;
-                    *reinterpret_cast<f32x4*>(lds + (g + 1) * M * LDA + r * LDA + wave * 16 + fsub) = v;
+                    *reinterpret_cast<f32x4*>(lds + (bi + 1) * M * LDA + r * LDA + wave * 16 + fsub) = v;
                     if (a.delta && row_ok)
-                        *reinterpret_cast<f32x4*>(a.delta + (((size_t)n * NG + g + 1) * B + row) * H + wave * 16 + fsub) = v;
+                        *reinterpret_cast<f32x4*>(a.delta + (((size_t)n * NS + bi + 1) * B + row) * H + wave * 16 + fsub) = v;
                 }
                 __syncthreads();
             } else {
@@ -1376,7 +1391,7 @@ struct MfmaPlan {
 
 struct RevPlan {
     bool ok;
-    int H, NHID, GEO, FL, NW, NN, SRK, n_layers, fold_tmp, total_floats, emb;
+    int H, NHID, GEO, FL, NW, NN, SRK, IO0, n_layers, fold_tmp, total_floats, emb;
     int nwg;                    // workgroups of the adjoint launch
     size_t ds_off, dth_off;     // diffusion-side partial sums inside the backward workspace (0 = none)
     MfmaLayerPack layer[MAXL];
@@ -1421,6 +1436,7 @@ int dispatch_io(const MfmaPlan& p, const MfmaArgs& a, hipStream_t st) {
     if (p.IO == IO_ && p.NHID == NHID_) return a.dW ? launch_cfg<Cfg<H, 5, NHID_, IO_, FL, 0, 1, 0>>(a, st) \
                                                     : launch_cfg<Cfg<H, 5, NHID_, IO_, FL, 1, 1, 0>>(a, st);
     if (p.KUX == 5) {      // wide control paths (32 < C <= 80, e.g. the sepsis channels): folded first layer only
+        SNSDE_WIDE(0, 0) SNSDE_WIDE(0, 1) SNSDE_WIDE(0, 2) SNSDE_WIDE(0, 3)
         SNSDE_WIDE(2, 0) SNSDE_WIDE(2, 1) SNSDE_WIDE(2, 2) SNSDE_WIDE(2, 3)
         SNSDE_WIDE(4, 0) SNSDE_WIDE(4, 1) SNSDE_WIDE(4, 2) SNSDE_WIDE(4, 3)
         SNSDE_WIDE(6, 0) SNSDE_WIDE(6, 1) SNSDE_WIDE(6, 2) SNSDE_WIDE(6, 3)
@@ -1430,6 +1446,7 @@ int dispatch_io(const MfmaPlan& p, const MfmaArgs& a, hipStream_t st) {
 #define SNSDE_CASE(IO_, NHID_, NN_) \
     if (p.IO == IO_ && p.NHID == NHID_ && p.NN == NN_) return dispatch_var<H, (IO_ % 2 == 0 ? 2 : 1), NHID_, IO_, FL, NN_>(p, a, st);
 #define SNSDE_CASES(IO_, NN_) SNSDE_CASE(IO_, 0, NN_) SNSDE_CASE(IO_, 1, NN_) SNSDE_CASE(IO_, 2, NN_) SNSDE_CASE(IO_, 3, NN_)
+    SNSDE_CASES(0, 0) SNSDE_CASES(0, 1) SNSDE_CASES(0, 2)
     SNSDE_CASES(2, 0) SNSDE_CASES(4, 0) SNSDE_CASES(6, 0)
     SNSDE_CASES(1, 0) SNSDE_CASES(3, 0) SNSDE_CASES(5, 0)
     SNSDE_CASES(1, 1) SNSDE_CASES(3, 1) SNSDE_CASES(5, 1) SNSDE_CASES(1, 2) SNSDE_CASES(3, 2) SNSDE_CASES(5, 2)
@@ -1452,6 +1469,15 @@ int dispatch_rev(const RevPlan& p, const RevArgs& a, hipStream_t st) {
             SNSDE_RSRK(0) SNSDE_RSRK(1) SNSDE_RSRK(2) SNSDE_RSRK(3)
 #undef SNSDE_RSRK
         }
+        return SNSDE_ERR_UNSUPPORTED;
+    }
+    if (p.IO0) {
+#define SNSDE_R0(NH_) if (p.NHID == NH_) { \
+        if (p.NN == 1) return launch_rev<CfgR<H, NH_, 0, FL, 1, 1>>(a, st); \
+        if (p.NN == 2) return launch_rev<CfgR<H, NH_, 0, FL, 2, 1>>(a, st); \
+        return launch_rev<CfgR<H, NH_, 0, FL, 0, 1>>(a, st); }
+        SNSDE_R0(0) SNSDE_R0(1) SNSDE_R0(2) SNSDE_R0(3)
+#undef SNSDE_R0
         return SNSDE_ERR_UNSUPPORTED;
     }
 #define SNSDE_RCASE(NH_) if (p.NHID == NH_) { \

@@ -345,8 +345,10 @@ __global__ void __launch_bounds__(256) snsde_assemble_kernel(AArgs a) {
     int rel;
     if (inside(net.out.src_w, H * H, rel)) val = a.sums[a.o_out + rel];
     else if (inside(net.out.src_b, H, rel)) val = a.sums[a.b_out + rel];
-    else if (!emb && inside(net.in.src_w, H * Kin, rel)) val = a.sums[a.o_first + (size_t)(rel / Kin) * a.ld_first + rel % Kin];
-    else if (!emb && inside(net.in.src_b, H, rel)) val = a.sums[a.b_first + rel];
+    else if (a.io == 0 && inside(net.init.src_w, H * a.C, rel)) val = a.sums[a.o_first + rel];      // ld_first == C
+    else if (a.io == 0 && inside(net.init.src_b, H, rel)) val = a.sums[a.b_first + rel];
+    else if (a.io != 0 && !emb && inside(net.in.src_w, H * Kin, rel)) val = a.sums[a.o_first + (size_t)(rel / Kin) * a.ld_first + rel % Kin];
+    else if (a.io != 0 && !emb && inside(net.in.src_b, H, rel)) val = a.sums[a.b_first + rel];
     else if (emb && inside(net.emb.src_b, H, rel)) val = a.sums[a.b_first + rel];
     else if (inside(net.off_theta, 1, rel)) {
         if (a.has_dth) {
@@ -433,15 +435,16 @@ bool make_wplan(const snsde_backward* b, const SnsdeNet& net, WPlan* w) {
     const snsde_solve& s = b->fwd;
     const int H = s.model.hidden_channels, C = s.model.input_channels, io = s.model.input_option, no = s.model.noise_option;
     const int nhid = s.model.num_hidden_layers - 1;
-    const bool emb = (io == 2 || io == 4 || io == 6), timef = io >= 3;
+    const bool emb = (io == 2 || io == 4 || io == 6), timef = io >= 3, io0 = io == 0;
+    const bool usex = emb || io0;                       // X(t) is an input of the first layer
     const int nn = (no == 18 || no == 19) ? 2 : ((no == 14 || no == 15) ? 1 : 0);
     const int ts = timef ? 2 : 0;
     const int xt = (timef || nn > 0) ? 2 : 0;          // time columns present in the xaux rows
     // xaux row = [sin t, cos t | X(t)] in the drift's order; a time-free embedded drift with a diffusion net (input_option 2)
     // keeps its X block first and the net's time columns after it (at a 16-byte aligned column)
-    const bool tau_last = emb && !timef && nn > 0;
+    const bool tau_last = usex && !timef && nn > 0;
     const int t_col0 = tau_last ? ((C + 3) & ~3) : 0, x_col0 = tau_last ? 0 : xt;
-    const int naux = tau_last ? t_col0 + 2 : xt + (emb ? C : 0);
+    const int naux = tau_last ? t_col0 + 2 : xt + (usex ? C : 0);
     const int nd = nhid + 2;                           // delta slots of the drift chain
     const bool srk = s.method == SNSDE_SRK;
     const int n_pass = s.n_steps * (srk ? 3 : 1);      // drift passes (one per step, three for SRK): rows of act / delta
@@ -474,10 +477,12 @@ bool make_wplan(const snsde_backward* b, const SnsdeNet& net, WPlan* w) {
         ok = add_tiles(nhid - l, 0, l, H, aa.o_hid[l], H, aa.b_hid[l], 1 << 30, 0);
     }
     // first layer: dense sums in linear_in's column order followed by the control channels: [sin t, cos t | y | X(t)]
-    aa.ld_first = ts + H + (emb ? C : 0);
+    // (the y-free drift of input_option 0 has the control channels only: the matrix is initial_network.weight's)
+    aa.ld_first = ts + (io0 ? 0 : H) + (usex ? C : 0);
     aa.o_first = alloc((size_t)H * aa.ld_first); aa.b_first = alloc(H);
-    ok = ok && add_tiles(nhid + 1, 1, 0, H, aa.o_first + ts, aa.ld_first, aa.b_first, 1 << 30, 0);
-    if (ok && ts + (emb ? C : 0) > 0) ok = add_tiles(nhid + 1, 2, 0, ts + (emb ? C : 0), aa.o_first, aa.ld_first, -1, ts, H, 0);
+    if (!io0) ok = ok && add_tiles(nhid + 1, 1, 0, H, aa.o_first + ts, aa.ld_first, aa.b_first, 1 << 30, 0);
+    if (ok && ts + (usex ? C : 0) > 0)
+        ok = add_tiles(nhid + 1, 2, 0, ts + (usex ? C : 0), aa.o_first, aa.ld_first, io0 ? aa.b_first : -1, ts, io0 ? 0 : H, 0);
     aa.nn = nn;
     if (ok && nn > 0) {     // diffusion net: first layer on [sin t, cos t | y] (delta slot nd + nn - 1), output layer on its hidden
         const int d0n = nd + nn - 1;
@@ -519,7 +524,7 @@ bool make_wplan(const snsde_backward* b, const SnsdeNet& net, WPlan* w) {
     w->n_pass = n_pass; w->n_trow = n_trow;
     w->ds_off = o; o += w->tnoise ? NH : 0;
     w->has_dth = w->tnoise || nn > 0 || (no >= 7 && no <= 10);
-    w->t_col0 = t_col0; w->x_col0 = x_col0; w->x_cols = emb ? C : 0;
+    w->t_col0 = t_col0; w->x_col0 = x_col0; w->x_cols = usex ? C : 0;
     w->nact = nhid + 2 + nn;
     w->xt = xt;
     w->dth_off = o; o += 4;

@@ -333,6 +333,10 @@ MFMA_CASES = [
     (3, 6, 3, 9, 64, 3, 8, [0, 2.5, 7], 1.0, 'milstein'),
     (5, 2, 2, 9, 32, 3, 8, [0, 7], 0.5, 'euler'),
     (4, 4, 2, 9, 32, 3, 8, [0, 7], 1.0, 'euler'),
+    (0, 17, 2, 13, 64, 5, 8, [0, 7], 1.0, 'milstein'),            # y-free drift: z = initial_network(X(t))
+    (0, 0, 1, 9, 32, 3, 8, [0, 3, 7], 1.0, 'euler'),
+    (0, 18, 3, 9, 128, 21, 8, [0, 7], 1.0, 'euler'),
+    (0, 9, 2, 9, 16, 40, 8, [0, 7], 0.5, 'euler'),
     (2, 18, 2, 13, 64, 5, 8, [0, 7], 1.0, 'euler'),               # ... and on the time-free embedded drift
     (2, 15, 1, 9, 32, 3, 8, [0, 3, 7], 1.0, 'euler'),
     (4, 18, 2, 13, 64, 5, 8, [0, 7], 1.0, 'euler'),               # diffusion nets behind the control embedding (folded layer)
@@ -373,7 +377,7 @@ def test_mfma_trajectory_vs_oracle(ci, kernel):
 
 
 def test_mfma_unsupported_configuration_is_refused_not_silently_rerouted():
-    pr = make_problem(1, 0, 18, 2, 8, 64, 3, 5)      # the y-free drift (input_option 0): generic only
+    pr = make_problem(1, 4, 18, 2, 8, 64, 40, 5)     # diffusion net with a wide control path: generic only
     with pytest.raises(S._lib.SnsdeError) as e:
         hip_solve(pr, [0, 4], 1.0, dW=draw_dW(1, [0, 4], 1.0, 8, 64), kernel='mfma')
     assert e.value.code == -4
@@ -523,6 +527,9 @@ BWD_CASES = [
     (3, 15, 1, 11, 128, 3, 8, [0, 7], 0.5, 'euler'),
     (1, 19, 3, 9, 16, 3, 8, [0, 2.5, 7], 1.0, 'euler'),
     (3, 19, 2, 9, 128, 3, 8, [0, 7], 1.0, 'euler'),
+    (0, 17, 2, 9, 64, 5, 8, [0, 7], 1.0, 'milstein'),         # y-free drift (input_option 0)
+    (0, 18, 2, 9, 32, 3, 8, [0, 3, 7], 1.0, 'euler'),
+    (0, 4, 3, 9, 16, 40, 8, [0, 7], 1.0, 'euler'),
     (2, 18, 2, 9, 64, 5, 8, [0, 7], 1.0, 'euler'),            # time-free embedded drift + net: xaux keeps X first, tau after
     (2, 14, 1, 9, 32, 6, 8, [0, 3, 7], 1.0, 'euler'),
     (4, 18, 2, 9, 64, 5, 8, [0, 7], 1.0, 'euler'),            # diffusion nets behind the control embedding
@@ -597,7 +604,7 @@ def test_srk_backward_on_the_mfma_path(ci, kernel):
     _check_backward(4000 + ci, io, no, NL, B, H, C, L, ts, dt, 'srk', kernel)
 
 
-@pytest.mark.parametrize('io', [1, 2, 3, 4, 5, 6])
+@pytest.mark.parametrize('io', [0, 1, 2, 3, 4, 5, 6])
 @pytest.mark.parametrize('no', [0, 1, 2, 3, 4, 5, 6, 8, 9, 10, 11, 12, 13, 16, 17])   # 7 (sqrt y): autograd's own gradient is NaN for y < 0
 def test_backward_sweep_mfma_options(io, no):
     """Every (input_option, elementwise noise_option) pair of the MFMA path: adjoint kernel + native parameter pass vs
@@ -699,8 +706,8 @@ def test_native_parameter_pass_matches_library_gemm_pass(case):
 
 
 def test_backward_unsupported_configurations_raise():
-    pr = make_problem(9, 0, 18, 2, 8, 64, 3, 5)       # a diffusion net on the y-free drift (input_option 0): no fused backward
-    m = S.Diffusion_model(3, 64, 64, 2, input_option=0, noise_option=18).to(DEV)
+    pr = make_problem(9, 4, 18, 2, 8, 64, 40, 5)      # a diffusion net with more than 32 control channels: no fused backward
+    m = S.Diffusion_model(40, 64, 64, 2, input_option=4, noise_option=18).to(DEV)
     m.set_X(torch.from_numpy(pr['coeffs']).to(DEV), torch.from_numpy(pr['times']).to(DEV))
     y0 = torch.from_numpy(pr['y0']).to(DEV).requires_grad_(True)
     with pytest.raises(NotImplementedError):
@@ -987,15 +994,15 @@ def _fuzz_configs(n, seed):
     rng = np.random.default_rng(seed)
     out = []
     while len(out) < n:
-        io = int(rng.integers(1, 7))
+        io = int(rng.integers(0, 7))
         # (11 = t*y is left to the option sweeps: with t up to 10 its dynamics amplify float32 round-off beyond a fixed tolerance)
         no = int(rng.choice([0, 1, 2, 3, 4, 5, 6, 8, 9, 10, 12, 13, 16, 17, 14, 15, 18, 19]))
         method = str(rng.choice(['euler', 'milstein', 'srk']))
-        if no in (14, 15, 18, 19) and method != 'euler':
+        if (no in (14, 15, 18, 19) and method != 'euler') or (io == 0 and method == 'srk'):
             continue
         H = int(rng.choice([16, 32, 64, 128]))
         C = int(rng.choice([2, 5, 21, 33, 40])) if method != 'srk' else int(rng.choice([2, 5, 21]))
-        if no in (14, 15, 18, 19) and io in (2, 4, 6) and C > 32:
+        if no in (14, 15, 18, 19) and io in (0, 2, 4, 6) and C > 32:
             continue
         out.append((io, no, int(rng.integers(1, 5)), int(rng.integers(3, 40)), H, C, int(rng.integers(5, 12)), method))
     return out
