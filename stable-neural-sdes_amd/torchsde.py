@@ -176,11 +176,12 @@ def _sdeint_hip(sde, rec, y0, ts, bm, method, dt, options):
 
 
 class _FusedSolve(torch.autograd.Function):
-    """Differentiable fused solve.  forward = the HIP solve in training mode (keeps every state, the increments
-    used and the per-step activations); backward = the HIP adjoint recursion (snsde_solve_backward) for dL/dy0
-    and every adjoint a_n, then ONE batched evaluation of a_{n+1} . (f h + g dW) over all (step, row) pairs
-    whose autograd (plain library GEMMs) yields the parameter gradients.  This replaces autograd through the
-    ~25 x N nodes of the unrolled loop (benchmark_classification/common_sde.py:158-160)."""
+    """Differentiable fused solve.  forward = the HIP solve in training mode (keeps every state, the increments used
+    and, on the MFMA path, the per-pass activations); backward = the HIP adjoint recursion (snsde_solve_backward) for
+    dL/dy0 and every adjoint a_n, then the parameter gradients: mode 1 (MFMA path) the native split-R weight-gradient
+    pass (snsde_param_gradients), mode 2 (generic adjoint kernels) ONE batched evaluation of the step function over
+    all (step, row) pairs whose autograd yields them.  This replaces autograd through the ~25 x N nodes of the
+    unrolled loop (benchmark_classification/common_sde.py:158-160)."""
 
     @staticmethod
     def forward(ctx, sde, rec, coeffs, grid, times_host, increments, method, seed, options, y0, *params):
@@ -199,8 +200,9 @@ class _FusedSolve(torch.autograd.Function):
         if mode == 0:
             raise NotImplementedError(
                 "the fused backward covers 'euler'/'milstein'/'srk' with a diffusion that is elementwise in y "
-                "(noise_option 0..13, 16, 17) and 'euler' with the diffusion nets on input_option 1/3; pass "
-                "options={'backend': 'torch'} to differentiate this configuration through the tensor-op loop")
+                "(noise_option 0..13, 16, 17) and 'euler' with the diffusion nets 14/15/18/19 where the MFMA path is "
+                "instantiated; pass options={'backend': 'torch'} to differentiate this configuration through the "
+                "tensor-op loop")
         # mode 2: the generic adjoint prepares its own weights, so the forward takes whatever kernel is fastest
         call = make(options.get('kernel', 'auto'), mode == 1)
         ctx.mode, ctx.method = mode, method
@@ -215,7 +217,7 @@ class _FusedSolve(torch.autograd.Function):
     @staticmethod
     def backward(ctx, grad_ys):
         call, sde, grid = ctx.call, ctx.sde, ctx.grid
-        if ctx.mode == 1:     # MFMA adjoint kernel + GEMMs on the saved activations / deltas
+        if ctx.mode == 1:     # MFMA adjoint kernel + native weight-gradient pass on the saved activations / deltas
             adj, delta = engine.solve_backward(call, grad_ys.to(torch.float32).contiguous(), save_delta=True)
             if ctx.param_pass == 'torch':     # library-GEMM cross-check of the native pass
                 grads = _parameter_gradients_gemm(sde, call, grid, adj, delta, method=ctx.method)
@@ -227,7 +229,7 @@ class _FusedSolve(torch.autograd.Function):
                 for name, p in sde.named_parameters():
                     off, shape = offs[name]
                     grads.append(flat[off:off + p.numel()].view_as(p).to(p.dtype))
-        else:                 # generic adjoint kernel (any dims, Euler / Milstein) + batched autograd parameter pass
+        else:                 # generic adjoint kernels (any dims; Euler / Milstein / SRK) + batched autograd parameter pass
             adj = engine.solve_backward(call, grad_ys.to(torch.float32).contiguous())
             grads = _parameter_gradients(sde, call, grid, adj, method=ctx.method)
         return (None,) * 9 + (adj[0].to(ctx.y0_dtype),) + tuple(grads)
