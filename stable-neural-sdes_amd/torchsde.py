@@ -69,6 +69,7 @@ def _fresh_seed():
 
 
 _CAPTURE_SEEDS = {}
+_UNFUSED_WARNED = set()
 
 
 def _dev_key(device):
@@ -162,6 +163,18 @@ def _sdeint_hip(sde, rec, y0, ts, bm, method, dt, options):
         row_out = row_out.to(device=dev, dtype=torch.int32).contiguous()
         options = dict(options, row_out=row_out)
     if needs_grad:
+        mode = engine.backward_mode(model, y0c.shape[0], coeffs.shape[1] + 1, grid, method, options.get('kernel', 'auto'),
+                                    bool(options.get('exact_order', False)))
+        if mode == 0 and not options.get('strict', False):
+            # no fused adjoint for this configuration (a diffusion net under Milstein / SRK, or with more than 32 control
+            # channels): differentiate through the unfused tensor-op loop on the same device rather than fail the
+            # reference's training loop; options={'strict': True} raises instead
+            key = (sde.input_option, sde.noise_option, method)
+            if key not in _UNFUSED_WARNED:
+                _UNFUSED_WARNED.add(key)
+                warnings.warn(f"sdeint: no fused backward for input_option={key[0]}, noise_option={key[1]}, method={method!r}; "
+                              "differentiating through the unfused tensor-op loop (slow).")
+            return _sdeint_torch(sde, y0, ts, bm, method, dt, options, None)
         return _FusedSolve.apply(sde, rec, coeffs, grid, times_host, (dW, dU), method, seed, options, y0,
                                       *[p for _, p in sde.named_parameters()])
     flat = engine.flatten_params(sde, layout, numel, dev)

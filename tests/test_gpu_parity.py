@@ -705,17 +705,26 @@ def test_native_parameter_pass_matches_library_gemm_pass(case):
         assert np.abs(got - ref).max() / scale < 2e-4, (k, np.abs(got - ref).max() / scale)
 
 
-def test_backward_unsupported_configurations_raise():
+def test_backward_without_a_fused_adjoint_falls_back_to_the_tensor_loop_or_raises_when_strict():
     pr = make_problem(9, 4, 18, 2, 8, 64, 40, 5)      # a diffusion net with more than 32 control channels: no fused backward
     m = S.Diffusion_model(40, 64, 64, 2, input_option=4, noise_option=18).to(DEV)
     m.set_X(torch.from_numpy(pr['coeffs']).to(DEV), torch.from_numpy(pr['times']).to(DEV))
     y0 = torch.from_numpy(pr['y0']).to(DEV).requires_grad_(True)
+    ts = torch.tensor([0., 4.], device=DEV)
     with pytest.raises(NotImplementedError):
-        S.sdeint(m, y0, torch.tensor([0., 4.], device=DEV), method='euler', dt=1.0)
+        S.sdeint(m, y0, ts, method='euler', dt=1.0, options={'strict': True})
     m2 = S.Diffusion_model(3, 64, 64, 2, input_option=1, noise_option=14).to(DEV)     # SRK through a diffusion net
-    m2.set_X(torch.from_numpy(pr['coeffs']).to(DEV), torch.from_numpy(pr['times']).to(DEV))
+    pr2 = make_problem(9, 1, 14, 2, 8, 64, 3, 5)
+    m2.set_X(torch.from_numpy(pr2['coeffs']).to(DEV), torch.from_numpy(pr2['times']).to(DEV))
     with pytest.raises(NotImplementedError):
-        S.sdeint(m2, y0, torch.tensor([0., 4.], device=DEV), method='srk', dt=1.0)
+        S.sdeint(m2, y0, ts, method='srk', dt=1.0, options={'strict': True})
+    # default: the reference's training loop keeps running — the call differentiates through the unfused tensor-op loop
+    S.torchsde._UNFUSED_WARNED.clear()
+    with pytest.warns(UserWarning, match='no fused backward'):
+        ys = S.sdeint(m2, y0, ts, method='srk', dt=1.0, options={'seed': 3})
+    ys[-1].sum().backward()
+    assert ys.shape == (2, 8, 64) and torch.isfinite(y0.grad).all()
+    assert all(p.grad is None or torch.isfinite(p.grad).all() for p in m2.parameters())
 
 
 @pytest.mark.parametrize('kernel,method,io,no', [('mfma4', 'euler', 4, 17), ('mfma16', 'milstein', 6, 17), ('generic', 'euler', 2, 7),
