@@ -132,6 +132,20 @@ class _HostTimes:
         return hit[0]
 
     @classmethod
+    def known(cls, t):
+        """True when `scalar(t)` needs no device->host copy (python number, CPU tensor, or an element of a cached vector)."""
+        if not (torch.is_tensor(t) and t.is_cuda):
+            return True
+        if t.numel() != 1:
+            return False
+        try:
+            base = t.untyped_storage().data_ptr()
+        except Exception:
+            return False
+        return any(ref.untyped_storage().data_ptr() == base and key[1] == t._version and key[4] == t.dtype
+                   for key, (_, ref) in cls._cache.items())
+
+    @classmethod
     def scalar(cls, t):
         """float(t) without a stream sync when `t` is an element of a device vector whose host copy is cached (the
         usual `X.evaluate(times[0])` of the reference's models, neuralsde.py:66): the value is read from the host copy
@@ -176,7 +190,24 @@ class NaturalCubicSpline:
         idx = min(max(idx, 0), times.shape[0] - 2)
         return t32 - times[idx], idx
 
+    def _eval_on_device(self, t, derivative):
+        """Same arithmetic with the interval found on the device (`t` is a CUDA scalar whose value the host does not know):
+        no stream sync, recordable into a CUDA/HIP graph — the generic-sde stepper relies on it."""
+        P, times = self._packed, self._times.to(self._packed.device)
+        tt = t.to(times.dtype).reshape(())
+        idx = ((tt > times).sum() - 1).clamp(0, times.shape[0] - 2)
+        idx = idx.reshape(1)                      # (indexing with a 0-dim tensor would read it back on the host)
+        frac = (tt - times.index_select(0, idx).squeeze(0)).to(P.dtype)
+        row = P.index_select(-2, idx).squeeze(-2)
+        Cn = self._channels
+        a, b, c2, d3 = (row[..., k * Cn:(k + 1) * Cn] for k in range(4))
+        if derivative:
+            return b + (c2 + d3 * frac) * frac
+        return a + (b + (0.5 * c2 + d3 * frac / 3) * frac) * frac
+
     def _eval(self, t, derivative):
+        if torch.is_tensor(t) and t.is_cuda and self._packed.is_cuda and not _HostTimes.known(t):
+            return self._eval_on_device(t, derivative)
         frac, idx = self._interpret_t(t)
         P = self._packed
         if P.is_cuda and P.dtype == torch.float32 and not P.requires_grad:

@@ -16,6 +16,7 @@ reference tree): time accumulates in float32 by repeated ``curr_t + dt`` clamped
 outputs are linearly interpolated between the two solver states bracketing each ``ts[k]``;
 Euler ``y + f*h + g*dW``; Milstein adds ``0.5 * g * dg/dy * (dW^2 - h)`` (Ito, diagonal noise).
 """
+import os
 import warnings
 
 import numpy as np
@@ -498,26 +499,47 @@ def _sdeint_torch(sde, y0, ts, bm, method, dt, options, names):
         raise NotImplementedError("only Ito SDEs are implemented")
     ts_host = _HostTimes.get(ts)
     grid = engine.StepGrid(ts_host, dt, np.array([0.0, 1.0], dtype=np.float32), None)
-    if bm is None:
-        bm = BrownianIncrements(size=tuple(y0.shape), dtype=y0.dtype, device=y0.device, entropy=options.get('seed'))
     t0s = torch.from_numpy(grid.t0).to(y0.device)
     t1s = torch.from_numpy(grid.t1).to(y0.device)
     w = torch.from_numpy(grid.out_w).to(device=y0.device, dtype=y0.dtype)
+    hs = (t1s - t0s).to(y0.dtype)
+    # every increment of the solve up front: (N, B, H) I_k (and I_k0 for SRK)
+    if bm is None:
+        gen = torch.Generator(device=y0.device)
+        seed = options.get('seed')
+        gen.manual_seed(int(seed) if seed is not None and not torch.is_tensor(seed) else _fresh_seed())
+        hcol = hs.reshape(-1, *([1] * y0.dim()))
+        dW_all = torch.randn((grid.N,) + tuple(y0.shape), dtype=y0.dtype, device=y0.device, generator=gen) * hcol.sqrt()
+        dU_all = None
+        if method == 'srk':      # I_k0 = h (I_k / 2 + sqrt(h / 12) xi): the space-time Levy integral
+            xi = torch.randn((grid.N,) + tuple(y0.shape), dtype=y0.dtype, device=y0.device, generator=gen)
+            dU_all = hcol * (0.5 * dW_all + (hcol / 12).sqrt() * xi)
+    elif method == 'srk':
+        pairs = [bm(t0s[n], t1s[n], return_U=True) for n in range(grid.N)]
+        dW_all = torch.stack([p[0].to(device=y0.device, dtype=y0.dtype) for p in pairs])
+        dU_all = torch.stack([p[1].to(device=y0.device, dtype=y0.dtype) for p in pairs])
+    else:
+        dW_all = torch.stack([bm(t0s[n], t1s[n]).to(device=y0.device, dtype=y0.dtype) for n in range(grid.N)])
+        dU_all = None
+    needs_grad = torch.is_grad_enabled() and (y0.requires_grad or any(
+        p.requires_grad for p in getattr(sde, 'parameters', lambda: [])()))
+    if (y0.is_cuda and not needs_grad and method in ('euler', 'srk') and options.get('graph', True)
+            and not torch.cuda.is_current_stream_capturing()):
+        ys = _graphed_steps(f, g, y0, grid, t0s, hs, w, dW_all, dU_all, method)
+        if ys is not None:
+            return _select_rows(ys, options)
     y = y0
     ys = [y0]
     k = 0
     for n in range(grid.N):
-        t0, t1 = t0s[n], t1s[n]
-        h = (t1 - t0).to(y0.dtype)
+        t0, h = t0s[n], hs[n]
         prev = y
+        I = dW_all[n]
         if method == 'srk':
-            I, I0 = bm(t0, t1, return_U=True)
-            y = _srk_step(f, g, t0, h, y, I, I0)
+            y = _srk_step(f, g, t0, h, y, I, dU_all[n])
         elif method == 'euler':
-            I = bm(t0, t1)
             y = y + f(t0, y) * h + g(t0, y) * I
         else:
-            I = bm(t0, t1)
             v = I * I - h
             # g * dg/dy * v for diagonal noise; when differentiating, the cotangent keeps its dependence on y so that
             # autograd through this loop is the exact gradient of the discrete scheme (what the fused adjoint computes)
@@ -534,9 +556,70 @@ def _sdeint_torch(sde, y0, ts, bm, method, dt, options, names):
         while k < grid.T - 1 and grid.out_step[k] == n:
             ys.append(y if grid.out_w[k, 0] == 0 else w[k, 0] * prev + w[k, 1] * y)
             k += 1
-    ys = torch.stack(ys, dim=0)
+    return _select_rows(torch.stack(ys, dim=0), options)
+
+
+def _select_rows(ys, options):
     row_out = (options or {}).get('row_out')
     if row_out is not None:     # same contract as the fused path: each row's own output state, (B, H)
         idx = row_out.to(device=ys.device, dtype=torch.int64).reshape(1, -1, 1).expand(1, ys.shape[1], ys.shape[2])
         ys = ys.gather(0, idx).squeeze(0)
+    return ys
+
+
+def _graphed_steps(f, g, y0, grid, t0s, hs, w, dW_all, dU_all, method):
+    """Generic-`sde` stepper for CUDA tensors without gradients: ONE solver step of the user's f / g —
+    time, step size and increments picked from device arrays by an in-graph step counter, state updated in place — is
+    recorded into a hipGraph inside this call and replayed N times, so a step costs one graph launch instead of the
+    ~25-100 kernel launches of the tensor-op loop.  The graph lives only for this call (every tensor the user's module
+    touches is alive and fixed meanwhile).  Returns None — the caller then runs the eager loop — when the step cannot be
+    recorded (a device->host sync or data-dependent control flow inside f / g)."""
+    dev = y0.device
+    y_buf = y0.detach().clone()
+    prev_buf = y_buf.clone()
+    cnt = torch.zeros(1, dtype=torch.int64, device=dev)
+
+    def step():
+        t = t0s.index_select(0, cnt).squeeze(0)
+        h = hs.index_select(0, cnt).squeeze(0)
+        I = dW_all.index_select(0, cnt).squeeze(0)
+        prev_buf.copy_(y_buf)
+        if method == 'euler':
+            y_new = y_buf + f(t, y_buf) * h + g(t, y_buf) * I
+        else:
+            y_new = _srk_step(f, g, t, h, y_buf, I, dU_all.index_select(0, cnt).squeeze(0))
+        y_buf.copy_(y_new)
+        cnt.add_(1)
+
+    prev_mode = torch.cuda.get_sync_debug_mode()
+    try:
+        side = torch.cuda.Stream(device=dev)
+        side.wait_stream(torch.cuda.current_stream(dev))
+        with torch.cuda.stream(side), torch.no_grad():
+            torch.cuda.set_sync_debug_mode('error')        # a sync inside f / g means the step cannot be recorded
+            step()                                          # torch's capture recipe: one eager run on a side stream
+            torch.cuda.set_sync_debug_mode(prev_mode)
+        torch.cuda.current_stream(dev).wait_stream(side)
+        y_buf.copy_(y0); cnt.zero_()
+        graph = torch.cuda.CUDAGraph()
+        with torch.no_grad(), torch.cuda.graph(graph):
+            step()
+    except Exception as exc:
+        torch.cuda.set_sync_debug_mode(prev_mode)
+        torch.cuda.synchronize(dev)
+        if os.environ.get('SNSDE_DEBUG_GRAPH') == '1':
+            warnings.warn(f'generic-sde step not recorded: {type(exc).__name__}: {exc}')
+        return None
+    ys = torch.empty((grid.T,) + tuple(y0.shape), dtype=y0.dtype, device=dev)
+    ys[0].copy_(y0)
+    k = 0
+    with torch.no_grad():
+        for n in range(grid.N):
+            graph.replay()
+            while k < grid.T - 1 and grid.out_step[k] == n:
+                if grid.out_w[k, 0] == 0:
+                    ys[k + 1].copy_(y_buf)
+                else:
+                    ys[k + 1].copy_(w[k, 0] * prev_buf + w[k, 1] * y_buf)
+                k += 1
     return ys

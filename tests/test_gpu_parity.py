@@ -1144,3 +1144,54 @@ def test_wide_batches_auto_selection_vs_generic(case):
             assert ga is None or float(ga.abs().max()) < 1e-4
             continue
         assert float((ga - gb).abs().max()) / float(gb.abs().max()) < 5e-3
+
+
+# ---- generic sde (arbitrary f / g modules): the hipGraph-replayed stepper -----------------------
+class _LipSwish(torch.nn.Module):
+    def forward(self, x):
+        return 0.909 * torch.nn.functional.silu(x)
+
+
+class _TutorialField(torch.nn.Module):
+    """The tutorial's 'pure' LSDE vector field (tutorial/*.ipynb cell 7): LipSwish MLPs, control path through
+    torchcde.CubicSpline, time-only diffusion."""
+    sde_type, noise_type = 'ito', 'diagonal'
+
+    def __init__(self, input_dim, hidden, sync=False):
+        super().__init__()
+        mlp = lambda i, o: torch.nn.Sequential(torch.nn.Linear(i, hidden), _LipSwish(), torch.nn.Linear(hidden, o))
+        self.linear_X = torch.nn.Linear(input_dim, hidden)
+        self.emb = torch.nn.Linear(2 * hidden, hidden)
+        self.f_net, self.linear_out = mlp(hidden, hidden), torch.nn.Linear(hidden, hidden)
+        self.noise_in, self.g_net = torch.nn.Linear(1, hidden), mlp(hidden, hidden)
+        self.sync = sync
+
+    def set_X(self, coeffs, times):
+        self.X = S.torchcde.CubicSpline(coeffs, times)
+
+    def f(self, t, y):
+        if self.sync:
+            float(t)                      # a device->host sync: such a step cannot be recorded
+        z = self.emb(torch.cat([y, self.linear_X(self.X.evaluate(t))], dim=-1))
+        return self.linear_out(self.f_net(z))
+
+    def g(self, t, y):
+        tt = torch.full_like(y[:, :1], 1.0) * t
+        return self.g_net(self.noise_in(tt))
+
+
+@pytest.mark.parametrize('method', ['euler', 'srk'])
+@pytest.mark.parametrize('sync', [False, True])
+def test_generic_sde_graph_replayed_stepper_equals_the_eager_loop(method, sync):
+    torch.manual_seed(0)
+    B, H, C, L = 16, 32, 2, 20
+    field = _TutorialField(C, H, sync=sync).to(DEV)
+    times = torch.linspace(0, 1, L, device=DEV)
+    X = torch.cumsum(torch.randn(B, L, C, device=DEV) * 0.1, 1)
+    field.set_X(S.torchcde.hermite_cubic_coefficients_with_backward_differences(X, times), times)
+    y0 = torch.randn(B, H, device=DEV)
+    with torch.no_grad():
+        a = S.sdeint(field, y0, times, dt=0.05, method=method, options={'seed': 11})                     # graph (or fallback)
+        b = S.sdeint(field, y0, times, dt=0.05, method=method, options={'seed': 11, 'graph': False})     # eager loop
+    assert a.shape == (L, B, H) and torch.isfinite(a).all()
+    assert torch.equal(a, b)
