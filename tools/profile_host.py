@@ -9,6 +9,8 @@ import bench
 from tests.helpers import make_problem
 dev = torch.device('cuda:0')
 IO, NO, NL, B, H, C_, L, METHOD, TS_ALL = bench.IO, bench.NO, bench.NL, bench.B, bench.H, bench.C, bench.L, 'euler', False
+if 'k1' in sys.argv:
+    IO, NO, NL, B, H, C_, L, METHOD, TS_ALL = 2, 16, 1, 256, 32, 2, 51, 'euler', True
 if 'k5' in sys.argv:
     IO, NO, NL, B, H, C_, L, METHOD, TS_ALL = 4, 17, 2, 128, 256, 14, 50, 'milstein', True
 pr = make_problem(1234, IO, NO, NL, B, H, C_, L, nan_frac=0.3)
@@ -31,4 +33,4 @@ torch.cuda.synchronize()
 pf = cProfile.Profile(); pf.enable()
 for _ in range(20): step()
 pf.disable(); torch.cuda.synchronize()
-st = pstats.Stats(pf); st.sort_stats('cumulative').print_stats(28)
+st = pstats.Stats(pf); st.sort_stats('tottime').print_stats(22)
