@@ -734,6 +734,7 @@ def test_per_row_output_selection_equals_gather(kernel, method, io, no):
     """options['row_out'] (per-row output slot, fused into the solve) == solving for every output and gathering
     (the per-row selection of NeuralSDE.forward, neuralsde.py:115-116), forward and backward, bit for bit."""
     B, H, C, L = 37, 64, 5, 12
+    torch.manual_seed(99)
     pr = make_problem(41, io, no, 2, B, H, C, L)
     ts = torch.tensor([0., 2.5, 4., 7., 11.], device=DEV)       # includes an interpolated output
     slot = torch.randint(0, 5, (B,), device=DEV)
@@ -1081,6 +1082,7 @@ def test_long_grids_mfma_vs_generic_forward_and_backward(case, outputs):
     """Grids longer than one LDS step-table chunk, with final-only / every-knot / per-row outputs: MFMA kernels against the
     generic kernels (forward on Philox increments from the same key; gradients where both adjoints exist)."""
     io, no, NL, B, H, C, L, method, dt = case
+    torch.manual_seed(1234)
     pr = make_problem(L * 7 + io, io, no, NL, B, H, C, L)
     times = torch.from_numpy(pr['times']).to(DEV)
     ts = times if outputs != 'ends' else times[[0, L - 1]]
@@ -1121,6 +1123,7 @@ def test_wide_batches_auto_selection_vs_generic(case):
     """Batches beyond one round of workgroups (automatic M4 / M16 choice, many R-splits in the weight-gradient pass):
     forward and gradients against the generic kernels."""
     io, no, NL, B, H, C, L, method = case
+    torch.manual_seed(4321)
     pr = make_problem(B + L, io, no, NL, B, H, C, L)
     times = torch.from_numpy(pr['times']).to(DEV)
     ts = times[[0, L // 2, L - 1]]
