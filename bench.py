@@ -36,7 +36,7 @@ PEAK_FP32_TFLOPS = 157.3            # MI355X_MICROARCH.md: fp32 vector = fp32 MF
 PEAK_HBM_GBS = 8000.0
 # HBM bytes per launch of the solve kernel from rocprofv3 PMC passes (FETCH_SIZE doubled per the gfx950 correction
 # in MI355X_MICROARCH.md, + WRITE_SIZE; profiles/r01_pmc_traffic.txt); re-measure when the kernel's memory behaviour changes.
-HBM_TRAFFIC_BYTES_PER_LAUNCH = 38129664   # K2, MFMA M4 kernel, round 1
+HBM_TRAFFIC_BYTES_PER_LAUNCH = 38137856   # K2, MFMA M4 kernel, round 1
 
 
 def build_inputs(device, rank):

@@ -91,7 +91,7 @@ __host__ __device__ constexpr int ld_for(int K, int pad) { return ((K - pad + 63
 
 template <int FL> __device__ __forceinline__ f32x4 mfma(float a, float b, f32x4 c) {
     if constexpr (FL == 0) return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
-    else return __builtin_amdgcn_mfma_f32_4x4x1f32(a, b, c, 0, 0, 0);
+    else return __builtin_amdgcn_mfma_f32_4x4x1f32(a, b, c, 0, 0, 4);   // BLGP 4: B taken from lanes 0-15 for every 16-lane group
 }
 
 // k-slot reduction of the M4 flavour: lanes 4s+j (s = 0..3) of every 16-lane row hold partial sums
@@ -100,6 +100,27 @@ __device__ __forceinline__ float row_ror_add(float x) {
     x += a;
     float b = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x128, 0xf, 0xf, false));
     return x + b;
+}
+
+// k-slot reduce-scatter of the M4 flavour: lane 16q+4s+r holds the partial sums v[0..3] (features 4q..4q+3, row r) of
+// k-slot s; lane s gets back the total of v[s] over the four k-slots.  Butterfly over lane bit 3 (row_ror:8) and bit 2
+// (row_ror:12 = from lane+4 / row_ror:4 = from lane-4); which half a lane keeps is selected by the DPP bank mask
+// (bank = s), so there are no selects: 6 VALU ops (all-reduce of four values + select: 19).  The s_nops cover the
+// VALU-write -> DPP-read hazard the assembler does not see inside inline asm.
+__device__ __forceinline__ float m4_reduce_scatter(f32x4 v) {
+    float z0 = v[0], z1 = v[1], z2 = v[2], z3 = v[3], a0, a1, r;
+    asm volatile(
+        "s_nop 1\n\t"
+        "v_add_f32_dpp %0, %3, %3 row_ror:8 row_mask:0xf bank_mask:0x3\n\t"
+        "v_add_f32_dpp %0, %5, %5 row_ror:8 row_mask:0xf bank_mask:0xc\n\t"
+        "v_add_f32_dpp %1, %4, %4 row_ror:8 row_mask:0xf bank_mask:0x3\n\t"
+        "v_add_f32_dpp %1, %6, %6 row_ror:8 row_mask:0xf bank_mask:0xc\n\t"
+        "v_add_f32_dpp %2, %0, %0 row_ror:12 row_mask:0xf bank_mask:0x5\n\t"
+        "s_nop 0\n\t"
+        "v_add_f32_dpp %2, %1, %1 row_ror:4 row_mask:0xf bank_mask:0xa\n\t"
+        : "=&v"(a0), "=&v"(a1), "=&v"(r)
+        : "v"(z0), "v"(z1), "v"(z2), "v"(z3));
+    return r;
 }
 
 // y-only closed-form diffusions (noise_option 7..10, neuralsde.py:250-261): raw = phi(y) with its first two derivatives
@@ -145,8 +166,19 @@ template <int FL, int KU, int TPW>
 __device__ __forceinline__ void gemm(const float (&w)[TPW][KU * 4], const float* in, f32x4 (&acc)[TPW],
                                      f32x4 (&acc2)[TPW]) {
     f32x4 b[KU];
+    if constexpr (FL) {
+        // M4: the B operand depends on (k-slot, row) = lane & 15 only, the MFMA broadcasts lanes 0-15 (BLGP 4): only those
+        // lanes read LDS, a quarter of the LDS traffic of a full-wave ds_read_b128
 #pragma unroll
-    for (int u = 0; u < KU; ++u) b[u] = *reinterpret_cast<const f32x4*>(in + 16 * u);
+        for (int u = 0; u < KU; ++u) asm volatile("" : "=v"(b[u]));     // lanes 16-63: whatever the registers hold (never read)
+        if ((int)(threadIdx.x & 63) < 16) {
+#pragma unroll
+            for (int u = 0; u < KU; ++u) b[u] = *reinterpret_cast<const f32x4*>(in + 16 * u);
+        }
+    } else {
+#pragma unroll
+        for (int u = 0; u < KU; ++u) b[u] = *reinterpret_cast<const f32x4*>(in + 16 * u);
+    }
 #pragma unroll
     for (int u = 0; u < KU; ++u)
 #pragma unroll
@@ -385,10 +417,19 @@ __global__ void __launch_bounds__(CF::NT, CF::WPS) snsde_mfma_kernel(MfmaArgs a)
 
     // store one layer output fragment (bias came in through the accumulator init) as 16 B per lane
     int save_step = 0;   // current step, for the optional activation save
-    auto store_frag = [&](float* buf, int ld, int col0, f32x4 v, bool relu, int save_slot = -1) {
-        if constexpr (FL) {
+    // M4: the layer's bias is added after the k-slot reduction, from a register (one value per lane and layer)
+    float bias_own[CF::NLAYER];
 #pragma unroll
-            for (int i = 0; i < 4; ++i) v[i] = row_ror_add(v[i]);
+    for (int l = 0; l < CF::NLAYER; ++l) bias_own[l] = FL ? a.ws[a.bias_off + l * H + wave * 16 + fsub + s] : 0.0f;
+    auto finish = [&](int lyr, f32x4 v) { return m4_reduce_scatter(v) + bias_own[lyr]; };   // M4: this lane's output
+    auto store_frag = [&](float* buf, int ld, int col0, f32x4 v, bool relu, int save_slot, int lyr) {
+        if constexpr (FL) {
+            float o = finish(lyr, v);
+            if (relu) o = fmaxf(o, 0.0f);
+            buf[r * ld + col0 + fsub + s] = o;
+            if (save_slot >= 0 && a.act_save && row_ok)
+                a.act_save[(((size_t)save_step * CF::NSAVE + save_slot) * B + row) * H + wave * 16 + fsub + s] = o;
+            return;
         }
         if (relu) {
 #pragma unroll
@@ -402,9 +443,8 @@ __global__ void __launch_bounds__(CF::NT, CF::WPS) snsde_mfma_kernel(MfmaArgs a)
         }
     };
     auto bias_frag = [&](int layer, int t) {
-        f32x4 v = *reinterpret_cast<const f32x4*>(bias + layer * H + (wave * TPW + t) * 16 + fsub);
-        if constexpr (FL) { if (s != 0) v = f32x4{0.f, 0.f, 0.f, 0.f}; }
-        return v;
+        if constexpr (FL) return f32x4{0.f, 0.f, 0.f, 0.f};
+        return *reinterpret_cast<const f32x4*>(bias + layer * H + (wave * TPW + t) * 16 + fsub);
     };
 
     // Step-table rows are staged in LDS in chunks of ROWCH steps (a uniform global load per step would put its
@@ -562,21 +602,21 @@ __global__ void __launch_bounds__(CF::NT, CF::WPS) snsde_mfma_kernel(MfmaArgs a)
             sum_acc();
             TRACE(2)
 #pragma unroll
-            for (int t = 0; t < TPW; ++t) store_frag(bufA, LDA, (wave * TPW + t) * 16, acc[t], true, 0);
+            for (int t = 0; t < TPW; ++t) store_frag(bufA, LDA, (wave * TPW + t) * 16, acc[t], true, 0, layer);
             ++layer;
             if constexpr (CF::NN > 0) {   // diffusion net, first layer, on the same [y, sin t, cos t] rows
                 constexpr int NROW = CF::NLAYER - CF::NN;
                 init_acc(NROW);
                 gemm<FL, (CF::NN > 0) ? CF::KUN : 1, TPW>(wn0, yrow, acc, acc2);
                 sum_acc();
-                if constexpr (CF::NN == 2) store_frag(nbuf, LDA, wave * 16, acc[0], true, CF::ZSLOT + 1);
+                if constexpr (CF::NN == 2) store_frag(nbuf, LDA, wave * 16, acc[0], true, CF::ZSLOT + 1, NROW);
                 else {
                     gnv = acc[0];
                     if constexpr (FL) {
-#pragma unroll
-                        for (int i = 0; i < 4; ++i) gnv[i] = row_ror_add(gnv[i]);
-                    }
-                    if (writer && a.act_save && row_ok)
+                        gnv[0] = finish(NROW, gnv);
+                        if (a.act_save && row_ok)
+                            a.act_save[(((size_t)n * CF::NSAVE + CF::ZSLOT + 1) * B + row) * H + wave * 16 + fsub + s] = gnv[0];
+                    } else if (a.act_save && row_ok)
                         *reinterpret_cast<f32x4*>(a.act_save + (((size_t)n * CF::NSAVE + CF::ZSLOT + 1) * B + row) * H + wave * 16 + fsub) = gnv;
                 }
             }
@@ -588,13 +628,16 @@ __global__ void __launch_bounds__(CF::NT, CF::WPS) snsde_mfma_kernel(MfmaArgs a)
                 gemm<FL, (CF::NN > 1) ? KUH : 1, TPW>(wn1, nbuf + r * LDA + 4 * s, acc, acc2);
                 sum_acc();
                 gnv = acc[0];
+                if constexpr (FL) {
+                    gnv[0] = fmaxf(finish(CF::NLAYER - 1, gnv), 0.0f);
+                    if (a.act_save && row_ok)
+                        a.act_save[(((size_t)n * CF::NSAVE + CF::ZSLOT + 2) * B + row) * H + wave * 16 + fsub + s] = gnv[0];
+                } else {
 #pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    if constexpr (FL) gnv[i] = row_ror_add(gnv[i]);
-                    gnv[i] = fmaxf(gnv[i], 0.0f);
+                    for (int i = 0; i < 4; ++i) gnv[i] = fmaxf(gnv[i], 0.0f);
+                    if (a.act_save && row_ok)
+                        *reinterpret_cast<f32x4*>(a.act_save + (((size_t)n * CF::NSAVE + CF::ZSLOT + 2) * B + row) * H + wave * 16 + fsub) = gnv;
                 }
-                if (writer && a.act_save && row_ok)
-                    *reinterpret_cast<f32x4*>(a.act_save + (((size_t)n * CF::NSAVE + CF::ZSLOT + 2) * B + row) * H + wave * 16 + fsub) = gnv;
             }
             cur = arow;
         } else {
@@ -603,7 +646,7 @@ __global__ void __launch_bounds__(CF::NT, CF::WPS) snsde_mfma_kernel(MfmaArgs a)
                 gemm<FL, CF::EMB ? KUX : 1, TPW>(wx, xrow, acc, acc2);
                 sum_acc();
 #pragma unroll
-                for (int t = 0; t < TPW; ++t) store_frag(cat, LDC, H + (wave * TPW + t) * 16, acc[t], false);
+                for (int t = 0; t < TPW; ++t) store_frag(cat, LDC, H + (wave * TPW + t) * 16, acc[t], false, -1, layer);
                 ++layer;
             }
             init_acc(layer);
@@ -611,21 +654,21 @@ __global__ void __launch_bounds__(CF::NT, CF::WPS) snsde_mfma_kernel(MfmaArgs a)
             else gemm<FL, KUY, TPW>(wy, yrow, acc, acc2);
             sum_acc();
 #pragma unroll
-            for (int t = 0; t < TPW; ++t) store_frag(cat, LDC, (wave * TPW + t) * 16, acc[t], !CF::EMB, CF::EMB ? -1 : 0);
+            for (int t = 0; t < TPW; ++t) store_frag(cat, LDC, (wave * TPW + t) * 16, acc[t], !CF::EMB, CF::EMB ? -1 : 0, layer);
             ++layer;
             if constexpr (CF::NN > 0) {   // diffusion net, first layer, on the same [y, sin t, cos t] rows
                 constexpr int NROW = CF::NLAYER - CF::NN;
                 init_acc(NROW);
                 gemm<FL, (CF::NN > 0) ? CF::KUN : 1, TPW>(wn0, yrow, acc, acc2);
                 sum_acc();
-                if constexpr (CF::NN == 2) store_frag(nbuf, LDA, wave * 16, acc[0], true, CF::ZSLOT + 1);
+                if constexpr (CF::NN == 2) store_frag(nbuf, LDA, wave * 16, acc[0], true, CF::ZSLOT + 1, NROW);
                 else {
                     gnv = acc[0];
                     if constexpr (FL) {
-#pragma unroll
-                        for (int i = 0; i < 4; ++i) gnv[i] = row_ror_add(gnv[i]);
-                    }
-                    if (writer && a.act_save && row_ok)
+                        gnv[0] = finish(NROW, gnv);
+                        if (a.act_save && row_ok)
+                            a.act_save[(((size_t)n * CF::NSAVE + CF::ZSLOT + 1) * B + row) * H + wave * 16 + fsub + s] = gnv[0];
+                    } else if (a.act_save && row_ok)
                         *reinterpret_cast<f32x4*>(a.act_save + (((size_t)n * CF::NSAVE + CF::ZSLOT + 1) * B + row) * H + wave * 16 + fsub) = gnv;
                 }
             }
@@ -635,13 +678,16 @@ __global__ void __launch_bounds__(CF::NT, CF::WPS) snsde_mfma_kernel(MfmaArgs a)
                 gemm<FL, (CF::NN > 1) ? KUH : 1, TPW>(wn1, nbuf + r * LDA + 4 * s, acc, acc2);
                 sum_acc();
                 gnv = acc[0];
+                if constexpr (FL) {
+                    gnv[0] = fmaxf(finish(CF::NLAYER - 1, gnv), 0.0f);
+                    if (a.act_save && row_ok)
+                        a.act_save[(((size_t)n * CF::NSAVE + CF::ZSLOT + 2) * B + row) * H + wave * 16 + fsub + s] = gnv[0];
+                } else {
 #pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    if constexpr (FL) gnv[i] = row_ror_add(gnv[i]);
-                    gnv[i] = fmaxf(gnv[i], 0.0f);
+                    for (int i = 0; i < 4; ++i) gnv[i] = fmaxf(gnv[i], 0.0f);
+                    if (a.act_save && row_ok)
+                        *reinterpret_cast<f32x4*>(a.act_save + (((size_t)n * CF::NSAVE + CF::ZSLOT + 2) * B + row) * H + wave * 16 + fsub) = gnv;
                 }
-                if (writer && a.act_save && row_ok)
-                    *reinterpret_cast<f32x4*>(a.act_save + (((size_t)n * CF::NSAVE + CF::ZSLOT + 2) * B + row) * H + wave * 16 + fsub) = gnv;
             }
             cur = crow;
             if constexpr (CF::EMB) {
@@ -649,7 +695,7 @@ __global__ void __launch_bounds__(CF::NT, CF::WPS) snsde_mfma_kernel(MfmaArgs a)
                 gemm<FL, (CF::EMB && !CF::FOLD) ? KUE : 1, TPW>(we, crow, acc, acc2);
                 sum_acc();
 #pragma unroll
-                for (int t = 0; t < TPW; ++t) store_frag(bufA, LDA, (wave * TPW + t) * 16, acc[t], true, 0);
+                for (int t = 0; t < TPW; ++t) store_frag(bufA, LDA, (wave * TPW + t) * 16, acc[t], true, 0, layer);
                 ++layer;
                 __syncthreads();
                 cur = arow;
@@ -665,7 +711,7 @@ __global__ void __launch_bounds__(CF::NT, CF::WPS) snsde_mfma_kernel(MfmaArgs a)
             sum_acc();
             TRACE(5)
 #pragma unroll
-            for (int t = 0; t < TPW; ++t) store_frag(toB ? bufB : bufA, LDA, (wave * TPW + t) * 16, acc[t], true, 1 + l);
+            for (int t = 0; t < TPW; ++t) store_frag(toB ? bufB : bufA, LDA, (wave * TPW + t) * 16, acc[t], true, 1 + l, layer);
             ++layer;
             __syncthreads();
             TRACE(6)
@@ -681,15 +727,11 @@ __global__ void __launch_bounds__(CF::NT, CF::WPS) snsde_mfma_kernel(MfmaArgs a)
 #pragma unroll
         for (int t = 0; t < TPW; ++t) {
             f32x4 zv = acc[t];
-            if constexpr (FL) {
-#pragma unroll
-                for (int i = 0; i < 4; ++i) zv[i] = row_ror_add(zv[i]);
-            }
+            if constexpr (FL) zv[0] = finish(layer, zv);
             float ynew[EPT], yold[EPT], zsave[EPT];
 #pragma unroll
             for (int e = 0; e < EPT; ++e) {
                 float z = zv[FL ? 0 : e];
-                if constexpr (FL) { z = s1 ? zv[1] : z; z = s2 ? zv[2] : z; z = s3 ? zv[3] : z; }
                 zsave[e] = z;
                 const float y = yv[t][e];
                 if constexpr (CF::GEO) z *= fast_tanh(y);
@@ -735,7 +777,6 @@ __global__ void __launch_bounds__(CF::NT, CF::WPS) snsde_mfma_kernel(MfmaArgs a)
                 float gq = gtv[t][e];
                 if constexpr (CF::NN > 0) {
                     gq = gnv[FL ? 0 : e];
-                    if constexpr (FL) { gq = s1 ? gnv[1] : gq; gq = s2 ? gnv[2] : gq; gq = s3 ? gnv[3] : gq; }
                 }
                 float q1 = 0.0f, q2 = 0.0f;
                 const float raw = yfun ? snsde_phi(no, y, q1, q2) : (mul_y ? gq * y : gq);
