@@ -29,11 +29,15 @@ using namespace snsde_mfma;
 namespace {
 
 // packed[dst + ((w*TPW + t)*KU + u)*256 + lane*4 + e] = W[feature][k(u,s,e)]
-__global__ void snsde_mfma_pack_kernel(const float* __restrict__ params, float* __restrict__ ws, MfmaPackJob job) {
-    const MfmaLayerPack L = job.layer[blockIdx.y];
+// `direct`: the folded layers' in-range entries (and folded bias) are written by the fold blocks of the same launch
+// (snsde_prepare_kernel), this pass only writes their zero padding.
+__device__ __forceinline__ void pack_layer(const float* __restrict__ params, float* __restrict__ ws, const MfmaPackJob& job,
+                                           int layer, int bx, int nbx, bool direct) {
+    const MfmaLayerPack L = job.layer[layer];
     const int per_wave = job.TPW * L.KU * 256;
     const int total = job.NW * per_wave;
-    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+    const bool skip = direct && L.fold && !L.transpose;
+    for (int i = bx * blockDim.x + threadIdx.x; i < total; i += nbx * blockDim.x) {
         const int e = i & 3, lane = (i >> 2) & 63, blk = i >> 8;
         const int u = blk % L.KU, wt = blk / L.KU;  // wt = w*TPW + t
         int feat, s;
@@ -47,12 +51,13 @@ __global__ void snsde_mfma_pack_kernel(const float* __restrict__ params, float* 
                 v = L.fold ? ws[L.fold_tmp + k * L.src_ld + L.col_off + feat] : params[L.src_w + k * L.src_ld + L.col_off + feat];
         } else if (feat < L.N && k < L.K) {
             const int sk = (k < L.K - L.tshift) ? k + L.tshift : k - (L.K - L.tshift);
+            if (skip) continue;
             v = L.fold ? ws[L.fold_tmp + feat * L.K + sk] : params[L.src_w + feat * L.K + sk];
         }
         ws[L.dst + i] = v;
     }
     // bias table [row][H]
-    if (blockIdx.x == 0 && L.bias_row >= 0) {
+    if (bx == 0 && L.bias_row >= 0 && !skip) {
         for (int j = threadIdx.x; j < job.H; j += blockDim.x) {
             float b = 0.0f;
             if (j < L.N) {
@@ -67,11 +72,22 @@ __global__ void snsde_mfma_pack_kernel(const float* __restrict__ params, float* 
     }
 }
 
+__global__ void snsde_mfma_pack_kernel(const float* __restrict__ params, float* __restrict__ ws, MfmaPackJob job) {
+    pack_layer(params, ws, job, blockIdx.y, blockIdx.x, gridDim.x, false);
+}
+
+// position of weight (feature, k) inside a layer's packed fragment block (inverse of the pack loop's index map)
+__device__ __forceinline__ int packed_index(int flavor, int KU, int feat, int k) {
+    const int wt = feat >> 4, fl = feat & 15, u = k >> 4, s = (k >> 2) & 3, e = k & 3;
+    const int lane = flavor == 0 ? 16 * s + fl : 16 * (fl >> 2) + 4 * s + (fl & 3);
+    return ((wt * KU + u) * 64 + lane) * 4 + e;
+}
+
 // One "prepare" launch: blockIdx.y in {0,1} = the two folded products F = E[:, col:col+H] . W (one block per
 // output row f, lanes over the K columns, coalesced reads of W rows), blockIdx.y == 2 = the time-only diffusion
 // table (one block per solver step).
-__global__ void snsde_fold_kernel(const float* __restrict__ params, float* __restrict__ ws, FoldJob job) {
-    extern __shared__ float erow[];
+__device__ __forceinline__ void fold_block(const float* __restrict__ params, float* __restrict__ ws, const FoldJob& job,
+                                           const MfmaPackJob* pk, float* erow) {
     const int pc = blockIdx.y, H = job.H;
     if (pc == 2) {
         const int n = blockIdx.x;
@@ -99,15 +115,41 @@ __global__ void snsde_fold_kernel(const float* __restrict__ params, float* __res
             a3 = fmaf(ec[j + 3], W[(size_t)(j + 3) * K + k], a3);
         }
         for (; j < H; ++j) a0 = fmaf(ec[j], W[(size_t)j * K + k], a0);
-        ws[job.tmp[pc] + f * K + k] = (a0 + a1) + (a2 + a3);
+        const float val = (a0 + a1) + (a2 + a3);
+        ws[job.tmp[pc] + f * K + k] = val;
+        if (pk) {     // forward prepare: straight into the packed MFMA fragment layout (source column k -> packed column kp)
+            const MfmaLayerPack& L = pk->layer[pc];
+            const int kp = (k >= L.tshift) ? k - L.tshift : k + (L.K - L.tshift);
+            ws[L.dst + packed_index(pk->flavor, L.KU, f, kp)] = val;
+        }
     }
     if (pc == 0 && threadIdx.x < 64) {   // folded bias: b_emb + E1 b_in + E2 b_init (one wave, shuffle reduction)
         float acc = 0.0f;
         for (int j = threadIdx.x; j < H; j += 64)
             acc += erow[j] * params[job.b_in + j] + erow[H + j] * params[job.b_init + j];
         for (int o = 32; o > 0; o >>= 1) acc += __shfl_down(acc, o, 64);
-        if (threadIdx.x == 0) ws[job.bias_tmp + f] = acc + params[job.b_emb + f];
+        if (threadIdx.x == 0) {
+            const float b = acc + params[job.b_emb + f];
+            ws[job.bias_tmp + f] = b;
+            if (pk) {
+                for (int i = 0; i < 2; ++i)
+                    if (pk->layer[i].bias_row >= 0) ws[pk->bias_off + pk->layer[i].bias_row * pk->H + f] = b;
+            }
+        }
     }
+}
+
+__global__ void snsde_fold_kernel(const float* __restrict__ params, float* __restrict__ ws, FoldJob job) {
+    extern __shared__ float erow[];
+    fold_block(params, ws, job, nullptr, erow);
+}
+
+// Forward prepare in ONE launch: blockIdx.y 0/1 = folded products (written to the temp the backward reads AND to their
+// packed fragments), 2 = time-only diffusion table, 3 + l = packing of layer l (16 blocks each).
+__global__ void snsde_prepare_kernel(const float* __restrict__ params, float* __restrict__ ws, FoldJob fj, MfmaPackJob job) {
+    extern __shared__ float erow[];
+    if (blockIdx.y < 3) { fold_block(params, ws, fj, fj.fold_on ? &job : nullptr, erow); return; }
+    if (blockIdx.x < 16) pack_layer(params, ws, job, blockIdx.y - 3, blockIdx.x, 16, fj.fold_on != 0);
 }
 
 // SRK variant: one step-table row per drift pass (stage times t0, t0 + h, t0 + h/2 = slots 0, 3, 2 of the stage table);
@@ -281,7 +323,7 @@ int snsde_mfma_launch(const snsde_solve* s, const SnsdeNet& net, hipStream_t str
         job.fold_b_in = p.fold_b_in; job.fold_b_init = p.fold_b_init; job.fold_b_emb = p.fold_b_emb;
         job.fold_emb_w = p.fold_emb_w;
         job.fold_bias_tmp = p.fold_bias_tmp;
-        if (p.FOLD || (p.gt_off >= 0 && !p.SRK)) {   // folded products + time-only diffusion table in ONE launch
+        {   // folded products + time-only diffusion table + fragment packing in ONE launch
             FoldJob fj{};
             fj.fold_on = p.FOLD; fj.H = p.H; fj.n_pieces = 2;
             if (p.FOLD) {
@@ -295,11 +337,11 @@ int snsde_mfma_launch(const snsde_solve* s, const SnsdeNet& net, hipStream_t str
             fj.tab_on = p.gt_off >= 0 && !p.SRK; fj.tab_off = p.gt_off; fj.n_steps = s->n_steps; fj.no = s->model.noise_option;
             fj.nt0 = net.nt0; fj.nt1 = net.nt1; fj.step_tab = s->step_tab;
             fj.off_sigma = net.off_sigma; fj.off_sigma_diag = net.off_sigma_diag;
-            const int gx = fj.tab_on && s->n_steps > p.H ? s->n_steps : p.H;
-            hipLaunchKernelGGL(snsde_fold_kernel, dim3(gx, fj.tab_on ? 3 : 2), dim3(256), 2 * p.H * sizeof(float), stream,
-                               s->params, ws, fj);
+            int gx = fj.tab_on && s->n_steps > p.H ? s->n_steps : p.H;
+            if (gx < 16) gx = 16;
+            hipLaunchKernelGGL(snsde_prepare_kernel, dim3(gx, 3 + p.n_layers), dim3(256), 2 * p.H * sizeof(float), stream,
+                               s->params, ws, fj, job);
         }
-        hipLaunchKernelGGL(snsde_mfma_pack_kernel, dim3(16, p.n_layers), dim3(256), 0, stream, s->params, ws, job);
         if (p.SRK) {
             if (!s->srk_tab) return SNSDE_ERR_NULL;
             hipLaunchKernelGGL(snsde_srk_expand_kernel, dim3((3 * s->n_steps + 127) / 128), dim3(128), 0, stream, s->step_tab,
