@@ -170,7 +170,15 @@ __device__ __forceinline__ void snsde_time_table_row(const float* __restrict__ p
     for (int j = threadIdx.x; j < H; j += blockDim.x) {
         float acc = 0.0f;
         const float* w = params + nt1.src_w + (size_t)j * H;
-        for (int k = 0; k < H; ++k) acc = fmaf(hbuf[k], w[k], acc);
+        int k = 0;
+        for (; k + 15 < H; k += 16) {      // 16 loads in flight per round trip; the fmaf chain keeps its order
+            float wv[16];
+#pragma unroll
+            for (int i = 0; i < 16; ++i) wv[i] = w[k + i];
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc = fmaf(hbuf[k + i], wv[i], acc);
+        }
+        for (; k < H; ++k) acc = fmaf(hbuf[k], w[k], acc);
         gt[j] = fmaxf(acc + params[nt1.src_b + j], 0.0f);
     }
 }

@@ -108,6 +108,18 @@ __device__ __forceinline__ void fold_block(const float* __restrict__ params, flo
     for (int k = threadIdx.x; k < K; k += blockDim.x) {
         float a0 = 0.0f, a1 = 0.0f, a2 = 0.0f, a3 = 0.0f;   // four independent chains hide the load latency
         int j = 0;
+        for (; j + 15 < H; j += 16) {      // 16 loads in flight per round trip (same accumulation order as the 4-wide loop)
+            float wv[16];
+#pragma unroll
+            for (int i = 0; i < 16; ++i) wv[i] = W[(size_t)(j + i) * K + k];
+#pragma unroll
+            for (int i = 0; i < 16; i += 4) {
+                a0 = fmaf(ec[j + i], wv[i], a0);
+                a1 = fmaf(ec[j + i + 1], wv[i + 1], a1);
+                a2 = fmaf(ec[j + i + 2], wv[i + 2], a2);
+                a3 = fmaf(ec[j + i + 3], wv[i + 3], a3);
+            }
+        }
         for (; j + 3 < H; j += 4) {
             a0 = fmaf(ec[j], W[(size_t)j * K + k], a0);
             a1 = fmaf(ec[j + 1], W[(size_t)(j + 1) * K + k], a1);
