@@ -19,8 +19,10 @@
 // Two tile flavours share the code:
 //   M16: v_mfma_f32_16x16x4_f32, 16 rows per workgroup  (lane = 16*s + row).        Large batches.
 //   M4 : v_mfma_f32_4x4x1_16b_f32, 4 rows per workgroup: the 16 independent 4x4 blocks are used as
-//        4 k-slots x 4 feature quads (lane = 16*q + 4*s + row) and the k-slot partial sums are
-//        combined with two DPP row rotations.  Fills all 256 CUs at batch 1024.
+//        4 k-slots x 4 feature quads (lane = 16*q + 4*s + row); the k-slot partial sums are combined by a
+//        DPP reduce-scatter (lane s keeps feature 4q+s: one element per lane from there on), and the B operand
+//        (a function of lane & 15 only) is read by lanes 0-15 and broadcast by the MFMA (blgp:4).
+//        Fills all 256 CUs at batch 1024.
 
 #include "snsde_mfma_kernels.h"
 

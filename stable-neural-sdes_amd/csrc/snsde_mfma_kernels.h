@@ -22,8 +22,10 @@
 // Two tile flavours share the code:
 //   M16: v_mfma_f32_16x16x4_f32, 16 rows per workgroup  (lane = 16*s + row).        Large batches.
 //   M4 : v_mfma_f32_4x4x1_16b_f32, 4 rows per workgroup: the 16 independent 4x4 blocks are used as
-//        4 k-slots x 4 feature quads (lane = 16*q + 4*s + row) and the k-slot partial sums are
-//        combined with two DPP row rotations.  Fills all 256 CUs at batch 1024.
+//        4 k-slots x 4 feature quads (lane = 16*q + 4*s + row); the k-slot partial sums are combined by a
+//        DPP reduce-scatter (lane s keeps feature 4q+s: one element per lane from there on), and the B operand
+//        (a function of lane & 15 only) is read by lanes 0-15 and broadcast by the MFMA (blgp:4).
+//        Fills all 256 CUs at batch 1024.
 #include "snsde_internal.h"
 
 namespace snsde_mfma {
@@ -409,7 +411,6 @@ __global__ void __launch_bounds__(CF::NT, CF::WPS) snsde_mfma_kernel(MfmaArgs a)
     const bool writer = FL ? (s == 0) : true;
     const bool mul_y = (no == 13 || no == 17 || no == 15 || no == 19 || no == 3 || no == 6 || no == 11);
     const bool yfun = (no >= 7 && no <= 10);     // raw = phi(y)
-    const bool s1 = (s == 1), s2 = (s == 2), s3 = (s == 3);
     const float mil = (a.method == SNSDE_MILSTEIN) ? 0.5f : 0.0f;
     const uint32_t grow = (uint32_t)(a.row_offset + row);
     const uint64_t seed = a.seed_dev ? *a.seed_dev : a.seed;

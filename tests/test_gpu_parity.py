@@ -4,6 +4,8 @@ vectors generated from the reference.  Tolerances are the ones stated in SURVEY.
   single f/g evaluation:  allclose(rtol=1e-5, atol=2e-6) vs the reference's fp32 output
   trajectories (vs fp64 arbiter, identical dW): mean |err| <= 1e-5, |err| <= 1e-4 + 1e-4 |z| for
   >= 99.99 % of elements, max |err| <= 5e-3, and <= 4x the CPU-fp32-vs-fp64 error."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -1018,7 +1020,11 @@ def _fuzz_configs(n, seed):
     return out
 
 
-@pytest.mark.parametrize('cfg', _fuzz_configs(120, 2026))
+# SNSDE_FUZZ_SEED shifts both fuzz streams (exploration runs; the default is what CI runs)
+_FUZZ_SHIFT = int(os.environ.get('SNSDE_FUZZ_SEED', '0'))
+
+
+@pytest.mark.parametrize('cfg', _fuzz_configs(120, 2026 + _FUZZ_SHIFT))
 def test_fuzz_mfma_forward_matches_generic_forward(cfg):
     """Random supported configurations: the MFMA kernels (both tile flavours where instantiated) against the generic
     all-options kernel on identical increments — two independent implementations of the same scheme."""
@@ -1035,10 +1041,14 @@ def test_fuzz_mfma_forward_matches_generic_forward(cfg):
         assert np.isfinite(ys).all() and err.max() < 5e-4 and err.mean() < 2e-6, (cfg, kern, err.max(), err.mean())
 
 
-@pytest.mark.parametrize('cfg', [c for c in _fuzz_configs(120, 7) if c[1] not in (14, 15, 18, 19)][:72])
+@pytest.mark.parametrize('cfg', [c for c in _fuzz_configs(120, 7 + _FUZZ_SHIFT) if c[1] not in (14, 15, 18, 19)][:72])
 def test_fuzz_mfma_backward_matches_generic_backward(cfg):
     """Random configurations with an elementwise diffusion: gradients from the MFMA adjoint + native parameter pass against
-    the generic adjoint + batched autograd pass (both fused paths, different kernels and different parameter passes)."""
+    the generic adjoint + batched autograd pass (both fused paths, different kernels and different parameter passes).
+    (Exploration runs with SNSDE_FUZZ_SEED: 2 of ~1800 shifted configurations exceeded the tolerance, both through ONE relu
+    unit whose pre-activation is ~0 at one (row, step): the two float32 forwards put it on different sides of the kink, so
+    every parameter upstream of that unit differs by that sample's contribution while the MFMA gradients match float64
+    autograd to 1e-7 — tools/fuzz_debug.py prints the per-kernel comparison against float64 for a configuration.)"""
     io, no, NL, B, H, C, L, method = cfg
     sd = sum(int(v) * (i + 5) for i, v in enumerate(cfg[:7]))
     pr = make_problem(sd, io, no, NL, B, H, C, L)
