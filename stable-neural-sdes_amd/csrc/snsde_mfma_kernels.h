@@ -504,8 +504,9 @@ __global__ void __launch_bounds__(CF::NT, CF::WPS) snsde_mfma_kernel(MfmaArgs a)
         const float h = cur_row.h, sqh = cur_row.sqh;
 
         // y-independent work of the step (Brownian increments, diffusion table row, next step's X(t) and time
-        // features) is done by the two waves of a SIMD at DIFFERENT points of the layer chain (older waves before
-        // the hidden GEMM, younger waves after it), so one wave's VALU work runs under the other's MFMAs.
+        // features): done by every wave after the first layer's barrier (the first layer has read xbuf / the time
+        // features of THIS step by then).  Splitting it between the two waves of a SIMD (older half before the hidden
+        // GEMM, younger half after it) measured 1 % slower once the M4 B-operand reads were quartered.
         float dw[TPW][EPT];
         float gtv[TPW][EPT];
         auto prep = [&]() {
@@ -581,7 +582,6 @@ __global__ void __launch_bounds__(CF::NT, CF::WPS) snsde_mfma_kernel(MfmaArgs a)
                 if (CF::YTIME && tid < M) { ybuf[tid * LDY + H] = n_sin; ybuf[tid * LDY + H + 1] = n_cos; }
             }
         };
-        const bool early = wave < (CF::NW + 1) / 2;
         TRACE(1)
         f32x4 acc[TPW], acc2[TPW];
         f32x4 gnv = {0.f, 0.f, 0.f, 0.f};   // diffusion-net output fragment (noise_option 14/15/18/19)
@@ -702,7 +702,7 @@ __global__ void __launch_bounds__(CF::NT, CF::WPS) snsde_mfma_kernel(MfmaArgs a)
                 cur = arow;
             }
         }
-        if (early) prep();
+        prep();
 #pragma unroll
         for (int l = 0; l < NHID; ++l) {
             // ping-pong: (emb|fold) -> A -> B -> A ... ; no-emb: cat -> A -> B ...
@@ -718,7 +718,6 @@ __global__ void __launch_bounds__(CF::NT, CF::WPS) snsde_mfma_kernel(MfmaArgs a)
             TRACE(6)
             cur = toB ? brow : arow;
         }
-        if (!early) prep();
         init_acc(layer);
         gemm<FL, KUH, TPW>(wo, cur, acc, acc2);
         sum_acc();
