@@ -1045,10 +1045,11 @@ def test_fuzz_mfma_forward_matches_generic_forward(cfg):
 def test_fuzz_mfma_backward_matches_generic_backward(cfg):
     """Random configurations with an elementwise diffusion: gradients from the MFMA adjoint + native parameter pass against
     the generic adjoint + batched autograd pass (both fused paths, different kernels and different parameter passes).
-    (Exploration runs with SNSDE_FUZZ_SEED: 2 of ~1800 shifted configurations exceeded the tolerance, both through ONE relu
+    (Exploration runs with SNSDE_FUZZ_SEED: 3 of ~3000 shifted configurations exceeded the tolerance, each through ONE relu
     unit whose pre-activation is ~0 at one (row, step): the two float32 forwards put it on different sides of the kink, so
-    every parameter upstream of that unit differs by that sample's contribution while the MFMA gradients match float64
-    autograd to 1e-7 — tools/fuzz_debug.py prints the per-kernel comparison against float64 for a configuration.)"""
+    every parameter upstream of that unit differs by that sample's contribution, while the other kernel family matches
+    float64 autograd to 1e-7 (twice the MFMA side, once the generic side) — tools/fuzz_debug.py prints the per-kernel
+    comparison against float64 and whether a disagreement is confined to one unit.)"""
     io, no, NL, B, H, C, L, method = cfg
     sd = sum(int(v) * (i + 5) for i, v in enumerate(cfg[:7]))
     pr = make_problem(sd, io, no, NL, B, H, C, L)

@@ -11,7 +11,7 @@ from tests.helpers import make_problem, draw_dW
 DEV = T.DEV
 def run(shift, prefix):
     cfgs = [c for c in T._fuzz_configs(120, 7 + shift) if c[1] not in (14, 15, 18, 19)][:72]
-    cfg = [c for c in cfgs if tuple(c[:6]) == prefix][0]
+    cfg = cfgs[prefix] if isinstance(prefix, int) else [c for c in cfgs if tuple(c[:6]) == prefix][0]
     print('cfg', cfg)
     io, no, NL, B, H, C, L, method = cfg
     sd = sum(int(v) * (i + 5) for i, v in enumerate(cfg[:7]))
@@ -46,9 +46,16 @@ def run(shift, prefix):
             if k in res and res[k][name] is not None:
                 line += f'  {k} {float((res[k][name] - r).abs().max()) / sc:9.2e}'
         print(line)
-        if name == 'emb.bias' and 'generic' in res:
-            d = (res['generic'][name] - r).abs() / sc
-            top = torch.topk(d.flatten(), 3)
-            print('      emb.bias error by feature: top3', [(int(i), float(v)) for v, i in zip(top.values, top.indices)], 'median', float(d.median()))
-run(1555, (4, 0, 1, 5, 64, 5))
-run(1851, (2, 12, 4, 37, 128, 2))
+        if name.endswith('.bias'):      # is a disagreement confined to one unit (a relu kink) or spread over the layer?
+            for k in ('mfma4', 'generic'):
+                if k in res and res[k][name] is not None:
+                    d = (res[k][name] - r).abs() / sc
+                    if float(d.max()) > 1e-4:
+                        top = torch.topk(d.flatten(), min(3, d.numel()))
+                        print(f'      {k} {name} error by unit: top', [(int(i), float(v)) for v, i in zip(top.values, top.indices)],
+                              'median', float(d.median()))
+if len(sys.argv) > 2:      # fuzz_debug.py <SNSDE_FUZZ_SEED shift> <index of the backward fuzz configuration>
+    run(int(sys.argv[1]), int(sys.argv[2]))
+else:                      # the two relu-kink disagreements found by the exploration runs
+    run(1555, (4, 0, 1, 5, 64, 5))
+    run(1851, (2, 12, 4, 37, 128, 2))
