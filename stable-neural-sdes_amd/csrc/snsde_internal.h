@@ -109,10 +109,17 @@ __device__ __forceinline__ void snsde_philox4x32_10(uint32_t c0, uint32_t c1, ui
         const uint64_t p0 = (uint64_t)0xD2511F53u * c0, p1 = (uint64_t)0xCD9E8D57u * c2;   // one v_mad_u64_u32 each
         const uint32_t hi0 = (uint32_t)(p0 >> 32), lo0 = (uint32_t)p0;
         const uint32_t hi1 = (uint32_t)(p1 >> 32), lo1 = (uint32_t)p1;
+#ifdef SNSDE_OLD_PHILOX
         c0 = hi1 ^ c1 ^ k0;
         c1 = lo1;
         c2 = hi0 ^ c3 ^ k1;
         c3 = lo0;
+#else
+        c0 = __builtin_amdgcn_bitop3_b32(hi1, c1, k0, 0x96);     // three-input xor: one v_bitop3_b32 (gfx950)
+        c1 = lo1;
+        c2 = __builtin_amdgcn_bitop3_b32(hi0, c3, k1, 0x96);
+        c3 = lo0;
+#endif
         k0 += 0x9E3779B9u;
         k1 += 0xBB67AE85u;
     }
@@ -130,9 +137,10 @@ __device__ __forceinline__ void snsde_philox_normal4(uint64_t seed, uint32_t row
     // stream = 4th counter word: 0 = Brownian increments, 1 = the independent normal of the SRK space-time Levy area
     uint32_t x[4];
     snsde_philox4x32_10(row, step_block, col, stream, (uint32_t)seed, (uint32_t)(seed >> 32), x);
-    const float s = 1.1920928955078125e-07f;  // 2^-23
-    const float ua = ((float)(x[0] >> 9) + 0.5f) * s, ub = ((float)(x[1] >> 9) + 0.5f) * s;
-    const float uc = ((float)(x[2] >> 9) + 0.5f) * s, ud = ((float)(x[3] >> 9) + 0.5f) * s;
+    // u = ((x >> 9) + 0.5) * 2^-23 formed without an int->float conversion: v_alignbit_b32 (0x7f : x) >> 9 is the float
+    // 1 + (x >> 9) 2^-23 in [1, 2); subtracting 1 - 2^-24 is exact (the result (2k + 1) 2^-24 has 24 significant bits)
+    auto u01 = [](uint32_t v) { return __uint_as_float(__builtin_amdgcn_alignbit(0x7Fu, v, 9)) - 0.99999994f; };
+    const float ua = u01(x[0]), ub = u01(x[1]), uc = u01(x[2]), ud = u01(x[3]);
     // Box-Muller on the hardware transcendental units: v_log_f32 (log2), v_sqrt_f32, v_sin_f32 / v_cos_f32 (argument in
     // revolutions, so 2*pi*u needs no range reduction).  -2 ln u = -2 ln2 * log2 u.
     const float ra = __builtin_amdgcn_sqrtf(-1.3862943611198906f * __builtin_amdgcn_logf(ua));

@@ -1,0 +1,550 @@
+// Lean 4-row-tile forward kernel (Euler / Milstein, elementwise diffusions) of the MFMA fast path.
+//
+// Why a second M4 kernel: on gfx950 v_mfma_f32_4x4x1_16b_f32 (like every f32-input MFMA) issues through the SIMD's
+// VALU port and does NOT overlap with other VALU work of either wave of the SIMD (tools/ubench/mfma4_issue*.hip:
+// MFMA + k VALU ops cost 8 + ~5k cycles, alone or with two waves per SIMD; 16x16x4 behaves the same).  A solver step of
+// the 4-row tile therefore costs  (MFMA count) x 8 + (VALU count) x ~4.5 cycles per SIMD  plus whatever latency of the
+// three layer hand-offs (LDS write -> barrier -> LDS read) is left exposed.  This kernel is the general M4 kernel
+// (snsde_mfma_kernel<.., FL = 1>) re-cut for exactly that cost model:
+//   * the [sin t, cos t] features share the control path's k-block ([X(t) | sin t, cos t | 0..] in LDS) instead of
+//     occupying a 16-wide block of their own: 4 MFMAs per wave-step fewer;
+//   * layer biases enter through the accumulator operand of each chain's first MFMA (k-slot 0 lanes hold the bias):
+//     no bias add;
+//   * the diffusion g(t_n, y_n) and y_n + g dW_n are evaluated at the TOP of the step (they need only y_n) while the
+//     first layer's B operands are in flight; only  reduce -> tanh -> fma  follows the last GEMM;
+//   * tanh = copysign((1 - t) / (1 + t), x), t = 2^(-2 log2e |x|): 7 VALU ops, absolute error <= ~4e-8 (the |x| < 0.25
+//     polynomial branch of fast_tanh bought relative accuracy the Euler update cannot see); nan_to_num of the raw
+//     diffusion folds into it (NaN -> v_max(NaN, 0) = 0, +-inf -> t = 0 -> +-1 = tanh(sigmoid(theta) FLT_MAX));
+//   * the y-independent work of the NEXT step (spline value X(t_{n+1}), time features, Philox block, dW / diffusion
+//     table / coefficient fetches) sits in the windows right after the layer barriers, where both waves of a SIMD
+//     would otherwise wait for their B operands; the spline items are evaluated by one wave per SIMD only;
+//   * the step-table row is consumed as broadcast LDS reads in VGPRs (no v_readfirstlane except the output count).
+// Numerics: same MFMA chains (k order, two accumulators) as the general kernel; differences are the tanh form and the
+// order of the final update  y + g dW + f h  (was y + f h + g dW): both inside the parity tolerance (tests/helpers.py).
+// Reference semantics: benchmark_classification/models_sde/neuralsde.py:295-307 (f, g), SURVEY.md A3-A6 (stepping).
+#pragma once
+#include "snsde_mfma_kernels.h"
+
+namespace snsde_mfma {
+
+template <int H_, int NHID_, int KUXT_, int YIN_, int SAVE_>
+struct CfgL {
+    static constexpr int H = H_, NHID = NHID_, KUXT = KUXT_;
+    static constexpr bool YIN = YIN_ != 0;      // the first layer reads y (every input_option but 0)
+    static constexpr bool SAVE = SAVE_ != 0;    // training / diagnostics outputs: act_save, traj, dW_out
+    static constexpr int NW = H / 16;
+    static constexpr int NT = NW * 64;
+    static constexpr int WPS = NW >= 4 ? NW / 4 : 1;
+    static constexpr int KUH = H / 16;
+    static constexpr int LDY = ld_for(16 * KUH, 16);
+    static constexpr int LDX = ld_for(16 * (KUXT > 0 ? KUXT : 1), 16);
+    static constexpr int LDA = LDY;
+    static constexpr int NLAYER = NHID + 2;                   // bias rows: first, hidden.., out
+    static constexpr int NSAVE = NHID + 2;
+    static constexpr int ZSLOT = NHID + 1;
+    static constexpr int ZB = 4;                              // Philox calls generated together per element
+    static constexpr int ZSTASH = 4 * ZB * 64;                // floats per wave
+    static constexpr int ROWCH = 128;
+    static constexpr int XI = KUXT > 0 ? (4 * 16 * KUXT + NT - 1) / NT : 1;   // [X(t) | sin t, cos t] entries per lane (4 rows, spread over ALL waves)
+    static constexpr int RS = 8;                              // floats per step in the kernel's own table: quad A, quad B
+    static constexpr int LDS_FLOATS = 4 * (LDY + 2 * LDX + 2 * LDA) + (ROWCH + 3) * RS + NW * ZSTASH;
+};
+
+// tanh(x) = copysign((1 - t) / (1 + t), x), t = 2^(-2 log2(e) |x|) in (0, 1]: no cancellation beyond the rounding of t
+// (absolute error <= ~4e-8, saturates to +-1 for large |x| and for +-inf).  NANZ: a NaN argument gives +-0 (the
+// reference's nan_to_num(raw) = 0 followed by tanh), through v_max_f32(NaN, 0) = 0.
+template <bool NANZ>
+__device__ __forceinline__ float lean_tanh(float x) {
+    const float t = __builtin_amdgcn_exp2f(fabsf(x) * -2.8853900817779268f);
+    float q = (1.0f - t) * __builtin_amdgcn_rcpf(1.0f + t);
+    if constexpr (NANZ) q = __builtin_fmaxf(q, 0.0f);
+    return __builtin_copysignf(q, x);
+}
+
+template <int KU>
+__device__ __forceinline__ void lean_load_w(float (&w)[KU * 4], const float* __restrict__ g, int wave, int lane) {
+#pragma unroll
+    for (int u = 0; u < KU; ++u) {
+        const f32x4 v = *reinterpret_cast<const f32x4*>(g + (((size_t)wave * KU + u) * 64 + lane) * 4);
+        w[4 * u] = v[0]; w[4 * u + 1] = v[1]; w[4 * u + 2] = v[2]; w[4 * u + 3] = v[3];
+    }
+}
+
+// B operands of one layer: lanes 0-15 read (k-slot s, row r) = 16 bytes per 16-wide k-block; the MFMAs broadcast them
+// (blgp:4), so the other lanes' registers are never read.  The reads are issued from inline asm with EXEC narrowed to
+// lanes 0-15 (no branch), and waited for by lean_wait_b() just before the MFMAs: hipcc's own s_waitcnt insertion loses
+// count across the exec-masked branch it would otherwise generate and drains the LDS queue before ANY instruction placed
+// between the reads and the MFMAs (the filler work this kernel hides in that window).  Its own counts stay safe: LDS
+// returns in order, and an s_waitcnt computed without these reads only waits longer.
+__device__ __forceinline__ uint32_t lean_lds_addr(const float* p) {
+    return (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const float*)(p);
+}
+// Global loads of the step loop are issued from asm as well (one dword, scalar base + 32-bit lane offset) and waited for
+// ONCE per step by lean_vm_wait(): hipcc cannot count vmcnt across the loop's control flow and would otherwise drain the
+// vector-memory queue (s_waitcnt vmcnt(0)) right after the prefetches are issued.
+// (s_nop 4: a VALU-written SGPR, e.g. v_readfirstlane, needs 5 wait states before a VMEM instruction reads it, and the
+// hazard recognizer does not look inside asm.)
+__device__ __forceinline__ uint64_t lean_uniform(const float* p) {
+    const uint64_t v = (uint64_t)p;          // wave-uniform by construction; readfirstlane folds away when hipcc knows it
+    const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)v), hi = __builtin_amdgcn_readfirstlane((uint32_t)(v >> 32));
+    return ((uint64_t)hi << 32) | lo;
+}
+__device__ __forceinline__ void lean_gload(float& dst, uint32_t voff, const float* sbase) {
+    asm volatile("s_nop 4\n\tglobal_load_dword %0, %1, %2" : "=v"(dst) : "v"(voff), "s"(lean_uniform(sbase)) : "memory");
+}
+__device__ __forceinline__ void lean_gload4(float& d0, float& d1, float& d2, float& d3, uint32_t v0, uint32_t v1, uint32_t v2,
+                                            uint32_t v3, const float* sbase) {
+    asm volatile("s_nop 4\n\tglobal_load_dword %0, %4, %8\n\tglobal_load_dword %1, %5, %8\n\tglobal_load_dword %2, %6, %8\n\t"
+                 "global_load_dword %3, %7, %8"
+                 : "=&v"(d0), "=&v"(d1), "=&v"(d2), "=&v"(d3) : "v"(v0), "v"(v1), "v"(v2), "v"(v3), "s"(lean_uniform(sbase)) : "memory");
+}
+template <int KU> struct LeanB { f32x4 v[KU]; };
+__device__ __forceinline__ void lean_read_b(uint32_t a, LeanB<1>& b) {
+    asm volatile("s_mov_b64 exec, 0xffff\n\tds_read_b128 %0, %[a]\n\ts_mov_b64 exec, -1" : "=v"(b.v[0]) : [a] "v"(a));
+}
+__device__ __forceinline__ void lean_read_b(uint32_t a, LeanB<2>& b) {
+    asm volatile("s_mov_b64 exec, 0xffff\n\tds_read_b128 %0, %[a]\n\tds_read_b128 %1, %[a] offset:64\n\ts_mov_b64 exec, -1"
+                 : "=v"(b.v[0]), "=v"(b.v[1]) : [a] "v"(a));
+}
+__device__ __forceinline__ void lean_read_b(uint32_t a, LeanB<3>& b) {
+    asm volatile("s_mov_b64 exec, 0xffff\n\tds_read_b128 %0, %[a]\n\tds_read_b128 %1, %[a] offset:64\n\tds_read_b128 %2, %[a] offset:128\n\t"
+                 "s_mov_b64 exec, -1" : "=v"(b.v[0]), "=v"(b.v[1]), "=v"(b.v[2]) : [a] "v"(a));
+}
+__device__ __forceinline__ void lean_read_b(uint32_t a, LeanB<4>& b) {
+    asm volatile("s_mov_b64 exec, 0xffff\n\tds_read_b128 %0, %[a]\n\tds_read_b128 %1, %[a] offset:64\n\tds_read_b128 %2, %[a] offset:128\n\t"
+                 "ds_read_b128 %3, %[a] offset:192\n\ts_mov_b64 exec, -1"
+                 : "=v"(b.v[0]), "=v"(b.v[1]), "=v"(b.v[2]), "=v"(b.v[3]) : [a] "v"(a));
+}
+__device__ __forceinline__ void lean_read_b(uint32_t a, LeanB<5>& b) {
+    asm volatile("s_mov_b64 exec, 0xffff\n\tds_read_b128 %0, %[a]\n\tds_read_b128 %1, %[a] offset:64\n\tds_read_b128 %2, %[a] offset:128\n\t"
+                 "ds_read_b128 %3, %[a] offset:192\n\tds_read_b128 %4, %[a] offset:256\n\ts_mov_b64 exec, -1"
+                 : "=v"(b.v[0]), "=v"(b.v[1]), "=v"(b.v[2]), "=v"(b.v[3]), "=v"(b.v[4]) : [a] "v"(a));
+}
+__device__ __forceinline__ void lean_read_b(uint32_t a, LeanB<6>& b) {
+    asm volatile("s_mov_b64 exec, 0xffff\n\tds_read_b128 %0, %[a]\n\tds_read_b128 %1, %[a] offset:64\n\tds_read_b128 %2, %[a] offset:128\n\t"
+                 "ds_read_b128 %3, %[a] offset:192\n\tds_read_b128 %4, %[a] offset:256\n\tds_read_b128 %5, %[a] offset:320\n\t"
+                 "s_mov_b64 exec, -1"
+                 : "=v"(b.v[0]), "=v"(b.v[1]), "=v"(b.v[2]), "=v"(b.v[3]), "=v"(b.v[4]), "=v"(b.v[5]) : [a] "v"(a));
+}
+__device__ __forceinline__ void lean_read_b(uint32_t a, LeanB<8>& b) {
+    asm volatile("s_mov_b64 exec, 0xffff\n\tds_read_b128 %0, %[a]\n\tds_read_b128 %1, %[a] offset:64\n\tds_read_b128 %2, %[a] offset:128\n\t"
+                 "ds_read_b128 %3, %[a] offset:192\n\tds_read_b128 %4, %[a] offset:256\n\tds_read_b128 %5, %[a] offset:320\n\t"
+                 "ds_read_b128 %6, %[a] offset:384\n\tds_read_b128 %7, %[a] offset:448\n\ts_mov_b64 exec, -1"
+                 : "=v"(b.v[0]), "=v"(b.v[1]), "=v"(b.v[2]), "=v"(b.v[3]), "=v"(b.v[4]), "=v"(b.v[5]), "=v"(b.v[6]), "=v"(b.v[7])
+                 : [a] "v"(a));
+}
+#undef SNSDE_RD
+// The fragments are tied through the wait ("+v"): nothing that reads them can be scheduled above it.  Y = LDS operations
+// this wave issued AFTER the reads of `b` and that may stay in flight (LDS returns in order); pairs of k-blocks are
+// released as they land.
+template <int CNT> __device__ __forceinline__ void lean_wait2(f32x4& x, f32x4& y) {
+    asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(x), "+v"(y) : "n"(CNT < 15 ? CNT : 15));
+}
+template <int CNT> __device__ __forceinline__ void lean_wait1(f32x4& x) {
+    asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(x) : "n"(CNT < 15 ? CNT : 15));
+}
+// c/d += W . b over KU 16-wide k-blocks, two accumulator chains; k-blocks are consumed in pairs as their reads land
+// (the sched_barrier keeps hipcc from collecting all the waits in front of the first MFMA)
+template <int Y, int KU, int U>
+__device__ __forceinline__ void lean_gemm_from(const float (&w)[KU * 4], LeanB<KU>& b, f32x4& c, f32x4& d) {
+    if constexpr (U < KU) {
+        if constexpr (U + 1 < KU) lean_wait2<Y + KU - 2 - U>(b.v[U], b.v[U + 1]);
+        else lean_wait1<Y>(b.v[U]);
+#pragma unroll
+        for (int uu = U; uu < U + 2 && uu < KU; ++uu) {
+            c = __builtin_amdgcn_mfma_f32_4x4x1f32(w[4 * uu], b.v[uu][0], c, 0, 0, 4);
+            d = __builtin_amdgcn_mfma_f32_4x4x1f32(w[4 * uu + 1], b.v[uu][1], d, 0, 0, 4);
+            c = __builtin_amdgcn_mfma_f32_4x4x1f32(w[4 * uu + 2], b.v[uu][2], c, 0, 0, 4);
+            d = __builtin_amdgcn_mfma_f32_4x4x1f32(w[4 * uu + 3], b.v[uu][3], d, 0, 0, 4);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        lean_gemm_from<Y, KU, U + 2>(w, b, c, d);
+    }
+}
+template <int Y, int KU>
+__device__ __forceinline__ void lean_gemm(const float (&w)[KU * 4], LeanB<KU>& b, f32x4& c, f32x4& d) {
+    lean_gemm_from<Y, KU, 0>(w, b, c, d);
+}
+
+// Cycle timeline (development builds, -DLEAN_TRACE): s_memtime stamps at LT(i) are left in flight (no s_waitcnt) and only
+// collected after the step's closing barrier, so they do not drain the LDS queue the way TRACE() does.
+#ifdef LEAN_TRACE
+#define LT_DECL unsigned long long lt[10]; float lt_acc[10] = {0,0,0,0,0,0,0,0,0,0}; unsigned long long lt_prev = 0;
+#define LT(i) asm volatile("s_memtime %0" : "=s"(lt[i]));
+#define LT_COLLECT { asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(lt[0]), "+s"(lt[1]), "+s"(lt[2]), "+s"(lt[3]), "+s"(lt[4]), "+s"(lt[5]), "+s"(lt[6]), "+s"(lt[7]), "+s"(lt[8]), "+s"(lt[9])); \
+    if (lt_prev) lt_acc[0] += (float)(uint32_t)(lt[0] - lt_prev); _Pragma("unroll") for (int i_ = 1; i_ < 10; ++i_) lt_acc[i_] += (float)(uint32_t)(lt[i_] - lt[i_ - 1]); lt_prev = lt[9]; }
+#else
+#define LT_DECL
+#define LT(i)
+#define LT_COLLECT
+#endif
+
+template <class CF>
+__global__ void __launch_bounds__(CF::NT, CF::WPS) snsde_m4_kernel(MfmaArgs a) {
+    constexpr int H = CF::H, NT = CF::NT, NHID = CF::NHID, KUH = CF::KUH, KUXT = CF::KUXT;
+    constexpr int LDY = CF::LDY, LDX = CF::LDX, LDA = CF::LDA, RS = CF::RS;
+    constexpr bool YIN = CF::YIN, SAVE = CF::SAVE;
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    float* ybuf = lds;                       // [4][LDY]  y
+    float* xbuf = ybuf + 4 * LDY;            // [2][4][LDX]  X(t) (xc) | sin t, cos t | 0..   (step parity)
+    float* bufA = xbuf + 8 * LDX;            // [4][LDA]
+    float* bufB = bufA + 4 * LDA;            // [4][LDA]
+    float* rowtab = bufB + 4 * LDA;          // [ROWCH + 3][RS]  step i: (h, sqrt h, n_out, k_first | sin t, cos t, frac, idx of step i+1)
+    float* zstash_all = rowtab + (CF::ROWCH + 3) * RS;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int r = lane & 3, s = (lane >> 2) & 3, q = lane >> 4;
+    const int fo = wave * 16 + 4 * q + s;                 // the state / activation element this lane owns (row r)
+    const int row0 = blockIdx.x * 4;
+    const int B = a.B, C = a.C, N = a.N;
+    const int row = row0 + r;
+    const bool row_ok = row < B;
+    const int rowc = row_ok ? row : B - 1;
+    const size_t BH = (size_t)B * H;
+    const size_t goff = (size_t)rowc * H + fo;
+    float* zstash = zstash_all + wave * CF::ZSTASH;
+    const int xc = a.lean_xc;                              // control channels in the xt block (0: drift without X)
+    const bool time_on = a.lean_time != 0, geo = a.lean_geo != 0;
+
+    // ---- resident weights, bias fragments ---------------------------------------------------------------------
+    int li = 0;
+    float wxt[(KUXT > 0 ? KUXT : 1) * 4], wy[KUH * 4], wh[NHID > 0 ? NHID : 1][KUH * 4], wo[KUH * 4];
+    if constexpr (KUXT > 0) lean_load_w<KUXT>(wxt, a.ws + a.w_off[li++], wave, lane);
+    if constexpr (YIN) lean_load_w<KUH>(wy, a.ws + a.w_off[li++], wave, lane);
+#pragma unroll
+    for (int l = 0; l < NHID; ++l) lean_load_w<KUH>(wh[l], a.ws + a.w_off[li++], wave, lane);
+    lean_load_w<KUH>(wo, a.ws + a.w_off[li++], wave, lane);
+    f32x4 bfr[CF::NLAYER];                                 // accumulator init: the bias in the k-slot 0 lanes, 0 elsewhere
+#pragma unroll
+    for (int l = 0; l < CF::NLAYER; ++l)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) bfr[l][i] = (s == 0) ? a.ws[a.bias_off + l * H + wave * 16 + 4 * q + i] : 0.0f;
+
+    // ---- LDS init; the step table is re-cut into the two quads per step this kernel reads -------------------------
+    for (int i = tid; i < 4 * (LDY + 2 * LDX + 2 * LDA); i += NT) lds[i] = 0.0f;
+    auto fill_rows = [&](int base) {
+        for (int i = tid; i < (CF::ROWCH + 3) * RS; i += NT) {
+            const int j = i % RS;
+            int rr = base + i / RS + (j == 7 ? 1 : 0);
+            rr = rr < N - 1 ? rr : N - 1;
+            const int src = j == 0 ? 1 : j == 1 ? 6 : j == 2 ? 8 : j == 3 ? 9 : j == 4 ? 2 : j == 5 ? 3 : j == 6 ? 4 : 5;
+            rowtab[i] = a.step_tab[(size_t)rr * SNSDE_STEP_STRIDE + src];
+        }
+    };
+    fill_rows(0);
+    __syncthreads();
+
+    const float sig_theta = snsde_sigmoid(a.params[a.off_theta]);
+    const int no = a.no;
+    const bool tab = a.gt_off >= 0;
+    const float* gt = a.ws + (tab ? a.gt_off : 0);
+    const bool mul_y = (no == 13 || no == 17 || no == 3 || no == 6 || no == 11);
+    const bool yfun = (no >= 7 && no <= 10);
+    const bool mil = a.method == SNSDE_MILSTEIN;
+    const bool phx = a.dW == nullptr;
+    const uint32_t grow = (uint32_t)(a.row_offset + row);
+    const uint64_t seed = a.seed_dev ? *a.seed_dev : a.seed;
+    const int rslot = a.row_out ? a.row_out[rowc] : -1;
+
+    float yv = a.y0[goff];
+    ybuf[r * LDY + fo] = yv;
+    if (row_ok) {
+        a.ys[(size_t)row * H + fo] = yv;
+        if constexpr (SAVE) { if (a.traj) a.traj[(size_t)row * H + fo] = yv; }
+    }
+
+    // ---- the [X(t) | sin t, cos t] entries of the tile (4 rows x W columns), spread evenly over ALL waves: the waves of a
+    //      SIMD stay in step (a wave that works alone while its partner waits at the barrier issues one VALU instruction
+    //      per ~5.5 cycles and hides nothing).  Branch-free per step: every lane fetches and evaluates (idle lanes
+    //      re-read entry 0), only the owners write.  The cubic pieces of X(t_{n+2}) are fetched at the top of step n,
+    //      right after those of X(t_{n+1}) were evaluated out of the same registers ------------------------------------------
+    const int xw = xc + (time_on ? 2 : 0);                  // columns per row
+    const int xquota = (4 * xw + CF::NW - 1) / CF::NW;      // entries per wave
+    float ca[CF::XI], cb[CF::XI], cc[CF::XI], cd[CF::XI];
+    uint32_t cvo[CF::XI];                                   // byte offset of (tile row, channel) from the tile's first row
+    int xdst[CF::XI], xkind[CF::XI];                        // LDS float offset inside an xbuf half (-1: none); 0 spline, 1 sin, 2 cos
+    const size_t cstride = (size_t)(a.L - 1) * 4 * C;       // floats per batch row
+#pragma unroll
+    for (int i = 0; i < CF::XI; ++i) {
+        const int li_ = lane + 64 * i, it = wave * xquota + li_;
+        const bool ok = KUXT > 0 && li_ < xquota && it < 4 * xw;
+        const int rr = ok ? it / xw : 0, col = ok ? it - rr * xw : 0;
+        xdst[i] = ok ? rr * LDX + col : -1;
+        xkind[i] = col < xc ? 0 : (col == xc ? 1 : 2);
+        const int gr = row0 + rr < B ? rr : B - 1 - row0, ch = col < xc ? col : 0;
+        cvo[i] = (uint32_t)((gr * cstride + ch) * sizeof(float));
+    }
+    const bool has_x = KUXT > 0 && xc > 0;
+    const float* ctile = a.coeffs + (size_t)row0 * cstride;
+    const uint32_t cstep = (uint32_t)(C * sizeof(float));
+    const uint32_t cidx = (uint32_t)(4 * C * sizeof(float));       // bytes per spline interval
+    auto load_coeffs = [&](int idx) {      // idx may be a (lane-uniform) VGPR value: the interval offset is per-lane arithmetic,
+        if (__builtin_expect(has_x, 1)) {  // no v_readfirstlane / scalar round trip on the way to the addresses
+            const uint32_t io = (uint32_t)idx * cidx;
+#pragma unroll
+            for (int i = 0; i < CF::XI; ++i)
+                lean_gload4(ca[i], cb[i], cc[i], cd[i], cvo[i] + io, cvo[i] + io + cstep, cvo[i] + io + 2 * cstep,
+                            cvo[i] + io + 3 * cstep, ctile);
+        }
+    };
+    // every asm-issued load has landed: ties the registers they fill
+    auto vm_wait = [&](float& dwn, float& gtn) {
+        asm volatile("s_waitcnt vmcnt(0)" : "+v"(dwn), "+v"(gtn));
+#pragma unroll
+        for (int i = 0; i < CF::XI; ++i) asm volatile("" : "+v"(ca[i]), "+v"(cb[i]), "+v"(cc[i]), "+v"(cd[i]));
+    };
+    // X(t) = a + (b + (two_c / 2 + three_d frac / 3) frac) frac  (interpolate.py:270-276); the division by 3 as
+    // q = x/3 rounded via two fma corrections (correctly rounded for normal results)
+    auto store_xt = [&](float* xb, float frac, float sn, float cs) {
+        if constexpr (KUXT > 0) {
+#pragma unroll
+            for (int i = 0; i < CF::XI; ++i) {
+                float v = 0.0f;
+                if (__builtin_expect(has_x, 1)) {
+                    const float x3 = cd[i] * frac;
+                    float q3 = x3 * 0.333333343f;
+                    q3 = fmaf(fmaf(-3.0f, q3, x3), 0.333333343f, q3);
+                    v = ca[i] + (cb[i] + (0.5f * cc[i] + q3) * frac) * frac;
+                }
+                v = xkind[i] == 0 ? v : (xkind[i] == 1 ? sn : cs);
+                if (xdst[i] >= 0) xb[xdst[i]] = v;
+            }
+        }
+    };
+
+    // Brownian increment of step i for the owned element (Philox: ZB blocks of 4 steps generated together and parked
+    // in this wave's LDS stash; else the supplied increments)
+    auto next_dw = [&](int i, float sqh) -> float {
+        if (__builtin_expect(phx, 1)) {
+            const int k = i % (4 * CF::ZB);
+            if (__builtin_expect(k == 0, 0)) {
+                float zq[4 * CF::ZB];
+#pragma unroll
+                for (int bb = 0; bb < CF::ZB; ++bb)
+                    snsde_philox_normal4(seed, grow, (uint32_t)((i >> 2) + bb), (uint32_t)fo, &zq[4 * bb]);
+#pragma unroll
+                for (int j = 0; j < 4 * CF::ZB; ++j) zstash[j * 64 + lane] = zq[j];
+            }
+            return zstash[k * 64 + lane] * sqh;
+        }
+        float v;
+        lean_gload(v, (uint32_t)(goff * sizeof(float)), a.dW + (size_t)i * BH);
+        return v;
+    };
+    const uint32_t fo4 = (uint32_t)(fo * sizeof(float));
+
+    // diffusion g(t, y) and  y + g dW (+ the Milstein term)  for the owned element
+    auto gpart = [&](float y, float gtv, float dwv, float hh) -> float {
+        float g = 0.0f, draw = 0.0f;
+        if (__builtin_expect(yfun, 0)) {
+            float p1, p2;
+            const float raw = snsde_phi(no, y, p1, p2);
+            g = fast_tanh(sig_theta * snsde_nan_to_num(raw));
+            draw = (raw - raw == 0.0f) ? p1 : 0.0f;
+        } else
+        {                                 // table noise (no table: gtv = 0 and g = tanh(0) = 0)
+            const float raw = mul_y ? gtv * y : gtv;
+            g = lean_tanh<true>(sig_theta * raw);
+            draw = (mul_y && raw - raw == 0.0f) ? gtv : 0.0f;
+        }
+        float yp = fmaf(g, dwv, y);
+        if (__builtin_expect(mil, 0)) yp = fmaf(0.5f * (g * ((1.0f - g * g) * sig_theta * draw)), fmaf(dwv, dwv, -hh), yp);
+        return yp;
+    };
+
+    // ---- inputs of step 0; pieces of X(t_1) ---------------------------------------------------------------------------
+    float dw_cur, gt_cur = 0.0f, h_cur;
+    f32x4 qb;                         // (sin, cos, frac) of the step after the current one, idx of the step after that
+    {
+        const float* st = rowtab;
+        load_coeffs(__float_as_int(a.step_tab[5]));
+        h_cur = 0.0f;
+        vm_wait(h_cur, gt_cur);
+        store_xt(xbuf, st[6], st[4], st[5]);
+        dw_cur = next_dw(0, st[1]);
+        if (tab) lean_gload(gt_cur, fo4, gt);
+        load_coeffs(__float_as_int(st[7]));
+        vm_wait(dw_cur, gt_cur);
+        h_cur = st[0];
+        qb = *reinterpret_cast<const f32x4*>(st + RS + 4);
+    }
+    __syncthreads();
+    if (__builtin_amdgcn_readfirstlane(tid) >= NT / 2 && CF::NW >= 8) __builtin_amdgcn_s_setprio(1);   // younger half
+
+    // B-operand read addresses (LDS byte offsets; only lanes 0-15 read: q = 0 there)
+    const uint32_t yrow = lean_lds_addr(ybuf + r * LDY + 4 * s);
+    const uint32_t xrow = lean_lds_addr(xbuf + r * LDX + 4 * s);      // + 4 * LDX floats on odd steps
+    const uint32_t arow = lean_lds_addr(bufA + r * LDA + 4 * s);
+    const uint32_t brow = lean_lds_addr(bufB + r * LDA + 4 * s);
+    float* const aown = bufA + r * LDA + fo;
+    float* const bown = bufB + r * LDA + fo;
+    const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+
+    LeanB<(KUXT > 0 ? KUXT : 1)> bx;      // [X(t_n) | tau_n] operands of the step about to start
+    if constexpr (KUXT > 0) lean_read_b(xrow, bx);
+    LT_DECL
+    // Outer loop over the requested outputs, inner loop over the solver steps up to each of them (out_step[k] = the step
+    // after which output k + 1 is due): the step loop itself carries no output bookkeeping.
+    int n = 0;
+    float yold = yv;
+    for (int ko = 0; ko < a.T - 1; ++ko) {
+    const int n_end = a.out_step[ko];
+    for (; n <= n_end; ++n) {
+        const int rbase = (n / CF::ROWCH) * CF::ROWCH;
+        if (n > 0 && n == rbase) {               // next chunk of step-table rows (every wave is past the closing barrier)
+            fill_rows(rbase);
+            __syncthreads();
+        }
+        const bool more = n + 1 < N;
+        LT(0)
+        // ---- top: the first layer's B operands, then the table quads of the coming steps (asm: the compiler never waits
+        //      on them; they have landed once the first layer's last s_waitcnt has passed) ------------------------------------
+        LeanB<KUH> by;
+        if constexpr (YIN) lean_read_b(yrow, by);
+        f32x4 qa, qbn;      // quad A of step n+1: (h, sqrt h, n_out, k_first); quad B of step n+2
+        asm volatile("ds_read_b128 %0, %2\n\tds_read_b128 %1, %2 offset:%3"
+                     : "=v"(qa), "=v"(qbn) : "v"(lean_lds_addr(rowtab + (n + 1 - rbase) * RS)), "n"(RS * 4 + 16));
+        const float h = h_cur;
+        __builtin_amdgcn_sched_barrier(0);
+        // the [X(t_n) | tau_n] part of the first layer: its operands were read before the barrier, so these MFMAs start at
+        // once and cover the latency of the y reads
+        f32x4 c = bfr[0], d = zero4;
+        if constexpr (KUXT > 0) lean_gemm<15, KUXT>(wxt, bx, c, d);
+        // ---- in the shadow of those reads: diffusion, y + g dW; X(t_{n+1}) and the fetch of X(t_{n+2})'s pieces -----------
+        const float ypart = gpart(yv, gt_cur, dw_cur, h);
+        store_xt(xbuf + ((n + 1) & 1) * (4 * LDX), qb[2], qb[0], qb[1]);       // (past the last step: a clamped row, never read)
+        load_coeffs(__float_as_int(qb[3]));
+        __builtin_amdgcn_sched_barrier(0);
+        LT(1)
+        if constexpr (YIN) lean_gemm<2, KUH>(wy, by, c, d);
+        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(qa), "+v"(qbn));      // the table quads: long landed
+        LT(2)
+        {
+            const float o = fmaxf(m4_reduce_scatter(c + d), 0.0f);
+            *aown = o;
+            if constexpr (SAVE) { if (a.act_save && row_ok) a.act_save[((size_t)n * CF::NSAVE) * BH + goff] = o; }
+        }
+        LT(3)
+        __syncthreads();
+        LT(4)
+        // ---- hidden layers; the next step's increment and diffusion-table entry are produced in the first window -------------
+        float dw_nxt = 0.0f, gt_nxt = 0.0f;
+        auto prep = [&]() {
+            {
+                const int n1 = more ? n + 1 : n;          // (the last step prefetches its own inputs again: never used)
+                dw_nxt = next_dw(n1, qa[1]);
+                if (__builtin_expect(tab, 1)) lean_gload(gt_nxt, fo4, gt + (size_t)n1 * H);
+            }
+        };
+        uint32_t cur = arow;
+#pragma unroll
+        for (int l = 0; l < NHID; ++l) {
+            const bool toB = (l % 2 == 0);
+            LeanB<KUH> bh;
+            lean_read_b(cur, bh);
+            __builtin_amdgcn_sched_barrier(0);
+            if (l == 0) prep();
+            __builtin_amdgcn_sched_barrier(0);
+            if (l == 0) { LT(5) }
+            c = bfr[1 + l]; d = zero4;
+            lean_gemm<0, KUH>(wh[l], bh, c, d);
+            const float o = fmaxf(m4_reduce_scatter(c + d), 0.0f);
+            *(toB ? bown : aown) = o;
+            if constexpr (SAVE) { if (a.act_save && row_ok) a.act_save[((size_t)n * CF::NSAVE + 1 + l) * BH + goff] = o; }
+            if (l == NHID - 1) { LT(6) }
+            __syncthreads();
+            if (l == NHID - 1) { LT(7) }
+            cur = toB ? brow : arow;
+        }
+        // ---- output layer, f, update -------------------------------------------------------------------------------
+        {
+            LeanB<KUH> bo;
+            lean_read_b(cur, bo);
+            __builtin_amdgcn_sched_barrier(0);
+            if (NHID == 0) prep();
+            __builtin_amdgcn_sched_barrier(0);
+            c = bfr[NHID + 1]; d = zero4;
+            lean_gemm<0, KUH>(wo, bo, c, d);
+        }
+        LT(8)
+        vm_wait(dw_nxt, gt_nxt);      // this step's prefetches (issued one to three phases ago)
+        float z = m4_reduce_scatter(c + d);
+        if constexpr (SAVE) { if (a.act_save && row_ok) a.act_save[((size_t)n * CF::NSAVE + CF::ZSLOT) * BH + goff] = z; }
+        if (__builtin_expect(geo, 0)) z *= fast_tanh(yv);
+        const float f = lean_tanh<false>(z);
+        const float ynew = fmaf(f, h, ypart);
+        yold = yv;
+        yv = ynew;
+        ybuf[r * LDY + fo] = ynew;
+        if constexpr (SAVE) {
+            if (row_ok) {
+                if (a.traj) a.traj[(size_t)(n + 1) * BH + goff] = ynew;
+                if (a.dW_out) a.dW_out[(size_t)n * BH + goff] = dw_cur;
+            }
+        }
+        dw_cur = dw_nxt; gt_cur = gt_nxt;
+        h_cur = qa[0];
+        qb = qbn;
+        // next step's [X | tau] operands (written before this step's first barrier)
+        if constexpr (KUXT > 0) lean_read_b(xrow + ((n + 1) & 1) * (4 * LDX * 4), bx);
+        LT(9)
+        __syncthreads();
+        LT_COLLECT
+    }
+    if (row_ok) {          // output ko + 1 (linear interpolation inside the last step when the output time is not on the grid)
+        const float w0 = a.out_w[2 * ko], w1 = a.out_w[2 * ko + 1];
+        const float o = (w0 == 0.0f) ? yv : w0 * yold + w1 * yv;
+        if (!a.row_out) a.ys[(size_t)(ko + 1) * BH + goff] = o;
+        else if (rslot == ko + 1) a.ys[goff] = o;
+    }
+    }
+#ifdef LEAN_TRACE
+    if (blockIdx.x == 0 && lane == 0 && a.dW_out) {
+        for (int i = 0; i < 10; ++i) a.dW_out[wave * 16 + i] = lt_acc[i];
+    }
+#endif
+}
+
+template <class CF>
+int launch_lean(const MfmaArgs& a, hipStream_t stream) {
+    const size_t lds_bytes = (size_t)CF::LDS_FLOATS * sizeof(float);
+    static bool attr_set = false;   // per instantiation
+    if (lds_bytes > 64 * 1024 && !attr_set) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(snsde_m4_kernel<CF>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes) != hipSuccess)
+            return SNSDE_ERR_LDS;
+        attr_set = true;
+    }
+    const int grid = (a.B + 3) / 4;
+    hipLaunchKernelGGL(snsde_m4_kernel<CF>, dim3(grid), dim3(CF::NT), lds_bytes, stream, a);
+    return hipGetLastError() == hipSuccess ? SNSDE_OK : SNSDE_ERR_LAUNCH;
+}
+
+// KUXT = 16-wide k-blocks of [X(t) | sin t, cos t]; YIN = 0 only for input_option 0
+template <int H>
+int dispatch_lean(const MfmaPlan& p, const MfmaArgs& a, hipStream_t st) {
+    const bool save = a.act_save || a.traj || a.dW_out;
+#ifdef SNSDE_DEV_SUBSET
+    if (p.NHID == 1 && p.KUXT == 2 && p.IO != 0)
+        return save ? launch_lean<CfgL<H, 1, 2, 1, 1>>(a, st) : launch_lean<CfgL<H, 1, 2, 1, 0>>(a, st);
+    return SNSDE_ERR_UNSUPPORTED;
+#else
+#define SNSDE_LEAN(NH_, KX_, Y_) \
+    if (p.NHID == NH_ && p.KUXT == KX_ && (p.IO != 0) == (Y_ != 0)) \
+        return save ? launch_lean<CfgL<H, NH_, KX_, Y_, 1>>(a, st) : launch_lean<CfgL<H, NH_, KX_, Y_, 0>>(a, st);
+#define SNSDE_LEANS(KX_, Y_) SNSDE_LEAN(0, KX_, Y_) SNSDE_LEAN(1, KX_, Y_) SNSDE_LEAN(2, KX_, Y_) SNSDE_LEAN(3, KX_, Y_)
+    SNSDE_LEANS(0, 1) SNSDE_LEANS(1, 1) SNSDE_LEANS(2, 1) SNSDE_LEANS(3, 1) SNSDE_LEANS(5, 1) SNSDE_LEANS(6, 1)
+    SNSDE_LEANS(1, 0) SNSDE_LEANS(2, 0) SNSDE_LEANS(3, 0) SNSDE_LEANS(5, 0)
+#undef SNSDE_LEANS
+#undef SNSDE_LEAN
+    return SNSDE_ERR_UNSUPPORTED;
+#endif
+}
+
+int dispatch_lean_h32(const MfmaPlan& p, const MfmaArgs& a, hipStream_t st);
+int dispatch_lean_h64(const MfmaPlan& p, const MfmaArgs& a, hipStream_t st);
+int dispatch_lean_h128(const MfmaPlan& p, const MfmaArgs& a, hipStream_t st);
+
+}  // namespace snsde_mfma

@@ -24,7 +24,9 @@
 //        (a function of lane & 15 only) is read by lanes 0-15 and broadcast by the MFMA (blgp:4).
 //        Fills all 256 CUs at batch 1024.
 
-#include "snsde_mfma_kernels.h"
+#include "snsde_m4_kernel.h"
+
+#include <cstdlib>
 
 using namespace snsde_mfma;
 
@@ -33,12 +35,15 @@ namespace {
 // packed[dst + ((w*TPW + t)*KU + u)*256 + lane*4 + e] = W[feature][k(u,s,e)]
 // `direct`: the folded layers' in-range entries (and folded bias) are written by the fold blocks of the same launch
 // (snsde_prepare_kernel), this pass only writes their zero padding.
+__device__ __forceinline__ int packed_index(int flavor, int KU, int feat, int k);
+
 __device__ __forceinline__ void pack_layer(const float* __restrict__ params, float* __restrict__ ws, const MfmaPackJob& job,
                                            int layer, int bx, int nbx, bool direct) {
     const MfmaLayerPack L = job.layer[layer];
     const int per_wave = job.TPW * L.KU * 256;
     const int total = job.NW * per_wave;
     const bool skip = direct && L.fold && !L.transpose;
+    const int Kown = L.t_on ? L.K - L.tshift : L.K;     // columns of the layer's own block
     for (int i = bx * blockDim.x + threadIdx.x; i < total; i += nbx * blockDim.x) {
         const int e = i & 3, lane = (i >> 2) & 63, blk = i >> 8;
         const int u = blk % L.KU, wt = blk / L.KU;  // wt = w*TPW + t
@@ -51,12 +56,21 @@ __device__ __forceinline__ void pack_layer(const float* __restrict__ params, flo
         if (L.transpose) {
             if (feat < L.N && k < L.K)
                 v = L.fold ? ws[L.fold_tmp + k * L.src_ld + L.col_off + feat] : params[L.src_w + k * L.src_ld + L.col_off + feat];
-        } else if (feat < L.N && k < L.K) {
-            const int sk = (k < L.K - L.tshift) ? k + L.tshift : k - (L.K - L.tshift);
+        } else if (feat < L.N && k < Kown) {
+            const int sk = L.t_on ? k + L.tshift : ((k < L.K - L.tshift) ? k + L.tshift : k - (L.K - L.tshift));
             if (skip) continue;
             v = L.fold ? ws[L.fold_tmp + feat * L.K + sk] : params[L.src_w + feat * L.K + sk];
+        } else if (k >= L.hole0 && k < L.hole1) {
+            continue;                                   // columns another piece owns (the redirected time columns)
         }
         ws[L.dst + i] = v;
+    }
+    if (L.t_on && !skip && !L.transpose) {              // leading time columns -> the [X(t) | sin t, cos t] block
+        for (int i = bx * blockDim.x + threadIdx.x; i < L.N * L.tshift; i += nbx * blockDim.x) {
+            const int feat = i / L.tshift, j = i - feat * L.tshift;
+            ws[L.t_dst + packed_index(job.flavor, L.t_KU, feat, L.t_col0 + j)] =
+                L.fold ? ws[L.fold_tmp + feat * L.K + j] : params[L.src_w + feat * L.K + j];
+        }
     }
     // bias table [row][H]
     if (bx == 0 && L.bias_row >= 0 && !skip) {
@@ -133,8 +147,12 @@ __device__ __forceinline__ void fold_block(const float* __restrict__ params, flo
         ws[job.tmp[pc] + f * K + k] = val;
         if (pk) {     // forward prepare: straight into the packed MFMA fragment layout (source column k -> packed column kp)
             const MfmaLayerPack& L = pk->layer[pc];
-            const int kp = (k >= L.tshift) ? k - L.tshift : k + (L.K - L.tshift);
-            ws[L.dst + packed_index(pk->flavor, L.KU, f, kp)] = val;
+            if (L.t_on && k < L.tshift) {
+                ws[L.t_dst + packed_index(pk->flavor, L.t_KU, f, L.t_col0 + k)] = val;    // time column -> the xt block
+            } else {
+                const int kp = (k >= L.tshift) ? k - L.tshift : k + (L.K - L.tshift);
+                ws[L.dst + packed_index(pk->flavor, L.KU, f, kp)] = val;
+            }
         }
     }
     if (pc == 0 && threadIdx.x < 64) {   // folded bias: b_emb + E1 b_in + E2 b_init (one wave, shuffle reduction)
@@ -221,19 +239,54 @@ MfmaPlan make_plan(const snsde_solve* s, const SnsdeNet& net, int flavor_hint) {
     p.SRK = srk ? 1 : 0;
     if (srk) p.FL = 1;
     p.FOLD = (emb && (nhid > 1 || p.KUX > 2 || srk || noise_net || !(s->flags & SNSDE_FLAG_EXACT_ORDER))) ? 1 : 0;   // exact order: NL <= 2, C <= 32 only
-    int off = 0, n = 0, rows = 0;
-    auto add = [&](const SnsdeLayer& L, int KU, int fold_col, bool bias) {
+    // lean M4 kernel (snsde_m4_kernel.h): 4-row tiles, Euler / Milstein, elementwise diffusions, 32 <= H <= 128; the time
+    // features share the control path's k-block.  SNSDE_NO_LEAN=1 in the environment keeps the general kernel (A/B timing).
+    static const bool no_lean = getenv("SNSDE_NO_LEAN") != nullptr;
+    const bool usex = emb || io == 0, timef = io >= 3;
+    const int xcn = usex ? m.input_channels : 0;
+    int kuxt = (xcn + (timef ? 2 : 0) + 15) / 16;
+    if (kuxt == 4) kuxt = 5;
+    p.KUXT = kuxt;
+    p.LEAN = (!no_lean && p.FL == 1 && !srk && p.NN == 0 && H >= 32 && H <= 128 && (!emb || p.FOLD) && kuxt <= 6) ? 1 : 0;
+    // workspace layout: bias rows | time-only diffusion table | SRK pass table | packed fragments | fold temps.  The first
+    // three do not depend on the tile flavour / kernel variant, so the backward finds the table whatever forward ran.
+    int n = 0, rows = 0, woff = 0;
+    auto add = [&](const SnsdeLayer& L, int KU, int fold_col, bool bias) -> MfmaLayerPack& {
         MfmaLayerPack& q = p.layer[n++];
-        q.src_w = L.src_w; q.src_b = L.src_b; q.K = L.K; q.tshift = L.tshift; q.N = L.N; q.KU = KU; q.dst = off;
+        q = MfmaLayerPack{};
+        q.src_w = L.src_w; q.src_b = L.src_b; q.K = L.K; q.tshift = L.tshift; q.N = L.N; q.KU = KU; q.dst = woff;
         q.fold = fold_col >= 0 ? 1 : 0;
         q.fold_w = net.emb.src_w; q.fold_col = fold_col >= 0 ? fold_col : 0; q.fold_ld = 2 * H;
         q.bias_row = bias ? rows++ : -1;
         q.fold_tmp = -1;
-        off += p.NW * p.TPW * KU * 256;
+        woff += p.NW * p.TPW * KU * 256;
+        return q;
     };
     const int KUH = H / 16;
     const int KUYv = KUH + (io >= 3 ? 1 : 0);
-    if (p.FOLD) {
+    if (p.LEAN) {
+        // kernel load order: xt block ([X(t) | sin t, cos t], if any), y block, hidden.., out
+        if (kuxt > 0) {
+            if (usex) {
+                MfmaLayerPack& q = add(net.init, kuxt, p.FOLD ? H : -1, io == 0);
+                if (timef) { q.hole0 = xcn; q.hole1 = xcn + 2; }
+            } else {             // time features only: an all-padding block whose columns 0, 1 the `in` piece fills
+                MfmaLayerPack& q = p.layer[n++];
+                q = MfmaLayerPack{};
+                q.KU = kuxt; q.dst = woff; q.bias_row = -1; q.fold_tmp = -1; q.hole0 = 0; q.hole1 = 2;
+                woff += p.NW * p.TPW * kuxt * 256;
+            }
+        }
+        if (io != 0) {
+            const int xt_dst = p.layer[0].dst;
+            MfmaLayerPack& q = add(net.in, KUH, p.FOLD ? 0 : -1, true);
+            if (timef) { q.t_on = 1; q.t_dst = xt_dst; q.t_KU = kuxt; q.t_col0 = xcn; }
+        }
+        if (p.FOLD) {
+            p.fold_b_in = net.in.src_b; p.fold_b_init = net.init.src_b; p.fold_b_emb = net.emb.src_b;
+            p.fold_emb_w = net.emb.src_w;
+        }
+    } else if (p.FOLD) {
         // kernel load order: wx (init piece), wy (in piece); ONE bias row (written by the `in` piece)
         add(net.init, p.KUX, H, false);
         add(net.in, KUYv, 0, true);
@@ -252,6 +305,7 @@ MfmaPlan make_plan(const snsde_solve* s, const SnsdeNet& net, int flavor_hint) {
     if (p.NN >= 2) add(net.ny1, KUH, -1, true);
     p.n_bias_rows = rows;
     p.n_layers = n;
+    int off = 0;
     p.bias_off = off;
     off += rows * H;
     off = (off + 3) & ~3;
@@ -259,6 +313,12 @@ MfmaPlan make_plan(const snsde_solve* s, const SnsdeNet& net, int flavor_hint) {
     if (p.gt_off >= 0) off += s->n_steps * H * (srk ? 4 : 1);     // SRK: the four stage times of every step
     p.srk_tab_off = -1;
     if (srk) { p.srk_tab_off = off; off += 3 * s->n_steps * SNSDE_STEP_STRIDE; }
+    off = (off + 3) & ~3;
+    for (int i = 0; i < n; ++i) {
+        p.layer[i].dst += off;
+        if (p.layer[i].t_on) p.layer[i].t_dst += off;
+    }
+    off += woff;
     if (p.FOLD) {   // temps for the folded products
         for (int i = 0; i < 2; ++i) { p.layer[i].fold_tmp = off; off += H * p.layer[i].K; }
         p.fold_bias_tmp = off; off += H;
@@ -381,6 +441,16 @@ int snsde_mfma_launch(const snsde_solve* s, const SnsdeNet& net, hipStream_t str
     a.method = s->method; a.no = s->model.noise_option;
     a.off_theta = net.off_theta; a.gt_off = p.gt_off; a.bias_off = p.bias_off;
     for (int i = 0; i < p.n_layers; ++i) a.w_off[i] = p.layer[i].dst;
+    if (p.LEAN) {
+        const int io = p.IO;
+        a.lean_xc = (io == 0 || io == 2 || io == 4 || io == 6) ? s->model.input_channels : 0;
+        a.lean_time = io >= 3 ? 1 : 0;
+        a.lean_geo = (io == 5 || io == 6) ? 1 : 0;
+        if (p.H == 128) return dispatch_lean_h128(p, a, stream);
+        if (p.H == 64) return dispatch_lean_h64(p, a, stream);
+        if (p.H == 32) return dispatch_lean_h32(p, a, stream);
+        return SNSDE_ERR_UNSUPPORTED;
+    }
     if (p.H == 256) return dispatch_fwd_h256(p, a, stream);
     if (p.H == 128) return dispatch_fwd_h128(p, a, stream);
     if (p.H == 64) return dispatch_fwd_h64(p, a, stream);

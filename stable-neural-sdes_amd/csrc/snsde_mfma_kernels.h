@@ -43,6 +43,10 @@ struct MfmaLayerPack {
     // transpose (backward pass): packed row index = forward INPUT feature, k = forward OUTPUT feature:
     // value = src[k * src_ld + col_off + feat]  (src = params + src_w, or the folded product in ws + fold_tmp)
     int32_t transpose, src_ld, col_off;
+    // lean M4 layout (snsde_m4_kernel.h): the `tshift` leading source columns (sin t, cos t) are not rotated to the end of
+    // this layer's own k axis but written into ANOTHER packed block (the [X(t) | sin t, cos t] block) at columns t_col0..;
+    // [hole0, hole1) = padding columns of this block that another piece writes (left untouched here)
+    int32_t t_on, t_dst, t_KU, t_col0, hole0, hole1;
 };
 
 struct MfmaPackJob {
@@ -87,6 +91,7 @@ struct MfmaArgs {
     int32_t B, L, C, N, T, method, no;
     int32_t off_theta, gt_off, bias_off;
     int32_t w_off[MAXL];
+    int32_t lean_xc, lean_time, lean_geo;   // lean M4 kernel: control channels in the xt block, time features on, z *= tanh(y)
 };
 
 __host__ __device__ constexpr int ld_for(int K, int pad) { return ((K - pad + 63) / 64) * 64 + pad; }
@@ -1422,6 +1427,7 @@ int launch_rev_srk(const RevArgs& a, hipStream_t stream) {
 struct MfmaPlan {
     bool ok;
     int H, KUX, NHID, IO, FL, TPW, NW, FOLD, NN, SRK;
+    int LEAN, KUXT;    // lean M4 kernel (snsde_m4_kernel.h) and its 16-wide k-blocks of [X(t) | sin t, cos t]
     int srk_tab_off;   // expanded (3N-row) step table of the SRK variant inside the workspace
     int n_bias_rows;
     int fold_b_in, fold_b_init, fold_b_emb, fold_emb_w, fold_bias_tmp;

@@ -1,0 +1,29 @@
+#!/usr/bin/env python3
+"""Per-phase cycle timeline of the lean M4 kernel (library built with -DLEAN_TRACE, named by SNSDE_LIB): mean cycles per
+step between consecutive stamps, per wave of workgroup 0."""
+import os, sys
+import numpy as np, torch
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import stable_neural_sdes_amd as S
+import bench
+dev = torch.device('cuda:0')
+pr, params, flat, coeffs, y0 = bench.build_inputs(dev, 0)
+model = S.engine.model_struct(bench.C, bench.H, bench.H, bench.NL, bench.IO, bench.NO)
+grid = S.engine.step_grid(np.array([0.0, 100.0], np.float32), 1.0, pr['times'], dev)
+call = S.engine.SolveCall(model, flat, coeffs, grid, y0, seed=1, kernel='mfma4', save_dW=True)
+for _ in range(3):
+    call.launch()
+torch.cuda.synchronize()
+t = call.dW_out.reshape(-1)[:8 * 16].cpu().numpy().reshape(8, 16)[:, :10] / grid.N
+names = ['barrier C -> top', 'reads + top filler', 'L1 mfma', 'L1 epilogue', 'barrier A', 'reads + prep', 'L2 mfma + epilogue',
+         'barrier B', 'reads + L3 mfma', 'vm wait + update']
+print('cycles per step (mean over steps), waves 0..7:')
+for i, nme in enumerate(names):
+    print(f'{nme:22s}', ' '.join(f'{v:7.0f}' for v in t[:, i]))
+print(f'{"total":22s}', ' '.join(f'{v:7.0f}' for v in t.sum(1)))
+ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(20)]
+for a, b in ev:
+    a.record(); call.launch(reuse_prepared=True); b.record()
+torch.cuda.synchronize()
+print('kernel us (trace build, saves on):', np.median([a.elapsed_time(b) for a, b in ev]) * 1e3)
