@@ -8,15 +8,24 @@ coefficients (1024, 100, 84), dt=1 -> N=100 Euler steps, ts=[0, 100], Brownian i
 in-kernel Philox generator, inputs resident in HBM.  value = rows x solver-steps x K / wall time.
 
     python bench.py [--gpus N] [--steps K] [--warmup W]
-    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
-Multi-GPU: the batch shards by rows, one process per GPU, no collective inside the solver
-(weak scaling: every rank solves its own 1024-row shard of a 1024*N-row global batch, Philox counters
-use the global row index).  Timing: barrier + synchronize on both sides, MAX over ranks.
+--gpus N > 1 run as plain `python bench.py --gpus N` re-executes itself under
+`python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1` (one process per GPU over
+RCCL) and passes rank 0's JSON line through; launched by torchrun it reads RANK / LOCAL_RANK / WORLD_SIZE.
+
+Multi-GPU: the batch shards by rows, one process per GPU, no collective inside the solver.  The headline `value`
+is weak scaling (every rank solves its own 1024-row shard of a 1024*N-row global batch, Philox counters use the
+global row index).  Timing of `value`: barrier + synchronize on both sides of K solves, MAX over ranks.
+`timing` = HIP events around single solves (median of >= 50 after 10 warm-ups, p10 / p90).
+`extra` carries the two fixed-global-batch (strong scaling) configurations of BASELINE.json: K3 (GSDE, 4096 rows,
+200 steps, rows split N ways) and K5 (Milstein + fused adjoint, 1024 rows, H=256, rows split N ways, gradient
+all-reduce over RCCL).
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -31,20 +40,24 @@ import stable_neural_sdes_amd as S  # noqa: E402
 # K2 workload -----------------------------------------------------------------------------------------
 IO, NO, NL, B, H, C, L, NSTEP = 4, 17, 2, 1024, 128, 21, 101, 100
 FLOP_PER_ROWSTEP = 169_728          # SURVEY.md 8d "ALGORITHMIC flops per unit", K2 (t-only diffusion hoisted)
+# what the kernel EXECUTES per row-step: emb o linear_in / emb o initial_network are pre-multiplied (one layer fewer) and
+# the time features share the control path's k-block: 104 v_mfma_f32_4x4x1_16b (512 FLOP) per wave-step x 8 waves / 4 rows
+EXECUTED_FLOP_PER_ROWSTEP = 104 * 512 * 8 // 4
+MFMA_CYCLES_PER_STEP = 104 * 2 * 8  # per SIMD: two waves x 104 MFMAs x 8 cycles (the kernel's own MFMA-issue floor)
 BYTES_PER_ROWSTEP = 346             # SURVEY.md 8d algorithmic HBM bytes, Philox + final state only
 PEAK_FP32_TFLOPS = 157.3            # MI355X_MICROARCH.md: fp32 vector = fp32 MFMA peak
 PEAK_HBM_GBS = 8000.0
 # HBM bytes per launch of the solve kernel from rocprofv3 PMC passes (FETCH_SIZE doubled per the gfx950 correction
-# in MI355X_MICROARCH.md, + WRITE_SIZE; profiles/r01_pmc_traffic.txt); re-measure when the kernel's memory behaviour changes.
-HBM_TRAFFIC_BYTES_PER_LAUNCH = 38137856   # K2, MFMA M4 kernel, round 1
+# in MI355X_MICROARCH.md, + WRITE_SIZE; profiles/r02_pmc_traffic.txt); re-measure when the kernel's memory behaviour changes.
+HBM_TRAFFIC_BYTES_PER_LAUNCH = 38137856   # K2, M4 kernel
 
 
-def build_inputs(device, rank):
+def build_inputs(device, rank, io=IO, no=NO, nl=NL, b=B, h=H, c=C, l=L, nan_frac=0.3, hermite=False):
     from tests.helpers import make_problem, param_spec
-    pr = make_problem(1234 + rank, IO, NO, NL, B, H, C, L, nan_frac=0.3)
+    pr = make_problem(1234 + rank, io, no, nl, b, h, c, l, nan_frac=nan_frac, hermite=hermite)
     # weights are replicated: every rank uses rank 0's parameter draw
-    p0 = make_problem(1234, IO, NO, NL, 1, H, C, L, nan_frac=0.0)['params'] if rank else pr['params']
-    flat = torch.from_numpy(np.concatenate([p0[n].reshape(-1) for n, _ in param_spec(IO, NO, NL, C, H)])).to(device)
+    p0 = make_problem(1234, io, no, nl, 1, h, c, l, nan_frac=0.0)['params'] if rank else pr['params']
+    flat = torch.from_numpy(np.concatenate([p0[n].reshape(-1) for n, _ in param_spec(io, no, nl, c, h)])).to(device)
     coeffs = torch.from_numpy(pr['coeffs']).to(device)
     y0 = torch.from_numpy(pr['y0']).to(device)
     return pr, p0, flat, coeffs, y0
@@ -104,22 +117,116 @@ def cpu_baseline(pr, params, budget_s=12.0):
                       f"= fastest of the calibration on {avail} usable cores), {el:.1f} s"}
 
 
+def event_times_ms(fn, stream, n, warm):
+    """HIP-event duration of n calls of fn() on `stream` (each call bracketed by its own event pair) after `warm` calls."""
+    for _ in range(warm):
+        fn()
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(n)]
+    for a, b in ev:
+        a.record(stream)
+        fn()
+        b.record(stream)
+    torch.cuda.synchronize(stream.device)
+    return np.array([a.elapsed_time(b) for a, b in ev])
+
+
+def spread(t_ms):
+    return {"n": int(len(t_ms)), "median_ms": float(np.median(t_ms)), "p10_ms": float(np.percentile(t_ms, 10)),
+            "p90_ms": float(np.percentile(t_ms, 90))}
+
+
+def strong_k3(dev, rank, world, stream, barrier, maxr):
+    """BASELINE config 3: Neural GSDE (6, 17), 4096 rows GLOBAL split over the ranks, H=128, C=21, Hermite coefficients
+    without missing values, times=arange(201) -> 200 Euler steps, ts=[0, 200]; forward solve, in-kernel Philox."""
+    rows_g, n_steps = 4096, 200
+    lo, hi = S.sharding.shard_rows(rows_g, world, rank)
+    pr, _, flat, coeffs, y0 = build_inputs(dev, rank, io=6, no=17, b=hi - lo, l=n_steps + 1, nan_frac=0.0, hermite=True)
+    model = S.engine.model_struct(C, H, H, NL, 6, 17)
+    grid = S.engine.step_grid(np.array([0.0, float(n_steps)], np.float32), 1.0, pr['times'], dev)
+    call = S.engine.SolveCall(model, flat, coeffs, grid, y0, method='euler', seed=2024, row_offset=lo)
+    for _ in range(10):
+        call.launch(stream)
+    barrier()
+    k, t0 = 30, time.perf_counter()
+    for _ in range(k):
+        call.launch(stream)
+    barrier()
+    el = maxr(time.perf_counter() - t0)
+    return {"workload": f"K3: Neural GSDE (io=6,no=17) {rows_g} rows global ({hi - lo}/GPU), H=128, 200 Euler steps, "
+                        "Hermite coeffs, forward", "scaling": "strong", "value": rows_g * n_steps * k / el,
+            "unit": "row-steps/s", "ms_per_solve": el / k * 1e3, "solves": k}
+
+
+def strong_k5(dev, rank, world, stream, barrier, maxr, dist):
+    """BASELINE config 5: Milstein + fused adjoint, MuJoCo-forecast-shaped: LNSDE (4, 17), 1024 rows GLOBAL split over the
+    ranks, H=256, C=14, L=50 knots with dropped rows, 49 steps, every knot an output; loss = mean square of the last 10
+    states; forward + backward + gradient all-reduce (RCCL) per step."""
+    from tests.helpers import make_problem, param_spec
+    rows_g, hh, cc, ll = 1024, 256, 14, 50
+    lo, hi = S.sharding.shard_rows(rows_g, world, rank)
+    pr = make_problem(4321 + rank, 4, 17, 2, hi - lo, hh, cc, ll, nan_frac=0.3)
+    p0 = make_problem(4321, 4, 17, 2, 1, hh, cc, ll, nan_frac=0.0)['params']
+    sde = S.Diffusion_model(cc, hh, hh, 2, input_option=4, noise_option=17).to(dev)
+    with torch.no_grad():
+        for name, p in sde.named_parameters():
+            p.copy_(torch.from_numpy(np.asarray(p0[name], np.float32)).reshape(p.shape))
+    times = torch.from_numpy(pr['times']).to(dev)
+    sde.set_X(torch.from_numpy(pr['coeffs']).to(dev), times)
+    y0 = torch.from_numpy(pr['y0']).to(dev)
+    params = [p for p in sde.parameters()]
+
+    def step():
+        for p in params:
+            p.grad = None
+        ys = S.torchsde.sdeint(sde, y0, times, dt=1.0, method='milstein', options={'seed': 7, 'row_offset': lo})
+        loss = ys[-10:].square().mean() * ((hi - lo) / rows_g)
+        loss.backward()
+        if dist is not None:
+            flat = torch.cat([p.grad.reshape(-1) for p in params])
+            dist.all_reduce(flat)
+        return loss
+
+    for _ in range(5):
+        step()
+    barrier()
+    k, t0 = 20, time.perf_counter()
+    for _ in range(k):
+        step()
+    barrier()
+    el = maxr(time.perf_counter() - t0)
+    return {"workload": f"K5: LNSDE (io=4,no=17) Milstein + fused adjoint, {rows_g} rows global ({hi - lo}/GPU), H=256, "
+                        "C=14, 49 steps, 50 outputs, fwd+bwd+grad all-reduce", "scaling": "strong",
+            "value": rows_g * (ll - 1) * k / el, "unit": "row-steps/s (training steps)", "ms_per_step": el / k * 1e3,
+            "steps": k}
+
+
+def self_launch(args):
+    """`python bench.py --gpus N` without torchrun: re-execute under torch.distributed.run, one rank per GPU."""
+    with socket.socket() as s:
+        s.bind(('127.0.0.1', 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', f'--nproc-per-node={args.gpus}',
+           '--master-addr', '127.0.0.1', '--master-port', str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get('HSA_ENABLE_IPC_MODE_LEGACY', '0'))
+    raise SystemExit(subprocess.call(cmd, env=env))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=50)
-    ap.add_argument('--warmup', type=int, default=5)
+    ap.add_argument('--warmup', type=int, default=10)
     ap.add_argument('--kernel', default='auto')
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-extra', action='store_true', help='skip the K3 / K5 strong-scaling legs')
     ap.add_argument('--exact-order', action='store_true', help='keep the unfused emb(linear_in) operation order')
     args = ap.parse_args()
 
+    if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
+        self_launch(args)
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
     world = int(os.environ.get('WORLD_SIZE', '1'))
-    if args.gpus > 1 and world == 1:
-        raise SystemExit('for --gpus N > 1 launch with: python -m torch.distributed.run --nnodes=1 '
-                         '--nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...')
     assert torch.cuda.is_available(), 'bench.py needs a GPU (there is no CPU fallback for the product path)'
     torch.cuda.set_device(local_rank)
     dev = torch.device('cuda', local_rank)
@@ -127,7 +234,10 @@ def main():
     if world > 1 or os.environ.get('SNSDE_BENCH_FORCE_DIST') == '1':   # the env switch exercises the RCCL path on one GPU
         import torch.distributed as dist
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        os.environ.setdefault('MASTER_PORT', '29511')
         dist.init_process_group('nccl', device_id=dev)
+        assert dist.get_world_size() == max(args.gpus, 1) or os.environ.get('SNSDE_BENCH_FORCE_DIST') == '1', \
+            f'--gpus {args.gpus} but the process group has {dist.get_world_size()} ranks'
 
     pr, params, flat, coeffs, y0 = build_inputs(dev, rank)
     model = S.engine.model_struct(C, H, H, NL, IO, NO)
@@ -143,6 +253,9 @@ def main():
             dist.barrier()
         torch.cuda.synchronize(dev)
 
+    def maxr(x):
+        return S.sharding.max_over_ranks(x, device=dev)
+
     for _ in range(args.warmup):
         call.launch(stream)
     barrier()
@@ -150,23 +263,26 @@ def main():
     for _ in range(args.steps):
         call.launch(stream)          # full call: weight pack + time table + fused solve
     barrier()
-    elapsed = S.sharding.max_over_ranks(time.perf_counter() - t0, device=dev)
+    elapsed = maxr(time.perf_counter() - t0)
 
-    # dominant kernel: the fused solve alone (prepared workspace reused), HIP events on the launch stream
-    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(20)]
-    for a, b in ev:
-        a.record(stream)
-        call.launch(stream, reuse_prepared=True)
-        b.record(stream)
-    torch.cuda.synchronize(dev)
-    kern_ms = float(np.mean([a.elapsed_time(b) for a, b in ev]))
+    # per-solve HIP-event timings on the launch stream: the whole call, and the dominant kernel alone (prepared
+    # workspace reused)
+    t_call = event_times_ms(lambda: call.launch(stream), stream, max(50, args.steps), 10)
+    t_kern = event_times_ms(lambda: call.launch(stream, reuse_prepared=True), stream, 50, 10)
+    kern_ms = float(np.median(t_kern))
     ys = call.ys
     assert bool(torch.isfinite(ys).all()), 'non-finite solver output'
+
+    extra = {}
+    if not args.no_extra:
+        extra["K3_strong"] = strong_k3(dev, rank, world, stream, barrier, maxr)
+        extra["K5_strong_train"] = strong_k5(dev, rank, world, stream, barrier, maxr, dist)
 
     if rank == 0:
         rowsteps = B * NSTEP
         value = world * rowsteps * args.steps / elapsed
         ach_tf = rowsteps * FLOP_PER_ROWSTEP / (kern_ms * 1e-3) / 1e12
+        exe_tf = rowsteps * EXECUTED_FLOP_PER_ROWSTEP / (kern_ms * 1e-3) / 1e12
         ach_gbs = rowsteps * BYTES_PER_ROWSTEP / (kern_ms * 1e-3) / 1e9
         out = {
             "metric": "SDE solver steps/sec (batch x steps / s), forward solve",
@@ -177,12 +293,21 @@ def main():
                                    "coeffs 30% NaN, 100 Euler steps dt=1, ts=[0,100], in-kernel Philox dW",
                        "rows_per_gpu": B, "solver_steps": NSTEP, "global_rows": world * B,
                        "parallelism": f"row-shard x{world}, no collective in the solver", "kernel": args.kernel},
+            "timing": {"solve_call": spread(t_call), "solve_kernel": spread(t_kern),
+                       "method": "HIP events on the launch stream, one pair per solve, after 10 warm-ups (SURVEY 8d)"},
             "roofline": {"bound": "mfma", "achieved": ach_tf, "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s",
                          "frac": ach_tf / PEAK_FP32_TFLOPS, "traffic": HBM_TRAFFIC_BYTES_PER_LAUNCH,
                          "kernel_ms": kern_ms, "flop_per_rowstep": FLOP_PER_ROWSTEP,
+                         "executed_flop_per_rowstep": EXECUTED_FLOP_PER_ROWSTEP, "executed_frac": exe_tf / PEAK_FP32_TFLOPS,
+                         "mfma_busy": MFMA_CYCLES_PER_STEP * NSTEP / (kern_ms * 1e-3 * 2.4e9),
                          "hbm_frac": ach_gbs / PEAK_HBM_GBS, "hbm_achieved_GBs": ach_gbs,
-                         "note": "fp32 FMA/MFMA roof binds (intensity ~490 FLOP/B); hbm_* = algorithmic 346 B/row-step"},
+                         "note": "fp32 FMA/MFMA roof binds (intensity ~490 FLOP/B); frac counts the reference's algorithmic "
+                                 "FLOPs, executed_frac the MFMA FLOPs the kernel issues (folded first layer); mfma_busy = "
+                                 "1664 MFMA-issue cycles per SIMD-step / kernel cycles at 2.4 GHz (f32 MFMA shares the VALU "
+                                 "port on gfx950, so VALU work adds to it: DESIGN.md 3.1); hbm_* = algorithmic 346 B/row-step"},
         }
+        if extra:
+            out["extra"] = extra
         if not args.no_cpu_baseline and world == 1:     # reported at N = 1 only (the other ranks would idle behind it)
             out["cpu_baseline"] = cpu_baseline(pr, params)
             out["speedup_vs_cpu"] = value / world / out["cpu_baseline"]["value"]

@@ -382,8 +382,14 @@ RevPlan make_rev_plan(const snsde_solve* s, const SnsdeNet& net, const MfmaPlan&
 bool snsde_mfma_supported(const snsde_solve* s, const SnsdeNet& net) { return make_plan(s, net, -1).ok; }
 
 size_t snsde_mfma_workspace_floats(const snsde_solve* s, const SnsdeNet& net) {
-    MfmaPlan p = make_plan(s, net, -1);
-    return p.ok ? (size_t)p.total_floats : 0;
+    // the packed layout depends on the kernel variant (the lean 4-row kernel merges the time features into the control
+    // block): size the workspace for whichever variant a later launch of this descriptor may select
+    size_t need = 0;
+    for (int hint = 0; hint <= 1; ++hint) {
+        MfmaPlan p = make_plan(s, net, hint);
+        if (p.ok && (size_t)p.total_floats > need) need = (size_t)p.total_floats;
+    }
+    return need;
 }
 
 int snsde_mfma_launch(const snsde_solve* s, const SnsdeNet& net, hipStream_t stream, int flavor_hint) {

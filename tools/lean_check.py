@@ -38,7 +38,9 @@ def parity():
             continue
         ref, _ = O.solve_diffusion_model(pr['params'], io, no, pr['coeffs'], pr['times'], pr['y0'], ts, 0.5, dW,
                                          dtype=np.float64, method=method)
-        rep = assert_parity(ys, ref, what=str((io, no, method)))
+        c32, _ = O.solve_diffusion_model(pr['params'], io, no, pr['coeffs'], pr['times'], pr['y0'], ts, 0.5, dW,
+                                         dtype=np.float32, method=method)
+        rep = assert_parity(ys, ref, c32, what=str((io, no, method)))
         print('case', (io, no, NL, B, H, C, L, method), 'ok', {k: f'{v:.2e}' for k, v in rep.items()})
 
 
