@@ -235,6 +235,8 @@ def main():
         import torch.distributed as dist
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         os.environ.setdefault('MASTER_PORT', '29511')
+        os.environ.setdefault('RANK', '0')
+        os.environ.setdefault('WORLD_SIZE', '1')
         dist.init_process_group('nccl', device_id=dev)
         assert dist.get_world_size() == max(args.gpus, 1) or os.environ.get('SNSDE_BENCH_FORCE_DIST') == '1', \
             f'--gpus {args.gpus} but the process group has {dist.get_world_size()} ranks'

@@ -8,9 +8,52 @@ batch x channel x time, cached on disk).  Here it is one batched Thomas solve ov
 whatever device the data is on.  Evaluation (A10) on CUDA tensors goes through the HIP spline
 kernel (``snsde_spline_evaluate``).
 """
+import importlib.machinery
+import importlib.util
+import os
+import sys
+
 import torch
 
 from . import engine
+
+_VENDORED = None
+
+
+def _vendored_package():
+    """The reference's own vendored ``controldiffeq`` package (benchmark_*/controldiffeq, found on sys.path), loaded under a
+    private name.  After ``stable_neural_sdes_amd.install()`` this mirror answers ``import controldiffeq``; names it does
+    not implement (``cdeint`` and friends, used by the reference's CDE baselines built by the same ``make_model``) are
+    served from the vendored package so those baselines keep working in the same process."""
+    global _VENDORED
+    if _VENDORED is None:
+        _VENDORED = False
+        here = os.path.dirname(os.path.abspath(__file__))
+        for entry in sys.path:
+            init = os.path.join(entry or '.', 'controldiffeq', '__init__.py')
+            if os.path.isfile(init) and os.path.abspath(os.path.dirname(os.path.dirname(init))) != here:
+                name = '_snsde_vendored_controldiffeq'
+                spec = importlib.util.spec_from_file_location(name, init, submodule_search_locations=[os.path.dirname(init)])
+                mod = importlib.util.module_from_spec(spec)
+                sys.modules[name] = mod
+                try:
+                    spec.loader.exec_module(mod)
+                    _VENDORED = mod
+                except Exception:      # its own dependencies (torchdiffeq) are missing: nothing to delegate to
+                    sys.modules.pop(name, None)
+                break
+    return _VENDORED or None
+
+
+def __getattr__(name):
+    if name.startswith('__'):
+        raise AttributeError(name)
+    mod = _vendored_package()
+    if mod is not None and hasattr(mod, name):
+        return getattr(mod, name)
+    raise AttributeError(f"module 'controldiffeq' (stable_neural_sdes_amd mirror) has no attribute {name!r}: the mirror "
+                         "implements natural_cubic_spline_coeffs / NaturalCubicSpline only and found no importable "
+                         "vendored controldiffeq package on sys.path to delegate to")
 
 
 def _series_coeffs(times, x):

@@ -147,16 +147,26 @@ class Diffusion_model(nn.Module):
         self.X = _torchcde.CubicSpline(self.coeffs, self.times)
 
     # -- vector field --------------------------------------------------------------------------------
-    def _fused_ok(self, y):
+    def _fused_ok(self, t, y):
+        """The HIP vector-field probe serves CUDA float32 states under no_grad, one scalar time for all rows, and a module
+        the engine recognises (NL - 1 <= 8 hidden `linears`); everything else takes the tensor-op formulas below."""
         return (y.is_cuda and y.dtype == torch.float32 and not torch.is_grad_enabled()
-                and hasattr(self, 'coeffs') and self.coeffs.is_cuda)
+                and hasattr(self, 'coeffs') and self.coeffs.is_cuda
+                and (not torch.is_tensor(t) or t.numel() == 1) and engine.recognise(self) is not None)
 
     def _fused_fg(self, t, y):
-        rec = engine.recognise(self)
-        model, layout, numel = rec
+        # f and g of one (t, y) come out of the same launch: a solver step that asks for both evaluates once
+        key = (float(t), y.data_ptr(), y._version, tuple(y.shape), self.coeffs.data_ptr(), self.coeffs._version,
+               tuple(p._version for p in self.parameters()))
+        hit = getattr(self, '_fg_cache', None)
+        if hit is not None and hit[0] == key:
+            return hit[1]
+        model, layout, numel = engine.recognise(self)
         flat = engine.flatten_params(self, layout, numel, y.device)
         coeffs = self.coeffs.detach().to(torch.float32).contiguous()
-        return engine.eval_fg(model, flat, coeffs, _HostTimes.get(self.times), float(t), y.contiguous())
+        out = engine.eval_fg(model, flat, coeffs, _HostTimes.get(self.times), float(t), y.contiguous())
+        object.__setattr__(self, '_fg_cache', (key, out))
+        return out
 
     @staticmethod
     def _tau(t, y):
@@ -174,12 +184,12 @@ class Diffusion_model(nn.Module):
         return raw_diffusion_rows(dict(self.named_parameters()), self.noise_option, col, tau, y)
 
     def f(self, t, y):
-        if self._fused_ok(y):
+        if self._fused_ok(t, y):
             return self._fused_fg(t, y)[0]
         return self._drift(t, y)
 
     def g(self, t, y):
-        if self._fused_ok(y):
+        if self._fused_ok(t, y):
             return self._fused_fg(t, y)[1]
         return (self.theta.sigmoid() * torch.nan_to_num(self._raw_diffusion(t, y))).tanh()
 

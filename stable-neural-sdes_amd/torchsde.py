@@ -54,6 +54,33 @@ class BrownianIncrements:
         return W, h * (0.5 * W + (h / 12).sqrt() * xi)     # U = int_ta^tb (W_s - W_ta) ds
 
 
+BrownianInterval = BrownianIncrements      # torchsde.BrownianInterval(t0, t1, size, dtype, device, entropy, ...) call sites
+
+
+class BaseSDE(torch.nn.Module):
+    """torchsde.BaseSDE: an nn.Module that records its noise / SDE type (torch-ists .../NSDE/latent_sde.py:31 subclasses
+    ``torchsde.SDEIto``)."""
+
+    def __init__(self, noise_type, sde_type):
+        super().__init__()
+        if noise_type not in ('diagonal', 'scalar', 'additive', 'general'):
+            raise ValueError(f"Expected noise type in ('diagonal', 'scalar', 'additive', 'general'), but found {noise_type}")
+        if sde_type not in ('ito', 'stratonovich'):
+            raise ValueError(f"Expected sde type in ('ito', 'stratonovich'), but found {sde_type}")
+        self.noise_type = noise_type
+        self.sde_type = sde_type
+
+
+class SDEIto(BaseSDE):
+    def __init__(self, noise_type):
+        super().__init__(noise_type=noise_type, sde_type='ito')
+
+
+class SDEStratonovich(BaseSDE):
+    def __init__(self, noise_type):
+        super().__init__(noise_type=noise_type, sde_type='stratonovich')
+
+
 def _as_ts(ts, y0):
     if not torch.is_tensor(ts):
         if not isinstance(ts, (tuple, list)) or not all(isinstance(t, (float, int)) for t in ts):
@@ -121,7 +148,10 @@ def sdeint(sde, y0, ts, bm=None, method=None, dt=1e-3, adaptive=False, rtol=1e-5
     if backend not in ('auto', 'hip', 'torch'):
         raise ValueError("options['backend'] must be 'auto', 'hip' or 'torch'")
 
-    rec = engine.recognise(sde) if names is None else None
+    # names={'drift': 'f', 'diffusion': 'g'} is the default mapping: still the fused path
+    default_names = names is None or (names.get('drift', 'f') == 'f' and names.get('diffusion', 'g') == 'g'
+                                      and not (set(names) - {'drift', 'diffusion'}))
+    rec = engine.recognise(sde) if default_names else None
     want_hip = backend == 'hip' or (backend == 'auto' and rec is not None and y0.is_cuda)
     if want_hip:
         if rec is None:
@@ -130,6 +160,17 @@ def sdeint(sde, y0, ts, bm=None, method=None, dt=1e-3, adaptive=False, rtol=1e-5
             raise ValueError("the HIP engine needs CUDA (ROCm) tensors")
         return _sdeint_hip(sde, rec, y0, ts, bm, method, float(dt), options)
     return _sdeint_torch(sde, y0, ts, bm, method, float(dt), options, names)
+
+
+def sdeint_adjoint(sde, y0, ts, bm=None, method=None, adjoint_method=None, adjoint_adaptive=False, adjoint_rtol=1e-5,
+                   adjoint_atol=1e-4, adjoint_options=None, adjoint_params=None, names=None, **kwargs):
+    """torchsde.sdeint_adjoint's call contract (in-tree user: torch-ists .../NSDE/latent_sde.py:134-141).  Gradients come
+    from the adjoint of the DISCRETE scheme: for a Diffusion_model on CUDA the fused HIP adjoint kernels
+    (snsde_solve_backward + snsde_param_gradients: no autograd graph over the steps, memory O(N B H) of saved states
+    rather than ~25 autograd nodes per step), otherwise autograd through the tensor-op loop.  torchsde integrates the
+    continuous adjoint SDE backwards instead; the two agree to the discretisation error of the forward scheme.  The
+    adjoint_* solver options have no counterpart here and are accepted for signature compatibility."""
+    return sdeint(sde, y0, ts, bm=bm, method=method, names=names, **kwargs)
 
 
 def _sdeint_hip(sde, rec, y0, ts, bm, method, dt, options):
@@ -159,6 +200,12 @@ def _sdeint_hip(sde, rec, y0, ts, bm, method, dt, options):
         seed = _capture_seed(dev) if torch.cuda.is_current_stream_capturing() else _fresh_seed()
     elif not torch.is_tensor(seed):
         seed = int(seed)
+    if 'row_offset' not in options:
+        # one process per GPU (DDP): ranks that seed identically must not integrate against identical Brownian paths.
+        # Philox counters use the global row, so shard r of equal-sized shards starts at row r * local_batch.
+        import torch.distributed as dist
+        if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+            options = dict(options, row_offset=dist.get_rank() * int(y0.shape[0]))
     row_out = options.get('row_out')
     if row_out is not None:     # per-row output selection fused into the solve: the result is (B, H)
         row_out = row_out.to(device=dev, dtype=torch.int32).contiguous()
@@ -183,7 +230,14 @@ def _sdeint_hip(sde, rec, y0, ts, bm, method, dt, options):
                             row_offset=int(options.get('row_offset', 0)), kernel=options.get('kernel', 'auto'),
                             save_traj=bool(options.get('save_traj', False)),
                             exact_order=bool(options.get('exact_order', False)), dU=dU, row_out=row_out)
-    ys = call.launch()
+    try:
+        ys = call.launch()
+    except engine._lib.SnsdeError as exc:
+        # a valid request no kernel covers (e.g. Milstein with a diffusion whose dg/dy is not closed-form, noise_option
+        # 7 / 14 / 15 / 18 / 19): same behaviour as the gradient path, the unfused tensor-op loop, unless strict
+        if exc.code != -4 or options.get('strict', False):
+            raise
+        return _sdeint_torch(sde, y0, ts, bm, method, dt, options, None)
     if options.get('save_traj', False):
         sde.last_trajectory = call.traj
     return ys.to(y0.dtype)

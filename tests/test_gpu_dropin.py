@@ -1,0 +1,246 @@
+"""GPU tests of the drop-in boundary itself (run with -m gpu):
+
+* G6 fixture (tests/golden/dropin.npz, written by tools/check_reference_dropin.py from the REFERENCE's own modules running
+  over this package's torchsde / torchcde mirrors): a FOREIGN module — defined here, not stable_neural_sdes_amd's
+  Diffusion_model — with the reference's attribute and parameter names is recognised by the engine, solved by the HIP
+  path, and reproduces the reference wrappers' outputs;
+* NeuralSDE_forecasting end to end on CUDA at the K5 shard size (B=128, H=256, L=50, C=14, Milstein, 50 outputs, loss on the
+  decoder of the last 10 states, backward): forward against the numpy fp64 oracle, gradients against fp64 autograd;
+* gradients of the fused adjoint against finite differences of the numpy fp64 ORACLE (oracle/sde_oracle.py) for the
+  K2 / K4 / K5 model families, so the backward is not only checked against this package's own tensor-op loop;
+* the HIP engine under DistributedDataParallel over NCCL (= RCCL), one process per visible GPU.
+"""
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+import stable_neural_sdes_amd as S
+from oracle import sde_oracle as O
+from tests.helpers import assert_parity, draw_dW, load, make_problem, param_spec
+
+pytestmark = pytest.mark.gpu
+DEV = 'cuda:0'
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+class _ReplayBM:
+    levy_area_approximation = 'space-time'
+
+    def __init__(self, dW, dU=None):
+        self.dW, self.dU, self.n = dW, dU, 0
+
+    def __call__(self, ta, tb, return_U=False):
+        i, self.n = self.n, self.n + 1
+        return (self.dW[i], self.dU[i]) if return_U else self.dW[i]
+
+
+class ForeignField(torch.nn.Module):
+    """A vector field written here from the reference's description (models_sde/neuralsde.py:123-307) for the two options
+    the fixture uses — (4, 17) and (6, 17): same attribute names, same parameter names / shapes, tensor-op f and g."""
+    sde_type, noise_type = 'ito', 'diagonal'
+
+    def __init__(self, input_channels, hidden_channels, num_hidden_layers, input_option):
+        super().__init__()
+        H = hidden_channels
+        self.input_channels, self.hidden_channels, self.hidden_hidden_channels = input_channels, H, H
+        self.num_hidden_layers, self.input_option, self.noise_option = num_hidden_layers, input_option, 17
+        self.theta = torch.nn.Parameter(torch.tensor([[1.0]]))
+        self.initial_network = torch.nn.Linear(input_channels, H)
+        self.linear_in = torch.nn.Linear(H + 2, H)
+        self.emb = torch.nn.Linear(2 * H, H)
+        self.linears = torch.nn.ModuleList(torch.nn.Linear(H, H) for _ in range(num_hidden_layers - 1))
+        self.linear_out = torch.nn.Linear(H, H)
+        self.noise_t = torch.nn.Sequential(torch.nn.Linear(2, H), torch.nn.ReLU(), torch.nn.Linear(H, H))
+
+    def set_X(self, coeffs, times):
+        self.coeffs, self.times = coeffs, times
+        self.X = S.torchcde.CubicSpline(coeffs, times)
+
+    def _tau(self, t, y):
+        t = torch.as_tensor(t, dtype=y.dtype, device=y.device).expand(y.shape[0], 1)
+        return torch.cat([t.sin(), t.cos()], dim=-1)
+
+    def f(self, t, y):
+        z = self.emb(torch.cat([self.linear_in(torch.cat([self._tau(t, y), y], dim=-1)),
+                                self.initial_network(self.X.evaluate(t))], dim=-1)).relu()
+        for lin in self.linears:
+            z = lin(z).relu()
+        z = self.linear_out(z)
+        if self.input_option == 6:
+            z = z * y.tanh()
+        return z.tanh()
+
+    def g(self, t, y):
+        raw = self.noise_t(self._tau(t, y)).relu() * y
+        return (self.theta.sigmoid() * torch.nan_to_num(raw)).tanh()
+
+
+FIX = load('dropin.npz')
+
+
+def _sd(prefix):
+    pre = prefix + '/sd/'
+    return {k[len(pre):]: torch.from_numpy(FIX[k].copy()) for k in FIX.files if k.startswith(pre)}
+
+
+def test_foreign_module_is_recognised_as_a_fast_path_module():
+    f = ForeignField(5, 32, 2, 4)
+    f.set_X(torch.zeros(3, 8, 20), torch.arange(9.0))
+    rec = S.engine.recognise(f)
+    assert rec is not None and rec[0].input_option == 4 and rec[0].noise_option == 17
+
+
+def test_dropin_fixture_classification_wrapper_foreign_field_on_the_hip_path():
+    B, H, C, L, NL, io, no, out_ch = (int(v) for v in FIX['cls/dims'])
+    model = S.NeuralSDE(ForeignField(C, H, NL, io), C, H, out_ch, initial=True)
+    model.load_state_dict(_sd('cls'))                 # the reference wrapper's state_dict, key for key
+    model = model.to(DEV).eval()
+    times = torch.from_numpy(FIX['cls/times']).to(DEV)
+    coeffs = torch.from_numpy(FIX['cls/coeffs']).to(DEV)
+    fi = torch.from_numpy(FIX['cls/final_index']).to(DEV)
+    with torch.no_grad():
+        out = model(times, (coeffs,), fi, bm=_ReplayBM(torch.from_numpy(FIX['cls/dW']).to(DEV)))
+        out_strict = model(times, (coeffs,), fi, bm=_ReplayBM(torch.from_numpy(FIX['cls/dW']).to(DEV)),
+                           options={'backend': 'hip'})      # raises unless the fused HIP solve takes the call
+    np.testing.assert_allclose(out.cpu().numpy(), FIX['cls/out'], rtol=2e-4, atol=2e-5)
+    assert torch.equal(out, out_strict)
+
+
+def test_dropin_fixture_forecasting_wrapper_on_the_hip_path():
+    B, H, C, L, NL, io, no, out_ch, out_time = (int(v) for v in FIX['fc/dims'])
+    model = S.NeuralSDE_forecasting(ForeignField(C, H, NL, io), C, out_time, H, out_ch, initial=True)
+    model.load_state_dict(_sd('fc'))
+    model = model.to(DEV).eval()
+    coeffs = torch.from_numpy(FIX['fc/coeffs']).to(DEV)
+    pieces = tuple(coeffs[..., k * C:(k + 1) * C] for k in range(4))
+    with torch.no_grad():
+        out = model(torch.from_numpy(FIX['fc/times']).to(DEV), pieces, None,
+                    bm=_ReplayBM(torch.from_numpy(FIX['fc/dW']).to(DEV)), options={'backend': 'hip'})
+    np.testing.assert_allclose(out.cpu().numpy(), FIX['fc/out'], rtol=2e-4, atol=2e-5)
+
+
+def test_dropin_fixture_ists_wrapper_default_srk_on_the_hip_path():
+    B, H, C, L, NL, io, no, out_ch = (int(v) for v in FIX['ists/dims'])
+    model = S.IstsNeuralSDE(ForeignField(C, H, NL, io), C, H, out_ch, initial=True)
+    model.load_state_dict(_sd('ists'))
+    model = model.to(DEV).eval()
+    bm = _ReplayBM(torch.from_numpy(FIX['ists/dW']).to(DEV), torch.from_numpy(FIX['ists/dU']).to(DEV))
+    with torch.no_grad():
+        out, z = model(torch.from_numpy(FIX['ists/coeffs']).to(DEV), torch.from_numpy(FIX['ists/times']).to(DEV), bm=bm,
+                       options={'backend': 'hip'})
+    np.testing.assert_allclose(z.cpu().numpy(), FIX['ists/z'], rtol=2e-4, atol=2e-5)
+    np.testing.assert_allclose(out.cpu().numpy(), FIX['ists/out'], rtol=2e-4, atol=2e-5)
+
+
+# ---- K5 shard: NeuralSDE_forecasting end to end ------------------------------------------------------------------
+def test_forecasting_wrapper_k5_shard_forward_vs_oracle_and_gradients_vs_fp64_autograd():
+    B, H, C, L, NL, out_time = 128, 256, 14, 50, 2, 10
+    pr = make_problem(55, 4, 17, NL, B, H, C, L, nan_frac=0.3)
+    times_h = pr['times']
+    dW = draw_dW(55, times_h, 1.0, B, H)
+    torch.manual_seed(3)
+    field = S.Diffusion_model(C, H, H, NL, input_option=4, noise_option=17)
+    field.load_state_dict({k: torch.from_numpy(v.copy()) for k, v in pr['params'].items()})
+    model = S.NeuralSDE_forecasting(field, C, out_time, H, C, initial=True)
+    import copy
+    model64 = copy.deepcopy(model).double().to(DEV).eval()
+    model = model.to(DEV).eval()
+    coeffs = torch.from_numpy(pr['coeffs']).to(DEV)
+    pieces = tuple(coeffs[..., k * C:(k + 1) * C] for k in range(4))
+    times = torch.from_numpy(times_h).to(DEV)
+    target = torch.from_numpy(np.random.default_rng(5).standard_normal((B, out_time, C)).astype(np.float32)).to(DEV)
+
+    pred = model(times, pieces, None, method='milstein', bm=_ReplayBM(torch.from_numpy(dW).to(DEV)),
+                 options={'backend': 'hip', 'save_traj': True})
+    loss = torch.nn.functional.mse_loss(pred, target)
+    loss.backward()
+    # forward: the states the solve produced against the numpy fp64 oracle on the same increments
+    z0 = model.initial_network(field.X.evaluate(times[0])).detach().cpu().numpy()
+    ref64, _ = O.solve_diffusion_model(pr['params'], 4, 17, pr['coeffs'], times_h, z0, times_h, 1.0, dW, method='milstein',
+                                       dtype=np.float64)
+    cpu32, _ = O.solve_diffusion_model(pr['params'], 4, 17, pr['coeffs'], times_h, z0, times_h, 1.0, dW, method='milstein',
+                                       dtype=np.float32)
+    with torch.no_grad():
+        zs = S.sdeint(field, torch.from_numpy(z0).to(DEV), times, dt=1.0, method='milstein',
+                      bm=_ReplayBM(torch.from_numpy(dW).to(DEV)), options={'backend': 'hip'})
+    assert_parity(zs.cpu().numpy(), ref64, cpu32, what='K5 shard forecasting states')
+    # gradients: fp64 autograd through the tensor-op loop of the same wrapper
+    pieces64 = tuple(p.double() for p in pieces)
+    pred64 = model64(times, pieces64, None, method='milstein', bm=_ReplayBM(torch.from_numpy(dW).double().to(DEV)),
+                     options={'backend': 'torch'})
+    torch.nn.functional.mse_loss(pred64, target.double()).backward()
+    np.testing.assert_allclose(pred.detach().cpu().numpy(), pred64.detach().cpu().numpy(), rtol=1e-3, atol=2e-4)
+    ref = dict(model64.named_parameters())
+    for name, p in model.named_parameters():
+        gref = ref[name].grad
+        if gref is None or float(gref.abs().max()) == 0.0:
+            continue
+        scale = float(gref.abs().max())
+        err = float((p.grad.double() - gref).abs().max()) / scale
+        assert err < 3e-3, (name, err, scale)
+
+
+# ---- backward against finite differences of the numpy oracle ----------------------------------------------------------
+FD_CASES = [
+    # io, no, NL, B, H, C, L, method, kernel     (K2 / K4 / K5 model families at sizes the fp64 oracle finishes in seconds)
+    (4, 17, 2, 12, 128, 21, 9, 'euler', 'auto'),
+    (6, 17, 2, 9, 128, 21, 7, 'euler', 'mfma16'),
+    (3, 18, 2, 10, 64, 8, 7, 'euler', 'auto'),
+    (4, 17, 2, 8, 256, 14, 6, 'milstein', 'auto'),
+]
+
+
+@pytest.mark.parametrize('case', FD_CASES)
+def test_fused_backward_vs_finite_differences_of_the_numpy_oracle(case):
+    io, no, NL, B, H, C, L, method, kernel = case
+    pr = make_problem(900 + io + no, io, no, NL, B, H, C, L)
+    ts = pr['times']
+    dW = draw_dW(900, ts, 1.0, B, H)
+    rng = np.random.default_rng(901)
+    wsum = rng.standard_normal((L, B, H))
+    spec = param_spec(io, no, NL, C, H)
+
+    def oracle_loss(params, y0):
+        ys, _ = O.solve_diffusion_model(params, io, no, pr['coeffs'], ts, y0, ts, 1.0, dW, method=method, dtype=np.float64)
+        return float((ys * wsum).sum())
+
+    m = S.Diffusion_model(C, H, H, NL, input_option=io, noise_option=no)
+    m.load_state_dict({k: torch.from_numpy(v.copy()) for k, v in pr['params'].items()})
+    m = m.to(DEV)
+    m.set_X(torch.from_numpy(pr['coeffs']).to(DEV), torch.from_numpy(ts).to(DEV))
+    y0 = torch.from_numpy(pr['y0']).to(DEV).requires_grad_(True)
+    ys = S.sdeint(m, y0, torch.from_numpy(ts).to(DEV), bm=_ReplayBM(torch.from_numpy(dW).to(DEV)), method=method, dt=1.0,
+                  options={'kernel': kernel, 'strict': True})
+    (ys * torch.from_numpy(wsum.astype(np.float32)).to(DEV)).sum().backward()
+    grads = {n: p.grad.detach().cpu().numpy().astype(np.float64) for n, p in m.named_parameters() if p.grad is not None}
+    gy0 = y0.grad.cpu().numpy().astype(np.float64)
+
+    p64 = {k: np.asarray(v, np.float64) for k, v in pr['params'].items()}
+    y64 = pr['y0'].astype(np.float64)
+    for trial in range(3):      # random directions over ALL parameters and y0 (a relu kink on the segment would show as an outlier)
+        vdir = {n: rng.standard_normal(s) / np.sqrt(np.prod(s)) for n, s in spec}
+        vy = rng.standard_normal(y64.shape) / np.sqrt(y64.size)
+        eps = 1e-5
+        up = oracle_loss({k: p64[k] + eps * vdir[k] for k in p64}, y64 + eps * vy)
+        dn = oracle_loss({k: p64[k] - eps * vdir[k] for k in p64}, y64 - eps * vy)
+        fd = (up - dn) / (2 * eps)
+        an = sum(float((grads[k] * vdir[k]).sum()) for k in grads) + float((gy0 * vy).sum())
+        assert abs(an - fd) <= 2e-3 * max(abs(fd), 1.0), (case, trial, an, fd)
+
+
+# ---- DistributedDataParallel over NCCL (= RCCL) ----------------------------------------------------------------------------
+def test_hip_engine_under_ddp_nccl_matches_the_single_process_full_batch_gradient():
+    """One process per visible GPU (world size 1 on a single-GPU box, device_count otherwise): the fused HIP solve inside
+    DistributedDataParallel with the parameter arena and a graph-captured step; every rank checks its sharded
+    trajectories bit-for-bit against the single-process solve and the all-reduced gradient against the full-batch one."""
+    n = max(1, torch.cuda.device_count())
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get('HSA_ENABLE_IPC_MODE_LEGACY', '0'))
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', f'--nproc-per-node={n}', '--master-addr', '127.0.0.1',
+           '--master-port', '29533', os.path.join(ROOT, 'tests', 'ddp_gpu_worker.py')]
+    r = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    assert f'ddp worker ok world={n}' in r.stdout

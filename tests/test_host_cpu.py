@@ -463,3 +463,131 @@ def test_ctypes_structs_follow_the_header_field_order():
     doc = open(os.path.join(ROOT, 'INTEGRATION.md')).read()
     stub = re.findall(r'"(\w+)"', re.search(r'\("params".*?"workspace"\)', doc, re.S).group(0))
     assert stub == [n for n, t in _lib.Solve._fields_ if t is C.c_void_p]
+
+
+# ---- torchsde / controldiffeq mirror: the names the reference's other call sites need -----------------------------------
+def test_torchsde_mirror_exports_the_names_the_reference_imports():
+    """torch-ists .../NSDE/latent_sde.py:31,134-141: `class LatentSDE(torchsde.SDEIto)`, `torchsde.sdeint_adjoint(...,
+    names={'drift': 'f_aug', 'diffusion': 'g_aug'})`; torchsde.BrownianInterval is what user code passes as bm."""
+    T = S.torchsde
+
+    class Lat(T.SDEIto):
+        def __init__(self):
+            super().__init__(noise_type='diagonal')
+            self.lin = torch.nn.Linear(3, 3)
+
+        def f_aug(self, t, y):
+            return self.lin(y).tanh()
+
+        def g_aug(self, t, y):
+            return 0.1 * torch.ones_like(y)
+
+    m = Lat()
+    assert m.sde_type == 'ito' and m.noise_type == 'diagonal' and isinstance(m, torch.nn.Module)
+    assert T.SDEStratonovich('diagonal').sde_type == 'stratonovich'
+    with pytest.raises(ValueError):
+        T.SDEIto('banana')
+    y0 = torch.zeros(4, 3, requires_grad=True)
+    ys = T.sdeint_adjoint(m, y0, torch.tensor([0.0, 0.5, 1.0]), dt=0.25, method='euler',
+                          names={'drift': 'f_aug', 'diffusion': 'g_aug'}, adjoint_method='euler')
+    assert ys.shape == (3, 4, 3)
+    ys.sum().backward()
+    assert m.lin.weight.grad is not None and y0.grad is not None
+    bm = T.BrownianInterval(t0=0.0, t1=1.0, size=(4, 3), entropy=3)
+    assert bm(0.0, 0.25).shape == (4, 3)
+    # the default name mapping keeps a Diffusion_model on whatever path plain sdeint takes (same numbers)
+    pr_ts = torch.tensor([0.0, 1.0, 2.0])
+    d = S.Diffusion_model(2, 8, 8, 2, input_option=4, noise_option=17)
+    d.set_X(torch.zeros(3, 4, 8), torch.arange(5.0))
+    a = T.sdeint(d, torch.ones(3, 8), pr_ts, dt=1.0, method='euler', options={'seed': 1})
+    b = T.sdeint(d, torch.ones(3, 8), pr_ts, dt=1.0, method='euler', options={'seed': 1}, names={'drift': 'f', 'diffusion': 'g'})
+    assert torch.equal(a, b)
+
+
+def test_controldiffeq_mirror_delegates_unknown_names_to_a_vendored_package(tmp_path, monkeypatch):
+    """After install() `import controldiffeq` resolves to the mirror; the reference's CDE baselines built by the same
+    common_sde.make_model call controldiffeq.cdeint (benchmark_classification/models_sde/metamodel.py), which the mirror
+    serves from the vendored package when one is importable."""
+    import sys
+    from stable_neural_sdes_amd import controldiffeq as M
+    pkg = tmp_path / 'controldiffeq'
+    pkg.mkdir()
+    (pkg / '__init__.py').write_text('from .solver import cdeint\nMARK = "vendored"\n')
+    (pkg / 'solver.py').write_text('def cdeint(*a, **k):\n    return "vendored-cdeint"\n')
+    monkeypatch.syspath_prepend(str(tmp_path))
+    monkeypatch.setattr(M, '_VENDORED', None)
+    try:
+        assert M.cdeint() == 'vendored-cdeint' and M.MARK == 'vendored'
+        assert M.natural_cubic_spline_coeffs.__module__.endswith('controldiffeq')      # own names stay the mirror's
+        with pytest.raises(AttributeError):
+            M.does_not_exist
+    finally:
+        sys.modules.pop('_snsde_vendored_controldiffeq', None)
+        sys.modules.pop('_snsde_vendored_controldiffeq.solver', None)
+        M._VENDORED = None
+    monkeypatch.setattr(M, '_VENDORED', False)      # nothing to delegate to: a clear AttributeError
+    with pytest.raises(AttributeError, match='mirror'):
+        M.cdeint
+
+
+def test_dropin_fixture_wrappers_reproduce_the_reference_outputs_on_cpu():
+    """tests/golden/dropin.npz = the reference's own wrapper + Diffusion_model code over this package's mirrors
+    (tools/check_reference_dropin.py).  The mirror's wrappers and Diffusion_model, loaded with the reference's state_dict,
+    reproduce those outputs on the CPU tensor-op path."""
+    from tests.helpers import load
+    F = load('dropin.npz')
+
+    class Replay:
+        levy_area_approximation = 'space-time'
+
+        def __init__(self, dW, dU=None):
+            self.dW, self.dU, self.n = dW, dU, 0
+
+        def __call__(self, ta, tb, return_U=False):
+            i, self.n = self.n, self.n + 1
+            return (self.dW[i], self.dU[i]) if return_U else self.dW[i]
+
+    def sd(prefix):
+        pre = prefix + '/sd/'
+        return {k[len(pre):]: torch.from_numpy(F[k].copy()) for k in F.files if k.startswith(pre)}
+
+    B, H, C, L, NL, io, no, oc = (int(v) for v in F['cls/dims'])
+    m = S.NeuralSDE(S.Diffusion_model(C, H, H, NL, input_option=io, noise_option=no), C, H, oc, initial=True)
+    m.load_state_dict(sd('cls'))
+    m.eval()
+    with torch.no_grad():
+        out = m(torch.from_numpy(F['cls/times']), (torch.from_numpy(F['cls/coeffs']),), torch.from_numpy(F['cls/final_index']),
+                bm=Replay(torch.from_numpy(F['cls/dW'])))
+    np.testing.assert_allclose(out.numpy(), F['cls/out'], rtol=1e-5, atol=1e-6)
+    B, H, C, L, NL, io, no, oc = (int(v) for v in F['ists/dims'])
+    m = S.IstsNeuralSDE(S.Diffusion_model(C, H, H, NL, input_option=io, noise_option=no), C, H, oc, initial=True)
+    m.load_state_dict(sd('ists'))
+    m.eval()
+    with torch.no_grad():
+        out, z = m(torch.from_numpy(F['ists/coeffs']), torch.from_numpy(F['ists/times']),
+                   bm=Replay(torch.from_numpy(F['ists/dW']), torch.from_numpy(F['ists/dU'])))
+    np.testing.assert_allclose(z.numpy(), F['ists/z'], rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(out.numpy(), F['ists/out'], rtol=1e-5, atol=1e-6)
+
+
+def test_bench_self_launch_builds_a_torchrun_command(monkeypatch):
+    """`python bench.py --gpus 4` (no torchrun around it) re-executes under torch.distributed.run with one rank per GPU."""
+    import importlib
+    import subprocess
+    import sys
+    monkeypatch.delenv('WORLD_SIZE', raising=False)
+    bench = importlib.import_module('bench')
+    seen = {}
+
+    def fake_call(cmd, env=None):
+        seen['cmd'], seen['env'] = cmd, env
+        return 0
+    monkeypatch.setattr(subprocess, 'call', fake_call)
+    monkeypatch.setattr(sys, 'argv', ['bench.py', '--gpus', '4', '--steps', '7'])
+    with pytest.raises(SystemExit) as e:
+        bench.main()
+    assert e.value.code == 0
+    cmd = seen['cmd']
+    assert cmd[1:4] == ['-m', 'torch.distributed.run', '--nnodes=1'] and '--nproc-per-node=4' in cmd
+    assert '127.0.0.1' in cmd and cmd[-4:] == ['--gpus', '4', '--steps', '7']
+    assert seen['env']['HSA_ENABLE_IPC_MODE_LEGACY'] == '0' or 'HSA_ENABLE_IPC_MODE_LEGACY' in os.environ
