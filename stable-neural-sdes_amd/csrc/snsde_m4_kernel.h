@@ -145,6 +145,41 @@ __device__ __forceinline__ void lean_read_b(uint32_t a, LeanB<8>& b) {
                  : "=v"(b.v[0]), "=v"(b.v[1]), "=v"(b.v[2]), "=v"(b.v[3]), "=v"(b.v[4]), "=v"(b.v[5]), "=v"(b.v[6]), "=v"(b.v[7])
                  : [a] "v"(a));
 }
+// the same into registers that live across the step loop ("+v": read in place, no copy at the back edge)
+__device__ __forceinline__ void lean_read_b_carried(uint32_t a, LeanB<1>& b) {
+    asm volatile("s_mov_b64 exec, 0xffff\n\tds_read_b128 %0, %[a]\n\ts_mov_b64 exec, -1" : "+v"(b.v[0]) : [a] "v"(a));
+}
+__device__ __forceinline__ void lean_read_b_carried(uint32_t a, LeanB<2>& b) {
+    asm volatile("s_mov_b64 exec, 0xffff\n\tds_read_b128 %0, %[a]\n\tds_read_b128 %1, %[a] offset:64\n\ts_mov_b64 exec, -1"
+                 : "+v"(b.v[0]), "+v"(b.v[1]) : [a] "v"(a));
+}
+__device__ __forceinline__ void lean_read_b_carried(uint32_t a, LeanB<3>& b) {
+    asm volatile("s_mov_b64 exec, 0xffff\n\tds_read_b128 %0, %[a]\n\tds_read_b128 %1, %[a] offset:64\n\tds_read_b128 %2, %[a] offset:128\n\t"
+                 "s_mov_b64 exec, -1" : "+v"(b.v[0]), "+v"(b.v[1]), "+v"(b.v[2]) : [a] "v"(a));
+}
+__device__ __forceinline__ void lean_read_b_carried(uint32_t a, LeanB<4>& b) {
+    asm volatile("s_mov_b64 exec, 0xffff\n\tds_read_b128 %0, %[a]\n\tds_read_b128 %1, %[a] offset:64\n\tds_read_b128 %2, %[a] offset:128\n\t"
+                 "ds_read_b128 %3, %[a] offset:192\n\ts_mov_b64 exec, -1"
+                 : "+v"(b.v[0]), "+v"(b.v[1]), "+v"(b.v[2]), "+v"(b.v[3]) : [a] "v"(a));
+}
+__device__ __forceinline__ void lean_read_b_carried(uint32_t a, LeanB<5>& b) {
+    asm volatile("s_mov_b64 exec, 0xffff\n\tds_read_b128 %0, %[a]\n\tds_read_b128 %1, %[a] offset:64\n\tds_read_b128 %2, %[a] offset:128\n\t"
+                 "ds_read_b128 %3, %[a] offset:192\n\tds_read_b128 %4, %[a] offset:256\n\ts_mov_b64 exec, -1"
+                 : "+v"(b.v[0]), "+v"(b.v[1]), "+v"(b.v[2]), "+v"(b.v[3]), "+v"(b.v[4]) : [a] "v"(a));
+}
+__device__ __forceinline__ void lean_read_b_carried(uint32_t a, LeanB<6>& b) {
+    asm volatile("s_mov_b64 exec, 0xffff\n\tds_read_b128 %0, %[a]\n\tds_read_b128 %1, %[a] offset:64\n\tds_read_b128 %2, %[a] offset:128\n\t"
+                 "ds_read_b128 %3, %[a] offset:192\n\tds_read_b128 %4, %[a] offset:256\n\tds_read_b128 %5, %[a] offset:320\n\t"
+                 "s_mov_b64 exec, -1"
+                 : "+v"(b.v[0]), "+v"(b.v[1]), "+v"(b.v[2]), "+v"(b.v[3]), "+v"(b.v[4]), "+v"(b.v[5]) : [a] "v"(a));
+}
+__device__ __forceinline__ void lean_read_b_carried(uint32_t a, LeanB<8>& b) {
+    asm volatile("s_mov_b64 exec, 0xffff\n\tds_read_b128 %0, %[a]\n\tds_read_b128 %1, %[a] offset:64\n\tds_read_b128 %2, %[a] offset:128\n\t"
+                 "ds_read_b128 %3, %[a] offset:192\n\tds_read_b128 %4, %[a] offset:256\n\tds_read_b128 %5, %[a] offset:320\n\t"
+                 "ds_read_b128 %6, %[a] offset:384\n\tds_read_b128 %7, %[a] offset:448\n\ts_mov_b64 exec, -1"
+                 : "+v"(b.v[0]), "+v"(b.v[1]), "+v"(b.v[2]), "+v"(b.v[3]), "+v"(b.v[4]), "+v"(b.v[5]), "+v"(b.v[6]), "+v"(b.v[7])
+                 : [a] "v"(a));
+}
 #undef SNSDE_RD
 // The fragments are tied through the wait ("+v"): nothing that reads them can be scheduled above it.  Y = LDS operations
 // this wave issued AFTER the reads of `b` and that may stay in flight (LDS returns in order); pairs of k-blocks are
@@ -208,7 +243,7 @@ __global__ void __launch_bounds__(CF::NT, CF::WPS) snsde_m4_kernel(MfmaArgs a) {
     float* xbuf = ybuf + 4 * LDY;            // [2][4][LDX]  X(t) (xc) | sin t, cos t | 0..   (step parity)
     float* bufA = xbuf + 8 * LDX;            // [4][LDA]
     float* bufB = bufA + 4 * LDA;            // [4][LDA]
-    float* rowtab = bufB + 4 * LDA;          // [ROWCH + 3][RS]  step i: (h, sqrt h, n_out, k_first | sin t, cos t, frac, idx of step i+1)
+    float* rowtab = bufB + 4 * LDA;          // [ROWCH + 3][RS]  step i: (h_i, sqrt h_{i+1}, -, - | sin t, cos t, frac of step i+1, idx of step i+2)
     float* zstash_all = rowtab + (CF::ROWCH + 3) * RS;
 
     const int tid = threadIdx.x;
@@ -246,9 +281,9 @@ __global__ void __launch_bounds__(CF::NT, CF::WPS) snsde_m4_kernel(MfmaArgs a) {
     auto fill_rows = [&](int base) {
         for (int i = tid; i < (CF::ROWCH + 3) * RS; i += NT) {
             const int j = i % RS;
-            int rr = base + i / RS + (j == 7 ? 1 : 0);
+            int rr = base + i / RS + (j == 0 ? 0 : (j == 7 ? 2 : 1));
             rr = rr < N - 1 ? rr : N - 1;
-            const int src = j == 0 ? 1 : j == 1 ? 6 : j == 2 ? 8 : j == 3 ? 9 : j == 4 ? 2 : j == 5 ? 3 : j == 6 ? 4 : 5;
+            const int src = j == 0 ? 1 : j == 1 ? 6 : j == 4 ? 2 : j == 5 ? 3 : j == 6 ? 4 : j == 7 ? 5 : 10;
             rowtab[i] = a.step_tab[(size_t)rr * SNSDE_STEP_STRIDE + src];
         }
     };
@@ -374,20 +409,20 @@ __global__ void __launch_bounds__(CF::NT, CF::WPS) snsde_m4_kernel(MfmaArgs a) {
     };
 
     // ---- inputs of step 0; pieces of X(t_1) ---------------------------------------------------------------------------
-    float dw_cur, gt_cur = 0.0f, h_cur;
-    f32x4 qb;                         // (sin, cos, frac) of the step after the current one, idx of the step after that
+    float dw_cur, gt_cur = 0.0f;
+    f32x4 qa, qb;       // the table row of the step about to run: (h_n, sqrt h_{n+1}, -, -), (sin, cos, frac of step n+1, idx of step n+2)
     {
-        const float* st = rowtab;
-        load_coeffs(__float_as_int(a.step_tab[5]));
-        h_cur = 0.0f;
-        vm_wait(h_cur, gt_cur);
-        store_xt(xbuf, st[6], st[4], st[5]);
-        dw_cur = next_dw(0, st[1]);
+        const float* g0 = a.step_tab;                       // row 0 of the host table: t0, h, sin, cos, frac, idx, sqrt h
+        load_coeffs(__float_as_int(g0[5]));
+        float dummy = 0.0f;
+        vm_wait(dummy, gt_cur);
+        store_xt(xbuf, g0[4], g0[2], g0[3]);
+        dw_cur = next_dw(0, g0[6]);
         if (tab) lean_gload(gt_cur, fo4, gt);
-        load_coeffs(__float_as_int(st[7]));
+        load_coeffs(__float_as_int(a.step_tab[(size_t)(N > 1 ? 1 : 0) * SNSDE_STEP_STRIDE + 5]));
         vm_wait(dw_cur, gt_cur);
-        h_cur = st[0];
-        qb = *reinterpret_cast<const f32x4*>(st + RS + 4);
+        qa = *reinterpret_cast<const f32x4*>(rowtab);
+        qb = *reinterpret_cast<const f32x4*>(rowtab + 4);
     }
     __syncthreads();
     if (__builtin_amdgcn_readfirstlane(tid) >= NT / 2 && CF::NW >= 8) __builtin_amdgcn_s_setprio(1);   // younger half
@@ -401,8 +436,8 @@ __global__ void __launch_bounds__(CF::NT, CF::WPS) snsde_m4_kernel(MfmaArgs a) {
     float* const bown = bufB + r * LDA + fo;
     const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
 
-    LeanB<(KUXT > 0 ? KUXT : 1)> bx;      // [X(t_n) | tau_n] operands of the step about to start
-    if constexpr (KUXT > 0) lean_read_b(xrow, bx);
+    LeanB<(KUXT > 0 ? KUXT : 1)> bx{};    // [X(t_n) | tau_n] operands of the step about to start
+    if constexpr (KUXT > 0) lean_read_b_carried(xrow, bx);
     LT_DECL
     // Outer loop over the requested outputs, inner loop over the solver steps up to each of them (out_step[k] = the step
     // after which output k + 1 is due): the step loop itself carries no output bookkeeping.
@@ -422,10 +457,8 @@ __global__ void __launch_bounds__(CF::NT, CF::WPS) snsde_m4_kernel(MfmaArgs a) {
         //      on them; they have landed once the first layer's last s_waitcnt has passed) ------------------------------------
         LeanB<KUH> by;
         if constexpr (YIN) lean_read_b(yrow, by);
-        f32x4 qa, qbn;      // quad A of step n+1: (h, sqrt h, n_out, k_first); quad B of step n+2
-        asm volatile("ds_read_b128 %0, %2\n\tds_read_b128 %1, %2 offset:%3"
-                     : "=v"(qa), "=v"(qbn) : "v"(lean_lds_addr(rowtab + (n + 1 - rbase) * RS)), "n"(RS * 4 + 16));
-        const float h = h_cur;
+        asm volatile("" : "+v"(qa), "+v"(qb));      // (read before the closing barrier of the previous step: landed)
+        const float h = qa[0];
         __builtin_amdgcn_sched_barrier(0);
         // the [X(t_n) | tau_n] part of the first layer: its operands were read before the barrier, so these MFMAs start at
         // once and cover the latency of the y reads
@@ -437,8 +470,7 @@ __global__ void __launch_bounds__(CF::NT, CF::WPS) snsde_m4_kernel(MfmaArgs a) {
         load_coeffs(__float_as_int(qb[3]));
         __builtin_amdgcn_sched_barrier(0);
         LT(1)
-        if constexpr (YIN) lean_gemm<2, KUH>(wy, by, c, d);
-        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(qa), "+v"(qbn));      // the table quads: long landed
+        if constexpr (YIN) lean_gemm<0, KUH>(wy, by, c, d);
         LT(2)
         {
             const float o = fmaxf(m4_reduce_scatter(c + d), 0.0f);
@@ -504,10 +536,11 @@ __global__ void __launch_bounds__(CF::NT, CF::WPS) snsde_m4_kernel(MfmaArgs a) {
             }
         }
         dw_cur = dw_nxt; gt_cur = gt_nxt;
-        h_cur = qa[0];
-        qb = qbn;
-        // next step's [X | tau] operands (written before this step's first barrier)
-        if constexpr (KUXT > 0) lean_read_b(xrow + ((n + 1) & 1) * (4 * LDX * 4), bx);
+        // the next step's table row and [X | tau] operands (written before this step's first barrier), in place; they
+        // land before the closing barrier releases (its s_waitcnt lgkmcnt(0))
+        asm volatile("ds_read_b128 %0, %2\n\tds_read_b128 %1, %2 offset:16"
+                     : "+v"(qa), "+v"(qb) : "v"(lean_lds_addr(rowtab + (n + 1 - rbase) * RS)));
+        if constexpr (KUXT > 0) lean_read_b_carried(xrow + ((n + 1) & 1) * (4 * LDX * 4), bx);
         LT(9)
         __syncthreads();
         LT_COLLECT
