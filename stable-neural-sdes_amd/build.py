@@ -25,6 +25,32 @@ def needs_build():
     return any(os.path.getmtime(s) > t for s in srcs)
 
 
+LEAN_RESOURCES = {}      # kernel name -> (VGPRs, scratch bytes per lane) of the lean 4-row-tile instantiations, last build
+
+
+def check_lean_resources(src, remarks):
+    """The lean kernel (csrc/snsde_m4_kernel.h) issues its LDS / global prefetches from inline asm and waits for them itself:
+    the compiler believes their destination registers are written at the asm statement.  A register spill of one of them
+    would save stale data, so every instantiation must compile WITHOUT scratch (csrc: lean_fits() keeps the register-heavy
+    configurations on the general kernel).  Checked here from hipcc's kernel-resource-usage remarks; a violation fails
+    the build instead of shipping a kernel that is wrong under register pressure."""
+    import re
+    name = None
+    for line in remarks.splitlines():
+        m = re.search(r'remark: Function Name: (\S+)', line)
+        if m:
+            name = m.group(1)
+            continue
+        if name and 'snsde_m4_kernel' in name:
+            m = re.search(r'remark:\s+(VGPRs|ScratchSize \[bytes/lane\]|VGPRs Spill): (\d+)', line)
+            if m:
+                LEAN_RESOURCES.setdefault(name, {})[m.group(1)] = int(m.group(2))
+    bad = {k: v for k, v in LEAN_RESOURCES.items() if v.get('ScratchSize [bytes/lane]', 0) or v.get('VGPRs Spill', 0)}
+    if bad:
+        raise RuntimeError(f'{os.path.basename(src)}: lean kernel instantiations spill registers (tighten lean_fits() in '
+                           f'csrc/snsde_mfma_kernels.h): {bad}')
+
+
 def build(force=False, verbose=False, defines=(), out=None):
     """Compile every csrc/*.hip to an object file (in parallel: the MFMA kernels are split by hidden size) and
     link libsnsde.so."""
@@ -40,12 +66,15 @@ def build(force=False, verbose=False, defines=(), out=None):
 
     def compile_one(src):
         obj = os.path.join(objdir, os.path.basename(src)[:-4] + '.o')
-        cmd = base + ['-c', src, '-o', obj]
+        lean = os.path.basename(src).startswith('snsde_m4_h')
+        cmd = base + (['-Rpass-analysis=kernel-resource-usage'] if lean else []) + ['-c', src, '-o', obj]
         if verbose:
             print(' '.join(cmd))
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError('hipcc failed for ' + src + ':\n' + r.stdout + r.stderr)
+        if lean:
+            check_lean_resources(src, r.stderr)
         return obj
 
     with ThreadPoolExecutor(max_workers=min(8, len(srcs))) as ex:

@@ -1,0 +1,8 @@
+// Lean 4-row-tile forward kernel (snsde_m4_kernel.h) instantiated for hidden size 64.
+#include "snsde_m4_kernel.h"
+
+namespace snsde_mfma {
+
+int dispatch_lean_h64(const MfmaPlan& p, const MfmaArgs& a, hipStream_t st) { return dispatch_lean<64>(p, a, st); }
+
+}  // namespace snsde_mfma

@@ -104,6 +104,10 @@ __device__ __forceinline__ uint64_t lean_uniform(const float* p) {
 __device__ __forceinline__ void lean_gload(float& dst, uint32_t voff, const float* sbase) {
     asm volatile("s_nop 4\n\tglobal_load_dword %0, %1, %2" : "=v"(dst) : "v"(voff), "s"(lean_uniform(sbase)) : "memory");
 }
+// store through a scalar base + 32-bit lane offset as well: the training-mode saves then need no 64-bit address VGPRs
+__device__ __forceinline__ void lean_gstore(float v, uint32_t voff, const float* sbase) {
+    asm volatile("s_nop 4\n\tglobal_store_dword %1, %0, %2" :: "v"(v), "v"(voff), "s"(lean_uniform(sbase)) : "memory");
+}
 __device__ __forceinline__ void lean_gload4(float& d0, float& d1, float& d2, float& d3, uint32_t v0, uint32_t v1, uint32_t v2,
                                             uint32_t v3, const float* sbase) {
     asm volatile("s_nop 4\n\tglobal_load_dword %0, %4, %8\n\tglobal_load_dword %1, %5, %8\n\tglobal_load_dword %2, %6, %8\n\t"
@@ -259,6 +263,7 @@ __global__ void __launch_bounds__(CF::NT, CF::WPS) snsde_m4_kernel(MfmaArgs a) {
     const size_t BH = (size_t)B * H;
     const size_t goff = (size_t)rowc * H + fo;
     float* zstash = zstash_all + wave * CF::ZSTASH;
+    const uint32_t fo4 = (uint32_t)(fo * sizeof(float)), goff4 = (uint32_t)(goff * sizeof(float));
     const int xc = a.lean_xc;                              // control channels in the xt block (0: drift without X)
     const bool time_on = a.lean_time != 0, geo = a.lean_geo != 0;
 
@@ -384,10 +389,9 @@ __global__ void __launch_bounds__(CF::NT, CF::WPS) snsde_m4_kernel(MfmaArgs a) {
             return zstash[k * 64 + lane] * sqh;
         }
         float v;
-        lean_gload(v, (uint32_t)(goff * sizeof(float)), a.dW + (size_t)i * BH);
+        lean_gload(v, goff4, a.dW + (size_t)i * BH);
         return v;
     };
-    const uint32_t fo4 = (uint32_t)(fo * sizeof(float));
 
     // diffusion g(t, y) and  y + g dW (+ the Milstein term)  for the owned element
     auto gpart = [&](float y, float gtv, float dwv, float hh) -> float {
@@ -475,7 +479,7 @@ __global__ void __launch_bounds__(CF::NT, CF::WPS) snsde_m4_kernel(MfmaArgs a) {
         {
             const float o = fmaxf(m4_reduce_scatter(c + d), 0.0f);
             *aown = o;
-            if constexpr (SAVE) { if (a.act_save && row_ok) a.act_save[((size_t)n * CF::NSAVE) * BH + goff] = o; }
+            if constexpr (SAVE) { if (a.act_save && row_ok) lean_gstore(o, goff4, a.act_save + ((size_t)n * CF::NSAVE) * BH); }
         }
         LT(3)
         __syncthreads();
@@ -503,7 +507,7 @@ __global__ void __launch_bounds__(CF::NT, CF::WPS) snsde_m4_kernel(MfmaArgs a) {
             lean_gemm<0, KUH>(wh[l], bh, c, d);
             const float o = fmaxf(m4_reduce_scatter(c + d), 0.0f);
             *(toB ? bown : aown) = o;
-            if constexpr (SAVE) { if (a.act_save && row_ok) a.act_save[((size_t)n * CF::NSAVE + 1 + l) * BH + goff] = o; }
+            if constexpr (SAVE) { if (a.act_save && row_ok) lean_gstore(o, goff4, a.act_save + ((size_t)n * CF::NSAVE + 1 + l) * BH); }
             if (l == NHID - 1) { LT(6) }
             __syncthreads();
             if (l == NHID - 1) { LT(7) }
@@ -522,7 +526,7 @@ __global__ void __launch_bounds__(CF::NT, CF::WPS) snsde_m4_kernel(MfmaArgs a) {
         LT(8)
         vm_wait(dw_nxt, gt_nxt);      // this step's prefetches (issued one to three phases ago)
         float z = m4_reduce_scatter(c + d);
-        if constexpr (SAVE) { if (a.act_save && row_ok) a.act_save[((size_t)n * CF::NSAVE + CF::ZSLOT) * BH + goff] = z; }
+        if constexpr (SAVE) { if (a.act_save && row_ok) lean_gstore(z, goff4, a.act_save + ((size_t)n * CF::NSAVE + CF::ZSLOT) * BH); }
         if (__builtin_expect(geo, 0)) z *= fast_tanh(yv);
         const float f = LEAN_TANH_F(z);
         const float ynew = fmaf(f, h, ypart);
@@ -531,8 +535,8 @@ __global__ void __launch_bounds__(CF::NT, CF::WPS) snsde_m4_kernel(MfmaArgs a) {
         ybuf[r * LDY + fo] = ynew;
         if constexpr (SAVE) {
             if (row_ok) {
-                if (a.traj) a.traj[(size_t)(n + 1) * BH + goff] = ynew;
-                if (a.dW_out) a.dW_out[(size_t)n * BH + goff] = dw_cur;
+                if (a.traj) lean_gstore(ynew, goff4, a.traj + (size_t)(n + 1) * BH);
+                if (a.dW_out) lean_gstore(dw_cur, goff4, a.dW_out + (size_t)n * BH);
             }
         }
         dw_cur = dw_nxt; gt_cur = gt_nxt;
@@ -585,11 +589,12 @@ int dispatch_lean(const MfmaPlan& p, const MfmaArgs& a, hipStream_t st) {
     return SNSDE_ERR_UNSUPPORTED;
 #else
 #define SNSDE_LEAN(NH_, KX_, Y_) \
-    if (p.NHID == NH_ && p.KUXT == KX_ && (p.IO != 0) == (Y_ != 0)) \
-        return save ? launch_lean<CfgL<H, NH_, KX_, Y_, 1>>(a, st) : launch_lean<CfgL<H, NH_, KX_, Y_, 0>>(a, st);
+    if constexpr (lean_fits(H, NH_, KX_, Y_ != 0)) { \
+        if (p.NHID == NH_ && p.KUXT == KX_ && (p.IO != 0) == (Y_ != 0)) \
+            return save ? launch_lean<CfgL<H, NH_, KX_, Y_, 1>>(a, st) : launch_lean<CfgL<H, NH_, KX_, Y_, 0>>(a, st); }
 #define SNSDE_LEANS(KX_, Y_) SNSDE_LEAN(0, KX_, Y_) SNSDE_LEAN(1, KX_, Y_) SNSDE_LEAN(2, KX_, Y_) SNSDE_LEAN(3, KX_, Y_)
-    SNSDE_LEANS(0, 1) SNSDE_LEANS(1, 1) SNSDE_LEANS(2, 1) SNSDE_LEANS(3, 1) SNSDE_LEANS(5, 1) SNSDE_LEANS(6, 1)
-    SNSDE_LEANS(1, 0) SNSDE_LEANS(2, 0) SNSDE_LEANS(3, 0) SNSDE_LEANS(5, 0)
+    SNSDE_LEANS(0, 1) SNSDE_LEANS(1, 1) SNSDE_LEANS(2, 1) SNSDE_LEANS(3, 1) SNSDE_LEANS(6, 1)
+    SNSDE_LEANS(1, 0) SNSDE_LEANS(2, 0) SNSDE_LEANS(3, 0) SNSDE_LEANS(6, 0)
 #undef SNSDE_LEANS
 #undef SNSDE_LEAN
     return SNSDE_ERR_UNSUPPORTED;

@@ -26,8 +26,6 @@
 
 #include "snsde_m4_kernel.h"
 
-#include <cstdlib>
-
 using namespace snsde_mfma;
 
 namespace {
@@ -240,14 +238,13 @@ MfmaPlan make_plan(const snsde_solve* s, const SnsdeNet& net, int flavor_hint) {
     if (srk) p.FL = 1;
     p.FOLD = (emb && (nhid > 1 || p.KUX > 2 || srk || noise_net || !(s->flags & SNSDE_FLAG_EXACT_ORDER))) ? 1 : 0;   // exact order: NL <= 2, C <= 32 only
     // lean M4 kernel (snsde_m4_kernel.h): 4-row tiles, Euler / Milstein, elementwise diffusions, 32 <= H <= 128; the time
-    // features share the control path's k-block.  SNSDE_NO_LEAN=1 in the environment keeps the general kernel (A/B timing).
-    static const bool no_lean = getenv("SNSDE_NO_LEAN") != nullptr;
+    // features share the control path's k-block
     const bool usex = emb || io == 0, timef = io >= 3;
     const int xcn = usex ? m.input_channels : 0;
     int kuxt = (xcn + (timef ? 2 : 0) + 15) / 16;
-    if (kuxt == 4) kuxt = 5;
+    if (kuxt == 4 || kuxt == 5) kuxt = 6;        // instantiated: 0, 1, 2, 3, 6 blocks
     p.KUXT = kuxt;
-    p.LEAN = (!no_lean && p.FL == 1 && !srk && p.NN == 0 && H >= 32 && H <= 128 && (!emb || p.FOLD) && kuxt <= 6) ? 1 : 0;
+    p.LEAN = (p.FL == 1 && !srk && p.NN == 0 && (!emb || p.FOLD) && kuxt <= 6 && lean_fits(H, nhid, kuxt, io != 0)) ? 1 : 0;
     // workspace layout: bias rows | time-only diffusion table | SRK pass table | packed fragments | fold temps.  The first
     // three do not depend on the tile flavour / kernel variant, so the backward finds the table whatever forward ran.
     int n = 0, rows = 0, woff = 0;
@@ -457,11 +454,11 @@ int snsde_mfma_launch(const snsde_solve* s, const SnsdeNet& net, hipStream_t str
         if (p.H == 32) return dispatch_lean_h32(p, a, stream);
         return SNSDE_ERR_UNSUPPORTED;
     }
-    if (p.H == 256) return dispatch_fwd_h256(p, a, stream);
-    if (p.H == 128) return dispatch_fwd_h128(p, a, stream);
-    if (p.H == 64) return dispatch_fwd_h64(p, a, stream);
-    if (p.H == 32) return dispatch_fwd_h32(p, a, stream);
-    if (p.H == 16) return dispatch_fwd_h16(p, a, stream);
+    if (p.H == 256) return p.FL ? dispatch_fwd_m4_h256(p, a, stream) : dispatch_fwd_m16_h256(p, a, stream);
+    if (p.H == 128) return p.FL ? dispatch_fwd_m4_h128(p, a, stream) : dispatch_fwd_m16_h128(p, a, stream);
+    if (p.H == 64) return p.FL ? dispatch_fwd_m4_h64(p, a, stream) : dispatch_fwd_m16_h64(p, a, stream);
+    if (p.H == 32) return p.FL ? dispatch_fwd_m4_h32(p, a, stream) : dispatch_fwd_m16_h32(p, a, stream);
+    if (p.H == 16) return p.FL ? dispatch_fwd_m4_h16(p, a, stream) : dispatch_fwd_m16_h16(p, a, stream);
     return SNSDE_ERR_UNSUPPORTED;
 }
 

@@ -1,16 +1,12 @@
-// MFMA fast-path kernels instantiated for hidden size 32 (forward and adjoint, both tile flavours).
-#include "snsde_m4_kernel.h"
+// MFMA fast-path kernels instantiated for hidden size 32: 16-row tiles (forward) and the adjoint kernels.
+#include "snsde_mfma_kernels.h"
 
 namespace snsde_mfma {
 
-int dispatch_fwd_h32(const MfmaPlan& p, const MfmaArgs& a, hipStream_t st) {
-    return p.FL ? dispatch_io<32, 1>(p, a, st) : dispatch_io<32, 0>(p, a, st);
-}
+int dispatch_fwd_m16_h32(const MfmaPlan& p, const MfmaArgs& a, hipStream_t st) { return dispatch_io<32, 0>(p, a, st); }
 
 int dispatch_rev_h32(const RevPlan& p, const RevArgs& a, hipStream_t st) {
     return p.FL ? dispatch_rev<32, 1>(p, a, st) : dispatch_rev<32, 0>(p, a, st);
 }
-
-int dispatch_lean_h32(const MfmaPlan& p, const MfmaArgs& a, hipStream_t st) { return dispatch_lean<32>(p, a, st); }
 
 }  // namespace snsde_mfma

@@ -245,7 +245,8 @@ template <int H_, int KUX_, int NHID_, int IO_, int FL_, int PHX_, int FOLD_, in
 struct Cfg {
     static constexpr bool SRK = SRK_ != 0;   // SRID2 stepper: three drift passes (pseudo-steps) per solver step
     static constexpr int H = H_, KUX = KUX_, NHID = NHID_, IO = IO_, FL = FL_;
-    static constexpr bool PHX = PHX_ != 0;   // in-kernel Philox increments (else supplied dW)
+    // PHX_ (in-kernel Philox increments vs supplied dW) is decided at run time from a.dW: one instantiation serves both
+    // (the template slot is kept at 1 by every dispatch)
     // one 16-feature tile per wave: H/16 waves per workgroup (8 at H=128 = two waves per SIMD, so one wave's
     // LDS/barrier/VALU latency hides under the other's MFMAs, and the 172 resident weight registers of a wave
     // fit the 256-register budget without AGPR round trips)
@@ -279,8 +280,9 @@ struct Cfg {
     static constexpr int ZSLOT = NHID + 1;                            // slot of the pre-tanh drift
     static constexpr int ZB = (FL && !STREAM && !SRK) ? 4 : 1;                     // Philox calls generated together per element
     static constexpr int ROWCH = 128;                                 // step-table rows staged in LDS per chunk
-    static constexpr int ZSTASH = (PHX && !SRK) ? 4 * ZB * 64 * EPT : 0;  // floats per wave
-    static constexpr int LDS_FLOATS = M * (LDY + LDX + LDC + 3 * LDA) + NLAYER * H + (ROWCH + 1) * SNSDE_STEP_STRIDE + NW * ZSTASH;
+    static constexpr int ZSTASH = !SRK ? 4 * ZB * 64 * EPT : 0;  // floats per wave (Philox normals of 4*ZB steps)
+    static constexpr int LDS_BASE = M * (LDY + LDX + LDC + 3 * LDA) + NLAYER * H + (ROWCH + 1) * SNSDE_STEP_STRIDE;
+    static constexpr int LDS_FLOATS = LDS_BASE + NW * ZSTASH;    // the Philox stash (last region) only when increments are generated
 };
 
 // Optional cycle trace (debug builds with -DSNSDE_TRACE): per-phase s_memtime deltas of every wave of block 0,
@@ -420,6 +422,7 @@ __global__ void __launch_bounds__(CF::NT, CF::WPS) snsde_mfma_kernel(MfmaArgs a)
     const uint32_t grow = (uint32_t)(a.row_offset + row);
     const uint64_t seed = a.seed_dev ? *a.seed_dev : a.seed;
     const int rslot = a.row_out ? a.row_out[rowc] : -1;     // per-row output selection (ys is (B, H))
+    const bool phx = a.dW == nullptr;                       // in-kernel Philox increments (else the supplied ones)
 
     // store one layer output fragment (bias came in through the accumulator init) as 16 B per lane
     int save_step = 0;   // current step, for the optional activation save
@@ -522,7 +525,7 @@ __global__ void __launch_bounds__(CF::NT, CF::WPS) snsde_mfma_kernel(MfmaArgs a)
                 if (stage == 0) {      // increments (I_k, I_k0) and the diffusion table rows of the step's three stage times
 #pragma unroll
                     for (int e = 0; e < EPT; ++e) {
-                        if constexpr (CF::PHX) {
+                        if (phx) {
                             if ((ns & 3) == 0) {
                                 snsde_philox_normal4(seed, grow, (uint32_t)(ns >> 2), (uint32_t)(fcol[0] + e), sk_z[e], 0u);
                                 snsde_philox_normal4(seed, grow, (uint32_t)(ns >> 2), (uint32_t)(fcol[0] + e), sk_x[e], 1u);
@@ -543,7 +546,7 @@ __global__ void __launch_bounds__(CF::NT, CF::WPS) snsde_mfma_kernel(MfmaArgs a)
                         }
                     }
                 }
-            } else if constexpr (CF::PHX) {
+            } else if (phx) {
                 // ZB independent Philox calls (ZB blocks of 4 steps) are generated together (their round chains interleave)
                 // and parked in this wave's private LDS stash [4*ZB steps][64 lanes][EPT]; each step reads back one entry.
                 constexpr int ZB = CF::ZB;
@@ -849,13 +852,13 @@ __global__ void __launch_bounds__(CF::NT, CF::WPS) snsde_mfma_kernel(MfmaArgs a)
 
 template <class CF>
 int launch_cfg(const MfmaArgs& a, hipStream_t stream) {
-    const size_t lds_bytes = (size_t)CF::LDS_FLOATS * sizeof(float);
-    static bool attr_set = false;   // per instantiation
-    if (lds_bytes > 64 * 1024 && !attr_set) {
+    const size_t lds_bytes = (size_t)(a.dW ? CF::LDS_BASE : CF::LDS_FLOATS) * sizeof(float);
+    static size_t attr_bytes = 0;   // per instantiation: the largest dynamic LDS size enabled so far
+    if (lds_bytes > 64 * 1024 && lds_bytes > attr_bytes) {
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(snsde_mfma_kernel<CF>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes) != hipSuccess)
             return SNSDE_ERR_LDS;
-        attr_set = true;
+        attr_bytes = lds_bytes;
     }
     const int grid = (a.B + CF::M - 1) / CF::M;
     hipLaunchKernelGGL(snsde_mfma_kernel<CF>, dim3(grid), dim3(CF::NT), lds_bytes, stream, a);
@@ -1444,17 +1447,37 @@ struct RevPlan {
     MfmaLayerPack layer[MAXL];
 };
 
+// Which 4-row-tile configurations the lean kernel (snsde_m4_kernel.h) takes: its resident weights plus one layer's B
+// operands must fit the 256-register budget of two waves per SIMD WITHOUT spilling (its asm-issued loads land in
+// registers the compiler believes are already written, so a spill of one of them would save stale data).  Measured on the
+// instantiations: no spill while  weight registers + the loop-carried [X | tau] operands  <= 112 (K2: 104 + 8, 253 VGPRs);
+// build.py fails the build if an instantiation spills.  KUXT = 16-wide k-blocks of [X(t) | sin t, cos t].
+__host__ __device__ constexpr bool lean_fits(int H, int NHID, int KUXT, bool YIN) {
+    return (H == 32 || H == 64 || H == 128) && 4 * (KUXT + (YIN ? H / 16 : 0) + (NHID + 1) * (H / 16)) + 4 * KUXT <= 112;
+}
+// largest KUXT a (input_option, KUX) class of the general kernel can meet (KUX = 5: 33..80 control channels)
+__host__ __device__ constexpr int lean_kuxt_max(int IO, int KUX) {
+    const bool usex = (IO == 0 || IO == 2 || IO == 4 || IO == 6), timef = IO >= 3;
+    return KUX == 5 ? 6 : (usex ? (timef ? 3 : 2) : (timef ? 1 : 0));
+}
+
 template <int H, int KUX, int NHID, int IO, int FL, int NN>
 int dispatch_var(const MfmaPlan& p, const MfmaArgs& a, hipStream_t st) {
     constexpr bool emb = (IO == 2 || IO == 4 || IO == 6);
+    // 4-row tiles with an elementwise diffusion at H = 32 / 64 / 128 run on the lean kernel (snsde_m4_kernel.h;
+    // snsde_mfma_launch dispatches them before coming here): not instantiated twice
+    constexpr bool lean_cov = (FL == 1 && NN == 0 && lean_fits(H, NHID, lean_kuxt_max(IO, KUX), IO != 0));
     if constexpr (emb) {
-        if (p.FOLD) return a.dW ? launch_cfg<Cfg<H, KUX, NHID, IO, FL, 0, 1, NN>>(a, st)
-                                : launch_cfg<Cfg<H, KUX, NHID, IO, FL, 1, 1, NN>>(a, st);
+        if (p.FOLD) {
+            if constexpr (lean_cov) return SNSDE_ERR_UNSUPPORTED;
+            else return launch_cfg<Cfg<H, KUX, NHID, IO, FL, 1, 1, NN>>(a, st);
+        }
         if constexpr (NN > 0) return SNSDE_ERR_UNSUPPORTED;   // diffusion nets behind a control embedding: folded layer only
         if constexpr (NHID > 1) return SNSDE_ERR_UNSUPPORTED;   // exact-order variant: diagnostic, NL <= 2 only
     }
-    if constexpr (!emb || (NHID <= 1 && NN == 0))
-        return a.dW ? launch_cfg<Cfg<H, KUX, NHID, IO, FL, 0, 0, NN>>(a, st) : launch_cfg<Cfg<H, KUX, NHID, IO, FL, 1, 0, NN>>(a, st);
+    if constexpr (!emb && lean_cov) return SNSDE_ERR_UNSUPPORTED;
+    else if constexpr (!emb || (NHID <= 1 && NN == 0))
+        return launch_cfg<Cfg<H, KUX, NHID, IO, FL, 1, 0, NN>>(a, st);
     return SNSDE_ERR_UNSUPPORTED;
 }
 
@@ -1470,8 +1493,7 @@ int dispatch_io(const MfmaPlan& p, const MfmaArgs& a, hipStream_t st) {
     if (p.SRK) {           // SRID2 stepper: M4 tiles, folded first layer, C <= 32, elementwise diffusions
         if constexpr (FL == 1) {
 #define SNSDE_SRKC(IO_, NHID_) \
-    if (p.IO == IO_ && p.NHID == NHID_) return a.dW ? launch_cfg<Cfg<H, (IO_ % 2 == 0 ? 2 : 1), NHID_, IO_, 1, 0, 1, 0, 1>>(a, st) \
-                                                    : launch_cfg<Cfg<H, (IO_ % 2 == 0 ? 2 : 1), NHID_, IO_, 1, 1, 1, 0, 1>>(a, st);
+    if (p.IO == IO_ && p.NHID == NHID_) return launch_cfg<Cfg<H, (IO_ % 2 == 0 ? 2 : 1), NHID_, IO_, 1, 1, 1, 0, 1>>(a, st);
 #define SNSDE_SRKS(IO_) SNSDE_SRKC(IO_, 0) SNSDE_SRKC(IO_, 1) SNSDE_SRKC(IO_, 2) SNSDE_SRKC(IO_, 3)
             SNSDE_SRKS(1) SNSDE_SRKS(2) SNSDE_SRKS(3) SNSDE_SRKS(4) SNSDE_SRKS(5) SNSDE_SRKS(6)
 #undef SNSDE_SRKS
@@ -1480,14 +1502,17 @@ int dispatch_io(const MfmaPlan& p, const MfmaArgs& a, hipStream_t st) {
         return SNSDE_ERR_UNSUPPORTED;
     }
 #define SNSDE_WIDE(IO_, NHID_) \
-    if (p.IO == IO_ && p.NHID == NHID_) return a.dW ? launch_cfg<Cfg<H, 5, NHID_, IO_, FL, 0, 1, 0>>(a, st) \
-                                                    : launch_cfg<Cfg<H, 5, NHID_, IO_, FL, 1, 1, 0>>(a, st);
+    if (p.IO == IO_ && p.NHID == NHID_) { \
+        if constexpr (FL == 1 && lean_fits(H, NHID_, 6, IO_ != 0)) return SNSDE_ERR_UNSUPPORTED;   /* lean kernel */ \
+        else return launch_cfg<Cfg<H, 5, NHID_, IO_, FL, 1, 1, 0>>(a, st); }
     if (p.KUX == 5) {      // wide control paths (32 < C <= 80, e.g. the sepsis channels): folded first layer only
+        {
         SNSDE_WIDE(0, 0) SNSDE_WIDE(0, 1) SNSDE_WIDE(0, 2) SNSDE_WIDE(0, 3)
         SNSDE_WIDE(2, 0) SNSDE_WIDE(2, 1) SNSDE_WIDE(2, 2) SNSDE_WIDE(2, 3)
         SNSDE_WIDE(4, 0) SNSDE_WIDE(4, 1) SNSDE_WIDE(4, 2) SNSDE_WIDE(4, 3)
         SNSDE_WIDE(6, 0) SNSDE_WIDE(6, 1) SNSDE_WIDE(6, 2) SNSDE_WIDE(6, 3)
         return SNSDE_ERR_UNSUPPORTED;
+        }
     }
 #undef SNSDE_WIDE
 #define SNSDE_CASE(IO_, NHID_, NN_) \
@@ -1537,16 +1562,21 @@ int dispatch_rev(const RevPlan& p, const RevArgs& a, hipStream_t st) {
 #endif
 }
 
-// per-hidden-size entry points (snsde_mfma_h*.hip)
-int dispatch_fwd_h16(const MfmaPlan& p, const MfmaArgs& a, hipStream_t st);
+// per-hidden-size, per-flavour entry points (snsde_mfma_h*.hip: one translation unit each, compiled in parallel)
+int dispatch_fwd_m16_h16(const MfmaPlan& p, const MfmaArgs& a, hipStream_t st);
+int dispatch_fwd_m4_h16(const MfmaPlan& p, const MfmaArgs& a, hipStream_t st);
 int dispatch_rev_h16(const RevPlan& p, const RevArgs& a, hipStream_t st);
-int dispatch_fwd_h32(const MfmaPlan& p, const MfmaArgs& a, hipStream_t st);
+int dispatch_fwd_m16_h32(const MfmaPlan& p, const MfmaArgs& a, hipStream_t st);
+int dispatch_fwd_m4_h32(const MfmaPlan& p, const MfmaArgs& a, hipStream_t st);
 int dispatch_rev_h32(const RevPlan& p, const RevArgs& a, hipStream_t st);
-int dispatch_fwd_h64(const MfmaPlan& p, const MfmaArgs& a, hipStream_t st);
+int dispatch_fwd_m16_h64(const MfmaPlan& p, const MfmaArgs& a, hipStream_t st);
+int dispatch_fwd_m4_h64(const MfmaPlan& p, const MfmaArgs& a, hipStream_t st);
 int dispatch_rev_h64(const RevPlan& p, const RevArgs& a, hipStream_t st);
-int dispatch_fwd_h128(const MfmaPlan& p, const MfmaArgs& a, hipStream_t st);
+int dispatch_fwd_m16_h128(const MfmaPlan& p, const MfmaArgs& a, hipStream_t st);
+int dispatch_fwd_m4_h128(const MfmaPlan& p, const MfmaArgs& a, hipStream_t st);
 int dispatch_rev_h128(const RevPlan& p, const RevArgs& a, hipStream_t st);
-int dispatch_fwd_h256(const MfmaPlan& p, const MfmaArgs& a, hipStream_t st);
+int dispatch_fwd_m16_h256(const MfmaPlan& p, const MfmaArgs& a, hipStream_t st);
+int dispatch_fwd_m4_h256(const MfmaPlan& p, const MfmaArgs& a, hipStream_t st);
 int dispatch_rev_h256(const RevPlan& p, const RevArgs& a, hipStream_t st);
 
 }  // namespace snsde_mfma
