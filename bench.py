@@ -200,6 +200,32 @@ def strong_k5(dev, rank, world, stream, barrier, maxr, dist):
             "steps": k}
 
 
+def tutorial_field(dev, stream):
+    """Tutorial-style field (reference tutorial/*.ipynb cell 7: LipSwish MLPs, raw time, g(t) * y) through torchsde.sdeint:
+    the fused composed-field path (fields.py) next to the generic graph-captured stepper on the same module; 1024 rows,
+    H=128, 100 Euler steps."""
+    from tests.helpers import make_problem
+    from tests.tutorial_fields import TutorialField
+    rows, hh, cc, n = 1024, 128, 2, 100
+    times = np.linspace(0.0, 1.0, 11).astype(np.float32)
+    pr = make_problem(99, 4, 17, 2, rows, hh, cc, len(times), times=times)
+    torch.manual_seed(99)
+    field = TutorialField('lnsde', cc, hh, 1).to(dev)
+    tt = torch.from_numpy(times).to(dev)
+    field.set_X(torch.from_numpy(pr['coeffs']).to(dev), tt)
+    y0 = torch.from_numpy(pr['y0']).to(dev)
+    ts = tt[[0, -1]]
+    with torch.no_grad():
+        fused = event_times_ms(lambda: S.sdeint(field, y0, ts, dt=1.0 / n, method='euler', options={'seed': 1}), stream, 30, 5)
+        assert S.fields.compose(field).verified.get(str(y0.device)) is True, 'tutorial field did not take the fused path'
+        generic = event_times_ms(lambda: S.sdeint(field, y0, ts, dt=1.0 / n, method='euler',
+                                                  options={'seed': 1, 'backend': 'torch'}), stream, 5, 2)
+    return {"workload": f"tutorial NeuralLNSDEFunc-shaped field (LipSwish, num_layers=1), {rows} rows, H={hh}, C={cc}, {n} Euler "
+                        "steps, whole sdeint() call incl. weight composition + noise table",
+            "fused": spread(fused), "generic_graph_stepper": spread(generic),
+            "value": rows * n / (float(np.median(fused)) * 1e-3), "unit": "row-steps/s"}
+
+
 def self_launch(args):
     """`python bench.py --gpus N` without torchrun: re-execute under torch.distributed.run, one rank per GPU."""
     with socket.socket() as s:
@@ -279,6 +305,8 @@ def main():
     if not args.no_extra:
         extra["K3_strong"] = strong_k3(dev, rank, world, stream, barrier, maxr)
         extra["K5_strong_train"] = strong_k5(dev, rank, world, stream, barrier, maxr, dist)
+        if world == 1:
+            extra["tutorial_field"] = tutorial_field(dev, stream)
 
     if rank == 0:
         rowsteps = B * NSTEP

@@ -68,7 +68,16 @@ enum {
     SNSDE_FLAG_EXACT_ORDER = 2
 };
 
-/* Shape of a Diffusion_model: neuralsde.py:123-179 constructor arguments. */
+/* Variants of the vector field beyond the benchmark Diffusion_model: the tutorial's Neural LSDE / LNSDE / GSDE fields
+ * (tutorial notebooks, cell 7: MLPs with LipSwish activations, raw time feature, un-squashed drift and diffusion) map
+ * onto the same fused step with these four switches (all 0 = the reference Diffusion_model, neuralsde.py:186-307).   */
+enum { SNSDE_ACT_RELU = 0, SNSDE_ACT_LIPSWISH = 1 /* 0.909 silu(x) */, SNSDE_ACT_SILU = 2 };
+enum { SNSDE_DRIFT_TANH = 0 /* f = tanh(z) (z * tanh(y) first for input_option 5/6) */, SNSDE_DRIFT_LINEAR = 1 /* f = z */,
+       SNSDE_DRIFT_TIMES_Y = 2 /* f = z * y */ };
+enum { SNSDE_DIFFUSION_TANH = 0 /* g = tanh(sigmoid(theta) nan_to_num(raw)) */, SNSDE_DIFFUSION_RAW = 1 /* g = raw */ };
+enum { SNSDE_TIME_SINCOS = 0 /* linear_in sees [sin t, cos t, y] */, SNSDE_TIME_RAW = 1 /* [t, 0, y] */ };
+
+/* Shape of a Diffusion_model: neuralsde.py:123-179 constructor arguments (+ the variant switches above). */
 typedef struct snsde_model {
     int32_t input_channels;          /* C  */
     int32_t hidden_channels;         /* H  */
@@ -76,6 +85,10 @@ typedef struct snsde_model {
     int32_t num_hidden_layers;       /* NL >= 1; there are NL-1 `linears` */
     int32_t input_option;            /* 0..6  */
     int32_t noise_option;            /* 0..19 */
+    int32_t activation;              /* SNSDE_ACT_*        (0 for the reference's models) */
+    int32_t drift_output;            /* SNSDE_DRIFT_*      (0 ...)                        */
+    int32_t diffusion_output;        /* SNSDE_DIFFUSION_*  (0 ...)                        */
+    int32_t time_feature;            /* SNSDE_TIME_*       (0 ...)                        */
 } snsde_model;
 
 /* ---- parameter block ------------------------------------------------------------------------
@@ -149,6 +162,9 @@ typedef struct snsde_solve {
     const uint64_t* seed_dev; /* optional device pointer to the Philox key: read when the kernel starts and used  */
                               /* instead of `seed`, so a captured hipGraph draws fresh increments on every replay */
                               /* (the owner updates the value in-stream between replays).                         */
+    const float*   noise_table;/* optional device (N, H): the time-only factor of the diffusion per solver step, supplied by  */
+                              /* the caller instead of being evaluated from noise_t (noise_option 12: raw = table[n],     */
+                              /* 13: raw = table[n] * y).  Used for fields whose time-only diffusion net is not noise_t.   */
     const int32_t* row_out;   /* optional device (B): per-row output selection (the gather of NeuralSDE.forward,  */
                               /* neuralsde.py:115-116).  When set, ys is (B, H) with ys[b] = the solution at      */
                               /* ts[row_out[b]] (0 <= row_out[b] < n_out), and the backward's grad_ys is (B, H).  */

@@ -21,7 +21,8 @@ KERNELS = {'auto': KERNEL_AUTO, 'generic': KERNEL_GENERIC, 'mfma': KERNEL_MFMA, 
 class Model(C.Structure):
     _fields_ = [('input_channels', C.c_int32), ('hidden_channels', C.c_int32),
                 ('hidden_hidden_channels', C.c_int32), ('num_hidden_layers', C.c_int32),
-                ('input_option', C.c_int32), ('noise_option', C.c_int32)]
+                ('input_option', C.c_int32), ('noise_option', C.c_int32), ('activation', C.c_int32),
+                ('drift_output', C.c_int32), ('diffusion_output', C.c_int32), ('time_feature', C.c_int32)]
 
 
 class Solve(C.Structure):
@@ -32,7 +33,7 @@ class Solve(C.Structure):
                 ('params', C.c_void_p), ('coeffs', C.c_void_p), ('step_tab', C.c_void_p),
                 ('out_step', C.c_void_p), ('out_w', C.c_void_p), ('y0', C.c_void_p), ('dW', C.c_void_p),
                 ('ys', C.c_void_p), ('traj', C.c_void_p), ('dW_out', C.c_void_p), ('srk_tab', C.c_void_p), ('dU', C.c_void_p),
-                ('dU_out', C.c_void_p), ('act_save', C.c_void_p), ('stage_save', C.c_void_p), ('seed_dev', C.c_void_p), ('row_out', C.c_void_p),
+                ('dU_out', C.c_void_p), ('act_save', C.c_void_p), ('stage_save', C.c_void_p), ('seed_dev', C.c_void_p), ('noise_table', C.c_void_p), ('row_out', C.c_void_p),
                 ('workspace', C.c_void_p), ('workspace_bytes', C.c_size_t)]
 
 

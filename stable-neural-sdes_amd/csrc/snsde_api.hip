@@ -24,6 +24,10 @@ int validate_model(const snsde_model* m) {
     if (m->num_hidden_layers - 1 > SNSDE_MAX_HIDDEN) return SNSDE_ERR_UNSUPPORTED;
     if (m->input_option < 0 || m->input_option > 6 || m->noise_option < 0 || m->noise_option > 19)
         return SNSDE_ERR_OPTION;
+    if (m->activation < 0 || m->activation > SNSDE_ACT_SILU || m->drift_output < 0 || m->drift_output > SNSDE_DRIFT_TIMES_Y ||
+        m->diffusion_output < 0 || m->diffusion_output > SNSDE_DIFFUSION_RAW || m->time_feature < 0 ||
+        m->time_feature > SNSDE_TIME_RAW)
+        return SNSDE_ERR_OPTION;
     const int io = m->input_option;
     // emb = Linear(2H, H) consumes cat[yy (HH), Xt (H)] and io 0 feeds Xt (H) to the HH-wide MLP:
     // both need HH == H (neuralsde.py:150-158, 206-210)
@@ -294,6 +298,11 @@ int snsde_grid_srk_build(const float* step_tab, int32_t n_steps, const float* ti
     return SNSDE_OK;
 }
 
+// field variants beyond the reference's Diffusion_model (tutorial fields): served by the lean 4-row-tile MFMA kernel only
+static bool is_variant(const snsde_model& m) {
+    return m.activation != 0 || m.drift_output != 0 || m.diffusion_output != 0 || m.time_feature != 0;
+}
+
 static int validate_solve(const snsde_solve* s, bool eval) {
     if (!s) return SNSDE_ERR_NULL;
     int rc = validate_model(&s->model);
@@ -310,6 +319,7 @@ static int validate_solve(const snsde_solve* s, bool eval) {
         // Milstein needs dg_i/dy_i in closed form: g_i may depend on y only through y_i
         if (s->method == SNSDE_MILSTEIN && (no == 7 || no == 14 || no == 15 || no == 18 || no == 19))
             return SNSDE_ERR_UNSUPPORTED;
+        if (s->noise_table && no != 12 && no != 13) return SNSDE_ERR_OPTION;   // a supplied table is the time-only factor
     }
     return SNSDE_OK;
 }
@@ -335,6 +345,11 @@ int snsde_solve_forward(const snsde_solve* s, void* hip_stream) {
     rc = snsde_build_net(s->model, s->n_steps, &net);
     if (rc) return rc;
     hipStream_t st = static_cast<hipStream_t>(hip_stream);
+    if (is_variant(s->model) || s->noise_table) {      // tutorial-style fields: the lean 4-row-tile kernel or nothing
+        if (s->method == SNSDE_SRK || s->kernel == SNSDE_KERNEL_GENERIC || s->kernel == SNSDE_KERNEL_MFMA_M16)
+            return SNSDE_ERR_UNSUPPORTED;
+        return snsde_mfma_launch(s, net, st, 1);
+    }
     if (s->method == SNSDE_SRK) {   // SRK: MFMA variant (M4 tiles) where instantiated, else the generic (all-options) family
         if (s->kernel == SNSDE_KERNEL_MFMA_M16) return SNSDE_ERR_UNSUPPORTED;
         if (s->kernel == SNSDE_KERNEL_MFMA || s->kernel == SNSDE_KERNEL_MFMA_M4) return snsde_mfma_launch(s, net, st, 1);
@@ -360,6 +375,7 @@ int snsde_eval_fg(const snsde_solve* s, const float* step_row, const float* y, f
     int rc = validate_solve(s, true);
     if (rc) return rc;
     if (!step_row || !y || !f_out || !g_out) return SNSDE_ERR_NULL;
+    if (is_variant(s->model) || s->noise_table) return SNSDE_ERR_UNSUPPORTED;
     snsde_solve tmp = *s;
     tmp.n_steps = 1;
     tmp.n_out = 2;
@@ -382,6 +398,7 @@ int snsde_act_slots(const snsde_model* m) {
 
 int snsde_backward_supported(const snsde_solve* s) {
     if (!s || validate_model(&s->model)) return 0;
+    if (is_variant(s->model) || s->noise_table) return 0;      // the adjoint kernels implement the reference's field only
     SnsdeNet net;
     if (snsde_build_net(s->model, s->n_steps, &net)) return 0;
     // 1: MFMA adjoint kernel (forward on the MFMA path with act_save); 2: generic adjoint kernel (forward on the

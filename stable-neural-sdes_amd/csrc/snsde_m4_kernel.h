@@ -27,8 +27,9 @@
 
 namespace snsde_mfma {
 
-template <int H_, int NHID_, int KUXT_, int YIN_, int SAVE_>
+template <int H_, int NHID_, int KUXT_, int YIN_, int SAVE_, int ACT_ = 0>
 struct CfgL {
+    static constexpr bool SWISH = ACT_ != 0;    // hidden activation scale * x * sigmoid(x) (LipSwish / SiLU) instead of relu
     static constexpr int H = H_, NHID = NHID_, KUXT = KUXT_;
     static constexpr bool YIN = YIN_ != 0;      // the first layer reads y (every input_option but 0)
     static constexpr bool SAVE = SAVE_ != 0;    // training / diagnostics outputs: act_save, traj, dW_out
@@ -71,6 +72,12 @@ __device__ __forceinline__ float lean_tanh_rel(float x) {
     p = fmaf(x * x2, p, x);
     const float q = lean_tanh<NANZ>(x);
     return fabsf(x) < 0.125f ? p : q;
+}
+
+// hidden activation of the tutorial fields: scale * x * sigmoid(x)  (LipSwish: scale = 0.909, SiLU: 1)
+__device__ __forceinline__ float lean_swish(float x, float scale) {
+    const float e = __builtin_amdgcn_exp2f(x * -1.4426950408889634f);
+    return (x * scale) * __builtin_amdgcn_rcpf(1.0f + e);
 }
 
 template <int KU>
@@ -266,6 +273,9 @@ __global__ void __launch_bounds__(CF::NT, CF::WPS) snsde_m4_kernel(MfmaArgs a) {
     const uint32_t fo4 = (uint32_t)(fo * sizeof(float)), goff4 = (uint32_t)(goff * sizeof(float));
     const int xc = a.lean_xc;                              // control channels in the xt block (0: drift without X)
     const bool time_on = a.lean_time != 0, geo = a.lean_geo != 0;
+    const float act_scale = a.act == SNSDE_ACT_LIPSWISH ? 0.909f : 1.0f;
+    const int f_out = a.f_out;                             // SNSDE_DRIFT_*: tanh(z) | z | z * y
+    const bool g_raw = a.g_out == SNSDE_DIFFUSION_RAW;     // g = raw instead of tanh(sigmoid(theta) nan_to_num(raw))
 
     // ---- resident weights, bias fragments ---------------------------------------------------------------------
     int li = 0;
@@ -288,7 +298,7 @@ __global__ void __launch_bounds__(CF::NT, CF::WPS) snsde_m4_kernel(MfmaArgs a) {
             const int j = i % RS;
             int rr = base + i / RS + (j == 0 ? 0 : (j == 7 ? 2 : 1));
             rr = rr < N - 1 ? rr : N - 1;
-            const int src = j == 0 ? 1 : j == 1 ? 6 : j == 4 ? 2 : j == 5 ? 3 : j == 6 ? 4 : j == 7 ? 5 : 10;
+            const int src = j == 0 ? 1 : j == 1 ? 6 : j == 4 ? (a.raw_time ? 0 : 2) : j == 5 ? (a.raw_time ? 10 : 3) : j == 6 ? 4 : j == 7 ? 5 : 10;
             rowtab[i] = a.step_tab[(size_t)rr * SNSDE_STEP_STRIDE + src];
         }
     };
@@ -298,7 +308,7 @@ __global__ void __launch_bounds__(CF::NT, CF::WPS) snsde_m4_kernel(MfmaArgs a) {
     const float sig_theta = snsde_sigmoid(a.params[a.off_theta]);
     const int no = a.no;
     const bool tab = a.gt_off >= 0;
-    const float* gt = a.ws + (tab ? a.gt_off : 0);
+    const float* gt = a.gt_ext ? a.gt_ext : a.ws + (tab ? a.gt_off : 0);
     const bool mul_y = (no == 13 || no == 17 || no == 3 || no == 6 || no == 11);
     const bool yfun = (no >= 7 && no <= 10);
     const bool mil = a.method == SNSDE_MILSTEIN;
@@ -404,6 +414,11 @@ __global__ void __launch_bounds__(CF::NT, CF::WPS) snsde_m4_kernel(MfmaArgs a) {
         } else
         {                                 // table noise (no table: gtv = 0 and g = tanh(0) = 0)
             const float raw = mul_y ? gtv * y : gtv;
+            if (__builtin_expect(g_raw, 0)) {     // tutorial fields: g = raw, dg/dy = the table entry (or 0)
+                float yp = fmaf(raw, dwv, y);
+                if (mil && mul_y) yp = fmaf(0.5f * raw * gtv, fmaf(dwv, dwv, -hh), yp);
+                return yp;
+            }
             g = LEAN_TANH_G(sig_theta * raw);
             draw = (mul_y && raw - raw == 0.0f) ? gtv : 0.0f;
         }
@@ -420,7 +435,7 @@ __global__ void __launch_bounds__(CF::NT, CF::WPS) snsde_m4_kernel(MfmaArgs a) {
         load_coeffs(__float_as_int(g0[5]));
         float dummy = 0.0f;
         vm_wait(dummy, gt_cur);
-        store_xt(xbuf, g0[4], g0[2], g0[3]);
+        store_xt(xbuf, g0[4], a.raw_time ? g0[0] : g0[2], a.raw_time ? 0.0f : g0[3]);
         dw_cur = next_dw(0, g0[6]);
         if (tab) lean_gload(gt_cur, fo4, gt);
         load_coeffs(__float_as_int(a.step_tab[(size_t)(N > 1 ? 1 : 0) * SNSDE_STEP_STRIDE + 5]));
@@ -477,7 +492,8 @@ __global__ void __launch_bounds__(CF::NT, CF::WPS) snsde_m4_kernel(MfmaArgs a) {
         if constexpr (YIN) lean_gemm<0, KUH>(wy, by, c, d);
         LT(2)
         {
-            const float o = fmaxf(m4_reduce_scatter(c + d), 0.0f);
+            const float pre = m4_reduce_scatter(c + d);
+            const float o = CF::SWISH ? lean_swish(pre, act_scale) : fmaxf(pre, 0.0f);
             *aown = o;
             if constexpr (SAVE) { if (a.act_save && row_ok) lean_gstore(o, goff4, a.act_save + ((size_t)n * CF::NSAVE) * BH); }
         }
@@ -505,7 +521,8 @@ __global__ void __launch_bounds__(CF::NT, CF::WPS) snsde_m4_kernel(MfmaArgs a) {
             if (l == 0) { LT(5) }
             c = bfr[1 + l]; d = zero4;
             lean_gemm<0, KUH>(wh[l], bh, c, d);
-            const float o = fmaxf(m4_reduce_scatter(c + d), 0.0f);
+            const float pre = m4_reduce_scatter(c + d);
+            const float o = CF::SWISH ? lean_swish(pre, act_scale) : fmaxf(pre, 0.0f);
             *(toB ? bown : aown) = o;
             if constexpr (SAVE) { if (a.act_save && row_ok) lean_gstore(o, goff4, a.act_save + ((size_t)n * CF::NSAVE + 1 + l) * BH); }
             if (l == NHID - 1) { LT(6) }
@@ -528,7 +545,9 @@ __global__ void __launch_bounds__(CF::NT, CF::WPS) snsde_m4_kernel(MfmaArgs a) {
         float z = m4_reduce_scatter(c + d);
         if constexpr (SAVE) { if (a.act_save && row_ok) lean_gstore(z, goff4, a.act_save + ((size_t)n * CF::NSAVE + CF::ZSLOT) * BH); }
         if (__builtin_expect(geo, 0)) z *= fast_tanh(yv);
-        const float f = LEAN_TANH_F(z);
+        float f;
+        if (__builtin_expect(f_out != SNSDE_DRIFT_TANH, 0)) f = f_out == SNSDE_DRIFT_TIMES_Y ? z * yv : z;
+        else f = LEAN_TANH_F(z);
         const float ynew = fmaf(f, h, ypart);
         yold = yv;
         yv = ynew;
@@ -582,6 +601,19 @@ int launch_lean(const MfmaArgs& a, hipStream_t stream) {
 template <int H>
 int dispatch_lean(const MfmaPlan& p, const MfmaArgs& a, hipStream_t st) {
     const bool save = a.act_save || a.traj || a.dW_out;
+    if (a.act != SNSDE_ACT_RELU) {      // tutorial fields (LipSwish / SiLU): y-dependent drift on [y | X, t], C + 1 <= 48
+#define SNSDE_LEAN_ACT(NH_, KX_) \
+    if constexpr (lean_fits(H, NH_, KX_, true)) { \
+        if (p.NHID == NH_ && p.KUXT == KX_ && p.IO != 0) \
+            return save ? launch_lean<CfgL<H, NH_, KX_, 1, 1, 1>>(a, st) : launch_lean<CfgL<H, NH_, KX_, 1, 0, 1>>(a, st); }
+#ifndef SNSDE_DEV_SUBSET
+        SNSDE_LEAN_ACT(0, 1) SNSDE_LEAN_ACT(1, 1) SNSDE_LEAN_ACT(2, 1) SNSDE_LEAN_ACT(3, 1)
+        SNSDE_LEAN_ACT(0, 2) SNSDE_LEAN_ACT(1, 2) SNSDE_LEAN_ACT(2, 2) SNSDE_LEAN_ACT(3, 2)
+        SNSDE_LEAN_ACT(0, 3) SNSDE_LEAN_ACT(1, 3) SNSDE_LEAN_ACT(2, 3) SNSDE_LEAN_ACT(3, 3)
+#endif
+#undef SNSDE_LEAN_ACT
+        return SNSDE_ERR_UNSUPPORTED;
+    }
 #ifdef SNSDE_DEV_SUBSET
     if (p.NHID == 1 && p.KUXT == 2 && p.IO != 0)
         return save ? launch_lean<CfgL<H, 1, 2, 1, 1>>(a, st) : launch_lean<CfgL<H, 1, 2, 1, 0>>(a, st);

@@ -245,6 +245,11 @@ MfmaPlan make_plan(const snsde_solve* s, const SnsdeNet& net, int flavor_hint) {
     if (kuxt == 4 || kuxt == 5) kuxt = 6;        // instantiated: 0, 1, 2, 3, 6 blocks
     p.KUXT = kuxt;
     p.LEAN = (p.FL == 1 && !srk && p.NN == 0 && (!emb || p.FOLD) && kuxt <= 6 && lean_fits(H, nhid, kuxt, io != 0)) ? 1 : 0;
+    const bool variant = m.activation != 0 || m.drift_output != 0 || m.diffusion_output != 0 || m.time_feature != 0 ||
+                         s->noise_table != nullptr;
+    if (variant && !(p.LEAN && (s->noise_table == nullptr || no == 12 || no == 13) && (no == 0 || tab_noise) && kuxt <= 3 &&
+                     io != 0 && io != 5 && io != 6))
+        return p;      // tutorial-style fields: lean kernel instantiations with an activation switch only
     // workspace layout: bias rows | time-only diffusion table | SRK pass table | packed fragments | fold temps.  The first
     // three do not depend on the tile flavour / kernel variant, so the backward finds the table whatever forward ran.
     int n = 0, rows = 0, woff = 0;
@@ -411,7 +416,7 @@ int snsde_mfma_launch(const snsde_solve* s, const SnsdeNet& net, hipStream_t str
                 }
                 fj.b_in = p.fold_b_in; fj.b_init = p.fold_b_init; fj.b_emb = p.fold_b_emb; fj.bias_tmp = p.fold_bias_tmp;
             }
-            fj.tab_on = p.gt_off >= 0 && !p.SRK; fj.tab_off = p.gt_off; fj.n_steps = s->n_steps; fj.no = s->model.noise_option;
+            fj.tab_on = p.gt_off >= 0 && !p.SRK && !s->noise_table; fj.tab_off = p.gt_off; fj.n_steps = s->n_steps; fj.no = s->model.noise_option;
             fj.nt0 = net.nt0; fj.nt1 = net.nt1; fj.step_tab = s->step_tab;
             fj.off_sigma = net.off_sigma; fj.off_sigma_diag = net.off_sigma_diag;
             int gx = fj.tab_on && s->n_steps > p.H ? s->n_steps : p.H;
@@ -449,6 +454,8 @@ int snsde_mfma_launch(const snsde_solve* s, const SnsdeNet& net, hipStream_t str
         a.lean_xc = (io == 0 || io == 2 || io == 4 || io == 6) ? s->model.input_channels : 0;
         a.lean_time = io >= 3 ? 1 : 0;
         a.lean_geo = (io == 5 || io == 6) ? 1 : 0;
+        a.act = s->model.activation; a.f_out = s->model.drift_output; a.g_out = s->model.diffusion_output;
+        a.raw_time = s->model.time_feature; a.gt_ext = s->noise_table;
         if (p.H == 128) return dispatch_lean_h128(p, a, stream);
         if (p.H == 64) return dispatch_lean_h64(p, a, stream);
         if (p.H == 32) return dispatch_lean_h32(p, a, stream);

@@ -92,6 +92,8 @@ struct MfmaArgs {
     int32_t off_theta, gt_off, bias_off;
     int32_t w_off[MAXL];
     int32_t lean_xc, lean_time, lean_geo;   // lean M4 kernel: control channels in the xt block, time features on, z *= tanh(y)
+    int32_t act, f_out, g_out, raw_time;    // field variants (include/snsde.h: SNSDE_ACT_*, SNSDE_DRIFT_*, SNSDE_DIFFUSION_*, SNSDE_TIME_*)
+    const float* gt_ext;                    // caller-supplied time-only diffusion table (N, H) or null
 };
 
 __host__ __device__ constexpr int ld_for(int K, int pad) { return ((K - pad + 63) / 64) * 64 + pad; }
@@ -1453,7 +1455,7 @@ struct RevPlan {
 // instantiations: no spill while  weight registers + the loop-carried [X | tau] operands  <= 112 (K2: 104 + 8, 253 VGPRs);
 // build.py fails the build if an instantiation spills.  KUXT = 16-wide k-blocks of [X(t) | sin t, cos t].
 __host__ __device__ constexpr bool lean_fits(int H, int NHID, int KUXT, bool YIN) {
-    return (H == 32 || H == 64 || H == 128) && 4 * (KUXT + (YIN ? H / 16 : 0) + (NHID + 1) * (H / 16)) + 4 * KUXT <= 112;
+    return (H == 32 || H == 64 || H == 128) && 4 * (KUXT + (YIN ? H / 16 : 0) + (NHID + 1) * (H / 16)) + 4 * KUXT <= (YIN ? 112 : 104);
 }
 // largest KUXT a (input_option, KUX) class of the general kernel can meet (KUX = 5: 33..80 control channels)
 __host__ __device__ constexpr int lean_kuxt_max(int IO, int KUX) {

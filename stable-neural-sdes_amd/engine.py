@@ -17,9 +17,11 @@ _GRID_CACHE_MAX = 16
 
 
 def model_struct(input_channels, hidden_channels, hidden_hidden_channels, num_hidden_layers, input_option,
-                 noise_option):
+                 noise_option, activation=0, drift_output=0, diffusion_output=0, time_feature=0):
+    """snsde_model; the four trailing switches (include/snsde.h SNSDE_ACT_* ...) are 0 for the reference's models."""
     return _lib.Model(int(input_channels), int(hidden_channels), int(hidden_hidden_channels),
-                      int(num_hidden_layers), int(input_option), int(noise_option))
+                      int(num_hidden_layers), int(input_option), int(noise_option), int(activation),
+                      int(drift_output), int(diffusion_output), int(time_feature))
 
 
 def recognise(sde):
@@ -122,6 +124,7 @@ class StepGrid:
         self.device = device
         if device is not None and device.type == 'cuda':
             self.d_step_tab = torch.from_numpy(self.step_tab).to(device)
+            self.d_t0 = torch.from_numpy(self.t0).to(device)
             self.d_out_step = torch.from_numpy(self.out_step).to(device)
             self.d_out_w = torch.from_numpy(self.out_w).to(device)
 
@@ -167,7 +170,8 @@ class SolveCall:
     launch itself is one C call that only enqueues kernels (hipGraph-capturable)."""
 
     def __init__(self, model, flat_params, coeffs, grid, y0, dW=None, method='euler', seed=0, row_offset=0,
-                 kernel='auto', save_traj=False, save_dW=False, exact_order=False, save_act=False, dU=None, row_out=None):
+                 kernel='auto', save_traj=False, save_dW=False, exact_order=False, save_act=False, dU=None, row_out=None,
+                 noise_table=None):
         B, H = y0.shape
         C_ = model.input_channels
         L = coeffs.shape[1] + 1
@@ -183,7 +187,9 @@ class SolveCall:
         if row_out is not None:
             if row_out.dtype != torch.int32 or not row_out.is_cuda or not row_out.is_contiguous() or tuple(row_out.shape) != (B,):
                 raise ValueError('row_out must be a contiguous int32 CUDA tensor of shape (batch,)')
-        self.keep = (flat_params, coeffs, y0, dW, grid, dU, row_out)
+        if noise_table is not None:
+            _check_f32('noise_table', noise_table, (grid.N, H))
+        self.keep = (flat_params, coeffs, y0, dW, grid, dU, row_out, noise_table)
         # per-row output selection: one state per row instead of one plane per output time
         self.ys = torch.empty((B, H) if row_out is not None else (grid.T, B, H), device=dev, dtype=torch.float32)
         self.traj = torch.empty((grid.N + 1, B, H), device=dev, dtype=torch.float32) if save_traj else None
@@ -223,6 +229,7 @@ class SolveCall:
         s.act_save = _ptr(self.act_save)
         s.stage_save = _ptr(self.stage_save)
         s.row_out = _ptr(row_out)
+        s.noise_table = _ptr(noise_table)
         nbytes = _lib.lib().snsde_workspace_bytes(C.byref(s))
         self.workspace = torch.empty(max(nbytes, 256), device=dev, dtype=torch.uint8)
         s.workspace = _ptr(self.workspace)
@@ -251,7 +258,8 @@ _MODE_CACHE = {}
 def backward_mode(model, batch, knots, grid, method, kernel='auto', exact_order=False):
     """backward_supported for a solve that has not been allocated yet (memoised per configuration)."""
     key = (model.input_channels, model.hidden_channels, model.hidden_hidden_channels, model.num_hidden_layers,
-           model.input_option, model.noise_option, batch, knots, grid.N, grid.T, method, kernel, exact_order)
+           model.input_option, model.noise_option, model.activation, model.drift_output, model.diffusion_output,
+           model.time_feature, batch, knots, grid.N, grid.T, method, kernel, exact_order)
     hit = _MODE_CACHE.get(key)
     if hit is None:
         s = _lib.Solve()

@@ -1,0 +1,247 @@
+"""Fused path for the tutorial-style vector fields (reference tutorial/*.ipynb, cell 7: NeuralLSDEFunc / NeuralLNSDEFunc /
+NeuralGSDEFunc).  They are not Diffusion_models (different parameter names, `nn.Sequential(Linear, act, ...)` MLPs with
+LipSwish, raw time, no tanh squashing) but their drift is the same chain of affine maps and pointwise activations, and
+their diffusion is a function of time alone times 1 or y:
+
+    f(t, y) = linear_out(f_net(emb([linear_in([t, y]) | y,  linear_X(X(t))])))   [* y for the GSDE field]
+    g(t, y) = g_net(noise_in(feature(t)))                                       [* y for the LNSDE / GSDE fields]
+
+`compose()` maps such a module onto the C ABI's Diffusion_model-shaped parameter block by composing adjacent affine maps
+(emb' = f_net[0] o emb, linear_out' = linear_out o f_net[-1], linear_in' = [w_t, 0, W_y] or the identity) and sets the
+variant switches of `snsde_model` (include/snsde.h: SNSDE_ACT_* / SNSDE_DRIFT_* / SNSDE_DIFFUSION_RAW / SNSDE_TIME_RAW);
+the time-only diffusion factor is evaluated ONCE per solve for every step time through the module's own g (one batched
+call over N times instead of N calls) and handed to the kernel as `snsde_solve.noise_table`.  The first solve of a module
+checks the mapping against the module's own f / g through the kernel (a one-step probe); a module that fails the
+structural match or the probe is simply not recognised and takes the generic graph-captured stepper
+(torchsde._graphed_steps).
+"""
+import numpy as np
+import torch
+
+from . import _lib, engine
+
+ACT_RELU, ACT_LIPSWISH, ACT_SILU = 0, 1, 2
+DRIFT_TANH, DRIFT_LINEAR, DRIFT_TIMES_Y = 0, 1, 2
+DIFFUSION_TANH, DIFFUSION_RAW = 0, 1
+TIME_SINCOS, TIME_RAW = 0, 1
+
+_PROBE = torch.tensor([-3.0, -1.0, -0.25, 0.0, 0.5, 1.0, 2.5])
+
+
+def _classify_activation(mod):
+    """SNSDE_ACT_* of a pointwise activation module, by its values on a probe vector (so a user-defined LipSwish class
+    is matched by what it computes, not by its name); None when it is none of the three the kernel implements."""
+    try:
+        with torch.no_grad():
+            v = mod(_PROBE.clone())
+    except Exception:
+        return None
+    if not torch.is_tensor(v) or v.shape != _PROBE.shape:
+        return None
+    silu = torch.nn.functional.silu(_PROBE)
+    for kind, ref in ((ACT_RELU, _PROBE.clamp_min(0)), (ACT_SILU, silu), (ACT_LIPSWISH, 0.909 * silu)):
+        if torch.allclose(v, ref, rtol=1e-6, atol=1e-7):
+            return kind
+    return None
+
+
+def _mlp_chain(net):
+    """[Linear, ..., Linear] and the activation kind of an MLP written as nn.Sequential(Linear, act, ..., Linear)
+    (directly, or held in an attribute `_model` as the tutorial's MLP class does); None when `net` is anything else."""
+    seq = getattr(net, '_model', net)
+    if not isinstance(seq, torch.nn.Sequential):
+        return None
+    mods = list(seq)
+    if len(mods) < 3 or len(mods) % 2 == 0:
+        return None
+    linears, kinds = [], set()
+    for i, m in enumerate(mods):
+        if i % 2 == 0:
+            if not isinstance(m, torch.nn.Linear) or m.bias is None:
+                return None
+            linears.append(m)
+        else:
+            kinds.add(_classify_activation(m))
+    if len(kinds) != 1 or None in kinds:
+        return None
+    return linears, kinds.pop()
+
+
+def _is_linear(m, n_in, n_out):
+    return isinstance(m, torch.nn.Linear) and m.bias is not None and m.in_features == n_in and m.out_features == n_out
+
+
+class ComposedField:
+    """A tutorial-style field mapped onto the fused step: `model` (snsde_model with the variant switches), `flat(dev)`
+    (the composed parameter block, rebuilt from the module's current weights on every solve) and `noise_table(grid)`."""
+
+    def __init__(self, sde, model, layout, numel, parts, additive):
+        self.sde, self.model, self.layout, self.numel = sde, model, layout, numel
+        self.parts, self.additive = parts, additive
+        self.verified = {}        # device -> bool (one-step probe through the kernel)
+
+    @torch.no_grad()
+    def flat(self, dev):
+        p = self.parts
+        H = self.model.hidden_channels
+        f64 = dict(device=dev, dtype=torch.float64)
+        W = lambda lin: lin.weight.detach().to(**f64)
+        b = lambda lin: lin.bias.detach().to(**f64)
+        first, last = p['mlp'][0], p['mlp'][-1]
+        vals = {
+            'initial_network.weight': W(p['linear_X']), 'initial_network.bias': b(p['linear_X']),
+            'emb.weight': W(first) @ W(p['emb']), 'emb.bias': W(first) @ b(p['emb']) + b(first),
+            'linear_out.weight': W(p['linear_out']) @ W(last), 'linear_out.bias': W(p['linear_out']) @ b(last) + b(p['linear_out']),
+            'theta': torch.zeros(1, 1, **f64),
+            'noise_t.weight': torch.zeros(H, 2, **f64), 'noise_t.bias': torch.zeros(H, **f64),
+        }
+        if p['linear_in'] is None:      # LSDE field: emb sees y itself
+            vals['linear_in.weight'] = torch.eye(H, **f64)
+            vals['linear_in.bias'] = torch.zeros(H, **f64)
+        else:                           # [t, y] -> the C ABI's [time feature 0, time feature 1, y] columns
+            w = W(p['linear_in'])
+            vals['linear_in.weight'] = torch.cat([w[:, :1], torch.zeros(H, 1, **f64), w[:, 1:]], dim=1)
+            vals['linear_in.bias'] = b(p['linear_in'])
+        for i, lin in enumerate(p['mlp'][1:-1]):
+            vals[f'linears.{i}.weight'] = W(lin)
+            vals[f'linears.{i}.bias'] = b(lin)
+        out = torch.empty(self.numel, device=dev, dtype=torch.float32)
+        for name, off, shape in self.layout:
+            v = vals[name]
+            assert tuple(v.shape) == tuple(shape), (name, tuple(v.shape), shape)
+            out[off:off + v.numel()] = v.reshape(-1).to(torch.float32)
+        return out
+
+    @torch.no_grad()
+    def noise_table(self, t0s, dev):
+        """(N, H) float32: the time-only diffusion factor at every step time, through the module's own g."""
+        N, H = t0s.shape[0], self.model.hidden_channels
+        ones = torch.ones(N, H, device=dev, dtype=torch.float32)
+        tab = self.sde.g(t0s.to(device=dev, dtype=torch.float32).reshape(N, 1), ones)
+        if tuple(tab.shape) != (N, H):
+            raise ValueError('g(t, y) over a column of times did not return (N, H)')
+        return tab.to(torch.float32).contiguous()
+
+
+def compose(sde):
+    """ComposedField of a tutorial-style module, or None.  Cached on the module (its structure is fixed after
+    construction; the composed weights are rebuilt per solve)."""
+    cached = getattr(sde, '_snsde_composed', None)
+    if cached is not None:
+        return cached[0]
+    result = _compose(sde)
+    try:
+        object.__setattr__(sde, '_snsde_composed', (result,))
+    except Exception:
+        pass
+    return result
+
+
+def _compose(sde):
+    if not isinstance(sde, torch.nn.Module):
+        return None
+    if getattr(sde, 'sde_type', None) != 'ito' or getattr(sde, 'noise_type', None) != 'diagonal':
+        return None
+    need = ('linear_X', 'emb', 'f_net', 'linear_out', 'noise_in', 'g_net', 'f', 'g')
+    if not all(hasattr(sde, a) for a in need) or hasattr(sde, 'input_option'):
+        return None
+    lin_X, emb, lin_out = sde.linear_X, sde.emb, sde.linear_out
+    if not isinstance(lin_X, torch.nn.Linear) or lin_X.bias is None:
+        return None
+    C_, H = lin_X.in_features, lin_X.out_features
+    chain = _mlp_chain(sde.f_net)
+    if chain is None or not _is_linear(emb, 2 * H, H) or not _is_linear(lin_out, H, H):
+        return None
+    mlp, act = chain
+    HH = mlp[0].out_features
+    # the C ABI's block has emb (H, 2H) feeding HH-wide hidden layers: the reference's own constraint H == HH
+    if HH != H or mlp[0].in_features != H or mlp[-1].out_features != H or mlp[-1].in_features != HH:
+        return None
+    if any(m.in_features != HH or m.out_features != HH for m in mlp[1:-1]):
+        return None
+    lin_in = getattr(sde, 'linear_in', None)
+    if lin_in is not None and not _is_linear(lin_in, H + 1, H):
+        return None
+    io = 2 if lin_in is None else 4
+    # diffusion: additive or multiplicative in y, decided by what g computes
+    try:
+        with torch.no_grad():
+            p0 = next(sde.parameters())
+            t = torch.tensor(0.37, device=p0.device, dtype=p0.dtype)
+            gen = torch.Generator().manual_seed(7)
+            y1 = (torch.rand(3, H, generator=gen) + 0.5).to(device=p0.device, dtype=p0.dtype)
+            y2 = (torch.rand(3, H, generator=gen) + 0.5).to(device=p0.device, dtype=p0.dtype)
+            g1, g2 = sde.g(t, y1), sde.g(t, y2)
+    except Exception:
+        return None
+    if tuple(g1.shape) != (3, H):
+        return None
+    if torch.allclose(g1, g2, rtol=1e-5, atol=1e-7):
+        additive = True
+    elif torch.allclose(g1 / y1, g2 / y2, rtol=1e-4, atol=1e-6):
+        additive = False
+    else:
+        return None
+    model = engine.model_struct(C_, H, HH, len(mlp) - 1, io, 12 if additive else 13, activation=act,
+                                drift_output=DRIFT_LINEAR, diffusion_output=DIFFUSION_RAW,
+                                time_feature=TIME_RAW if io == 4 else TIME_SINCOS)
+    try:
+        layout, numel = _lib.param_layout(model)
+    except _lib.SnsdeError:
+        return None
+    parts = dict(linear_X=lin_X, emb=emb, linear_out=lin_out, linear_in=lin_in, mlp=mlp)
+    field = ComposedField(sde, model, layout, numel, parts, additive)
+    # f = z or z * y: decided by the probe in verify() (two candidates, the kernel's result must match one)
+    return field
+
+
+@torch.no_grad()
+def verify(field, coeffs, times_host, dev):
+    """One-step probe THROUGH THE KERNEL against the module's own f / g on the first rows of the batch: fixes
+    drift_output (z or z * y) and confirms the whole mapping.  Memoised per device."""
+    hit = field.verified.get(str(dev))
+    if hit is not None:
+        return hit
+    sde, H = field.sde, field.model.hidden_channels
+    rows = min(int(coeffs.shape[0]), 8)
+    c = coeffs[:rows].contiguous()
+    t_lo, t_hi = float(times_host[0]), float(times_host[-1])
+    t = np.float32(t_lo + 0.31 * (t_hi - t_lo))
+    h = np.float32(max(0.05 * (t_hi - t_lo), 1e-3))
+    ts = np.array([t, t + h], dtype=np.float32)
+    grid = engine.StepGrid(ts, float(2 * h), times_host, dev)
+    if grid.N != 1:
+        return False
+    hh = float(grid.t1[0] - grid.t0[0])
+    gen = torch.Generator().manual_seed(11)
+    y0 = (torch.rand(rows, H, generator=gen) + 0.5).to(dev)
+    saved = (sde.coeffs, sde.times)
+    ok = False
+    try:
+        sde.set_X(c, sde.times) if hasattr(sde, 'set_X') else None
+        tt = torch.tensor(float(grid.t0[0]), device=dev)
+        f_ref, g_ref = sde.f(tt, y0).float(), sde.g(tt, y0).float()
+        tab = field.noise_table(torch.from_numpy(grid.t0), dev)
+        flat = field.flat(dev)
+        scale_f = float(f_ref.abs().max()) + 1e-6
+        scale_g = float(g_ref.abs().max()) + 1e-6
+        for drift in (DRIFT_LINEAR, DRIFT_TIMES_Y):
+            field.model.drift_output = drift
+            outs = []
+            for w in (0.0, 1.0):
+                dW = torch.full((1, rows, H), w, device=dev)
+                call = engine.SolveCall(field.model, flat, c, grid, y0, dW=dW, method='euler', noise_table=tab)
+                outs.append(call.launch()[1].clone())
+            f_k = (outs[0] - y0) / hh
+            g_k = outs[1] - outs[0]
+            if float((f_k - f_ref).abs().max()) <= 2e-4 * scale_f + 2e-5 / hh \
+                    and float((g_k - g_ref).abs().max()) <= 2e-4 * scale_g + 2e-5:
+                ok = True
+                break
+    except (_lib.SnsdeError, ValueError, AttributeError, TypeError):
+        ok = False
+    finally:
+        if hasattr(sde, 'set_X'):
+            sde.set_X(*saved)
+    field.verified[str(dev)] = ok
+    return ok

@@ -159,6 +159,10 @@ def sdeint(sde, y0, ts, bm=None, method=None, dt=1e-3, adaptive=False, rtol=1e-5
         if not y0.is_cuda:
             raise ValueError("the HIP engine needs CUDA (ROCm) tensors")
         return _sdeint_hip(sde, rec, y0, ts, bm, method, float(dt), options)
+    if default_names and rec is None and backend == 'auto' and y0.is_cuda and method in ('euler', 'milstein'):
+        ys = _sdeint_composed(sde, y0, ts, bm, method, float(dt), options)     # tutorial-style fields (fields.py)
+        if ys is not None:
+            return ys
     return _sdeint_torch(sde, y0, ts, bm, method, float(dt), options, names)
 
 
@@ -241,6 +245,49 @@ def _sdeint_hip(sde, rec, y0, ts, bm, method, dt, options):
     if options.get('save_traj', False):
         sde.last_trajectory = call.traj
     return ys.to(y0.dtype)
+
+
+def _sdeint_composed(sde, y0, ts, bm, method, dt, options):
+    """Fused solve of a tutorial-style field (tutorial/*.ipynb cell 7; fields.compose): no-grad calls only, the lean
+    4-row-tile kernel with the variant switches.  None = not such a field / not covered: the caller takes the generic
+    stepper."""
+    from . import fields
+    if torch.is_grad_enabled() and (y0.requires_grad or any(p.requires_grad for p in sde.parameters())):
+        return None           # training differentiates through the tensor-op loop (no fused adjoint for the variants)
+    field = fields.compose(sde)
+    coeffs = getattr(sde, 'coeffs', None)
+    if field is None or not torch.is_tensor(coeffs) or coeffs.dim() != 3 or coeffs.shape[0] != y0.shape[0] \
+            or torch.cuda.is_current_stream_capturing():
+        return None
+    dev = y0.device
+    coeffs = coeffs.detach().to(device=dev, dtype=torch.float32).contiguous()
+    times_host = _HostTimes.get(sde.times)
+    if not fields.verify(field, coeffs, times_host, dev):
+        return None
+    grid = engine.step_grid(_HostTimes.get(ts), dt, times_host, dev)
+    dW = None
+    if bm is not None:
+        t0, t1 = torch.from_numpy(grid.t0), torch.from_numpy(grid.t1)
+        dW = torch.stack([bm(t0[n], t1[n]).to(device=dev, dtype=torch.float32) for n in range(grid.N)]).contiguous()
+    seed = options.get('seed')
+    seed = _fresh_seed() if seed is None else (seed if torch.is_tensor(seed) else int(seed))
+    row_offset = options.get('row_offset')
+    if row_offset is None:
+        import torch.distributed as dist
+        multi = dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+        row_offset = dist.get_rank() * int(y0.shape[0]) if multi else 0
+    row_out = options.get('row_out')
+    if row_out is not None:
+        row_out = row_out.to(device=dev, dtype=torch.int32).contiguous()
+    tab = field.noise_table(grid.d_t0, dev)
+    call = engine.SolveCall(field.model, field.flat(dev), coeffs, grid, y0.detach().to(torch.float32).contiguous(), dW=dW,
+                            method=method, seed=seed, row_offset=int(row_offset), row_out=row_out, noise_table=tab)
+    try:
+        return call.launch().to(y0.dtype)
+    except engine._lib.SnsdeError as exc:
+        if exc.code != -4:
+            raise
+        return None
 
 
 class _FusedSolve(torch.autograd.Function):

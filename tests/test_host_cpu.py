@@ -591,3 +591,90 @@ def test_bench_self_launch_builds_a_torchrun_command(monkeypatch):
     assert cmd[1:4] == ['-m', 'torch.distributed.run', '--nnodes=1'] and '--nproc-per-node=4' in cmd
     assert '127.0.0.1' in cmd and cmd[-4:] == ['--gpus', '4', '--steps', '7']
     assert seen['env']['HSA_ENABLE_IPC_MODE_LEGACY'] == '0' or 'HSA_ENABLE_IPC_MODE_LEGACY' in os.environ
+
+
+# ---- tutorial-style fields (fields.py): structural recognition and weight composition, no GPU ----------------------------
+
+def _variant_drift(cf, flat, t, y, Xt):
+    """float64 evaluation of the C ABI's variant semantics (include/snsde.h SNSDE_ACT_* / SNSDE_DRIFT_* / SNSDE_TIME_RAW)
+    on a composed parameter block: what the lean kernel computes for the drift."""
+    import torch
+    P = {n: flat[o:o + int(np.prod(sh))].view(*sh).double() for n, o, sh in cf.layout}
+    m = cf.model
+    act = {0: torch.relu, 1: lambda x: 0.909 * torch.nn.functional.silu(x), 2: torch.nn.functional.silu}[m.activation]
+    if m.input_option == 4:
+        tf = torch.cat([torch.full_like(y[:, :1], t), torch.zeros_like(y[:, :1])], 1) if m.time_feature == 1 else \
+            torch.cat([torch.sin(torch.full_like(y[:, :1], t)), torch.cos(torch.full_like(y[:, :1], t))], 1)
+        yy = torch.cat([tf, y], 1) @ P['linear_in.weight'].T + P['linear_in.bias']
+    else:
+        yy = y @ P['linear_in.weight'].T + P['linear_in.bias']
+    xt = Xt @ P['initial_network.weight'].T + P['initial_network.bias']
+    z = act(torch.cat([yy, xt], 1) @ P['emb.weight'].T + P['emb.bias'])
+    for i in range(m.num_hidden_layers - 1):
+        z = act(z @ P[f'linears.{i}.weight'].T + P[f'linears.{i}.bias'])
+    z = z @ P['linear_out.weight'].T + P['linear_out.bias']
+    return {0: torch.tanh(z), 1: z, 2: z * y}[m.drift_output]
+
+
+@pytest.mark.parametrize('kind', ['lsde', 'lnsde', 'lnsde_additive', 'gsde'])
+@pytest.mark.parametrize('layers,act', [(1, 'lipswish'), (3, 'relu'), (2, 'silu')])
+def test_tutorial_field_composition_matches_module(kind, layers, act):
+    import torch
+    from stable_neural_sdes_amd import fields
+    from tests.tutorial_fields import TutorialField
+    from tests.helpers import make_problem
+    torch.manual_seed(3)
+    B, H, C_, L = 5, 32, 3, 6
+    pr = make_problem(1, 4, 17, 2, B, H, C_, L, times=np.linspace(0, 1, L))
+    field = TutorialField(kind, C_, H, layers, act).double()
+    field.set_X(torch.from_numpy(pr['coeffs']).double(), torch.from_numpy(pr['times']).double())
+    cf = fields.compose(field)
+    assert cf is not None
+    assert cf.model.activation == {'relu': 0, 'lipswish': 1, 'silu': 2}[act]
+    assert cf.model.input_option == (2 if kind == 'lsde' else 4) and cf.model.time_feature == (0 if kind == 'lsde' else 1)
+    assert cf.model.noise_option == (12 if kind in ('lsde', 'lnsde_additive') else 13) and cf.model.diffusion_output == 1
+    assert cf.model.num_hidden_layers == layers
+    cf.model.drift_output = fields.DRIFT_TIMES_Y if kind == 'gsde' else fields.DRIFT_LINEAR     # (the GPU probe decides this)
+    flat = cf.flat(torch.device('cpu'))
+    assert flat.dtype == torch.float32 and flat.numel() == cf.numel
+    t = torch.tensor(0.4, dtype=torch.float64)
+    y = torch.rand(B, H, dtype=torch.float64) + 0.2
+    with torch.no_grad():
+        want = field.f(t, y)
+        got = _variant_drift(cf, flat, 0.4, y, field.X.evaluate(t))
+        assert float((got - want).abs().max()) <= 2e-6 * (1 + float(want.abs().max()))
+        # time-only diffusion factor over a column of times == g(t, ones) row by row
+        ts = torch.tensor([0.0, 0.3, 0.9], dtype=torch.float64)
+        field32 = field.float()
+        tab = cf.noise_table(ts, torch.device('cpu'))
+        for n in range(3):
+            assert torch.allclose(tab[n], field32.g(ts[n].float(), torch.ones(1, H))[0], rtol=1e-5, atol=1e-6)
+
+
+def test_tutorial_field_structural_rejects():
+    import torch
+    from stable_neural_sdes_amd import fields
+    from tests.tutorial_fields import TutorialField
+    f = TutorialField('lsde', 2, 32, 1)
+    f.f_net._model.append(torch.nn.Tanh())
+    assert fields.compose(f) is None                       # Tanh-terminated MLP
+    f = TutorialField('lsde', 2, 32, 1)
+    f.f_net._model[1] = torch.nn.Tanh()
+    assert fields.compose(f) is None                       # activation the kernel does not implement
+    f = TutorialField('lnsde', 2, 32, 1)
+    f.g = lambda t, y: torch.sin(y)                        # diffusion neither additive nor proportional to y
+    assert fields.compose(f) is None
+    assert fields.compose(S.Diffusion_model(2, 32, 32, 2, input_option=4, noise_option=17)) is None   # own fast path instead
+    assert fields._classify_activation(torch.nn.SiLU()) == fields.ACT_SILU
+    assert fields._classify_activation(torch.nn.ReLU()) == fields.ACT_RELU
+
+
+def test_c_abi_variant_fields_validate():
+    import ctypes as C
+    from stable_neural_sdes_amd import _lib, engine
+    assert C.sizeof(_lib.Model) == 40
+    L = _lib.lib()
+    ok = engine.model_struct(3, 32, 32, 2, 4, 13, activation=1, drift_output=2, diffusion_output=1, time_feature=1)
+    assert L.snsde_param_count(C.byref(ok)) > 0
+    for kw in (dict(activation=3), dict(drift_output=3), dict(diffusion_output=2), dict(time_feature=2), dict(activation=-1)):
+        assert L.snsde_param_count(C.byref(engine.model_struct(3, 32, 32, 2, 4, 13, **kw))) < 0
