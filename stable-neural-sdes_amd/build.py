@@ -41,7 +41,7 @@ def check_lean_resources(src, remarks):
         if m:
             name = m.group(1)
             continue
-        if name and 'snsde_m4_kernel' in name:
+        if name and ('snsde_m4_kernel' in name or 'snsde_m4s_kernel' in name):
             m = re.search(r'remark:\s+(VGPRs|ScratchSize \[bytes/lane\]|VGPRs Spill): (\d+)', line)
             if m:
                 LEAN_RESOURCES.setdefault(name, {})[m.group(1)] = int(m.group(2))
@@ -66,7 +66,7 @@ def build(force=False, verbose=False, defines=(), out=None):
 
     def compile_one(src):
         obj = os.path.join(objdir, os.path.basename(src)[:-4] + '.o')
-        lean = os.path.basename(src).startswith('snsde_m4_h')
+        lean = os.path.basename(src).startswith(('snsde_m4_h', 'snsde_m4s_h'))
         cmd = base + (['-Rpass-analysis=kernel-resource-usage'] if lean else []) + ['-c', src, '-o', obj]
         if verbose:
             print(' '.join(cmd))

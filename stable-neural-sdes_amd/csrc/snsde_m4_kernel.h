@@ -636,5 +636,6 @@ int dispatch_lean(const MfmaPlan& p, const MfmaArgs& a, hipStream_t st) {
 int dispatch_lean_h32(const MfmaPlan& p, const MfmaArgs& a, hipStream_t st);
 int dispatch_lean_h64(const MfmaPlan& p, const MfmaArgs& a, hipStream_t st);
 int dispatch_lean_h128(const MfmaPlan& p, const MfmaArgs& a, hipStream_t st);
+int dispatch_lean_h256(const MfmaPlan& p, const MfmaArgs& a, hipStream_t st);   // snsde_m4s_kernel.h
 
 }  // namespace snsde_mfma

@@ -32,6 +32,7 @@ namespace snsde_mfma {
 
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 constexpr int MAXL = 4 + SNSDE_MAX_HIDDEN;
 
@@ -1455,6 +1456,8 @@ struct RevPlan {
 // instantiations: no spill while  weight registers + the loop-carried [X | tau] operands  <= 112 (K2: 104 + 8, 253 VGPRs);
 // build.py fails the build if an instantiation spills.  KUXT = 16-wide k-blocks of [X(t) | sin t, cos t].
 __host__ __device__ constexpr bool lean_fits(int H, int NHID, int KUXT, bool YIN) {
+    // streamed-weight variant (snsde_m4s_kernel.h); (NHID 0, KUXT 3) would spill two registers in training mode
+    if (H == 256) return YIN && NHID <= 2 && KUXT <= 3 && !(NHID == 0 && KUXT == 3);
     return (H == 32 || H == 64 || H == 128) && 4 * (KUXT + (YIN ? H / 16 : 0) + (NHID + 1) * (H / 16)) + 4 * KUXT <= (YIN ? 112 : 104);
 }
 // largest KUXT a (input_option, KUX) class of the general kernel can meet (KUX = 5: 33..80 control channels)

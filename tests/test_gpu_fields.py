@@ -39,7 +39,7 @@ CASES = [(kind, H, layers, act, method)
          for kind in ('lsde', 'lnsde', 'lnsde_additive', 'gsde')
          for H, layers, act, method in ((32, 1, 'lipswish', 'euler'), (64, 2, 'lipswish', 'euler'), (128, 2, 'lipswish', 'euler'),
                                         (128, 1, 'silu', 'milstein'), (64, 3, 'relu', 'euler'), (32, 2, 'lipswish', 'milstein'),
-                                        (64, 3, 'lipswish', 'milstein'))]
+                                        (64, 3, 'lipswish', 'milstein'), (256, 2, 'lipswish', 'euler'), (256, 1, 'silu', 'milstein'))]
 
 
 @pytest.mark.parametrize('kind,H,layers,act,method', CASES)

@@ -357,6 +357,15 @@ MFMA_CASES = [
     (4, 17, 2, 21, 256, 14, 11, [0, 4.5, 10], 1.0, 'milstein'),   # H = 256: weights streamed from L2 (K5 model)
     (6, 17, 1, 9, 256, 5, 9, [0, 8], 1.0, 'euler'),
     (1, 18, 2, 9, 256, 3, 8, [0, 7], 1.0, 'euler'),
+    # H = 256 on the streamed-weight lean kernel (snsde_m4s_kernel.h): 0 / 1 / 2 hidden layers, no xt block (latent-only
+    # drift), 1-3 xt blocks, ragged last tile, off-grid outputs, supplied and table diffusions
+    (1, 16, 1, 7, 256, 3, 8, [0, 2.5, 7], 1.0, 'milstein'),
+    (2, 12, 3, 10, 256, 20, 9, [0, 8], 0.5, 'euler'),
+    (3, 5, 2, 5, 256, 3, 8, [0, 7], 1.0, 'milstein'),
+    (4, 13, 3, 6, 256, 40, 8, [0, 3, 7], 1.0, 'euler'),
+    (5, 3, 2, 9, 256, 3, 12, [0, 11], 1.0, 'milstein'),
+    (6, 17, 2, 3, 256, 30, 9, [0, 8], 1.0, 'euler'),
+    (4, 9, 1, 9, 256, 17, 8, [0, 7], 1.0, 'euler'),
 ]
 
 
