@@ -129,6 +129,85 @@ class StepGrid:
             self.d_out_w = torch.from_numpy(self.out_w).to(device)
 
 
+def sub_grid(grid, n0, n1):
+    """The solver steps n0 .. n1-1 of `grid` as a StepGrid of their own: the SAME step rows (times, step sizes, spline
+    intervals), the parent's outputs that fall inside, and one more output at the end of the last step.  Returns
+    (sub grid, ks) with ks = the parent's output numbers (k + 1) of the sub grid's outputs 1 .. len(ks); its last output
+    (the state after step n1 - 1) is the chunk's hand-over to the steps behind it."""
+    g = StepGrid.__new__(StepGrid)
+    K = n1 - n0
+    tab = grid.step_tab[n0:n1].copy()
+    ks = [k for k in range(grid.T - 1) if n0 <= grid.out_step[k] < n1]
+    out_step = np.array([grid.out_step[k] - n0 for k in ks] + [K - 1], dtype=np.int32)
+    out_w = np.array([grid.out_w[k] for k in ks] + [(0.0, 1.0)], dtype=np.float32).reshape(-1, 2)
+    nout = np.zeros(K, dtype=np.int32)
+    first = np.zeros(K, dtype=np.int32)
+    for j, st in enumerate(out_step):
+        if nout[st] == 0:
+            first[st] = j
+        nout[st] += 1
+    tab[:, 8] = nout.view(np.float32)
+    tab[:, 9] = first.view(np.float32)
+    g.N, g.T = K, len(out_step) + 1
+    g.step_tab, g.out_step, g.out_w = tab, out_step, out_w
+    g._times32, g._d_srk = grid._times32, None
+    g.t0, g.t1 = tab[:, 0].copy(), tab[:, 7].copy()
+    g.device = grid.device
+    g.d_step_tab = torch.from_numpy(tab).to(grid.device)
+    g.d_t0 = torch.from_numpy(g.t0).to(grid.device)
+    g.d_out_step = torch.from_numpy(out_step).to(grid.device)
+    g.d_out_w = torch.from_numpy(out_w).to(grid.device)
+    return g, [k + 1 for k in ks]
+
+
+def chunk_plan(grid, chunk):
+    """[(n0, n1, sub grid, parent output numbers)] for the recompute-mode backward (memoised on the grid)."""
+    cache = grid.__dict__.setdefault('_chunks', {})
+    if chunk not in cache:
+        cache[chunk] = [(n0, min(n0 + chunk, grid.N)) + sub_grid(grid, n0, min(n0 + chunk, grid.N))
+                        for n0 in range(0, grid.N, chunk)]
+    return cache[chunk]
+
+
+def backward_recompute(call, grad_ys, chunk, stream=None):
+    """Recompute-mode backward of a solve that kept only its states and increments (SolveCall with save_traj / save_dW,
+    no save_act): the steps are revisited in chunks of `chunk`, last chunk first; each chunk re-runs the forward kernel
+    from its saved first state with the saved increments (bit-identical states, now with the per-step activations), then
+    the adjoint kernel and the weight-gradient pass on those.  Peak extra memory = one chunk's activations and deltas
+    (2 x chunk x NSAVE x B x H floats) instead of N x NSAVE x B x H for the whole solve; the chunk buffers are written
+    and read back within microseconds, i.e. out of the 256 MB last-level cache rather than HBM.
+    Returns (dL/dy0 (B, H), flat parameter gradient)."""
+    grid, N = call.grid, call.grid.N
+    model, flat, coeffs = call.model, call.keep[0], call.keep[1]
+    method = {_lib.EULER: 'euler', _lib.MILSTEIN: 'milstein'}[call.desc.method]
+    B, H = call.traj.shape[1:]
+    dev = call.traj.device
+    per_row = call.keep[6] is not None          # grad_ys is (B, H): row b's gradient belongs to output row_out[b]
+    row_out = call.keep[6]
+    carry = torch.zeros((B, H), device=dev, dtype=torch.float32)
+    total = None
+    for n0, n1, sub, ks in reversed(chunk_plan(grid, chunk)):
+        g = torch.zeros((sub.T, B, H), device=dev, dtype=torch.float32)
+        for j, k in enumerate(ks):                # the parent's outputs inside the chunk
+            if per_row:
+                g[j + 1] = torch.where((row_out == k).unsqueeze(1), grad_ys, g[j + 1])
+            else:
+                g[j + 1] = grad_ys[k]
+        g[sub.T - 1] += carry                     # everything behind the chunk acts on its last state
+        c = SolveCall(model, flat, coeffs, sub, call.traj[n0], dW=call.dW_out[n0:n1], method=method, kernel='auto',
+                      save_traj=True, save_dW=True, save_act=True, exact_order=bool(call.base_flags & _lib.FLAG_EXACT_ORDER))
+        c.launch(stream)
+        adj, delta = solve_backward(c, g, stream=stream, save_delta=True)
+        part = param_gradients(c, adj, delta, stream=stream)
+        total = part if total is None else total.add_(part)
+        carry = adj[0]
+    if per_row:
+        g0 = torch.where((row_out == 0).unsqueeze(1), grad_ys, torch.zeros_like(grad_ys))
+    else:
+        g0 = grad_ys[0]
+    return carry + g0, total
+
+
 def srk_table(grid):
     """Device (N, 4, SNSDE_SRK_STRIDE) stage-time table of a StepGrid (built on first use)."""
     if grid._d_srk is None:

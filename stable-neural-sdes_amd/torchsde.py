@@ -318,8 +318,13 @@ class _FusedSolve(torch.autograd.Function):
                 "(noise_option 0..13, 16, 17) and 'euler' with the diffusion nets 14/15/18/19 where the MFMA path is "
                 "instantiated; pass options={'backend': 'torch'} to differentiate this configuration through the "
                 "tensor-op loop")
+        # recompute mode (options={'recompute': steps per chunk} or SNSDE_RECOMPUTE_STEPS): keep states and increments only,
+        # re-run the forward kernel chunk by chunk inside backward (engine.backward_recompute)
+        ctx.recompute = 0
+        if mode == 1 and method != 'srk':
+            ctx.recompute = max(int(options.get('recompute', os.environ.get('SNSDE_RECOMPUTE_STEPS', 0)) or 0), 0)
         # mode 2: the generic adjoint prepares its own weights, so the forward takes whatever kernel is fastest
-        call = make(options.get('kernel', 'auto'), mode == 1)
+        call = make(options.get('kernel', 'auto'), mode == 1 and not ctx.recompute)
         ctx.mode, ctx.method = mode, method
         ctx.param_pass = options.get('param_pass', 'hip')
         ctx.layout = (layout, numel)
@@ -327,11 +332,22 @@ class _FusedSolve(torch.autograd.Function):
         ctx.call, ctx.sde, ctx.grid, ctx.times_host = call, sde, grid, times_host
         ctx.names = [n for n, _ in sde.named_parameters()]
         ctx.y0_dtype = y0.dtype
-        return ys.to(y0.dtype)
+        # a NEW tensor object for the output: returning call.ys itself would give it this node as grad_fn, and the node
+        # holds the call: a reference cycle that keeps every saved tensor of the solve alive until the cyclic collector runs
+        return ys.to(y0.dtype) if y0.dtype != ys.dtype else ys.detach()
 
     @staticmethod
     def backward(ctx, grad_ys):
         call, sde, grid = ctx.call, ctx.sde, ctx.grid
+        if ctx.mode == 1 and ctx.recompute:
+            g0, flat = engine.backward_recompute(call, grad_ys.to(torch.float32).contiguous(), ctx.recompute)
+            layout, _ = ctx.layout
+            offs = {name: (off, shape) for name, off, shape in layout}
+            grads = []
+            for name, p in sde.named_parameters():
+                off, shape = offs[name]
+                grads.append(flat[off:off + p.numel()].view_as(p).to(p.dtype))
+            return (None,) * 9 + (g0.to(ctx.y0_dtype),) + tuple(grads)
         if ctx.mode == 1:     # MFMA adjoint kernel + native weight-gradient pass on the saved activations / deltas
             adj, delta = engine.solve_backward(call, grad_ys.to(torch.float32).contiguous(), save_delta=True)
             if ctx.param_pass == 'torch':     # library-GEMM cross-check of the native pass

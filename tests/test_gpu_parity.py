@@ -685,6 +685,56 @@ def _check_backward(seed, io, no, NL, B, H, C, L, ts, dt, method, kernel):
         close(p.grad, gref, name)
 
 
+RECOMPUTE_CASES = [
+    # io, no, NL, B, H, C, L, ts, dt, method, chunk, per-row outputs
+    (4, 17, 2, 37, 128, 21, 13, [0, 12], 1.0, 'euler', 5, False),            # K2 model: one output at the end
+    (4, 17, 2, 21, 256, 14, 12, None, None, 'milstein', 4, False),           # K5 model: Milstein, every knot an output
+    (6, 17, 3, 9, 64, 5, 9, [0, 2.5, 4, 8], 0.5, 'milstein', 3, False),      # off-grid output inside a chunk, 16 half steps
+    (2, 16, 1, 50, 32, 2, 11, [0, 10], 1.0, 'euler', 1, False),              # one step per chunk
+    (4, 13, 2, 19, 64, 3, 10, None, None, 'euler', 4, True),                 # per-row output selection (classification wrapper)
+    (3, 18, 2, 13, 64, 5, 9, [0, 3.5, 8], 1.0, 'euler', 3, False),           # diffusion net (BASELINE config 4's model)
+    (4, 17, 2, 11, 128, 21, 9, [0, 8], 1.0, 'euler', 100, False),            # chunk longer than the solve
+]
+
+
+@pytest.mark.parametrize('ci', range(len(RECOMPUTE_CASES)))
+def test_recompute_mode_backward_equals_saved_activation_backward(ci):
+    """options={'recompute': K}: states and increments kept, activations re-created chunk by chunk in backward
+    (engine.backward_recompute).  dL/dy0 goes through the same kernels on the same numbers: bit-equal; the parameter
+    gradients are the same sums taken chunk by chunk: equal to rounding of the accumulation order."""
+    io, no, NL, B, H, C, L, ts, dt, method, chunk, per_row = RECOMPUTE_CASES[ci]
+    times = np.linspace(0, 1, L).astype(np.float32) if ts is None else None
+    pr = make_problem(1700 + ci, io, no, NL, B, H, C, L, times=times)
+    ts = pr['times'] if ts is None else np.asarray(ts, np.float32)
+    dt = dt or max(float(np.diff(pr['times']).min()), 1e-3)
+    rng = np.random.default_rng(ci)
+    row_out = torch.from_numpy(rng.integers(0, len(ts), B)).to(DEV) if per_row else None
+    wsum = torch.from_numpy(rng.standard_normal((B, H) if per_row else (len(ts), B, H)).astype(np.float32)).to(DEV)
+    out = {}
+    for mode in ('saved', 'recompute'):
+        m = S.Diffusion_model(C, H, H, NL, input_option=io, noise_option=no)
+        m.load_state_dict({k: torch.from_numpy(v.copy()) for k, v in pr['params'].items()})
+        m = m.to(DEV)
+        m.set_X(torch.from_numpy(pr['coeffs']).to(DEV), torch.from_numpy(pr['times']).to(DEV))
+        y0 = torch.from_numpy(pr['y0']).to(DEV).requires_grad_(True)
+        opts = {'seed': 11}
+        if mode == 'recompute':
+            opts['recompute'] = chunk
+        if per_row:
+            opts['row_out'] = row_out
+        torch.cuda.reset_peak_memory_stats()
+        ys = S.sdeint(m, y0, torch.from_numpy(ts).to(DEV), method=method, dt=dt, options=opts)
+        (ys * wsum).sum().backward()
+        out[mode] = (ys.detach(), y0.grad.detach(), {k: p.grad.detach() for k, p in m.named_parameters() if p.grad is not None})
+    assert torch.equal(out['saved'][0], out['recompute'][0])
+    assert torch.equal(out['saved'][1], out['recompute'][1]), 'dL/dy0 differs between the two modes'
+    assert set(out['saved'][2]) == set(out['recompute'][2])
+    for k, ref in out['saved'][2].items():
+        got = out['recompute'][2][k]
+        scale = float(ref.abs().max()) + 1e-12
+        assert float((got - ref).abs().max()) <= 2e-5 * scale + 1e-7, (k, float((got - ref).abs().max()), scale)
+
+
 @pytest.mark.parametrize('case', [(4, 17, 2, 300, 128, 21, 13, 'euler'), (6, 17, 3, 70, 64, 7, 9, 'milstein'),
                                   (3, 13, 2, 45, 32, 3, 8, 'milstein'), (1, 0, 1, 33, 16, 3, 8, 'euler'),
                                   (5, 12, 4, 40, 128, 3, 8, 'euler'), (2, 16, 2, 130, 256, 14, 9, 'milstein')])
