@@ -236,6 +236,18 @@ int snsde_hermite_coeffs(const float* times, const float* X, int32_t batch, int3
 int snsde_eval_fg(const snsde_solve* s, const float* step_row, const float* y, float* f_out,
                   float* g_out, void* hip_stream);
 
+/* Kernel family a forward solve of this descriptor runs on (host-side query, no device access): the coverage table in
+ * profiles/ is generated from it.                                                                                  */
+enum { SNSDE_PATH_NONE = 0,          /* no kernel: snsde_solve_forward returns SNSDE_ERR_UNSUPPORTED                 */
+       SNSDE_PATH_GENERIC = 1,       /* generic kernel family (every option, any dims; one wave per row group)      */
+       SNSDE_PATH_MFMA_M16 = 2,      /* MFMA, 16-row tiles                                                          */
+       SNSDE_PATH_MFMA_M4 = 3,       /* MFMA, 4-row tiles, general kernel                                           */
+       SNSDE_PATH_LEAN = 4,          /* MFMA, 4-row tiles, lean kernel (register-resident weights, H = 32/64/128)    */
+       SNSDE_PATH_LEAN_STREAMED = 5, /* MFMA, 4-row tiles, lean kernel with L2 -> LDS streamed weights (H = 256)     */
+       SNSDE_PATH_GENERIC_SRK = 6,   /* SRK on the generic family                                                   */
+       SNSDE_PATH_MFMA_SRK = 7 };    /* SRK on the MFMA 4-row tiles                                                 */
+int snsde_forward_path(const snsde_solve* s);
+
 int         snsde_version(void);
 const char* snsde_strerror(int code);
 

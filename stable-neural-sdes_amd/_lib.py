@@ -15,6 +15,7 @@ SNSDE_SRK_STRIDE = 8
 KERNEL_AUTO, KERNEL_GENERIC, KERNEL_MFMA = 0, 1, 2
 FLAG_REUSE_PREPARED = 1
 FLAG_EXACT_ORDER = 2
+PATHS = ('none', 'generic', 'mfma16', 'mfma4', 'lean', 'lean-streamed', 'generic-srk', 'mfma-srk')
 KERNELS = {'auto': KERNEL_AUTO, 'generic': KERNEL_GENERIC, 'mfma': KERNEL_MFMA, 'mfma16': 3, 'mfma4': 4}
 
 
@@ -57,7 +58,7 @@ EXPORTS = ('snsde_version', 'snsde_strerror', 'snsde_param_count', 'snsde_param_
            'snsde_spline_evaluate', 'snsde_eval_fg', 'snsde_act_slots', 'snsde_backward_supported',
            'snsde_backward_workspace_bytes', 'snsde_solve_backward', 'snsde_spline_workspace_bytes',
            'snsde_natural_cubic_coeffs', 'snsde_hermite_coeffs', 'snsde_param_gradients_workspace_bytes',
-           'snsde_param_gradients')
+           'snsde_param_gradients', 'snsde_forward_path')
 
 
 def lib():
@@ -98,6 +99,7 @@ def lib():
     L.snsde_param_gradients_workspace_bytes.restype = C.c_size_t
     L.snsde_param_gradients.argtypes = [C.POINTER(Backward), C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]
     L.snsde_backward_supported.argtypes = [C.POINTER(Solve)]
+    L.snsde_forward_path.argtypes = [C.POINTER(Solve)]
     L.snsde_backward_workspace_bytes.argtypes = [C.POINTER(Backward)]
     L.snsde_backward_workspace_bytes.restype = C.c_size_t
     L.snsde_solve_backward.argtypes = [C.POINTER(Backward), C.c_void_p]

@@ -370,6 +370,33 @@ int snsde_solve_forward(const snsde_solve* s, void* hip_stream) {
     return snsde_generic_launch(s, net, static_cast<hipStream_t>(hip_stream), 0, nullptr, nullptr, nullptr, nullptr);
 }
 
+// Host-only query: the kernel family snsde_solve_forward would launch for this descriptor (needs model, batch, knots,
+// n_steps, method, kernel, flags, input dims; no device pointers).  SNSDE_PATH_NONE = no kernel covers the request
+// (snsde_solve_forward returns SNSDE_ERR_UNSUPPORTED and the host layer takes its tensor loop).
+int snsde_forward_path(const snsde_solve* s) {
+    if (!s || validate_model(&s->model) || s->batch <= 0 || s->knots < 2 || s->n_steps <= 0) return SNSDE_PATH_NONE;
+    const int no = s->model.noise_option;
+    if (s->method == SNSDE_MILSTEIN && (no == 7 || no == 14 || no == 15 || no == 18 || no == 19)) return SNSDE_PATH_NONE;
+    SnsdeNet net;
+    if (snsde_build_net(s->model, s->n_steps, &net)) return SNSDE_PATH_NONE;
+    const bool variant = is_variant(s->model) || s->noise_table;
+    if (variant) {
+        if (s->method == SNSDE_SRK || s->kernel == SNSDE_KERNEL_GENERIC || s->kernel == SNSDE_KERNEL_MFMA_M16) return SNSDE_PATH_NONE;
+        return snsde_mfma_path(s, net, 1);
+    }
+    const int hint = s->kernel == SNSDE_KERNEL_MFMA_M16 ? 0 : (s->kernel == SNSDE_KERNEL_MFMA_M4 ? 1 : -1);
+    if (s->method == SNSDE_SRK) {
+        if (s->kernel == SNSDE_KERNEL_MFMA_M16) return SNSDE_PATH_NONE;
+        if (s->kernel == SNSDE_KERNEL_MFMA || s->kernel == SNSDE_KERNEL_MFMA_M4) return snsde_mfma_path(s, net, 1);
+        if (s->kernel == SNSDE_KERNEL_AUTO && snsde_mfma_supported(s, net)) return snsde_mfma_path(s, net, -1);
+        return SNSDE_PATH_GENERIC_SRK;
+    }
+    if (s->kernel == SNSDE_KERNEL_GENERIC) return SNSDE_PATH_GENERIC;
+    const int path = snsde_mfma_path(s, net, hint);
+    if (path != SNSDE_PATH_NONE || s->kernel != SNSDE_KERNEL_AUTO) return path;
+    return SNSDE_PATH_GENERIC;
+}
+
 int snsde_eval_fg(const snsde_solve* s, const float* step_row, const float* y, float* f_out, float* g_out,
                   void* hip_stream) {
     int rc = validate_solve(s, true);

@@ -57,6 +57,7 @@ int snsde_time_table_srk_launch(const float* params, const float* srk_tab, float
                                 int n_rows, hipStream_t stream);
 // launchers (snsde_mfma.hip)
 bool snsde_mfma_supported(const snsde_solve* s, const SnsdeNet& net);
+int snsde_mfma_path(const snsde_solve* s, const SnsdeNet& net, int flavor_hint);
 size_t snsde_mfma_workspace_floats(const snsde_solve* s, const SnsdeNet& net);
 int snsde_mfma_launch(const snsde_solve* s, const SnsdeNet& net, hipStream_t stream, int flavor_hint);
 bool snsde_mfma_backward_supported(const snsde_solve* s, const SnsdeNet& net);

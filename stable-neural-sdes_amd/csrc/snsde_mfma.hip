@@ -383,6 +383,15 @@ RevPlan make_rev_plan(const snsde_solve* s, const SnsdeNet& net, const MfmaPlan&
 
 bool snsde_mfma_supported(const snsde_solve* s, const SnsdeNet& net) { return make_plan(s, net, -1).ok; }
 
+// which MFMA kernel family a forward launch of this descriptor takes (SNSDE_PATH_*; 0: none)
+int snsde_mfma_path(const snsde_solve* s, const SnsdeNet& net, int flavor_hint) {
+    const MfmaPlan p = make_plan(s, net, flavor_hint);
+    if (!p.ok) return SNSDE_PATH_NONE;
+    if (p.SRK) return SNSDE_PATH_MFMA_SRK;
+    if (p.LEAN) return p.H == 256 ? SNSDE_PATH_LEAN_STREAMED : SNSDE_PATH_LEAN;
+    return p.FL ? SNSDE_PATH_MFMA_M4 : SNSDE_PATH_MFMA_M16;
+}
+
 size_t snsde_mfma_workspace_floats(const snsde_solve* s, const SnsdeNet& net) {
     // the packed layout depends on the kernel variant (the lean 4-row kernel merges the time features into the control
     // block): size the workspace for whichever variant a later launch of this descriptor may select

@@ -678,3 +678,29 @@ def test_c_abi_variant_fields_validate():
     assert L.snsde_param_count(C.byref(ok)) > 0
     for kw in (dict(activation=3), dict(drift_output=3), dict(diffusion_output=2), dict(time_feature=2), dict(activation=-1)):
         assert L.snsde_param_count(C.byref(engine.model_struct(3, 32, 32, 2, 4, 13, **kw))) < 0
+
+
+def test_forward_path_query_names_the_kernel_family():
+    """snsde_forward_path (host-side): the BASELINE configurations land on the kernels DESIGN.md says they do."""
+    import ctypes as C
+    from stable_neural_sdes_amd import _lib, engine
+    L = _lib.lib()
+
+    def path(H, Cn, io, no, B, method, NL=2, kernel='auto', **variant):
+        s = _lib.Solve()
+        s.model = engine.model_struct(Cn, H, H, NL, io, no, **variant)
+        s.batch, s.knots, s.n_steps, s.n_out = B, 51, 50, 2
+        s.method, s.kernel = {'euler': _lib.EULER, 'milstein': _lib.MILSTEIN, 'srk': _lib.SRK}[method], _lib.KERNELS[kernel]
+        return _lib.PATHS[L.snsde_forward_path(C.byref(s))]
+
+    assert path(128, 21, 4, 17, 1024, 'euler') == 'lean'                 # K2
+    assert path(128, 21, 6, 17, 512, 'euler') == 'lean'                  # K3 shard
+    assert path(64, 69, 3, 18, 2048, 'euler') in ('mfma4', 'mfma16')     # K4: diffusion net
+    assert path(256, 14, 4, 17, 128, 'milstein') == 'lean-streamed'      # K5 shard
+    assert path(256, 14, 4, 17, 16384, 'milstein') == 'mfma16'           # large batch: 16-row tiles
+    assert path(128, 21, 4, 17, 1024, 'srk') == 'mfma-srk'
+    assert path(48, 5, 4, 17, 64, 'euler') == 'generic'                  # no MFMA instantiation for H = 48
+    assert path(128, 21, 3, 18, 64, 'milstein') == 'none'                # Milstein needs dg/dy in closed form
+    assert path(128, 21, 4, 17, 64, 'euler', kernel='generic') == 'generic'
+    assert path(32, 2, 4, 13, 256, 'euler', NL=1, activation=1, drift_output=1, diffusion_output=1, time_feature=1) == 'lean'
+    assert path(48, 2, 4, 13, 256, 'euler', NL=1, activation=1, drift_output=1, diffusion_output=1, time_feature=1) == 'none'

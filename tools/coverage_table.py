@@ -1,0 +1,64 @@
+#!/usr/bin/env python3
+"""Coverage table of the fused paths (host-side queries only, runs without a GPU): for every (input_option, noise_option,
+method) of the reference's Diffusion_model at the BASELINE hidden sizes, which kernel family the forward solve takes
+(snsde_forward_path) and which backward a training step takes (snsde_backward_supported: 1 = MFMA adjoint + native
+weight-gradient pass, 2 = generic adjoint kernels + batched parameter pass, 0 = autograd through the tensor-op loop).
+usage: python tools/coverage_table.py > profiles/rNN_coverage.txt"""
+import ctypes as C
+import os, sys
+import numpy as np
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from stable_neural_sdes_amd import _lib, engine
+
+L = _lib.lib()
+METHODS = (('euler', _lib.EULER), ('milstein', _lib.MILSTEIN), ('srk', _lib.SRK))
+FWD = {0: 'LOOP', 1: 'gen', 2: 'M16', 3: 'M4', 4: 'lean', 5: 'leanS', 6: 'genS', 7: 'M4S'}
+BWD = {0: 'loop', 1: 'mfma', 2: 'gen'}
+
+
+def query(H, C_, io, no, NL, B, method, N=50, knots=51):
+    s = _lib.Solve()
+    s.model = engine.model_struct(C_, H, H, NL, io, no)
+    s.batch, s.knots, s.n_steps, s.n_out, s.method = B, knots, N, 2, method
+    return L.snsde_forward_path(C.byref(s)), L.snsde_backward_supported(C.byref(s))
+
+
+def main():
+    print('Fused-path coverage (host-side query of the C ABI; no GPU involved).  Cell = forward kernel family / backward mode.')
+    print('forward: lean = lean 4-row-tile MFMA kernel, leanS = its streamed-weight variant (H = 256), M4 / M16 = general MFMA')
+    print('         kernel with 4- / 16-row tiles, M4S = SRK on MFMA 4-row tiles, gen / genS = generic kernels (any option),')
+    print('         LOOP = no kernel: the host layer integrates with its graph-captured tensor-op stepper.')
+    print('backward: mfma = MFMA adjoint kernel + native weight-gradient pass, gen = generic adjoint kernels + batched')
+    print('          parameter pass, loop = autograd through the tensor-op loop (options={"strict": True} raises instead).')
+    for (H, C_, B, NL, what) in ((128, 21, 1024, 2, 'K2 / K3 shape'), (64, 69, 2048, 2, 'K4 shape (sepsis channels)'),
+                                 (256, 14, 128, 2, 'K5 per-GPU shard'), (32, 2, 256, 1, 'K1 / tutorial shape'),
+                                 (48, 5, 64, 2, 'a hidden size without MFMA instantiation'), (128, 21, 16384, 4, 'large batch, 3 hidden layers')):
+        print(f'\nH={H} C={C_} B={B} num_hidden_layers={NL}  ({what})')
+        print('  io\\no ' + ' '.join(f'{no:>10d}' for no in range(20)))
+        for mname, mval in METHODS:
+            for io in range(7):
+                cells = []
+                for no in range(20):
+                    f, b = query(H, C_, io, no, NL, B, mval)
+                    cells.append(f'{FWD[f]}/{BWD[b] if f else "loop"}')
+                print(f'  {mname[:4]:4s} {io} ' + ' '.join(f'{c:>10s}' for c in cells))
+    # summary over the reference's named models (the factory's (input_option, noise_option) pairs)
+    print('\nNamed models of the reference factory at H=128, C=21, B=1024 (forward / backward per method):')
+    named = {'neuralsde_0_0 (ODE-like)': (0, 0), 'neurallsde (2,16)': (2, 16), 'neurallnsde (4,17)': (4, 17), 'neuralgsde (6,17)': (6, 17),
+             'neuralsde_3_18 (K4)': (3, 18), 'neuralsde_1_14': (1, 14), 'neuralsde_5_19': (5, 19), 'neuralsde_4_7 (sqrt y)': (4, 7)}
+    for name, (io, no) in named.items():
+        row = []
+        for mname, mval in METHODS:
+            f, b = query(128, 21, io, no, 2, 1024, mval)
+            row.append(f'{mname}: {FWD[f]}/{BWD[b] if f else "loop"}')
+        print(f'  {name:28s} ' + '   '.join(row))
+    fall = sum(1 for H in (32, 64, 128, 256) for io in range(7) for no in range(20) for _, mv in METHODS
+               if query(H, 21, io, no, 2, 1024, mv)[0] == 0)
+    tot = 4 * 7 * 20 * 3
+    print(f'\nforward requests without a kernel at H in (32, 64, 128, 256), C=21: {fall} of {tot} '
+          '(all of them Milstein with a diffusion whose dg/dy is not closed-form: noise_option 7, 14, 15, 18, 19)')
+
+
+if __name__ == '__main__':
+    main()
