@@ -2,7 +2,7 @@
 yongkyung-oh/Stable-Neural-SDEs).  See DESIGN.md / INTEGRATION.md."""
 import sys as _sys
 
-from . import _lib, build, controldiffeq, engine, fields, modules, sharding, torchcde, torchsde  # noqa: F401
+from . import _lib, build, controldiffeq, engine, fields, modules, sharding, torchcde, torchsde, train  # noqa: F401
 from .modules import (Diffusion_model, IstsNeuralSDE, NeuralSDE, NeuralSDE_forecasting,  # noqa: F401
                       make_sde_model, prepare_sde_solver_kwargs)
 from .torchsde import sdeint  # noqa: F401

@@ -244,3 +244,29 @@ def test_hip_engine_under_ddp_nccl_matches_the_single_process_full_batch_gradien
     r = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
     assert f'ddp worker ok world={n}' in r.stdout
+
+
+def test_training_driver_on_gpu_uses_the_fused_path_and_learns(monkeypatch):
+    """train.main (the engine's common_sde.py equivalent; benchmark_classification/common_sde.py:248-298) on cuda: every
+    solve of training and evaluation goes through the HIP engine (the tensor-op loop is disabled for the test), the
+    training loss falls, the metrics are consistent and the best model is restored."""
+    from stable_neural_sdes_amd import train as T
+    from tests.test_train_cpu import synthetic_loader
+    dev = torch.device('cuda')
+    torch.manual_seed(3)
+    L, C, H = 12, 4, 32
+    times, train = synthetic_loader(256, L, C, 2, 64, seed=1)
+    _, val = synthetic_loader(128, L, C, 2, 128, seed=2)
+    _, test = synthetic_loader(128, L, C, 2, 128, seed=3)
+
+    def no_loop(*a, **k):
+        raise AssertionError('the tensor-op loop ran on a CUDA training step')
+    monkeypatch.setattr(S.torchsde, '_sdeint_torch', no_loop)
+    factory = T.make_model('neurallnsde', C, 1, H, H, 2, initial=True)
+    res = T.main(None, 'neurallnsde', times, train, val, test, dev, factory, 2, 6, 1e-2, dict(method='euler'), 'valloss', log=None)
+    losses = [h.train_metrics.loss for h in res.history]
+    assert len(losses) == 6 and losses[-1] < losses[0], losses
+    assert res.train_metrics.dataset_size == 256 and res.val_metrics.confusion.sum() == 128
+    assert res.test_metrics.auroc > 0.7, res.test_metrics            # the label is a function of the series' slope
+    assert res.memory_usage is not None and res.memory_usage > 0
+    assert getattr(res.model.model.func, '_snsde_flat', None) is not None    # the parameter arena was in use
