@@ -95,19 +95,11 @@ __device__ __forceinline__ void lean_load_w(float (&w)[KU * 4], const float* __r
 // count across the exec-masked branch it would otherwise generate and drains the LDS queue before ANY instruction placed
 // between the reads and the MFMAs (the filler work this kernel hides in that window).  Its own counts stay safe: LDS
 // returns in order, and an s_waitcnt computed without these reads only waits longer.
-__device__ __forceinline__ uint32_t lean_lds_addr(const float* p) {
-    return (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const float*)(p);
-}
 // Global loads of the step loop are issued from asm as well (one dword, scalar base + 32-bit lane offset) and waited for
 // ONCE per step by lean_vm_wait(): hipcc cannot count vmcnt across the loop's control flow and would otherwise drain the
 // vector-memory queue (s_waitcnt vmcnt(0)) right after the prefetches are issued.
 // (s_nop 4: a VALU-written SGPR, e.g. v_readfirstlane, needs 5 wait states before a VMEM instruction reads it, and the
 // hazard recognizer does not look inside asm.)
-__device__ __forceinline__ uint64_t lean_uniform(const float* p) {
-    const uint64_t v = (uint64_t)p;          // wave-uniform by construction; readfirstlane folds away when hipcc knows it
-    const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)v), hi = __builtin_amdgcn_readfirstlane((uint32_t)(v >> 32));
-    return ((uint64_t)hi << 32) | lo;
-}
 __device__ __forceinline__ void lean_gload(float& dst, uint32_t voff, const float* sbase) {
     asm volatile("s_nop 4\n\tglobal_load_dword %0, %1, %2" : "=v"(dst) : "v"(voff), "s"(lean_uniform(sbase)) : "memory");
 }

@@ -45,60 +45,6 @@ struct CfgS {
     static_assert(TB % R == 0 && KUH % R == 0 && R % CH == 0, "static ring slots");
 };
 
-// LDS-DMA of streamed k-block G (static): layer G / 16, block u = G % 16 of the wave's slice, into ring slot u % 8.
-// Source = sb (the wave's slice of the layer, SGPR pair) + vo (lane * 16 + 4096 [+ 8192 for u >= 8]) + imm, imm =
-// (u % 8) * 1024 - 4096; the immediate also moves the LDS destination (tools/ubench/glds_probe.hip), which therefore is
-// M0 + imm + lane * 16 with M0 = ring base + 4096 for every slot.
-template <int U>
-__device__ __forceinline__ void stream_refill(uint32_t m0v, uint32_t vo_lo, uint32_t vo_hi, uint64_t sb) {
-    constexpr int IMM = (U % 8) * 1024 - 4096;
-    asm volatile("s_mov_b32 m0, %0\n\ts_nop 4\n\tglobal_load_lds_dwordx4 %1, %2 offset:%3"
-                 :: "s"(m0v), "v"(U < 8 ? vo_lo : vo_hi), "s"(sb), "n"(IMM) : "memory");
-}
-
-// One chunk: k-blocks U0, U0+1 of a layer.  B operands (lanes 0-15) from the activation row, wait for the chunk's ring
-// slots (the R - 2 younger refills may stay in flight), A operands from the ring, refill the two slots, 8 MFMAs.
-template <int U0, int BOFF>
-__device__ __forceinline__ void stream_chunk(uint32_t baddr, uint32_t ra, uint32_t m0v, uint32_t vo_lo, uint32_t vo_hi,
-                                             uint64_t sb_next, f32x4& c, f32x4& d) {
-    f32x4 b0, b1, a0, a1;
-    asm volatile("s_mov_b64 exec, 0xffff\n\t"
-                 "ds_read_b128 %0, %[b] offset:%[o0]\n\tds_read_b128 %1, %[b] offset:%[o1]\n\t"
-                 "s_mov_b64 exec, -1\n\t"
-                 "s_waitcnt vmcnt(6)\n\t"
-                 "ds_read_b128 %2, %[a] offset:%[s0]\n\tds_read_b128 %3, %[a] offset:%[s1]"
-                 : "=&v"(b0), "=&v"(b1), "=&v"(a0), "=&v"(a1)
-                 : [b] "v"(baddr), [a] "v"(ra), [o0] "n"(BOFF + U0 * 64), [o1] "n"(BOFF + U0 * 64 + 64),
-                   [s0] "n"((U0 % 8) * 1024), [s1] "n"((U0 % 8) * 1024 + 1024)
-                 : "memory");
-    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(b0), "+v"(b1), "+v"(a0), "+v"(a1));
-    // the slots are free: their next tenants are blocks U0 + 8, U0 + 9 (same layer while U0 < 8, else the next streamed
-    // layer's / next step's first blocks)
-    stream_refill<(U0 + 8) % 16>(m0v, vo_lo, vo_hi, sb_next);
-    stream_refill<(U0 + 9) % 16>(m0v, vo_lo, vo_hi, sb_next);
-#define SNSDE_S4(av, bv) \
-    c = __builtin_amdgcn_mfma_f32_4x4x1f32(av[0], bv[0], c, 0, 0, 4); d = __builtin_amdgcn_mfma_f32_4x4x1f32(av[1], bv[1], d, 0, 0, 4); \
-    c = __builtin_amdgcn_mfma_f32_4x4x1f32(av[2], bv[2], c, 0, 0, 4); d = __builtin_amdgcn_mfma_f32_4x4x1f32(av[3], bv[3], d, 0, 0, 4);
-    SNSDE_S4(a0, b0) SNSDE_S4(a1, b1)
-#undef SNSDE_S4
-    __builtin_amdgcn_sched_barrier(0);
-}
-
-// one streamed layer: sb = this layer's slice (the first half's chunks refill from it), sbn = the next streamed layer's;
-// BOFF = byte offset of the layer's input rows from the y rows (same row stride)
-template <int BOFF>
-__device__ __forceinline__ void stream_layer(uint32_t baddr, uint32_t ra, uint32_t m0v, uint32_t vo_lo, uint32_t vo_hi,
-                                             uint64_t sb, uint64_t sbn, f32x4& c, f32x4& d) {
-    stream_chunk<0, BOFF>(baddr, ra, m0v, vo_lo, vo_hi, sb, c, d);
-    stream_chunk<2, BOFF>(baddr, ra, m0v, vo_lo, vo_hi, sb, c, d);
-    stream_chunk<4, BOFF>(baddr, ra, m0v, vo_lo, vo_hi, sb, c, d);
-    stream_chunk<6, BOFF>(baddr, ra, m0v, vo_lo, vo_hi, sb, c, d);
-    stream_chunk<8, BOFF>(baddr, ra, m0v, vo_lo, vo_hi, sbn, c, d);
-    stream_chunk<10, BOFF>(baddr, ra, m0v, vo_lo, vo_hi, sbn, c, d);
-    stream_chunk<12, BOFF>(baddr, ra, m0v, vo_lo, vo_hi, sbn, c, d);
-    stream_chunk<14, BOFF>(baddr, ra, m0v, vo_lo, vo_hi, sbn, c, d);
-}
-
 template <class CF>
 __global__ void __launch_bounds__(CF::NT, 1) snsde_m4s_kernel(MfmaArgs a) {
     constexpr int H = CF::H, NT = CF::NT, NHID = CF::NHID, KUH = CF::KUH, KUXT = CF::KUXT;

@@ -244,6 +244,73 @@ __device__ __forceinline__ void gemm(const Wt<true, KU, TPW>& w, const float* in
     }
 }
 
+// ---- streamed weights through a per-wave LDS ring (H = 256, 4-row tiles; forward: snsde_m4s_kernel.h, adjoint: the
+//      STREAM && FL branch of snsde_mfma_reverse_kernel) ------------------------------------------------------------------
+// LDS byte address of a __shared__ float
+__device__ __forceinline__ uint32_t lean_lds_addr(const float* p) {
+    return (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const float*)(p);
+}
+// a wave-uniform pointer as an SGPR pair for "s" asm operands (readfirstlane folds away when hipcc knows it is uniform)
+__device__ __forceinline__ uint64_t lean_uniform(const float* p) {
+    const uint64_t v = (uint64_t)p;          // wave-uniform by construction; readfirstlane folds away when hipcc knows it
+    const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)v), hi = __builtin_amdgcn_readfirstlane((uint32_t)(v >> 32));
+    return ((uint64_t)hi << 32) | lo;
+}
+// LDS-DMA of streamed k-block G (static): layer G / 16, block u = G % 16 of the wave's slice, into ring slot u % 8.
+// Source = sb (the wave's slice of the layer, SGPR pair) + vo (lane * 16 + 4096 [+ 8192 for u >= 8]) + imm, imm =
+// (u % 8) * 1024 - 4096; the immediate also moves the LDS destination (tools/ubench/glds_probe.hip), which therefore is
+// M0 + imm + lane * 16 with M0 = ring base + 4096 for every slot.
+template <int U>
+__device__ __forceinline__ void stream_refill(uint32_t m0v, uint32_t vo_lo, uint32_t vo_hi, uint64_t sb) {
+    constexpr int IMM = (U % 8) * 1024 - 4096;
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 4\n\tglobal_load_lds_dwordx4 %1, %2 offset:%3"
+                 :: "s"(m0v), "v"(U < 8 ? vo_lo : vo_hi), "s"(sb), "n"(IMM) : "memory");
+}
+
+// One chunk: k-blocks U0, U0+1 of a layer.  B operands (lanes 0-15) from the activation row, wait for the chunk's ring
+// slots (the R - 2 younger refills may stay in flight), A operands from the ring, refill the two slots, 8 MFMAs.
+template <int U0, int BOFF>
+__device__ __forceinline__ void stream_chunk(uint32_t baddr, uint32_t ra, uint32_t m0v, uint32_t vo_lo, uint32_t vo_hi,
+                                             uint64_t sb_next, f32x4& c, f32x4& d) {
+    f32x4 b0, b1, a0, a1;
+    asm volatile("s_mov_b64 exec, 0xffff\n\t"
+                 "ds_read_b128 %0, %[b] offset:%[o0]\n\tds_read_b128 %1, %[b] offset:%[o1]\n\t"
+                 "s_mov_b64 exec, -1\n\t"
+                 "s_waitcnt vmcnt(6)\n\t"
+                 "ds_read_b128 %2, %[a] offset:%[s0]\n\tds_read_b128 %3, %[a] offset:%[s1]"
+                 : "=&v"(b0), "=&v"(b1), "=&v"(a0), "=&v"(a1)
+                 : [b] "v"(baddr), [a] "v"(ra), [o0] "n"(BOFF + U0 * 64), [o1] "n"(BOFF + U0 * 64 + 64),
+                   [s0] "n"((U0 % 8) * 1024), [s1] "n"((U0 % 8) * 1024 + 1024)
+                 : "memory");
+    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(b0), "+v"(b1), "+v"(a0), "+v"(a1));
+    // the slots are free: their next tenants are blocks U0 + 8, U0 + 9 (same layer while U0 < 8, else the next streamed
+    // layer's / next step's first blocks)
+    stream_refill<(U0 + 8) % 16>(m0v, vo_lo, vo_hi, sb_next);
+    stream_refill<(U0 + 9) % 16>(m0v, vo_lo, vo_hi, sb_next);
+#define SNSDE_S4(av, bv) \
+    c = __builtin_amdgcn_mfma_f32_4x4x1f32(av[0], bv[0], c, 0, 0, 4); d = __builtin_amdgcn_mfma_f32_4x4x1f32(av[1], bv[1], d, 0, 0, 4); \
+    c = __builtin_amdgcn_mfma_f32_4x4x1f32(av[2], bv[2], c, 0, 0, 4); d = __builtin_amdgcn_mfma_f32_4x4x1f32(av[3], bv[3], d, 0, 0, 4);
+    SNSDE_S4(a0, b0) SNSDE_S4(a1, b1)
+#undef SNSDE_S4
+    __builtin_amdgcn_sched_barrier(0);
+}
+
+// one streamed layer: sb = this layer's slice (the first half's chunks refill from it), sbn = the next streamed layer's;
+// BOFF = byte offset of the layer's input rows from the y rows (same row stride)
+template <int BOFF>
+__device__ __forceinline__ void stream_layer(uint32_t baddr, uint32_t ra, uint32_t m0v, uint32_t vo_lo, uint32_t vo_hi,
+                                             uint64_t sb, uint64_t sbn, f32x4& c, f32x4& d) {
+    stream_chunk<0, BOFF>(baddr, ra, m0v, vo_lo, vo_hi, sb, c, d);
+    stream_chunk<2, BOFF>(baddr, ra, m0v, vo_lo, vo_hi, sb, c, d);
+    stream_chunk<4, BOFF>(baddr, ra, m0v, vo_lo, vo_hi, sb, c, d);
+    stream_chunk<6, BOFF>(baddr, ra, m0v, vo_lo, vo_hi, sb, c, d);
+    stream_chunk<8, BOFF>(baddr, ra, m0v, vo_lo, vo_hi, sbn, c, d);
+    stream_chunk<10, BOFF>(baddr, ra, m0v, vo_lo, vo_hi, sbn, c, d);
+    stream_chunk<12, BOFF>(baddr, ra, m0v, vo_lo, vo_hi, sbn, c, d);
+    stream_chunk<14, BOFF>(baddr, ra, m0v, vo_lo, vo_hi, sbn, c, d);
+}
+
+
 template <int H_, int KUX_, int NHID_, int IO_, int FL_, int PHX_, int FOLD_, int NN_ = 0, int SRK_ = 0>
 struct Cfg {
     static constexpr bool SRK = SRK_ != 0;   // SRID2 stepper: three drift passes (pseudo-steps) per solver step
@@ -897,7 +964,9 @@ struct CfgR {
     static constexpr int EPT = FL ? 1 : 4;
     static constexpr int ROWCH = 128;
     static constexpr bool STREAM = H > 128;
-    static constexpr int LDS_FLOATS = NBUF * M * LDA + (ROWCH + 1) * SNSDE_STEP_STRIDE;
+    static constexpr bool RING = STREAM && FL;   // transposed weights through the per-wave LDS ring (as snsde_m4s_kernel.h)
+    static constexpr int RING0 = NBUF * M * LDA + (ROWCH + 1) * SNSDE_STEP_STRIDE;        // multiple of 4 floats
+    static constexpr int LDS_FLOATS = RING0 + (RING ? NW * 8 * 256 : 0);
 };
 
 struct RevArgs {
@@ -945,8 +1014,25 @@ __global__ void __launch_bounds__(CF::NT, CF::WPS) snsde_mfma_reverse_kernel(Rev
     const size_t goff = (size_t)rowc * H + fcol;
 
     Wt<CF::STREAM, KUH, TPW> wt[NG];
+    uint64_t sbr[NG];                 // RING: this wave's slice of every transposed matrix (SGPR pairs)
+    uint32_t ring_m0 = 0, ring_ra = 0, ring_lo = 0, ring_hi = 0;
 #pragma unroll
-    for (int g = 0; g < NG; ++g) wt[g].load(a.ws + a.w_off[g], wave, lane);
+    for (int g = 0; g < NG; ++g) {
+        if constexpr (CF::RING) sbr[g] = lean_uniform(a.ws + a.w_off[g] + (size_t)wave * KUH * 256);
+        else wt[g].load(a.ws + a.w_off[g], wave, lane);
+    }
+    if constexpr (CF::RING) {
+        const uint32_t ringb = lean_lds_addr(lds + CF::RING0) + (uint32_t)wave * (8 * 1024);
+        ring_m0 = __builtin_amdgcn_readfirstlane(ringb + 4096u);
+        ring_ra = ringb + (uint32_t)lane * 16u;
+        ring_lo = (uint32_t)lane * 16u + 4096u;
+        ring_hi = ring_lo + 8192u;
+        // the ring's first eight blocks (GEMM 0); every later block is requested eight blocks ahead of its use
+        stream_refill<0>(ring_m0, ring_lo, ring_hi, sbr[0]); stream_refill<1>(ring_m0, ring_lo, ring_hi, sbr[0]);
+        stream_refill<2>(ring_m0, ring_lo, ring_hi, sbr[0]); stream_refill<3>(ring_m0, ring_lo, ring_hi, sbr[0]);
+        stream_refill<4>(ring_m0, ring_lo, ring_hi, sbr[0]); stream_refill<5>(ring_m0, ring_lo, ring_hi, sbr[0]);
+        stream_refill<6>(ring_m0, ring_lo, ring_hi, sbr[0]); stream_refill<7>(ring_m0, ring_lo, ring_hi, sbr[0]);
+    }
     for (int i = tid; i < NS * M * LDA; i += NT) lds[i] = 0.0f;
 
     const float sig_theta = snsde_sigmoid(a.params[a.off_theta]);
@@ -972,6 +1058,8 @@ __global__ void __launch_bounds__(CF::NT, CF::WPS) snsde_mfma_reverse_kernel(Rev
     float th_acc = 0.0f;
 
     // per-step inputs from HBM are fetched one step ahead, so their latency hides behind the previous step's GEMM chain
+    // M16: the writer lanes hold the relu masks of their four features (f32x4); M4: after the k-slot reduce-scatter every
+    // lane owns ONE output (row r, feature fcol), so the mask is one float per lane (mask[g][0])
     struct StepIn { float y[EPT], z[EPT], dw[EPT], gq[EPT]; f32x4 mask[NM > 0 ? NM : 1]; f32x4 nmask; };
     auto prefetch = [&](int n, StepIn& p) {
 #pragma unroll
@@ -982,17 +1070,23 @@ __global__ void __launch_bounds__(CF::NT, CF::WPS) snsde_mfma_reverse_kernel(Rev
             if constexpr (NN > 0) p.gq[e] = a.act[(((size_t)n * NSAVE + NSAVE - 1) * B) * H + goff + e];   // diffusion-net output
             else p.gq[e] = a.gt ? a.gt[(size_t)n * H + fcol + e] : 0.0f;
         }
-        if (writer) {
+        if constexpr (FL) {
 #pragma unroll
             for (int g = 0; g < NM; ++g)     // relu mask of the forward activation feeding transposed GEMM g + 1
+                p.mask[g][0] = a.act[((size_t)n * NSAVE + (NHID - g)) * BH + goff];
+            if constexpr (NN == 2)               // hidden activation of the diffusion net
+                p.nmask[0] = a.act[((size_t)n * NSAVE + CF::ZSLOT + 1) * BH + goff];
+        } else if (writer) {
+#pragma unroll
+            for (int g = 0; g < NM; ++g)
                 p.mask[g] = *reinterpret_cast<const f32x4*>(
                     a.act + (((size_t)n * NSAVE + (NHID - g)) * B + rowc) * H + wave * 16 + fsub);
-            if constexpr (NN == 2)               // hidden activation of the diffusion net
+            if constexpr (NN == 2)
                 p.nmask = *reinterpret_cast<const f32x4*>(
                     a.act + (((size_t)n * NSAVE + CF::ZSLOT + 1) * B + rowc) * H + wave * 16 + fsub);
         }
     };
-    constexpr bool AHEAD = !CF::STREAM;   // the streamed-weight variant (H = 256) has no registers to spare for it
+    constexpr bool AHEAD = !CF::STREAM || CF::RING;   // (the M16 streamed-weight variant has no registers to spare for it)
     StepIn cur, nxt;
     if constexpr (AHEAD) prefetch(a.N - 1, cur);
 
@@ -1141,11 +1235,27 @@ __global__ void __launch_bounds__(CF::NT, CF::WPS) snsde_mfma_reverse_kernel(Rev
             const int bi = g < ND ? g : NB0 + (g - ND);     // LDS buffer / delta slot holding this GEMM's input
             const bool mid = (g < ND - 1) || (g == ND - 1 && IO0) || (g >= ND && g != NG - 1);
             acc[0] = acc2[0] = f32x4{0.f, 0.f, 0.f, 0.f};
-            gemm<FL, KUH, TPW>(wt[g], lds + bi * M * LDA + r * LDA + 4 * s, acc, acc2);
+            if constexpr (CF::RING)
+                stream_layer<0>(lean_lds_addr(lds + bi * M * LDA + r * LDA + 4 * s), ring_ra, ring_m0, ring_lo, ring_hi, sbr[g],
+                                sbr[(g + 1) % NG], acc[0], acc2[0]);
+            else
+                gemm<FL, KUH, TPW>(wt[g], lds + bi * M * LDA + r * LDA + 4 * s, acc, acc2);
             f32x4 v = acc[0] + acc2[0];
             if constexpr (FL) {
-#pragma unroll
-                for (int i = 0; i < 4; ++i) v[i] = row_ror_add(v[i]);
+                // k-slot reduce-scatter (6 DPP ops): this lane's single output (row r, feature fcol)
+                const float o = m4_reduce_scatter(v);
+                if (mid) {
+                    const float zs = g < ND ? cur.mask[g < NM ? g : 0][0] : cur.nmask[0];
+                    const float dv = zs > 0.0f ? o : 0.0f;
+                    lds[(bi + 1) * M * LDA + r * LDA + fcol] = dv;
+                    if (a.delta && row_ok) a.delta[((size_t)n * NS + bi + 1) * BH + goff] = dv;
+                    __syncthreads();
+                } else if (g == ND - 1) {
+                    adj[0] = ay[0] + o + carry[0];      // end of the drift chain
+                } else {
+                    adj[0] += o;                        // end of the diffusion net's chain
+                }
+                continue;
             }
             if (mid) {
                 // relu mask of the forward activation that produced this gradient's input: slot NHID - g (drift chain),
@@ -1180,11 +1290,19 @@ __global__ void __launch_bounds__(CF::NT, CF::WPS) snsde_mfma_reverse_kernel(Rev
         for (int off = 32; off > 0; off >>= 1) th_acc += __shfl_down(th_acc, off, 64);
         if (lane == 0) a.dth_part[blockIdx.x * CF::NW + wave] = th_acc;
     }
+    if constexpr (CF::RING) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the ring's last requests land before the wave ends
 }
 
 template <class CF>
 int launch_rev(const RevArgs& a, hipStream_t stream) {
     const size_t lds_bytes = (size_t)CF::LDS_FLOATS * sizeof(float);
+    static bool attr_set = false;   // per instantiation
+    if (lds_bytes > 64 * 1024 && !attr_set) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(snsde_mfma_reverse_kernel<CF>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes) != hipSuccess)
+            return SNSDE_ERR_LDS;
+        attr_set = true;
+    }
     const int grid = (a.B + CF::M - 1) / CF::M;
     hipLaunchKernelGGL(snsde_mfma_reverse_kernel<CF>, dim3(grid), dim3(CF::NT), lds_bytes, stream, a);
     return hipGetLastError() == hipSuccess ? SNSDE_OK : SNSDE_ERR_LAUNCH;
@@ -1541,7 +1659,7 @@ int dispatch_rev(const RevPlan& p, const RevArgs& a, hipStream_t st) {
     return SNSDE_ERR_UNSUPPORTED;
 #else
     if (p.SRK) {
-        if constexpr (FL == 1) {
+        if constexpr (FL == 1 && H <= 128) {      // (the SRK variant of the forward is instantiated up to H = 128)
 #define SNSDE_RSRK(NH_) if (p.NHID == NH_) return p.GEO ? launch_rev_srk<CfgR<H, NH_, 1, 1>>(a, st) : launch_rev_srk<CfgR<H, NH_, 0, 1>>(a, st);
             SNSDE_RSRK(0) SNSDE_RSRK(1) SNSDE_RSRK(2) SNSDE_RSRK(3)
 #undef SNSDE_RSRK
