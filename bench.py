@@ -49,7 +49,7 @@ PEAK_FP32_TFLOPS = 157.3            # MI355X_MICROARCH.md: fp32 vector = fp32 MF
 PEAK_HBM_GBS = 8000.0
 # HBM bytes per launch of the solve kernel from rocprofv3 PMC passes (FETCH_SIZE doubled per the gfx950 correction
 # in MI355X_MICROARCH.md, + WRITE_SIZE; profiles/r02_pmc_counters.txt); re-measure when the kernel's memory behaviour changes.
-HBM_TRAFFIC_BYTES_PER_LAUNCH = 38061056   # K2, lean M4 kernel (profiles/r02_pmc_counters.txt)
+HBM_TRAFFIC_BYTES_PER_LAUNCH = 38083584   # K2, lean M4 kernel (profiles/r02_pmc_counters.txt)
 
 
 def build_inputs(device, rank, io=IO, no=NO, nl=NL, b=B, h=H, c=C, l=L, nan_frac=0.3, hermite=False):

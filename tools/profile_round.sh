@@ -26,4 +26,11 @@ PY
 python $R/tools/sweep_batch.py > $O/${tag}_batch_sweep.txt 2>&1
 python $R/tools/time_configs.py > $O/${tag}_time_configs.txt 2>&1
 python $R/tools/time_train.py > $O/${tag}_time_train.txt 2>&1
+python $R/tools/time_k5.py > $O/${tag}_time_h256.txt 2>&1
+python $R/tools/time_recompute.py > $O/${tag}_recompute_modes.txt 2>&1
+python $R/tools/time_wrapper.py > $O/${tag}_time_wrapper.txt 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_train -o run -- python $R/tools/time_configs.py > /dev/null 2>&1
+cp $(find $O/stats_train -name '*kernel_stats.csv' | head -1) $O/${tag}_train_kernel_stats.csv
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_wrap -o run -- python $R/tools/prof_wrapper.py 30 > /dev/null 2>&1
+cp $(find $O/stats_wrap -name '*kernel_stats.csv' | head -1) $O/${tag}_wrapper_step_kernel_stats.csv
 cat $O/bench_prof.json | head -c 600; echo; cat $O/${tag}_pmc_counters.txt; cat $O/${tag}_batch_sweep.txt; tail -15 $O/${tag}_time_configs.txt; tail -12 $O/${tag}_time_train.txt
