@@ -205,7 +205,7 @@ MfmaPlan make_plan(const snsde_solve* s, const SnsdeNet& net, int flavor_hint) {
     p.ok = false;
     if (m.hidden_hidden_channels != H) return p;
     const bool srk = s->method == SNSDE_SRK;
-    if (srk && (H > 128 || flavor_hint == 0)) return p;      // SRK variant: M4 tiles
+    if (srk && flavor_hint == 0) return p;                   // SRK variant: M4 tiles
     if (!(H == 256 || H == 128 || H == 64 || H == 32 || H == 16)) return p;
     if (!(io >= 0 && io <= 6)) return p;
     if (io == 0 && srk) return p;                     // the y-free drift under SRK stays on the generic kernels

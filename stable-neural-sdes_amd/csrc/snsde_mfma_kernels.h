@@ -1542,7 +1542,7 @@ __global__ void __launch_bounds__(CF::NT, CF::WPS) snsde_mfma_srk_reverse_kernel
 
 template <class CF>
 int launch_rev_srk(const RevArgs& a, hipStream_t stream) {
-    const size_t lds_bytes = (size_t)CF::LDS_FLOATS * sizeof(float);
+    const size_t lds_bytes = (size_t)CF::RING0 * sizeof(float);      // (no weight ring in this kernel)
     const int grid = (a.B + CF::M - 1) / CF::M;
     hipLaunchKernelGGL(snsde_mfma_srk_reverse_kernel<CF>, dim3(grid), dim3(CF::NT), lds_bytes, stream, a);
     return hipGetLastError() == hipSuccess ? SNSDE_OK : SNSDE_ERR_LAUNCH;
@@ -1659,7 +1659,7 @@ int dispatch_rev(const RevPlan& p, const RevArgs& a, hipStream_t st) {
     return SNSDE_ERR_UNSUPPORTED;
 #else
     if (p.SRK) {
-        if constexpr (FL == 1 && H <= 128) {      // (the SRK variant of the forward is instantiated up to H = 128)
+        if constexpr (FL == 1) {
 #define SNSDE_RSRK(NH_) if (p.NHID == NH_) return p.GEO ? launch_rev_srk<CfgR<H, NH_, 1, 1>>(a, st) : launch_rev_srk<CfgR<H, NH_, 0, 1>>(a, st);
             SNSDE_RSRK(0) SNSDE_RSRK(1) SNSDE_RSRK(2) SNSDE_RSRK(3)
 #undef SNSDE_RSRK

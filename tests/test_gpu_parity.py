@@ -605,6 +605,8 @@ SRK_BWD_CASES = [
     (4, 9, 2, 9, 32, 5, 8, [0, 7], 1.0),             # y-only closed forms under SRK
     (1, 8, 2, 9, 16, 3, 8, [0, 3, 7], 0.5),
     (6, 10, 1, 9, 64, 3, 8, [0, 7], 1.0),
+    (4, 17, 2, 9, 256, 14, 8, [0, 3, 7], 1.0),       # H = 256 (streamed weights): the torch_ists default method at the K5 width
+    (6, 16, 1, 6, 256, 5, 7, [0, 6], 0.5),
 ]
 
 
@@ -972,6 +974,8 @@ SRK_CASES = [
     (1, 2, 2, 9, 64, 3, 8, [0, 3, 7], 0.5),
     (2, 9, 2, 9, 32, 3, 8, [0, 7], 1.0),
     (5, 7, 2, 9, 16, 3, 8, [0, 7], 0.5),
+    (4, 17, 2, 9, 256, 14, 9, [0, 3.5, 8], 1.0),     # H = 256 on the MFMA SRK variant (weights streamed)
+    (1, 13, 1, 5, 256, 3, 8, [0, 7], 0.5),
 ]
 
 
