@@ -220,9 +220,21 @@ def tutorial_field(dev, stream):
         assert S.fields.compose(field).verified.get(str(y0.device)) is True, 'tutorial field did not take the fused path'
         generic = event_times_ms(lambda: S.sdeint(field, y0, ts, dt=1.0 / n, method='euler',
                                                   options={'seed': 1, 'backend': 'torch'}), stream, 5, 2)
+    params = list(field.parameters())
+
+    def train_step(backend):
+        def fn():
+            for p in params:
+                p.grad = None
+            ys = S.sdeint(field, y0, ts, dt=1.0 / n, method='euler', options={'seed': 1, 'backend': backend})
+            ys[-1].square().mean().backward()
+        return fn
+    fused_train = event_times_ms(train_step('auto'), stream, 20, 5)
+    loop_train = event_times_ms(train_step('torch'), stream, 2, 1)
     return {"workload": f"tutorial NeuralLNSDEFunc-shaped field (LipSwish, num_layers=1), {rows} rows, H={hh}, C={cc}, {n} Euler "
                         "steps, whole sdeint() call incl. weight composition + noise table",
             "fused": spread(fused), "generic_graph_stepper": spread(generic),
+            "fused_forward_backward": spread(fused_train), "tensor_loop_forward_backward": spread(loop_train),
             "value": rows * n / (float(np.median(fused)) * 1e-3), "unit": "row-steps/s"}
 
 

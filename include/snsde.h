@@ -194,9 +194,13 @@ typedef struct snsde_backward {
                              /* the weight-gradient GEMMs  dW_layer = sum delta^T . layer_input                  */
     void*        workspace;  /* device scratch >= snsde_backward_workspace_bytes (separate from fwd's)    */
     size_t       workspace_bytes;
+    float*       grad_noise_table; /* snsde_param_gradients with fwd.noise_table set: optional device (N, H) out,      */
+                             /* dL/d noise_table (the caller back-propagates it through whatever produced the table) */
 } snsde_backward;
 
-int    snsde_act_slots(const snsde_model* m);             /* activation tensors saved per step, or <0     */
+int    snsde_act_slots(const snsde_model* m);             /* activation tensors saved per step, or <0: layer outputs (first, hidden.., */
+                                                          /* pre-tanh drift) [+ diffusion-net slots]; models with a smooth activation  */
+                                                          /* (SNSDE_ACT_LIPSWISH / SILU) also save every pre-activation (NL more slots) */
 int    snsde_backward_supported(const snsde_solve* s);    /* 1 / 2 / 0, see above                          */
 size_t snsde_backward_workspace_bytes(const snsde_backward* b);
 int    snsde_solve_backward(const snsde_backward* b, void* hip_stream);

@@ -41,7 +41,7 @@ class Solve(C.Structure):
 class Backward(C.Structure):
     _fields_ = [('fwd', Solve), ('grad_ys', C.c_void_p), ('adj', C.c_void_p), ('delta_save', C.c_void_p),
                 ('workspace', C.c_void_p),
-                ('workspace_bytes', C.c_size_t)]
+                ('workspace_bytes', C.c_size_t), ('grad_noise_table', C.c_void_p)]
 
 
 class SnsdeError(RuntimeError):

@@ -420,14 +420,17 @@ int snsde_act_slots(const snsde_model* m) {
     int rc = validate_model(m);
     if (rc) return rc;
     const int no = m->noise_option;   // + the diffusion net's activations (hidden for 18/19, output)
-    return m->num_hidden_layers + 1 + ((no == 18 || no == 19) ? 2 : ((no == 14 || no == 15) ? 1 : 0));
+    // smooth activations (tutorial fields): the pre-activations of the NL activated layers as well (their derivative)
+    return m->num_hidden_layers + 1 + ((no == 18 || no == 19) ? 2 : ((no == 14 || no == 15) ? 1 : 0)) +
+           (m->activation != SNSDE_ACT_RELU ? m->num_hidden_layers : 0);
 }
 
 int snsde_backward_supported(const snsde_solve* s) {
     if (!s || validate_model(&s->model)) return 0;
-    if (is_variant(s->model) || s->noise_table) return 0;      // the adjoint kernels implement the reference's field only
     SnsdeNet net;
     if (snsde_build_net(s->model, s->n_steps, &net)) return 0;
+    if (is_variant(s->model) || s->noise_table)                // tutorial-style fields: the 4-row-tile MFMA adjoint or nothing
+        return (s->kernel != SNSDE_KERNEL_GENERIC && s->kernel != SNSDE_KERNEL_MFMA_M16 && snsde_mfma_backward_supported(s, net)) ? 1 : 0;
     // 1: MFMA adjoint kernel (forward on the MFMA path with act_save); 2: generic adjoint kernel (forward on the
     // generic kernel, traj + dW_out only); 0: no fused backward for this configuration
     if (snsde_mfma_backward_supported(s, net) && s->kernel != SNSDE_KERNEL_GENERIC) return 1;

@@ -41,8 +41,9 @@ struct CfgL {
     static constexpr int LDX = ld_for(16 * (KUXT > 0 ? KUXT : 1), 16);
     static constexpr int LDA = LDY;
     static constexpr int NLAYER = NHID + 2;                   // bias rows: first, hidden.., out
-    static constexpr int NSAVE = NHID + 2;
+    static constexpr int NSAVE = NHID + 2 + (SWISH ? NHID + 1 : 0);   // outputs: first, hidden.., pre-tanh drift [, the pre-activations]
     static constexpr int ZSLOT = NHID + 1;
+    static constexpr int PRE0 = NHID + 2;                     // SWISH: slot of the first layer's pre-activation (then hidden..)
     static constexpr int ZB = 4;                              // Philox calls generated together per element
     static constexpr int ZSTASH = 4 * ZB * 64;                // floats per wave
     static constexpr int ROWCH = 128;
@@ -487,7 +488,12 @@ __global__ void __launch_bounds__(CF::NT, CF::WPS) snsde_m4_kernel(MfmaArgs a) {
             const float pre = m4_reduce_scatter(c + d);
             const float o = CF::SWISH ? lean_swish(pre, act_scale) : fmaxf(pre, 0.0f);
             *aown = o;
-            if constexpr (SAVE) { if (a.act_save && row_ok) lean_gstore(o, goff4, a.act_save + ((size_t)n * CF::NSAVE) * BH); }
+            if constexpr (SAVE) {
+                if (a.act_save && row_ok) {
+                    lean_gstore(o, goff4, a.act_save + ((size_t)n * CF::NSAVE) * BH);
+                    if constexpr (CF::SWISH) lean_gstore(pre, goff4, a.act_save + ((size_t)n * CF::NSAVE + CF::PRE0) * BH);
+                }
+            }
         }
         LT(3)
         __syncthreads();
@@ -516,7 +522,12 @@ __global__ void __launch_bounds__(CF::NT, CF::WPS) snsde_m4_kernel(MfmaArgs a) {
             const float pre = m4_reduce_scatter(c + d);
             const float o = CF::SWISH ? lean_swish(pre, act_scale) : fmaxf(pre, 0.0f);
             *(toB ? bown : aown) = o;
-            if constexpr (SAVE) { if (a.act_save && row_ok) lean_gstore(o, goff4, a.act_save + ((size_t)n * CF::NSAVE + 1 + l) * BH); }
+            if constexpr (SAVE) {
+                if (a.act_save && row_ok) {
+                    lean_gstore(o, goff4, a.act_save + ((size_t)n * CF::NSAVE + 1 + l) * BH);
+                    if constexpr (CF::SWISH) lean_gstore(pre, goff4, a.act_save + ((size_t)n * CF::NSAVE + CF::PRE0 + 1 + l) * BH);
+                }
+            }
             if (l == NHID - 1) { LT(6) }
             __syncthreads();
             if (l == NHID - 1) { LT(7) }
@@ -594,10 +605,13 @@ template <int H>
 int dispatch_lean(const MfmaPlan& p, const MfmaArgs& a, hipStream_t st) {
     const bool save = a.act_save || a.traj || a.dW_out;
     if (a.act != SNSDE_ACT_RELU) {      // tutorial fields (LipSwish / SiLU): y-dependent drift on [y | X, t], C + 1 <= 48
+    // (training mode also stores the pre-activations: one more live register, so the fullest configurations are inference-only)
 #define SNSDE_LEAN_ACT(NH_, KX_) \
     if constexpr (lean_fits(H, NH_, KX_, true)) { \
-        if (p.NHID == NH_ && p.KUXT == KX_ && p.IO != 0) \
-            return save ? launch_lean<CfgL<H, NH_, KX_, 1, 1, 1>>(a, st) : launch_lean<CfgL<H, NH_, KX_, 1, 0, 1>>(a, st); }
+        if (p.NHID == NH_ && p.KUXT == KX_ && p.IO != 0) { \
+            if (!save) return launch_lean<CfgL<H, NH_, KX_, 1, 0, 1>>(a, st); \
+            if constexpr (lean_act_save_fits(H, NH_, KX_)) return launch_lean<CfgL<H, NH_, KX_, 1, 1, 1>>(a, st); \
+            else return SNSDE_ERR_UNSUPPORTED; } }
 #ifndef SNSDE_DEV_SUBSET
         SNSDE_LEAN_ACT(0, 1) SNSDE_LEAN_ACT(1, 1) SNSDE_LEAN_ACT(2, 1) SNSDE_LEAN_ACT(3, 1)
         SNSDE_LEAN_ACT(0, 2) SNSDE_LEAN_ACT(1, 2) SNSDE_LEAN_ACT(2, 2) SNSDE_LEAN_ACT(3, 2)

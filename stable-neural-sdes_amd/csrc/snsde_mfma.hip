@@ -197,6 +197,12 @@ __global__ void snsde_srk_expand_kernel(const float* __restrict__ step_tab, cons
     o[8] = stg == 2 ? st[8] : __int_as_float(0); o[9] = st[9]; o[10] = 0.0f; o[11] = 0.0f;
 }
 
+// tutorial-style fields (variant switches of snsde_model / a caller-supplied noise table): the lean 4-row-tile kernels only
+static bool variant_of(const snsde_solve* s) {
+    const snsde_model& m = s->model;
+    return m.activation != 0 || m.drift_output != 0 || m.diffusion_output != 0 || m.time_feature != 0 || s->noise_table != nullptr;
+}
+
 // Which configurations the fast path is instantiated for.
 MfmaPlan make_plan(const snsde_solve* s, const SnsdeNet& net, int flavor_hint) {
     MfmaPlan p{};
@@ -336,6 +342,12 @@ RevPlan make_rev_plan(const snsde_solve* s, const SnsdeNet& net, const MfmaPlan&
     p.ok = false;
     if (!fp.ok || (s->method != SNSDE_EULER && s->method != SNSDE_MILSTEIN && s->method != SNSDE_SRK)) return p;
     if (fp.NN != 0 && s->method != SNSDE_EULER) return p;
+    // tutorial-style fields: the register-resident lean forward (its training-mode instantiations), Euler / Milstein
+    if (variant_of(s) && !(fp.LEAN && fp.FL == 1 && fp.H <= 128 && !fp.SRK && s->method != SNSDE_SRK &&
+                           (s->model.activation == SNSDE_ACT_RELU || lean_act_save_fits(fp.H, fp.NHID, fp.KUXT)) &&
+                           (s->model.diffusion_output == SNSDE_DIFFUSION_RAW || s->model.noise_option == 0) &&
+                           (s->noise_table != nullptr || s->model.noise_option == 0)))
+        return p;      // (a raw diffusion from a supplied table, or none: theta and noise_t take no part)
     p.SRK = fp.SRK;
     const int H = fp.H, io = fp.IO;
     p.H = H; p.NHID = fp.NHID; p.GEO = (io == 5 || io == 6) ? 1 : 0; p.FL = fp.FL; p.NW = fp.NW; p.NN = fp.NN;
@@ -488,15 +500,17 @@ const float* snsde_mfma_srk_pass_table(const snsde_solve* s, const SnsdeNet& net
 }
 
 const float* snsde_mfma_gt_table(const snsde_solve* s, const SnsdeNet& net) {
+    if (s->noise_table) return s->noise_table;
     MfmaPlan p = make_plan(s, net, -1);
     return (p.ok && p.gt_off >= 0 && s->workspace) ? static_cast<const float*>(s->workspace) + p.gt_off : nullptr;
 }
 
 bool snsde_mfma_backward_supported(const snsde_solve* s, const SnsdeNet& net) {
-    return make_rev_plan(s, net, make_plan(s, net, -1)).ok;
+    return make_rev_plan(s, net, make_plan(s, net, variant_of(s) ? 1 : -1)).ok;
 }
 
 static int flavor_hint_of(const snsde_solve* s) {
+    if (variant_of(s)) return 1;      // tutorial-style fields: 4-row tiles only (snsde_solve_forward launches them that way)
     return s->kernel == SNSDE_KERNEL_MFMA_M16 ? 0 : (s->kernel == SNSDE_KERNEL_MFMA_M4 ? 1 : -1);
 }
 
@@ -515,7 +529,7 @@ size_t snsde_mfma_backward_workspace_floats(const snsde_solve* s, const SnsdeNet
 
 int snsde_mfma_backward_launch(const snsde_backward* b, const SnsdeNet& net, hipStream_t stream) {
     const snsde_solve* s = &b->fwd;
-    const int hint = s->kernel == SNSDE_KERNEL_MFMA_M16 ? 0 : (s->kernel == SNSDE_KERNEL_MFMA_M4 ? 1 : -1);
+    const int hint = flavor_hint_of(s);
     MfmaPlan fp = make_plan(s, net, hint);
     RevPlan p = make_rev_plan(s, net, fp);
     if (!p.ok) return SNSDE_ERR_UNSUPPORTED;
@@ -534,7 +548,9 @@ int snsde_mfma_backward_launch(const snsde_backward* b, const SnsdeNet& net, hip
     hipLaunchKernelGGL(snsde_mfma_pack_kernel, dim3(16, p.n_layers), dim3(256), 0, stream, s->params, ws, job);
     RevArgs a{};
     a.params = s->params; a.ws = ws;
-    a.gt = fp.gt_off >= 0 ? static_cast<const float*>(s->workspace) + fp.gt_off : nullptr;
+    a.gt = s->noise_table ? s->noise_table : (fp.gt_off >= 0 ? static_cast<const float*>(s->workspace) + fp.gt_off : nullptr);
+    a.act_fn = s->model.activation; a.f_out = s->model.drift_output; a.g_out = s->model.diffusion_output;
+    a.nsave = s->model.num_hidden_layers + 1 + fp.NN + (s->model.activation != SNSDE_ACT_RELU ? s->model.num_hidden_layers : 0);
     a.step_tab = s->step_tab; a.out_w = s->out_w; a.traj = s->traj; a.act = s->act_save; a.dW = s->dW_out;
     a.grad_ys = b->grad_ys; a.adj = b->adj; a.delta = b->delta_save; a.row_out = s->row_out;
     if (p.SRK) {

@@ -987,7 +987,15 @@ struct RevArgs {
     float* dth_part;   // (workgroups, waves) partial sums of dL/d sigmoid(theta), or null
     int32_t B, N, T, no, off_theta, method;
     int32_t w_off[MAXL];
+    int32_t nsave;                     // activation slots per step in `act` (snsde_act_slots)
+    int32_t act_fn, f_out, g_out;      // field variants (SNSDE_ACT_*, SNSDE_DRIFT_*, SNSDE_DIFFUSION_*): 4-row tiles only
 };
+
+// d/dx [scale * x * sigmoid(x)]  (LipSwish: scale = 0.909, SiLU: 1)
+__device__ __forceinline__ float swish_grad(float x, float scale) {
+    const float sg = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(x * -1.4426950408889634f));
+    return scale * sg * fmaf(x, 1.0f - sg, 1.0f);
+}
 
 template <class CF>
 __global__ void __launch_bounds__(CF::NT, CF::WPS) snsde_mfma_reverse_kernel(RevArgs a) {
@@ -996,7 +1004,10 @@ __global__ void __launch_bounds__(CF::NT, CF::WPS) snsde_mfma_reverse_kernel(Rev
     constexpr int NB0 = NHID + 2;                // first buffer / slot of the diffusion net's chain
     constexpr bool IO0 = CF::IO0;
     constexpr int NM = IO0 ? CF::ND : CF::ND - 1;   // relu masks of the drift chain
-    constexpr int KUH = CF::KUH, EPT = CF::EPT, LDA = CF::LDA, NSAVE = CF::NSAVE, ND = CF::ND, NN = CF::NN;
+    constexpr int KUH = CF::KUH, EPT = CF::EPT, LDA = CF::LDA, ND = CF::ND, NN = CF::NN;
+    const int NSAVE = a.nsave;                   // activation slots per step (the smooth-activation variants save more)
+    const bool variant = FL && (a.act_fn != 0 || a.f_out != 0 || a.g_out != 0);      // tutorial-style fields (4-row tiles)
+    const float act_scale = a.act_fn == SNSDE_ACT_LIPSWISH ? 0.909f : 1.0f;
     extern __shared__ __attribute__((aligned(16))) float lds[];
     float* rowtab = lds + NS * M * LDA;
     const int tid = threadIdx.x, lane = tid & 63;
@@ -1073,7 +1084,7 @@ __global__ void __launch_bounds__(CF::NT, CF::WPS) snsde_mfma_reverse_kernel(Rev
         if constexpr (FL) {
 #pragma unroll
             for (int g = 0; g < NM; ++g)     // relu mask of the forward activation feeding transposed GEMM g + 1
-                p.mask[g][0] = a.act[((size_t)n * NSAVE + (NHID - g)) * BH + goff];
+                p.mask[g][0] = a.act[((size_t)n * NSAVE + (NHID - g) + (a.act_fn != 0 ? NHID + 2 : 0)) * BH + goff];
             if constexpr (NN == 2)               // hidden activation of the diffusion net
                 p.nmask[0] = a.act[((size_t)n * NSAVE + CF::ZSLOT + 1) * BH + goff];
         } else if (writer) {
@@ -1132,6 +1143,35 @@ __global__ void __launch_bounds__(CF::NT, CF::WPS) snsde_mfma_reverse_kernel(Rev
             dsv[e] = 0.0f; dq[e] = 0.0f;
             const float y = cur.y[e], z = cur.z[e], dw = cur.dw[e], gq = cur.gq[e];
             const float av = adj[e];
+            if (__builtin_expect(variant, 0)) {
+                // f = tanh z | z | z y;  g = raw = s_n or s_n y (SNSDE_DIFFUSION_RAW), else the reference's tanh(sigmoid(theta) raw)
+                float fz = 1.0f, acc = av;
+                if (a.f_out == SNSDE_DRIFT_TANH) { const float f = fast_tanh(z); fz = 1.0f - f * f; }
+                else if (a.f_out == SNSDE_DRIFT_TIMES_Y) { fz = y; acc = fmaf(av * h, z, acc); }
+                dz[e] = av * h * fz;
+                const float qq = mil * fmaf(dw, dw, -h);
+                float d = 0.0f;
+                if (a.g_out == SNSDE_DIFFUSION_RAW) {
+                    if (mul_y) { acc = fmaf(av * gq, fmaf(qq, gq, dw), acc); d = av * rowf * y * fmaf(2.0f * qq, gq, dw); }
+                    else d = av * rowf * dw;
+                } else {
+                    const float raw = mul_y ? gq * y : gq;
+                    const float g = fast_tanh(sig_theta * snsde_nan_to_num(raw));
+                    const float om = 1.0f - g * g;
+                    const bool finite = (raw - raw == 0.0f);
+                    if (mul_y && finite) {
+                        const float c = sig_theta * gq;
+                        acc = fmaf(av * om * c, dw + qq * c * fmaf(-3.0f * g, g, 1.0f), acc);
+                    }
+                    const float du = av * dw * om * rowf;
+                    d = finite ? du * sig_theta * (mul_y ? y : 1.0f) : 0.0f;
+                    if (mul_y && finite && mil != 0.0f)
+                        d = fmaf(av * rowf * om * qq * fmaf(fmaf(-3.0f * g, g, 1.0f) * sig_theta * gq, y, g), sig_theta, d);
+                }
+                ay[e] = acc;
+                if (dsum) dsv[e] = d;
+                continue;
+            }
             float ty = 1.0f, zt = z;
             if constexpr (CF::GEO) { ty = fast_tanh(y); zt = z * ty; }
             const float f = fast_tanh(zt);
@@ -1246,7 +1286,7 @@ __global__ void __launch_bounds__(CF::NT, CF::WPS) snsde_mfma_reverse_kernel(Rev
                 const float o = m4_reduce_scatter(v);
                 if (mid) {
                     const float zs = g < ND ? cur.mask[g < NM ? g : 0][0] : cur.nmask[0];
-                    const float dv = zs > 0.0f ? o : 0.0f;
+                    const float dv = __builtin_expect(a.act_fn != 0, 0) ? o * swish_grad(zs, act_scale) : (zs > 0.0f ? o : 0.0f);
                     lds[(bi + 1) * M * LDA + r * LDA + fcol] = dv;
                     if (a.delta && row_ok) a.delta[((size_t)n * NS + bi + 1) * BH + goff] = dv;
                     __syncthreads();
@@ -1577,6 +1617,10 @@ __host__ __device__ constexpr bool lean_fits(int H, int NHID, int KUXT, bool YIN
     // streamed-weight variant (snsde_m4s_kernel.h); (NHID 0, KUXT 3) would spill two registers in training mode
     if (H == 256) return YIN && NHID <= 2 && KUXT <= 3 && !(NHID == 0 && KUXT == 3);
     return (H == 32 || H == 64 || H == 128) && 4 * (KUXT + (YIN ? H / 16 : 0) + (NHID + 1) * (H / 16)) + 4 * KUXT <= (YIN ? 112 : 104);
+}
+// training-mode instantiations of the smooth-activation variants (they also store the pre-activations)
+__host__ __device__ constexpr bool lean_act_save_fits(int H, int NHID, int KUXT) {
+    return H <= 128 && lean_fits(H, NHID, KUXT, true) && 4 * (KUXT + H / 16 + (NHID + 1) * (H / 16)) + 4 * KUXT <= 104;
 }
 // largest KUXT a (input_option, KUX) class of the general kernel can meet (KUX = 5: 33..80 control channels)
 __host__ __device__ constexpr int lean_kuxt_max(int IO, int KUX) {

@@ -57,7 +57,7 @@ struct WArgs {
 };
 
 // control-path columns of the first layer's input, one row per (step, batch row): [sin t, cos t][X_c(t_n)], zero padded
-struct XArgs { const float* coeffs; const float* step_tab; float* xaux; int32_t B, C, Lm1, t_col0, t_cols, x_col0, x_cols, ldx, R; };
+struct XArgs { const float* coeffs; const float* step_tab; float* xaux; int32_t B, C, Lm1, t_col0, t_cols, x_col0, x_cols, ldx, R, raw_time; };
 
 __global__ void __launch_bounds__(256) snsde_xaux_kernel(XArgs a) {
     const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
@@ -66,7 +66,7 @@ __global__ void __launch_bounds__(256) snsde_xaux_kernel(XArgs a) {
     const int n = r / a.B, b = r - n * a.B;
     const float* st = a.step_tab + (size_t)n * SNSDE_STEP_STRIDE;
     float val = 0.0f;
-    if (j >= a.t_col0 && j < a.t_col0 + a.t_cols) val = st[2 + j - a.t_col0];
+    if (j >= a.t_col0 && j < a.t_col0 + a.t_cols) val = a.raw_time ? (j == a.t_col0 ? st[0] : 0.0f) : st[2 + j - a.t_col0];   // [t, 0] | [sin t, cos t]
     else if (j >= a.x_col0 && j < a.x_col0 + a.x_cols) {
         const int c = j - a.x_col0;
         const float* cr = a.coeffs + ((size_t)b * a.Lm1 + __float_as_int(st[5])) * 4 * a.C;
@@ -563,14 +563,15 @@ int snsde_wgrad_launch(const snsde_backward* b, const SnsdeNet& net, float* grad
         if (!pass_tab || !s.stage_save || !s.srk_tab) return SNSDE_ERR_NULL;
         a.traj = s.stage_save;                     // first-layer inputs = the stage states
     }
-    a.B = s.batch; a.H = H; a.N = wp->n_pass; a.NG = wp->nact; a.NSAVE = wp->nact;
+    const bool smooth = s.model.activation != SNSDE_ACT_RELU;      // act_save then also holds the NL pre-activations per step
+    a.B = s.batch; a.H = H; a.N = wp->n_pass; a.NG = wp->nact; a.NSAVE = wp->nact + (smooth ? s.model.num_hidden_layers : 0);
     a.ldx = wp->ldx; a.R = wp->n_pass * s.batch; a.ntiles = wp->ntiles;
     for (int i = 0; i < wp->ntiles; ++i) a.tile[i] = wp->tile[i];
     if (wp->naux > 0) {
         XArgs x{};
         x.coeffs = s.coeffs; x.step_tab = pass_tab; x.xaux = ws + wp->xaux_off;
         x.B = s.batch; x.C = C; x.Lm1 = s.knots - 1; x.t_col0 = wp->t_col0; x.t_cols = wp->xt; x.x_col0 = wp->x_col0;
-        x.x_cols = wp->x_cols; x.ldx = wp->ldx; x.R = a.R;
+        x.x_cols = wp->x_cols; x.ldx = wp->ldx; x.R = a.R; x.raw_time = s.model.time_feature == SNSDE_TIME_RAW ? 1 : 0;
         const size_t total = (size_t)a.R * wp->ldx;
         hipLaunchKernelGGL(snsde_xaux_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, x);
     }
@@ -600,6 +601,7 @@ int snsde_wgrad_launch(const snsde_backward* b, const SnsdeNet& net, float* grad
         const float* bws = static_cast<const float*>(b->workspace);
         DArgs d{};
         d.ds_part = bws + ds_off; d.dth_part = bws + dth_off; d.ds = ds; d.dth = ws + wp->dth_off;
+        if (s.noise_table && b->grad_noise_table) d.ds = b->grad_noise_table;     // dL/d(supplied table): the caller's to propagate
         d.nwg = nwg; d.n_dth = nwg * waves; d.NH = wp->tnoise ? wp->n_trow * H : 0;
         hipLaunchKernelGGL(snsde_dsum_reduce_kernel, dim3((d.NH + 63) / 64 + 1), dim3(256), 0, stream, d);
         if (two)      // (two implies the noise MLP of 16/17)
@@ -629,7 +631,7 @@ int snsde_wgrad_launch(const snsde_backward* b, const SnsdeNet& net, float* grad
         add_job(E + H, 2 * H, s0, 1, grad_params + net.init.src_b, 1, H, 1, H, 1, nullptr, nullptr);
         maxM = H; maxN = Kin > H ? Kin : H;
     }
-    const bool mlp = (no == 12 || no == 13 || no == 16 || no == 17);
+    const bool mlp = (no == 12 || no == 13 || no == 16 || no == 17) && !s.noise_table;    // (a supplied table: noise_t takes no part)
     if (mlp) {
         const float* tau = aa.tau;
         const float* src = two ? aa.dz1 : ds;          // gradient at the output of noise_t(.0)

@@ -334,9 +334,10 @@ def backward_supported(call):
 _MODE_CACHE = {}
 
 
-def backward_mode(model, batch, knots, grid, method, kernel='auto', exact_order=False):
-    """backward_supported for a solve that has not been allocated yet (memoised per configuration)."""
-    key = (model.input_channels, model.hidden_channels, model.hidden_hidden_channels, model.num_hidden_layers,
+def backward_mode(model, batch, knots, grid, method, kernel='auto', exact_order=False, table=False):
+    """backward_supported for a solve that has not been allocated yet (memoised per configuration); table: the solve
+    supplies a noise_table."""
+    key = (table, model.input_channels, model.hidden_channels, model.hidden_hidden_channels, model.num_hidden_layers,
            model.input_option, model.noise_option, model.activation, model.drift_output, model.diffusion_output,
            model.time_feature, batch, knots, grid.N, grid.T, method, kernel, exact_order)
     hit = _MODE_CACHE.get(key)
@@ -347,6 +348,7 @@ def backward_mode(model, batch, knots, grid, method, kernel='auto', exact_order=
         s.method = {'euler': _lib.EULER, 'milstein': _lib.MILSTEIN, 'srk': _lib.SRK}[method]
         s.kernel = _lib.KERNELS[kernel]
         s.flags = _lib.FLAG_EXACT_ORDER if exact_order else 0
+        s.noise_table = C.c_void_p(16) if table else None      # (only its presence matters to the query)
         hit = int(_lib.lib().snsde_backward_supported(C.byref(s)))
         _MODE_CACHE[key] = hit
     return hit
@@ -374,13 +376,18 @@ def solve_backward(call, grad_ys, stream=None, save_delta=False):
     return (adj, delta) if save_delta else adj
 
 
-def param_gradients(call, adj, delta, stream=None):
+def param_gradients(call, adj, delta, stream=None, want_table_grad=False):
     """Flat parameter gradient (the C ABI's layout) of a finished MFMA-path solve + adjoint: snsde_param_gradients
-    (split-R MFMA weight-gradient GEMMs, diffusion reductions, first-layer algebra), all on the device."""
+    (split-R MFMA weight-gradient GEMMs, diffusion reductions, first-layer algebra), all on the device.
+    want_table_grad (solves with a supplied noise_table): returns (grad, dL/d noise_table (N, H))."""
     b = _lib.Backward()
     b.fwd = call.desc
     b.fwd.flags = call.base_flags
     b.adj, b.delta_save = _ptr(adj), _ptr(delta)
+    tab_grad = None
+    if want_table_grad:
+        tab_grad = torch.zeros((call.grid.N, call.model.hidden_channels), device=adj.device, dtype=torch.float32)
+        b.grad_noise_table = _ptr(tab_grad)
     bws = call.keep_bwd[0]          # the adjoint's workspace: holds its per-workgroup diffusion-side sums
     b.workspace, b.workspace_bytes = _ptr(bws), bws.numel()
     L = _lib.lib()
@@ -392,8 +399,8 @@ def param_gradients(call, adj, delta, stream=None):
     stream = torch.cuda.current_stream(adj.device) if stream is None else stream
     _lib.check(L.snsde_param_gradients(C.byref(b), _ptr(grad), _ptr(ws), ws.numel(), C.c_void_p(stream.cuda_stream)),
                'snsde_param_gradients')
-    call.keep_pg = (ws, adj, delta)
-    return grad
+    call.keep_pg = (ws, adj, delta, tab_grad)
+    return (grad, tab_grad) if want_table_grad else grad
 
 
 def eval_fg(model, flat_params, coeffs, times_host, t, y, kernel='auto'):

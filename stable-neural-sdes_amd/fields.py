@@ -10,7 +10,8 @@ their diffusion is a function of time alone times 1 or y:
 (emb' = f_net[0] o emb, linear_out' = linear_out o f_net[-1], linear_in' = [w_t, 0, W_y] or the identity) and sets the
 variant switches of `snsde_model` (include/snsde.h: SNSDE_ACT_* / SNSDE_DRIFT_* / SNSDE_DIFFUSION_RAW / SNSDE_TIME_RAW);
 the time-only diffusion factor is evaluated ONCE per solve for every step time through the module's own g (one batched
-call over N times instead of N calls) and handed to the kernel as `snsde_solve.noise_table`.  The first solve of a module
+call over N times instead of N calls) and handed to the kernel as `snsde_solve.noise_table`.  Training keeps both of them
+in the autograd graph around the fused forward + adjoint (torchsde._ComposedSolve).  The first solve of a module
 checks the mapping against the module's own f / g through the kernel (a one-step probe); a module that fails the
 structural match or the probe is simply not recognised and takes the generic graph-captured stepper
 (torchsde._graphed_steps).
@@ -80,13 +81,18 @@ class ComposedField:
         self.parts, self.additive = parts, additive
         self.verified = {}        # device -> bool (one-step probe through the kernel)
 
-    @torch.no_grad()
-    def flat(self, dev):
+    def flat(self, dev, grad=False):
+        """The composed parameter block (float32, the C ABI's layout).  grad=True keeps the autograd graph from the module's
+        parameters to the block (training: the fused backward's flat gradient flows back through the composition)."""
+        with torch.set_grad_enabled(grad):
+            return self._flat(dev, grad)
+
+    def _flat(self, dev, grad):
         p = self.parts
         H = self.model.hidden_channels
         f64 = dict(device=dev, dtype=torch.float64)
-        W = lambda lin: lin.weight.detach().to(**f64)
-        b = lambda lin: lin.bias.detach().to(**f64)
+        W = lambda lin: (lin.weight if grad else lin.weight.detach()).to(**f64)
+        b = lambda lin: (lin.bias if grad else lin.bias.detach()).to(**f64)
         first, last = p['mlp'][0], p['mlp'][-1]
         vals = {
             'initial_network.weight': W(p['linear_X']), 'initial_network.bias': b(p['linear_X']),
@@ -105,22 +111,25 @@ class ComposedField:
         for i, lin in enumerate(p['mlp'][1:-1]):
             vals[f'linears.{i}.weight'] = W(lin)
             vals[f'linears.{i}.bias'] = b(lin)
-        out = torch.empty(self.numel, device=dev, dtype=torch.float32)
-        for name, off, shape in self.layout:
+        pieces = []
+        for name, off, shape in self.layout:          # (the layout is contiguous in this order)
             v = vals[name]
             assert tuple(v.shape) == tuple(shape), (name, tuple(v.shape), shape)
-            out[off:off + v.numel()] = v.reshape(-1).to(torch.float32)
+            pieces.append(v.reshape(-1).to(torch.float32))
+        out = torch.cat(pieces)
+        assert out.numel() == self.numel
         return out
 
-    @torch.no_grad()
-    def noise_table(self, t0s, dev):
-        """(N, H) float32: the time-only diffusion factor at every step time, through the module's own g."""
+    def noise_table(self, t0s, dev, grad=False):
+        """(N, H) float32: the time-only diffusion factor at every step time, through the module's own g (one batched call);
+        grad=True keeps its autograd graph."""
         N, H = t0s.shape[0], self.model.hidden_channels
-        ones = torch.ones(N, H, device=dev, dtype=torch.float32)
-        tab = self.sde.g(t0s.to(device=dev, dtype=torch.float32).reshape(N, 1), ones)
-        if tuple(tab.shape) != (N, H):
-            raise ValueError('g(t, y) over a column of times did not return (N, H)')
-        return tab.to(torch.float32).contiguous()
+        with torch.set_grad_enabled(grad):
+            ones = torch.ones(N, H, device=dev, dtype=torch.float32)
+            tab = self.sde.g(t0s.to(device=dev, dtype=torch.float32).reshape(N, 1), ones)
+            if tuple(tab.shape) != (N, H):
+                raise ValueError('g(t, y) over a column of times did not return (N, H)')
+            return tab.to(torch.float32).contiguous()
 
 
 def compose(sde):

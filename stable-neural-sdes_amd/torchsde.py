@@ -252,8 +252,7 @@ def _sdeint_composed(sde, y0, ts, bm, method, dt, options):
     4-row-tile kernel with the variant switches.  None = not such a field / not covered: the caller takes the generic
     stepper."""
     from . import fields
-    if torch.is_grad_enabled() and (y0.requires_grad or any(p.requires_grad for p in sde.parameters())):
-        return None           # training differentiates through the tensor-op loop (no fused adjoint for the variants)
+    needs_grad = torch.is_grad_enabled() and (y0.requires_grad or any(p.requires_grad for p in sde.parameters()))
     field = fields.compose(sde)
     coeffs = getattr(sde, 'coeffs', None)
     if field is None or not torch.is_tensor(coeffs) or coeffs.dim() != 3 or coeffs.shape[0] != y0.shape[0] \
@@ -279,6 +278,14 @@ def _sdeint_composed(sde, y0, ts, bm, method, dt, options):
     row_out = options.get('row_out')
     if row_out is not None:
         row_out = row_out.to(device=dev, dtype=torch.int32).contiguous()
+    if needs_grad:
+        # training: the composition and the module's own g stay in the autograd graph; the solve between them is the fused
+        # forward + adjoint + weight-gradient pass (flat-block and table gradients flow back through those graphs)
+        if engine.backward_mode(field.model, int(y0.shape[0]), coeffs.shape[1] + 1, grid, method, table=True) != 1:
+            return None
+        flat = field.flat(dev, grad=True)
+        tab = field.noise_table(grid.d_t0, dev, grad=True)
+        return _ComposedSolve.apply(field.model, coeffs, grid, dW, method, seed, int(row_offset), row_out, y0, flat, tab)
     tab = field.noise_table(grid.d_t0, dev)
     call = engine.SolveCall(field.model, field.flat(dev), coeffs, grid, y0.detach().to(torch.float32).contiguous(), dW=dW,
                             method=method, seed=seed, row_offset=int(row_offset), row_out=row_out, noise_table=tab)
@@ -288,6 +295,29 @@ def _sdeint_composed(sde, y0, ts, bm, method, dt, options):
         if exc.code != -4:
             raise
         return None
+
+
+class _ComposedSolve(torch.autograd.Function):
+    """Differentiable fused solve of a composed (tutorial-style) field: inputs are the composed parameter block and the
+    time-only diffusion table, both produced by ordinary torch ops from the module's parameters, so autograd carries the
+    gradients this node returns (dL/dy0, dL/d block, dL/d table) on to the module."""
+
+    @staticmethod
+    def forward(ctx, model, coeffs, grid, dW, method, seed, row_offset, row_out, y0, flat, tab):
+        y0c = y0.detach().to(torch.float32).contiguous()
+        call = engine.SolveCall(model, flat.detach().contiguous(), coeffs, grid, y0c, dW=dW, method=method, seed=seed,
+                                row_offset=row_offset, row_out=row_out, noise_table=tab.detach().contiguous(),
+                                save_traj=True, save_dW=True, save_act=True)
+        ys = call.launch()
+        ctx.call, ctx.y0_dtype = call, y0.dtype
+        return ys.to(y0.dtype) if y0.dtype != ys.dtype else ys.detach()
+
+    @staticmethod
+    def backward(ctx, grad_ys):
+        call = ctx.call
+        adj, delta = engine.solve_backward(call, grad_ys.to(torch.float32).contiguous(), save_delta=True)
+        gflat, gtab = engine.param_gradients(call, adj, delta, want_table_grad=True)
+        return (None,) * 8 + (adj[0].to(ctx.y0_dtype), gflat, gtab)
 
 
 class _FusedSolve(torch.autograd.Function):

@@ -106,3 +106,57 @@ def test_unrecognised_variants_take_the_generic_stepper(H, layers):
     field2 = TutorialField('lsde', C, 64, 1)
     field2.f_net._model.append(torch.nn.Tanh())
     assert fields.compose(field2) is None
+
+
+GRAD_CASES = [(kind, H, layers, act, method)
+              for kind in ('lsde', 'lnsde', 'lnsde_additive', 'gsde')
+              for H, layers, act, method in ((32, 1, 'lipswish', 'euler'), (64, 2, 'lipswish', 'milstein'), (128, 2, 'silu', 'euler'),
+                                             (32, 3, 'relu', 'milstein'))]
+
+
+@pytest.mark.parametrize('kind,H,layers,act,method', GRAD_CASES)
+def test_tutorial_field_training_step_fused_vs_fp64_autograd(kind, H, layers, act, method):
+    """loss.backward() through the fused solve of a tutorial-style field (forward + adjoint + weight-gradient kernels, the
+    composition and the module's own g in autograd around them) against float64 autograd through the tensor-op loop on
+    the same increments: dL/dy0 and every parameter of the module."""
+    dev = torch.device('cuda')
+    B, C, L = 19, 3, 9
+    field, times, coeffs, y0 = problem(50 + H + layers, B, H, C, L, kind, layers, act, dev)
+    dt = 0.125
+    grid = S.engine.StepGrid(times.numpy(), dt, times.numpy(), None)
+    h = (grid.t1 - grid.t0).astype(np.float64)
+    rng = np.random.default_rng(4)
+    dW = torch.from_numpy(rng.standard_normal((grid.N, B, H)) * np.sqrt(h)[:, None, None] * 0.5)
+    wsum = torch.from_numpy(rng.standard_normal((L, B, H)))
+    f64 = TutorialField(kind, C, H, layers, act).double()
+    f64.load_state_dict({k: v.double() for k, v in field.state_dict().items()})
+    f64.set_X(coeffs.double(), times.double())
+    y64 = y0.double().requires_grad_(True)
+    want = S.sdeint(f64, y64, times.double(), bm=Replay(dW), dt=dt, method=method, options={'backend': 'torch'})
+    (want * wsum).sum().backward()
+
+    field = field.to(dev)
+    field.set_X(coeffs.to(dev), times.to(dev))
+    yg = y0.to(dev).requires_grad_(True)
+    generic = S.torchsde._sdeint_torch
+    S.torchsde._sdeint_torch = lambda *a, **k: (_ for _ in ()).throw(AssertionError('fell back to the tensor-op loop'))
+    try:
+        got = S.sdeint(field, yg, times.to(dev), bm=Replay(dW.float().to(dev)), dt=dt, method=method)
+        (got * wsum.float().to(dev)).sum().backward()
+    finally:
+        S.torchsde._sdeint_torch = generic
+    assert float((got.detach().double().cpu() - want.detach()).abs().max()) <= 2e-4 * max(float(want.detach().abs().max()), 1.0)
+
+    def close(g, ref, name):
+        scale = float(ref.abs().max()) + 1e-12
+        err = float((g.double().cpu() - ref).abs().max()) / scale
+        assert err < 2e-3, (name, err, scale)
+    close(yg.grad, y64.grad, 'y0')
+    ref = dict(f64.named_parameters())
+    for name, p in field.named_parameters():
+        gr = ref[name].grad
+        if gr is None or float(gr.abs().max()) == 0.0:
+            assert p.grad is None or float(p.grad.abs().max()) < 1e-6, name
+            continue
+        assert p.grad is not None, name
+        close(p.grad, gr, name)
