@@ -160,3 +160,22 @@ def test_tutorial_field_training_step_fused_vs_fp64_autograd(kind, H, layers, ac
             continue
         assert p.grad is not None, name
         close(p.grad, gr, name)
+
+
+@pytest.mark.parametrize('kind', ['lsde', 'lnsde', 'gsde'])
+def test_tutorial_workflow_trains_on_the_fused_path(kind, monkeypatch):
+    """examples/tutorial_ou_process.py = the tutorial notebooks' workflow (OU data, Hermite coefficients, batch 16, hidden 32,
+    ts = every knot, dt = 0.05, Adam, MSE): every solve of training and evaluation must take the fused kernels (the
+    tensor-op loop is disabled), and the test error must fall."""
+    import importlib.util
+    import os
+    path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'examples', 'tutorial_ou_process.py')
+    spec = importlib.util.spec_from_file_location('tutorial_ou_process', path)
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+
+    def no_loop(*a, **k):
+        raise AssertionError('the tensor-op loop ran')
+    monkeypatch.setattr(S.torchsde, '_sdeint_torch', no_loop)
+    hist = mod.main(['--field', kind, '--epochs', '3', '--samples', '320', '--device', 'cuda'])
+    assert len(hist) == 4 and all(np.isfinite(hist)) and hist[-1] < 0.7 * hist[0], hist
