@@ -67,6 +67,75 @@ def _recognise(sde):
     return m, layout, numel
 
 
+_MFMA_SIZES = (16, 32, 64, 128, 256)
+_PAD_CACHE = {}
+
+
+def forward_path(model, batch, knots, n_steps, method='euler', kernel='auto', table=False):
+    """Name of the kernel family a forward solve of this shape takes (_lib.PATHS; host-side query)."""
+    s = _lib.Solve()
+    s.model = model
+    s.batch, s.knots, s.n_steps, s.n_out = int(batch), int(knots), int(n_steps), 2
+    s.method = {'euler': _lib.EULER, 'milstein': _lib.MILSTEIN, 'srk': _lib.SRK}[method]
+    s.kernel = _lib.KERNELS[kernel]
+    s.noise_table = C.c_void_p(16) if table else None
+    return _lib.PATHS[_lib.lib().snsde_forward_path(C.byref(s))]
+
+
+def padding_plan(model, batch, knots, n_steps, method):
+    """Hidden sizes the MFMA kernels are not instantiated for (H not in 16 / 32 / 64 / 128 / 256, or a hidden width HH != H)
+    would land on the generic VALU kernels (~13x slower).  Zero-padding the model to the next instantiated size P is exact:
+    padded hidden units have zero weights and biases (relu(0) = 0), padded state components have zero output weights
+    (tanh(0) = 0 drift) and are read by nothing (zero first-layer / diffusion-net columns), so the real components evolve
+    exactly as in the unpadded model and the padded ones are dropped from the outputs.
+    Returns (padded model struct, its layout, numel, P) when that moves the solve onto an MFMA kernel, else None."""
+    H, HH = model.hidden_channels, model.hidden_hidden_channels
+    if H in _MFMA_SIZES and HH == H:
+        return None
+    key = (model.input_channels, H, HH, model.num_hidden_layers, model.input_option, model.noise_option, int(batch), int(knots),
+           int(n_steps), method)
+    if key not in _PAD_CACHE:
+        plan = None
+        P = next((p for p in _MFMA_SIZES if p >= max(H, HH)), None)
+        if P is not None and model.activation == 0 and forward_path(model, batch, knots, n_steps, method) in ('generic', 'generic-srk'):
+            mp = model_struct(model.input_channels, P, P, model.num_hidden_layers, model.input_option, model.noise_option)
+            try:
+                layout_p, numel_p = _lib.param_layout(mp)
+                if forward_path(mp, batch, knots, n_steps, method) not in ('none', 'generic', 'generic-srk'):
+                    plan = (mp, layout_p, numel_p, P)
+            except _lib.SnsdeError:
+                plan = None
+        _PAD_CACHE[key] = plan
+    return _PAD_CACHE[key]
+
+
+def padded_flat(sde, layout, layout_p, H, P, device, grad):
+    """The padded model's parameter block from the module's parameters (torch ops: differentiable when grad).  Every tensor
+    sits in the top-left corner of its padded shape, except emb.weight whose two H-wide column blocks (yy | X_t) go to
+    columns [0, H) and [P, P + H)."""
+    params = dict(sde.named_parameters())
+    pieces = []
+    with torch.set_grad_enabled(grad):
+        for (name, _, shape), (name_p, _, shape_p) in zip(layout, layout_p):
+            assert name == name_p
+            w = params[name].to(device=device, dtype=torch.float32)
+            if not grad:
+                w = w.detach()
+            if tuple(shape) == tuple(shape_p):
+                z = w
+            else:
+                z = w.new_zeros(tuple(shape_p))
+                if name == 'emb.weight':
+                    z[:shape[0], :H] = w[:, :H]
+                    z[:shape[0], P:P + H] = w[:, H:]
+                elif w.dim() == 2:
+                    z[:shape[0], :shape[1]] = w
+                else:
+                    z[:shape[0]] = w
+            pieces.append(z.reshape(-1))
+        return torch.cat(pieces)
+
+
 def flatten_params(sde, layout, numel, device):
     """One float32 device buffer in the C ABI's layout (state_dict order).
 

@@ -214,6 +214,12 @@ def _sdeint_hip(sde, rec, y0, ts, bm, method, dt, options):
     if row_out is not None:     # per-row output selection fused into the solve: the result is (B, H)
         row_out = row_out.to(device=dev, dtype=torch.int32).contiguous()
         options = dict(options, row_out=row_out)
+    if options.get('kernel', 'auto') == 'auto' and not options.get('save_traj', False) and not options.get('recompute'):
+        pad = engine.padding_plan(model, y0c.shape[0], coeffs.shape[1] + 1, grid.N, method)
+        if pad is not None:       # a hidden size without MFMA instantiation: solve the zero-padded model (exact)
+            out = _sdeint_padded(sde, rec, pad, coeffs, grid, y0, dW, dU, method, seed, options, row_out, needs_grad)
+            if out is not None:
+                return out
     if needs_grad:
         mode = engine.backward_mode(model, y0c.shape[0], coeffs.shape[1] + 1, grid, method, options.get('kernel', 'auto'),
                                     bool(options.get('exact_order', False)))
@@ -297,27 +303,51 @@ def _sdeint_composed(sde, y0, ts, bm, method, dt, options):
         return None
 
 
+def _sdeint_padded(sde, rec, pad, coeffs, grid, y0, dW, dU, method, seed, options, row_out, needs_grad):
+    """Solve the zero-padded model (engine.padding_plan) on the MFMA kernels and drop the padded state components."""
+    model, layout, _ = rec
+    model_p, layout_p, _, P = pad
+    H, dev = model.hidden_channels, y0.device
+    if needs_grad and engine.backward_mode(model_p, int(y0.shape[0]), coeffs.shape[1] + 1, grid, method) != 1:
+        return None
+    flat = engine.padded_flat(sde, layout, layout_p, H, P, dev, needs_grad)
+    widen = lambda t: None if t is None else torch.nn.functional.pad(t, (0, P - H)).contiguous()
+    row_offset = int(options.get('row_offset', 0))
+    if needs_grad:
+        ys = _ComposedSolve.apply(model_p, coeffs, grid, widen(dW), method, seed, row_offset, row_out,
+                                  torch.nn.functional.pad(y0, (0, P - H)), flat, None, widen(dU))
+    else:
+        call = engine.SolveCall(model_p, flat, coeffs, grid, widen(y0.detach().to(torch.float32)), dW=widen(dW), method=method,
+                                seed=seed, row_offset=row_offset, dU=widen(dU), row_out=row_out)
+        ys = call.launch().to(y0.dtype)
+    return ys[..., :H]
+
+
 class _ComposedSolve(torch.autograd.Function):
     """Differentiable fused solve of a composed (tutorial-style) field: inputs are the composed parameter block and the
     time-only diffusion table, both produced by ordinary torch ops from the module's parameters, so autograd carries the
     gradients this node returns (dL/dy0, dL/d block, dL/d table) on to the module."""
 
     @staticmethod
-    def forward(ctx, model, coeffs, grid, dW, method, seed, row_offset, row_out, y0, flat, tab):
+    def forward(ctx, model, coeffs, grid, dW, method, seed, row_offset, row_out, y0, flat, tab, dU=None):
         y0c = y0.detach().to(torch.float32).contiguous()
         call = engine.SolveCall(model, flat.detach().contiguous(), coeffs, grid, y0c, dW=dW, method=method, seed=seed,
-                                row_offset=row_offset, row_out=row_out, noise_table=tab.detach().contiguous(),
+                                row_offset=row_offset, row_out=row_out, dU=dU,
+                                noise_table=None if tab is None else tab.detach().contiguous(),
                                 save_traj=True, save_dW=True, save_act=True)
         ys = call.launch()
-        ctx.call, ctx.y0_dtype = call, y0.dtype
+        ctx.call, ctx.y0_dtype, ctx.has_tab = call, y0.dtype, tab is not None
         return ys.to(y0.dtype) if y0.dtype != ys.dtype else ys.detach()
 
     @staticmethod
     def backward(ctx, grad_ys):
         call = ctx.call
         adj, delta = engine.solve_backward(call, grad_ys.to(torch.float32).contiguous(), save_delta=True)
-        gflat, gtab = engine.param_gradients(call, adj, delta, want_table_grad=True)
-        return (None,) * 8 + (adj[0].to(ctx.y0_dtype), gflat, gtab)
+        if ctx.has_tab:
+            gflat, gtab = engine.param_gradients(call, adj, delta, want_table_grad=True)
+        else:
+            gflat, gtab = engine.param_gradients(call, adj, delta), None
+        return (None,) * 8 + (adj[0].to(ctx.y0_dtype), gflat, gtab, None)
 
 
 class _FusedSolve(torch.autograd.Function):

@@ -270,3 +270,86 @@ def test_training_driver_on_gpu_uses_the_fused_path_and_learns(monkeypatch):
     assert res.test_metrics.auroc > 0.7, res.test_metrics            # the label is a function of the series' slope
     assert res.memory_usage is not None and res.memory_usage > 0
     assert getattr(res.model.model.func, '_snsde_flat', None) is not None    # the parameter arena was in use
+
+
+PAD_CASES = [
+    # io, no, NL, B, H, HH, C, L, ts, dt, method     hidden sizes without an MFMA instantiation: solved zero-padded
+    (4, 17, 2, 21, 48, 48, 5, 9, [0, 3.5, 8], 1.0, 'euler'),
+    (6, 17, 3, 9, 100, 100, 3, 9, [0, 8], 0.5, 'milstein'),
+    (3, 18, 2, 13, 40, 24, 5, 9, [0, 8], 1.0, 'euler'),          # HH != H (latent-only drifts), diffusion net
+    (2, 16, 1, 7, 200, 200, 4, 8, [0, 2.5, 7], 1.0, 'srk'),
+    (5, 6, 2, 9, 24, 72, 3, 8, [0, 7], 1.0, 'milstein'),         # sigma_diag: the padded state components random-walk, unread
+    (1, 13, 4, 11, 96, 80, 3, 8, [0, 7], 1.0, 'euler'),
+]
+
+
+@pytest.mark.parametrize('ci', range(len(PAD_CASES)))
+def test_uninstantiated_hidden_sizes_run_zero_padded_on_the_mfma_kernels(ci, monkeypatch):
+    """engine.padding_plan: H not in {16, 32, 64, 128, 256} or HH != H used to land on the generic VALU kernels; the
+    zero-padded model is exact.  States and gradients vs float64 autograd through the tensor-op loop on replayed increments,
+    and the kernel family actually launched must be an MFMA one at the padded width."""
+    io, no, NL, B, H, HH, C, L, ts, dt, method = PAD_CASES[ci]
+    rng = np.random.default_rng(4000 + ci)
+    pr = make_problem(4000 + ci, io, no, NL, B, H, C, L)          # (inputs; the parameters are redrawn below for HH)
+    ts = np.asarray(ts, np.float32)
+    torch.manual_seed(ci)
+    dW = draw_dW(4000 + ci, ts, dt, B, H)
+    dU = None
+    if method == 'srk':
+        g0, g1 = O.step_grid(ts, dt)[:2]
+        hh = (g1 - g0).astype(np.float32).reshape(-1, 1, 1)
+        dU = (hh * (0.5 * dW + np.sqrt(hh / 12) * rng.standard_normal(dW.shape).astype(np.float32))).astype(np.float32)
+    wsum = rng.standard_normal((len(ts), B, H)).astype(np.float32)
+    ref_model = S.Diffusion_model(C, H, HH, NL, input_option=io, noise_option=no)
+    with torch.no_grad():
+        for p in ref_model.parameters():
+            p.mul_(1.3)
+    state = {k: v.clone() for k, v in ref_model.state_dict().items()}
+
+    def build(dtype, device):
+        m = S.Diffusion_model(C, H, HH, NL, input_option=io, noise_option=no)
+        m.load_state_dict(state)
+        m = m.to(device=device, dtype=dtype)
+        m.set_X(torch.from_numpy(pr['coeffs']).to(device=device, dtype=dtype), torch.from_numpy(pr['times']).to(device))
+        return m, torch.from_numpy(pr['y0']).to(device=device, dtype=dtype).requires_grad_(True)
+
+    m64, y64 = build(torch.float64, 'cpu')
+    want = S.sdeint(m64, y64, torch.from_numpy(ts), method=method, dt=dt, options={'backend': 'torch'},
+                    bm=_ReplayBM(torch.from_numpy(dW).double(), None if dU is None else torch.from_numpy(dU).double()))
+    (want * torch.from_numpy(wsum).double()).sum().backward()
+
+    launched = []
+    real = S.engine.SolveCall
+
+    class Spy(real):
+        def __init__(self, model, *a, **k):
+            launched.append((model.hidden_channels, model.hidden_hidden_channels))
+            super().__init__(model, *a, **k)
+    monkeypatch.setattr(S.engine, 'SolveCall', Spy)
+    m, y0 = build(torch.float32, DEV)
+    got = S.sdeint(m, y0, torch.from_numpy(ts).to(DEV), method=method, dt=dt,
+                   bm=_ReplayBM(torch.from_numpy(dW).to(DEV), None if dU is None else torch.from_numpy(dU).to(DEV)))
+    (got * torch.from_numpy(wsum).to(DEV)).sum().backward()
+    P = next(p for p in (16, 32, 64, 128, 256) if p >= max(H, HH))
+    assert launched and all(dims == (P, P) for dims in launched), launched
+    assert tuple(got.shape) == (len(ts), B, H)
+    scale = max(float(want.detach().abs().max()), 1.0)
+    assert float((got.detach().double().cpu() - want.detach()).abs().max()) <= 2e-4 * scale
+
+    def close(g, ref, name):
+        sc = float(ref.abs().max()) + 1e-12
+        err = float((g.double().cpu() - ref).abs().max()) / sc
+        assert err < 2e-3, (name, err, sc)
+    close(y0.grad, y64.grad, 'y0')
+    ref = dict(m64.named_parameters())
+    for name, p in m.named_parameters():
+        gr = ref[name].grad
+        if gr is None or float(gr.abs().max()) == 0.0:
+            assert p.grad is None or float(p.grad.abs().max()) < 1e-6, name
+            continue
+        close(p.grad, gr, name)
+    # inference path as well, and Philox increments: the real components of the padded solve = the generic kernel's solve
+    with torch.no_grad():
+        a = S.sdeint(m, y0.detach(), torch.from_numpy(ts).to(DEV), method=method, dt=dt, options={'seed': 5})
+        b = S.sdeint(m, y0.detach(), torch.from_numpy(ts).to(DEV), method=method, dt=dt, options={'seed': 5, 'kernel': 'generic'})
+    assert float((a - b).abs().max()) <= 2e-4 * max(float(b.abs().max()), 1.0)

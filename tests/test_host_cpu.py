@@ -704,3 +704,42 @@ def test_forward_path_query_names_the_kernel_family():
     assert path(128, 21, 4, 17, 64, 'euler', kernel='generic') == 'generic'
     assert path(32, 2, 4, 13, 256, 'euler', NL=1, activation=1, drift_output=1, diffusion_output=1, time_feature=1) == 'lean'
     assert path(48, 2, 4, 13, 256, 'euler', NL=1, activation=1, drift_output=1, diffusion_output=1, time_feature=1) == 'none'
+
+
+@pytest.mark.parametrize('io,no,H,HH', [(4, 17, 48, 48), (3, 18, 40, 24), (6, 13, 20, 20), (1, 5, 24, 40), (2, 16, 12, 12), (5, 15, 10, 30)])
+def test_zero_padded_model_reproduces_the_original_on_its_real_components(io, no, H, HH):
+    """engine.padded_flat: the padded parameter block, loaded into a Diffusion_model of the padded width, gives the same
+    f and g on the real state components (and exact zeros of the drift on the padded ones) - the premise of
+    engine.padding_plan.  Pure host logic (CPU tensors)."""
+    import torch
+    from stable_neural_sdes_amd import _lib, engine
+    from tests.helpers import make_problem
+    C_, NL, B, L, P = 3, 3, 6, 7, 64
+    torch.manual_seed(io * 100 + no)
+    pr = make_problem(3, io, no, NL, B, H, C_, L)
+    small = S.Diffusion_model(C_, H, HH, NL, input_option=io, noise_option=no)
+    with torch.no_grad():
+        for p in small.parameters():
+            p.mul_(1.5)
+    times, coeffs = torch.from_numpy(pr['times']), torch.from_numpy(pr['coeffs'])
+    small.set_X(coeffs, times)
+    layout, _ = _lib.param_layout(engine.model_struct(C_, H, HH, NL, io, no))
+    mp = engine.model_struct(C_, P, P, NL, io, no)
+    layout_p, numel_p = _lib.param_layout(mp)
+    flat = engine.padded_flat(small, layout, layout_p, H, P, torch.device('cpu'), grad=False)
+    assert flat.numel() == numel_p
+    big = S.Diffusion_model(C_, P, P, NL, input_option=io, noise_option=no)
+    big.load_state_dict({name: flat[off:off + int(np.prod(shape))].view(*shape) for name, off, shape in layout_p})
+    big.set_X(coeffs, times)
+    y = torch.rand(B, H) + 0.1
+    yp = torch.nn.functional.pad(y, (0, P - H))
+    t = torch.tensor(2.5)
+    with torch.no_grad():
+        assert torch.allclose(big.f(t, yp)[:, :H], small.f(t, y), rtol=1e-5, atol=1e-6)
+        assert torch.allclose(big.g(t, yp)[:, :H], small.g(t, y), rtol=1e-5, atol=1e-6)
+        assert float(big.f(t, yp)[:, H:].abs().max()) == 0.0
+    # differentiable: the gradient of a function of the padded block reaches the module's parameters
+    small.zero_grad()
+    engine.padded_flat(small, layout, layout_p, H, P, torch.device('cpu'), grad=True).square().sum().backward()
+    w = small.linear_out.weight
+    assert torch.allclose(w.grad, 2 * w.detach())
