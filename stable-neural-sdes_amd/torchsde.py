@@ -177,6 +177,18 @@ def sdeint_adjoint(sde, y0, ts, bm=None, method=None, adjoint_method=None, adjoi
     return sdeint(sde, y0, ts, bm=bm, method=method, names=names, **kwargs)
 
 
+class _DrawnIncrements:
+    """bm(ta, tb[, return_U]) over increments that were already drawn from the caller's Brownian object, in call order: a
+    fallback from the fused path to the tensor-op loop must not query a stateful `bm` a second time."""
+
+    def __init__(self, dW, dU=None):
+        self.dW, self.dU, self.n = dW, dU, 0
+
+    def __call__(self, ta, tb=None, return_U=False, **kwargs):
+        i, self.n = self.n, self.n + 1
+        return (self.dW[i], self.dU[i]) if return_U else self.dW[i]
+
+
 def _sdeint_hip(sde, rec, y0, ts, bm, method, dt, options):
     model, layout, numel = rec
     needs_grad = torch.is_grad_enabled() and (y0.requires_grad or any(p.requires_grad for p in sde.parameters()))
@@ -232,7 +244,7 @@ def _sdeint_hip(sde, rec, y0, ts, bm, method, dt, options):
                 _UNFUSED_WARNED.add(key)
                 warnings.warn(f"sdeint: no fused backward for input_option={key[0]}, noise_option={key[1]}, method={method!r}; "
                               "differentiating through the unfused tensor-op loop (slow).")
-            return _sdeint_torch(sde, y0, ts, bm, method, dt, options, None)
+            return _sdeint_torch(sde, y0, ts, bm if dW is None else _DrawnIncrements(dW, dU), method, dt, options, None)
         return _FusedSolve.apply(sde, rec, coeffs, grid, times_host, (dW, dU), method, seed, options, y0,
                                       *[p for _, p in sde.named_parameters()])
     flat = engine.flatten_params(sde, layout, numel, dev)
@@ -247,7 +259,7 @@ def _sdeint_hip(sde, rec, y0, ts, bm, method, dt, options):
         # 7 / 14 / 15 / 18 / 19): same behaviour as the gradient path, the unfused tensor-op loop, unless strict
         if exc.code != -4 or options.get('strict', False):
             raise
-        return _sdeint_torch(sde, y0, ts, bm, method, dt, options, None)
+        return _sdeint_torch(sde, y0, ts, bm if dW is None else _DrawnIncrements(dW, dU), method, dt, options, None)
     if options.get('save_traj', False):
         sde.last_trajectory = call.traj
     return ys.to(y0.dtype)

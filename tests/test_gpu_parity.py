@@ -1065,6 +1065,8 @@ def test_spline_construction_hip_vs_oracle_large():
 
 
 # ---- randomized cross-checks between the kernel families ------------------------------------------------
+# SNSDE_FUZZ_H (exploration runs): hidden sizes drawn, e.g. SNSDE_FUZZ_H=256 to fuzz the streamed-weight kernels only
+_FUZZ_H = [int(x) for x in os.environ.get('SNSDE_FUZZ_H', '16,32,64,128').split(',')]
 def _fuzz_configs(n, seed):
     rng = np.random.default_rng(seed)
     out = []
@@ -1075,7 +1077,7 @@ def _fuzz_configs(n, seed):
         method = str(rng.choice(['euler', 'milstein', 'srk']))
         if (no in (14, 15, 18, 19) and method != 'euler') or (io == 0 and method == 'srk'):
             continue
-        H = int(rng.choice([16, 32, 64, 128]))
+        H = int(rng.choice(_FUZZ_H))
         C = int(rng.choice([2, 5, 21, 33, 40])) if method != 'srk' else int(rng.choice([2, 5, 21]))
         if no in (14, 15, 18, 19) and io in (0, 2, 4, 6) and C > 32:
             continue
