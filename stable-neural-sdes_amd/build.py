@@ -62,7 +62,9 @@ def build(force=False, verbose=False, defines=(), out=None):
     objdir = os.path.join(HERE, 'build_' + ('_'.join(d.strip('-D') for d in defines) or 'obj'))
     os.makedirs(objdir, exist_ok=True)
     cc = hipcc()
-    base = [cc, '--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-I', INCLUDE, '-I', CSRC] + list(defines)
+    # --offload-compress: the device code objects (~24 of the library's 27 MB uncompressed) are stored zstd-compressed
+    # and inflated by the HIP runtime when the library is loaded
+    base = [cc, '--offload-arch=gfx950', '--offload-compress', '-O3', '-std=c++17', '-fPIC', '-I', INCLUDE, '-I', CSRC] + list(defines)
 
     def compile_one(src):
         obj = os.path.join(objdir, os.path.basename(src)[:-4] + '.o')
