@@ -214,7 +214,6 @@ MfmaPlan make_plan(const snsde_solve* s, const SnsdeNet& net, int flavor_hint) {
     if (srk && flavor_hint == 0) return p;                   // SRK variant: M4 tiles
     if (!(H == 256 || H == 128 || H == 64 || H == 32 || H == 16)) return p;
     if (!(io >= 0 && io <= 6)) return p;
-    if (io == 0 && srk) return p;                     // the y-free drift under SRK stays on the generic kernels
     const bool noise_net = (no == 14 || no == 15 || no == 18 || no == 19);
     // table noise: raw = (row of a per-step table) x {1, y}: the time-only noise MLPs and the closed forms in t, sigma
     const bool tab_noise = (no >= 1 && no <= 6) || no == 11 || no == 12 || no == 13 || no == 16 || no == 17;
@@ -222,7 +221,7 @@ MfmaPlan make_plan(const snsde_solve* s, const SnsdeNet& net, int flavor_hint) {
     if (!(no == 0 || tab_noise || y_noise || noise_net)) return p;
     if (noise_net && (io == 0 || io == 2 || io == 4 || io == 6) && m.input_channels > 32) return p;   // nets + wide control: generic
     if (noise_net && s->method != SNSDE_EULER) return p;
-    if (srk && (m.input_channels > 32 && (io == 2 || io == 4 || io == 6))) return p;
+    if (srk && m.input_channels > 32 && (io == 0 || m.num_hidden_layers > 3)) return p;   // wide control under SRK: embedded drifts, NL <= 3
     const bool emb = (io == 2 || io == 4 || io == 6);
     const int nhid = m.num_hidden_layers - 1;
     if (nhid > 3) return p;
@@ -350,6 +349,7 @@ RevPlan make_rev_plan(const snsde_solve* s, const SnsdeNet& net, const MfmaPlan&
         return p;      // (a raw diffusion from a supplied table, or none: theta and noise_t take no part)
     p.SRK = fp.SRK;
     const int H = fp.H, io = fp.IO;
+    if (p.SRK && io == 0) return p;      // (the SRK adjoint kernel has no y-free variant: the generic adjoint takes it)
     p.H = H; p.NHID = fp.NHID; p.GEO = (io == 5 || io == 6) ? 1 : 0; p.FL = fp.FL; p.NW = fp.NW; p.NN = fp.NN;
     p.emb = (io == 2 || io == 4 || io == 6) ? 1 : 0;
     p.IO0 = io == 0 ? 1 : 0;

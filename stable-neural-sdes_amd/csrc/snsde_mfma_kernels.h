@@ -1660,9 +1660,10 @@ int dispatch_io(const MfmaPlan& p, const MfmaArgs& a, hipStream_t st) {
     if (p.SRK) {           // SRID2 stepper: M4 tiles, folded first layer, C <= 32, elementwise diffusions
         if constexpr (FL == 1) {
 #define SNSDE_SRKC(IO_, NHID_) \
-    if (p.IO == IO_ && p.NHID == NHID_) return launch_cfg<Cfg<H, (IO_ % 2 == 0 ? 2 : 1), NHID_, IO_, 1, 1, 1, 0, 1>>(a, st);
+    if (p.IO == IO_ && p.NHID == NHID_ && p.KUX != 5) return launch_cfg<Cfg<H, (IO_ % 2 == 0 ? 2 : 1), NHID_, IO_, 1, 1, (IO_ != 0 ? 1 : 0), 0, 1>>(a, st); \
+    if (p.IO == IO_ && p.NHID == NHID_ && p.KUX == 5 && IO_ % 2 == 0 && IO_ != 0 && NHID_ <= 2) return launch_cfg<Cfg<H, (IO_ % 2 == 0 && IO_ != 0 && NHID_ <= 2 ? 5 : 1), NHID_, IO_, 1, 1, 1, 0, 1>>(a, st);
 #define SNSDE_SRKS(IO_) SNSDE_SRKC(IO_, 0) SNSDE_SRKC(IO_, 1) SNSDE_SRKC(IO_, 2) SNSDE_SRKC(IO_, 3)
-            SNSDE_SRKS(1) SNSDE_SRKS(2) SNSDE_SRKS(3) SNSDE_SRKS(4) SNSDE_SRKS(5) SNSDE_SRKS(6)
+            SNSDE_SRKS(0) SNSDE_SRKS(1) SNSDE_SRKS(2) SNSDE_SRKS(3) SNSDE_SRKS(4) SNSDE_SRKS(5) SNSDE_SRKS(6)
 #undef SNSDE_SRKS
 #undef SNSDE_SRKC
         }

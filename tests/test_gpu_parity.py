@@ -607,6 +607,8 @@ SRK_BWD_CASES = [
     (6, 10, 1, 9, 64, 3, 8, [0, 7], 1.0),
     (4, 17, 2, 9, 256, 14, 8, [0, 3, 7], 1.0),       # H = 256 (streamed weights): the torch_ists default method at the K5 width
     (6, 16, 1, 6, 256, 5, 7, [0, 6], 0.5),
+    (4, 17, 2, 9, 64, 40, 8, [0, 3, 7], 1.0),        # wide control path (C > 32) under SRK
+    (6, 13, 3, 7, 128, 69, 7, [0, 6], 1.0),
 ]
 
 
@@ -976,6 +978,11 @@ SRK_CASES = [
     (5, 7, 2, 9, 16, 3, 8, [0, 7], 0.5),
     (4, 17, 2, 9, 256, 14, 9, [0, 3.5, 8], 1.0),     # H = 256 on the MFMA SRK variant (weights streamed)
     (1, 13, 1, 5, 256, 3, 8, [0, 7], 0.5),
+    (0, 17, 2, 9, 64, 5, 8, [0, 7], 1.0),            # y-free drift and wide control paths on the MFMA SRK variant
+    (0, 4, 1, 6, 128, 21, 8, [0, 3, 7], 0.5),
+    (4, 17, 2, 9, 64, 40, 9, [0, 8], 1.0),
+    (6, 16, 3, 7, 128, 69, 8, [0, 7], 1.0),
+    (2, 12, 1, 9, 32, 33, 8, [0, 2.5, 7], 0.5),
 ]
 
 
