@@ -743,3 +743,30 @@ def test_zero_padded_model_reproduces_the_original_on_its_real_components(io, no
     engine.padded_flat(small, layout, layout_p, H, P, torch.device('cpu'), grad=True).square().sum().backward()
     w = small.linear_out.weight
     assert torch.allclose(w.grad, 2 * w.detach())
+
+
+@pytest.mark.parametrize('ts,dt,chunk', [([0, 12], 1.0, 5), ([0, 2.5, 4, 8], 0.5, 3), (list(range(10)), 1.0, 4), ([0, 0.3, 0.35, 1.0], 0.25, 1)])
+def test_recompute_chunks_partition_the_step_table(ts, dt, chunk):
+    """engine.sub_grid / chunk_plan (recompute-mode backward): the chunks' step rows are the parent's rows, every parent output
+    belongs to exactly one chunk with its interpolation weights, each chunk ends with an on-grid output (the hand-over state)
+    and the per-step output bookkeeping (count, first index) is consistent with the chunk's own out_step list."""
+    from stable_neural_sdes_amd import engine
+    times = np.linspace(0, max(ts), 9).astype(np.float32)
+    g = engine.StepGrid(np.asarray(ts, np.float32), dt, times, None)
+    plan = engine.chunk_plan(g, chunk)
+    assert [(a, b) for a, b, _, _ in plan] == [(n0, min(n0 + chunk, g.N)) for n0 in range(0, g.N, chunk)]
+    seen = []
+    for n0, n1, sub, ks in plan:
+        assert sub.N == n1 - n0 and sub.T == len(ks) + 2
+        np.testing.assert_array_equal(sub.step_tab[:, :8], g.step_tab[n0:n1, :8])          # same times / sizes / spline intervals
+        for j, k in enumerate(ks):                       # parent output k (ys index) = sub output j + 1
+            assert sub.out_step[j] == g.out_step[k - 1] - n0
+            np.testing.assert_array_equal(sub.out_w[j], g.out_w[k - 1])
+        assert sub.out_step[-1] == sub.N - 1 and tuple(sub.out_w[-1]) == (0.0, 1.0)
+        nout = sub.step_tab[:, 8].view(np.int32)
+        first = sub.step_tab[:, 9].view(np.int32)
+        for n in range(sub.N):
+            idx = [j for j, st in enumerate(sub.out_step) if st == n]
+            assert nout[n] == len(idx) and (not idx or first[n] == idx[0])
+        seen += ks
+    assert seen == list(range(1, g.T))
