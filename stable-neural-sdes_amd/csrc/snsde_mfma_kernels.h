@@ -1071,24 +1071,8 @@ __global__ void __launch_bounds__(CF::NT, CF::WPS) snsde_mfma_reverse_kernel(Rev
     // per-step inputs from HBM are fetched one step ahead, so their latency hides behind the previous step's GEMM chain
     // M16: the writer lanes hold the relu masks of their four features (f32x4); M4: after the k-slot reduce-scatter every
     // lane owns ONE output (row r, feature fcol), so the mask is one float per lane (mask[g][0])
-    // gk / w0 / w1 / nout / kfirst: the step's FIRST emitted output (ts = every knot, the wrappers' case: one per step) with
-    // its gradient row, fetched with the other inputs so that no load sits at the top of the step's dependent chain
-    struct StepIn { float y[EPT], z[EPT], dw[EPT], gq[EPT], gk[EPT]; f32x4 mask[NM > 0 ? NM : 1]; f32x4 nmask;
-                    float w0, w1; int nout, kfirst; };
+    struct StepIn { float y[EPT], z[EPT], dw[EPT], gq[EPT]; f32x4 mask[NM > 0 ? NM : 1]; f32x4 nmask; };
     auto prefetch = [&](int n, StepIn& p) {
-        {
-            const float* sr = a.step_tab + (size_t)n * SNSDE_STEP_STRIDE;
-            p.nout = __float_as_int(sr[8]); p.kfirst = __float_as_int(sr[9]);
-            p.w0 = 0.0f; p.w1 = 1.0f;
-#pragma unroll
-            for (int e = 0; e < EPT; ++e) p.gk[e] = 0.0f;
-            if (p.nout > 0) {
-                p.w0 = a.out_w[2 * p.kfirst]; p.w1 = a.out_w[2 * p.kfirst + 1];
-#pragma unroll
-                for (int e = 0; e < EPT; ++e)
-                    p.gk[e] = a.row_out ? (rslot == p.kfirst + 1 ? gfin[e] : 0.0f) : a.grad_ys[(size_t)(p.kfirst + 1) * BH + goff + e];
-            }
-        }
 #pragma unroll
         for (int e = 0; e < EPT; ++e) {
             p.y[e] = a.traj[(size_t)n * BH + goff + e];
@@ -1133,20 +1117,13 @@ __global__ void __launch_bounds__(CF::NT, CF::WPS) snsde_mfma_reverse_kernel(Rev
         }
         const float* st = rowtab + (n - rbase) * SNSDE_STEP_STRIDE;
         const float h = st[1];
-        const int nout = cur.nout, kfirst = cur.kfirst;
+        const int nout = __float_as_int(st[8]), kfirst = __float_as_int(st[9]);
 
         // outputs emitted after step n: ys[k+1] = y_{n+1}  or  w0 y_n + w1 y_{n+1}
         float carry[EPT];
 #pragma unroll
         for (int e = 0; e < EPT; ++e) carry[e] = 0.0f;
-        if (cur.nout > 0) {          // first output of the step: prefetched
-#pragma unroll
-            for (int e = 0; e < EPT; ++e) {
-                if (cur.w0 == 0.0f) adj[e] += cur.gk[e];
-                else { adj[e] = fmaf(cur.w1, cur.gk[e], adj[e]); carry[e] = fmaf(cur.w0, cur.gk[e], carry[e]); }
-            }
-        }
-        for (int k = kfirst + 1; k < kfirst + nout; ++k) {      // further outputs inside the same step (dt > output spacing)
+        for (int k = kfirst; k < kfirst + nout; ++k) {
             const float w0 = a.out_w[2 * k], w1 = a.out_w[2 * k + 1];
 #pragma unroll
             for (int e = 0; e < EPT; ++e) {
