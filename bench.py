@@ -353,10 +353,22 @@ def main():
         if not args.no_cpu_baseline and world == 1:     # reported at N = 1 only (the other ranks would idle behind it)
             out["cpu_baseline"] = cpu_baseline(pr, params)
             out["speedup_vs_cpu"] = value / world / out["cpu_baseline"]["value"]
-        print(json.dumps(out))
+        line = json.dumps(out)
+    else:
+        line = None
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
+    if line is not None:
+        # the JSON line is the LAST thing on stdout: RCCL writes a version banner through C stdio (flushed at exit when
+        # stdout is a pipe), so flush that first
+        import ctypes
+        try:
+            ctypes.CDLL(None).fflush(None)
+        except OSError:
+            pass
+        sys.stdout.flush()
+        print(line, flush=True)
 
 
 if __name__ == '__main__':
