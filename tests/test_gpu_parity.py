@@ -400,14 +400,15 @@ def test_mfma_unsupported_configuration_is_refused_not_silently_rerouted():
     assert np.isfinite(ys).all()
 
 
+@pytest.mark.parametrize('H', [128, 256])       # 256: the streamed-weight kernel keeps its Philox normals in registers
 @pytest.mark.parametrize('kernel', ['mfma16', 'mfma4'])
-def test_mfma_philox_spec_and_shard_invariance(kernel):
-    pr = make_problem(31, 4, 17, 2, 96, 128, 21, 9)
+def test_mfma_philox_spec_and_shard_invariance(kernel, H):
+    pr = make_problem(31, 4, 17, 2, 96, H, 21, 9)
     ts, dt = [0, 2.5, 8], 0.5
     ys, call = hip_solve(pr, ts, dt, dW=None, seed=0xABCDEF0123, row_offset=4096, save_dW=True, kernel=kernel)
     t0, t1, *_ = O.step_grid(np.asarray(ts, np.float32), dt)
     got = call.dW_out.cpu().numpy()
-    np.testing.assert_allclose(got, O.philox_dW(0xABCDEF0123, 4096, 96, 128, t0, t1), rtol=2e-6, atol=2e-7)
+    np.testing.assert_allclose(got, O.philox_dW(0xABCDEF0123, 4096, 96, H, t0, t1), rtol=2e-6, atol=2e-7)
     ref64, _ = oracle_solve(pr, ts, dt, got, 'euler', np.float64)
     assert_parity(ys, ref64, what='mfma philox')
     # the increments are the same stream the generic kernel draws
