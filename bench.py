@@ -200,17 +200,17 @@ def strong_k5(dev, rank, world, stream, barrier, maxr, dist):
             "steps": k}
 
 
-def tutorial_field(dev, stream):
-    """Tutorial-style field (reference tutorial/*.ipynb cell 7: LipSwish MLPs, raw time, g(t) * y) through torchsde.sdeint:
-    the fused composed-field path (fields.py) next to the generic graph-captured stepper on the same module; 1024 rows,
-    H=128, 100 Euler steps."""
+def tutorial_field(dev, stream, kind='lnsde', rows=1024, hh=128, n=100):
+    """Tutorial-style field (reference tutorial/*.ipynb cell 7: LipSwish MLPs, raw time, g(t) [* y]) through torchsde.sdeint:
+    the fused composed-field path (fields.py) next to the generic graph-captured stepper on the same module.  Defaults: the
+    K2-sized case (1024 rows, H=128, 100 Euler steps); BASELINE config 0 is (kind='lsde', 256 rows, H=32, 50 steps)."""
     from tests.helpers import make_problem
     from tests.tutorial_fields import TutorialField
-    rows, hh, cc, n = 1024, 128, 2, 100
+    cc = 2
     times = np.linspace(0.0, 1.0, 11).astype(np.float32)
     pr = make_problem(99, 4, 17, 2, rows, hh, cc, len(times), times=times)
     torch.manual_seed(99)
-    field = TutorialField('lnsde', cc, hh, 1).to(dev)
+    field = TutorialField(kind, cc, hh, 1).to(dev)
     tt = torch.from_numpy(times).to(dev)
     field.set_X(torch.from_numpy(pr['coeffs']).to(dev), tt)
     y0 = torch.from_numpy(pr['y0']).to(dev)
@@ -231,7 +231,7 @@ def tutorial_field(dev, stream):
         return fn
     fused_train = event_times_ms(train_step('auto'), stream, 20, 5)
     loop_train = event_times_ms(train_step('torch'), stream, 2, 1)
-    return {"workload": f"tutorial NeuralLNSDEFunc-shaped field (LipSwish, num_layers=1), {rows} rows, H={hh}, C={cc}, {n} Euler "
+    return {"workload": f"tutorial Neural{kind.upper()}Func-shaped field (LipSwish, num_layers=1), {rows} rows, H={hh}, C={cc}, {n} Euler "
                         "steps, whole sdeint() call incl. weight composition + noise table",
             "fused": spread(fused), "generic_graph_stepper": spread(generic),
             "fused_forward_backward": spread(fused_train), "tensor_loop_forward_backward": spread(loop_train),
@@ -319,6 +319,7 @@ def main():
         extra["K5_strong_train"] = strong_k5(dev, rank, world, stream, barrier, maxr, dist)
         if world == 1:
             extra["tutorial_field"] = tutorial_field(dev, stream)
+            extra["K1_tutorial_lsde"] = tutorial_field(dev, stream, kind='lsde', rows=256, hh=32, n=50)
 
     if rank == 0:
         rowsteps = B * NSTEP

@@ -80,12 +80,24 @@ class ComposedField:
         self.sde, self.model, self.layout, self.numel = sde, model, layout, numel
         self.parts, self.additive = parts, additive
         self.verified = {}        # device -> bool (one-step probe through the kernel)
+        self._flat_cache = None
+        self._tab_cache = None
 
     def flat(self, dev, grad=False):
         """The composed parameter block (float32, the C ABI's layout).  grad=True keeps the autograd graph from the module's
         parameters to the block (training: the fused backward's flat gradient flows back through the composition)."""
-        with torch.set_grad_enabled(grad):
-            return self._flat(dev, grad)
+        if grad:
+            with torch.enable_grad():
+                return self._flat(dev, True)
+        # inference: the block only changes when a parameter does (every in-place update bumps the tensor's version counter,
+        # a re-assigned .data / a new Parameter changes the address), so repeated solves reuse it
+        key = (str(dev),) + tuple((q.data_ptr(), q._version) for q in self.sde.parameters())
+        hit = self._flat_cache
+        if hit is None or hit[0] != key:
+            with torch.no_grad():
+                hit = (key, self._flat(dev, False))
+            self._flat_cache = hit
+        return hit[1]
 
     def _flat(self, dev, grad):
         p = self.parts
@@ -124,12 +136,20 @@ class ComposedField:
         """(N, H) float32: the time-only diffusion factor at every step time, through the module's own g (one batched call);
         grad=True keeps its autograd graph."""
         N, H = t0s.shape[0], self.model.hidden_channels
+        key = None
+        if not grad and t0s.is_cuda:       # (same step times tensor of a cached grid + unchanged parameters: reuse the table)
+            key = (t0s.data_ptr(), N, str(dev)) + tuple((q.data_ptr(), q._version) for q in self.sde.parameters())
+            if self._tab_cache is not None and self._tab_cache[0] == key:
+                return self._tab_cache[1]
         with torch.set_grad_enabled(grad):
             ones = torch.ones(N, H, device=dev, dtype=torch.float32)
             tab = self.sde.g(t0s.to(device=dev, dtype=torch.float32).reshape(N, 1), ones)
             if tuple(tab.shape) != (N, H):
                 raise ValueError('g(t, y) over a column of times did not return (N, H)')
-            return tab.to(torch.float32).contiguous()
+            tab = tab.to(torch.float32).contiguous()
+        if key is not None:
+            self._tab_cache = (key, tab, t0s)      # (holds t0s: its address stays valid while cached)
+        return tab
 
 
 def compose(sde):

@@ -179,3 +179,35 @@ def test_tutorial_workflow_trains_on_the_fused_path(kind, monkeypatch):
     monkeypatch.setattr(S.torchsde, '_sdeint_torch', no_loop)
     hist = mod.main(['--field', kind, '--epochs', '3', '--samples', '320', '--device', 'cuda'])
     assert len(hist) == 4 and all(np.isfinite(hist)) and hist[-1] < 0.7 * hist[0], hist
+
+
+def test_composed_block_and_table_caches_follow_parameter_updates():
+    """Inference solves reuse the composed parameter block and the diffusion table while no parameter changed; an in-place
+    update (what an optimizer step does) or a re-assigned parameter must be seen by the next solve."""
+    import copy
+    dev = torch.device('cuda')
+    B, H, C, L = 16, 32, 2, 9
+    field, times, coeffs, y0 = problem(77, B, H, C, L, 'lnsde', 1, 'lipswish', dev)
+    field = field.to(dev)
+    field.set_X(coeffs.to(dev), times.to(dev))
+
+    def solve(f):
+        with torch.no_grad():
+            return S.sdeint(f, y0.to(dev), times.to(dev), dt=0.05, method='euler', options={'seed': 3})
+    a1, a2 = solve(field), solve(field)
+    assert torch.equal(a1, a2)
+    cf = fields.compose(field)
+    assert cf._flat_cache is not None and cf._tab_cache is not None
+    with torch.no_grad():
+        field.linear_out.weight.mul_(1.25)           # in-place: version counter
+        field.g_net._model[0].bias.add_(0.05)
+    b1 = solve(field)
+    fresh = copy.deepcopy(field)
+    fresh.__dict__.pop('_snsde_composed', None)       # no cache at all
+    fresh.set_X(coeffs.to(dev), times.to(dev))
+    assert not torch.equal(a1, b1) and torch.equal(b1, solve(fresh))
+    field.linear_X.weight = torch.nn.Parameter(field.linear_X.weight.detach() * 0.5)     # re-assigned parameter: new address
+    fresh2 = copy.deepcopy(field)
+    fresh2.__dict__.pop('_snsde_composed', None)
+    fresh2.set_X(coeffs.to(dev), times.to(dev))
+    assert torch.equal(solve(field), solve(fresh2)) and not torch.equal(solve(field), b1)
