@@ -102,7 +102,9 @@ class ComposedField:
     def _flat(self, dev, grad):
         p = self.parts
         H = self.model.hidden_channels
-        f64 = dict(device=dev, dtype=torch.float64)
+        # float64 products for the (cached) inference block; training composes in float32: a third of the launches, and the
+        # products' rounding is that of the kernels' own arithmetic
+        f64 = dict(device=dev, dtype=torch.float32 if grad else torch.float64)
         W = lambda lin: (lin.weight if grad else lin.weight.detach()).to(**f64)
         b = lambda lin: (lin.bias if grad else lin.bias.detach()).to(**f64)
         first, last = p['mlp'][0], p['mlp'][-1]
