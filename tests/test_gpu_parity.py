@@ -400,6 +400,24 @@ def test_mfma_unsupported_configuration_is_refused_not_silently_rerouted():
     assert np.isfinite(ys).all()
 
 
+@pytest.mark.parametrize('H,method', [(32, 'euler'), (64, 'milstein'), (128, 'euler'), (256, 'milstein'), (256, 'euler')])
+def test_long_solves_cross_the_step_table_chunks(H, method):
+    """More than 128 solver steps: the kernels re-stage their step-table rows in LDS chunk by chunk (forward: lean /
+    streamed kernels; backward: the adjoint kernel).  States vs the float64 oracle, gradients vs float64 autograd, with two
+    off-grid outputs among the 300 steps."""
+    io, no, NL, B, C, L = 4, 17, 2, 9, 5, 9
+    pr = make_problem(700 + H, io, no, NL, B, H, C, L)
+    ts = np.asarray([0.0, 3.1, 8.0], np.float32)
+    dt = 8.0 / 300
+    dW = draw_dW(700 + H, ts, dt, B, H)
+    assert dW.shape[0] > 256
+    ys, _ = hip_solve(pr, ts, dt, dW=dW, method=method, kernel='mfma4')
+    ref64, _ = oracle_solve(pr, ts, dt, dW, method, np.float64)
+    cpu32, _ = oracle_solve(pr, ts, dt, dW, method, np.float32)
+    assert_parity(ys, ref64, cpu32, what=f'long solve H={H}')
+    _check_backward(700 + H, io, no, NL, B, H, C, L, list(ts), dt, method, 'mfma4')
+
+
 @pytest.mark.parametrize('H', [128, 256])       # 256: the streamed-weight kernel keeps its Philox normals in registers
 @pytest.mark.parametrize('kernel', ['mfma16', 'mfma4'])
 def test_mfma_philox_spec_and_shard_invariance(kernel, H):
