@@ -248,6 +248,7 @@ def verify(field, coeffs, times_host, dev):
     y0 = (torch.rand(rows, H, generator=gen) + 0.5).to(dev)
     saved = (sde.coeffs, sde.times)
     ok = False
+    drift0 = field.model.drift_output          # (kept if the probe fails here but passed on another device)
     try:
         sde.set_X(c, sde.times) if hasattr(sde, 'set_X') else None
         tt = torch.tensor(float(grid.t0[0]), device=dev)
@@ -274,5 +275,7 @@ def verify(field, coeffs, times_host, dev):
     finally:
         if hasattr(sde, 'set_X'):
             sde.set_X(*saved)
+        if not ok:
+            field.model.drift_output = drift0
     field.verified[str(dev)] = ok
     return ok
