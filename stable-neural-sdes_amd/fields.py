@@ -82,6 +82,19 @@ class ComposedField:
         self.verified = {}        # device -> bool (one-step probe through the kernel)
         self._flat_cache = None
         self._tab_cache = None
+        self._proj = None
+
+    def _param_key(self, dev):
+        """Identity of the module's current parameter VALUES: addresses and version counters (re-assigned parameters,
+        optimizer steps, copy_ / load_state_dict) plus a fingerprint of the contents - a fixed random projection of all
+        parameters, two small launches and one host read - because in-place updates through `param.data` (p.data.add_(..),
+        clamp_ ...) leave the version counter untouched."""
+        params = list(self.sde.parameters())
+        vec = torch.cat([q.detach().reshape(-1).to(device=dev, dtype=torch.float32) for q in params])
+        if self._proj is None or self._proj.numel() != vec.numel() or self._proj.device != vec.device:
+            gen = torch.Generator().manual_seed(0x5DE)
+            self._proj = torch.randn(vec.numel(), generator=gen).to(vec.device)
+        return (str(dev), float(torch.dot(vec, self._proj))) + tuple((q.data_ptr(), q._version) for q in params)
 
     def flat(self, dev, grad=False):
         """The composed parameter block (float32, the C ABI's layout).  grad=True keeps the autograd graph from the module's
@@ -89,9 +102,8 @@ class ComposedField:
         if grad:
             with torch.enable_grad():
                 return self._flat(dev, True)
-        # inference: the block only changes when a parameter does (every in-place update bumps the tensor's version counter,
-        # a re-assigned .data / a new Parameter changes the address), so repeated solves reuse it
-        key = (str(dev),) + tuple((q.data_ptr(), q._version) for q in self.sde.parameters())
+        # inference: the block only changes when a parameter does, so repeated solves reuse it (key: see _param_key)
+        key = self._param_key(dev)
         hit = self._flat_cache
         if hit is None or hit[0] != key:
             with torch.no_grad():
@@ -140,7 +152,7 @@ class ComposedField:
         N, H = t0s.shape[0], self.model.hidden_channels
         key = None
         if not grad and t0s.is_cuda:       # (same step times tensor of a cached grid + unchanged parameters: reuse the table)
-            key = (t0s.data_ptr(), N, str(dev)) + tuple((q.data_ptr(), q._version) for q in self.sde.parameters())
+            key = (t0s.data_ptr(), N) + self._param_key(dev)
             if self._tab_cache is not None and self._tab_cache[0] == key:
                 return self._tab_cache[1]
         with torch.set_grad_enabled(grad):

@@ -206,6 +206,13 @@ def test_composed_block_and_table_caches_follow_parameter_updates():
     fresh.__dict__.pop('_snsde_composed', None)       # no cache at all
     fresh.set_X(coeffs.to(dev), times.to(dev))
     assert not torch.equal(a1, b1) and torch.equal(b1, solve(fresh))
+    field.emb.bias.data.add_(0.2)                    # through .data: no version bump - caught by the content fingerprint
+    fresh3 = copy.deepcopy(field)
+    fresh3.__dict__.pop('_snsde_composed', None)
+    fresh3.set_X(coeffs.to(dev), times.to(dev))
+    c1 = solve(field)
+    assert not torch.equal(c1, b1) and torch.equal(c1, solve(fresh3))
+    b1 = c1
     field.linear_X.weight = torch.nn.Parameter(field.linear_X.weight.detach() * 0.5)     # re-assigned parameter: new address
     fresh2 = copy.deepcopy(field)
     fresh2.__dict__.pop('_snsde_composed', None)
