@@ -154,18 +154,21 @@ class Diffusion_model(nn.Module):
                 and hasattr(self, 'coeffs') and self.coeffs.is_cuda
                 and (not torch.is_tensor(t) or t.numel() == 1) and engine.recognise(self) is not None)
 
-    def _fused_fg(self, t, y):
-        # f and g of one (t, y) come out of the same launch: a solver step that asks for both evaluates once
+    def _fused_fg(self, t, y, which):
+        # f and g of one (t, y) come out of the same launch: a solver step that asks for both evaluates once.  Each half is
+        # handed out once per launch - asking for the same half again re-evaluates, so a caller that edits parameters
+        # through `.data` (no version bump) between two f(t, y) calls, finite differences say, never sees the old value.
         key = (float(t), y.data_ptr(), y._version, tuple(y.shape), self.coeffs.data_ptr(), self.coeffs._version,
                tuple(p._version for p in self.parameters()))
         hit = getattr(self, '_fg_cache', None)
-        if hit is not None and hit[0] == key:
+        if hit is not None and hit[0] == key and which not in hit[2]:
+            hit[2].add(which)
             return hit[1]
         model, layout, numel = engine.recognise(self)
         flat = engine.flatten_params(self, layout, numel, y.device)
         coeffs = self.coeffs.detach().to(torch.float32).contiguous()
         out = engine.eval_fg(model, flat, coeffs, _HostTimes.get(self.times), float(t), y.contiguous())
-        object.__setattr__(self, '_fg_cache', (key, out))
+        object.__setattr__(self, '_fg_cache', (key, out, {which}))
         return out
 
     @staticmethod
@@ -185,12 +188,12 @@ class Diffusion_model(nn.Module):
 
     def f(self, t, y):
         if self._fused_ok(t, y):
-            return self._fused_fg(t, y)[0]
+            return self._fused_fg(t, y, 0)[0]
         return self._drift(t, y)
 
     def g(self, t, y):
         if self._fused_ok(t, y):
-            return self._fused_fg(t, y)[1]
+            return self._fused_fg(t, y, 1)[1]
         return (self.theta.sigmoid() * torch.nan_to_num(self._raw_diffusion(t, y))).tanh()
 
 

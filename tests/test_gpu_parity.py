@@ -260,6 +260,14 @@ def test_sdeint_drop_in_on_cuda_dispatches_to_hip():
     p64 = O.cast_params(pr['params'], np.float64)
     Xt = O.spline_evaluate(pr['coeffs'].astype(np.float64), pr['times'].astype(np.float64), 2.0)
     np.testing.assert_allclose(f, O.drift_f(p64, 4, 2.0, pr['y0'].astype(np.float64), Xt), rtol=1e-5, atol=2e-6)
+    # f and g of one (t, y) share a launch, but a parameter edit through .data (no version bump) between two f calls is seen
+    with torch.no_grad():
+        t2, y2 = torch.tensor(2.0), torch.from_numpy(pr['y0']).to(DEV)
+        f0, g0 = m.f(t2, y2), m.g(t2, y2)
+        assert m._fg_cache[2] == {0, 1}
+        m.linear_out.bias.data.add_(0.25)
+        f1 = m.f(t2, y2)
+        assert not torch.equal(f1, f0) and torch.equal(m.g(t2, y2), g0)
 
 
 def test_neuralsde_forward_on_cuda():
