@@ -572,7 +572,10 @@ __global__ void __launch_bounds__(GT) snsde_generic_adjoint_kernel(AdjArgs aa) {
     float* dl = zo + GR * ldw;                      // delta pong
     float* abuf = dl + GR * ldw;                    // adjoint a (GR x ldy)
     float* ayb = abuf + GR * ldy;                   // a_y accumulator
-    const int lds_floats = GR * (3 * ldy + ldx + (3 + nact) * ldw);
+    const bool noise_net = (no == 14 || no == 15 || no == 18 || no == 19);
+    const bool net2 = (no == 18 || no == 19), net_y = (no == 15 || no == 19);
+    float* gnb = ayb + GR * ldy;                    // diffusion net (no 18/19): output layer, then its delta
+    const int lds_floats = GR * (3 * ldy + ldx + (3 + nact + (noise_net ? 1 : 0)) * ldw);
     const int tid = threadIdx.x, row0 = blockIdx.x * GR;
     for (int i = tid; i < lds_floats; i += GT) lds[i] = 0.0f;
     __syncthreads();
@@ -584,6 +587,9 @@ __global__ void __launch_bounds__(GT) snsde_generic_adjoint_kernel(AdjArgs aa) {
     const float* gt = a.ws + (net.gt_tab >= 0 ? net.gt_tab : 0);
     const size_t BH = (size_t)B * H;
     const float mil = (d.method == SNSDE_MILSTEIN) ? 0.5f : 0.0f;
+    // diffusion net on [tau, y] (neuralsde.py:270-273, 278-281): its first layer lands in `cat` (free once z0 exists), the
+    // second in gnb; the transposed chain borrows `dl` (free until the drift's transposed chain starts)
+    float* nraw = net2 ? gnb : cat;
 
     auto for_elems = [&](auto&& fn) {
         for (int i = tid; i < GR * H; i += GT) {
@@ -644,6 +650,14 @@ __global__ void __launch_bounds__(GT) snsde_generic_adjoint_kernel(AdjArgs aa) {
         }
         dense(a.params, a.ws, net.out, act + (size_t)net.n_hid * GR * ldw, ldw, zo, ldw, false);
         __syncthreads();
+        if (noise_net) {
+            dense(a.params, a.ws, net.ny0, ybuf, ldy, cat, ldw, net2);
+            __syncthreads();
+            if (net2) {
+                dense(a.params, a.ws, net.ny1, cat, ldw, gnb, ldw, true);
+                __syncthreads();
+            }
+        }
         // ---- elementwise derivatives: delta_zout -> zo (in place), direct y terms -> ayb ----
         for_elems([&](int r, int j, int row) {
             const float y = ybuf[r * ldy + j], z = zo[r * ldw + j], av = abuf[r * ldy + j];
@@ -672,10 +686,13 @@ __global__ void __launch_bounds__(GT) snsde_generic_adjoint_kernel(AdjArgs aa) {
                 case 11: raw = t0 * y; r1 = t0; break;
                 case 12: case 16: raw = gt[(size_t)n * H + j]; break;
                 case 13: case 17: r1 = gt[(size_t)n * H + j]; raw = r1 * y; break;
+                case 14: case 18: raw = nraw[r * ldw + j]; break;
+                case 15: case 19: r1 = nraw[r * ldw + j]; raw = r1 * y; break;      // r1: the direct y factor only
                 default: break;
             }
             const bool fin = (raw - raw == 0.0f);
             const float g = tanhf(sig_theta * snsde_nan_to_num(raw));
+            float dnet = 0.0f;
             if (fin) {
                 const float sech = 1.0f - g * g;
                 const float g1 = sech * sig_theta * r1;
@@ -684,10 +701,29 @@ __global__ void __launch_bounds__(GT) snsde_generic_adjoint_kernel(AdjArgs aa) {
                     const float g2 = sech * sig_theta * r2 - 2.0f * g * g1 * sig_theta * r1;
                     accy = fmaf(av * mil * (g1 * g1 + g * g2), dw * dw - h, accy);
                 }
+                dnet = av * dw * sech * sig_theta * (net_y ? y : 1.0f);     // cotangent of the net's output
             }
+            if (noise_net) nraw[r * ldw + j] = (net2 && !(nraw[r * ldw + j] > 0.0f)) ? 0.0f : dnet;
             zo[r * ldw + j] = dz;
             ayb[r * ldy + j] = accy;
         });
+        if (noise_net) {     // J_net^T: (second layer, relu mask of the hidden layer,) y columns of the first layer
+            const float* dfirst = cat;
+            if (net2) {
+                dense_T(a.params + net.ny1.src_w, net.ny1.K, 0, net.ny1.K, net.ny1.N, gnb, ldw, dl, ldw);
+                __syncthreads();
+                for (int i = tid; i < GR * net.ny0.N; i += GT) {
+                    const int r = i / net.ny0.N, j = i - r * net.ny0.N;
+                    if (!(cat[r * ldw + j] > 0.0f)) dl[r * ldw + j] = 0.0f;
+                }
+                __syncthreads();
+                dfirst = dl;
+            }
+            float* dy = net2 ? gnb : dl;
+            dense_T(a.params + net.ny0.src_w, net.ny0.K, net.ny0.tshift, H, net.ny0.N, dfirst, ldw, dy, ldw);
+            __syncthreads();
+            for_elems([&](int r, int j, int) { ayb[r * ldy + j] += dy[r * ldw + j]; });
+        }
         // ---- transposed chain ----
         float* cur = zo;
         float* oth = dl;
@@ -775,7 +811,11 @@ __global__ void __launch_bounds__(GT) snsde_generic_srk_adjoint_kernel(SrkAdjArg
     float* FB0 = V + 6 * plane; float* FB1 = V + 7 * plane; float* FB2 = V + 8 * plane;
     float* GB0 = V + 9 * plane; float* GB1 = V + 10 * plane; float* GB2 = V + 11 * plane;
     float* YB = V + 12 * plane; float* AV = V + 13 * plane; float* DW = V + 14 * plane; float* DU = V + 15 * plane;
-    const int lds_floats = GR * (2 * ldy + ldx + (3 + nact) * ldw + 16 * ldf);
+    const bool noise_net = (no == 14 || no == 15 || no == 18 || no == 19);
+    const bool net2 = (no == 18 || no == 19), net_y = (no == 15 || no == 19);
+    float* S1 = V + 16 * plane;                     // diffusion nets: diffusion stage state | sin, cos
+    float* gnb = S1 + GR * ldy;                     //                 output layer of the two-layer net / its delta
+    const int lds_floats = GR * (2 * ldy + ldx + (3 + nact) * ldw + 16 * ldf + (noise_net ? ldy + ldw : 0));
     const int tid = threadIdx.x, row0 = blockIdx.x * GR;
     for (int i = tid; i < lds_floats; i += GT) lds[i] = 0.0f;
     __syncthreads();
@@ -836,9 +876,11 @@ __global__ void __launch_bounds__(GT) snsde_generic_srk_adjoint_kernel(SrkAdjArg
         });
     };
     // g(t, y) and dg/dy for the elementwise diffusions
-    auto g_and_prime = [&](float y, float t, int n, int slot, int j, float& g1) {
+    auto g_and_prime = [&](float y, float t, int n, int slot, int j, float& g1, float nbv = 0.0f, float* gs = nullptr) {
         float raw = 0.0f, r1 = 0.0f;
         switch (no) {
+            case 14: case 18: raw = nbv; break;                  // nbv: the diffusion net's output for this element
+            case 15: case 19: r1 = nbv; raw = nbv * y; break;    // (g1: the direct y factor only)
             case 0: break;
             case 1: raw = exp_sigma; break;
             case 2: raw = exp_sigma * t; break;
@@ -856,8 +898,64 @@ __global__ void __launch_bounds__(GT) snsde_generic_srk_adjoint_kernel(SrkAdjArg
             default: break;
         }
         const float g = tanhf(sig_theta * snsde_nan_to_num(raw));
-        g1 = (raw - raw == 0.0f) ? (1.0f - g * g) * sig_theta * r1 : 0.0f;
+        const float dgr = (raw - raw == 0.0f) ? (1.0f - g * g) * sig_theta : 0.0f;     // dg / d raw
+        g1 = dgr * r1;
+        if (gs) *gs = dgr;
         return g;
+    };
+    // diffusion net on [tau, state] at the stage time of tp, state in S1 (neuralsde.py:270-273, 278-281): raw output buffer.
+    // First layer in `cat`, second in gnb; both and `dl` are free between a drift forward and its VJP.
+    auto gnet_fwd = [&](const float* tp) -> float* {
+        if (tid < GR) { S1[tid * ldy + H] = tp[1]; S1[tid * ldy + H + 1] = tp[2]; }
+        __syncthreads();
+        dense(a.params, a.ws, net.ny0, S1, ldy, cat, ldw, net2);
+        __syncthreads();
+        if (!net2) return cat;
+        dense(a.params, a.ws, net.ny1, cat, ldw, gnb, ldw, true);
+        __syncthreads();
+        return gnb;
+    };
+    // J_net^T applied to the output cotangent the caller left in the raw-output buffer: d/d state (ldw stride)
+    auto gnet_vjp = [&]() -> const float* {
+        const float* dfirst = cat;
+        if (net2) {
+            dense_T(a.params + net.ny1.src_w, net.ny1.K, 0, net.ny1.K, net.ny1.N, gnb, ldw, dl, ldw);
+            __syncthreads();
+            for (int i = tid; i < GR * net.ny0.N; i += GT) {
+                const int r = i / net.ny0.N, j = i - r * net.ny0.N;
+                if (!(cat[r * ldw + j] > 0.0f)) dl[r * ldw + j] = 0.0f;
+            }
+            __syncthreads();
+            dfirst = dl;
+        }
+        float* dy = net2 ? gnb : dl;
+        dense_T(a.params + net.ny0.src_w, net.ny0.K, net.ny0.tshift, H, net.ny0.N, dfirst, ldw, dy, ldw);
+        __syncthreads();
+        return dy;
+    };
+    // g at (stage time tp, state(r, j)) -> plane G
+    auto gnet_value = [&](auto&& state, const float* tp, float* G) {
+        for_elems([&](int r, int j, int) { S1[r * ldy + j] = state(r, j); });
+        const float* nb = gnet_fwd(tp);
+        for_elems([&](int r, int j, int) {
+            float gp;
+            G[r * ldf + j] = g_and_prime(S1[r * ldy + j], tp[0], 0, 0, j, gp, nb[r * ldw + j]);
+        });
+    };
+    // hb = J_g(tp, state)^T cot, handed to `consume` in two additive parts (direct y factor, then the net's chain)
+    auto gnet_stage_vjp = [&](auto&& state, const float* tp, auto&& cot, auto&& consume) {
+        for_elems([&](int r, int j, int) { S1[r * ldy + j] = state(r, j); });
+        float* nb = gnet_fwd(tp);
+        for_elems([&](int r, int j, int) {
+            const float y = S1[r * ldy + j], nbv = nb[r * ldw + j];
+            float gp, gs;
+            g_and_prime(y, tp[0], 0, 0, j, gp, nbv, &gs);
+            const float v = cot(r, j);
+            if (net_y) consume(r, j, v * gp);
+            nb[r * ldw + j] = (net2 && !(nbv > 0.0f)) ? 0.0f : v * gs * (net_y ? y : 1.0f);
+        });
+        const float* dy = gnet_vjp();
+        for_elems([&](int r, int j, int) { consume(r, j, dy[r * ldw + j]); });
     };
     // J_f(stage)^T FB for the stage whose activations are in act[] / zo and whose state is in S0:
     // result added to YB; returns the buffer holding dL/dH0 (ldw stride) for the caller's combinations
@@ -934,6 +1032,92 @@ __global__ void __launch_bounds__(GT) snsde_generic_srk_adjoint_kernel(SrkAdjArg
             Y[r * ldy + j] = y; S0[r * ldy + j] = y;
             DW[r * ldf + j] = dw; DU[r * ldf + j] = du;
         });
+        if (noise_net) {
+            // ---- forward stages (every diffusion evaluation is a net pass on its own stage state) ----
+            fwd_chain(tp0);
+            f_value(F0);
+            gnet_value([&](int r, int j) { return Y[r * ldy + j]; }, tp0, G0);
+            for_elems([&](int r, int j, int) { S0[r * ldy + j] = Y[r * ldy + j] + F0[r * ldf + j] * h; });     // H0_1
+            fwd_chain(tp1);
+            f_value(F1);
+            auto h11 = [&](int r, int j) { return Y[r * ldy + j] + 0.25f * F0[r * ldf + j] * h + 0.5f * G0[r * ldf + j] * rdt; };
+            auto h12 = [&](int r, int j) { return Y[r * ldy + j] + F0[r * ldf + j] * h - G0[r * ldf + j] * rdt; };
+            gnet_value(h11, tpq, G1);
+            for_elems([&](int r, int j, int) {
+                const float du = DU[r * ldf + j];
+                S0[r * ldy + j] = Y[r * ldy + j] + 0.25f * F0[r * ldf + j] * h + 0.25f * F1[r * ldf + j] * h +
+                                  G0[r * ldf + j] * du / h + 0.5f * G1[r * ldf + j] * du / h;                 // H0_2
+            });
+            fwd_chain(tph);        // activations of this evaluation feed the first drift VJP below
+            f_value(F2);
+            gnet_value(h12, tp1, G2);
+            // ---- backward: cotangents of the combination ----
+            for_elems([&](int r, int j, int) {
+                const float av = AV[r * ldf + j], ik = DW[r * ldf + j], ik0 = DU[r * ldf + j];
+                const float ikk = 0.5f * (ik * ik - h);
+                const float ikkk = (ik * ik * ik - 3.0f * h * ik) / 6.0f;
+                const float a1 = ik, a2 = ikk / rdt, a3 = ik0 / h, a4 = ikkk / h;
+                FB0[r * ldf + j] = av * (h / 6.0f); FB1[r * ldf + j] = av * (h / 6.0f); FB2[r * ldf + j] = av * (2.0f * h / 3.0f);
+                GB0[r * ldf + j] = (-a1 - a2 + 2.0f * a3 - 2.0f * a4) * av;
+                GB1[r * ldf + j] = ((4.0f / 3.0f) * a1 + (4.0f / 3.0f) * a2 - (4.0f / 3.0f) * a3 + (5.0f / 3.0f) * a4) * av;
+                GB2[r * ldf + j] = ((2.0f / 3.0f) * a1 - (1.0f / 3.0f) * a2 - (2.0f / 3.0f) * a3 - (2.0f / 3.0f) * a4) * av;
+            });
+            // stage 3: g(t0 + h/4, H1_3), H1_3 = y + f2 h/4 + (-5 g0 + 3 g1 + g2/2) sqrt(h), weight I_kkk / h
+            gnet_stage_vjp([&](int r, int j) {
+                               return Y[r * ldy + j] + 0.25f * F2[r * ldf + j] * h +
+                                      (-5.0f * G0[r * ldf + j] + 3.0f * G1[r * ldf + j] + 0.5f * G2[r * ldf + j]) * rdt; },
+                           tpq,
+                           [&](int r, int j) {
+                               const float ik = DW[r * ldf + j];
+                               return AV[r * ldf + j] * ((ik * ik * ik - 3.0f * h * ik) / 6.0f) / h; },
+                           [&](int r, int j, float hb) {
+                               YB[r * ldf + j] += hb; FB2[r * ldf + j] = fmaf(0.25f * h, hb, FB2[r * ldf + j]);
+                               GB0[r * ldf + j] = fmaf(-5.0f * rdt, hb, GB0[r * ldf + j]);
+                               GB1[r * ldf + j] = fmaf(3.0f * rdt, hb, GB1[r * ldf + j]);
+                               GB2[r * ldf + j] = fmaf(0.5f * rdt, hb, GB2[r * ldf + j]); });
+            // stage 2, diffusion half: H1_2 = y + f0 h - g0 sqrt(h)
+            gnet_stage_vjp(h12, tp1, [&](int r, int j) { return GB2[r * ldf + j]; },
+                           [&](int r, int j, float hb) {
+                               YB[r * ldf + j] += hb; FB0[r * ldf + j] = fmaf(h, hb, FB0[r * ldf + j]);
+                               GB0[r * ldf + j] = fmaf(-rdt, hb, GB0[r * ldf + j]); });
+            // stage 2, drift half: H0_2 = y + (f0 + f1) h/4 + (g0 + g1/2) I_k0/h
+            {
+                const float* dH = vjp(FB2);
+                for_elems([&](int r, int j, int) {
+                    const float dv = dH[r * ldw + j], du = DU[r * ldf + j];
+                    YB[r * ldf + j] += dv;
+                    FB0[r * ldf + j] = fmaf(0.25f * h, dv, FB0[r * ldf + j]);
+                    FB1[r * ldf + j] = fmaf(0.25f * h, dv, FB1[r * ldf + j]);
+                    GB0[r * ldf + j] = fmaf(du / h, dv, GB0[r * ldf + j]);
+                    GB1[r * ldf + j] = fmaf(0.5f * du / h, dv, GB1[r * ldf + j]);
+                });
+            }
+            // stage 1: H1_1 = y + f0 h/4 + g0 sqrt(h)/2 (diffusion at t0 + h/4), H0_1 = y + f0 h (drift at t0 + h)
+            gnet_stage_vjp(h11, tpq, [&](int r, int j) { return GB1[r * ldf + j]; },
+                           [&](int r, int j, float hb) {
+                               YB[r * ldf + j] += hb; FB0[r * ldf + j] = fmaf(0.25f * h, hb, FB0[r * ldf + j]);
+                               GB0[r * ldf + j] = fmaf(0.5f * rdt, hb, GB0[r * ldf + j]); });
+            for_elems([&](int r, int j, int) { S0[r * ldy + j] = Y[r * ldy + j] + F0[r * ldf + j] * h; });
+            fwd_chain(tp1);
+            {
+                const float* dH = vjp(FB1);
+                for_elems([&](int r, int j, int) {
+                    const float dv = dH[r * ldw + j];
+                    YB[r * ldf + j] += dv;
+                    FB0[r * ldf + j] = fmaf(h, dv, FB0[r * ldf + j]);
+                });
+            }
+            // stage 0: both evaluated at (t0, y)
+            gnet_stage_vjp([&](int r, int j) { return Y[r * ldy + j]; }, tp0, [&](int r, int j) { return GB0[r * ldf + j]; },
+                           [&](int r, int j, float hb) { YB[r * ldf + j] += hb; });
+            for_elems([&](int r, int j, int) { S0[r * ldy + j] = Y[r * ldy + j]; });
+            fwd_chain(tp0);
+            {
+                const float* dH = vjp(FB0);
+                for_elems([&](int r, int j, int) { AV[r * ldf + j] = YB[r * ldf + j] + dH[r * ldw + j]; });
+            }
+            continue;
+        }
         // ---- forward stages ----
         fwd_chain(tp0);
         f_value(F0);
@@ -1135,17 +1319,18 @@ int snsde_generic_launch(const snsde_solve* s, const SnsdeNet& net, hipStream_t 
 
 bool snsde_generic_backward_supported(const snsde_solve* s) {
     const int no = s->model.noise_option;
-    if (no == 14 || no == 15 || no == 18 || no == 19) return false;        // dense diffusion Jacobian: not yet
+    const bool noise_net = (no == 14 || no == 15 || no == 18 || no == 19);   // dense diffusion Jacobian: one more buffer
+    const int H = s->model.hidden_channels, HH = s->model.hidden_hidden_channels;
+    const int wmax = 2 * H > HH ? 2 * H : HH;
+    const size_t ldy = round4(H + 2), ldw = round4(wmax) + 4, ldx = round4(s->model.input_channels);
     if (s->method == SNSDE_SRK) {     // SRK adjoint: bounded by its LDS planes
-        const int H = s->model.hidden_channels, HH = s->model.hidden_hidden_channels;
-        const int wmax = 2 * H > HH ? 2 * H : HH;
-        const size_t fl = (size_t)GR * (2 * round4(H + 2) + round4(s->model.input_channels) +
-                                        (3 + s->model.num_hidden_layers) * (round4(wmax) + 4) + 16 * round4(H));
+        const size_t fl = (size_t)GR * (2 * ldy + ldx + (3 + s->model.num_hidden_layers) * ldw + 16 * round4(H) +
+                                        (noise_net ? ldy + ldw : 0));
         return fl * sizeof(float) <= 160 * 1024;
     }
     if (s->method != SNSDE_EULER && s->method != SNSDE_MILSTEIN) return false;
-    if (s->method == SNSDE_MILSTEIN && no == 7) return false;
-    return true;
+    if (s->method == SNSDE_MILSTEIN && (no == 7 || noise_net)) return false;
+    return (size_t)GR * (3 * ldy + ldx + (3 + s->model.num_hidden_layers + (noise_net ? 1 : 0)) * ldw) * sizeof(float) <= 160 * 1024;
 }
 
 // The adjoint kernels need the generic packed weights and the time-only diffusion table: prepared here in the
@@ -1198,7 +1383,8 @@ int snsde_generic_backward_launch(const snsde_backward* b, const SnsdeNet& net, 
         sa.g = a;
         sa.srk_tab = s->srk_tab; sa.traj = s->traj; sa.dW_used = s->dW_out; sa.dU_used = s->dU_out;
         sa.grad_ys = b->grad_ys; sa.adj = b->adj; sa.ldf = round4(H);
-        const size_t bytes = (size_t)GR * (2 * a.ldy + a.ldx + (3 + net.n_hid + 1) * a.ldw + 16 * sa.ldf) * sizeof(float);
+        const bool nn = (m.noise_option == 14 || m.noise_option == 15 || m.noise_option == 18 || m.noise_option == 19);
+        const size_t bytes = (size_t)GR * (2 * a.ldy + a.ldx + (3 + net.n_hid + 1) * a.ldw + 16 * sa.ldf + (nn ? a.ldy + a.ldw : 0)) * sizeof(float);
         if (bytes > 160 * 1024) return SNSDE_ERR_LDS;
         if (bytes > 64 * 1024 &&
             hipFuncSetAttribute(reinterpret_cast<const void*>(snsde_generic_srk_adjoint_kernel),
@@ -1208,7 +1394,8 @@ int snsde_generic_backward_launch(const snsde_backward* b, const SnsdeNet& net, 
         return hipGetLastError() == hipSuccess ? SNSDE_OK : SNSDE_ERR_LAUNCH;
     }
     aa.traj = s->traj; aa.dW_used = s->dW_out; aa.grad_ys = b->grad_ys; aa.adj = b->adj; aa.nbuf = net.n_hid + 1;
-    const size_t lds_bytes = (size_t)GR * (3 * a.ldy + a.ldx + (3 + net.n_hid + 1) * a.ldw) * sizeof(float);
+    const bool nn = (m.noise_option == 14 || m.noise_option == 15 || m.noise_option == 18 || m.noise_option == 19);
+    const size_t lds_bytes = (size_t)GR * (3 * a.ldy + a.ldx + (3 + net.n_hid + 1 + (nn ? 1 : 0)) * a.ldw) * sizeof(float);
     if (lds_bytes > 160 * 1024) return SNSDE_ERR_LDS;
     if (lds_bytes > 64 * 1024 &&
         hipFuncSetAttribute(reinterpret_cast<const void*>(snsde_generic_adjoint_kernel),

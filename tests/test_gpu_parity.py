@@ -597,13 +597,22 @@ GEN_BWD_CASES = [
     (1, 8, 2, 9, 12, 3, 8, [0, 2.5, 7], 0.5, 'srk'),
     (3, 13, 2, 10, 64, 3, 8, [0, 7], 1.0, 'srk'),
     (0, 6, 2, 9, 12, 3, 8, [0, 7], 1.0, 'srk'),
+    (3, 18, 2, 11, 24, 5, 9, [0, 3.5, 8], 1.0, 'euler'),      # diffusion nets on [tau, y]: dense Jacobian of g
+    (1, 14, 1, 9, 12, 3, 8, [0, 7], 0.5, 'euler'),
+    (4, 19, 2, 9, 64, 69, 8, [0, 3, 7], 1.0, 'euler'),        # ... behind a wide control embedding (no MFMA variant)
+    (2, 15, 3, 9, 40, 40, 8, [0, 7], 1.0, 'euler'),
+    (1, 18, 2, 11, 24, 3, 9, [0, 3.5, 8], 1.0, 'srk'),        # torch_ists `neuralsde_1_18` under its default method
+    (3, 14, 1, 9, 12, 3, 8, [0, 7], 0.5, 'srk'),
+    (4, 15, 2, 9, 32, 5, 8, [0, 3, 7], 1.0, 'srk'),
+    (6, 19, 3, 7, 64, 5, 8, [0, 7], 0.5, 'srk'),
+    (0, 18, 2, 9, 128, 21, 8, [0, 7], 1.0, 'srk'),
 ]
 
 
 @pytest.mark.parametrize('ci', range(len(GEN_BWD_CASES)))
 def test_generic_backward_matches_fp64_autograd(ci):
     io, no, NL, B, H, C, L, ts, dt, method = GEN_BWD_CASES[ci]
-    _check_backward(900 + ci, io, no, NL, B, H, C, L, ts, dt, method, 'generic')
+    _check_backward(900 + ci, io, no, NL, B, H, C, L, ts, dt, method, 'generic', strict=True)
 
 
 @pytest.mark.parametrize('kernel', ['mfma4', 'mfma16'])
@@ -665,7 +674,17 @@ def test_backward_sweep_generic_options(io, no):
     _check_backward(3000 + k, io, no, 1 + k % 2, 7, 12, 3, 6, [0, 5], 1.0 if k % 2 else 0.5, method, 'generic')
 
 
-def _check_backward(seed, io, no, NL, B, H, C, L, ts, dt, method, kernel):
+@pytest.mark.parametrize('io', [0, 1, 2, 3, 4, 5, 6])
+@pytest.mark.parametrize('no', [14, 15, 18, 19])
+@pytest.mark.parametrize('method', ['euler', 'srk'])
+def test_backward_sweep_generic_diffusion_nets(io, no, method):
+    """Diffusion nets on [tau, y] (dense dg/dy) through the generic adjoint kernels, every input_option, Euler and SRK."""
+    k = io * 4 + no
+    _check_backward(3500 + k, io, no, 1 + k % 2, 7, 12 if k % 2 else 20, 3, 6, [0, 5], 1.0 if k % 3 else 0.5, method, 'generic',
+                    strict=True)
+
+
+def _check_backward(seed, io, no, NL, B, H, C, L, ts, dt, method, kernel, strict=False):
     times = np.linspace(0, 1, L).astype(np.float32) if ts is None else None
     pr = make_problem(seed, io, no, NL, B, H, C, L, times=times)
     ts = pr['times'] if ts is None else np.asarray(ts, np.float32)
@@ -697,7 +716,7 @@ def _check_backward(seed, io, no, NL, B, H, C, L, ts, dt, method, kernel):
     m, y0 = build(torch.float32, DEV)
     ys = S.sdeint(m, y0, torch.from_numpy(ts).to(DEV),
                   bm=_ReplayBM(torch.from_numpy(dW).to(DEV), None if dU is None else torch.from_numpy(dU).to(DEV)),
-                  method=method, dt=dt, options={'kernel': kernel})
+                  method=method, dt=dt, options={'kernel': kernel, 'strict': strict})     # strict: no tensor-op fallback
     (ys * torch.from_numpy(wsum).to(DEV)).sum().backward()
 
     def close(got, ref, name):
