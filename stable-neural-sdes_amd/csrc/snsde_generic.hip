@@ -116,6 +116,34 @@ __device__ void dense(const float* __restrict__ params, const float* __restrict_
     }
 }
 
+// ---- wide-workgroup variants (SRK forward, adjoints): GW threads, one output column per thread, the GR rows split over
+// GW / NP thread groups; compiled once (noinline) - these kernels call them from dozens of sites, and inlined copies drove
+// the register allocator into kilobytes of scratch per lane.  Per-output summation order is the same as in dense().
+constexpr int GW = 512;
+
+template <int NP>
+__device__ __forceinline__ void dense_group(const float* __restrict__ wt, const float* __restrict__ bias, int K4, int N,
+                                            const float* in, int ldin, float* out, int ldout, bool relu) {
+    constexpr int G0 = GW / NP, RG = G0 > GR ? GR : G0;
+    const int n = threadIdx.x % NP, rg = threadIdx.x / NP;
+    if (rg < RG && n < N) dense_rows<GR / RG>(wt, bias[n], K4, N, in, ldin, out, ldout, relu, n, rg);
+}
+
+__device__ __noinline__ void dense_w(const float* __restrict__ params, const float* __restrict__ ws, const SnsdeLayer& L,
+                                     const float* in, int ldin, float* out, int ldout, bool relu) {
+    const int N = L.N, K4 = L.Kpad >> 2;
+    const float* wt = ws + L.w;
+    const float* bias = params + L.src_b;
+    if (N <= 64) dense_group<64>(wt, bias, K4, N, in, ldin, out, ldout, relu);
+    else if (N <= 128) dense_group<128>(wt, bias, K4, N, in, ldin, out, ldout, relu);
+    else if (N <= 256) dense_group<256>(wt, bias, K4, N, in, ldin, out, ldout, relu);
+    else if (N <= 512) dense_group<512>(wt, bias, K4, N, in, ldin, out, ldout, relu);
+    else {
+        for (int n = threadIdx.x; n < N; n += GW)
+            dense_rows<GR>(wt, bias[n], K4, N, in, ldin, out, ldout, relu, n, 0);
+    }
+}
+
 __global__ void __launch_bounds__(GT) snsde_generic_kernel(GenericArgs a) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const SnsdeDims& d = a.d;
@@ -298,7 +326,7 @@ struct SrkArgs {
     int32_t ldf;
 };
 
-__global__ void __launch_bounds__(GT) snsde_generic_srk_kernel(SrkArgs sa) {
+__global__ void __launch_bounds__(GW) snsde_generic_srk_kernel(SrkArgs sa) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const GenericArgs& a = sa.g;
     const SnsdeDims& d = a.d;
@@ -319,9 +347,9 @@ __global__ void __launch_bounds__(GT) snsde_generic_srk_kernel(SrkArgs sa) {
     float* DW = V + 6 * plane; float* DU = V + 7 * plane;
     const int lds_floats = GR * (3 * ldy + 3 * ldw + ldx + 8 * ldf);
     const int tid = threadIdx.x, row0 = blockIdx.x * GR;
-    for (int i = tid; i < lds_floats; i += GT) lds[i] = 0.0f;
+    for (int i = tid; i < lds_floats; i += GW) lds[i] = 0.0f;
     __syncthreads();
-    for (int i = tid; i < GR * H; i += GT) {
+    for (int i = tid; i < GR * H; i += GW) {
         const int r = i / H, j = i - r * H, row = row0 + r;
         if (row < B) {
             const float v = a.y0[(size_t)row * H + j];
@@ -341,7 +369,7 @@ __global__ void __launch_bounds__(GT) snsde_generic_srk_kernel(SrkArgs sa) {
     __syncthreads();
 
     auto for_elems = [&](auto&& fn) {
-        for (int i = tid; i < GR * H; i += GT) {
+        for (int i = tid; i < GR * H; i += GW) {
             const int r = i / H, j = i - r * H;
             fn(r, j, row0 + r);
         }
@@ -353,7 +381,7 @@ __global__ void __launch_bounds__(GT) snsde_generic_srk_kernel(SrkArgs sa) {
         const int idx = __float_as_int(tp[4]);
         if (tid < GR) { sbuf[tid * ldy + H] = tp[1]; sbuf[tid * ldy + H + 1] = tp[2]; }
         if (uses_x) {
-            for (int i = tid; i < GR * C; i += GT) {
+            for (int i = tid; i < GR * C; i += GW) {
                 const int r = i / C, c = i - r * C, row = row0 + r;
                 float v = 0.0f;
                 if (row < B) {
@@ -367,25 +395,25 @@ __global__ void __launch_bounds__(GT) snsde_generic_srk_kernel(SrkArgs sa) {
         float* cur;
         float* oth;
         if (io == 0) {
-            dense(a.params, a.ws, net.init, xbuf, ldx, bufA, ldw, true);
+            dense_w(a.params, a.ws, net.init, xbuf, ldx, bufA, ldw, true);
             cur = bufA; oth = bufB;
         } else if (!uses_emb) {
-            dense(a.params, a.ws, net.in, sbuf, ldy, bufA, ldw, true);
+            dense_w(a.params, a.ws, net.in, sbuf, ldy, bufA, ldw, true);
             cur = bufA; oth = bufB;
         } else {
-            dense(a.params, a.ws, net.in, sbuf, ldy, bufA, ldw, false);
-            dense(a.params, a.ws, net.init, xbuf, ldx, bufA + H, ldw, false);
+            dense_w(a.params, a.ws, net.in, sbuf, ldy, bufA, ldw, false);
+            dense_w(a.params, a.ws, net.init, xbuf, ldx, bufA + H, ldw, false);
             __syncthreads();
-            dense(a.params, a.ws, net.emb, bufA, ldw, bufB, ldw, true);
+            dense_w(a.params, a.ws, net.emb, bufA, ldw, bufB, ldw, true);
             cur = bufB; oth = bufA;
         }
         __syncthreads();
         for (int l = 0; l < net.n_hid; ++l) {
-            dense(a.params, a.ws, net.hid[l], cur, ldw, oth, ldw, true);
+            dense_w(a.params, a.ws, net.hid[l], cur, ldw, oth, ldw, true);
             float* t = cur; cur = oth; oth = t;
             __syncthreads();
         }
-        dense(a.params, a.ws, net.out, cur, ldw, oth, ldw, false);
+        dense_w(a.params, a.ws, net.out, cur, ldw, oth, ldw, false);
         __syncthreads();
         for_elems([&](int r, int j, int) {
             float z = oth[r * ldw + j];
@@ -398,10 +426,10 @@ __global__ void __launch_bounds__(GT) snsde_generic_srk_kernel(SrkArgs sa) {
         if (!noise_net) return bufC;
         if (tid < GR) { sbuf[tid * ldy + H] = tp[1]; sbuf[tid * ldy + H + 1] = tp[2]; }
         __syncthreads();
-        dense(a.params, a.ws, net.ny0, sbuf, ldy, bufA, ldw, no >= 18);
+        dense_w(a.params, a.ws, net.ny0, sbuf, ldy, bufA, ldw, no >= 18);
         __syncthreads();
         if (no < 18) return bufA;
-        dense(a.params, a.ws, net.ny1, bufA, ldw, bufC, ldw, true);
+        dense_w(a.params, a.ws, net.ny1, bufA, ldw, bufC, ldw, true);
         __syncthreads();
         return bufC;
     };
@@ -539,24 +567,42 @@ struct AdjArgs {
 };
 
 // out[r][k] (+)= sum_n W[n][k] * in[r][n]  for k in [k0, k0 + Kn): W row-major (N, ldk)
-__device__ void dense_T(const float* __restrict__ W, int ldk, int k0, int Kn, int N, const float* in, int ldin, float* out,
-                        int ldout) {
-    for (int k = threadIdx.x; k < Kn; k += GT) {
-        float acc[GR];
+template <int RPT>
+__device__ __forceinline__ void dense_T_rows(const float* __restrict__ wp, int ldk, int N, const float* in, int ldin, float* out,
+                                             int ldout, int k, int r0) {
+    constexpr int G = GR / RPT;
+    float acc[RPT];
 #pragma unroll
-        for (int r = 0; r < GR; ++r) acc[r] = 0.0f;
-        const float* wp = W + k0 + k;
-        for (int n = 0; n < N; ++n) {
-            const float w = wp[(size_t)n * ldk];
+    for (int i = 0; i < RPT; ++i) acc[i] = 0.0f;
+#pragma unroll 8
+    for (int n = 0; n < N; ++n) {
+        const float w = wp[(size_t)n * ldk];
 #pragma unroll
-            for (int r = 0; r < GR; ++r) acc[r] = fmaf(in[r * ldin + n], w, acc[r]);
-        }
+        for (int i = 0; i < RPT; ++i) acc[i] = fmaf(in[(r0 + i * G) * ldin + n], w, acc[i]);
+    }
 #pragma unroll
-        for (int r = 0; r < GR; ++r) out[r * ldout + k] = acc[r];
+    for (int i = 0; i < RPT; ++i) out[(r0 + i * G) * ldout + k] = acc[i];
+}
+
+template <int KP>
+__device__ __forceinline__ void dense_T_group(const float* __restrict__ W, int ldk, int k0, int Kn, int N, const float* in,
+                                              int ldin, float* out, int ldout) {
+    constexpr int G0 = GW / KP, RG = G0 > GR ? GR : G0;
+    const int k = threadIdx.x % KP, rg = threadIdx.x / KP;
+    if (rg < RG && k < Kn) dense_T_rows<GR / RG>(W + k0 + k, ldk, N, in, ldin, out, ldout, k, rg);
+}
+
+__device__ __noinline__ void dense_T(const float* __restrict__ W, int ldk, int k0, int Kn, int N, const float* in, int ldin,
+                                     float* out, int ldout) {
+    if (Kn <= 64) dense_T_group<64>(W, ldk, k0, Kn, N, in, ldin, out, ldout);
+    else if (Kn <= 128) dense_T_group<128>(W, ldk, k0, Kn, N, in, ldin, out, ldout);
+    else if (Kn <= 256) dense_T_group<256>(W, ldk, k0, Kn, N, in, ldin, out, ldout);
+    else {
+        for (int k = threadIdx.x; k < Kn; k += GW) dense_T_rows<GR>(W + k0 + k, ldk, N, in, ldin, out, ldout, k, 0);
     }
 }
 
-__global__ void __launch_bounds__(GT) snsde_generic_adjoint_kernel(AdjArgs aa) {
+__global__ void __launch_bounds__(GW) snsde_generic_adjoint_kernel(AdjArgs aa) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const GenericArgs& a = aa.g;
     const SnsdeDims& d = a.d;
@@ -577,7 +623,7 @@ __global__ void __launch_bounds__(GT) snsde_generic_adjoint_kernel(AdjArgs aa) {
     float* gnb = ayb + GR * ldy;                    // diffusion net (no 18/19): output layer, then its delta
     const int lds_floats = GR * (3 * ldy + ldx + (3 + nact + (noise_net ? 1 : 0)) * ldw);
     const int tid = threadIdx.x, row0 = blockIdx.x * GR;
-    for (int i = tid; i < lds_floats; i += GT) lds[i] = 0.0f;
+    for (int i = tid; i < lds_floats; i += GW) lds[i] = 0.0f;
     __syncthreads();
     const float sig_theta = snsde_sigmoid(a.params[net.off_theta]);
     const float exp_sigma = (net.off_sigma >= 0) ? expf(a.params[net.off_sigma]) : 0.0f;
@@ -592,7 +638,7 @@ __global__ void __launch_bounds__(GT) snsde_generic_adjoint_kernel(AdjArgs aa) {
     float* nraw = net2 ? gnb : cat;
 
     auto for_elems = [&](auto&& fn) {
-        for (int i = tid; i < GR * H; i += GT) {
+        for (int i = tid; i < GR * H; i += GW) {
             const int r = i / H, j = i - r * H;
             fn(r, j, row0 + r);
         }
@@ -622,7 +668,7 @@ __global__ void __launch_bounds__(GT) snsde_generic_adjoint_kernel(AdjArgs aa) {
         });
         if (tid < GR) { ybuf[tid * ldy + H] = st[2]; ybuf[tid * ldy + H + 1] = st[3]; }
         if (uses_x) {
-            for (int i = tid; i < GR * C; i += GT) {
+            for (int i = tid; i < GR * C; i += GW) {
                 const int r = i / C, c = i - r * C, row = row0 + r;
                 float v = 0.0f;
                 if (row < B) {
@@ -635,26 +681,26 @@ __global__ void __launch_bounds__(GT) snsde_generic_adjoint_kernel(AdjArgs aa) {
         __syncthreads();
         // ---- forward re-evaluation, activations kept ----
         float* z0 = act;
-        if (io == 0) dense(a.params, a.ws, net.init, xbuf, ldx, z0, ldw, true);
-        else if (!uses_emb) dense(a.params, a.ws, net.in, ybuf, ldy, z0, ldw, true);
+        if (io == 0) dense_w(a.params, a.ws, net.init, xbuf, ldx, z0, ldw, true);
+        else if (!uses_emb) dense_w(a.params, a.ws, net.in, ybuf, ldy, z0, ldw, true);
         else {
-            dense(a.params, a.ws, net.in, ybuf, ldy, cat, ldw, false);
-            dense(a.params, a.ws, net.init, xbuf, ldx, cat + H, ldw, false);
+            dense_w(a.params, a.ws, net.in, ybuf, ldy, cat, ldw, false);
+            dense_w(a.params, a.ws, net.init, xbuf, ldx, cat + H, ldw, false);
             __syncthreads();
-            dense(a.params, a.ws, net.emb, cat, ldw, z0, ldw, true);
+            dense_w(a.params, a.ws, net.emb, cat, ldw, z0, ldw, true);
         }
         __syncthreads();
         for (int l = 0; l < net.n_hid; ++l) {
-            dense(a.params, a.ws, net.hid[l], act + (size_t)l * GR * ldw, ldw, act + (size_t)(l + 1) * GR * ldw, ldw, true);
+            dense_w(a.params, a.ws, net.hid[l], act + (size_t)l * GR * ldw, ldw, act + (size_t)(l + 1) * GR * ldw, ldw, true);
             __syncthreads();
         }
-        dense(a.params, a.ws, net.out, act + (size_t)net.n_hid * GR * ldw, ldw, zo, ldw, false);
+        dense_w(a.params, a.ws, net.out, act + (size_t)net.n_hid * GR * ldw, ldw, zo, ldw, false);
         __syncthreads();
         if (noise_net) {
-            dense(a.params, a.ws, net.ny0, ybuf, ldy, cat, ldw, net2);
+            dense_w(a.params, a.ws, net.ny0, ybuf, ldy, cat, ldw, net2);
             __syncthreads();
             if (net2) {
-                dense(a.params, a.ws, net.ny1, cat, ldw, gnb, ldw, true);
+                dense_w(a.params, a.ws, net.ny1, cat, ldw, gnb, ldw, true);
                 __syncthreads();
             }
         }
@@ -712,7 +758,7 @@ __global__ void __launch_bounds__(GT) snsde_generic_adjoint_kernel(AdjArgs aa) {
             if (net2) {
                 dense_T(a.params + net.ny1.src_w, net.ny1.K, 0, net.ny1.K, net.ny1.N, gnb, ldw, dl, ldw);
                 __syncthreads();
-                for (int i = tid; i < GR * net.ny0.N; i += GT) {
+                for (int i = tid; i < GR * net.ny0.N; i += GW) {
                     const int r = i / net.ny0.N, j = i - r * net.ny0.N;
                     if (!(cat[r * ldw + j] > 0.0f)) dl[r * ldw + j] = 0.0f;
                 }
@@ -733,7 +779,7 @@ __global__ void __launch_bounds__(GT) snsde_generic_adjoint_kernel(AdjArgs aa) {
             // oth holds dL/d(post-relu z_l): mask with z_l > 0, then move one layer down
             const float* zl = act + (size_t)l * GR * ldw;
             const int width = (l == 0 && io != 0) ? net.in.N : (l == 0 ? H : net.hid[l - 1].N);
-            for (int i = tid; i < GR * width; i += GT) {
+            for (int i = tid; i < GR * width; i += GW) {
                 const int r = i / width, j = i - r * width;
                 if (!(zl[r * ldw + j] > 0.0f)) oth[r * ldw + j] = 0.0f;
             }
@@ -760,7 +806,7 @@ __global__ void __launch_bounds__(GT) snsde_generic_adjoint_kernel(AdjArgs aa) {
             for_elems([&](int r, int j, int) { abuf[r * ldy + j] = ayb[r * ldy + j]; });
         }
     }
-    for (int i = tid; i < GR * H; i += GT) {      // ys[0] = y0
+    for (int i = tid; i < GR * H; i += GW) {      // ys[0] = y0
         const int r = i / H, j = i - r * H, row = row0 + r;
         if (row < B) aa.adj[(size_t)row * H + j] = abuf[r * ldy + j] +
             ((!a.row_out || a.row_out[row] == 0) ? aa.grad_ys[(size_t)row * H + j] : 0.0f);
@@ -789,7 +835,7 @@ struct SrkAdjArgs {
     int32_t ldf;
 };
 
-__global__ void __launch_bounds__(GT) snsde_generic_srk_adjoint_kernel(SrkAdjArgs aa) {
+__global__ void __launch_bounds__(GW) snsde_generic_srk_adjoint_kernel(SrkAdjArgs aa) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const GenericArgs& a = aa.g;
     const SnsdeDims& d = a.d;
@@ -817,7 +863,7 @@ __global__ void __launch_bounds__(GT) snsde_generic_srk_adjoint_kernel(SrkAdjArg
     float* gnb = S1 + GR * ldy;                     //                 output layer of the two-layer net / its delta
     const int lds_floats = GR * (2 * ldy + ldx + (3 + nact) * ldw + 16 * ldf + (noise_net ? ldy + ldw : 0));
     const int tid = threadIdx.x, row0 = blockIdx.x * GR;
-    for (int i = tid; i < lds_floats; i += GT) lds[i] = 0.0f;
+    for (int i = tid; i < lds_floats; i += GW) lds[i] = 0.0f;
     __syncthreads();
     const float sig_theta = snsde_sigmoid(a.params[net.off_theta]);
     const float exp_sigma = (net.off_sigma >= 0) ? expf(a.params[net.off_sigma]) : 0.0f;
@@ -828,7 +874,7 @@ __global__ void __launch_bounds__(GT) snsde_generic_srk_adjoint_kernel(SrkAdjArg
     const size_t BH = (size_t)B * H;
 
     auto for_elems = [&](auto&& fn) {
-        for (int i = tid; i < GR * H; i += GT) {
+        for (int i = tid; i < GR * H; i += GW) {
             const int r = i / H, j = i - r * H;
             fn(r, j, row0 + r);
         }
@@ -840,7 +886,7 @@ __global__ void __launch_bounds__(GT) snsde_generic_srk_adjoint_kernel(SrkAdjArg
         const int idx = __float_as_int(tp[4]);
         if (tid < GR) { S0[tid * ldy + H] = tp[1]; S0[tid * ldy + H + 1] = tp[2]; }
         if (uses_x) {
-            for (int i = tid; i < GR * C; i += GT) {
+            for (int i = tid; i < GR * C; i += GW) {
                 const int r = i / C, c = i - r * C, row = row0 + r;
                 float v = 0.0f;
                 if (row < B) {
@@ -852,20 +898,20 @@ __global__ void __launch_bounds__(GT) snsde_generic_srk_adjoint_kernel(SrkAdjArg
         }
         __syncthreads();
         float* z0 = act;
-        if (io == 0) dense(a.params, a.ws, net.init, xbuf, ldx, z0, ldw, true);
-        else if (!uses_emb) dense(a.params, a.ws, net.in, S0, ldy, z0, ldw, true);
+        if (io == 0) dense_w(a.params, a.ws, net.init, xbuf, ldx, z0, ldw, true);
+        else if (!uses_emb) dense_w(a.params, a.ws, net.in, S0, ldy, z0, ldw, true);
         else {
-            dense(a.params, a.ws, net.in, S0, ldy, cat, ldw, false);
-            dense(a.params, a.ws, net.init, xbuf, ldx, cat + H, ldw, false);
+            dense_w(a.params, a.ws, net.in, S0, ldy, cat, ldw, false);
+            dense_w(a.params, a.ws, net.init, xbuf, ldx, cat + H, ldw, false);
             __syncthreads();
-            dense(a.params, a.ws, net.emb, cat, ldw, z0, ldw, true);
+            dense_w(a.params, a.ws, net.emb, cat, ldw, z0, ldw, true);
         }
         __syncthreads();
         for (int l = 0; l < net.n_hid; ++l) {
-            dense(a.params, a.ws, net.hid[l], act + (size_t)l * GR * ldw, ldw, act + (size_t)(l + 1) * GR * ldw, ldw, true);
+            dense_w(a.params, a.ws, net.hid[l], act + (size_t)l * GR * ldw, ldw, act + (size_t)(l + 1) * GR * ldw, ldw, true);
             __syncthreads();
         }
-        dense(a.params, a.ws, net.out, act + (size_t)net.n_hid * GR * ldw, ldw, zo, ldw, false);
+        dense_w(a.params, a.ws, net.out, act + (size_t)net.n_hid * GR * ldw, ldw, zo, ldw, false);
         __syncthreads();
     };
     auto f_value = [&](float* fout) {
@@ -908,10 +954,10 @@ __global__ void __launch_bounds__(GT) snsde_generic_srk_adjoint_kernel(SrkAdjArg
     auto gnet_fwd = [&](const float* tp) -> float* {
         if (tid < GR) { S1[tid * ldy + H] = tp[1]; S1[tid * ldy + H + 1] = tp[2]; }
         __syncthreads();
-        dense(a.params, a.ws, net.ny0, S1, ldy, cat, ldw, net2);
+        dense_w(a.params, a.ws, net.ny0, S1, ldy, cat, ldw, net2);
         __syncthreads();
         if (!net2) return cat;
-        dense(a.params, a.ws, net.ny1, cat, ldw, gnb, ldw, true);
+        dense_w(a.params, a.ws, net.ny1, cat, ldw, gnb, ldw, true);
         __syncthreads();
         return gnb;
     };
@@ -921,7 +967,7 @@ __global__ void __launch_bounds__(GT) snsde_generic_srk_adjoint_kernel(SrkAdjArg
         if (net2) {
             dense_T(a.params + net.ny1.src_w, net.ny1.K, 0, net.ny1.K, net.ny1.N, gnb, ldw, dl, ldw);
             __syncthreads();
-            for (int i = tid; i < GR * net.ny0.N; i += GT) {
+            for (int i = tid; i < GR * net.ny0.N; i += GW) {
                 const int r = i / net.ny0.N, j = i - r * net.ny0.N;
                 if (!(cat[r * ldw + j] > 0.0f)) dl[r * ldw + j] = 0.0f;
             }
@@ -976,7 +1022,7 @@ __global__ void __launch_bounds__(GT) snsde_generic_srk_adjoint_kernel(SrkAdjArg
         for (int l = net.n_hid; l >= 0; --l) {
             const float* zl = act + (size_t)l * GR * ldw;
             const int width = (l == 0 && io != 0) ? net.in.N : (l == 0 ? H : net.hid[l - 1].N);
-            for (int i = tid; i < GR * width; i += GT) {
+            for (int i = tid; i < GR * width; i += GW) {
                 const int r = i / width, j = i - r * width;
                 if (!(zl[r * ldw + j] > 0.0f)) oth[r * ldw + j] = 0.0f;
             }
@@ -1218,7 +1264,7 @@ __global__ void __launch_bounds__(GT) snsde_generic_srk_adjoint_kernel(SrkAdjArg
             for_elems([&](int r, int j, int) { AV[r * ldf + j] = YB[r * ldf + j] + dH[r * ldw + j]; });
         }
     }
-    for (int i = tid; i < GR * H; i += GT) {      // ys[0] = y0
+    for (int i = tid; i < GR * H; i += GW) {      // ys[0] = y0
         const int r = i / H, j = i - r * H, row = row0 + r;
         if (row < B) aa.adj[(size_t)row * H + j] = AV[r * ldf + j] +
             ((!a.row_out || a.row_out[row] == 0) ? aa.grad_ys[(size_t)row * H + j] : 0.0f);
@@ -1390,7 +1436,7 @@ int snsde_generic_backward_launch(const snsde_backward* b, const SnsdeNet& net, 
             hipFuncSetAttribute(reinterpret_cast<const void*>(snsde_generic_srk_adjoint_kernel),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes) != hipSuccess)
             return SNSDE_ERR_LDS;
-        hipLaunchKernelGGL(snsde_generic_srk_adjoint_kernel, dim3((s->batch + GR - 1) / GR), dim3(GT), bytes, stream, sa);
+        hipLaunchKernelGGL(snsde_generic_srk_adjoint_kernel, dim3((s->batch + GR - 1) / GR), dim3(GW), bytes, stream, sa);
         return hipGetLastError() == hipSuccess ? SNSDE_OK : SNSDE_ERR_LAUNCH;
     }
     aa.traj = s->traj; aa.dW_used = s->dW_out; aa.grad_ys = b->grad_ys; aa.adj = b->adj; aa.nbuf = net.n_hid + 1;
@@ -1401,7 +1447,7 @@ int snsde_generic_backward_launch(const snsde_backward* b, const SnsdeNet& net, 
         hipFuncSetAttribute(reinterpret_cast<const void*>(snsde_generic_adjoint_kernel),
                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes) != hipSuccess)
         return SNSDE_ERR_LDS;
-    hipLaunchKernelGGL(snsde_generic_adjoint_kernel, dim3((s->batch + GR - 1) / GR), dim3(GT), lds_bytes, stream, aa);
+    hipLaunchKernelGGL(snsde_generic_adjoint_kernel, dim3((s->batch + GR - 1) / GR), dim3(GW), lds_bytes, stream, aa);
     return hipGetLastError() == hipSuccess ? SNSDE_OK : SNSDE_ERR_LAUNCH;
 }
 
@@ -1441,7 +1487,7 @@ int snsde_srk_launch(const snsde_solve* s, const SnsdeNet& net, hipStream_t stre
         hipFuncSetAttribute(reinterpret_cast<const void*>(snsde_generic_srk_kernel),
                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes) != hipSuccess)
         return SNSDE_ERR_LDS;
-    hipLaunchKernelGGL(snsde_generic_srk_kernel, dim3((s->batch + GR - 1) / GR), dim3(GT), lds_bytes, stream, sa);
+    hipLaunchKernelGGL(snsde_generic_srk_kernel, dim3((s->batch + GR - 1) / GR), dim3(GW), lds_bytes, stream, sa);
     return hipGetLastError() == hipSuccess ? SNSDE_OK : SNSDE_ERR_LAUNCH;
 }
 
