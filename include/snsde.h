@@ -168,6 +168,10 @@ typedef struct snsde_solve {
     const int32_t* row_out;   /* optional device (B): per-row output selection (the gather of NeuralSDE.forward,  */
                               /* neuralsde.py:115-116).  When set, ys is (B, H) with ys[b] = the solution at      */
                               /* ts[row_out[b]] (0 <= row_out[b] < n_out), and the backward's grad_ys is (B, H).  */
+    const float*   z0_weight; /* optional device (H, C) + z0_bias (H): the wrapper's initial_network.  When set, the   */
+    const float*   z0_bias;   /* solve starts from y0 = z0_weight . X(ts[0]) + z0_bias (NeuralSDE._prepare_initial_state, */
+                              /* neuralsde.py:63-69) and `y0` is an OUTPUT: the caller passes an uninitialised (B, H)      */
+                              /* buffer, the library fills it in the same launch that packs the weights.                   */
     void*          workspace; /* device scratch, >= snsde_workspace_bytes()                      */
     size_t         workspace_bytes;
 } snsde_solve;
@@ -251,6 +255,28 @@ enum { SNSDE_PATH_NONE = 0,          /* no kernel: snsde_solve_forward returns S
        SNSDE_PATH_GENERIC_SRK = 6,   /* SRK on the generic family                                                   */
        SNSDE_PATH_MFMA_SRK = 7 };    /* SRK on the MFMA 4-row tiles                                                 */
 int snsde_forward_path(const snsde_solve* s);
+
+/* Readout head of the wrappers in one launch (inference; replaces the 4-5 tensor ops of `self.linear(z)`,
+ * benchmark_classification/models_sde/neuralsde.py:59-61,119; benchmark_forecasting/models_sde/neuralsde.py:186; torch_ists
+ * nsde_model.py):  out = W2 relu(bn(W1 act(x) + b1)) + b2  with act = tanh when input_tanh else identity and bn the
+ * BatchNorm1d inference transform (v - mean) / sqrt(var + eps) * weight + bias when bn_mean is set.  All pointers device,
+ * fp32, row-major contiguous; nn.Linear layout (out_features, in_features).                                              */
+typedef struct snsde_head {
+    int32_t rows, in_features, hidden, out_features;
+    int32_t input_tanh;
+    float   bn_eps;
+    const float* x;          /* (rows, in_features)                                   */
+    const float* w1;         /* (hidden, in_features)                                 */
+    const float* b1;         /* (hidden) or NULL                                      */
+    const float* bn_mean;    /* (hidden) running mean, or NULL: no normalisation      */
+    const float* bn_var;     /* (hidden) running variance (with bn_mean)              */
+    const float* bn_weight;  /* (hidden) or NULL                                      */
+    const float* bn_bias;    /* (hidden) or NULL                                      */
+    const float* w2;         /* (out_features, hidden)                                */
+    const float* b2;         /* (out_features) or NULL                                */
+    float*       out;        /* (rows, out_features)                                  */
+} snsde_head;
+int snsde_readout_head(const snsde_head* h, void* hip_stream);
 
 int         snsde_version(void);
 const char* snsde_strerror(int code);

@@ -35,6 +35,7 @@ class Solve(C.Structure):
                 ('out_step', C.c_void_p), ('out_w', C.c_void_p), ('y0', C.c_void_p), ('dW', C.c_void_p),
                 ('ys', C.c_void_p), ('traj', C.c_void_p), ('dW_out', C.c_void_p), ('srk_tab', C.c_void_p), ('dU', C.c_void_p),
                 ('dU_out', C.c_void_p), ('act_save', C.c_void_p), ('stage_save', C.c_void_p), ('seed_dev', C.c_void_p), ('noise_table', C.c_void_p), ('row_out', C.c_void_p),
+                ('z0_weight', C.c_void_p), ('z0_bias', C.c_void_p),
                 ('workspace', C.c_void_p), ('workspace_bytes', C.c_size_t)]
 
 
@@ -42,6 +43,13 @@ class Backward(C.Structure):
     _fields_ = [('fwd', Solve), ('grad_ys', C.c_void_p), ('adj', C.c_void_p), ('delta_save', C.c_void_p),
                 ('workspace', C.c_void_p),
                 ('workspace_bytes', C.c_size_t), ('grad_noise_table', C.c_void_p)]
+
+
+class Head(C.Structure):
+    _fields_ = [('rows', C.c_int32), ('in_features', C.c_int32), ('hidden', C.c_int32), ('out_features', C.c_int32),
+                ('input_tanh', C.c_int32), ('bn_eps', C.c_float),
+                ('x', C.c_void_p), ('w1', C.c_void_p), ('b1', C.c_void_p), ('bn_mean', C.c_void_p), ('bn_var', C.c_void_p),
+                ('bn_weight', C.c_void_p), ('bn_bias', C.c_void_p), ('w2', C.c_void_p), ('b2', C.c_void_p), ('out', C.c_void_p)]
 
 
 class SnsdeError(RuntimeError):
@@ -58,7 +66,7 @@ EXPORTS = ('snsde_version', 'snsde_strerror', 'snsde_param_count', 'snsde_param_
            'snsde_spline_evaluate', 'snsde_eval_fg', 'snsde_act_slots', 'snsde_backward_supported',
            'snsde_backward_workspace_bytes', 'snsde_solve_backward', 'snsde_spline_workspace_bytes',
            'snsde_natural_cubic_coeffs', 'snsde_hermite_coeffs', 'snsde_param_gradients_workspace_bytes',
-           'snsde_param_gradients', 'snsde_forward_path')
+           'snsde_param_gradients', 'snsde_forward_path', 'snsde_readout_head')
 
 
 def lib():
@@ -100,6 +108,7 @@ def lib():
     L.snsde_param_gradients.argtypes = [C.POINTER(Backward), C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]
     L.snsde_backward_supported.argtypes = [C.POINTER(Solve)]
     L.snsde_forward_path.argtypes = [C.POINTER(Solve)]
+    L.snsde_readout_head.argtypes = [C.POINTER(Head), C.c_void_p]
     L.snsde_backward_workspace_bytes.argtypes = [C.POINTER(Backward)]
     L.snsde_backward_workspace_bytes.restype = C.c_size_t
     L.snsde_solve_backward.argtypes = [C.POINTER(Backward), C.c_void_p]

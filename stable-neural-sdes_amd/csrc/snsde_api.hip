@@ -320,6 +320,7 @@ static int validate_solve(const snsde_solve* s, bool eval) {
         if (s->method == SNSDE_MILSTEIN && (no == 7 || no == 14 || no == 15 || no == 18 || no == 19))
             return SNSDE_ERR_UNSUPPORTED;
         if (s->noise_table && no != 12 && no != 13) return SNSDE_ERR_OPTION;   // a supplied table is the time-only factor
+        if ((s->z0_weight != nullptr) != (s->z0_bias != nullptr)) return SNSDE_ERR_NULL;
     }
     return SNSDE_OK;
 }
@@ -355,6 +356,7 @@ int snsde_solve_forward(const snsde_solve* s, void* hip_stream) {
         if (s->kernel == SNSDE_KERNEL_MFMA || s->kernel == SNSDE_KERNEL_MFMA_M4) return snsde_mfma_launch(s, net, st, 1);
         if (s->kernel == SNSDE_KERNEL_AUTO && snsde_mfma_supported(s, net)) return snsde_mfma_launch(s, net, st, -1);
         if (s->kernel != SNSDE_KERNEL_AUTO && s->kernel != SNSDE_KERNEL_GENERIC) return SNSDE_ERR_OPTION;
+        if (s->z0_weight && (rc = snsde_z0_launch(s, st)) != SNSDE_OK) return rc;
         return snsde_srk_launch(s, net, st);
     }
     switch (s->kernel) {
@@ -367,6 +369,7 @@ int snsde_solve_forward(const snsde_solve* s, void* hip_stream) {
         case SNSDE_KERNEL_MFMA_M4: return snsde_mfma_launch(s, net, st, 1);
         default: return SNSDE_ERR_OPTION;
     }
+    if (s->z0_weight && (rc = snsde_z0_launch(s, st)) != SNSDE_OK) return rc;
     return snsde_generic_launch(s, net, static_cast<hipStream_t>(hip_stream), 0, nullptr, nullptr, nullptr, nullptr);
 }
 

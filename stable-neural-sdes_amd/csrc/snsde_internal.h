@@ -71,6 +71,7 @@ bool snsde_mfma_backward_partials(const snsde_solve* s, const SnsdeNet& net, int
 size_t snsde_wgrad_workspace_floats(const snsde_backward* b, const SnsdeNet& net);
 int snsde_wgrad_launch(const snsde_backward* b, const SnsdeNet& net, float* grad_params, int32_t n_params, float* ws,
                        hipStream_t stream);
+int snsde_z0_launch(const snsde_solve* s, hipStream_t stream);   // y0 = z0_weight . X(ts[0]) + z0_bias (stand-alone launch)
 int snsde_spline_launch(const float* coeffs, int32_t B, int32_t L, int32_t C, int32_t index, float frac,
                         int32_t derivative, float* out, hipStream_t stream);
 
@@ -95,6 +96,33 @@ __device__ __forceinline__ float snsde_spline_eval(float a, float b, float two_c
     float inner = 0.5f * two_c + three_d * frac / 3.0f;
     inner = b + inner * frac;
     return a + inner * frac;
+}
+
+// Initial state rows of the wrapper (NeuralSDE._prepare_initial_state, neuralsde.py:63-69): y0 = W X(ts[0]) + b with the
+// control path evaluated in the interval of the first solver step.  Blocks bx of nbx share the (row, feature) pairs.
+struct SnsdeZ0Job {
+    const float* w;        // (H, C)
+    const float* b;        // (H)
+    const float* coeffs;   // (B, L-1, 4C)
+    const float* step_tab; // row 0: frac at [4], interval index at [5]
+    float* y0;             // (B, H) out
+    int32_t B, H, C, L;
+};
+
+__device__ __forceinline__ void snsde_z0_rows(const SnsdeZ0Job& z, int bx, int nbx) {
+    const float frac = z.step_tab[4];
+    const int idx = __float_as_int(z.step_tab[5]);
+    const int total = z.B * z.H;
+    for (int i = bx * blockDim.x + threadIdx.x; i < total; i += nbx * blockDim.x) {
+        const int row = i / z.H, j = i - row * z.H;
+        const float* cp = z.coeffs + ((size_t)row * (z.L - 1) + idx) * (4 * z.C);
+        const float* wp = z.w + (size_t)j * z.C;
+        float acc = z.b[j];
+#pragma unroll 4
+        for (int c = 0; c < z.C; ++c)
+            acc = fmaf(wp[c], snsde_spline_eval(cp[c], cp[z.C + c], cp[2 * z.C + c], cp[3 * z.C + c], frac), acc);
+        z.y0[i] = acc;
+    }
 }
 __device__ __forceinline__ float snsde_spline_deriv(float b, float two_c, float three_d, float frac) {
 #pragma clang fp contract(off)

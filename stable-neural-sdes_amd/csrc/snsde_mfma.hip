@@ -179,6 +179,7 @@ __global__ void snsde_fold_kernel(const float* __restrict__ params, float* __res
 __global__ void snsde_prepare_kernel(const float* __restrict__ params, float* __restrict__ ws, FoldJob fj, MfmaPackJob job) {
     extern __shared__ float erow[];
     if (blockIdx.y < 3) { fold_block(params, ws, fj, fj.fold_on ? &job : nullptr, erow); return; }
+    if ((int)blockIdx.y == 3 + job.n_layers) { snsde_z0_rows(fj.z0, blockIdx.x, gridDim.x); return; }   // y0 = W0 X(ts[0]) + b0
     if (blockIdx.x < 16) pack_layer(params, ws, job, blockIdx.y - 3, blockIdx.x, 16, fj.fold_on != 0);
 }
 
@@ -442,8 +443,16 @@ int snsde_mfma_launch(const snsde_solve* s, const SnsdeNet& net, hipStream_t str
             fj.off_sigma = net.off_sigma; fj.off_sigma_diag = net.off_sigma_diag;
             int gx = fj.tab_on && s->n_steps > p.H ? s->n_steps : p.H;
             if (gx < 16) gx = 16;
-            hipLaunchKernelGGL(snsde_prepare_kernel, dim3(gx, 3 + p.n_layers), dim3(256), 2 * p.H * sizeof(float), stream,
-                               s->params, ws, fj, job);
+            fj.z0 = SnsdeZ0Job{};
+            if (s->z0_weight) {      // one initial-state element per thread: the slice wants B H / 256 blocks (the others exit early)
+                fj.z0 = SnsdeZ0Job{s->z0_weight, s->z0_bias, s->coeffs, s->step_tab, const_cast<float*>(s->y0), s->batch,
+                                   s->model.hidden_channels, s->model.input_channels, s->knots};
+                int gz = (s->batch * s->model.hidden_channels + 255) / 256;
+                if (gz > 2048) gz = 2048;
+                if (gz > gx) gx = gz;
+            }
+            hipLaunchKernelGGL(snsde_prepare_kernel, dim3(gx, 3 + p.n_layers + (s->z0_weight ? 1 : 0)), dim3(256),
+                               2 * p.H * sizeof(float), stream, s->params, ws, fj, job);
         }
         if (p.SRK) {
             if (!s->srk_tab) return SNSDE_ERR_NULL;
@@ -455,6 +464,9 @@ int snsde_mfma_launch(const snsde_solve* s, const SnsdeNet& net, hipStream_t str
                 if (rc) return rc;
             }
         }
+    } else if (s->z0_weight) {
+        const int rc = snsde_z0_launch(s, stream);
+        if (rc) return rc;
     }
     MfmaArgs a{};
     a.params = s->params; a.ws = ws; a.coeffs = s->coeffs; a.step_tab = s->step_tab; a.out_step = s->out_step;

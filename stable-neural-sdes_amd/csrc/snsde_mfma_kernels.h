@@ -67,6 +67,7 @@ struct FoldJob {
     int32_t tab_on, tab_off, n_steps, no, fold_on, off_sigma, off_sigma_diag;
     SnsdeLayer nt0, nt1;
     const float* step_tab;
+    SnsdeZ0Job z0;      // initial state from the control path in the same launch (z0.w == nullptr: none)
 };
 
 struct MfmaArgs {

@@ -195,3 +195,20 @@ int snsde_hermite_coeffs(const float* times, const float* X, int32_t batch, int3
 }
 
 }  // extern "C"
+
+// ---- initial state from the control path (stand-alone form; the MFMA forward folds it into its prepare launch) ----
+namespace {
+__global__ void snsde_z0_kernel(SnsdeZ0Job z) { snsde_z0_rows(z, blockIdx.x, gridDim.x); }
+}
+
+int snsde_z0_launch(const snsde_solve* s, hipStream_t stream) {
+    if (!s->z0_weight || !s->z0_bias || !s->y0 || !s->step_tab) return SNSDE_ERR_NULL;
+    SnsdeZ0Job z{s->z0_weight, s->z0_bias, s->coeffs, s->step_tab, const_cast<float*>(s->y0), s->batch,
+                 s->model.hidden_channels, s->model.input_channels, s->knots};
+    const int total = s->batch * s->model.hidden_channels;
+    int grid = (total + 255) / 256;
+    if (grid > 2048) grid = 2048;
+    hipLaunchKernelGGL(snsde_z0_kernel, dim3(grid), dim3(256), 0, stream, z);
+    return hipGetLastError() == hipSuccess ? SNSDE_OK : SNSDE_ERR_LAUNCH;
+}
+

@@ -319,7 +319,7 @@ class SolveCall:
 
     def __init__(self, model, flat_params, coeffs, grid, y0, dW=None, method='euler', seed=0, row_offset=0,
                  kernel='auto', save_traj=False, save_dW=False, exact_order=False, save_act=False, dU=None, row_out=None,
-                 noise_table=None):
+                 noise_table=None, z0_linear=None):
         B, H = y0.shape
         C_ = model.input_channels
         L = coeffs.shape[1] + 1
@@ -337,7 +337,10 @@ class SolveCall:
                 raise ValueError('row_out must be a contiguous int32 CUDA tensor of shape (batch,)')
         if noise_table is not None:
             _check_f32('noise_table', noise_table, (grid.N, H))
-        self.keep = (flat_params, coeffs, y0, dW, grid, dU, row_out, noise_table)
+        if z0_linear is not None:     # (weight (H, C), bias (H)): y0 is then an output, filled by the solve's prepare launch
+            _check_f32('z0 weight', z0_linear[0], (H, C_))
+            _check_f32('z0 bias', z0_linear[1], (H,))
+        self.keep = (flat_params, coeffs, y0, dW, grid, dU, row_out, noise_table, z0_linear)
         # per-row output selection: one state per row instead of one plane per output time
         self.ys = torch.empty((B, H) if row_out is not None else (grid.T, B, H), device=dev, dtype=torch.float32)
         self.traj = torch.empty((grid.N + 1, B, H), device=dev, dtype=torch.float32) if save_traj else None
@@ -378,6 +381,8 @@ class SolveCall:
         s.stage_save = _ptr(self.stage_save)
         s.row_out = _ptr(row_out)
         s.noise_table = _ptr(noise_table)
+        if z0_linear is not None:
+            s.z0_weight, s.z0_bias = _ptr(z0_linear[0]), _ptr(z0_linear[1])
         nbytes = _lib.lib().snsde_workspace_bytes(C.byref(s))
         self.workspace = torch.empty(max(nbytes, 256), device=dev, dtype=torch.uint8)
         s.workspace = _ptr(self.workspace)
@@ -495,6 +500,65 @@ def eval_fg(model, flat_params, coeffs, times_host, t, y, kernel='auto'):
     _lib.check(_lib.lib().snsde_eval_fg(C.byref(s), _ptr(g.d_step_tab), _ptr(y), _ptr(f), _ptr(gg),
                                         C.c_void_p(stream.cuda_stream)), 'snsde_eval_fg')
     return f, gg
+
+
+def head_layers(seq):
+    """(input_tanh, linear1, batchnorm or None, linear2) when `seq` is one of the wrappers' readout heads in a state the
+    fused head reproduces - [Tanh,] Linear, [BatchNorm1d on running statistics,] ReLU, [Dropout in eval mode,] Linear - else
+    None (benchmark_classification/models_sde/neuralsde.py:59-61; benchmark_forecasting/...:153-155; torch_ists nsde_model)."""
+    mods = list(seq) if isinstance(seq, torch.nn.Sequential) else None
+    if not mods:
+        return None
+    tanh = isinstance(mods[0], torch.nn.Tanh)
+    if tanh:
+        mods = mods[1:]
+    if len(mods) < 3 or not isinstance(mods[0], torch.nn.Linear) or not isinstance(mods[-1], torch.nn.Linear):
+        return None
+    lin1, lin2, mid = mods[0], mods[-1], mods[1:-1]
+    bn = None
+    if isinstance(mid[0], torch.nn.BatchNorm1d):
+        bn, mid = mid[0], mid[1:]
+        if bn.training or bn.running_mean is None:
+            return None
+    if not mid or not isinstance(mid[0], torch.nn.ReLU):
+        return None
+    for m in mid[1:]:
+        if not (isinstance(m, torch.nn.Dropout) and (not m.training or m.p == 0.0)):
+            return None
+    if lin2.in_features != lin1.out_features or (bn is not None and bn.num_features != lin1.out_features):
+        return None
+    if lin1.out_features > 128 or lin1.in_features > 256:
+        # wider heads: the library GEMM chain is faster (measured 27 vs 42 us at 1280 x 256 x 256 x 14; the kernel itself
+        # takes hidden sizes up to 512)
+        return None
+    return tanh, lin1, bn, lin2
+
+
+def readout_head(x, layers, stream=None):
+    """out = linear2(relu(bn(linear1(act(x))))) over the last dimension of x in ONE launch (snsde_readout_head); inference
+    only - the caller checks torch.is_grad_enabled().  `layers` = (input_tanh, linear1, batchnorm or None, linear2)."""
+    tanh, lin1, bn, lin2 = layers
+    lead = x.shape[:-1]
+    x2 = x.reshape(-1, x.shape[-1])
+    if not x2.is_contiguous():
+        x2 = x2.contiguous()
+    _check_f32('head input', x2, (x2.shape[0], lin1.in_features))
+    out = torch.empty((x2.shape[0], lin2.out_features), device=x.device, dtype=torch.float32)
+    h = _lib.Head()
+    h.rows, h.in_features, h.hidden, h.out_features = x2.shape[0], lin1.in_features, lin1.out_features, lin2.out_features
+    h.input_tanh = 1 if tanh else 0
+    keep = [x2, lin1.weight.detach().contiguous(), lin2.weight.detach().contiguous()]
+    h.x, h.w1, h.w2, h.out = _ptr(x2), _ptr(keep[1]), _ptr(keep[2]), _ptr(out)
+    h.b1 = _ptr(None if lin1.bias is None else lin1.bias.detach())
+    h.b2 = _ptr(None if lin2.bias is None else lin2.bias.detach())
+    if bn is not None:
+        h.bn_eps = float(bn.eps)
+        h.bn_mean, h.bn_var = _ptr(bn.running_mean), _ptr(bn.running_var)
+        h.bn_weight = _ptr(None if bn.weight is None else bn.weight.detach())
+        h.bn_bias = _ptr(None if bn.bias is None else bn.bias.detach())
+    stream = torch.cuda.current_stream(x.device) if stream is None else stream
+    _lib.check(_lib.lib().snsde_readout_head(C.byref(h), C.c_void_p(stream.cuda_stream)), 'snsde_readout_head')
+    return out.reshape(*lead, lin2.out_features)
 
 
 def spline_coeffs(times, X, kind='natural'):

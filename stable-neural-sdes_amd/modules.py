@@ -208,6 +208,30 @@ class _SDEHead(nn.Module):
         assert not self.initial, "Was expecting to be given a value of z0."
         return z0
 
+    def _initial_state(self, times, z0, kwargs):
+        """(z0, kwargs).  Inference on the fused path: z0 is an uninitialised placeholder and options['z0_linear'] hands the
+        solve `initial_network`, which evaluates initial_network(X(times[0])) inside its prepare launch (no spline-evaluate
+        and addmm launches of its own); everything else: `_prepare_initial_state` (neuralsde.py:63-69)."""
+        func = self.func
+        if (z0 is None and self.initial and not torch.is_grad_enabled() and getattr(func, 'coeffs', None) is not None
+                and func.coeffs.is_cuda and self.initial_network.weight.is_cuda
+                and self.initial_network.weight.dtype == torch.float32 and engine.recognise(func) is not None):
+            kwargs = dict(kwargs)
+            kwargs['options'] = dict(kwargs.get('options') or {}, z0_linear=self.initial_network)
+            z0 = torch.empty(func.coeffs.shape[0], self.initial_network.out_features, device=func.coeffs.device,
+                             dtype=torch.float32)
+            return z0, kwargs
+        return self._prepare_initial_state(times, z0), kwargs
+
+    def _readout(self, z):
+        """self.linear(z); one fused launch (snsde_readout_head) for inference on CUDA float32 when the head has the
+        wrappers' structure and is in evaluation mode."""
+        if z.is_cuda and z.dtype == torch.float32 and not torch.is_grad_enabled():
+            layers = engine.head_layers(self.linear)
+            if layers is not None and layers[1].weight.is_cuda and layers[1].weight.dtype == torch.float32:
+                return engine.readout_head(z, layers)
+        return self.linear(z)
+
     def _solve_sde_path(self, times, ts, z0, kwargs):
         kwargs, dt = prepare_sde_solver_kwargs(times, kwargs, default_method=self.default_method,
                                                respect_euler_grid=self.respect_euler_grid)
@@ -241,7 +265,7 @@ class NeuralSDE(_SDEHead):
 
     def forward(self, times, coeffs, final_index, z0=None, stream=False, **kwargs):
         self.func.set_X(*coeffs, times)
-        z0 = self._prepare_initial_state(times, z0)
+        z0, kwargs = self._initial_state(times, z0, kwargs)
         if stream:
             return self.linear(self._solve_sde_path(times, times, z0, kwargs).movedim(0, -2))
         if z0.is_cuda and engine.recognise(self.func) is not None:
@@ -252,12 +276,12 @@ class NeuralSDE(_SDEHead):
             # (neuralsde.py:91-116) — without its two device->host syncs and without the (T, B, H) round trip.
             kwargs = dict(kwargs)
             kwargs['options'] = dict(kwargs.get('options') or {}, row_out=final_index)
-            return self.linear(self._solve_sde_path(times, times, z0, kwargs))
+            return self._readout(self._solve_sde_path(times, times, z0, kwargs))
         ts, row_slot = self.output_times(times, final_index)
         z_t = self._solve_sde_path(times, ts, z0, kwargs)
         idx = row_slot.reshape(1, -1, 1).expand(1, z_t.shape[1], z_t.shape[2])
         z = z_t.gather(0, idx).squeeze(0)
-        return self.linear(z)
+        return self._readout(z)
 
 
 class NeuralSDE_forecasting(_SDEHead):
@@ -275,9 +299,9 @@ class NeuralSDE_forecasting(_SDEHead):
 
     def forward(self, times, coeffs, final_index, z0=None, stream=False, **kwargs):
         self.func.set_X(torch.cat(coeffs, dim=-1), times)
-        z0 = self._prepare_initial_state(times, z0)
+        z0, kwargs = self._initial_state(times, z0, kwargs)
         z = self._solve_sde_path(times, times, z0, kwargs).movedim(0, -2)
-        return self.linear(z[:, z.shape[1] - self.output_time:, :])
+        return self._readout(z[:, z.shape[1] - self.output_time:, :])
 
 
 class IstsNeuralSDE(_SDEHead):
@@ -295,11 +319,12 @@ class IstsNeuralSDE(_SDEHead):
 
     def forward(self, coeffs, times, **kwargs):
         self.func.set_X(coeffs, times)
-        x0 = self.func.X.evaluate(times[0])
-        if not self.initial:
-            x0 = torch.zeros_like(x0)
-        z = self._solve_sde_path(times, times, self.initial_network(x0), kwargs).permute(1, 0, 2)
-        return self.linear(z), z
+        if self.initial:
+            z0, kwargs = self._initial_state(times, None, kwargs)
+        else:
+            z0 = self.initial_network(torch.zeros_like(self.func.X.evaluate(times[0])))
+        z = self._solve_sde_path(times, times, z0, kwargs).permute(1, 0, 2)
+        return self._readout(z), z
 
 
 def make_sde_model(name, input_channels, output_channels, hidden_channels, hidden_hidden_channels,

@@ -153,6 +153,8 @@ def sdeint(sde, y0, ts, bm=None, method=None, dt=1e-3, adaptive=False, rtol=1e-5
                                       and not (set(names) - {'drift', 'diffusion'}))
     rec = engine.recognise(sde) if default_names else None
     want_hip = backend == 'hip' or (backend == 'auto' and rec is not None and y0.is_cuda)
+    if 'z0_linear' in options and not (want_hip and rec is not None and y0.is_cuda):
+        y0 = _materialise_z0(sde, y0, ts, options)      # only the fused solve evaluates the initial state itself
     if want_hip:
         if rec is None:
             raise ValueError("options['backend']='hip' needs an sde honouring the Diffusion_model contract")
@@ -177,6 +179,20 @@ def sdeint_adjoint(sde, y0, ts, bm=None, method=None, adjoint_method=None, adjoi
     return sdeint(sde, y0, ts, bm=bm, method=method, names=names, **kwargs)
 
 
+def _materialise_z0(sde, y0, ts, options):
+    """options['z0_linear'] = the wrapper's `initial_network`: y0 is a placeholder and the solve starts from
+    initial_network(X(ts[0])) (NeuralSDE._prepare_initial_state, neuralsde.py:63-69).  Evaluated here with tensor ops for
+    every path but the no-grad fused solve, which computes it inside its prepare launch."""
+    lin = options.pop('z0_linear')
+    return lin(sde.X.evaluate(ts[0])).to(y0.dtype)
+
+
+def _z0_fusable(lin, sde, y0):
+    w, b = lin.weight, lin.bias
+    return (b is not None and w.is_cuda and w.dtype == torch.float32 and b.dtype == torch.float32 and w.is_contiguous()
+            and tuple(w.shape) == (y0.shape[1], sde.input_channels) and not torch.is_grad_enabled())
+
+
 class _DrawnIncrements:
     """bm(ta, tb[, return_U]) over increments that were already drawn from the caller's Brownian object, in call order: a
     fallback from the fused path to the tensor-op loop must not query a stateful `bm` a second time."""
@@ -191,6 +207,14 @@ class _DrawnIncrements:
 
 def _sdeint_hip(sde, rec, y0, ts, bm, method, dt, options):
     model, layout, numel = rec
+    z0_lin = None
+    if 'z0_linear' in options:
+        options = dict(options)
+        if (_z0_fusable(options['z0_linear'], sde, y0) and bm is None and options.get('kernel', 'auto') == 'auto'
+                and not options.get('save_traj', False)):
+            z0_lin = options.pop('z0_linear')
+        else:
+            y0 = _materialise_z0(sde, y0, ts, options)
     needs_grad = torch.is_grad_enabled() and (y0.requires_grad or any(p.requires_grad for p in sde.parameters()))
     dev = y0.device
     coeffs = sde.coeffs
@@ -229,6 +253,9 @@ def _sdeint_hip(sde, rec, y0, ts, bm, method, dt, options):
     if options.get('kernel', 'auto') == 'auto' and not options.get('save_traj', False) and not options.get('recompute'):
         pad = engine.padding_plan(model, y0c.shape[0], coeffs.shape[1] + 1, grid.N, method)
         if pad is not None:       # a hidden size without MFMA instantiation: solve the zero-padded model (exact)
+            if z0_lin is not None:
+                y0 = _materialise_z0(sde, y0, ts, {'z0_linear': z0_lin})
+                y0c, z0_lin = y0.detach().to(torch.float32).contiguous(), None
             out = _sdeint_padded(sde, rec, pad, coeffs, grid, y0, dW, dU, method, seed, options, row_out, needs_grad)
             if out is not None:
                 return out
@@ -251,7 +278,8 @@ def _sdeint_hip(sde, rec, y0, ts, bm, method, dt, options):
     call = engine.SolveCall(model, flat, coeffs, grid, y0c, dW=dW, method=method, seed=seed,
                             row_offset=int(options.get('row_offset', 0)), kernel=options.get('kernel', 'auto'),
                             save_traj=bool(options.get('save_traj', False)),
-                            exact_order=bool(options.get('exact_order', False)), dU=dU, row_out=row_out)
+                            exact_order=bool(options.get('exact_order', False)), dU=dU, row_out=row_out,
+                            z0_linear=None if z0_lin is None else (z0_lin.weight.detach(), z0_lin.bias.detach().contiguous()))
     try:
         ys = call.launch()
     except engine._lib.SnsdeError as exc:
@@ -259,6 +287,8 @@ def _sdeint_hip(sde, rec, y0, ts, bm, method, dt, options):
         # 7 / 14 / 15 / 18 / 19): same behaviour as the gradient path, the unfused tensor-op loop, unless strict
         if exc.code != -4 or options.get('strict', False):
             raise
+        if z0_lin is not None:
+            y0 = _materialise_z0(sde, y0, ts, {'z0_linear': z0_lin})
         return _sdeint_torch(sde, y0, ts, bm if dW is None else _DrawnIncrements(dW, dU), method, dt, options, None)
     if options.get('save_traj', False):
         sde.last_trajectory = call.traj

@@ -770,3 +770,20 @@ def test_recompute_chunks_partition_the_step_table(ts, dt, chunk):
             assert nout[n] == len(idx) and (not idx or first[n] == idx[0])
         seen += ks
     assert seen == list(range(1, g.T))
+
+
+def test_readout_head_recognition_gate():
+    """engine.head_layers: the fused inference head only stands in for the wrappers' readout structures in evaluation mode
+    (neuralsde.py:59-61: Linear, BatchNorm1d, ReLU, Dropout, Linear)."""
+    nn = torch.nn
+    head = nn.Sequential(nn.Linear(8, 8), nn.BatchNorm1d(8), nn.ReLU(), nn.Dropout(0.1), nn.Linear(8, 2))
+    engine = S.engine
+    assert engine.head_layers(head) is None                     # training mode: batch statistics and dropout
+    head.eval()
+    tanh, lin1, bn, lin2 = engine.head_layers(head)
+    assert not tanh and lin1 is head[0] and bn is head[1] and lin2 is head[4]
+    assert engine.head_layers(nn.Sequential(nn.Tanh(), nn.Linear(8, 8), nn.ReLU(), nn.Linear(8, 2)))[0] is True
+    assert engine.head_layers(nn.Sequential(nn.Linear(8, 8), nn.Tanh(), nn.Linear(8, 2))) is None
+    assert engine.head_layers(nn.Sequential(nn.Linear(8, 8), nn.ReLU(), nn.Linear(4, 2))) is None
+    assert engine.head_layers(nn.Linear(8, 2)) is None
+

@@ -57,5 +57,23 @@ for name, B, H, C, L in (('neurallnsde', 1024, 128, 21, 101), ('naivesde', 2048,
         with torch.no_grad():
             model(times, [coeffs], fi)
     t_train, t_inf = timeit(train_step), timeit(infer)
+    # (3) evaluation mode (BatchNorm running statistics, no dropout): eager and recorded into a graph; the bare solve beside it
+    model.eval()
+    t_eval = timeit(infer)
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        for _ in range(3): infer()
+    torch.cuda.current_stream().wait_stream(side); torch.cuda.synchronize()
+    gi = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(gi):
+        infer()
+    t_eval_graph = timeit(gi.replay)
+    z0 = torch.zeros(B, H, device=dev)
+    model.func.set_X(coeffs, times)
+    def solve():
+        with torch.no_grad():
+            S.sdeint(model.func, z0, times, dt=1.0, method='euler', options={'row_out': fi})
+    t_solve = timeit(solve)
     print(f'{name:12s} B={B} H={H} L={L}: inference {t_inf:.3f} ms, training step {t_train:.3f} ms, '
-          f'graph-replayed training step {t_graph:.3f} ms')
+          f'graph-replayed training step {t_graph:.3f} ms; eval-mode inference {t_eval:.3f} ms, graph-replayed '
+          f'{t_eval_graph:.3f} ms, its solve alone {t_solve:.3f} ms')
