@@ -25,11 +25,11 @@ for name, B, H, C, L in (('neurallnsde', 1024, 128, 21, 101), ('naivesde', 2048,
     fi = torch.randint(2, L, (B,), device=dev)
     target = (torch.rand(B, device=dev) > 0.5).float()
 
-    def build(capturable):
+    def build(capturable, fused=None):
         torch.manual_seed(0)
         model, _ = S.make_sde_model(name, C, 1, H, H, 2, initial=True)
         model = model.to(dev).train()
-        return model, torch.optim.Adam(model.parameters(), lr=1e-3, capturable=capturable)
+        return model, torch.optim.Adam(model.parameters(), lr=1e-3, capturable=capturable, fused=fused)
 
     def make_step(model, opt):
         def train_step():
@@ -57,6 +57,18 @@ for name, B, H, C, L in (('neurallnsde', 1024, 128, 21, 101), ('naivesde', 2048,
         with torch.no_grad():
             model(times, [coeffs], fi)
     t_train, t_inf = timeit(train_step), timeit(infer)
+    mf, of = build(False, fused=True)                # train.py's optimizer: single-launch Adam
+    t_train_fused = timeit(make_step(mf, of))
+    mfg, ofg = build(True, fused=True)
+    cap2 = make_step(mfg, ofg)
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        for _ in range(3): cap2()
+    torch.cuda.current_stream().wait_stream(side); torch.cuda.synchronize()
+    g2 = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g2):
+        cap2()
+    t_graph_fused = timeit(g2.replay)
     # (3) evaluation mode (BatchNorm running statistics, no dropout): eager and recorded into a graph; the bare solve beside it
     model.eval()
     t_eval = timeit(infer)
@@ -75,5 +87,5 @@ for name, B, H, C, L in (('neurallnsde', 1024, 128, 21, 101), ('naivesde', 2048,
             S.sdeint(model.func, z0, times, dt=1.0, method='euler', options={'row_out': fi})
     t_solve = timeit(solve)
     print(f'{name:12s} B={B} H={H} L={L}: inference {t_inf:.3f} ms, training step {t_train:.3f} ms, '
-          f'graph-replayed training step {t_graph:.3f} ms; eval-mode inference {t_eval:.3f} ms, graph-replayed '
+          f'graph-replayed training step {t_graph:.3f} ms; with fused Adam {t_train_fused:.3f} / {t_graph_fused:.3f} ms; eval-mode inference {t_eval:.3f} ms, graph-replayed '
           f'{t_eval_graph:.3f} ms, its solve alone {t_solve:.3f} ms')
