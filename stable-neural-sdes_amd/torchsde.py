@@ -263,8 +263,8 @@ def _sdeint_hip(sde, rec, y0, ts, bm, method, dt, options):
         mode = engine.backward_mode(model, y0c.shape[0], coeffs.shape[1] + 1, grid, method, options.get('kernel', 'auto'),
                                     bool(options.get('exact_order', False)))
         if mode == 0 and not options.get('strict', False):
-            # no fused adjoint for this configuration (a diffusion net under Milstein / SRK, or with more than 32 control
-            # channels): differentiate through the unfused tensor-op loop on the same device rather than fail the
+            # no fused adjoint for this configuration (Milstein with a diffusion net or sqrt(y)): differentiate through the
+            # unfused tensor-op loop on the same device rather than fail the
             # reference's training loop; options={'strict': True} raises instead
             key = (sde.input_option, sde.noise_option, method)
             if key not in _UNFUSED_WARNED:
@@ -416,9 +416,9 @@ class _FusedSolve(torch.autograd.Function):
                                     bool(options.get('exact_order', False)))
         if mode == 0:
             raise NotImplementedError(
-                "the fused backward covers 'euler'/'milstein'/'srk' with a diffusion that is elementwise in y "
-                "(noise_option 0..13, 16, 17) and 'euler' with the diffusion nets 14/15/18/19 where the MFMA path is "
-                "instantiated; pass options={'backend': 'torch'} to differentiate this configuration through the "
+                "the fused backward covers 'euler' and 'srk' for every noise_option and 'milstein' where dg/dy is "
+                "elementwise in closed form (every noise_option but 7, 14, 15, 18, 19), within the LDS budget of the generic "
+                "adjoint kernels; pass options={'backend': 'torch'} to differentiate this configuration through the "
                 "tensor-op loop")
         # recompute mode (options={'recompute': steps per chunk} or SNSDE_RECOMPUTE_STEPS): keep states and increments only,
         # re-run the forward kernel chunk by chunk inside backward (engine.backward_recompute)

@@ -817,22 +817,26 @@ def test_native_parameter_pass_matches_library_gemm_pass(case):
 
 
 def test_backward_without_a_fused_adjoint_falls_back_to_the_tensor_loop_or_raises_when_strict():
-    pr = make_problem(9, 4, 18, 2, 8, 64, 40, 5)      # a diffusion net with more than 32 control channels: no fused backward
+    # Milstein with a diffusion net: dg/dy is dense (torchsde takes a VJP of g) - the one family without a fused backward
+    pr = make_problem(9, 4, 18, 2, 8, 64, 40, 5)
     m = S.Diffusion_model(40, 64, 64, 2, input_option=4, noise_option=18).to(DEV)
     m.set_X(torch.from_numpy(pr['coeffs']).to(DEV), torch.from_numpy(pr['times']).to(DEV))
     y0 = torch.from_numpy(pr['y0']).to(DEV).requires_grad_(True)
     ts = torch.tensor([0., 4.], device=DEV)
     with pytest.raises(NotImplementedError):
-        S.sdeint(m, y0, ts, method='euler', dt=1.0, options={'strict': True})
-    m2 = S.Diffusion_model(3, 64, 64, 2, input_option=1, noise_option=14).to(DEV)     # SRK through a diffusion net
+        S.sdeint(m, y0, ts, method='milstein', dt=1.0, options={'strict': True})
+    for method in ('euler', 'srk'):        # (round 2: the generic adjoint kernels take the nets, wide control path included)
+        S.sdeint(m, y0, ts, method=method, dt=1.0, options={'strict': True, 'seed': 1})[-1].sum().backward()
+    m2 = S.Diffusion_model(3, 64, 64, 2, input_option=1, noise_option=14).to(DEV)
     pr2 = make_problem(9, 1, 14, 2, 8, 64, 3, 5)
     m2.set_X(torch.from_numpy(pr2['coeffs']).to(DEV), torch.from_numpy(pr2['times']).to(DEV))
     with pytest.raises(NotImplementedError):
-        S.sdeint(m2, y0, ts, method='srk', dt=1.0, options={'strict': True})
+        S.sdeint(m2, y0, ts, method='milstein', dt=1.0, options={'strict': True})
     # default: the reference's training loop keeps running — the call differentiates through the unfused tensor-op loop
     S.torchsde._UNFUSED_WARNED.clear()
+    y0.grad = None
     with pytest.warns(UserWarning, match='no fused backward'):
-        ys = S.sdeint(m2, y0, ts, method='srk', dt=1.0, options={'seed': 3})
+        ys = S.sdeint(m2, y0, ts, method='milstein', dt=1.0, options={'seed': 3})
     ys[-1].sum().backward()
     assert ys.shape == (2, 8, 64) and torch.isfinite(y0.grad).all()
     assert all(p.grad is None or torch.isfinite(p.grad).all() for p in m2.parameters())
@@ -890,11 +894,17 @@ def test_neuralsde_wrapper_all_knot_outputs_equal_reference_output_time_selectio
     with torch.no_grad():
         got = model(times, [coeffs], fi, options={'seed': 5})
         field.set_X(coeffs, times)
-        z0 = model.initial_network(field.X.evaluate(times[0]))
         ts, slot = model.output_times(times, fi)
-        z_t = S.sdeint(field, z0, ts, method='euler', dt=1.0, options={'seed': 5})
-        want = model.linear(z_t.gather(0, slot.reshape(1, -1, 1).expand(1, B, H)).squeeze(0))
+        # (initial state and readout through the same fused launches the wrapper uses in inference: the comparison is about
+        # the output-time selection; fused vs tensor-op initial state / head: tests/test_gpu_wrappers.py)
+        z_t = S.sdeint(field, torch.empty(B, H, device=DEV), ts, method='euler', dt=1.0,
+                       options={'seed': 5, 'z0_linear': model.initial_network})
+        want = model._readout(z_t.gather(0, slot.reshape(1, -1, 1).expand(1, B, H)).squeeze(0))
+        z0 = model.initial_network(field.X.evaluate(times[0]))
+        plain = model.linear(S.sdeint(field, z0, ts, method='euler', dt=1.0, options={'seed': 5})
+                             .gather(0, slot.reshape(1, -1, 1).expand(1, B, H)).squeeze(0))
     assert torch.equal(got, want)
+    assert float((got - plain).abs().max()) < 2e-4 * (float(plain.abs().max()) + 1e-6)
 
 
 def test_training_step_recorded_into_a_graph_draws_fresh_noise_and_matches_eager():
