@@ -188,7 +188,7 @@ int    snsde_solve_forward(const snsde_solve* s, void* hip_stream);
  * (engine.py) with library GEMMs.  Forward must have been run with traj, dW_out and act_save set.
  * snsde_backward_supported: 1 = MFMA adjoint kernel (forward on the MFMA path with act_save; Euler; fills delta_save),
  * 2 = generic adjoint kernels (forward on any kernel; traj + dW_out (+ dU_out for SRK) only; Euler, Milstein and SRK,
- * any dims, noise_option 0..13, 16, 17; delta_save must be NULL), 0 = none. */
+ * any dims within the LDS budget, every noise_option (Milstein: all but 7); delta_save must be NULL), 0 = none. */
 typedef struct snsde_backward {
     snsde_solve  fwd;        /* the forward descriptor (traj, dW_out, act_save filled by the forward)      */
     const float* grad_ys;    /* device (T, B, H): dL/d ys                                                 */

@@ -409,6 +409,41 @@ def diffusion_g_dgdy(p, no, t, y):
     return g, dg.astype(dtype)
 
 
+def diffusion_g_vjp(p, no, t, y, cot):
+    """(g, J_g(y)^T cot) for the diffusion nets on [tau, y] (noise_option 14/15/18/19, neuralsde.py:270-273, 278-281).
+
+    torchsde's diagonal-noise Milstein takes "g dg/dy v" as the VJP of g with cotangent g*v; for these options
+    dg/dy is dense, so the product is a transposed pass through the net: cot -> dg/draw -> [raw = net * y: direct factor and
+    * y] -> [relu masks] -> W^T, keeping the y columns of the first layer (its inputs are [sin t, cos t, y]).
+    """
+    if no not in (14, 15, 18, 19):
+        raise ValueError(f"diffusion_g_vjp is for the diffusion nets, not noise_option {no}")
+    dtype = y.dtype
+    B, H = y.shape
+    _, tf = time_features(t, B, dtype)
+    ty = np.concatenate([tf, y], axis=-1)
+    two = no in (18, 19)
+    if two:
+        h1 = np.maximum(_lin(ty, p['noise_y.0.weight'], p['noise_y.0.bias']), 0)
+        net = np.maximum(_lin(h1, p['noise_y.2.weight'], p['noise_y.2.bias']), 0)
+    else:
+        net = _lin(ty, p['noise_y.weight'], p['noise_y.bias'])
+    times_y = no in (15, 19)
+    with np.errstate(all='ignore'):
+        raw = net * y if times_y else net
+        sig = _sigmoid(p['theta']).reshape(1, 1)
+        g = np.tanh(sig * _nan_to_num(raw.astype(dtype)))
+    c_raw = np.where(np.isfinite(raw), cot * (1 - g * g) * sig, 0).astype(dtype)
+    direct = c_raw * net if times_y else np.zeros_like(c_raw)
+    c_net = c_raw * y if times_y else c_raw
+    if two:
+        c_h1 = (c_net * (net > 0)) @ p['noise_y.2.weight']
+        c_ty = (c_h1 * (h1 > 0)) @ p['noise_y.0.weight']
+    else:
+        c_ty = c_net @ p['noise_y.weight']
+    return g.astype(dtype), (c_ty[:, 2:] + direct).astype(dtype)
+
+
 # --------------------------------------------------------------------------------------
 # torchsde fixed-step integrate semantics (restated; unpinned)
 # --------------------------------------------------------------------------------------
@@ -497,12 +532,13 @@ def srk_step(f, g, t0, h, y, I_k, I_k0):
     return y1
 
 
-def integrate(f, g, y0, ts, dt, dW, method='euler', gdg=None, dU=None):
+def integrate(f, g, y0, ts, dt, dW, method='euler', gdg=None, dU=None, gvjp=None):
     """Fixed-step Ito integration with supplied increments.
 
     f(t, y), g(t, y) -> (B, H);  dW (N, B, H) = bm(t0_n, t1_n) for the steps of ``step_grid``.
     Euler:    y1 = y0 + f*dt + g*dW
-    Milstein: y1 = y0 + f*dt + g*dW + 0.5 * g*dg/dy * (dW^2 - dt); ``gdg(t,y)`` returns (g, dg/dy).
+    Milstein: y1 = y0 + f*dt + g*dW + 0.5 * g*dg/dy * (dW^2 - dt); ``gdg(t,y)`` returns (g, dg/dy); with
+                          ``gvjp(t, y, cot) -> (g, J_g^T cot)`` instead (dense dg/dy): + 0.5 * J_g^T (g * (dW^2 - dt)).
     Returns ys (T, B, H) and the full trajectory (N+1, B, H), computed in y0.dtype.
     """
     dtype = y0.dtype
@@ -521,6 +557,9 @@ def integrate(f, g, y0, ts, dt, dW, method='euler', gdg=None, dU=None):
         prev_y = y
         if method == 'euler':
             y = y + f(t, y) * h + g(t, y) * I
+        elif method == 'milstein' and gvjp is not None:
+            gv, m = gvjp(t, y, g(t, y) * (I * I - h))
+            y = y + f(t, y) * h + gv * I + dtype.type(0.5) * m
         elif method == 'milstein':
             gv, dg = gdg(t, y)
             y = y + f(t, y) * h + gv * I + dtype.type(0.5) * (gv * dg) * (I * I - h)
@@ -553,7 +592,9 @@ def solve_diffusion_model(p, io, no, coeffs, times, y0, ts, dt, dW, method='eule
     def gdg(t, y):
         return diffusion_g_dgdy(p, no, t, y)
 
-    return integrate(f, g, y0, ts, dt, np.asarray(dW), method=method, gdg=gdg, dU=None if dU is None else np.asarray(dU))
+    gvjp = (lambda t, y, cot: diffusion_g_vjp(p, no, t, y, cot)) if no in (14, 15, 18, 19) else None
+    return integrate(f, g, y0, ts, dt, np.asarray(dW), method=method, gdg=gdg, dU=None if dU is None else np.asarray(dU),
+                     gvjp=gvjp)
 
 
 # --------------------------------------------------------------------------------------

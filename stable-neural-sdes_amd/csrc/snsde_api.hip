@@ -316,9 +316,9 @@ static int validate_solve(const snsde_solve* s, bool eval) {
         if (s->method == SNSDE_SRK && !s->srk_tab) return SNSDE_ERR_NULL;
         if (s->method == SNSDE_SRK && s->dW && !s->dU) return SNSDE_ERR_NULL;   // supplied dW needs its Levy integral
         const int no = s->model.noise_option;
-        // Milstein needs dg_i/dy_i in closed form: g_i may depend on y only through y_i
-        if (s->method == SNSDE_MILSTEIN && (no == 7 || no == 14 || no == 15 || no == 18 || no == 19))
-            return SNSDE_ERR_UNSUPPORTED;
+        // Milstein: g dg/dy in closed form where g_i depends on y through y_i only, a transposed pass through the
+        // diffusion net for 14/15/18/19 (generic kernels); sqrt(y) has no finite derivative at the clipped values
+        if (s->method == SNSDE_MILSTEIN && no == 7) return SNSDE_ERR_UNSUPPORTED;
         if (s->noise_table && no != 12 && no != 13) return SNSDE_ERR_OPTION;   // a supplied table is the time-only factor
         if ((s->z0_weight != nullptr) != (s->z0_bias != nullptr)) return SNSDE_ERR_NULL;
     }
@@ -379,7 +379,7 @@ int snsde_solve_forward(const snsde_solve* s, void* hip_stream) {
 int snsde_forward_path(const snsde_solve* s) {
     if (!s || validate_model(&s->model) || s->batch <= 0 || s->knots < 2 || s->n_steps <= 0) return SNSDE_PATH_NONE;
     const int no = s->model.noise_option;
-    if (s->method == SNSDE_MILSTEIN && (no == 7 || no == 14 || no == 15 || no == 18 || no == 19)) return SNSDE_PATH_NONE;
+    if (s->method == SNSDE_MILSTEIN && no == 7) return SNSDE_PATH_NONE;
     SnsdeNet net;
     if (snsde_build_net(s->model, s->n_steps, &net)) return SNSDE_PATH_NONE;
     const bool variant = is_variant(s->model) || s->noise_table;
@@ -430,6 +430,7 @@ int snsde_act_slots(const snsde_model* m) {
 
 int snsde_backward_supported(const snsde_solve* s) {
     if (!s || validate_model(&s->model)) return 0;
+    if (s->method == SNSDE_MILSTEIN && s->model.noise_option == 7) return 0;     // no forward kernel either (validate_solve)
     SnsdeNet net;
     if (snsde_build_net(s->model, s->n_steps, &net)) return 0;
     if (is_variant(s->model) || s->noise_table)                // tutorial-style fields: the 4-row-tile MFMA adjoint or nothing

@@ -130,10 +130,10 @@ __device__ __forceinline__ void dense_group(const float* __restrict__ wt, const 
 }
 
 __device__ __noinline__ void dense_w(const float* __restrict__ params, const float* __restrict__ ws, const SnsdeLayer& L,
-                                     const float* in, int ldin, float* out, int ldout, bool relu) {
+                                     const float* in, int ldin, float* out, int ldout, bool relu, const float* zero_bias = nullptr) {
     const int N = L.N, K4 = L.Kpad >> 2;
     const float* wt = ws + L.w;
-    const float* bias = params + L.src_b;
+    const float* bias = zero_bias ? zero_bias : params + L.src_b;     // zero_bias: N zeros (tangent passes carry no bias)
     if (N <= 64) dense_group<64>(wt, bias, K4, N, in, ldin, out, ldout, relu);
     else if (N <= 128) dense_group<128>(wt, bias, K4, N, in, ldin, out, ldout, relu);
     else if (N <= 256) dense_group<256>(wt, bias, K4, N, in, ldin, out, ldout, relu);
@@ -602,6 +602,156 @@ __device__ __noinline__ void dense_T(const float* __restrict__ W, int ldk, int k
     }
 }
 
+// =====================================================================================================
+// Milstein with a diffusion net on [tau, y] (noise_option 14/15/18/19).  torchsde's diagonal-noise Milstein takes
+// g dg/dy (dW^2 - h) as a VJP of g with cotangent g (dW^2 - h): y1 = y + f h + g dW + 1/2 J_g(y)^T (g (dW^2 - h)).
+// With a dense J_g that is one transposed pass through the net per step: dL/draw -> [q > 0] -> W2^T -> [h1 > 0] -> W1_y^T
+// (+ the direct factor of the `raw = net(y) y` options).  Same tile structure as the SRK kernel (GW threads, dense_w / dense_T).
+// =====================================================================================================
+__global__ void __launch_bounds__(GW) snsde_generic_milnet_kernel(GenericArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const SnsdeDims& d = a.d;
+    const SnsdeNet& net = a.net;
+    const int H = d.H, C = d.C, B = d.B, io = d.io, no = d.no;
+    const int ldy = a.ldy, ldw = a.ldw, ldx = a.ldx;
+    float* ybuf = lds;
+    float* bufA = ybuf + GR * ldy;
+    float* bufB = bufA + GR * ldw;
+    float* bufC = bufB + GR * ldw;      // diffusion net output / its cotangent
+    float* bufD = bufC + GR * ldw;      // first net layer (no 18/19) / transposed-chain scratch
+    float* bufE = bufD + GR * ldw;      // transposed-chain scratch
+    float* xbuf = bufE + GR * ldw;
+    const int lds_floats = GR * (ldy + 5 * ldw + ldx);
+    const int tid = threadIdx.x, row0 = blockIdx.x * GR;
+    for (int i = tid; i < lds_floats; i += GW) lds[i] = 0.0f;
+    __syncthreads();
+    for (int i = tid; i < GR * H; i += GW) {
+        const int r = i / H, j = i - r * H, row = row0 + r;
+        if (row < B) {
+            const float v = a.y0[(size_t)row * H + j];
+            ybuf[r * ldy + j] = v;
+            a.ys[(size_t)row * H + j] = v;
+            if (a.traj) a.traj[(size_t)row * H + j] = v;
+        }
+    }
+    const float sig_theta = snsde_sigmoid(a.params[net.off_theta]);
+    const bool uses_x = (io == 0 || io == 2 || io == 4 || io == 6);
+    const bool uses_emb = (io == 2 || io == 4 || io == 6);
+    const bool net2 = (no >= 18), net_y = (no == 15 || no == 19);
+    const size_t BH = (size_t)B * H;
+    int kout = 0;
+    auto for_elems = [&](auto&& fn) {
+        for (int i = tid; i < GR * H; i += GW) {
+            const int r = i / H, j = i - r * H;
+            fn(r, j, row0 + r);
+        }
+        __syncthreads();
+    };
+    for (int n = 0; n < d.N; ++n) {
+        const float* st = a.step_tab + (size_t)n * SNSDE_STEP_STRIDE;
+        const float h = st[1], frac = st[4], sqh = st[6];
+        const int idx = __float_as_int(st[5]);
+        if (tid < GR) { ybuf[tid * ldy + H] = st[2]; ybuf[tid * ldy + H + 1] = st[3]; }
+        if (uses_x) {
+            for (int i = tid; i < GR * C; i += GW) {
+                const int r = i / C, c = i - r * C, row = row0 + r;
+                float v = 0.0f;
+                if (row < B) {
+                    const float* cp = a.coeffs + ((size_t)row * (d.L - 1) + idx) * (4 * C) + c;
+                    v = snsde_spline_eval(cp[0], cp[C], cp[2 * C], cp[3 * C], frac);
+                }
+                xbuf[r * ldx + c] = v;
+            }
+        }
+        __syncthreads();
+        // ---- drift (neuralsde.py:295-302) ----
+        float* cur;
+        float* oth;
+        if (io == 0) { dense_w(a.params, a.ws, net.init, xbuf, ldx, bufA, ldw, true); cur = bufA; oth = bufB; }
+        else if (!uses_emb) { dense_w(a.params, a.ws, net.in, ybuf, ldy, bufA, ldw, true); cur = bufA; oth = bufB; }
+        else {
+            dense_w(a.params, a.ws, net.in, ybuf, ldy, bufA, ldw, false);
+            dense_w(a.params, a.ws, net.init, xbuf, ldx, bufA + H, ldw, false);
+            __syncthreads();
+            dense_w(a.params, a.ws, net.emb, bufA, ldw, bufB, ldw, true);
+            cur = bufB; oth = bufA;
+        }
+        __syncthreads();
+        for (int l = 0; l < net.n_hid; ++l) {
+            dense_w(a.params, a.ws, net.hid[l], cur, ldw, oth, ldw, true);
+            float* t = cur; cur = oth; oth = t;
+            __syncthreads();
+        }
+        dense_w(a.params, a.ws, net.out, cur, ldw, oth, ldw, false);
+        float* zbuf = oth;                   // pre-tanh drift, then the step without the transposed-chain term
+        // ---- diffusion net (neuralsde.py:270-273, 278-281): first layer -> bufD (no 18/19) or straight to bufC ----
+        dense_w(a.params, a.ws, net.ny0, ybuf, ldy, net2 ? bufD : bufC, ldw, net2);
+        __syncthreads();
+        if (net2) {
+            dense_w(a.params, a.ws, net.ny1, bufD, ldw, bufC, ldw, true);
+            __syncthreads();
+        }
+        // ---- f, g, increment; everything of the step that is elementwise; cotangent of the net output ----
+        for_elems([&](int r, int j, int row) {
+            const float y = ybuf[r * ldy + j];
+            float z = zbuf[r * ldw + j];
+            if (io == 5 || io == 6) z *= tanhf(y);
+            const float f = tanhf(z);
+            const float nb = bufC[r * ldw + j];
+            const float raw = net_y ? nb * y : nb;
+            const float g = tanhf(sig_theta * snsde_nan_to_num(raw));
+            float dw = 0.0f;
+            if (row < B) {
+                if (a.dW) dw = a.dW[(size_t)n * BH + (size_t)row * H + j];
+                else {
+                    float z4[4];
+                    snsde_philox_normal4(a.seed_dev ? *a.seed_dev : a.seed, (uint32_t)(a.row_offset + row), (uint32_t)(n >> 2), (uint32_t)j, z4);
+                    dw = ((n & 3) == 0 ? z4[0] : (n & 3) == 1 ? z4[1] : (n & 3) == 2 ? z4[2] : z4[3]) * sqh;
+                }
+                if (a.dW_out) a.dW_out[(size_t)n * BH + (size_t)row * H + j] = dw;
+            }
+            const float dgr = (raw - raw == 0.0f) ? (1.0f - g * g) * sig_theta : 0.0f;       // dg / d raw
+            const float craw = g * fmaf(dw, dw, -h) * dgr;                                    // cotangent of raw
+            float base = fmaf(g, dw, fmaf(f, h, y));
+            if (net_y) base = fmaf(0.5f * craw, nb, base);                                    // direct factor: d(net y)/dy = net
+            zbuf[r * ldw + j] = base;
+            bufC[r * ldw + j] = (net2 && !(nb > 0.0f)) ? 0.0f : (net_y ? craw * y : craw);
+        });
+        // ---- J_net^T ----
+        const float* dfirst = bufC;
+        if (net2) {
+            dense_T(a.params + net.ny1.src_w, net.ny1.K, 0, net.ny1.K, net.ny1.N, bufC, ldw, bufE, ldw);
+            __syncthreads();
+            for (int i = tid; i < GR * net.ny0.N; i += GW) {
+                const int r = i / net.ny0.N, j = i - r * net.ny0.N;
+                if (!(bufD[r * ldw + j] > 0.0f)) bufE[r * ldw + j] = 0.0f;
+            }
+            __syncthreads();
+            dfirst = bufE;
+        }
+        float* dy = net2 ? bufC : bufE;
+        dense_T(a.params + net.ny0.src_w, net.ny0.K, net.ny0.tshift, H, net.ny0.N, dfirst, ldw, dy, ldw);
+        __syncthreads();
+        int kend = kout;
+        while (kend < d.T - 1 && a.out_step[kend] == n) ++kend;
+        for_elems([&](int r, int j, int row) {
+            const float y = ybuf[r * ldy + j];
+            const float ynew = fmaf(0.5f, dy[r * ldw + j], zbuf[r * ldw + j]);
+            ybuf[r * ldy + j] = ynew;
+            if (row < B) {
+                if (a.traj) a.traj[(size_t)(n + 1) * BH + (size_t)row * H + j] = ynew;
+                for (int k = kout; k < kend; ++k) {
+                    const float c0 = a.out_w[2 * k], c1 = a.out_w[2 * k + 1];
+                    const float o = (c0 == 0.0f) ? ynew : c0 * y + c1 * ynew;
+                    if (!a.row_out) a.ys[(size_t)(k + 1) * BH + (size_t)row * H + j] = o;
+                    else if (a.row_out[row] == k + 1) a.ys[(size_t)row * H + j] = o;
+                }
+            }
+        });
+        kout = kend;
+    }
+}
+
 __global__ void __launch_bounds__(GW) snsde_generic_adjoint_kernel(AdjArgs aa) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const GenericArgs& a = aa.g;
@@ -621,7 +771,10 @@ __global__ void __launch_bounds__(GW) snsde_generic_adjoint_kernel(AdjArgs aa) {
     const bool noise_net = (no == 14 || no == 15 || no == 18 || no == 19);
     const bool net2 = (no == 18 || no == 19), net_y = (no == 15 || no == 19);
     float* gnb = ayb + GR * ldy;                    // diffusion net (no 18/19): output layer, then its delta
-    const int lds_floats = GR * (3 * ldy + ldx + (3 + nact + (noise_net ? 1 : 0)) * ldw);
+    const bool milnet = noise_net && d.method == SNSDE_MILSTEIN;
+    float* gp = gnb + (noise_net ? GR * ldw : 0);   // Milstein with a diffusion net: tangent J_net a of the adjoint
+    float* zb = gp + GR * ldw;                      //                                a row of zeros (bias of the tangent passes)
+    const int lds_floats = GR * (3 * ldy + ldx + (3 + nact + (noise_net ? 1 : 0) + (milnet ? 1 : 0)) * ldw) + (milnet ? ldw : 0);
     const int tid = threadIdx.x, row0 = blockIdx.x * GR;
     for (int i = tid; i < lds_floats; i += GW) lds[i] = 0.0f;
     __syncthreads();
@@ -703,6 +856,19 @@ __global__ void __launch_bounds__(GW) snsde_generic_adjoint_kernel(AdjArgs aa) {
                 dense_w(a.params, a.ws, net.ny1, cat, ldw, gnb, ldw, true);
                 __syncthreads();
             }
+            if (milnet) {      // tangent of the net along the adjoint: J_net a (abuf's time columns are zero; no bias)
+                dense_w(a.params, a.ws, net.ny0, abuf, ldy, net2 ? dl : gp, ldw, false, zb);
+                __syncthreads();
+                if (net2) {
+                    for (int i = tid; i < GR * net.ny0.N; i += GW) {
+                        const int r = i / net.ny0.N, j = i - r * net.ny0.N;
+                        if (!(cat[r * ldw + j] > 0.0f)) dl[r * ldw + j] = 0.0f;
+                    }
+                    __syncthreads();
+                    dense_w(a.params, a.ws, net.ny1, dl, ldw, gp, ldw, false, zb);
+                    __syncthreads();
+                }
+            }
         }
         // ---- elementwise derivatives: delta_zout -> zo (in place), direct y terms -> ayb ----
         for_elems([&](int r, int j, int row) {
@@ -743,11 +909,26 @@ __global__ void __launch_bounds__(GW) snsde_generic_adjoint_kernel(AdjArgs aa) {
                 const float sech = 1.0f - g * g;
                 const float g1 = sech * sig_theta * r1;
                 accy = fmaf(av * dw, g1, accy);
-                if (mil != 0.0f) {
+                if (mil != 0.0f && !noise_net) {
                     const float g2 = sech * sig_theta * r2 - 2.0f * g * g1 * sig_theta * r1;
                     accy = fmaf(av * mil * (g1 * g1 + g * g2), dw * dw - h, accy);
                 }
                 dnet = av * dw * sech * sig_theta * (net_y ? y : 1.0f);     // cotangent of the net's output
+                if (milnet) {
+                    // a . d/dy [1/2 J_raw^T u],  u = g dg/draw (dW^2 - h):  with p = J_net a,  w = (J_raw a) (dW^2 - h) d(g dg/draw)/draw
+                    //   raw = net:     J_net^T w                                   raw = net y:  p u + w net + J_net^T (a u + w y)
+                    const float nbv = nraw[r * ldw + j];
+                    const float pj = (net2 && !(nbv > 0.0f)) ? 0.0f : gp[r * ldw + j];
+                    const float v = fmaf(dw, dw, -h), s1 = sech * sig_theta;
+                    const float u = g * s1 * v, sp = sig_theta * s1 * (1.0f - 3.0f * g * g);
+                    if (net_y) {
+                        const float w = fmaf(y, pj, nbv * av) * v * sp;
+                        accy = fmaf(mil, fmaf(pj, u, w * nbv), accy);
+                        dnet = fmaf(mil, fmaf(av, u, w * y), dnet);
+                    } else {
+                        dnet = fmaf(mil, pj * v * sp, dnet);
+                    }
+                }
             }
             if (noise_net) nraw[r * ldw + j] = (net2 && !(nraw[r * ldw + j] > 0.0f)) ? 0.0f : dnet;
             zo[r * ldw + j] = dz;
@@ -1351,6 +1532,17 @@ int snsde_generic_launch(const snsde_solve* s, const SnsdeNet& net, hipStream_t 
     int wmax = 2 * H > HH ? 2 * H : HH;
     a.ldw = round4(wmax) + 4;
     a.ldx = round4(m.input_channels);
+    if (!eval_mode && s->method == SNSDE_MILSTEIN && (no == 14 || no == 15 || no == 18 || no == 19)) {
+        // Milstein through a diffusion net: its own kernel (one transposed pass through the net per step)
+        const size_t bytes = (size_t)GR * (a.ldy + 5 * a.ldw + a.ldx) * sizeof(float);
+        if (bytes > 160 * 1024) return SNSDE_ERR_LDS;
+        if (bytes > 64 * 1024 &&
+            hipFuncSetAttribute(reinterpret_cast<const void*>(snsde_generic_milnet_kernel),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes) != hipSuccess)
+            return SNSDE_ERR_LDS;
+        hipLaunchKernelGGL(snsde_generic_milnet_kernel, dim3((s->batch + GR - 1) / GR), dim3(GW), bytes, stream, a);
+        return hipGetLastError() == hipSuccess ? SNSDE_OK : SNSDE_ERR_LAUNCH;
+    }
     const size_t lds_bytes = (size_t)GR * (a.ldy + 3 * a.ldw + a.ldx) * sizeof(float);
     if (lds_bytes > 160 * 1024) return SNSDE_ERR_LDS;
     if (lds_bytes > 64 * 1024) {
@@ -1375,8 +1567,10 @@ bool snsde_generic_backward_supported(const snsde_solve* s) {
         return fl * sizeof(float) <= 160 * 1024;
     }
     if (s->method != SNSDE_EULER && s->method != SNSDE_MILSTEIN) return false;
-    if (s->method == SNSDE_MILSTEIN && (no == 7 || noise_net)) return false;
-    return (size_t)GR * (3 * ldy + ldx + (3 + s->model.num_hidden_layers + (noise_net ? 1 : 0)) * ldw) * sizeof(float) <= 160 * 1024;
+    if (s->method == SNSDE_MILSTEIN && no == 7) return false;
+    const bool milnet = noise_net && s->method == SNSDE_MILSTEIN;
+    return ((size_t)GR * (3 * ldy + ldx + (3 + s->model.num_hidden_layers + (noise_net ? 1 : 0) + (milnet ? 1 : 0)) * ldw) +
+            (milnet ? ldw : 0)) * sizeof(float) <= 160 * 1024;
 }
 
 // The adjoint kernels need the generic packed weights and the time-only diffusion table: prepared here in the
@@ -1441,7 +1635,9 @@ int snsde_generic_backward_launch(const snsde_backward* b, const SnsdeNet& net, 
     }
     aa.traj = s->traj; aa.dW_used = s->dW_out; aa.grad_ys = b->grad_ys; aa.adj = b->adj; aa.nbuf = net.n_hid + 1;
     const bool nn = (m.noise_option == 14 || m.noise_option == 15 || m.noise_option == 18 || m.noise_option == 19);
-    const size_t lds_bytes = (size_t)GR * (3 * a.ldy + a.ldx + (3 + net.n_hid + 1 + (nn ? 1 : 0)) * a.ldw) * sizeof(float);
+    const bool mn = nn && s->method == SNSDE_MILSTEIN;
+    const size_t lds_bytes = ((size_t)GR * (3 * a.ldy + a.ldx + (3 + net.n_hid + 1 + (nn ? 1 : 0) + (mn ? 1 : 0)) * a.ldw) +
+                              (mn ? a.ldw : 0)) * sizeof(float);
     if (lds_bytes > 160 * 1024) return SNSDE_ERR_LDS;
     if (lds_bytes > 64 * 1024 &&
         hipFuncSetAttribute(reinterpret_cast<const void*>(snsde_generic_adjoint_kernel),

@@ -263,8 +263,8 @@ def _sdeint_hip(sde, rec, y0, ts, bm, method, dt, options):
         mode = engine.backward_mode(model, y0c.shape[0], coeffs.shape[1] + 1, grid, method, options.get('kernel', 'auto'),
                                     bool(options.get('exact_order', False)))
         if mode == 0 and not options.get('strict', False):
-            # no fused adjoint for this configuration (Milstein with a diffusion net or sqrt(y)): differentiate through the
-            # unfused tensor-op loop on the same device rather than fail the
+            # no fused adjoint for this configuration (Milstein with sqrt(y); shapes beyond the generic adjoint's LDS budget):
+            # differentiate through the unfused tensor-op loop on the same device rather than fail the
             # reference's training loop; options={'strict': True} raises instead
             key = (sde.input_option, sde.noise_option, method)
             if key not in _UNFUSED_WARNED:
@@ -283,8 +283,8 @@ def _sdeint_hip(sde, rec, y0, ts, bm, method, dt, options):
     try:
         ys = call.launch()
     except engine._lib.SnsdeError as exc:
-        # a valid request no kernel covers (e.g. Milstein with a diffusion whose dg/dy is not closed-form, noise_option
-        # 7 / 14 / 15 / 18 / 19): same behaviour as the gradient path, the unfused tensor-op loop, unless strict
+        # a valid request no kernel covers (Milstein with noise_option 7, sqrt(y)): same behaviour as the gradient path, the
+        # unfused tensor-op loop, unless strict
         if exc.code != -4 or options.get('strict', False):
             raise
         if z0_lin is not None:
@@ -416,8 +416,8 @@ class _FusedSolve(torch.autograd.Function):
                                     bool(options.get('exact_order', False)))
         if mode == 0:
             raise NotImplementedError(
-                "the fused backward covers 'euler' and 'srk' for every noise_option and 'milstein' where dg/dy is "
-                "elementwise in closed form (every noise_option but 7, 14, 15, 18, 19), within the LDS budget of the generic "
+                "the fused backward covers 'euler', 'srk' and 'milstein' for every noise_option (Milstein: all but 7, "
+                "sqrt(y), whose derivative is not finite at the clipped values), within the LDS budget of the generic "
                 "adjoint kernels; pass options={'backend': 'torch'} to differentiate this configuration through the "
                 "tensor-op loop")
         # recompute mode (options={'recompute': steps per chunk} or SNSDE_RECOMPUTE_STEPS): keep states and increments only,
@@ -606,7 +606,13 @@ def _parameter_gradients(sde, call, grid, adj, max_rows=1 << 19, method='euler')
                         acc.add_(gpart)
                 continue
             f = modules.drift_rows(P, io, tau, Y, Xraw)
-            if method == 'milstein':   # + 1/2 g dg/dy (dW^2 - h); g is elementwise in y for the supported options
+            if method == 'milstein' and no in (14, 15, 18, 19):
+                # diffusion net: torchsde's Milstein term is the VJP of g with cotangent g (dW^2 - h) (dense dg/dy)
+                Yg = Y.detach().requires_grad_(True)
+                g = modules.diffusion_rows(P, no, col, tau, Yg)
+                gdg, = torch.autograd.grad(g, Yg, grad_outputs=g * (DW * DW - hcol), create_graph=True)
+                surrogate = (A * (f * hcol + g * DW + 0.5 * gdg)).sum()
+            elif method == 'milstein':   # + 1/2 g dg/dy (dW^2 - h); g is elementwise in y for the other options
                 Yg = Y.detach().requires_grad_(True)
                 g = modules.diffusion_rows(P, no, col, tau, Yg)
                 if g.requires_grad and g.grad_fn is not None:

@@ -166,11 +166,33 @@ def test_all_noise_options_one_step_chain():
     assert not bad, bad
 
 
-def test_milstein_unsupported_for_dense_jacobian_options():
-    pr = make_problem(1, 1, 18, 2, 4, 8, 3, 5)
+def test_milstein_refused_where_dg_dy_is_not_finite():
+    """sqrt(y) (noise_option 7): nan_to_num clips the value, its derivative has no finite counterpart (torchsde's VJP
+    returns NaN there).  The diffusion nets (dense dg/dy) are served by the generic Milstein kernel."""
+    pr = make_problem(1, 1, 7, 2, 4, 8, 3, 5)
     with pytest.raises(S._lib.SnsdeError) as e:
         hip_solve(pr, [0, 4], 1.0, dW=draw_dW(1, [0, 4], 1.0, 4, 8), method='milstein')
     assert e.value.code == -4
+    pr = make_problem(1, 1, 18, 2, 4, 8, 3, 5)
+    ys, _ = hip_solve(pr, [0, 4], 1.0, dW=draw_dW(1, [0, 4], 1.0, 4, 8), method='milstein')
+    assert np.isfinite(ys).all()
+
+
+@pytest.mark.parametrize('cfg', [(3, 18, 2, 33, 64, 5, 12), (1, 14, 1, 17, 32, 3, 9), (4, 19, 2, 21, 128, 21, 10), (6, 15, 3, 9, 48, 40, 8),
+                                 (0, 18, 2, 12, 100, 6, 9)])
+def test_milstein_through_a_diffusion_net_vs_oracle(cfg):
+    """Milstein with a dense dg/dy (noise_option 14/15/18/19): J_g^T (g (dW^2 - h)) per step, torchsde's VJP form, against the
+    numpy restatement in float64 (oracle.diffusion_g_vjp) on replayed increments."""
+    io, no, NL, B, H, C, L = cfg
+    pr = make_problem(60 + no, io, no, NL, B, H, C, L)
+    ts = [0, 2.5, L - 1]
+    dW = draw_dW(7, ts, 0.5, B, H)
+    ys, _ = hip_solve(pr, ts, 0.5, dW=dW, method='milstein')
+    ref64, _ = oracle_solve(pr, ts, 0.5, dW, 'milstein', np.float64)
+    cpu32, _ = oracle_solve(pr, ts, 0.5, dW, 'milstein', np.float32)
+    assert_parity(ys, ref64, cpu32, what=f'milstein io={io} no={no}')
+    eu, _ = oracle_solve(pr, ts, 0.5, dW, 'euler', np.float64)
+    assert np.abs(eu - ref64).max() > 1e-3          # the correction is not a no-op in these cases
 
 
 def test_drift_only_control_is_a_quadrature():
@@ -606,6 +628,12 @@ GEN_BWD_CASES = [
     (4, 15, 2, 9, 32, 5, 8, [0, 3, 7], 1.0, 'srk'),
     (6, 19, 3, 7, 64, 5, 8, [0, 7], 0.5, 'srk'),
     (0, 18, 2, 9, 128, 21, 8, [0, 7], 1.0, 'srk'),
+    (3, 18, 2, 11, 24, 5, 9, [0, 3.5, 8], 1.0, 'milstein'),   # Milstein through a diffusion net: VJP of g per step, its
+    (1, 14, 1, 9, 12, 3, 8, [0, 7], 0.5, 'milstein'),         # adjoint needs the net's tangent as well
+    (4, 19, 2, 9, 64, 69, 8, [0, 3, 7], 1.0, 'milstein'),
+    (2, 15, 3, 9, 40, 40, 8, [0, 7], 0.5, 'milstein'),
+    (5, 19, 2, 9, 128, 3, 8, [0, 2.5, 7], 0.5, 'milstein'),
+    (0, 15, 2, 7, 32, 5, 8, None, None, 'milstein'),
 ]
 
 
@@ -676,9 +704,9 @@ def test_backward_sweep_generic_options(io, no):
 
 @pytest.mark.parametrize('io', [0, 1, 2, 3, 4, 5, 6])
 @pytest.mark.parametrize('no', [14, 15, 18, 19])
-@pytest.mark.parametrize('method', ['euler', 'srk'])
+@pytest.mark.parametrize('method', ['euler', 'srk', 'milstein'])
 def test_backward_sweep_generic_diffusion_nets(io, no, method):
-    """Diffusion nets on [tau, y] (dense dg/dy) through the generic adjoint kernels, every input_option, Euler and SRK."""
+    """Diffusion nets on [tau, y] (dense dg/dy) through the generic kernels, every input_option: Euler, SRK, Milstein."""
     k = io * 4 + no
     _check_backward(3500 + k, io, no, 1 + k % 2, 7, 12 if k % 2 else 20, 3, 6, [0, 5], 1.0 if k % 3 else 0.5, method, 'generic',
                     strict=True)
@@ -725,6 +753,8 @@ def _check_backward(seed, io, no, NL, B, H, C, L, ts, dt, method, kernel, strict
         err = np.abs(got.cpu().numpy().astype(np.float64) - ref).max() / scale
         assert err < 2e-3, (name, err, scale)
 
+    fscale = float(ys_ref.detach().abs().max()) + 1e-12
+    assert float((ys.detach().double().cpu() - ys_ref.detach()).abs().max()) / fscale < 2e-4, 'forward'
     close(y0.grad, y0_ref.grad, 'y0')
     ref_grads = dict(m_ref.named_parameters())
     for name, p in m.named_parameters():
@@ -817,29 +847,27 @@ def test_native_parameter_pass_matches_library_gemm_pass(case):
 
 
 def test_backward_without_a_fused_adjoint_falls_back_to_the_tensor_loop_or_raises_when_strict():
-    # Milstein with a diffusion net: dg/dy is dense (torchsde takes a VJP of g) - the one family without a fused backward
-    pr = make_problem(9, 4, 18, 2, 8, 64, 40, 5)
-    m = S.Diffusion_model(40, 64, 64, 2, input_option=4, noise_option=18).to(DEV)
+    # Milstein with sqrt(y) (noise_option 7) is the one family without kernels: no finite dg/dy at the clipped values
+    pr = make_problem(9, 1, 7, 2, 8, 64, 3, 5)
+    m = S.Diffusion_model(3, 64, 64, 2, input_option=1, noise_option=7).to(DEV)
     m.set_X(torch.from_numpy(pr['coeffs']).to(DEV), torch.from_numpy(pr['times']).to(DEV))
     y0 = torch.from_numpy(pr['y0']).to(DEV).requires_grad_(True)
     ts = torch.tensor([0., 4.], device=DEV)
     with pytest.raises(NotImplementedError):
         S.sdeint(m, y0, ts, method='milstein', dt=1.0, options={'strict': True})
-    for method in ('euler', 'srk'):        # (round 2: the generic adjoint kernels take the nets, wide control path included)
-        S.sdeint(m, y0, ts, method=method, dt=1.0, options={'strict': True, 'seed': 1})[-1].sum().backward()
-    m2 = S.Diffusion_model(3, 64, 64, 2, input_option=1, noise_option=14).to(DEV)
-    pr2 = make_problem(9, 1, 14, 2, 8, 64, 3, 5)
+    # (round 2: every diffusion net has a fused backward - Euler, SRK and Milstein, wide control path included)
+    pr2 = make_problem(9, 4, 18, 2, 8, 64, 40, 5)
+    m2 = S.Diffusion_model(40, 64, 64, 2, input_option=4, noise_option=18).to(DEV)
     m2.set_X(torch.from_numpy(pr2['coeffs']).to(DEV), torch.from_numpy(pr2['times']).to(DEV))
-    with pytest.raises(NotImplementedError):
-        S.sdeint(m2, y0, ts, method='milstein', dt=1.0, options={'strict': True})
+    for method in ('euler', 'srk', 'milstein'):
+        S.sdeint(m2, y0, ts, method=method, dt=1.0, options={'strict': True, 'seed': 1})[-1].sum().backward()
     # default: the reference's training loop keeps running — the call differentiates through the unfused tensor-op loop
     S.torchsde._UNFUSED_WARNED.clear()
     y0.grad = None
     with pytest.warns(UserWarning, match='no fused backward'):
-        ys = S.sdeint(m2, y0, ts, method='milstein', dt=1.0, options={'seed': 3})
-    ys[-1].sum().backward()
-    assert ys.shape == (2, 8, 64) and torch.isfinite(y0.grad).all()
-    assert all(p.grad is None or torch.isfinite(p.grad).all() for p in m2.parameters())
+        ys = S.sdeint(m, y0, ts, method='milstein', dt=1.0, options={'seed': 3})
+    ys[-1].sum().backward()      # (autograd's own derivative of sqrt is not finite once a state goes negative: no value check)
+    assert ys.shape == (2, 8, 64) and ys.grad_fn is not None and y0.grad is not None
 
 
 @pytest.mark.parametrize('kernel,method,io,no', [('mfma4', 'euler', 4, 17), ('mfma16', 'milstein', 6, 17), ('generic', 'euler', 2, 7),

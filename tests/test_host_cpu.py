@@ -700,7 +700,8 @@ def test_forward_path_query_names_the_kernel_family():
     assert path(256, 14, 4, 17, 16384, 'milstein') == 'mfma16'           # large batch: 16-row tiles
     assert path(128, 21, 4, 17, 1024, 'srk') == 'mfma-srk'
     assert path(48, 5, 4, 17, 64, 'euler') == 'generic'                  # no MFMA instantiation for H = 48
-    assert path(128, 21, 3, 18, 64, 'milstein') == 'none'                # Milstein needs dg/dy in closed form
+    assert path(128, 21, 3, 18, 64, 'milstein') == 'generic'             # Milstein through a diffusion net: generic kernels
+    assert path(128, 21, 3, 7, 64, 'milstein') == 'none'                 # sqrt(y): no finite dg/dy at the clipped values
     assert path(128, 21, 4, 17, 64, 'euler', kernel='generic') == 'generic'
     assert path(32, 2, 4, 13, 256, 'euler', NL=1, activation=1, drift_output=1, diffusion_output=1, time_feature=1) == 'lean'
     assert path(48, 2, 4, 13, 256, 'euler', NL=1, activation=1, drift_output=1, diffusion_output=1, time_feature=1) == 'none'
@@ -786,4 +787,44 @@ def test_readout_head_recognition_gate():
     assert engine.head_layers(nn.Sequential(nn.Linear(8, 8), nn.Tanh(), nn.Linear(8, 2))) is None
     assert engine.head_layers(nn.Sequential(nn.Linear(8, 8), nn.ReLU(), nn.Linear(4, 2))) is None
     assert engine.head_layers(nn.Linear(8, 2)) is None
+
+
+
+@pytest.mark.parametrize('no', [14, 15, 18, 19])
+def test_oracle_diffusion_net_vjp_equals_autograd_on_the_module(no):
+    """oracle.diffusion_g_vjp (the Milstein term of the diffusion nets) against torch autograd through Diffusion_model.g in
+    float64, and the oracle's Milstein trajectory against the tensor-op loop (torchsde's VJP form) on the same increments."""
+    torch.manual_seed(no)
+    B, H, C, L = 6, 10, 3, 7
+    m = S.Diffusion_model(C, H, H, 2, input_option=1, noise_option=no).double()
+    p = {k: v.detach().numpy() for k, v in m.state_dict().items()}
+    y = torch.randn(B, H, dtype=torch.float64, requires_grad=True)
+    cot = torch.randn(B, H, dtype=torch.float64)
+    t = torch.tensor(0.7, dtype=torch.float64)
+    g = m.g(t, y)
+    want, = torch.autograd.grad(g, y, grad_outputs=cot)
+    g_o, vjp_o = O.diffusion_g_vjp(p, no, 0.7, y.detach().numpy(), cot.numpy())
+    np.testing.assert_allclose(g_o, g.detach().numpy(), rtol=1e-12, atol=1e-13)
+    np.testing.assert_allclose(vjp_o, want.numpy(), rtol=1e-10, atol=1e-12)
+    rng = np.random.default_rng(no)
+    times = np.arange(L, dtype=np.float32)
+    X = rng.standard_normal((B, L, C)).cumsum(1)
+    coeffs = S.controldiffeq.natural_cubic_spline_coeffs(torch.from_numpy(times), torch.from_numpy(X).float())
+    coeffs = torch.cat(coeffs, dim=-1).double()
+    m.set_X(coeffs, torch.from_numpy(times))
+    y0 = rng.standard_normal((B, H))
+    ts = np.array([0, 2.5, L - 1], np.float32)
+    t0s = O.step_grid(ts, 0.5)[0]
+    dW = rng.standard_normal((len(t0s), B, H)) * np.sqrt(0.5)
+
+    class Replay:
+        n = 0
+        def __call__(self, ta, tb):
+            self.n += 1
+            return torch.from_numpy(dW[self.n - 1])
+    with torch.no_grad():
+        loop = S.sdeint(m, torch.from_numpy(y0), torch.from_numpy(ts), bm=Replay(), method='milstein', dt=0.5,
+                        options={'backend': 'torch'})
+    ora, _ = O.solve_diffusion_model(p, 1, no, coeffs.numpy(), times, y0, ts, 0.5, dW, method='milstein')
+    np.testing.assert_allclose(ora, loop.numpy(), rtol=1e-9, atol=1e-10)
 
