@@ -109,7 +109,7 @@ def cpu_baseline(pr, params, budget_s=12.0):
         if tcur == 0:
             y = y0
         el = time.perf_counter() - t_begin
-        if el > budget_s or steps >= 50 * NSTEP:
+        if el > budget_s or steps >= 100 * NSTEP:
             break
     return {"value": B * steps / el, "unit": "row-steps/s", "cores": best_threads, "kind": "port",
             "sample": f"{steps} Euler steps of the K2 workload (B={B} rows, = {steps / NSTEP:.1f} forward solves) "
