@@ -102,6 +102,9 @@ class ComposedField:
         if grad:
             with torch.enable_grad():
                 return self._flat(dev, True)
+        if torch.cuda.is_current_stream_capturing():       # graph capture: no host read - the composition is recorded
+            with torch.no_grad():
+                return self._flat(dev, False)
         # inference: the block only changes when a parameter does, so repeated solves reuse it (key: see _param_key)
         key = self._param_key(dev)
         hit = self._flat_cache
@@ -110,6 +113,18 @@ class ComposedField:
                 hit = (key, self._flat(dev, False))
             self._flat_cache = hit
         return hit[1]
+
+    def inference_inputs(self, t0s, dev):
+        """(parameter block, diffusion table) of a no-grad solve, cached on ONE reading of the parameters' identity."""
+        if torch.cuda.is_current_stream_capturing():
+            return self.flat(dev), self.noise_table(t0s, dev)
+        key = self._param_key(dev)
+        hit = self._flat_cache
+        if hit is None or hit[0] != key:
+            with torch.no_grad():
+                hit = (key, self._flat(dev, False))
+            self._flat_cache = hit
+        return hit[1], self.noise_table(t0s, dev, param_key=key)
 
     def _flat(self, dev, grad):
         p = self.parts
@@ -146,13 +161,15 @@ class ComposedField:
         assert out.numel() == self.numel
         return out
 
-    def noise_table(self, t0s, dev, grad=False):
+    def noise_table(self, t0s, dev, grad=False, param_key=None):
         """(N, H) float32: the time-only diffusion factor at every step time, through the module's own g (one batched call);
-        grad=True keeps its autograd graph."""
+        grad=True keeps its autograd graph.  param_key: the parameter identity a caller already took for this solve
+        (`inference_inputs`: one fingerprint read-back per solve, not two)."""
         N, H = t0s.shape[0], self.model.hidden_channels
         key = None
-        if not grad and t0s.is_cuda:       # (same step times tensor of a cached grid + unchanged parameters: reuse the table)
-            key = (t0s.data_ptr(), N) + self._param_key(dev)
+        if not grad and t0s.is_cuda and not torch.cuda.is_current_stream_capturing():
+            # (same step times tensor of a cached grid + unchanged parameters: reuse the table)
+            key = (t0s.data_ptr(), N) + (self._param_key(dev) if param_key is None else param_key)
             if self._tab_cache is not None and self._tab_cache[0] == key:
                 return self._tab_cache[1]
         with torch.set_grad_enabled(grad):

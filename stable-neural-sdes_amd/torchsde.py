@@ -303,10 +303,12 @@ def _sdeint_composed(sde, y0, ts, bm, method, dt, options):
     needs_grad = torch.is_grad_enabled() and (y0.requires_grad or any(p.requires_grad for p in sde.parameters()))
     field = fields.compose(sde)
     coeffs = getattr(sde, 'coeffs', None)
-    if field is None or not torch.is_tensor(coeffs) or coeffs.dim() != 3 or coeffs.shape[0] != y0.shape[0] \
-            or torch.cuda.is_current_stream_capturing():
+    if field is None or not torch.is_tensor(coeffs) or coeffs.dim() != 3 or coeffs.shape[0] != y0.shape[0]:
         return None
     dev = y0.device
+    capturing = torch.cuda.is_current_stream_capturing()
+    if capturing and (needs_grad or bm is not None or field.verified.get(str(dev)) is not True):
+        return None      # graph capture: no-grad solves of a mapping that was verified before the capture (a warm-up solve)
     coeffs = coeffs.detach().to(device=dev, dtype=torch.float32).contiguous()
     times_host = _HostTimes.get(sde.times)
     if not fields.verify(field, coeffs, times_host, dev):
@@ -317,7 +319,10 @@ def _sdeint_composed(sde, y0, ts, bm, method, dt, options):
         t0, t1 = torch.from_numpy(grid.t0), torch.from_numpy(grid.t1)
         dW = torch.stack([bm(t0[n], t1[n]).to(device=dev, dtype=torch.float32) for n in range(grid.N)]).contiguous()
     seed = options.get('seed')
-    seed = _fresh_seed() if seed is None else (seed if torch.is_tensor(seed) else int(seed))
+    if seed is None:     # recorded solves read a device-resident key that the recording itself advances: fresh noise per replay
+        seed = _capture_seed(dev) if capturing else _fresh_seed()
+    elif not torch.is_tensor(seed):
+        seed = int(seed)
     row_offset = options.get('row_offset')
     if row_offset is None:
         import torch.distributed as dist
@@ -334,8 +339,8 @@ def _sdeint_composed(sde, y0, ts, bm, method, dt, options):
         flat = field.flat(dev, grad=True)
         tab = field.noise_table(grid.d_t0, dev, grad=True)
         return _ComposedSolve.apply(field.model, coeffs, grid, dW, method, seed, int(row_offset), row_out, y0, flat, tab)
-    tab = field.noise_table(grid.d_t0, dev)
-    call = engine.SolveCall(field.model, field.flat(dev), coeffs, grid, y0.detach().to(torch.float32).contiguous(), dW=dW,
+    flat, tab = field.inference_inputs(grid.d_t0, dev)
+    call = engine.SolveCall(field.model, flat, coeffs, grid, y0.detach().to(torch.float32).contiguous(), dW=dW,
                             method=method, seed=seed, row_offset=int(row_offset), row_out=row_out, noise_table=tab)
     try:
         return call.launch().to(y0.dtype)

@@ -218,3 +218,40 @@ def test_composed_block_and_table_caches_follow_parameter_updates():
     fresh2.__dict__.pop('_snsde_composed', None)
     fresh2.set_X(coeffs.to(dev), times.to(dev))
     assert torch.equal(solve(field), solve(fresh2)) and not torch.equal(solve(field), b1)
+
+
+def test_tutorial_field_solve_records_into_a_graph():
+    """A no-grad solve of a composed field inside a CUDA/HIP graph capture: no host read-back (the parameter fingerprint of the
+    inference cache is skipped, the composition is part of the recording), fresh increments on every replay, and a parameter
+    update between replays is seen (the recorded composition re-reads the module's weights)."""
+    from stable_neural_sdes_amd import torchsde as T
+    dev = torch.device('cuda')
+    B, H, C, L = 16, 32, 2, 9
+    field, times, coeffs, y0 = problem(78, B, H, C, L, 'lnsde', 1, 'lipswish', dev)
+    field = field.to(dev)
+    times, y0 = times.to(dev), y0.to(dev)
+    field.set_X(coeffs.to(dev), times)
+    T.prepare_graph_capture(dev)
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side), torch.no_grad():
+        S.sdeint(field, y0, times, dt=0.05, method='euler')
+    torch.cuda.current_stream().wait_stream(side)
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.no_grad(), torch.cuda.graph(g):
+        out = S.sdeint(field, y0, times, dt=0.05, method='euler')
+    g.replay(); torch.cuda.synchronize()
+    a = out.clone()
+    g.replay(); torch.cuda.synchronize()
+    b = out.clone()
+    assert torch.isfinite(a).all() and torch.isfinite(b).all() and not torch.equal(a, b)      # fresh Brownian increments
+    assert torch.equal(a[0], y0) and torch.equal(b[0], y0)
+    with torch.no_grad():
+        field.linear_out.weight.zero_(); field.linear_out.bias.zero_()        # drift off, ...
+        for m in field.g_net.modules():
+            if isinstance(m, torch.nn.Linear):
+                m.weight.zero_(); m.bias.zero_()                               # ... diffusion factor g(t) = const
+    g.replay(); torch.cuda.synchronize()
+    c = out.clone()
+    assert not torch.allclose(c, b)
