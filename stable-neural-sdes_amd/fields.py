@@ -72,6 +72,10 @@ def _is_linear(m, n_in, n_out):
     return isinstance(m, torch.nn.Linear) and m.bias is not None and m.in_features == n_in and m.out_features == n_out
 
 
+def _capturing(dev):
+    return torch.device(dev).type == 'cuda' and torch.cuda.is_current_stream_capturing()
+
+
 class ComposedField:
     """A tutorial-style field mapped onto the fused step: `model` (snsde_model with the variant switches), `flat(dev)`
     (the composed parameter block, rebuilt from the module's current weights on every solve) and `noise_table(grid)`."""
@@ -102,7 +106,7 @@ class ComposedField:
         if grad:
             with torch.enable_grad():
                 return self._flat(dev, True)
-        if torch.cuda.is_current_stream_capturing():       # graph capture: no host read - the composition is recorded
+        if _capturing(dev):       # graph capture: no host read - the composition is recorded
             with torch.no_grad():
                 return self._flat(dev, False)
         # inference: the block only changes when a parameter does, so repeated solves reuse it (key: see _param_key)
@@ -116,7 +120,7 @@ class ComposedField:
 
     def inference_inputs(self, t0s, dev):
         """(parameter block, diffusion table) of a no-grad solve, cached on ONE reading of the parameters' identity."""
-        if torch.cuda.is_current_stream_capturing():
+        if _capturing(dev):
             return self.flat(dev), self.noise_table(t0s, dev)
         key = self._param_key(dev)
         hit = self._flat_cache
@@ -167,7 +171,7 @@ class ComposedField:
         (`inference_inputs`: one fingerprint read-back per solve, not two)."""
         N, H = t0s.shape[0], self.model.hidden_channels
         key = None
-        if not grad and t0s.is_cuda and not torch.cuda.is_current_stream_capturing():
+        if not grad and t0s.is_cuda and not _capturing(dev):
             # (same step times tensor of a cached grid + unchanged parameters: reuse the table)
             key = (t0s.data_ptr(), N) + (self._param_key(dev) if param_key is None else param_key)
             if self._tab_cache is not None and self._tab_cache[0] == key:
