@@ -358,6 +358,12 @@ def g5(ref, interp, out):
         ('gsde_milstein', 6, 17, 2, 5, 8, 3, torch.linspace(0, 1, 9), torch.linspace(0, 1, 9), None, 'milstein'),
         ('lsde_milstein', 2, 16, 2, 5, 8, 3, torch.arange(0., 9.), torch.tensor([0., 8.]), 1.0, 'milstein'),
         ('y_8_milstein', 5, 8, 2, 5, 8, 3, torch.arange(0., 9.), torch.tensor([0., 8.]), 0.5, 'milstein'),
+        # (round 2, appended: the generator stream of the cases above is unchanged)  Milstein through the diffusion nets:
+        # torchsde's VJP of g with cotangent g (dW^2 - h), taken by autograd on the reference's g
+        ('nsde_3_18_milstein', 3, 18, 2, 6, 8, 5, torch.linspace(1, 10, 10), torch.tensor([1., 4., 7., 10.]), 1.0, 'milstein'),
+        ('naive_1_14_milstein', 1, 14, 1, 4, 8, 3, torch.arange(0., 8.), torch.tensor([0., 7.]), 0.5, 'milstein'),
+        ('net_4_19_milstein', 4, 19, 2, 5, 16, 3, torch.arange(0., 9.), torch.tensor([0., 3.5, 8.]), 1.0, 'milstein'),
+        ('net_2_15_milstein', 2, 15, 2, 4, 8, 3, torch.arange(0., 8.), torch.tensor([0., 7.]), 0.5, 'milstein'),
     ]
     for (name, io, no, NL, B, H, C, times, ts, dt, method) in cases:
         L = times.shape[0]
