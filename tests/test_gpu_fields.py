@@ -255,3 +255,35 @@ def test_tutorial_field_solve_records_into_a_graph():
     g.replay(); torch.cuda.synchronize()
     c = out.clone()
     assert not torch.allclose(c, b)
+
+
+# ---- the notebooks' own vector fields (tests/golden/tutorial.npz: generated by executing tutorial/*.ipynb cell 7) ------------
+from tests.helpers import group, load, params_of      # noqa: E402
+TUT = load('tutorial.npz')
+T1_CASES = sorted({k.split('/')[1] for k in TUT.files if k.startswith('T1/')})
+
+
+@pytest.mark.parametrize('case', T1_CASES)
+def test_fused_path_vs_trajectories_of_the_reference_notebooks_fields(case):
+    """State_dict of the notebook's Neural{LSDE, LNSDE, GSDE}Func loaded into the test-side class (strict: same parameter
+    names and shapes), solved on the fused path with the fixture's increments, against the float64 trajectory that the
+    notebook's own f / g produced under the fixed-step scheme."""
+    dev = torch.device('cuda')
+    g = group(TUT, f'T1/{case}')
+    C, H, layers = (int(v) for v in g['meta'])
+    field = TutorialField(str(g['kind']), C, H, layers, str(g['activation']))
+    field.load_state_dict({k: torch.from_numpy(v.copy()) for k, v in params_of(TUT, f'T1/{case}').items()}, strict=True)
+    field = field.to(dev)
+    times = torch.from_numpy(g['times']).to(dev)
+    field.set_X(torch.from_numpy(g['coeffs']).to(dev), times)
+    with torch.no_grad():
+        ys = S.sdeint(field, torch.from_numpy(g['y0']).to(dev), times, dt=float(g['dt']), method=str(g['method']),
+                      bm=Replay(torch.from_numpy(g['dW']).to(dev)))
+    cf = fields.compose(field)
+    assert cf is not None and any(v is True for v in cf.verified.values()), 'the field did not take the fused path'
+    ref = g['ys64']
+    scale = np.abs(ref).max()
+    err = np.abs(ys.double().cpu().numpy() - ref).max()
+    assert err <= 2e-4 * max(scale, 1.0), (err, scale)
+    # no further from the float64 trajectory than the float32 tensor-op evaluation of the notebook's module (x4)
+    assert err <= 4 * np.abs(g['ys32'].astype(np.float64) - ref).max() + 1e-5 * scale

@@ -828,3 +828,41 @@ def test_oracle_diffusion_net_vjp_equals_autograd_on_the_module(no):
     ora, _ = O.solve_diffusion_model(p, 1, no, coeffs.numpy(), times, y0, ts, 0.5, dW, method='milstein')
     np.testing.assert_allclose(ora, loop.numpy(), rtol=1e-9, atol=1e-10)
 
+
+TUT = load('tutorial.npz')
+T1_CASES = sorted({k.split('/')[1] for k in TUT.files if k.startswith('T1/')})
+
+
+@pytest.mark.parametrize('case', T1_CASES)
+def test_tutorial_field_class_reproduces_the_notebooks_fields(case):
+    """tests/golden/tutorial.npz was produced by executing the notebooks' vector-field cell (tutorial/*.ipynb cell 7).  The
+    test-side class must load those state_dicts strictly and give the same f / g; the host tensor-op loop over the mirror's
+    CubicSpline must reproduce the float64 trajectory; the composition (fields.compose) must accept the module."""
+    from stable_neural_sdes_amd import fields
+    from tests.tutorial_fields import TutorialField
+    g = group(TUT, f'T1/{case}')
+    C, H, layers = (int(v) for v in g['meta'])
+    sd = {k: torch.from_numpy(v.copy()) for k, v in params_of(TUT, f'T1/{case}').items()}
+    field = TutorialField(str(g['kind']), C, H, layers, str(g['activation']))
+    field.load_state_dict(sd, strict=True)
+    times = torch.from_numpy(g['times'])
+    field.set_X(torch.from_numpy(g['coeffs']), times)
+    y0 = torch.from_numpy(g['y0'])
+    with torch.no_grad():
+        for i, t in enumerate(torch.from_numpy(g['probe_t'])):
+            np.testing.assert_allclose(field.f(t, y0).numpy(), g['f'][i], rtol=2e-5, atol=2e-6)
+            np.testing.assert_allclose(field.g(t, y0).numpy(), g['g'][i], rtol=2e-5, atol=2e-6)
+    assert fields.compose(field) is not None
+    f64 = TutorialField(str(g['kind']), C, H, layers, str(g['activation'])).double()
+    f64.load_state_dict({k: v.double() for k, v in sd.items()}, strict=True)
+    f64.set_X(torch.from_numpy(g['coeffs']).double(), times)
+
+    class Replay:
+        n = 0
+        def __call__(self, ta, tb):
+            self.n += 1
+            return torch.from_numpy(g['dW'][self.n - 1]).double()
+    with torch.no_grad():
+        ys = S.sdeint(f64, y0.double(), times, bm=Replay(), dt=float(g['dt']), method=str(g['method']),
+                      options={'backend': 'torch'})
+    np.testing.assert_allclose(ys.numpy(), g['ys64'], rtol=1e-7, atol=1e-8)
