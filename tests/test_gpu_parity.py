@@ -222,6 +222,26 @@ def test_philox_increments_match_specification():
     assert_parity(ys, ref64, cpu32, what='philox')
 
 
+@pytest.mark.parametrize('cfg', [(3, 18, 'milstein'), (1, 15, 'milstein'), (1, 18, 'srk'), (4, 19, 'euler')])
+def test_philox_increments_of_the_generic_kernels_with_a_diffusion_net(cfg):
+    """In-kernel increments of the kernels that serve the diffusion nets outside the MFMA path (Milstein kernel, generic SRK,
+    generic Euler): the specified Philox stream, written out, and the trajectory is the scheme on exactly those increments."""
+    io, no, method = cfg
+    pr = make_problem(14, io, no, 2, 21, 24, 5, 9)
+    ts, dt = [0, 2.5, 8], 0.5
+    ys, call = hip_solve(pr, ts, dt, dW=None, seed=0xFEED_5EED, row_offset=300, save_dW=True, method=method, kernel='generic')
+    t0, t1, *_ = O.step_grid(np.asarray(ts, np.float32), dt)
+    got = call.dW_out.cpu().numpy()
+    np.testing.assert_allclose(got, O.philox_dW(0xFEED_5EED, 300, 21, 24, t0, t1), rtol=2e-6, atol=2e-7)
+    dU = call.dU_out.cpu().numpy() if method == 'srk' else None
+    again, _ = hip_solve(pr, ts, dt, dW=got, dU=dU, method=method, kernel='generic')
+    np.testing.assert_array_equal(ys, again)            # replaying the written increments: the same bits
+    if method != 'srk':
+        ref64, _ = oracle_solve(pr, ts, dt, got, method, np.float64)
+        cpu32, _ = oracle_solve(pr, ts, dt, got, method, np.float32)
+        assert_parity(ys, ref64, cpu32, what=f'philox {cfg}')
+
+
 def test_philox_statistics_and_seed_sensitivity():
     pr = make_problem(12, 2, 16, 2, 512, 64, 3, 5)
     _, c1 = hip_solve(pr, [0, 4], 1.0, seed=1, save_dW=True)
