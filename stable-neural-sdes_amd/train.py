@@ -155,10 +155,65 @@ def evaluate_metrics(dataloader, model, times, loss_fn, num_classes, device, kwa
         return metrics
 
 
+class GraphedStep:
+    """The training step of the loop below - forward, loss, backward, optimizer step - recorded into one CUDA/HIP graph per
+    batch shape and replayed with each batch copied into the recording's input buffers (the step is launch-bound: ~60
+    kernels; replaying takes about two thirds of the eager time).  The solver draws fresh Brownian increments
+    on every replay from a device-resident Philox key (torchsde.prepare_graph_capture).  The first `warmup` batches of a
+    shape run eagerly (on a side stream, as capture requires); a learning-rate change drops the recordings (the rate is a
+    constant of the recorded optimizer kernel).  Needs an optimizer created with capturable=True."""
+
+    def __init__(self, model, times, optimizer, loss_fn, kwargs, device, warmup=3):
+        from . import torchsde as _T
+        _T.prepare_graph_capture(device)
+        self.model, self.times, self.opt, self.loss_fn, self.kwargs = model, times, optimizer, loss_fn, kwargs
+        self.device, self.warmup = device, warmup
+        self.entries, self.lrs = {}, None
+        self.side = torch.cuda.Stream(device)
+        self.replays = 0
+
+    def _step(self, coeffs, y, lengths):
+        pred = self.model(self.times, coeffs, lengths, **self.kwargs)
+        loss = self.loss_fn(pred, y)
+        loss.backward()
+        self.opt.step()
+        self.opt.zero_grad(set_to_none=True)
+
+    def __call__(self, coeffs, y, lengths):
+        lrs = tuple(float(g['lr']) for g in self.opt.param_groups)
+        if lrs != self.lrs:
+            self.entries, self.lrs = {}, lrs
+        batch = tuple(coeffs) + (y, lengths)
+        key = tuple((tuple(b.shape), b.dtype) for b in batch)
+        entry = self.entries.setdefault(key, {'seen': 0, 'graph': None, 'static': None})
+        if entry['graph'] is None:
+            if entry['seen'] < self.warmup:          # eager steps of this shape, on the side stream
+                entry['seen'] += 1
+                self.side.wait_stream(torch.cuda.current_stream(self.device))
+                with torch.cuda.stream(self.side):
+                    self._step(list(coeffs), y, lengths)
+                torch.cuda.current_stream(self.device).wait_stream(self.side)
+                return
+            static = tuple(b.clone() for b in batch)
+            graph = torch.cuda.CUDAGraph()
+            torch.cuda.synchronize(self.device)
+            with torch.cuda.graph(graph):
+                self._step(list(static[:-2]), static[-2], static[-1])
+            entry['graph'], entry['static'] = graph, static
+            graph.replay()                            # (the capture itself does not execute: run this batch's step now)
+            self.replays += 1
+            return
+        for dst, src in zip(entry['static'], batch):
+            dst.copy_(src, non_blocking=True)
+        entry['graph'].replay()
+        self.replays += 1
+
+
 def train_loop(train_dataloader, val_dataloader, model, times, optimizer, loss_fn, max_epochs, num_classes, device, kwargs,
-               step_mode, log=None, plateau_terminate=None):
+               step_mode, log=None, plateau_terminate=None, graph_steps=False):
     """The reference's epoch loop (common_sde.py:107-216).  Returns the history; `model` ends with the best parameters
-    (validation accuracy for classification, validation loss for regression)."""
+    (validation accuracy for classification, validation loss for regression).  graph_steps=True replays the training step
+    from a CUDA/HIP graph (GraphedStep; one process, CUDA, optimizer with capturable=True)."""
     modes = {'trainloss': 'min', 'valloss': 'min', 'valaccuracy': 'max', 'valauc': 'max', 'none': None}
     if step_mode not in modes:
         raise ValueError(f'step_mode must be one of {sorted(modes)}')
@@ -174,6 +229,7 @@ def train_loop(train_dataloader, val_dataloader, model, times, optimizer, loss_f
     best_train_accuracy, best_train_accuracy_epoch = 0.0, 0
     best_val = -math.inf
     history = []
+    graphed = GraphedStep(model, times, optimizer, loss_fn, kwargs, torch.device(device)) if graph_steps else None
     for epoch in range(max_epochs):
         sampler = getattr(train_dataloader, 'sampler', None)
         if hasattr(sampler, 'set_epoch'):
@@ -181,6 +237,9 @@ def train_loop(train_dataloader, val_dataloader, model, times, optimizer, loss_f
         for batch in train_dataloader:
             batch = tuple(b.to(device, non_blocking=True) for b in batch)
             *train_coeffs, train_y, lengths = batch
+            if graphed is not None:
+                graphed(train_coeffs, train_y, lengths)
+                continue
             try:
                 pred_y = model(times, train_coeffs, lengths, **kwargs)
                 loss = loss_fn(pred_y, train_y)
@@ -259,9 +318,11 @@ def make_model(name, input_channels, output_channels, hidden_channels, hidden_hi
 
 
 def main(name, model_name, times, train_dataloader, val_dataloader, test_dataloader, device, make_model, num_classes,
-         max_epochs, lr, kwargs, step_mode, pos_weight=torch.tensor(1), results_dir=None, log=print, regularise='l2'):
+         max_epochs, lr, kwargs, step_mode, pos_weight=torch.tensor(1), results_dir=None, log=print, regularise='l2',
+         graph_steps=False):
     """common_sde.main (common_sde.py:248-298): build, train, evaluate; `num_classes=None` trains a regression model with
-    the mean-squared error (the forecasting benchmark).  Results are written only when `name` and `results_dir` are set."""
+    the mean-squared error (the forecasting benchmark).  Results are written only when `name` and `results_dir` are set.
+    graph_steps=True (one process on a GPU): the training step is replayed from a CUDA/HIP graph (GraphedStep)."""
     device = torch.device(device)
     times = times.to(device)
     on_gpu = device.type == 'cuda'
@@ -285,9 +346,11 @@ def main(name, model_name, times, train_dataloader, val_dataloader, test_dataloa
         net = torch.nn.parallel.DistributedDataParallel(model, device_ids=[device.index] if on_gpu else None)
     # same update rule as the reference's Adam (common_sde.py:287); on the GPU the single-launch implementation instead of
     # the default multi-tensor one (~15 launches per step for these models)
-    optimizer = torch.optim.Adam(net.parameters(), lr=lr, weight_decay=lr * 0.01, fused=True if on_gpu else None)
+    graph_steps = bool(graph_steps) and on_gpu and dist is None
+    optimizer = torch.optim.Adam(net.parameters(), lr=lr, weight_decay=lr * 0.01, fused=True if on_gpu else None,
+                                 capturable=graph_steps)
     history = train_loop(train_dataloader, val_dataloader, net, times, optimizer, loss_fn, max_epochs, num_classes, device,
-                         kwargs, step_mode, log=log if (dist is None or dist.get_rank() == 0) else None)
+                         kwargs, step_mode, log=log if (dist is None or dist.get_rank() == 0) else None, graph_steps=graph_steps)
     net.eval()
     train_metrics = evaluate_metrics(train_dataloader, net, times, loss_fn, num_classes, device, kwargs)
     val_metrics = evaluate_metrics(val_dataloader, net, times, loss_fn, num_classes, device, kwargs)

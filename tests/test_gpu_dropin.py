@@ -272,6 +272,37 @@ def test_training_driver_on_gpu_uses_the_fused_path_and_learns(monkeypatch):
     assert getattr(res.model.model.func, '_snsde_flat', None) is not None    # the parameter arena was in use
 
 
+def test_training_driver_with_graph_replayed_steps(monkeypatch):
+    """train.main(graph_steps=True): after three eager batches per batch shape the training step is replayed from a CUDA/HIP
+    graph (train.GraphedStep) - same recipe, same learning behaviour; the ReduceLROnPlateau change of the rate drops the
+    recordings and re-captures."""
+    from stable_neural_sdes_amd import train as T
+    from tests.test_train_cpu import synthetic_loader
+    dev = torch.device('cuda')
+    torch.manual_seed(3)
+    L, C, H = 12, 4, 32
+    times, train = synthetic_loader(288, L, C, 2, 64, seed=1)          # four full batches of 64 and one of 32 per epoch
+    _, val = synthetic_loader(128, L, C, 2, 128, seed=2)
+    _, test = synthetic_loader(128, L, C, 2, 128, seed=3)
+    made = []
+    orig = T.GraphedStep
+
+    class Spy(orig):
+        def __init__(self, *a, **k):
+            super().__init__(*a, **k)
+            made.append(self)
+    monkeypatch.setattr(T, 'GraphedStep', Spy)
+    factory = T.make_model('neurallnsde', C, 1, H, H, 2, initial=True)
+    res = T.main(None, 'neurallnsde', times, train, val, test, dev, factory, 2, 8, 1e-2, dict(method='euler'), 'valloss', log=None,
+                 graph_steps=True)
+    losses = [h.train_metrics.loss for h in res.history]
+    assert len(losses) == 8 and losses[-1] < losses[0], losses
+    assert res.test_metrics.auroc > 0.7, res.test_metrics
+    gs = made[0]
+    assert gs.replays >= 8 * 5 - 2 * (3 + 1) - 8          # everything but the warm-up / capture batches of the two shapes (and re-captures)
+    assert all(e['graph'] is not None for e in gs.entries.values()) and len(gs.entries) == 2
+
+
 PAD_CASES = [
     # io, no, NL, B, H, HH, C, L, ts, dt, method     hidden sizes without an MFMA instantiation: solved zero-padded
     (4, 17, 2, 21, 48, 48, 5, 9, [0, 3.5, 8], 1.0, 'euler'),
