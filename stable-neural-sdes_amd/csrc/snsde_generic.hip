@@ -551,7 +551,8 @@ __global__ void __launch_bounds__(GW) snsde_generic_srk_kernel(SrkArgs sa) {
 
 // =====================================================================================================
 // Generic adjoint (backward) kernel: discretise-then-optimise adjoint of the Euler / Milstein step for every
-// input_option and every noise_option whose diffusion is elementwise in y (0..13, 16, 17), any H / HH / C / NL.
+// input_option and every noise_option (Milstein: all but 7), any H / HH / C / NL within the LDS budget; the diffusion nets
+// (14 / 15 / 18 / 19, dense dg/dy) add the net's forward, its transposed chain and - under Milstein - its tangent pass.
 // Per step (last to first) a workgroup re-evaluates the drift chain on its GR rows from the saved state y_n
 // (activations stay in LDS: one buffer per layer), applies the elementwise derivatives of f, g and the Milstein
 // term to the adjoint, and walks the chain backwards with the ORIGINAL (out, in) weight layout
@@ -996,7 +997,7 @@ __global__ void __launch_bounds__(GW) snsde_generic_adjoint_kernel(AdjArgs aa) {
 
 
 // =====================================================================================================
-// SRK adjoint: discretise-then-optimise backward of the SRID2 step above (elementwise diffusions, any dims).
+// SRK adjoint: discretise-then-optimise backward of the SRID2 step above (every noise_option, any dims in the LDS budget).
 // Per step (last to first) the workgroup re-evaluates the three drift stages from the saved state y_n and the saved
 // increments (I_k, I_k0), then walks the stage graph backwards:
 //     Fbar_s, Gbar_s  <-  a (alpha_s h, w_s)  +  the H0/H1 combinations of later stages
