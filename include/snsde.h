@@ -157,8 +157,9 @@ typedef struct snsde_solve {
     float*         dU_out;    /* optional device (N, B, H): the I_k0 actually used                    */
     float*         act_save;  /* optional device (N, snsde_act_slots, B, H): per-step activations the MFMA adjoint */
                               /* needs (training mode; see snsde_solve_backward)                                   */
-    float*         stage_save;/* SRK training on the MFMA path: optional device (3N + 1, B, H), the input state of every   */
-                              /* drift pass (act_save / delta_save are then indexed by pass, 3N of them)                */
+    float*         stage_save;/* SRK training on the MFMA path: optional device (3N + 1, planes, B, H), the input state of */
+                              /* every drift pass (act_save / delta_save are then indexed by pass, 3N of them); planes = 1, */
+                              /* or 3 with a diffusion net (snsde_save_layout)                                              */
     const uint64_t* seed_dev; /* optional device pointer to the Philox key: read when the kernel starts and used  */
                               /* instead of `seed`, so a captured hipGraph draws fresh increments on every replay */
                               /* (the owner updates the value in-stream between replays).                         */
@@ -205,6 +206,13 @@ typedef struct snsde_backward {
 int    snsde_act_slots(const snsde_model* m);             /* activation tensors saved per step, or <0: layer outputs (first, hidden.., */
                                                           /* pre-tanh drift) [+ diffusion-net slots]; models with a smooth activation  */
                                                           /* (SNSDE_ACT_LIPSWISH / SILU) also save every pre-activation (NL more slots) */
+int    snsde_save_layout(const snsde_solve* s, int32_t* act_slots, int32_t* stage_planes);
+                                                          /* training-mode buffers of THIS solve (model + method): act_save /     */
+                                                          /* delta_save are (passes, act_slots, B, H), stage_save (passes + 1,     */
+                                                          /* stage_planes, B, H); passes = N (3N for SRK).  SRK through a          */
+                                                          /* diffusion net (noise_option 14/15/18/19) saves a second set of net    */
+                                                          /* slots (the step's fourth diffusion evaluation) and three stage planes */
+                                                          /* (drift input H0 | diffusion input H1 | H1 of the fourth evaluation)   */
 int    snsde_backward_supported(const snsde_solve* s);    /* 1 / 2 / 0, see above                          */
 size_t snsde_backward_workspace_bytes(const snsde_backward* b);
 int    snsde_solve_backward(const snsde_backward* b, void* hip_stream);

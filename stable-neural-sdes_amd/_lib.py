@@ -66,7 +66,7 @@ EXPORTS = ('snsde_version', 'snsde_strerror', 'snsde_param_count', 'snsde_param_
            'snsde_spline_evaluate', 'snsde_eval_fg', 'snsde_act_slots', 'snsde_backward_supported',
            'snsde_backward_workspace_bytes', 'snsde_solve_backward', 'snsde_spline_workspace_bytes',
            'snsde_natural_cubic_coeffs', 'snsde_hermite_coeffs', 'snsde_param_gradients_workspace_bytes',
-           'snsde_param_gradients', 'snsde_forward_path', 'snsde_readout_head')
+           'snsde_param_gradients', 'snsde_forward_path', 'snsde_readout_head', 'snsde_save_layout')
 
 
 def lib():
@@ -103,6 +103,7 @@ def lib():
                                              C.c_size_t, C.c_void_p]
     L.snsde_hermite_coeffs.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p]
     L.snsde_act_slots.argtypes = [C.POINTER(Model)]
+    L.snsde_save_layout.argtypes = [C.POINTER(Solve), C.POINTER(C.c_int32), C.POINTER(C.c_int32)]
     L.snsde_param_gradients_workspace_bytes.argtypes = [C.POINTER(Backward)]
     L.snsde_param_gradients_workspace_bytes.restype = C.c_size_t
     L.snsde_param_gradients.argtypes = [C.POINTER(Backward), C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]

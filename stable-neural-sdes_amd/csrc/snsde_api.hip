@@ -428,6 +428,19 @@ int snsde_act_slots(const snsde_model* m) {
            (m->activation != SNSDE_ACT_RELU ? m->num_hidden_layers : 0);
 }
 
+int snsde_save_layout(const snsde_solve* s, int32_t* act_slots, int32_t* stage_planes) {
+    if (!s) return SNSDE_ERR_NULL;
+    int slots = snsde_act_slots(&s->model);
+    if (slots < 0) return slots;
+    const int no = s->model.noise_option;
+    const int nn = (no == 18 || no == 19) ? 2 : ((no == 14 || no == 15) ? 1 : 0);
+    int planes = 1;
+    if (s->method == SNSDE_SRK && nn > 0) { slots += nn; planes = 3; }
+    if (act_slots) *act_slots = slots;
+    if (stage_planes) *stage_planes = planes;
+    return SNSDE_OK;
+}
+
 int snsde_backward_supported(const snsde_solve* s) {
     if (!s || validate_model(&s->model)) return 0;
     if (s->method == SNSDE_MILSTEIN && s->model.noise_option == 7) return 0;     // no forward kernel either (validate_solve)

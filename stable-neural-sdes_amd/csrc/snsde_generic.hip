@@ -287,7 +287,7 @@ __global__ void __launch_bounds__(GT) snsde_generic_kernel(GenericArgs a) {
                 const float dw = a.dW ? a.dW[(size_t)n * BH + (size_t)row * H + j] : zn[e] * sqh;
                 float ynew = fmaf(g, dw, fmaf(f, h, y));
                 if (d.method == SNSDE_MILSTEIN) {
-                    const float fin = (raw - raw == 0.0f) ? 1.0f : 0.0f;  // finite raw
+                    const float fin = snsde_finite(raw) ? 1.0f : 0.0f;  // finite raw
                     const float dg = (1.0f - g * g) * sig_theta * draw * fin;
                     ynew = fmaf(0.5f * (g * dg), fmaf(dw, dw, -h), ynew);
                 }
@@ -711,7 +711,7 @@ __global__ void __launch_bounds__(GW) snsde_generic_milnet_kernel(GenericArgs a)
                 }
                 if (a.dW_out) a.dW_out[(size_t)n * BH + (size_t)row * H + j] = dw;
             }
-            const float dgr = (raw - raw == 0.0f) ? (1.0f - g * g) * sig_theta : 0.0f;       // dg / d raw
+            const float dgr = snsde_finite(raw) ? (1.0f - g * g) * sig_theta : 0.0f;       // dg / d raw
             const float craw = g * fmaf(dw, dw, -h) * dgr;                                    // cotangent of raw
             float base = fmaf(g, dw, fmaf(f, h, y));
             if (net_y) base = fmaf(0.5f * craw, nb, base);                                    // direct factor: d(net y)/dy = net
@@ -903,7 +903,7 @@ __global__ void __launch_bounds__(GW) snsde_generic_adjoint_kernel(AdjArgs aa) {
                 case 15: case 19: r1 = nraw[r * ldw + j]; raw = r1 * y; break;      // r1: the direct y factor only
                 default: break;
             }
-            const bool fin = (raw - raw == 0.0f);
+            const bool fin = snsde_finite(raw);
             const float g = tanhf(sig_theta * snsde_nan_to_num(raw));
             float dnet = 0.0f;
             if (fin) {
@@ -1126,7 +1126,7 @@ __global__ void __launch_bounds__(GW) snsde_generic_srk_adjoint_kernel(SrkAdjArg
             default: break;
         }
         const float g = tanhf(sig_theta * snsde_nan_to_num(raw));
-        const float dgr = (raw - raw == 0.0f) ? (1.0f - g * g) * sig_theta : 0.0f;     // dg / d raw
+        const float dgr = snsde_finite(raw) ? (1.0f - g * g) * sig_theta : 0.0f;     // dg / d raw
         g1 = dgr * r1;
         if (gs) *gs = dgr;
         return g;

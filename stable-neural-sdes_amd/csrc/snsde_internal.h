@@ -88,6 +88,11 @@ __device__ __forceinline__ float snsde_nan_to_num(float x) {
     return fminf(fmaxf(x, -3.402823466e+38f), 3.402823466e+38f);
 }
 
+// Finiteness test of a diffusion's raw value (the derivative of nan_to_num is taken as 0 at the clipped values).  NOT
+// `x - x == 0`: with x = a * b hipcc's default fp-contract fuses that into fma(a, b, -x), the rounding residual of the
+// product, which is non-zero for finite x.
+__device__ __forceinline__ bool snsde_finite(float x) { return __builtin_fabsf(x) <= 3.402823466e+38f; }
+
 // Cubic piece evaluation with the reference's exact operation order (controldiffeq/interpolate.py:270-283).
 // FMA contraction is switched off for these two functions (HIP's __fmul_rn/__fadd_rn are plain
 // operators and would be contracted), so the result is bit-identical to the CPU reference.

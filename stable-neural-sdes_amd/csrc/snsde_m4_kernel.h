@@ -403,7 +403,7 @@ __global__ void __launch_bounds__(CF::NT, CF::WPS) snsde_m4_kernel(MfmaArgs a) {
             float p1, p2;
             const float raw = snsde_phi(no, y, p1, p2);
             g = fast_tanh(sig_theta * snsde_nan_to_num(raw));
-            draw = (raw - raw == 0.0f) ? p1 : 0.0f;
+            draw = snsde_finite(raw) ? p1 : 0.0f;
         } else
         {                                 // table noise (no table: gtv = 0 and g = tanh(0) = 0)
             const float raw = mul_y ? gtv * y : gtv;
@@ -413,7 +413,7 @@ __global__ void __launch_bounds__(CF::NT, CF::WPS) snsde_m4_kernel(MfmaArgs a) {
                 return yp;
             }
             g = LEAN_TANH_G(sig_theta * raw);
-            draw = (mul_y && raw - raw == 0.0f) ? gtv : 0.0f;
+            draw = (mul_y && snsde_finite(raw)) ? gtv : 0.0f;
         }
         float yp = fmaf(g, dwv, y);
         if (__builtin_expect(mil, 0)) yp = fmaf(0.5f * (g * ((1.0f - g * g) * sig_theta * draw)), fmaf(dwv, dwv, -hh), yp);

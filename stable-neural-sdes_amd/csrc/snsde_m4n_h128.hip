@@ -1,0 +1,8 @@
+// 4-row-tile MFMA kernels for the diffusion nets under SRK / Milstein (snsde_m4n_kernel.h), hidden size 128.
+#include "snsde_m4n_kernel.h"
+
+namespace snsde_mfma {
+
+int dispatch_m4n_h128(const MfmaPlan& p, const MfmaArgs& a, hipStream_t st) { return dispatch_m4n<128>(p, a, st); }
+
+}  // namespace snsde_mfma

@@ -1,0 +1,8 @@
+// 4-row-tile MFMA kernels for the diffusion nets under SRK / Milstein (snsde_m4n_kernel.h), hidden size 16.
+#include "snsde_m4n_kernel.h"
+
+namespace snsde_mfma {
+
+int dispatch_m4n_h16(const MfmaPlan& p, const MfmaArgs& a, hipStream_t st) { return dispatch_m4n<16>(p, a, st); }
+
+}  // namespace snsde_mfma

@@ -186,7 +186,7 @@ __global__ void __launch_bounds__(CF::NT, 1) snsde_m4s_kernel(MfmaArgs a) {
             float p1, p2;
             const float raw = snsde_phi(no, y, p1, p2);
             g = fast_tanh(sig_theta * snsde_nan_to_num(raw));
-            draw = (raw - raw == 0.0f) ? p1 : 0.0f;
+            draw = snsde_finite(raw) ? p1 : 0.0f;
         } else {
             const float raw = mul_y ? gtv * y : gtv;
             if (__builtin_expect(g_raw, 0)) {
@@ -195,7 +195,7 @@ __global__ void __launch_bounds__(CF::NT, 1) snsde_m4s_kernel(MfmaArgs a) {
                 return yp;
             }
             g = LEAN_TANH_G(sig_theta * raw);
-            draw = (mul_y && raw - raw == 0.0f) ? gtv : 0.0f;
+            draw = (mul_y && snsde_finite(raw)) ? gtv : 0.0f;
         }
         float yp = fmaf(g, dwv, y);
         if (__builtin_expect(mil, 0)) yp = fmaf(0.5f * (g * ((1.0f - g * g) * sig_theta * draw)), fmaf(dwv, dwv, -hh), yp);

@@ -25,6 +25,7 @@
 //        Fills all 256 CUs at batch 1024.
 
 #include "snsde_m4_kernel.h"
+#include "snsde_m4n_kernel.h"
 
 using namespace snsde_mfma;
 
@@ -195,7 +196,10 @@ __global__ void snsde_srk_expand_kernel(const float* __restrict__ step_tab, cons
     const float* tp = srk_tab + ((size_t)n * 4 + slot) * SNSDE_SRK_STRIDE;
     float* o = out + (size_t)i * SNSDE_STEP_STRIDE;
     o[0] = tp[0]; o[1] = st[1]; o[2] = tp[1]; o[3] = tp[2]; o[4] = tp[3]; o[5] = tp[4]; o[6] = st[6]; o[7] = st[7];
-    o[8] = stg == 2 ? st[8] : __int_as_float(0); o[9] = st[9]; o[10] = 0.0f; o[11] = 0.0f;
+    o[8] = stg == 2 ? st[8] : __int_as_float(0); o[9] = st[9];
+    // [10], [11]: sin / cos of the DIFFUSION stage time evaluated beside this pass (snsde_m4n_kernel.h): t0, t0 + h/4, t0 + h
+    const float* tn = srk_tab + ((size_t)n * 4 + (stg == 0 ? 0 : (stg == 1 ? 1 : 3))) * SNSDE_SRK_STRIDE;
+    o[10] = tn[1]; o[11] = tn[2];
 }
 
 // tutorial-style fields (variant switches of snsde_model / a caller-supplied noise table): the lean 4-row-tile kernels only
@@ -220,8 +224,13 @@ MfmaPlan make_plan(const snsde_solve* s, const SnsdeNet& net, int flavor_hint) {
     const bool tab_noise = (no >= 1 && no <= 6) || no == 11 || no == 12 || no == 13 || no == 16 || no == 17;
     const bool y_noise = (no >= 7 && no <= 10);      // raw = phi(y): sqrt y, y^3, sigmoid y, relu y
     if (!(no == 0 || tab_noise || y_noise || noise_net)) return p;
-    if (noise_net && (io == 0 || io == 2 || io == 4 || io == 6) && m.input_channels > 32) return p;   // nets + wide control: generic
-    if (noise_net && s->method != SNSDE_EULER) return p;
+    // SRK / Milstein through a diffusion net: the 4-row-tile kernels of snsde_m4n_kernel.h (embedded or latent-only drifts)
+    const bool m4n = noise_net && s->method != SNSDE_EULER;
+    const int kuxn = (io == 2 || io == 4 || io == 6) ? (m.input_channels > 32 ? 5 : 2) : 0;
+    if (m4n && (flavor_hint == 0 || io == 0 || m.num_hidden_layers > 4 ||
+                !m4n_instantiated(H, kuxn, m.num_hidden_layers - 1, no >= 18 ? 2 : 1, s->method)))
+        return p;
+    if (noise_net && !m4n && (io == 0 || io == 2 || io == 4 || io == 6) && m.input_channels > 32) return p;   // nets + wide control: generic
     if (srk && m.input_channels > 32 && (io == 0 || m.num_hidden_layers > 3)) return p;   // wide control under SRK: embedded drifts, NL <= 3
     const bool emb = (io == 2 || io == 4 || io == 6);
     const int nhid = m.num_hidden_layers - 1;
@@ -241,7 +250,8 @@ MfmaPlan make_plan(const snsde_solve* s, const SnsdeNet& net, int flavor_hint) {
         p.FL = flavor_hint >= 0 ? flavor_hint : (10 * r4 > 22 * r16 ? 0 : 1);
     }
     p.SRK = srk ? 1 : 0;
-    if (srk) p.FL = 1;
+    if (srk || m4n) p.FL = 1;
+    p.M4N = m4n ? 1 : 0; p.KUXN = kuxn;
     p.FOLD = (emb && (nhid > 1 || p.KUX > 2 || srk || noise_net || !(s->flags & SNSDE_FLAG_EXACT_ORDER))) ? 1 : 0;   // exact order: NL <= 2, C <= 32 only
     // lean M4 kernel (snsde_m4_kernel.h): 4-row tiles, Euler / Milstein, elementwise diffusions, 32 <= H <= 128; the time
     // features share the control path's k-block
@@ -250,7 +260,7 @@ MfmaPlan make_plan(const snsde_solve* s, const SnsdeNet& net, int flavor_hint) {
     int kuxt = (xcn + (timef ? 2 : 0) + 15) / 16;
     if (kuxt == 4 || kuxt == 5) kuxt = 6;        // instantiated: 0, 1, 2, 3, 6 blocks
     p.KUXT = kuxt;
-    p.LEAN = (p.FL == 1 && !srk && p.NN == 0 && (!emb || p.FOLD) && kuxt <= 6 && lean_fits(H, nhid, kuxt, io != 0)) ? 1 : 0;
+    p.LEAN = (p.FL == 1 && !srk && !m4n && p.NN == 0 && (!emb || p.FOLD) && kuxt <= 6 && lean_fits(H, nhid, kuxt, io != 0)) ? 1 : 0;
     const bool variant = m.activation != 0 || m.drift_output != 0 || m.diffusion_output != 0 || m.time_feature != 0 ||
                          s->noise_table != nullptr;
     if (variant && !(p.LEAN && (s->noise_table == nullptr || no == 12 || no == 13) && (no == 0 || tab_noise) && kuxt <= 3 &&
@@ -297,20 +307,31 @@ MfmaPlan make_plan(const snsde_solve* s, const SnsdeNet& net, int flavor_hint) {
     } else if (p.FOLD) {
         // kernel load order: wx (init piece), wy (in piece); ONE bias row (written by the `in` piece)
         add(net.init, p.KUX, H, false);
-        add(net.in, KUYv, 0, true);
+        add(net.in, m4n ? KUH + 1 : KUYv, 0, true);     // (the net kernels always carry the time block: zero columns without it)
         p.fold_b_in = net.in.src_b; p.fold_b_init = net.init.src_b; p.fold_b_emb = net.emb.src_b;
         p.fold_emb_w = net.emb.src_w;
     } else if (io == 0) {
         add(net.init, p.KUX, -1, true);                  // z0 = initial_network(X(t))
     } else {
         if (emb) add(net.init, p.KUX, -1, true);
-        add(net.in, KUYv, -1, true);
+        add(net.in, m4n ? KUH + 1 : KUYv, -1, true);
         if (emb) add(net.emb, 2 * KUH, -1, true);
     }
     for (int l = 0; l < nhid; ++l) add(net.hid[l], KUH, -1, true);
     add(net.out, KUH, -1, true);
     if (p.NN >= 1) add(net.ny0, KUH + 1, -1, true);
     if (p.NN >= 2) add(net.ny1, KUH, -1, true);
+    if (m4n && s->method == SNSDE_MILSTEIN) {      // the VJP through the net: ny1^T, ny0[:, y columns]^T
+        auto add_t = [&](const SnsdeLayer& L, int col_off) {
+            MfmaLayerPack& q = p.layer[n++];
+            q = MfmaLayerPack{};
+            q.src_w = L.src_w; q.src_b = L.src_b; q.K = H; q.N = H; q.KU = KUH; q.dst = woff;
+            q.transpose = 1; q.src_ld = L.K; q.col_off = col_off; q.bias_row = -1; q.fold_tmp = -1;
+            woff += p.NW * KUH * 256;
+        };
+        if (p.NN >= 2) add_t(net.ny1, 0);
+        add_t(net.ny0, net.ny0.tshift);
+    }
     p.n_bias_rows = rows;
     p.n_layers = n;
     int off = 0;
@@ -482,6 +503,14 @@ int snsde_mfma_launch(const snsde_solve* s, const SnsdeNet& net, hipStream_t str
     a.method = s->method; a.no = s->model.noise_option;
     a.off_theta = net.off_theta; a.gt_off = p.gt_off; a.bias_off = p.bias_off;
     for (int i = 0; i < p.n_layers; ++i) a.w_off[i] = p.layer[i].dst;
+    if (p.M4N) {
+        a.lean_geo = (p.IO == 5 || p.IO == 6) ? 1 : 0;
+        if (p.H == 128) return dispatch_m4n_h128(p, a, stream);
+        if (p.H == 64) return dispatch_m4n_h64(p, a, stream);
+        if (p.H == 32) return dispatch_m4n_h32(p, a, stream);
+        if (p.H == 16) return dispatch_m4n_h16(p, a, stream);
+        return SNSDE_ERR_UNSUPPORTED;
+    }
     if (p.LEAN) {
         const int io = p.IO;
         a.lean_xc = (io == 0 || io == 2 || io == 4 || io == 6) ? s->model.input_channels : 0;

@@ -863,7 +863,7 @@ __global__ void __launch_bounds__(CF::NT, CF::WPS) snsde_mfma_kernel(MfmaArgs a)
                 float yn = fmaf(g, dw[t][e], fmaf(f, h, y));
                 // Milstein: + 0.5 g dg/dy (dW^2 - h), dg/dy = (1 - g^2) sigmoid(theta) d raw/dy (raw finite)
                 if (mil != 0.0f) {
-                    const float draw = (raw - raw == 0.0f) ? (yfun ? q1 : (mul_y ? gq : 0.0f)) : 0.0f;
+                    const float draw = snsde_finite(raw) ? (yfun ? q1 : (mul_y ? gq : 0.0f)) : 0.0f;
                     yn = fmaf(mil * (g * ((1.0f - g * g) * sig_theta * draw)), fmaf(dw[t][e], dw[t][e], -h), yn);
                 }
                 yold[e] = y; ynew[e] = yn; yv[t][e] = yn;
@@ -1159,7 +1159,7 @@ __global__ void __launch_bounds__(CF::NT, CF::WPS) snsde_mfma_reverse_kernel(Rev
                     const float raw = mul_y ? gq * y : gq;
                     const float g = fast_tanh(sig_theta * snsde_nan_to_num(raw));
                     const float om = 1.0f - g * g;
-                    const bool finite = (raw - raw == 0.0f);
+                    const bool finite = snsde_finite(raw);
                     if (mul_y && finite) {
                         const float c = sig_theta * gq;
                         acc = fmaf(av * om * c, dw + qq * c * fmaf(-3.0f * g, g, 1.0f), acc);
@@ -1184,7 +1184,7 @@ __global__ void __launch_bounds__(CF::NT, CF::WPS) snsde_mfma_reverse_kernel(Rev
             const float raw = yfun ? snsde_phi(a.no, y, q1, q2) : (mul_y ? gq * y : gq);
             const float rcv = snsde_nan_to_num(raw);
             const float g = fast_tanh(sig_theta * rcv);
-            const bool finite = (raw - raw == 0.0f);
+            const bool finite = snsde_finite(raw);
             const float om = 1.0f - g * g;
             if (yfun) {
                 if (finite) {
@@ -1398,7 +1398,7 @@ __global__ void __launch_bounds__(CF::NT, CF::WPS) snsde_mfma_srk_reverse_kernel
     auto gfun = [&](float tv, float yy, float& gp, float& rc, bool& fin) {
         float q1 = mul_y ? tv : 0.0f, q2 = 0.0f;
         const float raw = yfun ? snsde_phi(a.no, yy, q1, q2) : (mul_y ? tv * yy : tv);
-        fin = (raw - raw == 0.0f);
+        fin = snsde_finite(raw);
         rc = snsde_nan_to_num(raw);
         const float g = fast_tanh(sig_theta * rc);
         gp = fin ? (1.0f - g * g) * sig_theta * q1 : 0.0f;
@@ -1593,6 +1593,7 @@ struct MfmaPlan {
     bool ok;
     int H, KUX, NHID, IO, FL, TPW, NW, FOLD, NN, SRK;
     int LEAN, KUXT;    // lean M4 kernel (snsde_m4_kernel.h) and its 16-wide k-blocks of [X(t) | sin t, cos t]
+    int M4N, KUXN;     // diffusion nets under SRK / Milstein (snsde_m4n_kernel.h) and its control k-blocks (0: latent-only drift)
     int srk_tab_off;   // expanded (3N-row) step table of the SRK variant inside the workspace
     int n_bias_rows;
     int fold_b_in, fold_b_init, fold_b_emb, fold_emb_w, fold_bias_tmp;

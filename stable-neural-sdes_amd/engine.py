@@ -346,17 +346,18 @@ class SolveCall:
         self.traj = torch.empty((grid.N + 1, B, H), device=dev, dtype=torch.float32) if save_traj else None
         self.dW_out = torch.empty((grid.N, B, H), device=dev, dtype=torch.float32) if save_dW else None
         self.act_save = self.stage_save = None
-        if save_act:
-            slots = _lib.lib().snsde_act_slots(C.byref(model))
-            _lib.check(min(slots, 0), 'snsde_act_slots')
-            passes = 3 * grid.N if method == 'srk' else grid.N      # SRK: three drift passes per step
-            self.act_save = torch.empty((passes, slots, B, H), device=dev, dtype=torch.float32)
-            if method == 'srk':
-                self.stage_save = torch.empty((passes + 1, B, H), device=dev, dtype=torch.float32)
         s = _lib.Solve()
         s.model = model
         s.batch, s.knots, s.n_steps, s.n_out = B, L, grid.N, grid.T
         s.method = {'euler': _lib.EULER, 'milstein': _lib.MILSTEIN, 'srk': _lib.SRK}[method]
+        if save_act:
+            slots, planes = C.c_int32(), C.c_int32()
+            _lib.check(_lib.lib().snsde_save_layout(C.byref(s), C.byref(slots), C.byref(planes)), 'snsde_save_layout')
+            passes = 3 * grid.N if method == 'srk' else grid.N      # SRK: three drift passes per step
+            self.act_save = torch.empty((passes, slots.value, B, H), device=dev, dtype=torch.float32)
+            if method == 'srk':
+                shape = (passes + 1, B, H) if planes.value == 1 else (passes + 1, planes.value, B, H)
+                self.stage_save = torch.empty(shape, device=dev, dtype=torch.float32)
         if method == 'srk':
             s.srk_tab = _ptr(srk_table(grid))
             s.dU = _ptr(dU)
