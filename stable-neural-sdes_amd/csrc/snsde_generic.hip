@@ -11,6 +11,8 @@
 //   A5  bm(t0, t1)     supplied dW, or Philox4x32-10 keyed by (seed; global row, step, col/4)
 //   A4/A6 Euler / Milstein update, A3 output interpolation (torchsde 0.2.5, restated)
 // The MFMA fast path for the headline configurations lives in snsde_mfma.hip.
+#include <stddef.h>
+
 #include "snsde_internal.h"
 
 namespace {
@@ -24,7 +26,7 @@ struct PackJob {
 };
 
 __global__ void snsde_pack_kernel(const float* __restrict__ params, float* __restrict__ ws, PackJob job) {
-    const SnsdeLayer L = job.layer[blockIdx.y];
+    const SnsdeLayer L = snsde_kernarg_element<SnsdeLayer>(16 + offsetof(PackJob, layer), blockIdx.y);     // kernarg: params, ws, job
     const int total = L.Kpad * L.N;
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
         const int k = i / L.N, n = i - k * L.N;

@@ -88,6 +88,24 @@ __device__ __forceinline__ float snsde_nan_to_num(float x) {
     return fminf(fmaxf(x, -3.402823466e+38f), 3.402823466e+38f);
 }
 
+// Element `index` (wave-uniform, known only at run time) of an array member of a kernel's BY-VALUE argument struct, read
+// straight from the kernarg segment with scalar loads.  `byte_offset` = offset of the array inside the kernarg segment
+// (argument offset + offsetof(struct, member)).  Indexing the by-value struct itself (`a.tile[blockIdx.y]`) makes hipcc copy
+// the WHOLE struct to scratch in every lane first: kilobytes of private memory per lane, written by every thread of every
+// workgroup — and beyond ~3 KB per lane the launches of this library started to fault in the scratch aperture.
+template <class T>
+__device__ __forceinline__ T snsde_kernarg_element(size_t byte_offset, int index) {
+    static_assert(sizeof(T) % 4 == 0, "dword-sized elements");
+    typedef const uint32_t __attribute__((address_space(4)))* KP;
+    KP p = (KP)((const char __attribute__((address_space(4)))*)__builtin_amdgcn_kernarg_segment_ptr() + byte_offset +
+                (size_t)index * sizeof(T));
+    T out;
+    uint32_t* d = reinterpret_cast<uint32_t*>(&out);
+#pragma unroll
+    for (int i = 0; i < (int)(sizeof(T) / 4); ++i) d[i] = p[i];
+    return out;
+}
+
 // Finiteness test of a diffusion's raw value (the derivative of nan_to_num is taken as 0 at the clipped values).  NOT
 // `x - x == 0`: with x = a * b hipcc's default fp-contract fuses that into fma(a, b, -x), the rounding residual of the
 // product, which is non-zero for finite x.

@@ -1,0 +1,333 @@
+// Adjoint of the SRID2 step through a DIFFUSION NET (noise_option 14 / 15 / 18 / 19) on the MFMA path, 4-row tiles:
+// the backward of snsde_m4n_kernel<.., SNSDE_SRK>.  Per solver step (walked backwards) SEVEN transposed chains:
+//
+//     G3 | G2 || drift pass 2 | G1 || drift pass 1 | G0 || drift pass 0
+//
+// `G_e` = the net's chain  dL/dg_e -> (1 - g^2) sigmoid(theta) {y, direct term} -> [q > 0] -> ny1^T -> [h > 0] -> ny0_y^T
+// (the cotangent of the state the e-th diffusion evaluation saw), `drift pass s` = the Euler adjoint's chain
+// out^T -> [relu] -> hid^T .. -> first_y^T on pass 3n + s.  A net chain and the drift chain written beside it are
+// independent (SRID2's stage dependencies, see the comments in the step loop) and share their barriers.  F_s, G_e, H0_s,
+// H1_e are recomputed per lane from y_n, the saved pre-tanh drifts / net outputs and (I_k, I_k0); relu masks come from the
+// forward's act_save.  Left for snsde_param_gradients: the per-layer deltas of every pass (delta_save: drift slots 0 ..
+// NHID + 1, net slots NHID + 2 .., the step's fourth evaluation in a second set of net slots at pass 3n + 2) and the
+// per-workgroup sums of dL/d sigmoid(theta).
+// Weights as in the forward: what does not fit the register budget is parked in the wave's private LDS slice.
+#pragma once
+#include "snsde_m4n_kernel.h"
+
+namespace snsde_mfma {
+
+__host__ __device__ constexpr int m4nr_reg_budget(int H) { return H >= 128 ? 104 : 144; }
+__host__ __device__ constexpr int m4nr_nlds(int H, int NHID, int NN) {
+    const int KUH = H / 16, nm = NHID + 2 + NN;
+    int regs = 4 * KUH * nm, nl = 0, blocks = 0;
+    while (regs > m4nr_reg_budget(H) && nl < nm) {
+        if (blocks + KUH > m4n_lds_cap_blocks(H)) break;
+        regs -= 4 * KUH; blocks += KUH; ++nl;
+    }
+    return regs > m4nr_reg_budget(H) + 32 ? -1 : nl;
+}
+
+template <int H_, int NHID_, int NN_>
+struct CfgNR {
+    static constexpr int H = H_, NHID = NHID_, NN = NN_;
+    static constexpr int NW = H / 16, NT = NW * 64, WPS = NW >= 8 ? NW / 4 : 2, M = 4;
+    static constexpr int KUH = H / 16, LDA = ld_for(16 * KUH, 16);
+    static constexpr int ND = NHID + 2, NMAT = ND + NN;
+    static constexpr int NSLOT = NHID + 2 + 2 * NN;       // act_save / delta_save slots per pass
+    static constexpr int ZSLOT = NHID + 1, NB0 = NHID + 2;
+    static constexpr int NLDS = m4nr_nlds(H, NHID, NN);
+    static constexpr bool FITS = NLDS >= 0;
+    static constexpr bool in_lds(int i) { return i >= 0 && i < NMAT && i >= NMAT - NLDS; }
+    static constexpr int lds_w_off(int i) {
+        int o = 0;
+        for (int j = 0; j < i && j < NMAT; ++j) if (in_lds(j)) o += KUH * 256 * NW;
+        return o;
+    }
+    static constexpr int NBUF = ND + 2;                   // drift buffers 0 .. ND - 1, two net buffers
+    static constexpr int LDS_ACT = NBUF * M * LDA;
+    static constexpr int LDS_FLOATS = LDS_ACT + lds_w_off(NMAT);
+};
+
+template <class CF>
+__global__ void __launch_bounds__(CF::NT, CF::WPS) snsde_m4n_srk_reverse_kernel(RevArgs a) {
+    constexpr int H = CF::H, M = 4, NT = CF::NT, NHID = CF::NHID, NN = CF::NN, ND = CF::ND, KUH = CF::KUH, LDA = CF::LDA;
+    constexpr int NSLOT = CF::NSLOT, ZSLOT = CF::ZSLOT, NB0 = CF::NB0;
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    float* nb0 = lds + ND * M * LDA;
+    float* nb1 = nb0 + M * LDA;
+    float* wlds = lds + CF::LDS_ACT;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int r = lane & 3, s = (lane >> 2) & 3, fsub = 4 * (lane >> 4);
+    const int row0 = blockIdx.x * M, B = a.B;
+    const int row = row0 + r, rowc = row < B ? row : B - 1;
+    const bool row_ok = row < B;
+    const size_t BH = (size_t)B * H;
+    const int fcol = wave * 16 + fsub + s;
+    const size_t goff = (size_t)rowc * H + fcol;
+    const int lrow = r * LDA + fcol;               // own element inside an LDS buffer
+    const int brow = r * LDA + 4 * s;              // this lane's B-operand row inside an LDS buffer
+
+    // transposed matrices in chain order: out^T, hid^T (last first), first_y^T, [ny1^T], ny0_y^T
+    WN<CF::in_lds(0), KUH> w0;
+    WN<CF::in_lds(1), KUH> w1;
+    WN<(ND > 2) && CF::in_lds(2), KUH> w2;
+    WN<(ND > 3) && CF::in_lds(3), KUH> w3;
+    WN<(ND > 4) && CF::in_lds(4), KUH> w4;
+    WN<CF::in_lds(ND), KUH> wnA;
+    WN<(NN > 1) && CF::in_lds(ND + 1), KUH> wnB;
+    {
+        auto slice = [&](int ix) { return wlds + CF::lds_w_off(ix) + wave * KUH * 256; };
+        w0.load(a.ws + a.w_off[0], wave, lane, slice(0));
+        w1.load(a.ws + a.w_off[1], wave, lane, slice(1));
+        if constexpr (ND > 2) w2.load(a.ws + a.w_off[2], wave, lane, slice(2));
+        if constexpr (ND > 3) w3.load(a.ws + a.w_off[3], wave, lane, slice(3));
+        if constexpr (ND > 4) w4.load(a.ws + a.w_off[4], wave, lane, slice(4));
+        wnA.load(a.ws + a.w_off[ND], wave, lane, slice(ND));
+        if constexpr (NN > 1) wnB.load(a.ws + a.w_off[ND + 1], wave, lane, slice(ND + 1));
+    }
+    for (int i = tid; i < CF::LDS_ACT; i += NT) lds[i] = 0.0f;
+    __syncthreads();
+
+    const float sig_theta = snsde_sigmoid(a.params[a.off_theta]);
+    const bool mul_y = (a.no == 15 || a.no == 19);
+    const bool geo = a.geo != 0;
+    const float rowf = row_ok ? 1.0f : 0.0f;
+    const int rslot = a.row_out ? a.row_out[rowc] : -1;
+    const float gfin = a.row_out ? a.grad_ys[goff] : 0.0f;
+    float adj = 0.0f, th_acc = 0.0f;
+    int nsel = 0;                                  // NN == 1: consecutive net chains alternate their LDS buffer
+
+    auto drift_gemm = [&](int g, const float* in, f32x4& c, f32x4& d) {
+        if (g == 0) gemm4<KUH>(w0, in, c, d);
+        else if (g == 1) gemm4<KUH>(w1, in, c, d);
+        else if (g == 2) gemm4<KUH>(w2, in, c, d);
+        else if (g == 3) gemm4<KUH>(w3, in, c, d);
+        else gemm4<KUH>(w4, in, c, d);
+    };
+
+    struct StepIn {
+        float y, ik, ik0, z[3], q[4], nh[4], dm[3][NHID + 1];
+        float h, rdt; int nout, kfirst;
+    };
+    auto fetch = [&](int n, StepIn& p) {
+        const size_t so = (size_t)n * BH + goff;
+        p.y = a.traj[so]; p.ik = a.dW[so]; p.ik0 = a.dU[so];
+#pragma unroll
+        for (int st = 0; st < 3; ++st) {
+            const float* ap = a.act + ((size_t)(3 * n + st) * NSLOT) * BH + goff;
+            p.z[st] = ap[(size_t)ZSLOT * BH];
+            p.q[st] = ap[(size_t)(ZSLOT + NN) * BH];
+            if constexpr (NN == 2) p.nh[st] = ap[(size_t)(ZSLOT + 1) * BH];
+#pragma unroll
+            for (int g = 0; g < NHID + 1; ++g) p.dm[st][g] = ap[(size_t)(NHID - g) * BH];     // relu mask behind transposed GEMM g
+            if (st == 2) {
+                p.q[3] = ap[(size_t)(ZSLOT + 2 * NN) * BH];
+                if constexpr (NN == 2) p.nh[3] = ap[(size_t)(ZSLOT + NN + 1) * BH];
+            }
+        }
+        const float* stp = a.step_tab + (size_t)n * SNSDE_STEP_STRIDE;
+        p.h = stp[1]; p.rdt = stp[6]; p.nout = __float_as_int(stp[8]); p.kfirst = __float_as_int(stp[9]);
+    };
+
+    // Two independent chains under common barriers.  Drift: input cotangent dz at the pre-tanh output of pass p (delta slot
+    // 0), relu masks dm[]; returns first_y^T(..) for the own element.  Net: input cotangent qb at the net's output
+    // pre-activation of an evaluation whose deltas go to pass pn, slots ns0 / ns0 + 1; hidden mask nm; returns ny0_y^T(..).
+    auto chains = [&](bool do_d, int p, float dz, const float* dm, bool do_n, int pn, int ns0, float qb, float nm,
+                      float& d_res, float& n_res) {
+        float* nbA = (NN == 1 && nsel) ? nb1 : nb0;
+        float* nbB = nb1;
+        if (do_d) {
+            lds[lrow] = dz;
+            if (a.delta && row_ok) a.delta[((size_t)p * NSLOT) * BH + goff] = dz;
+        }
+        if (do_n) {
+            nbA[lrow] = qb;
+            if (a.delta && row_ok) a.delta[((size_t)pn * NSLOT + ns0) * BH + goff] = qb;
+            if constexpr (NN == 1) nsel ^= 1;
+        }
+        __syncthreads();
+        constexpr int PMAX = ND > NN ? ND : NN;
+#pragma unroll
+        for (int k = 0; k < PMAX; ++k) {
+            bool more = false;
+            if (do_d && k < ND) {
+                f32x4 c = {0.f, 0.f, 0.f, 0.f}, d = c;
+                drift_gemm(k, lds + k * M * LDA + brow, c, d);
+                const float o = m4_reduce_scatter(c + d);
+                if (k < ND - 1) {
+                    const float dv = dm[k] > 0.0f ? o : 0.0f;
+                    lds[(k + 1) * M * LDA + lrow] = dv;
+                    if (a.delta && row_ok) a.delta[((size_t)p * NSLOT + k + 1) * BH + goff] = dv;
+                    more = true;
+                } else {
+                    d_res = o;
+                }
+            }
+            if (do_n && k < NN) {
+                f32x4 c = {0.f, 0.f, 0.f, 0.f}, d = c;
+                if (k == 0) gemm4<KUH>(wnA, nbA + brow, c, d);
+                else gemm4<KUH>(wnB, nbB + brow, c, d);
+                const float o = m4_reduce_scatter(c + d);
+                if (k < NN - 1) {
+                    const float dv = nm > 0.0f ? o : 0.0f;
+                    nbB[lrow] = dv;
+                    if (a.delta && row_ok) a.delta[((size_t)pn * NSLOT + ns0 + 1) * BH + goff] = dv;
+                    more = true;
+                } else {
+                    n_res = o;
+                }
+            }
+            if (more) __syncthreads();
+        }
+    };
+
+    StepIn cur, nxt;
+    fetch(a.N - 1, cur);
+    for (int n = a.N - 1; n >= 0; --n) {
+        nxt = cur;
+        if (n > 0) fetch(n - 1, nxt);
+        const float h = cur.h, rdt = cur.rdt;
+        float carry = 0.0f;
+        for (int k = cur.kfirst; k < cur.kfirst + cur.nout; ++k) {
+            const float w0o = a.out_w[2 * k], w1o = a.out_w[2 * k + 1];
+            const float gk = a.row_out ? (rslot == k + 1 ? gfin : 0.0f) : a.grad_ys[(size_t)(k + 1) * BH + goff];
+            if (w0o == 0.0f) adj += gk;
+            else { adj = fmaf(w1o, gk, adj); carry = fmaf(w0o, gk, carry); }
+        }
+        if (row_ok) a.adj[(size_t)(n + 1) * BH + goff] = adj;
+
+        // ---- recompute the stage values of the step (own element) ----
+        const float y = cur.y, ik = cur.ik, ik0 = cur.ik0;
+        auto gate = [&](float hv) { return geo ? fast_tanh(hv) : 1.0f; };
+        // g = tanh(sigmoid(theta) nan_to_num(raw)), raw = q or q * (input state); keeps (1 - g^2), clipped raw, finiteness
+        auto gfun = [&](float q, float yy, float& om, float& rc, bool& fin) {
+            const float raw = mul_y ? q * yy : q;
+            fin = snsde_finite(raw);
+            rc = snsde_nan_to_num(raw);
+            const float g = fast_tanh(sig_theta * rc);
+            om = 1.0f - g * g;
+            return g;
+        };
+        float om0, om1, om2, om3, rc0, rc1, rc2, rc3;
+        bool fi0, fi1, fi2, fi3;
+        const float f0 = fast_tanh(cur.z[0] * gate(y));
+        const float g0 = gfun(cur.q[0], y, om0, rc0, fi0);
+        const float h01 = y + f0 * h;
+        const float h11 = y + 0.25f * f0 * h + 0.5f * g0 * rdt;
+        const float f1 = fast_tanh(cur.z[1] * gate(h01));
+        const float g1 = gfun(cur.q[1], h11, om1, rc1, fi1);
+        const float h02 = y + 0.25f * f0 * h + 0.25f * f1 * h + g0 * ik0 / h + 0.5f * g1 * ik0 / h;
+        const float f2 = fast_tanh(cur.z[2] * gate(h02));
+        const float h12 = y + f0 * h - g0 * rdt;
+        const float g2 = gfun(cur.q[2], h12, om2, rc2, fi2);
+        const float h13 = y + 0.25f * f2 * h + (-5.0f * g0 + 3.0f * g1 + 0.5f * g2) * rdt;
+        const float g3 = gfun(cur.q[3], h13, om3, rc3, fi3);
+        (void)g3;
+
+        const float av = adj;
+        const float ikk = 0.5f * (ik * ik - h);
+        const float ikkk = (ik * ik * ik - 3.0f * h * ik) / 6.0f;
+        const float a1 = ik, a2 = ikk / rdt, a3 = ik0 / h, a4 = ikkk / h;
+        const float wg0 = -a1 - a2 + 2.0f * a3 - 2.0f * a4;
+        const float wg1 = (4.0f / 3.0f) * a1 + (4.0f / 3.0f) * a2 - (4.0f / 3.0f) * a3 + (5.0f / 3.0f) * a4;
+        const float wg2 = (2.0f / 3.0f) * a1 - (1.0f / 3.0f) * a2 - (2.0f / 3.0f) * a3 - (2.0f / 3.0f) * a4;
+        float yb = carry + av;
+        float fb0 = av * (h / 6.0f), fb1 = fb0, fb2 = av * (2.0f * h / 3.0f);
+        float gb0 = wg0 * av, gb1 = wg1 * av, gb2 = wg2 * av;
+        const float gb3 = a4 * av;
+
+        // cotangent of a diffusion evaluation -> input of its net chain (+ the direct term of raw = q * y); theta's share
+        auto net_in = [&](float gb, float om, float rc, bool fin, float q, float hin, float& direct) {
+            const float rb = fin ? gb * om * sig_theta : 0.0f;
+            th_acc = fmaf(gb * om * rowf, rc, th_acc);
+            direct = mul_y ? rb * q : 0.0f;
+            float qb = mul_y ? rb * hin : rb;
+            if constexpr (NN == 2) qb = q > 0.0f ? qb : 0.0f;
+            return qb;
+        };
+        // cotangent of a drift evaluation F = tanh(z * gate(hin)) -> input of its chain (+ the gate's direct term)
+        auto drift_in = [&](float fb, float F, float z, float hin, float& direct) {
+            const float ty = gate(hin);
+            const float dzt = fb * (1.0f - F * F);
+            direct = geo ? dzt * z * (1.0f - ty * ty) : 0.0f;
+            return dzt * ty;
+        };
+        float dd, nd, dres = 0.0f, nres = 0.0f;
+
+        // ---- G3 = g(t0 + h/4, H1_3): the tail evaluation (second set of net slots of pass 3n + 2) ----
+        float qb = net_in(gb3, om3, rc3, fi3, cur.q[3], h13, nd);
+        chains(false, 0, 0.0f, cur.dm[2], true, 3 * n + 2, NB0 + NN, qb, cur.nh[3], dres, nres);
+        float hb = nres + nd;
+        yb += hb; fb2 = fmaf(0.25f * h, hb, fb2);
+        gb0 = fmaf(-5.0f * rdt, hb, gb0); gb1 = fmaf(3.0f * rdt, hb, gb1); gb2 = fmaf(0.5f * rdt, hb, gb2);
+        // ---- G2 = g(t0 + h, H1_2) beside the drift at (t0 + h/2, H0_2) ----
+        qb = net_in(gb2, om2, rc2, fi2, cur.q[2], h12, nd);
+        float dz = drift_in(fb2, f2, cur.z[2], h02, dd);
+        chains(true, 3 * n + 2, dz, cur.dm[2], true, 3 * n + 2, NB0, qb, cur.nh[2], dres, nres);
+        hb = nres + nd;
+        float d = dres + dd;
+        yb += hb; fb0 = fmaf(h, hb, fb0); gb0 = fmaf(-rdt, hb, gb0);
+        yb += d;
+        fb0 = fmaf(0.25f * h, d, fb0); fb1 = fmaf(0.25f * h, d, fb1);
+        gb0 = fmaf(ik0 / h, d, gb0); gb1 = fmaf(0.5f * ik0 / h, d, gb1);
+        // ---- G1 = g(t0 + h/4, H1_1) beside the drift at (t0 + h, H0_1) ----
+        qb = net_in(gb1, om1, rc1, fi1, cur.q[1], h11, nd);
+        dz = drift_in(fb1, f1, cur.z[1], h01, dd);
+        chains(true, 3 * n + 1, dz, cur.dm[1], true, 3 * n + 1, NB0, qb, cur.nh[1], dres, nres);
+        hb = nres + nd;
+        d = dres + dd;
+        yb += hb; fb0 = fmaf(0.25f * h, hb, fb0); gb0 = fmaf(0.5f * rdt, hb, gb0);
+        yb += d; fb0 = fmaf(h, d, fb0);
+        // ---- G0 and F0, both at (t0, y) ----
+        qb = net_in(gb0, om0, rc0, fi0, cur.q[0], y, nd);
+        dz = drift_in(fb0, f0, cur.z[0], y, dd);
+        chains(true, 3 * n, dz, cur.dm[0], true, 3 * n, NB0, qb, cur.nh[0], dres, nres);
+        adj = yb + (nres + nd) + (dres + dd);
+        cur = nxt;
+    }
+    if (row_ok) a.adj[goff] = adj + (a.row_out ? (rslot == 0 ? gfin : 0.0f) : a.grad_ys[goff]);
+    if (a.dth_part) {
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) th_acc += __shfl_down(th_acc, off, 64);
+        if (lane == 0) a.dth_part[blockIdx.x * CF::NW + wave] = th_acc;
+    }
+}
+
+template <class CF>
+int launch_m4n_rev(const RevArgs& a, hipStream_t stream) {
+    if constexpr (!CF::FITS) return SNSDE_ERR_UNSUPPORTED;
+    else {
+        const size_t lds_bytes = (size_t)CF::LDS_FLOATS * sizeof(float);
+        static bool attr_set = false;
+        if (lds_bytes > 64 * 1024 && !attr_set) {
+            if (hipFuncSetAttribute(reinterpret_cast<const void*>(snsde_m4n_srk_reverse_kernel<CF>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes) != hipSuccess)
+                return SNSDE_ERR_LDS;
+            attr_set = true;
+        }
+        hipLaunchKernelGGL(snsde_m4n_srk_reverse_kernel<CF>, dim3((a.B + 3) / 4), dim3(CF::NT), lds_bytes, stream, a);
+        return hipGetLastError() == hipSuccess ? SNSDE_OK : SNSDE_ERR_LAUNCH;
+    }
+}
+
+inline bool m4n_rev_instantiated(int H, int NHID, int NN) {
+    if (!(H == 16 || H == 32 || H == 64 || H == 128) || NHID < 0 || NHID > 3 || NN < 1 || NN > 2) return false;
+    return m4nr_nlds(H, NHID, NN) >= 0;
+}
+
+template <int H>
+int dispatch_m4n_rev(const RevPlan& p, const RevArgs& a, hipStream_t st) {
+#define SNSDE_NR(NHID_, NN_) if (p.NHID == NHID_ && p.NN == NN_) return launch_m4n_rev<CfgNR<H, NHID_, NN_>>(a, st);
+    SNSDE_NR(0, 1) SNSDE_NR(0, 2) SNSDE_NR(1, 1) SNSDE_NR(1, 2) SNSDE_NR(2, 1) SNSDE_NR(2, 2) SNSDE_NR(3, 1) SNSDE_NR(3, 2)
+#undef SNSDE_NR
+    return SNSDE_ERR_UNSUPPORTED;
+}
+
+int dispatch_m4n_rev_h16(const RevPlan& p, const RevArgs& a, hipStream_t st);
+int dispatch_m4n_rev_h32(const RevPlan& p, const RevArgs& a, hipStream_t st);
+int dispatch_m4n_rev_h64(const RevPlan& p, const RevArgs& a, hipStream_t st);
+int dispatch_m4n_rev_h128(const RevPlan& p, const RevArgs& a, hipStream_t st);
+
+}  // namespace snsde_mfma

@@ -24,8 +24,10 @@
 //        (a function of lane & 15 only) is read by lanes 0-15 and broadcast by the MFMA (blgp:4).
 //        Fills all 256 CUs at batch 1024.
 
+#include <stddef.h>
+
 #include "snsde_m4_kernel.h"
-#include "snsde_m4n_kernel.h"
+#include "snsde_m4n_rev_kernel.h"
 
 using namespace snsde_mfma;
 
@@ -37,8 +39,7 @@ namespace {
 __device__ __forceinline__ int packed_index(int flavor, int KU, int feat, int k);
 
 __device__ __forceinline__ void pack_layer(const float* __restrict__ params, float* __restrict__ ws, const MfmaPackJob& job,
-                                           int layer, int bx, int nbx, bool direct) {
-    const MfmaLayerPack L = job.layer[layer];
+                                           const MfmaLayerPack& L, int bx, int nbx, bool direct) {
     const int per_wave = job.TPW * L.KU * 256;
     const int total = job.NW * per_wave;
     const bool skip = direct && L.fold && !L.transpose;
@@ -87,8 +88,14 @@ __device__ __forceinline__ void pack_layer(const float* __restrict__ params, flo
     }
 }
 
+// kernarg offsets of the by-value job structs (their `layer` arrays are indexed by blockIdx.y: snsde_kernarg_element)
+constexpr size_t PACK_JOB_OFF = 16;      // snsde_mfma_pack_kernel(params, ws, job)
+constexpr size_t PREP_JOB_OFF = (16 + sizeof(FoldJob) + alignof(MfmaPackJob) - 1) / alignof(MfmaPackJob) * alignof(MfmaPackJob);
+static_assert(alignof(FoldJob) == 8 && alignof(MfmaPackJob) == 4, "kernarg layout of snsde_prepare_kernel");
+
 __global__ void snsde_mfma_pack_kernel(const float* __restrict__ params, float* __restrict__ ws, MfmaPackJob job) {
-    pack_layer(params, ws, job, blockIdx.y, blockIdx.x, gridDim.x, false);
+    const MfmaLayerPack L = snsde_kernarg_element<MfmaLayerPack>(PACK_JOB_OFF + offsetof(MfmaPackJob, layer), blockIdx.y);
+    pack_layer(params, ws, job, L, blockIdx.x, gridDim.x, false);
 }
 
 // position of weight (feature, k) inside a layer's packed fragment block (inverse of the pack loop's index map)
@@ -102,7 +109,7 @@ __device__ __forceinline__ int packed_index(int flavor, int KU, int feat, int k)
 // output row f, lanes over the K columns, coalesced reads of W rows), blockIdx.y == 2 = the time-only diffusion
 // table (one block per solver step).
 __device__ __forceinline__ void fold_block(const float* __restrict__ params, float* __restrict__ ws, const FoldJob& job,
-                                           const MfmaPackJob* pk, float* erow) {
+                                           const MfmaPackJob* pk, const MfmaLayerPack* pkL, float* erow) {      // pkL = &pk->layer[blockIdx.y]
     const int pc = blockIdx.y, H = job.H;
     if (pc == 2) {
         const int n = blockIdx.x;
@@ -145,7 +152,7 @@ __device__ __forceinline__ void fold_block(const float* __restrict__ params, flo
         const float val = (a0 + a1) + (a2 + a3);
         ws[job.tmp[pc] + f * K + k] = val;
         if (pk) {     // forward prepare: straight into the packed MFMA fragment layout (source column k -> packed column kp)
-            const MfmaLayerPack& L = pk->layer[pc];
+            const MfmaLayerPack& L = *pkL;
             if (L.t_on && k < L.tshift) {
                 ws[L.t_dst + packed_index(pk->flavor, L.t_KU, f, L.t_col0 + k)] = val;    // time column -> the xt block
             } else {
@@ -172,16 +179,23 @@ __device__ __forceinline__ void fold_block(const float* __restrict__ params, flo
 
 __global__ void snsde_fold_kernel(const float* __restrict__ params, float* __restrict__ ws, FoldJob job) {
     extern __shared__ float erow[];
-    fold_block(params, ws, job, nullptr, erow);
+    fold_block(params, ws, job, nullptr, nullptr, erow);
 }
 
 // Forward prepare in ONE launch: blockIdx.y 0/1 = folded products (written to the temp the backward reads AND to their
 // packed fragments), 2 = time-only diffusion table, 3 + l = packing of layer l (16 blocks each).
 __global__ void snsde_prepare_kernel(const float* __restrict__ params, float* __restrict__ ws, FoldJob fj, MfmaPackJob job) {
     extern __shared__ float erow[];
-    if (blockIdx.y < 3) { fold_block(params, ws, fj, fj.fold_on ? &job : nullptr, erow); return; }
+    if (blockIdx.y < 3) {
+        const MfmaLayerPack L = snsde_kernarg_element<MfmaLayerPack>(PREP_JOB_OFF + offsetof(MfmaPackJob, layer), blockIdx.y < 2 ? blockIdx.y : 0);
+        fold_block(params, ws, fj, fj.fold_on ? &job : nullptr, &L, erow);
+        return;
+    }
     if ((int)blockIdx.y == 3 + job.n_layers) { snsde_z0_rows(fj.z0, blockIdx.x, gridDim.x); return; }   // y0 = W0 X(ts[0]) + b0
-    if (blockIdx.x < 16) pack_layer(params, ws, job, blockIdx.y - 3, blockIdx.x, 16, fj.fold_on != 0);
+    if (blockIdx.x < 16) {
+        const MfmaLayerPack L = snsde_kernarg_element<MfmaLayerPack>(PREP_JOB_OFF + offsetof(MfmaPackJob, layer), blockIdx.y - 3);
+        pack_layer(params, ws, job, L, blockIdx.x, 16, fj.fold_on != 0);
+    }
 }
 
 // SRK variant: one step-table row per drift pass (stage times t0, t0 + h, t0 + h/2 = slots 0, 3, 2 of the stage table);
@@ -362,7 +376,10 @@ RevPlan make_rev_plan(const snsde_solve* s, const SnsdeNet& net, const MfmaPlan&
     RevPlan p{};
     p.ok = false;
     if (!fp.ok || (s->method != SNSDE_EULER && s->method != SNSDE_MILSTEIN && s->method != SNSDE_SRK)) return p;
-    if (fp.NN != 0 && s->method != SNSDE_EULER) return p;
+    // diffusion nets: Euler on the general adjoint kernel, SRK on snsde_m4n_rev_kernel.h (Milstein: the generic adjoint)
+    const bool m4n_rev = fp.M4N && s->method == SNSDE_SRK && m4n_rev_instantiated(fp.H, fp.NHID, fp.NN);
+    if (fp.NN != 0 && s->method != SNSDE_EULER && !m4n_rev) return p;
+    p.M4N = m4n_rev ? 1 : 0;
     // tutorial-style fields: the register-resident lean forward (its training-mode instantiations), Euler / Milstein
     if (variant_of(s) && !(fp.LEAN && fp.FL == 1 && fp.H <= 128 && !fp.SRK && s->method != SNSDE_SRK &&
                            (s->model.activation == SNSDE_ACT_RELU || lean_act_save_fits(fp.H, fp.NHID, fp.KUXT)) &&
@@ -602,6 +619,14 @@ int snsde_mfma_backward_launch(const snsde_backward* b, const SnsdeNet& net, hip
     a.dth_part = p.dth_off ? ws + p.dth_off : nullptr;
     a.B = s->batch; a.N = s->n_steps; a.T = s->n_out; a.no = s->model.noise_option; a.off_theta = net.off_theta; a.method = s->method;
     for (int i = 0; i < p.n_layers; ++i) a.w_off[i] = p.layer[i].dst;
+    if (p.M4N) {
+        a.geo = p.GEO;
+        if (p.H == 128) return dispatch_m4n_rev_h128(p, a, stream);
+        if (p.H == 64) return dispatch_m4n_rev_h64(p, a, stream);
+        if (p.H == 32) return dispatch_m4n_rev_h32(p, a, stream);
+        if (p.H == 16) return dispatch_m4n_rev_h16(p, a, stream);
+        return SNSDE_ERR_UNSUPPORTED;
+    }
     if (p.H == 256) return dispatch_rev_h256(p, a, stream);
     if (p.H == 128) return dispatch_rev_h128(p, a, stream);
     if (p.H == 64) return dispatch_rev_h64(p, a, stream);

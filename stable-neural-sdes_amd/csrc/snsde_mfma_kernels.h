@@ -990,6 +990,7 @@ struct RevArgs {
     int32_t w_off[MAXL];
     int32_t nsave;                     // activation slots per step in `act` (snsde_act_slots)
     int32_t act_fn, f_out, g_out;      // field variants (SNSDE_ACT_*, SNSDE_DRIFT_*, SNSDE_DIFFUSION_*): 4-row tiles only
+    int32_t geo;                       // snsde_m4n_rev_kernel.h: the drift is gated by tanh(y) (input_option 5 / 6)
 };
 
 // d/dx [scale * x * sigmoid(x)]  (LipSwish: scale = 0.909, SiLU: 1)
@@ -1605,6 +1606,7 @@ struct MfmaPlan {
 struct RevPlan {
     bool ok;
     int H, NHID, GEO, FL, NW, NN, SRK, IO0, n_layers, fold_tmp, total_floats, emb;
+    int M4N;                    // SRK through a diffusion net: snsde_m4n_rev_kernel.h
     int nwg;                    // workgroups of the adjoint launch
     size_t ds_off, dth_off;     // diffusion-side partial sums inside the backward workspace (0 = none)
     MfmaLayerPack layer[MAXL];

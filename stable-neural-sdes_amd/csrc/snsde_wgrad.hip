@@ -16,6 +16,10 @@
 //         d emb.weight = [S_y W_in^T + s0 b_in^T | S_x W_init^T + s0 b_init^T],  d linear_in.weight = E_y^T S_y, ...
 //      so no (N, B, .) intermediate of the un-folded first layer is ever materialised; the time-only noise MLP is
 //      back-propagated over its N inputs the same way.
+#include <stddef.h>
+#include <stdio.h>
+#include <stdlib.h>
+
 #include "snsde_internal.h"
 
 namespace {
@@ -46,18 +50,24 @@ struct WTile {
     int32_t cls;      // 2 * log2(8 / sub-tiles) + (no bias): selects the kernel body
     int32_t csplit;   // destination column remap: tile columns >= csplit land cshift further right (the aux tile's
     int32_t cshift;   // [sin t, cos t | X(t)] columns straddle the y block of the first layer's dense sums)
+    // which (pass, row) pairs the tile reduces over: reduction row r -> pass (r / B) * pstride + poff, batch row r % B,
+    // r < rows.  Default: every pass.  SRK through a diffusion net: the step's fourth evaluation lives at passes 3n + 2 only.
+    int32_t pstride, poff, rows;
+    int32_t xplane;   // x_kind 1: plane of the (passes + 1, NP, B, H) state buffer (SRK + net: 0 drift input, 1 / 2 net inputs)
 };
 
 struct WArgs {
     const float* delta; const float* act; const float* traj; const float* xaux;
     float* part;       // [tile][split][TILE_FLOATS]
     float* sums;       // dense job matrices
-    int32_t B, H, N, NG, NSAVE, ldx, R, ntiles;
+    int32_t B, H, N, NG, NSAVE, ldx, R, ntiles, NP;
     WTile tile[MAX_TILES];
 };
 
 // control-path columns of the first layer's input, one row per (step, batch row): [sin t, cos t][X_c(t_n)], zero padded
-struct XArgs { const float* coeffs; const float* step_tab; float* xaux; int32_t B, C, Lm1, t_col0, t_cols, x_col0, x_cols, ldx, R, raw_time; };
+struct XArgs { const float* coeffs; const float* step_tab; float* xaux; int32_t B, C, Lm1, t_col0, t_cols, x_col0, x_cols, ldx, R, raw_time;
+               int32_t n_col0; };   // SRK + diffusion net: columns n_col0 + {0, 1} = sin / cos of the pass's own diffusion stage time,
+                                    // n_col0 + {4, 5} = those of the step's fourth evaluation (rows of passes 3n + 2), else -1
 
 __global__ void __launch_bounds__(256) snsde_xaux_kernel(XArgs a) {
     const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
@@ -66,6 +76,11 @@ __global__ void __launch_bounds__(256) snsde_xaux_kernel(XArgs a) {
     const int n = r / a.B, b = r - n * a.B;
     const float* st = a.step_tab + (size_t)n * SNSDE_STEP_STRIDE;
     float val = 0.0f;
+    if (a.n_col0 >= 0 && j >= a.n_col0) {
+        const int jj = j - a.n_col0;
+        if (jj < 2) val = st[10 + jj];
+        else if ((jj == 4 || jj == 5) && n % 3 == 2) val = (st - SNSDE_STEP_STRIDE)[10 + jj - 4];     // t0 + h/4: pass 3n + 1's
+    } else
     if (j >= a.t_col0 && j < a.t_col0 + a.t_cols) val = a.raw_time ? (j == a.t_col0 ? st[0] : 0.0f) : st[2 + j - a.t_col0];   // [t, 0] | [sin t, cos t]
     else if (j >= a.x_col0 && j < a.x_col0 + a.x_cols) {
         const int c = j - a.x_col0;
@@ -81,7 +96,7 @@ __device__ __forceinline__ void wgrad_body(const WArgs& a, const WTile& t, float
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int split = blockIdx.x;
     const int r_begin = split * t.rows_per_split;
-    const int r_end = min(a.R, r_begin + t.rows_per_split);
+    const int r_end = min(t.rows, r_begin + t.rows_per_split);
     const int B = a.B, H = a.H;
 
     // staging assignment: rows (tid >> 5) and (tid >> 5) + 16 of the chunk, float4 column 4 * (tid & 31), for D and X
@@ -95,15 +110,16 @@ __device__ __forceinline__ void wgrad_body(const WArgs& a, const WTile& t, float
             const int r = r0 + (tid >> 5) + 16 * p;
             float4 dv = make_float4(0.f, 0.f, 0.f, 0.f), xv = dv;
             if (r < r_end) {
-                const int n = r / B, b = r - n * B;
+                const int n0 = r / B, b = r - n0 * B;
+                const int n = n0 * t.pstride + t.poff;
                 if (dcol) dv = *reinterpret_cast<const float4*>(a.delta + (((size_t)n * a.NG + t.d_slot) * B + b) * H + t.h0 + c4);
                 if (xcol) {
                     if (t.x_kind == 0)
                         xv = *reinterpret_cast<const float4*>(a.act + (((size_t)n * a.NSAVE + t.x_slot) * B + b) * H + t.k0 + c4);
                     else if (t.x_kind == 1)
-                        xv = *reinterpret_cast<const float4*>(a.traj + ((size_t)n * B + b) * H + t.k0 + c4);
+                        xv = *reinterpret_cast<const float4*>(a.traj + (((size_t)n * a.NP + t.xplane) * B + b) * H + t.k0 + c4);
                     else
-                        xv = *reinterpret_cast<const float4*>(a.xaux + (size_t)r * a.ldx + t.k0 + c4);
+                        xv = *reinterpret_cast<const float4*>(a.xaux + ((size_t)n * B + b) * a.ldx + t.k0 + c4);
                 }
             }
             dreg[p] = dv; xreg[p] = xv;
@@ -174,7 +190,7 @@ __device__ __forceinline__ void wgrad_body(const WArgs& a, const WTile& t, float
 
 __global__ void __launch_bounds__(NT, 4) snsde_wgrad_kernel(WArgs a) {
     extern __shared__ __attribute__((aligned(16))) float lds[];   // [2 buffers][D | X][RC][LD]
-    const WTile t = a.tile[blockIdx.y];
+    const WTile t = snsde_kernarg_element<WTile>(offsetof(WArgs, tile), blockIdx.y);     // (not a.tile[blockIdx.y]: see the helper)
     if ((int)blockIdx.x >= t.nsplit) return;
     switch (t.cls) {     // uniform per workgroup
         case 0: wgrad_body<8, true>(a, t, lds); break;
@@ -190,7 +206,7 @@ __global__ void __launch_bounds__(NT, 4) snsde_wgrad_kernel(WArgs a) {
 
 // sums[job matrix] = sum over splits of the partial tiles (fixed order: deterministic)
 __global__ void __launch_bounds__(256) snsde_wgrad_reduce_kernel(WArgs a) {
-    const WTile t = a.tile[blockIdx.y];
+    const WTile t = snsde_kernarg_element<WTile>(offsetof(WArgs, tile), blockIdx.y);     // (not a.tile[blockIdx.y]: see the helper)
     const int e = blockIdx.x * 256 + threadIdx.x;
     if (e >= TILE_FLOATS) return;
     if (e < TILE * TILE ? (e % TILE >= t.ncols) : (t.bias < 0)) return;    // never written by the GEMM kernel
@@ -297,6 +313,7 @@ struct AArgs {
     int32_t H, C, N, io, no, nhid, P, has_dth;
     int32_t o_out, b_out, o_hid[SNSDE_MAX_HIDDEN], b_hid[SNSDE_MAX_HIDDEN], o_first, ld_first, b_first;   // offsets in sums
     int32_t o_ny0, b_ny0, o_ny1, b_ny1, nn;   // diffusion net on [tau, y] (noise_option 14/15/18/19), dense sums in the parameters' own layout
+    int32_t o_ny0b, b_ny0b, o_ny1b, b_ny1b, tail;   // SRK: the sums over the step's fourth evaluation (added to the above)
     int32_t n_jobs;
     GJob job[MAX_GJOBS];
 };
@@ -355,10 +372,10 @@ __global__ void __launch_bounds__(256) snsde_assemble_kernel(AArgs a) {
             const float sg = snsde_sigmoid(a.params[net.off_theta]);
             val = a.dth[0] * sg * (1.0f - sg);
         }
-    } else if (a.nn >= 1 && inside(net.ny0.src_w, H * (H + 2), rel)) val = a.sums[a.o_ny0 + rel];
-    else if (a.nn >= 1 && inside(net.ny0.src_b, H, rel)) val = a.sums[a.b_ny0 + rel];
-    else if (a.nn == 2 && inside(net.ny1.src_w, H * H, rel)) val = a.sums[a.o_ny1 + rel];
-    else if (a.nn == 2 && inside(net.ny1.src_b, H, rel)) val = a.sums[a.b_ny1 + rel];
+    } else if (a.nn >= 1 && inside(net.ny0.src_w, H * (H + 2), rel)) val = a.sums[a.o_ny0 + rel] + (a.tail ? a.sums[a.o_ny0b + rel] : 0.0f);
+    else if (a.nn >= 1 && inside(net.ny0.src_b, H, rel)) val = a.sums[a.b_ny0 + rel] + (a.tail ? a.sums[a.b_ny0b + rel] : 0.0f);
+    else if (a.nn == 2 && inside(net.ny1.src_w, H * H, rel)) val = a.sums[a.o_ny1 + rel] + (a.tail ? a.sums[a.o_ny1b + rel] : 0.0f);
+    else if (a.nn == 2 && inside(net.ny1.src_b, H, rel)) val = a.sums[a.b_ny1 + rel] + (a.tail ? a.sums[a.b_ny1b + rel] : 0.0f);
     else {
         for (int l = 0; l < a.nhid; ++l) {
             if (inside(net.hid[l].src_w, H * H, rel)) { val = a.sums[a.o_hid[l] + rel]; break; }
@@ -371,7 +388,7 @@ __global__ void __launch_bounds__(256) snsde_assemble_kernel(AArgs a) {
 // the small products of the epilogue (K, M, N of a few hundred): 32 x 32 output tiles, operands staged through LDS
 __global__ void __launch_bounds__(256) snsde_small_gemm_kernel(AArgs a) {
     __shared__ float As[32][33], Bs[32][33];
-    const GJob j = a.job[blockIdx.z];
+    const GJob j = snsde_kernarg_element<GJob>(offsetof(AArgs, job), blockIdx.z);
     const int m0 = blockIdx.y * 32, n0 = blockIdx.x * 32;
     if (m0 >= j.M || n0 >= j.N) return;
     const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;     // 32 x 8
@@ -424,7 +441,7 @@ struct WPlan {
     int ntiles, max_split, naux, ldx, n_pass, n_trow;
     size_t part_floats, sums_floats, ds_off, dth_off, dz1_off, dz2_off, a1_off, xaux_off, total_floats;
     bool tnoise, has_dth;
-    int nact, xt, t_col0, x_col0, x_cols;
+    int nact, xt, t_col0, x_col0, x_cols, n_col0, NP;
     AArgs aa;
     WTile tile[MAX_TILES];
 };
@@ -455,6 +472,7 @@ bool make_wplan(const snsde_backward* b, const SnsdeNet& net, WPlan* w) {
     int nt = 0;
     size_t off = 0;
     const int ht = (H + TILE - 1) / TILE;
+    int cur_pstride = 1, cur_poff = 0, cur_plane = 0;     // pass selection / state plane of the tiles being added
     auto add_tiles = [&](int d_slot, int x_kind, int x_slot, int ncols_total, int o_mat, int ldo, int o_bias, int csplit,
                          int cshift, int src0 = 0) {
         for (int hi = 0; hi < ht; ++hi)
@@ -466,6 +484,8 @@ bool make_wplan(const snsde_backward* b, const SnsdeNet& net, WPlan* w) {
                 t.ncols = ncols_total - k0 < TILE ? ncols_total - k0 : TILE;
                 t.out = o_mat; t.ldo = ldo; t.bias = (o_bias >= 0 && k0 == 0) ? o_bias : -1;
                 t.csplit = csplit; t.cshift = cshift;
+                t.pstride = cur_pstride; t.poff = cur_poff; t.xplane = cur_plane;
+                t.rows = (n_pass / cur_pstride) * s.batch;
             }
         return true;
     };
@@ -484,33 +504,53 @@ bool make_wplan(const snsde_backward* b, const SnsdeNet& net, WPlan* w) {
     if (ok && ts + (usex ? C : 0) > 0)
         ok = add_tiles(nhid + 1, 2, 0, ts + (usex ? C : 0), aa.o_first, aa.ld_first, io0 ? aa.b_first : -1, ts, io0 ? 0 : H, 0);
     aa.nn = nn;
+    // SRK through a diffusion net (snsde_m4n_rev_kernel.h): the net's inputs are the H1 states (plane 1 of the stage buffer)
+    // at the diffusion stage times (xaux columns n_col0 ..), and the step's fourth evaluation adds a second set of sums over
+    // the passes 3n + 2 (delta / activation slots + nn, state plane 2, time columns n_col0 + 4 ..)
+    const bool srknet = srk && nn > 0;
+    const int n_col0 = srknet ? ((naux + 3) & ~3) : -1;
+    aa.tail = srknet ? 1 : 0;
     if (ok && nn > 0) {     // diffusion net: first layer on [sin t, cos t | y] (delta slot nd + nn - 1), output layer on its hidden
         const int d0n = nd + nn - 1;
         aa.o_ny0 = alloc((size_t)H * (H + 2)); aa.b_ny0 = alloc(H);
+        cur_plane = srknet ? 1 : 0;
         ok = add_tiles(d0n, 1, 0, H, aa.o_ny0 + 2, H + 2, aa.b_ny0, 1 << 30, 0)
-             && add_tiles(d0n, 2, 0, 2, aa.o_ny0, H + 2, -1, 1 << 30, 0, t_col0);
+             && add_tiles(d0n, 2, 0, 2, aa.o_ny0, H + 2, -1, 1 << 30, 0, srknet ? n_col0 : t_col0);
         if (ok && nn == 2) {
             aa.o_ny1 = alloc((size_t)H * H); aa.b_ny1 = alloc(H);
             ok = add_tiles(nd, 0, nhid + 2, H, aa.o_ny1, H, aa.b_ny1, 1 << 30, 0);
         }
+        if (ok && srknet) {
+            cur_pstride = 3; cur_poff = 2; cur_plane = 2;
+            aa.o_ny0b = alloc((size_t)H * (H + 2)); aa.b_ny0b = alloc(H);
+            ok = add_tiles(d0n + nn, 1, 0, H, aa.o_ny0b + 2, H + 2, aa.b_ny0b, 1 << 30, 0)
+                 && add_tiles(d0n + nn, 2, 0, 2, aa.o_ny0b, H + 2, -1, 1 << 30, 0, n_col0 + 4);
+            if (ok && nn == 2) {
+                aa.o_ny1b = alloc((size_t)H * H); aa.b_ny1b = alloc(H);
+                ok = add_tiles(nd + nn, 0, nhid + 2 + nn, H, aa.o_ny1b, H, aa.b_ny1b, 1 << 30, 0);
+            }
+            cur_pstride = 1; cur_poff = 0;
+        }
+        cur_plane = 0;
     }
     if (!ok) return false;
     w->ntiles = nt;
     // R-splits per tile proportional to its work (MFMAs per slab + staging), ~2 workgroups per CU in total
-    const int chunks = (R + RC - 1) / RC;
-    int wsum = 0;
-    for (int i = 0; i < nt; ++i) wsum += nkt_class(w->tile[i].ncols) + 4;
+    long wsum = 0;
+    for (int i = 0; i < nt; ++i) wsum += (long)(nkt_class(w->tile[i].ncols) + 4) * (w->tile[i].rows / s.batch);
+    if (wsum < 1) wsum = 1;
     int nparts = 0;
     w->max_split = 1;
     for (int i = 0; i < nt; ++i) {
         WTile& t = w->tile[i];
         const int nk = nkt_class(t.ncols);
+        const int chunks = (t.rows + RC - 1) / RC;
         t.cls = (nk == 8 ? 0 : (nk == 4 ? 2 : (nk == 2 ? 4 : 6))) + (t.bias >= 0 ? 0 : 1);
-        int ns = (512 * (nk + 4) + wsum / 2) / wsum;
+        int ns = (int)((512L * (nk + 4) * (t.rows / s.batch) + wsum / 2) / wsum);
         if (ns < 1) ns = 1;
         if (ns > chunks) ns = chunks;
         t.rows_per_split = ((chunks + ns - 1) / ns) * RC;
-        t.nsplit = (R + t.rows_per_split - 1) / t.rows_per_split;
+        t.nsplit = (t.rows + t.rows_per_split - 1) / t.rows_per_split;
         t.part = nparts;
         nparts += t.nsplit;
         if (t.nsplit > w->max_split) w->max_split = t.nsplit;
@@ -525,16 +565,27 @@ bool make_wplan(const snsde_backward* b, const SnsdeNet& net, WPlan* w) {
     w->ds_off = o; o += w->tnoise ? NH : 0;
     w->has_dth = w->tnoise || nn > 0 || (no >= 7 && no <= 10);
     w->t_col0 = t_col0; w->x_col0 = x_col0; w->x_cols = usex ? C : 0;
-    w->nact = nhid + 2 + nn;
+    w->nact = nhid + 2 + nn + (srknet ? nn : 0);      // act_save / delta_save slots per pass (snsde_save_layout)
     w->xt = xt;
     w->dth_off = o; o += 4;
     w->dz1_off = o; o += two ? NH : 0;
     w->dz2_off = o; o += two ? NH : 0;
     w->a1_off = o; o += two ? NH : 0;
     o = (o + 3) & ~(size_t)3;
-    w->naux = naux; w->ldx = (naux + 3) & ~3;
+    w->n_col0 = n_col0; w->NP = srknet ? 3 : 1;
+    w->naux = srknet ? n_col0 + 8 : naux; w->ldx = (w->naux + 3) & ~3;
     w->xaux_off = o; o += (size_t)R * w->ldx;
     w->total_floats = o + 16;
+    if (getenv("SNSDE_DEBUG_WPLAN")) {
+        for (int i = 0; i < nt; ++i) {
+            const WTile& t = w->tile[i];
+            fprintf(stderr, "tile %d: d_slot %d h0 %d x_kind %d x_slot %d k0 %d kd %d ncols %d out %d ldo %d bias %d nsplit %d rps %d part %d cls %d "
+                    "pstride %d poff %d rows %d xplane %d\n", i, t.d_slot, t.h0, t.x_kind, t.x_slot, t.k0, t.kd, t.ncols, t.out, t.ldo, t.bias,
+                    t.nsplit, t.rows_per_split, t.part, t.cls, t.pstride, t.poff, t.rows, t.xplane);
+        }
+        fprintf(stderr, "nact %d ldx %d naux %d n_col0 %d NP %d sums %zu part %zu xaux_off %zu total %zu\n", w->nact, w->ldx, w->naux, w->n_col0,
+                w->NP, w->sums_floats, w->part_floats, w->xaux_off, w->total_floats);
+    }
     aa.net = net; aa.H = H; aa.C = C; aa.N = n_trow; aa.io = io; aa.no = no; aa.nhid = nhid; aa.has_dth = w->has_dth ? 1 : 0;
     return true;
 }
@@ -565,13 +616,14 @@ int snsde_wgrad_launch(const snsde_backward* b, const SnsdeNet& net, float* grad
     }
     const bool smooth = s.model.activation != SNSDE_ACT_RELU;      // act_save then also holds the NL pre-activations per step
     a.B = s.batch; a.H = H; a.N = wp->n_pass; a.NG = wp->nact; a.NSAVE = wp->nact + (smooth ? s.model.num_hidden_layers : 0);
-    a.ldx = wp->ldx; a.R = wp->n_pass * s.batch; a.ntiles = wp->ntiles;
+    a.ldx = wp->ldx; a.R = wp->n_pass * s.batch; a.ntiles = wp->ntiles; a.NP = wp->NP;
     for (int i = 0; i < wp->ntiles; ++i) a.tile[i] = wp->tile[i];
     if (wp->naux > 0) {
         XArgs x{};
         x.coeffs = s.coeffs; x.step_tab = pass_tab; x.xaux = ws + wp->xaux_off;
         x.B = s.batch; x.C = C; x.Lm1 = s.knots - 1; x.t_col0 = wp->t_col0; x.t_cols = wp->xt; x.x_col0 = wp->x_col0;
         x.x_cols = wp->x_cols; x.ldx = wp->ldx; x.R = a.R; x.raw_time = s.model.time_feature == SNSDE_TIME_RAW ? 1 : 0;
+        x.n_col0 = wp->n_col0;
         const size_t total = (size_t)a.R * wp->ldx;
         hipLaunchKernelGGL(snsde_xaux_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, x);
     }
