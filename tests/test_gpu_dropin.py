@@ -191,6 +191,11 @@ FD_CASES = [
     (6, 17, 2, 9, 128, 21, 7, 'euler', 'mfma16'),
     (3, 18, 2, 10, 64, 8, 7, 'euler', 'auto'),
     (4, 17, 2, 8, 256, 14, 6, 'milstein', 'auto'),
+    (4, 17, 2, 9, 64, 5, 7, 'srk', 'auto'),             # SRID2: MFMA SRK variant (elementwise diffusion)
+    (1, 18, 2, 9, 64, 4, 7, 'srk', 'auto'),             # SRID2 through a diffusion net (torch_ists' neuralsde_1_18 under its default srk)
+    (3, 18, 2, 7, 128, 4, 6, 'srk', 'mfma4'),           # README's neuralsde_3_18 at H = 128 (net matrices parked in LDS)
+    (3, 18, 2, 8, 64, 4, 6, 'milstein', 'auto'),        # Milstein through a diffusion net (dense dg/dy)
+    (5, 15, 1, 8, 32, 4, 6, 'milstein', 'auto'),
 ]
 
 
@@ -203,9 +208,12 @@ def test_fused_backward_vs_finite_differences_of_the_numpy_oracle(case):
     rng = np.random.default_rng(901)
     wsum = rng.standard_normal((L, B, H))
     spec = param_spec(io, no, NL, C, H)
+    dU = None
+    if method == 'srk':      # space-time Levy integrals on the scale of the increments (h = 1)
+        dU = (0.5 * dW + np.sqrt(1.0 / 12) * rng.standard_normal(dW.shape)).astype(np.float32)
 
     def oracle_loss(params, y0):
-        ys, _ = O.solve_diffusion_model(params, io, no, pr['coeffs'], ts, y0, ts, 1.0, dW, method=method, dtype=np.float64)
+        ys, _ = O.solve_diffusion_model(params, io, no, pr['coeffs'], ts, y0, ts, 1.0, dW, method=method, dtype=np.float64, dU=dU)
         return float((ys * wsum).sum())
 
     m = S.Diffusion_model(C, H, H, NL, input_option=io, noise_option=no)
@@ -213,7 +221,8 @@ def test_fused_backward_vs_finite_differences_of_the_numpy_oracle(case):
     m = m.to(DEV)
     m.set_X(torch.from_numpy(pr['coeffs']).to(DEV), torch.from_numpy(ts).to(DEV))
     y0 = torch.from_numpy(pr['y0']).to(DEV).requires_grad_(True)
-    ys = S.sdeint(m, y0, torch.from_numpy(ts).to(DEV), bm=_ReplayBM(torch.from_numpy(dW).to(DEV)), method=method, dt=1.0,
+    ys = S.sdeint(m, y0, torch.from_numpy(ts).to(DEV),
+                  bm=_ReplayBM(torch.from_numpy(dW).to(DEV), None if dU is None else torch.from_numpy(dU).to(DEV)), method=method, dt=1.0,
                   options={'kernel': kernel, 'strict': True})
     (ys * torch.from_numpy(wsum.astype(np.float32)).to(DEV)).sum().backward()
     grads = {n: p.grad.detach().cpu().numpy().astype(np.float64) for n, p in m.named_parameters() if p.grad is not None}

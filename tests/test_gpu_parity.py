@@ -178,16 +178,21 @@ def test_milstein_refused_where_dg_dy_is_not_finite():
     assert np.isfinite(ys).all()
 
 
+@pytest.mark.parametrize('kernel', ['auto', 'generic'])
 @pytest.mark.parametrize('cfg', [(3, 18, 2, 33, 64, 5, 12), (1, 14, 1, 17, 32, 3, 9), (4, 19, 2, 21, 128, 21, 10), (6, 15, 3, 9, 48, 40, 8),
-                                 (0, 18, 2, 12, 100, 6, 9)])
-def test_milstein_through_a_diffusion_net_vs_oracle(cfg):
+                                 (0, 18, 2, 12, 100, 6, 9), (5, 19, 2, 21, 64, 5, 9), (1, 19, 1, 9, 16, 3, 8), (2, 15, 2, 13, 128, 7, 9),
+                                 (6, 19, 4, 7, 32, 3, 8), (4, 14, 2, 11, 64, 69, 9)])
+def test_milstein_through_a_diffusion_net_vs_oracle(cfg, kernel):
     """Milstein with a dense dg/dy (noise_option 14/15/18/19): J_g^T (g (dW^2 - h)) per step, torchsde's VJP form, against the
     numpy restatement in float64 (oracle.diffusion_g_vjp) on replayed increments."""
     io, no, NL, B, H, C, L = cfg
     pr = make_problem(60 + no, io, no, NL, B, H, C, L)
     ts = [0, 2.5, L - 1]
     dW = draw_dW(7, ts, 0.5, B, H)
-    ys, _ = hip_solve(pr, ts, 0.5, dW=dW, method='milstein')
+    if kernel == 'auto' and H in (16, 32, 64) and io != 0:      # instantiated: the MFMA net kernel, not the generic family
+        N = S.engine.step_grid(np.asarray(ts, np.float32), 0.5, pr['times'], torch.device(DEV)).N
+        assert S.engine.forward_path(S.engine.model_struct(C, H, H, NL, io, no), B, L, N, method='milstein') == 'mfma4'
+    ys, _ = hip_solve(pr, ts, 0.5, dW=dW, method='milstein', kernel=kernel)
     ref64, _ = oracle_solve(pr, ts, 0.5, dW, 'milstein', np.float64)
     cpu32, _ = oracle_solve(pr, ts, 0.5, dW, 'milstein', np.float32)
     assert_parity(ys, ref64, cpu32, what=f'milstein io={io} no={no}')
@@ -693,6 +698,17 @@ SRK_BWD_CASES = [
     (6, 16, 1, 6, 256, 5, 7, [0, 6], 0.5),
     (4, 17, 2, 9, 64, 40, 8, [0, 3, 7], 1.0),        # wide control path (C > 32) under SRK
     (6, 13, 3, 7, 128, 69, 7, [0, 6], 1.0),
+    (1, 18, 2, 9, 16, 3, 8, [0, 7], 0.5),            # SRK through a diffusion net: snsde_m4n_srk_reverse_kernel + weight-gradient
+    (3, 15, 3, 8, 16, 4, 8, [0, 7], 1.0),            # jobs over the pass subsets / state planes of the four evaluations
+    (1, 14, 1, 17, 32, 3, 9, [0, 2.5, 8], 0.5),
+    (3, 18, 2, 33, 64, 5, 12, [0, 2.5, 11], 0.5),
+    (5, 19, 2, 21, 64, 5, 9, [0, 8], 1.0),
+    (4, 19, 2, 21, 128, 21, 10, [0, 9], 1.0),
+    (2, 14, 2, 13, 32, 7, 9, [0, 3.5, 8], 0.5),
+    (6, 15, 3, 9, 64, 40, 8, [0, 7], 1.0),
+    (1, 18, 2, 37, 128, 5, 9, [0, 8], 1.0),
+    (3, 18, 3, 11, 128, 5, 9, [0, 8], 0.5),
+    (4, 18, 1, 11, 128, 69, 9, [0, 8], 1.0),
 ]
 
 
@@ -700,7 +716,10 @@ SRK_BWD_CASES = [
 @pytest.mark.parametrize('ci', range(len(SRK_BWD_CASES)))
 def test_srk_backward_on_the_mfma_path(ci, kernel):
     io, no, NL, B, H, C, L, ts, dt = SRK_BWD_CASES[ci]
-    _check_backward(4000 + ci, io, no, NL, B, H, C, L, ts, dt, 'srk', kernel)
+    if ts is not None:      # the fused MFMA adjoint, not the generic family
+        grid = S.engine.step_grid(np.asarray(ts, np.float32), dt, np.arange(L, dtype=np.float32), torch.device(DEV))
+        assert S.engine.backward_mode(S.engine.model_struct(C, H, H, NL, io, no), B, L, grid, 'srk', kernel) == 1
+    _check_backward(4000 + ci, io, no, NL, B, H, C, L, ts, dt, 'srk', kernel, strict=True)
 
 
 @pytest.mark.parametrize('io', [0, 1, 2, 3, 4, 5, 6])
@@ -1087,7 +1106,19 @@ SRK_CASES = [
     (4, 17, 2, 9, 64, 40, 9, [0, 8], 1.0),
     (6, 16, 3, 7, 128, 69, 8, [0, 7], 1.0),
     (2, 12, 1, 9, 32, 33, 8, [0, 2.5, 7], 0.5),
+    (1, 18, 2, 9, 16, 3, 8, [0, 7], 0.5),            # diffusion nets on the MFMA net kernels (snsde_m4n_kernel.h): H = 16 .. 128,
+    (1, 14, 1, 17, 32, 3, 9, [0, 2.5, 8], 0.5),      # one- and two-layer nets, raw = net and net * y, every drift family
+    (3, 18, 2, 33, 64, 5, 12, [0, 2.5, 11], 0.5),
+    (5, 19, 2, 21, 64, 5, 9, [0, 8], 1.0),
+    (4, 19, 2, 21, 128, 21, 10, [0, 9], 1.0),
+    (2, 14, 2, 13, 32, 7, 9, [0, 3.5, 8], 0.5),
+    (6, 15, 3, 9, 64, 40, 8, [0, 7], 1.0),
+    (1, 18, 2, 37, 128, 5, 9, [0, 8], 1.0),          # H = 128: net matrices parked in the waves' LDS slices
+    (3, 18, 3, 11, 128, 5, 9, [0, 8], 0.5),
+    (4, 18, 1, 11, 128, 69, 9, [0, 8], 1.0),         # wide control path (C = 69) with a net
+    (6, 19, 4, 7, 32, 3, 8, [0, 7], 1.0),
 ]
+SRK_NET_ROWS = [i for i, c in enumerate(SRK_CASES) if c[1] in (14, 15, 18, 19) and c[4] in (16, 32, 64, 128)]
 
 
 def _draw_dU(seed, dW, ts, dt):
@@ -1115,6 +1146,23 @@ def test_srk_trajectory_vs_oracle(ci, kernel):
                                        np.asarray(ts, np.float32), dt, dW, method='srk', dtype=np.float32, dU=dU)
     assert_parity(ys, ref64, cpu32, what=f'srk case {ci}')
     assert_parity(call.traj.cpu().numpy(), traj64, what=f'srk traj {ci}')
+
+
+@pytest.mark.parametrize('ci', SRK_NET_ROWS)
+def test_srk_diffusion_nets_take_the_mfma_net_kernels(ci):
+    """The diffusion-net rows of SRK_CASES at instantiated hidden sizes run on the MFMA path (not the generic VALU family) under
+    kernel='auto', and the explicit 'mfma4' selector gives the same bits."""
+    io, no, NL, B, H, C, L, ts, dt = SRK_CASES[ci]
+    pr = make_problem(700 + ci, io, no, NL, B, H, C, L)
+    model = S.engine.model_struct(C, H, H, NL, io, no)
+    grid = S.engine.step_grid(np.asarray(ts, np.float32), dt, pr['times'], torch.device(DEV))
+    assert S.engine.forward_path(model, B, L, grid.N, method='srk') == 'mfma-srk'
+    assert S.engine.backward_mode(model, B, L, grid, 'srk') == 1
+    dW = draw_dW(700 + ci, ts, dt, B, H)
+    dU = _draw_dU(700 + ci, dW, ts, dt)
+    y_auto, _ = hip_solve(pr, ts, dt, dW=dW, dU=dU, method='srk', kernel='auto')
+    y_m4, _ = hip_solve(pr, ts, dt, dW=dW, dU=dU, method='srk', kernel='mfma4')
+    assert np.array_equal(y_auto, y_m4)
 
 
 def test_srk_philox_levy_area_matches_specification_and_shards():
