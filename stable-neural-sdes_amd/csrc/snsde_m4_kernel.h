@@ -116,37 +116,37 @@ __device__ __forceinline__ void lean_gload4(float& d0, float& d1, float& d2, flo
 }
 template <int KU> struct LeanB { f32x4 v[KU]; };
 __device__ __forceinline__ void lean_read_b(uint32_t a, LeanB<1>& b) {
-    asm volatile("s_mov_b64 exec, 0xffff\n\tds_read_b128 %0, %[a]\n\ts_mov_b64 exec, -1" : "=v"(b.v[0]) : [a] "v"(a));
+    asm volatile("s_mov_b64 exec, 0xffff\n\tds_read_b128 %0, %[a]\n\ts_mov_b64 exec, -1" : "=&v"(b.v[0]) : [a] "v"(a));
 }
 __device__ __forceinline__ void lean_read_b(uint32_t a, LeanB<2>& b) {
     asm volatile("s_mov_b64 exec, 0xffff\n\tds_read_b128 %0, %[a]\n\tds_read_b128 %1, %[a] offset:64\n\ts_mov_b64 exec, -1"
-                 : "=v"(b.v[0]), "=v"(b.v[1]) : [a] "v"(a));
+                 : "=&v"(b.v[0]), "=&v"(b.v[1]) : [a] "v"(a));
 }
 __device__ __forceinline__ void lean_read_b(uint32_t a, LeanB<3>& b) {
     asm volatile("s_mov_b64 exec, 0xffff\n\tds_read_b128 %0, %[a]\n\tds_read_b128 %1, %[a] offset:64\n\tds_read_b128 %2, %[a] offset:128\n\t"
-                 "s_mov_b64 exec, -1" : "=v"(b.v[0]), "=v"(b.v[1]), "=v"(b.v[2]) : [a] "v"(a));
+                 "s_mov_b64 exec, -1" : "=&v"(b.v[0]), "=&v"(b.v[1]), "=&v"(b.v[2]) : [a] "v"(a));
 }
 __device__ __forceinline__ void lean_read_b(uint32_t a, LeanB<4>& b) {
     asm volatile("s_mov_b64 exec, 0xffff\n\tds_read_b128 %0, %[a]\n\tds_read_b128 %1, %[a] offset:64\n\tds_read_b128 %2, %[a] offset:128\n\t"
                  "ds_read_b128 %3, %[a] offset:192\n\ts_mov_b64 exec, -1"
-                 : "=v"(b.v[0]), "=v"(b.v[1]), "=v"(b.v[2]), "=v"(b.v[3]) : [a] "v"(a));
+                 : "=&v"(b.v[0]), "=&v"(b.v[1]), "=&v"(b.v[2]), "=&v"(b.v[3]) : [a] "v"(a));
 }
 __device__ __forceinline__ void lean_read_b(uint32_t a, LeanB<5>& b) {
     asm volatile("s_mov_b64 exec, 0xffff\n\tds_read_b128 %0, %[a]\n\tds_read_b128 %1, %[a] offset:64\n\tds_read_b128 %2, %[a] offset:128\n\t"
                  "ds_read_b128 %3, %[a] offset:192\n\tds_read_b128 %4, %[a] offset:256\n\ts_mov_b64 exec, -1"
-                 : "=v"(b.v[0]), "=v"(b.v[1]), "=v"(b.v[2]), "=v"(b.v[3]), "=v"(b.v[4]) : [a] "v"(a));
+                 : "=&v"(b.v[0]), "=&v"(b.v[1]), "=&v"(b.v[2]), "=&v"(b.v[3]), "=&v"(b.v[4]) : [a] "v"(a));
 }
 __device__ __forceinline__ void lean_read_b(uint32_t a, LeanB<6>& b) {
     asm volatile("s_mov_b64 exec, 0xffff\n\tds_read_b128 %0, %[a]\n\tds_read_b128 %1, %[a] offset:64\n\tds_read_b128 %2, %[a] offset:128\n\t"
                  "ds_read_b128 %3, %[a] offset:192\n\tds_read_b128 %4, %[a] offset:256\n\tds_read_b128 %5, %[a] offset:320\n\t"
                  "s_mov_b64 exec, -1"
-                 : "=v"(b.v[0]), "=v"(b.v[1]), "=v"(b.v[2]), "=v"(b.v[3]), "=v"(b.v[4]), "=v"(b.v[5]) : [a] "v"(a));
+                 : "=&v"(b.v[0]), "=&v"(b.v[1]), "=&v"(b.v[2]), "=&v"(b.v[3]), "=&v"(b.v[4]), "=&v"(b.v[5]) : [a] "v"(a));
 }
 __device__ __forceinline__ void lean_read_b(uint32_t a, LeanB<8>& b) {
     asm volatile("s_mov_b64 exec, 0xffff\n\tds_read_b128 %0, %[a]\n\tds_read_b128 %1, %[a] offset:64\n\tds_read_b128 %2, %[a] offset:128\n\t"
                  "ds_read_b128 %3, %[a] offset:192\n\tds_read_b128 %4, %[a] offset:256\n\tds_read_b128 %5, %[a] offset:320\n\t"
                  "ds_read_b128 %6, %[a] offset:384\n\tds_read_b128 %7, %[a] offset:448\n\ts_mov_b64 exec, -1"
-                 : "=v"(b.v[0]), "=v"(b.v[1]), "=v"(b.v[2]), "=v"(b.v[3]), "=v"(b.v[4]), "=v"(b.v[5]), "=v"(b.v[6]), "=v"(b.v[7])
+                 : "=&v"(b.v[0]), "=&v"(b.v[1]), "=&v"(b.v[2]), "=&v"(b.v[3]), "=&v"(b.v[4]), "=&v"(b.v[5]), "=&v"(b.v[6]), "=&v"(b.v[7])
                  : [a] "v"(a));
 }
 // the same into registers that live across the step loop ("+v": read in place, no copy at the back edge)

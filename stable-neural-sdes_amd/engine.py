@@ -92,6 +92,8 @@ def padding_plan(model, batch, knots, n_steps, method):
     H, HH = model.hidden_channels, model.hidden_hidden_channels
     if H in _MFMA_SIZES and HH == H:
         return None
+    if model.activation or model.drift_output or model.diffusion_output or model.time_feature:
+        return None      # field variants: the padded block below is the reference Diffusion_model's, not theirs
     key = (model.input_channels, H, HH, model.num_hidden_layers, model.input_option, model.noise_option, int(batch), int(knots),
            int(n_steps), method)
     if key not in _PAD_CACHE:

@@ -233,8 +233,9 @@ def _compose(sde):
             p0 = next(sde.parameters())
             t = torch.tensor(0.37, device=p0.device, dtype=p0.dtype)
             gen = torch.Generator().manual_seed(7)
+            # mixed signs: g = s(t) relu(y) / s(t) |y| must not be taken for the multiplicative form s(t) y
             y1 = (torch.rand(3, H, generator=gen) + 0.5).to(device=p0.device, dtype=p0.dtype)
-            y2 = (torch.rand(3, H, generator=gen) + 0.5).to(device=p0.device, dtype=p0.dtype)
+            y2 = -(torch.rand(3, H, generator=gen) + 0.5).to(device=p0.device, dtype=p0.dtype)
             g1, g2 = sde.g(t, y1), sde.g(t, y2)
     except Exception:
         return None
@@ -270,37 +271,43 @@ def verify(field, coeffs, times_host, dev):
     rows = min(int(coeffs.shape[0]), 8)
     c = coeffs[:rows].contiguous()
     t_lo, t_hi = float(times_host[0]), float(times_host[-1])
-    t = np.float32(t_lo + 0.31 * (t_hi - t_lo))
     h = np.float32(max(0.05 * (t_hi - t_lo), 1e-3))
-    ts = np.array([t, t + h], dtype=np.float32)
-    grid = engine.StepGrid(ts, float(2 * h), times_host, dev)
-    if grid.N != 1:
-        return False
-    hh = float(grid.t1[0] - grid.t0[0])
     gen = torch.Generator().manual_seed(11)
-    y0 = (torch.rand(rows, H, generator=gen) + 0.5).to(dev)
+    # mixed-sign states and two distinct times: a field that uses relu(y) / |y| / clamp(y) where the kernel multiplies by y, or
+    # whose time dependence differs from the composed one, must not pass on a lucky probe point
+    y0 = ((torch.rand(rows, H, generator=gen) * 2.0 - 1.0) * 1.5).to(dev)
+    y0 = torch.where(y0.abs() < 0.05, torch.full_like(y0, 0.7), y0)
     saved = (sde.coeffs, sde.times)
     ok = False
     drift0 = field.model.drift_output          # (kept if the probe fails here but passed on another device)
-    try:
-        sde.set_X(c, sde.times) if hasattr(sde, 'set_X') else None
+
+    def probe(frac, drift):
+        t = np.float32(t_lo + frac * (t_hi - t_lo))
+        grid = engine.StepGrid(np.array([t, t + h], dtype=np.float32), float(2 * h), times_host, dev)
+        if grid.N != 1:
+            return False
+        hh = float(grid.t1[0] - grid.t0[0])
         tt = torch.tensor(float(grid.t0[0]), device=dev)
         f_ref, g_ref = sde.f(tt, y0).float(), sde.g(tt, y0).float()
         tab = field.noise_table(torch.from_numpy(grid.t0), dev)
         flat = field.flat(dev)
         scale_f = float(f_ref.abs().max()) + 1e-6
         scale_g = float(g_ref.abs().max()) + 1e-6
+        field.model.drift_output = drift
+        outs = []
+        for w in (0.0, 1.0):
+            dW = torch.full((1, rows, H), w, device=dev)
+            call = engine.SolveCall(field.model, flat, c, grid, y0, dW=dW, method='euler', noise_table=tab)
+            outs.append(call.launch()[1].clone())
+        f_k = (outs[0] - y0) / hh
+        g_k = outs[1] - outs[0]
+        return (float((f_k - f_ref).abs().max()) <= 2e-4 * scale_f + 2e-5 / hh
+                and float((g_k - g_ref).abs().max()) <= 2e-4 * scale_g + 2e-5)
+
+    try:
+        sde.set_X(c, sde.times) if hasattr(sde, 'set_X') else None
         for drift in (DRIFT_LINEAR, DRIFT_TIMES_Y):
-            field.model.drift_output = drift
-            outs = []
-            for w in (0.0, 1.0):
-                dW = torch.full((1, rows, H), w, device=dev)
-                call = engine.SolveCall(field.model, flat, c, grid, y0, dW=dW, method='euler', noise_table=tab)
-                outs.append(call.launch()[1].clone())
-            f_k = (outs[0] - y0) / hh
-            g_k = outs[1] - outs[0]
-            if float((f_k - f_ref).abs().max()) <= 2e-4 * scale_f + 2e-5 / hh \
-                    and float((g_k - g_ref).abs().max()) <= 2e-4 * scale_g + 2e-5:
+            if probe(0.31, drift) and probe(0.67, drift):
                 ok = True
                 break
     except (_lib.SnsdeError, ValueError, AttributeError, TypeError):

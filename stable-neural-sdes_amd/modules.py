@@ -158,17 +158,23 @@ class Diffusion_model(nn.Module):
         # f and g of one (t, y) come out of the same launch: a solver step that asks for both evaluates once.  Each half is
         # handed out once per launch - asking for the same half again re-evaluates, so a caller that edits parameters
         # through `.data` (no version bump) between two f(t, y) calls, finite differences say, never sees the old value.
-        key = (float(t), y.data_ptr(), y._version, tuple(y.shape), self.coeffs.data_ptr(), self.coeffs._version,
+        # The entry keeps `y` itself: the other half is handed out only to a call with the SAME tensor object at the same
+        # version (an address-keyed entry could be hit by a new temporary that the caching allocator placed at a freed
+        # temporary's address: f(t, y + d) followed by g(t, y - d)), and holding the reference keeps that address taken.
+        key = (float(t), y._version, tuple(y.shape), self.coeffs.data_ptr(), self.coeffs._version,
                tuple(p._version for p in self.parameters()))
         hit = getattr(self, '_fg_cache', None)
-        if hit is not None and hit[0] == key and which not in hit[2]:
+        if hit is not None and hit[3] is y and hit[0] == key and which not in hit[2]:
             hit[2].add(which)
-            return hit[1]
+            out = hit[1]
+            if len(hit[2]) == 2:
+                object.__setattr__(self, '_fg_cache', None)     # both halves handed out: drop the references
+            return out
         model, layout, numel = engine.recognise(self)
         flat = engine.flatten_params(self, layout, numel, y.device)
         coeffs = self.coeffs.detach().to(torch.float32).contiguous()
         out = engine.eval_fg(model, flat, coeffs, _HostTimes.get(self.times), float(t), y.contiguous())
-        object.__setattr__(self, '_fg_cache', (key, out, {which}))
+        object.__setattr__(self, '_fg_cache', (key, out, {which}, y))
         return out
 
     @staticmethod

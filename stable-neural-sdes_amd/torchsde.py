@@ -285,7 +285,9 @@ def _sdeint_hip(sde, rec, y0, ts, bm, method, dt, options):
     except engine._lib.SnsdeError as exc:
         # a valid request no kernel covers (Milstein with noise_option 7, sqrt(y)): same behaviour as the gradient path, the
         # unfused tensor-op loop, unless strict
-        if exc.code != -4 or options.get('strict', False):
+        # (-6, SNSDE_ERR_LDS: a hidden size whose per-tile buffers exceed the LDS budget of the only kernel family that covers
+        # the request — the generic Milstein kernel for the diffusion nets above H ~ 460 — is the same situation)
+        if exc.code not in (-4, -6) or options.get('strict', False):
             raise
         if z0_lin is not None:
             y0 = _materialise_z0(sde, y0, ts, {'z0_linear': z0_lin})

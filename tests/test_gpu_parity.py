@@ -310,11 +310,21 @@ def test_sdeint_drop_in_on_cuda_dispatches_to_hip():
     # f and g of one (t, y) share a launch, but a parameter edit through .data (no version bump) between two f calls is seen
     with torch.no_grad():
         t2, y2 = torch.tensor(2.0), torch.from_numpy(pr['y0']).to(DEV)
-        f0, g0 = m.f(t2, y2), m.g(t2, y2)
-        assert m._fg_cache[2] == {0, 1}
+        f0 = m.f(t2, y2)
+        assert m._fg_cache[2] == {0} and m._fg_cache[3] is y2
+        g0 = m.g(t2, y2)
+        assert m._fg_cache is None                 # both halves of the launch handed out
         m.linear_out.bias.data.add_(0.25)
         f1 = m.f(t2, y2)
         assert not torch.equal(f1, f0) and torch.equal(m.g(t2, y2), g0)
+        # temporaries: the allocator hands f's freed argument address to g's argument; the cached half must not be served
+        for _ in range(4):
+            d = torch.full_like(y2, 0.5)
+            m.f(t2, y2 + d)
+            g_tmp = m.g(t2, y2 - d)
+            keep = y2 - d
+            m.f(t2, y2 * 0 + 7.0)                  # evict
+            assert torch.equal(g_tmp, m.g(t2, keep))
 
 
 def test_neuralsde_forward_on_cuda():
