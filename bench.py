@@ -49,7 +49,33 @@ PEAK_FP32_TFLOPS = 157.3            # MI355X_MICROARCH.md: fp32 vector = fp32 MF
 PEAK_HBM_GBS = 8000.0
 # HBM bytes per launch of the solve kernel from rocprofv3 PMC passes (FETCH_SIZE doubled per the gfx950 correction
 # in MI355X_MICROARCH.md, + WRITE_SIZE; profiles/r02_pmc_counters.txt); re-measure when the kernel's memory behaviour changes.
-HBM_TRAFFIC_BYTES_PER_LAUNCH = 38083584   # K2, lean M4 kernel (profiles/r02_pmc_counters.txt)
+HBM_TRAFFIC_BYTES_PER_LAUNCH = 38085632   # K2, lean M4 kernel: (2 x 18084.5 + 1024.0) KB
+HBM_TRAFFIC_SOURCE = ("profiles/r03_pmc_counters.txt: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes over this bench command, "
+                      "mean of 127 dispatches of the solve kernel), 2 x FETCH_SIZE + WRITE_SIZE per the gfx950 correction of "
+                      "MI355X_MICROARCH.md; a constant of the kernel's memory behaviour, not re-measured in this run")
+# L2-fabric bytes of one K2 training step (forward + adjoint + weight gradients): profiles/r03_train_traffic.txt
+TRAIN_TRAFFIC_BYTES_PER_STEP = None       # filled from the profile below when present
+TRAIN_TRAFFIC_SOURCE = "profiles/r03_train_traffic.txt (tools/pmc_train_modes.sh: FETCH_SIZE / WRITE_SIZE summed over every kernel of 10 steps)"
+
+
+def flops_drift(io, h, c, nl):
+    """algorithmic FLOPs of one drift evaluation per row (2 per MAC; HH = H)."""
+    emb, usex, timef = io in (2, 4, 6), io in (0, 2, 4, 6), io >= 3
+    f = 2 * c * h if usex else 0
+    f += 2 * (h + (2 if timef else 0)) * h if io != 0 else 0
+    f += 2 * (2 * h) * h if emb else 0
+    return f + 2 * (nl - 1) * h * h + 2 * h * h
+
+
+def flops_net(no, h):
+    """One evaluation of the diffusion net on [sin t, cos t, y] per row (noise_option 14/15: one layer, 18/19: two)."""
+    return (2 * (h + 2) * h + (2 * h * h if no in (18, 19) else 0)) if no in (14, 15, 18, 19) else 0
+
+
+def roofline_obj(flops, seconds, what):
+    tf = flops / seconds / 1e12
+    return {"bound": "mfma", "achieved": tf, "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s", "frac": tf / PEAK_FP32_TFLOPS,
+            "flops": flops, "seconds": seconds, "counted": what}
 
 
 def build_inputs(device, rank, io=IO, no=NO, nl=NL, b=B, h=H, c=C, l=L, nan_frac=0.3, hermite=False):
@@ -152,9 +178,14 @@ def strong_k3(dev, rank, world, stream, barrier, maxr):
         call.launch(stream)
     barrier()
     el = maxr(time.perf_counter() - t0)
+    t_kern = event_times_ms(lambda: call.launch(stream, reuse_prepared=True), stream, 20, 3)
+    kern_s = float(np.median(t_kern)) * 1e-3
     return {"workload": f"K3: Neural GSDE (io=6,no=17) {rows_g} rows global ({hi - lo}/GPU), H=128, 200 Euler steps, "
                         "Hermite coeffs, forward", "scaling": "strong", "value": rows_g * n_steps * k / el,
-            "unit": "row-steps/s", "ms_per_solve": el / k * 1e3, "solves": k}
+            "unit": "row-steps/s", "ms_per_solve": el / k * 1e3, "solves": k,
+            "roofline": roofline_obj((hi - lo) * n_steps * flops_drift(6, H, C, NL), kern_s,
+                                     "this rank's solve kernel (HIP events, median of 20): SURVEY 8d algorithmic FLOPs of the drift, "
+                                     "169 728 per row-step; the time-only diffusion is hoisted")}
 
 
 def strong_k5(dev, rank, world, stream, barrier, maxr, dist):
@@ -197,7 +228,73 @@ def strong_k5(dev, rank, world, stream, barrier, maxr, dist):
     return {"workload": f"K5: LNSDE (io=4,no=17) Milstein + fused adjoint, {rows_g} rows global ({hi - lo}/GPU), H=256, "
                         "C=14, 49 steps, 50 outputs, fwd+bwd+grad all-reduce", "scaling": "strong",
             "value": rows_g * (ll - 1) * k / el, "unit": "row-steps/s (training steps)", "ms_per_step": el / k * 1e3,
-            "steps": k}
+            "steps": k,
+            "roofline": roofline_obj(3 * (hi - lo) * (ll - 1) * flops_drift(4, hh, cc, 2), el / k,
+                                     "whole training step of this rank (host + forward + adjoint + weight gradients + all-reduce, wall "
+                                     "clock): 3 x the forward's algorithmic FLOPs (SURVEY 8d: 663 552 per row-step forward at K5)")}
+
+
+def _module(dev, io, no, rows, hh, cc, ll, seed, nan_frac=0.3):
+    from tests.helpers import make_problem
+    pr = make_problem(seed, io, no, 2, rows, hh, cc, ll, nan_frac=nan_frac)
+    sde = S.Diffusion_model(cc, hh, hh, 2, input_option=io, noise_option=no)
+    sde.load_state_dict({k: torch.from_numpy(np.asarray(v, np.float32).copy()) for k, v in pr['params'].items()})
+    sde = sde.to(dev)
+    times = torch.from_numpy(pr['times']).to(dev)
+    sde.set_X(torch.from_numpy(pr['coeffs']).to(dev), times)
+    return sde, times, torch.from_numpy(pr['y0']).to(dev)
+
+
+def train_leg(dev, stream, io, no, rows, hh, cc, ll, method, label, outputs='ends'):
+    """sdeint forward and forward + backward (fused adjoint + native weight-gradient pass) of one Diffusion_model shape:
+    HIP-event medians of the whole calls, FLOP roofline (3 x forward for the training step)."""
+    sde, times, y0 = _module(dev, io, no, rows, hh, cc, ll, 77)
+    ts = times if outputs == 'knots' else times[[0, -1]]
+    params = list(sde.parameters())
+    opts = {'seed': 5, 'strict': True}
+
+    def fwd():
+        with torch.no_grad():
+            S.torchsde.sdeint(sde, y0, ts, dt=1.0, method=method, options=opts)
+
+    def step():
+        for p in params:
+            p.grad = None
+        yy = y0.clone().requires_grad_(True)
+        S.torchsde.sdeint(sde, yy, ts, dt=1.0, method=method, options=opts)[-1].square().mean().backward()
+
+    t_f = event_times_ms(fwd, stream, 20, 5)
+    t_s = event_times_ms(step, stream, 20, 5)
+    n = ll - 1
+    per_eval = flops_drift(io, hh, cc, 2)
+    fl = (3 * per_eval + 4 * flops_net(no, hh)) if method == 'srk' else per_eval + flops_net(no, hh) * (2 if method == 'milstein' else 1)      # Milstein: + the VJP through the net
+    model = S.engine.model_struct(cc, hh, hh, 2, io, no)
+    out = {"workload": f"{label}: Diffusion_model (io={io},no={no}) NL=2, {rows} rows, H={hh}, C={cc}, {n} {method} steps, Philox increments",
+           "forward_path": S.engine.forward_path(model, rows, ll, n, method=method),
+           "forward": spread(t_f), "forward_backward": spread(t_s),
+           "value": rows * n / (float(np.median(t_f)) * 1e-3), "unit": "row-steps/s (forward)",
+           "flop_per_rowstep": fl,
+           "roofline_forward": roofline_obj(rows * n * fl, float(np.median(t_f)) * 1e-3, "whole sdeint() forward call (HIP events); "
+                                            "algorithmic FLOPs per step: drift evaluations + diffusion-net evaluations of the scheme"),
+           "roofline_training": roofline_obj(3 * rows * n * fl, float(np.median(t_s)) * 1e-3, "whole forward + backward call: 3 x forward FLOPs")}
+    return out
+
+
+def k2_training(dev, stream):
+    """K2 training step (forward + fused adjoint + native weight gradients), with the bytes-based roofline of its L2-fabric
+    traffic (from the committed PMC profile; the step is neither FLOP- nor HBM-bound but a chain of latency-bound launches)."""
+    out = train_leg(dev, stream, IO, NO, B, H, C, L, 'euler', 'K2 training step')
+    traffic = None
+    path = os.path.join(ROOT, 'profiles', 'r03_train_traffic.txt')
+    if os.path.exists(path):
+        for line in open(path):
+            if line.startswith('saved activations'):
+                traffic = float(line.split('total')[1].split('MB')[0]) * 1e6
+    sec = out["forward_backward"]["median_ms"] * 1e-3
+    if traffic:
+        out["roofline_bytes"] = {"bound": "hbm", "achieved": traffic / sec / 1e9, "peak": PEAK_HBM_GBS, "unit": "GB/s",
+                                 "frac": traffic / sec / 1e9 / PEAK_HBM_GBS, "traffic": traffic, "traffic_source": TRAIN_TRAFFIC_SOURCE}
+    return out
 
 
 def tutorial_field(dev, stream, kind='lnsde', rows=1024, hh=128, n=100):
@@ -318,6 +415,12 @@ def main():
         extra["K3_strong"] = strong_k3(dev, rank, world, stream, barrier, maxr)
         extra["K5_strong_train"] = strong_k5(dev, rank, world, stream, barrier, maxr, dist)
         if world == 1:
+            extra["K2_train"] = k2_training(dev, stream)
+            # the reference's headline Neural SDE (neuralsde_3_18, README.md:32) under torch_ists' default `srk`, K4 shape, and
+            # torch_ists' neuralsde_1_18 at the K2 width: diffusion nets on the MFMA net kernels (snsde_m4n_kernel.h)
+            extra["NSDE_3_18_srk_K4_shape"] = train_leg(dev, stream, 3, 18, 2048, 64, 69, 72, 'srk', 'neuralsde_3_18, srk')
+            extra["NSDE_1_18_srk_H128"] = train_leg(dev, stream, 1, 18, 1024, 128, 21, 50, 'srk', 'neuralsde_1_18, srk')
+            extra["NSDE_3_18_milstein_K4_shape"] = train_leg(dev, stream, 3, 18, 2048, 64, 69, 72, 'milstein', 'neuralsde_3_18, milstein')
             extra["tutorial_field"] = tutorial_field(dev, stream)
             extra["K1_tutorial_lsde"] = tutorial_field(dev, stream, kind='lsde', rows=256, hh=32, n=50)
 
@@ -340,14 +443,16 @@ def main():
                        "method": "HIP events on the launch stream, one pair per solve, after 10 warm-ups (SURVEY 8d)"},
             "roofline": {"bound": "mfma", "achieved": ach_tf, "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s",
                          "frac": ach_tf / PEAK_FP32_TFLOPS, "traffic": HBM_TRAFFIC_BYTES_PER_LAUNCH,
+                         "traffic_source": HBM_TRAFFIC_SOURCE,
                          "kernel_ms": kern_ms, "flop_per_rowstep": FLOP_PER_ROWSTEP,
                          "executed_flop_per_rowstep": EXECUTED_FLOP_PER_ROWSTEP, "executed_frac": exe_tf / PEAK_FP32_TFLOPS,
-                         "mfma_busy": MFMA_CYCLES_PER_STEP * NSTEP / (kern_ms * 1e-3 * 2.4e9),
+                         "mfma_issue_cycles_per_simd_step": MFMA_CYCLES_PER_STEP,
+                         "kernel_ns_per_step": kern_ms * 1e6 / NSTEP,
                          "hbm_frac": ach_gbs / PEAK_HBM_GBS, "hbm_achieved_GBs": ach_gbs,
                          "note": "fp32 FMA/MFMA roof binds (intensity ~490 FLOP/B); frac counts the reference's algorithmic "
-                                 "FLOPs, executed_frac the MFMA FLOPs the kernel issues (folded first layer); mfma_busy = "
-                                 "1664 MFMA-issue cycles per SIMD-step / kernel cycles at 2.4 GHz (f32 MFMA shares the VALU "
-                                 "port on gfx950, so VALU work adds to it: DESIGN.md 3.1); hbm_* = algorithmic 346 B/row-step"},
+                                 "FLOPs, executed_frac the MFMA FLOPs the kernel issues (folded first layer); the kernel issues "
+                                 "1664 MFMA cycles per SIMD and step (two waves x 104 x 8) - measured MFMA-busy share and clock: "
+                                 "profiles/r03_pmc_counters.txt (SQ_VALU_MFMA_BUSY_CYCLES / GRBM_GUI_ACTIVE); hbm_* = algorithmic 346 B/row-step"},
         }
         if extra:
             out["extra"] = extra

@@ -180,16 +180,21 @@ typedef struct snsde_solve {
 size_t snsde_workspace_bytes(const snsde_solve* s);
 int    snsde_solve_forward(const snsde_solve* s, void* hip_stream);
 
-/* ---- backward of the solve (discretise-then-optimise adjoint of the Euler scheme) ------------
+/* ---- backward of the solve (discretise-then-optimise adjoint of the fixed-step scheme) ------
  * Replaces autograd THROUGH the unrolled solver loop (`loss.backward()` in
- * benchmark_classification/common_sde.py:160, ~25 autograd nodes per solver step): given dL/d ys it runs the
- * adjoint recursion  a_n = a_{n+1} + h (df/dy)^T a_{n+1} + (dg/dy)^T (a_{n+1} * dW_n)  backwards over the saved
- * trajectory and writes EVERY a_n (adj[0] = dL/dy0).  Parameter gradients are the batched reduction
- * sum_{n,rows} a_{n+1} . d(f h + g dW)/d theta over (traj, adj, dW_used), a plain GEMM-shaped job done by the host
- * (engine.py) with library GEMMs.  Forward must have been run with traj, dW_out and act_save set.
- * snsde_backward_supported: 1 = MFMA adjoint kernel (forward on the MFMA path with act_save; Euler; fills delta_save),
- * 2 = generic adjoint kernels (forward on any kernel; traj + dW_out (+ dU_out for SRK) only; Euler, Milstein and SRK,
- * any dims within the LDS budget, every noise_option (Milstein: all but 7); delta_save must be NULL), 0 = none. */
+ * benchmark_classification/common_sde.py:160, ~25 autograd nodes per solver step): given dL/d ys it runs the adjoint
+ * recursion of the scheme (Euler: a_n = a_{n+1} + h (df/dy)^T a_{n+1} + (dg/dy)^T (a_{n+1} * dW_n); Milstein and SRID2: the
+ * reverse of their step formulas) backwards over the saved trajectory and writes EVERY a_n (adj[0] = dL/dy0).
+ * snsde_backward_supported:
+ *   1 = MFMA adjoint kernels: forward on the MFMA path with traj, dW_out (+ dU_out, stage_save for SRK) and act_save;
+ *       Euler, Milstein and SRK for the elementwise diffusions, Euler and SRK for the diffusion nets (noise_option
+ *       14/15/18/19); fills delta_save, and snsde_param_gradients then forms every parameter gradient ON THE DEVICE
+ *       (split-R MFMA weight-gradient GEMMs over the saved activations / deltas, diffusion-side reductions, the folded
+ *       first layer's algebra) in the flat layout of `params`;
+ *   2 = generic adjoint kernels (forward on any kernel; traj + dW_out (+ dU_out for SRK) only; Euler, Milstein and SRK, any
+ *       dims within the LDS budget, every noise_option (Milstein: all but 7); delta_save must be NULL): adjoints only, the
+ *       host layer takes the parameter gradients from one batched evaluation of the step function;
+ *   0 = none. */
 typedef struct snsde_backward {
     snsde_solve  fwd;        /* the forward descriptor (traj, dW_out, act_save filled by the forward)      */
     const float* grad_ys;    /* device (T, B, H): dL/d ys                                                 */

@@ -175,7 +175,16 @@ def sdeint_adjoint(sde, y0, ts, bm=None, method=None, adjoint_method=None, adjoi
     (snsde_solve_backward + snsde_param_gradients: no autograd graph over the steps, memory O(N B H) of saved states
     rather than ~25 autograd nodes per step), otherwise autograd through the tensor-op loop.  torchsde integrates the
     continuous adjoint SDE backwards instead; the two agree to the discretisation error of the forward scheme.  The
-    adjoint_* solver options have no counterpart here and are accepted for signature compatibility."""
+    adjoint_* solver options have no counterpart here: they are accepted for signature compatibility and a non-default value
+    is reported once per process."""
+    given = [n for n, v, d in (('adjoint_method', adjoint_method, None), ('adjoint_adaptive', adjoint_adaptive, False),
+                               ('adjoint_rtol', adjoint_rtol, 1e-5), ('adjoint_atol', adjoint_atol, 1e-4),
+                               ('adjoint_options', adjoint_options, None), ('adjoint_params', adjoint_params, None)) if v != d]
+    if given and 'sdeint_adjoint' not in _UNFUSED_WARNED:
+        _UNFUSED_WARNED.add('sdeint_adjoint')
+        warnings.warn(f"sdeint_adjoint: {', '.join(given)} ignored - gradients are the adjoint of the DISCRETE scheme "
+                      "(fused HIP adjoint kernels for a Diffusion_model on CUDA, autograd through the step loop otherwise), "
+                      "not torchsde's continuous stochastic adjoint; both agree to the forward scheme's discretisation error.")
     return sdeint(sde, y0, ts, bm=bm, method=method, names=names, **kwargs)
 
 

@@ -393,3 +393,22 @@ def test_uninstantiated_hidden_sizes_run_zero_padded_on_the_mfma_kernels(ci, mon
         a = S.sdeint(m, y0.detach(), torch.from_numpy(ts).to(DEV), method=method, dt=dt, options={'seed': 5})
         b = S.sdeint(m, y0.detach(), torch.from_numpy(ts).to(DEV), method=method, dt=dt, options={'seed': 5, 'kernel': 'generic'})
     assert float((a - b).abs().max()) <= 2e-4 * max(float(b.abs().max()), 1.0)
+
+
+def test_bench_runs_its_rccl_branch_on_one_gpu_and_emits_the_contract_line():
+    """`python bench.py` with SNSDE_BENCH_FORCE_DIST=1: the process group (nccl = RCCL), the barrier / max-over-ranks timing and
+    the K5 gradient all-reduce run at world size 1; the last stdout line is the contract's JSON with roofline objects on the
+    headline and on the strong-scaling legs."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, SNSDE_BENCH_FORCE_DIST='1', MASTER_ADDR='127.0.0.1', MASTER_PORT='29533', HSA_ENABLE_IPC_MODE_LEGACY='0')
+    r = subprocess.run([sys.executable, os.path.join(root, 'bench.py'), '--steps', '5', '--warmup', '2', '--no-cpu-baseline'],
+                       capture_output=True, text=True, env=env, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = json.loads(r.stdout.strip().splitlines()[-1])
+    assert line['n_gpus'] == 1 and line['steps'] == 5 and line['unit'] == 'row-steps/s' and line['value'] > 1e7
+    assert 0.0 < line['roofline']['frac'] < 1.0 and line['roofline']['traffic_source']
+    for leg in ('K3_strong', 'K5_strong_train'):
+        assert 0.0 < line['extra'][leg]['roofline']['frac'] < 1.0, leg

@@ -562,6 +562,31 @@ def test_k3_gsde_per_gpu_shard_full_size():
         print('K3', kernel, assert_parity(ys, ref64, cpu32, what='K3 ' + kernel, amplifying=True))
 
 
+def test_bench_sized_single_gpu_solves_vs_oracle():
+    """The sizes bench.py times on ONE GPU in its `extra` legs, at full size against the fp64 oracle on replayed increments:
+    K3 with all 4096 rows (16-row tiles chosen by 'auto', 200 steps) and K5 with all 1024 rows (H = 256 Milstein, LDS-ring
+    streamed weights on 4-row tiles, 50 outputs)."""
+    B, H, C, L = 4096, 128, 21, 201
+    pr = make_problem(3004, 6, 17, 2, B, H, C, L, nan_frac=0.0, hermite=True)
+    ts, dt = [0, L - 1], 1.0
+    dW = draw_dW(3004, ts, dt, B, H)
+    ref64, _ = oracle_solve(pr, ts, dt, dW, 'euler', np.float64)
+    cpu32, _ = oracle_solve(pr, ts, dt, dW, 'euler', np.float32)
+    assert S.engine.forward_path(S.engine.model_struct(C, H, H, 2, 6, 17), B, L, L - 1) == 'mfma16'
+    ys, _ = hip_solve(pr, ts, dt, dW=dW, kernel='auto')
+    print('K3 4096 rows', assert_parity(ys, ref64, cpu32, what='K3 4096 rows auto', amplifying=True))
+    B, H, C, L = 1024, 256, 14, 50
+    pr = make_problem(5006, 4, 17, 2, B, H, C, L, nan_frac=0.3)
+    ts, dt = pr['times'], 1.0
+    dW = draw_dW(5006, ts, dt, B, H)
+    ref64, _ = oracle_solve(pr, ts, dt, dW, 'milstein', np.float64)
+    cpu32, _ = oracle_solve(pr, ts, dt, dW, 'milstein', np.float32)
+    assert S.engine.forward_path(S.engine.model_struct(C, H, H, 2, 4, 17), B, L, L - 1, method='milstein') == 'lean-streamed'
+    ys, _ = hip_solve(pr, ts, dt, dW=dW, method='milstein', kernel='auto')
+    assert ys.shape == (50, B, H)
+    print('K5 1024 rows', assert_parity(ys, ref64, cpu32, what='K5 1024 rows auto'))
+
+
 def test_k4_sepsis_shaped_nsde_full_size():
     """configs[3]: Neural SDE (3,18), B=2048, H=64, C=69, times=linspace(1,72,72), per-row lengths, z0 supplied,
     ts = the distinct final times (T ~ 70)."""

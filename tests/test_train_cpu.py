@@ -159,3 +159,29 @@ def test_main_under_two_gloo_ranks_trains_one_model_and_reduces_metrics():
     assert a[1] == b[1] == 40 and a[2] == b[2] == 20 and a[5] == b[5] == 20.0       # global sizes on every rank
     assert a[3] == b[3] and a[4] == b[4]                                            # reduced metrics agree
     assert np.array_equal(a[6], b[6])                                               # one model: DDP kept the ranks in step
+
+
+def test_package_training_loop_reproduces_the_reference_common_sde_loop_trace():
+    """tests/golden/dropin.npz `trainloop/*` was recorded by running the REFERENCE's own benchmark_classification/
+    common_sde.py:_train_loop / _evaluate_metrics (and its NeuralSDE / Diffusion_model) over this package's torchsde /
+    torchcde / controldiffeq mirrors on CPU (tools/check_reference_dropin.py).  The package's own model classes and
+    training loop, on the same problem with the same seeds, must land on the same per-epoch metrics and final weights."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location('check_reference_dropin', os.path.join(ROOT, 'tools', 'check_reference_dropin.py'))
+    tool = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(tool)
+    gold = np.load(os.path.join(ROOT, 'tests', 'golden', 'dropin.npz'))
+    tl = tool.trainloop_problem()
+    torch.manual_seed(21)
+    func = S.Diffusion_model(tl['C'], tl['H'], tl['H'], 2, input_option=4, noise_option=17)
+    model = T.SqueezeEnd(S.NeuralSDE(func, tl['C'], tl['H'], 1, initial=True))
+    optimizer = torch.optim.Adam(model.parameters(), lr=1e-2, weight_decay=1e-2 * 0.01)
+    loss_fn = T.add_weight_regularisation(torch.nn.functional.binary_cross_entropy_with_logits, func)
+    torch.manual_seed(22)
+    hist = T.train_loop(tl['train'], tl['val'], model, tl['times'], optimizer, loss_fn, 2, 2, 'cpu', {}, 'trainloss')
+    trace = np.array([[h.train_metrics.loss, h.train_metrics.accuracy, h.train_metrics.auroc, h.val_metrics.loss,
+                       h.val_metrics.accuracy, h.val_metrics.auroc] for h in hist], dtype=np.float64)
+    np.testing.assert_allclose(trace, gold['trainloop/trace'], rtol=2e-5, atol=2e-6)
+    sd = model.state_dict()
+    for k in sd:
+        np.testing.assert_allclose(sd[k].numpy(), gold['trainloop/final_sd/' + k], rtol=2e-4, atol=2e-6, err_msg=k)

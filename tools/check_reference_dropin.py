@@ -64,6 +64,23 @@ def make_inputs(rng, B, L, C, times):
     return coeffs
 
 
+def trainloop_problem():
+    """Small synthetic binary classification problem for the training-loop replay (also imported by tests/test_train_cpu.py):
+    (coeffs, label, final_index) loaders in common_sde's batch format."""
+    n, L, C, H = 24, 8, 3, 8
+    rng = np.random.default_rng(5)
+    times = np.arange(L, dtype=np.float32)
+    slope = rng.standard_normal((n, 1, C)).astype(np.float32) * 0.2
+    X = slope * times[None, :, None] + 0.05 * rng.standard_normal((n, L, C)).astype(np.float32)
+    X[:, :, 0] = times[None]
+    y = torch.from_numpy((slope[:, 0, 1] > 0).astype(np.float32))
+    coeffs = torch.cat(S.controldiffeq.natural_cubic_spline_coeffs(torch.from_numpy(times), torch.from_numpy(X)), dim=-1)
+    fi = torch.from_numpy(rng.integers(3, L, size=n).astype(np.int64))
+    mk = lambda lo, hi: torch.utils.data.DataLoader(torch.utils.data.TensorDataset(coeffs[lo:hi], y[lo:hi], fi[lo:hi]),
+                                                    batch_size=8, shuffle=False)
+    return dict(times=torch.from_numpy(times), train=mk(0, 16), val=mk(16, 24), C=C, H=H)
+
+
 def main():
     S.install()
     import torchsde
@@ -130,6 +147,30 @@ def main():
     ys = torchsde.sdeint_adjoint(lat, torch.zeros(3, 8), torch.tensor([0.0, 0.5, 1.0]), dt=0.25, method='euler',
                                  names={'drift': 'f_aug', 'diffusion': 'g_aug'})
     assert ys.shape == (3, 3, 8) and bool(torch.isfinite(ys).all())
+
+    # ---- the reference's TRAINING LOOP itself (benchmark_classification/common_sde.py:_train_loop / _evaluate_metrics) over the
+    #      mirrors: two epochs on a small synthetic binary problem, CPU.  common_sde.py does `import models_sde`, whose package
+    #      __init__ pulls torchdiffeq-based baselines this image lacks, so the name is bound to a module holding the classes of
+    #      models_sde/neuralsde.py loaded above; the loop, the metrics and the model are the reference's own code.
+    import types
+    ms = types.ModuleType('models_sde')
+    ms.NeuralSDE, ms.Diffusion_model = cls.NeuralSDE, cls.Diffusion_model
+    sys.modules['models_sde'] = ms
+    common = load('ref_common_sde', f'{REF}/benchmark_classification/common_sde.py')
+    tl = trainloop_problem()
+    torch.manual_seed(21)
+    func = cls.Diffusion_model(tl['C'], tl['H'], tl['H'], 2, input_option=4, noise_option=17)
+    model = common._SqueezeEnd(cls.NeuralSDE(func, tl['C'], tl['H'], 1, initial=True))
+    optimizer = torch.optim.Adam(model.parameters(), lr=1e-2, weight_decay=1e-2 * 0.01)
+    loss_fn = common._add_weight_regularisation(torch.nn.functional.binary_cross_entropy_with_logits, func)
+    torch.manual_seed(22)          # the Brownian increments of the CPU path are drawn from torch's global generator
+    hist = common._train_loop(tl['train'], tl['val'], model, tl['times'], optimizer, loss_fn, 2, 2, 'cpu', {}, 'trainloss')
+    trace = np.array([[h.train_metrics.loss, h.train_metrics.accuracy, h.train_metrics.auroc, h.val_metrics.loss,
+                       h.val_metrics.accuracy, h.val_metrics.auroc] for h in hist], dtype=np.float64)
+    assert trace.shape == (2, 6) and np.isfinite(trace).all()
+    out['trainloop/trace'] = trace
+    out.update({'trainloop/final_sd/' + k: v.numpy() for k, v in model.state_dict().items()})
+    print('reference common_sde._train_loop over install(): epochs', len(hist), 'train loss', trace[:, 0])
 
     path = os.path.join(ROOT, 'tests', 'golden', 'dropin.npz')
     if '--write' in sys.argv:

@@ -57,7 +57,19 @@ def main():
                if query(H, 21, io, no, 2, 1024, mv)[0] == 0)
     tot = 4 * 7 * 20 * 3
     print(f'\nforward requests without a kernel at H in (32, 64, 128, 256), C=21: {fall} of {tot} '
-          '(all of them Milstein with a diffusion whose dg/dy is not closed-form: noise_option 7, 14, 15, 18, 19)')
+          '(Milstein with sqrt(y), noise_option 7: no finite dg/dy at the clipped values)')
+    # the diffusion nets (noise_option 14 / 15 / 18 / 19) on the MFMA net kernels (snsde_m4n_kernel.h), by shape
+    print('\nDiffusion nets under SRK / Milstein, input_option 1..6 x noise_option 14, 15, 18, 19 (forward/backward), per hidden size and depth:')
+    for (H, C_, B) in ((16, 3, 256), (32, 5, 256), (64, 69, 2048), (128, 21, 1024), (128, 69, 1024), (256, 14, 128)):
+        for NL in (1, 2, 3, 4):
+            for mname, mval in METHODS[1:]:
+                cells = {}
+                for io in range(1, 7):
+                    for no in (14, 15, 18, 19):
+                        f, b = query(H, C_, io, no, NL, B, mval)
+                        cells.setdefault(f'{FWD[f]}/{BWD[b] if f else "loop"}', []).append((io, no))
+                desc = '; '.join(f'{k}: {len(v)} of 24' + ('' if len(v) in (24,) else ' ' + str(sorted(set(v)))[:120]) for k, v in sorted(cells.items()))
+                print(f'  H={H:3d} C={C_:2d} NL={NL} {mname:8s} {desc}')
 
 
 if __name__ == '__main__':
