@@ -74,7 +74,9 @@ enum {
 enum { SNSDE_ACT_RELU = 0, SNSDE_ACT_LIPSWISH = 1 /* 0.909 silu(x) */, SNSDE_ACT_SILU = 2 };
 enum { SNSDE_DRIFT_TANH = 0 /* f = tanh(z) (z * tanh(y) first for input_option 5/6) */, SNSDE_DRIFT_LINEAR = 1 /* f = z */,
        SNSDE_DRIFT_TIMES_Y = 2 /* f = z * y */ };
-enum { SNSDE_DIFFUSION_TANH = 0 /* g = tanh(sigmoid(theta) nan_to_num(raw)) */, SNSDE_DIFFUSION_RAW = 1 /* g = raw */ };
+enum { SNSDE_DIFFUSION_TANH = 0 /* g = tanh(sigmoid(theta) nan_to_num(raw)) */, SNSDE_DIFFUSION_RAW = 1 /* g = raw */,
+       SNSDE_DIFFUSION_RAW_NET = 2 /* noise_option 18 / 19 only: g = raw AND the net's last layer is not rectified (the tutorial's */
+                                   /* NeuralSDEFunc: g = g_net(noise_in([t, y])), an MLP that ends in a Linear)                  */ };
 enum { SNSDE_TIME_SINCOS = 0 /* linear_in sees [sin t, cos t, y] */, SNSDE_TIME_RAW = 1 /* [t, 0, y] */ };
 
 /* Shape of a Diffusion_model: neuralsde.py:123-179 constructor arguments (+ the variant switches above). */

@@ -25,9 +25,10 @@ int validate_model(const snsde_model* m) {
     if (m->input_option < 0 || m->input_option > 6 || m->noise_option < 0 || m->noise_option > 19)
         return SNSDE_ERR_OPTION;
     if (m->activation < 0 || m->activation > SNSDE_ACT_SILU || m->drift_output < 0 || m->drift_output > SNSDE_DRIFT_TIMES_Y ||
-        m->diffusion_output < 0 || m->diffusion_output > SNSDE_DIFFUSION_RAW || m->time_feature < 0 ||
+        m->diffusion_output < 0 || m->diffusion_output > SNSDE_DIFFUSION_RAW_NET || m->time_feature < 0 ||
         m->time_feature > SNSDE_TIME_RAW)
         return SNSDE_ERR_OPTION;
+    if (m->diffusion_output == SNSDE_DIFFUSION_RAW_NET && m->noise_option != 18 && m->noise_option != 19) return SNSDE_ERR_OPTION;
     const int io = m->input_option;
     // emb = Linear(2H, H) consumes cat[yy (HH), Xt (H)] and io 0 feeds Xt (H) to the HH-wide MLP:
     // both need HH == H (neuralsde.py:150-158, 206-210)
@@ -346,9 +347,8 @@ int snsde_solve_forward(const snsde_solve* s, void* hip_stream) {
     rc = snsde_build_net(s->model, s->n_steps, &net);
     if (rc) return rc;
     hipStream_t st = static_cast<hipStream_t>(hip_stream);
-    if (is_variant(s->model) || s->noise_table) {      // tutorial-style fields: the lean 4-row-tile kernel or nothing
-        if (s->method == SNSDE_SRK || s->kernel == SNSDE_KERNEL_GENERIC || s->kernel == SNSDE_KERNEL_MFMA_M16)
-            return SNSDE_ERR_UNSUPPORTED;
+    if (is_variant(s->model) || s->noise_table) {      // tutorial-style fields: the 4-row-tile MFMA kernels or nothing
+        if (s->kernel == SNSDE_KERNEL_GENERIC || s->kernel == SNSDE_KERNEL_MFMA_M16) return SNSDE_ERR_UNSUPPORTED;
         return snsde_mfma_launch(s, net, st, 1);
     }
     if (s->method == SNSDE_SRK) {   // SRK: MFMA variant (M4 tiles) where instantiated, else the generic (all-options) family
@@ -384,7 +384,7 @@ int snsde_forward_path(const snsde_solve* s) {
     if (snsde_build_net(s->model, s->n_steps, &net)) return SNSDE_PATH_NONE;
     const bool variant = is_variant(s->model) || s->noise_table;
     if (variant) {
-        if (s->method == SNSDE_SRK || s->kernel == SNSDE_KERNEL_GENERIC || s->kernel == SNSDE_KERNEL_MFMA_M16) return SNSDE_PATH_NONE;
+        if (s->kernel == SNSDE_KERNEL_GENERIC || s->kernel == SNSDE_KERNEL_MFMA_M16) return SNSDE_PATH_NONE;
         return snsde_mfma_path(s, net, 1);
     }
     const int hint = s->kernel == SNSDE_KERNEL_MFMA_M16 ? 0 : (s->kernel == SNSDE_KERNEL_MFMA_M4 ? 1 : -1);

@@ -192,6 +192,17 @@ __global__ void __launch_bounds__(CF::NT, CF::WPS) snsde_m4n_kernel(MfmaArgs a) 
     const float sig_theta = snsde_sigmoid(a.params[a.off_theta]);
     const int no = a.no;
     const bool mul_y = (no == 15 || no == 19);
+    // field variants (tutorial-style NeuralSDEFunc, fields.py): LipSwish / SiLU instead of relu, f = z, g = the net's LINEAR output
+    // (no rectifier on its last layer, no tanh(sigmoid(theta) .)), raw time feature [t, 0]
+    const int act_fn = a.act;
+    const bool f_lin = a.f_out != 0, g_raw = a.g_out != 0, net_lin = a.g_out == SNSDE_DIFFUSION_RAW_NET, raw_time = a.raw_time != 0;
+    const float act_scale = act_fn == SNSDE_ACT_LIPSWISH ? 0.909f : 1.0f;
+    auto actf = [&](float x) {
+        if (__builtin_expect(act_fn != 0, 0)) return act_scale * x * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(x * -1.4426950408889634f));
+        return fmaxf(x, 0.0f);
+    };
+    // d act(x) / dx from the PRE-activation (relu: from the sign)
+    auto dactf = [&](float x) { return __builtin_expect(act_fn != 0, 0) ? swish_grad(x, act_scale) : (x > 0.0f ? 1.0f : 0.0f); };
     const bool geo = a.lean_geo != 0;
     const uint32_t grow = (uint32_t)(a.row_offset + row);
     const uint64_t seed = a.seed_dev ? *a.seed_dev : a.seed;
@@ -243,7 +254,9 @@ __global__ void __launch_bounds__(CF::NT, CF::WPS) snsde_m4n_kernel(MfmaArgs a) 
         const float* st = a.step_tab;
         if constexpr (CF::EMB) { load_coeffs(__float_as_int(st[5])); store_x(st[4]); }
         if (tid < M) {
-            ybuf[tid * LDY + H] = st[2]; ybuf[tid * LDY + H + 1] = st[3];
+            // (Euler / Milstein rows carry sin / cos of the host grid: the raw feature is [t0, 0]; the SRK pass table is built
+            //  with the right feature already)
+            ybuf[tid * LDY + H] = (raw_time && !SRK) ? st[0] : st[2]; ybuf[tid * LDY + H + 1] = (raw_time && !SRK) ? 0.0f : st[3];
             if constexpr (SRK) { gybuf[tid * LDY + H] = st[10]; gybuf[tid * LDY + H + 1] = st[11]; }
         }
     }
@@ -255,7 +268,7 @@ __global__ void __launch_bounds__(CF::NT, CF::WPS) snsde_m4n_kernel(MfmaArgs a) 
     const float* brow = bufB + r * LDA + 4 * s;
     const float* nrow = nbuf + r * LDA + 4 * s;
 
-    struct Row { float h, sn, cs, frac, sqh, nsn, ncs; int idx, nout, kfirst; };
+    struct Row { float h, sn, cs, frac, sqh, nsn, ncs; int idx, nout, kfirst; };      // (sn, cs: the pass's time features)
     const int n_loop = SRK ? 3 * a.N : a.N;
     auto fill_rows = [&](int base) {
         for (int i = tid; i < (CF::ROWCH + 1) * SNSDE_STEP_STRIDE; i += NT) {
@@ -269,6 +282,7 @@ __global__ void __launch_bounds__(CF::NT, CF::WPS) snsde_m4n_kernel(MfmaArgs a) 
                     v2 = *reinterpret_cast<const f32x4*>(st + 8);
         Row q;
         q.h = v0[1]; q.sn = v0[2]; q.cs = v0[3]; q.frac = v1[0]; q.sqh = v1[2];
+        if (!SRK && raw_time) { q.sn = v0[0]; q.cs = 0.0f; }
         q.idx = __float_as_int(v1[1]); q.nout = __float_as_int(v2[0]); q.kfirst = __float_as_int(v2[1]);
         q.nsn = v2[2]; q.ncs = v2[3];
         return q;
@@ -279,6 +293,7 @@ __global__ void __launch_bounds__(CF::NT, CF::WPS) snsde_m4n_kernel(MfmaArgs a) 
     // g = tanh(sigmoid(theta) nan_to_num(raw)), raw = q or q * (the state the net was evaluated at)
     auto gfun = [&](float q, float yy) {
         const float raw = mul_y ? q * yy : q;
+        if (__builtin_expect(g_raw, 0)) return raw;
         return fast_tanh(sig_theta * snsde_nan_to_num(raw));
     };
     auto save_act = [&](int pass, int slot, float v) {
@@ -289,19 +304,21 @@ __global__ void __launch_bounds__(CF::NT, CF::WPS) snsde_m4n_kernel(MfmaArgs a) 
         f32x4 c = {0.f, 0.f, 0.f, 0.f}, d = c;
         gemm4<KUN>(wn0, gyrow, c, d);
         float o = m4_reduce_scatter(c + d) + bias_own[NROW];
+        const float pre = o;
         if constexpr (NN == 2) {
-            o = fmaxf(o, 0.0f);
+            o = actf(o);
             nbuf[r * LDA + fcol] = o;
         } else {
             q = o;
         }
         save_act(pass, slot0, o);
-        return o;
+        return pre;          // (NN == 2: the hidden PRE-activation, for the derivative of the activation)
     };
     auto net_l2 = [&](int pass, int slot1, float& q) {      // NN == 2: q = relu(W2 hidden + b2)
         f32x4 c = {0.f, 0.f, 0.f, 0.f}, d = c;
         gemm4<(NN > 1) ? KUH : 1>(wn1, nrow, c, d);
-        q = fmaxf(m4_reduce_scatter(c + d) + bias_own[NN > 1 ? NROW + 1 : NROW], 0.0f);
+        q = m4_reduce_scatter(c + d) + bias_own[NN > 1 ? NROW + 1 : NROW];
+        if (!net_lin) q = fmaxf(q, 0.0f);        // (SNSDE_DIFFUSION_RAW_NET: the net ends in its linear layer)
         save_act(pass, slot1, q);
     };
 
@@ -330,11 +347,11 @@ __global__ void __launch_bounds__(CF::NT, CF::WPS) snsde_m4n_kernel(MfmaArgs a) 
             f32x4 c = {0.f, 0.f, 0.f, 0.f}, d = c;
             gemm4<KUY>(wy, yrow, c, d);
             if constexpr (CF::EMB) gemm4<CF::EMB ? KUX : 1>(wx, xrow, c, d);
-            const float o = fmaxf(m4_reduce_scatter(c + d) + bias_own[0], 0.0f);
+            const float o = actf(m4_reduce_scatter(c + d) + bias_own[0]);
             bufA[r * LDA + fcol] = o;
             save_act(n, 0, o);
         }
-        const float nhid_own = net_l1(n, CF::ZSLOT + 1, q);      // (NN == 2: this lane's hidden activation of the net)
+        const float nhid_own = net_l1(n, CF::ZSLOT + 1, q);      // (NN == 2: this lane's hidden pre-activation of the net)
         __syncthreads();
         // ---- phase 1: net output; increments; next pass's control values / time features ----
         if constexpr (NN == 2) net_l2(n, CF::ZSLOT + 2, q);
@@ -382,11 +399,12 @@ __global__ void __launch_bounds__(CF::NT, CF::WPS) snsde_m4n_kernel(MfmaArgs a) 
         float mg = 0.0f, mdirect = 0.0f, mv = 0.0f;
         if constexpr (MIL) {
             const float raw = mul_y ? q * yv : q;
-            mg = fast_tanh(sig_theta * snsde_nan_to_num(raw));
-            const float cr = snsde_finite(raw) ? 0.5f * mg * fmaf(dw, dw, -h) * (1.0f - mg * mg) * sig_theta : 0.0f;
+            mg = g_raw ? raw : fast_tanh(sig_theta * snsde_nan_to_num(raw));
+            const float dgr = g_raw ? 1.0f : (1.0f - mg * mg) * sig_theta;          // dg / d raw
+            const float cr = snsde_finite(raw) ? 0.5f * mg * fmaf(dw, dw, -h) * dgr : 0.0f;
             mdirect = mul_y ? cr * q : 0.0f;
             float u = mul_y ? cr * yv : cr;
-            if constexpr (NN == 2) u = q > 0.0f ? u : 0.0f;
+            if constexpr (NN == 2) { if (!net_lin) u = q > 0.0f ? u : 0.0f; }
             tb0[r * LDA + fcol] = u;
         }
         // ---- drift hidden layers / output layer, the net's transposed chain beside them (Milstein) ----
@@ -399,7 +417,7 @@ __global__ void __launch_bounds__(CF::NT, CF::WPS) snsde_m4n_kernel(MfmaArgs a) 
             if (NN == 2 && tdone == 0) {
                 gemm4<(MIL && NN > 1) ? KUH : 1>(wn1t, tb0 + r * LDA + 4 * s, c, d);
                 const float o = m4_reduce_scatter(c + d);
-                tb1[r * LDA + fcol] = nhid_own > 0.0f ? o : 0.0f;
+                tb1[r * LDA + fcol] = o * dactf(nhid_own);
             } else {
                 gemm4<MIL ? KUH : 1>(wn0t, (NN == 2 ? tb1 : tb0) + r * LDA + 4 * s, c, d);
                 mv = m4_reduce_scatter(c + d) + mdirect;
@@ -415,7 +433,7 @@ __global__ void __launch_bounds__(CF::NT, CF::WPS) snsde_m4n_kernel(MfmaArgs a) 
             if (l == 0) gemm4<KUH>(wh0, cur, c, d);
             else if (l == 1) gemm4<KUH>(wh1, cur, c, d);
             else gemm4<KUH>(wh2, cur, c, d);
-            const float o = fmaxf(m4_reduce_scatter(c + d) + bias_own[1 + l], 0.0f);
+            const float o = actf(m4_reduce_scatter(c + d) + bias_own[1 + l]);
             (toB ? bufB : bufA)[r * LDA + fcol] = o;
             save_act(n, 1 + l, o);
             if constexpr (MIL) { if (tdone < NTR) net_t(); }
@@ -441,7 +459,7 @@ __global__ void __launch_bounds__(CF::NT, CF::WPS) snsde_m4n_kernel(MfmaArgs a) 
 
         // ---- f, g and the update (own element) ----
         const float yin = SRK ? sk_y : yv;         // (the drift pass's input state is yv)
-        const float f = fast_tanh(geo ? z * fast_tanh(yv) : z);
+        const float f = f_lin ? z : fast_tanh(geo ? z * fast_tanh(yv) : z);
         if constexpr (!SRK) {
             float g, yn;
             if constexpr (MIL) { g = mg; yn = fmaf(g, dw, fmaf(f, h, yv)) + mv; }
@@ -558,7 +576,7 @@ int launch_m4n(const MfmaArgs& a, hipStream_t stream) {
 inline bool m4n_instantiated(int H, int KUX, int NHID, int NN, int METHOD) {
     if (!(H == 16 || H == 32 || H == 64 || H == 128)) return false;
     if (!(KUX == 0 || KUX == 2 || KUX == 5) || NHID < 0 || NHID > 3 || NN < 1 || NN > 2) return false;
-    if (METHOD != SNSDE_SRK && METHOD != SNSDE_MILSTEIN) return false;
+    if (METHOD != SNSDE_SRK && METHOD != SNSDE_MILSTEIN && METHOD != SNSDE_EULER) return false;
     return m4n_nlds(H, KUX, NHID, NN, METHOD) >= 0;
 }
 
@@ -567,7 +585,8 @@ int dispatch_m4n(const MfmaPlan& p, const MfmaArgs& a, hipStream_t st) {
 #define SNSDE_N1(KUX_, NHID_, NN_, METH_) \
     if (p.KUXN == KUX_ && p.NHID == NHID_ && p.NN == NN_ && a.method == METH_) return launch_m4n<CfgN<H, KUX_, NHID_, NN_, METH_>>(a, st);
 #define SNSDE_N2(KUX_, NHID_) SNSDE_N1(KUX_, NHID_, 1, SNSDE_SRK) SNSDE_N1(KUX_, NHID_, 2, SNSDE_SRK) \
-                              SNSDE_N1(KUX_, NHID_, 1, SNSDE_MILSTEIN) SNSDE_N1(KUX_, NHID_, 2, SNSDE_MILSTEIN)
+                              SNSDE_N1(KUX_, NHID_, 1, SNSDE_MILSTEIN) SNSDE_N1(KUX_, NHID_, 2, SNSDE_MILSTEIN) \
+                              SNSDE_N1(KUX_, NHID_, 1, SNSDE_EULER) SNSDE_N1(KUX_, NHID_, 2, SNSDE_EULER)
 #define SNSDE_N3(KUX_) SNSDE_N2(KUX_, 0) SNSDE_N2(KUX_, 1) SNSDE_N2(KUX_, 2) SNSDE_N2(KUX_, 3)
     SNSDE_N3(0) SNSDE_N3(2) SNSDE_N3(5)
 #undef SNSDE_N3

@@ -201,7 +201,7 @@ __global__ void snsde_prepare_kernel(const float* __restrict__ params, float* __
 // SRK variant: one step-table row per drift pass (stage times t0, t0 + h, t0 + h/2 = slots 0, 3, 2 of the stage table);
 // outputs are emitted after the last pass of a step only.
 __global__ void snsde_srk_expand_kernel(const float* __restrict__ step_tab, const float* __restrict__ srk_tab,
-                                        float* __restrict__ out, int n_steps) {
+                                        float* __restrict__ out, int n_steps, int raw_time) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= 3 * n_steps) return;
     const int n = i / 3, stg = i - 3 * n;
@@ -209,11 +209,12 @@ __global__ void snsde_srk_expand_kernel(const float* __restrict__ step_tab, cons
     const float* st = step_tab + (size_t)n * SNSDE_STEP_STRIDE;
     const float* tp = srk_tab + ((size_t)n * 4 + slot) * SNSDE_SRK_STRIDE;
     float* o = out + (size_t)i * SNSDE_STEP_STRIDE;
-    o[0] = tp[0]; o[1] = st[1]; o[2] = tp[1]; o[3] = tp[2]; o[4] = tp[3]; o[5] = tp[4]; o[6] = st[6]; o[7] = st[7];
+    o[0] = tp[0]; o[1] = st[1]; o[4] = tp[3]; o[5] = tp[4]; o[6] = st[6]; o[7] = st[7];
+    o[2] = raw_time ? tp[0] : tp[1]; o[3] = raw_time ? 0.0f : tp[2];      // time features: [sin t, cos t] or [t, 0] (SNSDE_TIME_RAW)
     o[8] = stg == 2 ? st[8] : __int_as_float(0); o[9] = st[9];
     // [10], [11]: sin / cos of the DIFFUSION stage time evaluated beside this pass (snsde_m4n_kernel.h): t0, t0 + h/4, t0 + h
     const float* tn = srk_tab + ((size_t)n * 4 + (stg == 0 ? 0 : (stg == 1 ? 1 : 3))) * SNSDE_SRK_STRIDE;
-    o[10] = tn[1]; o[11] = tn[2];
+    o[10] = raw_time ? tn[0] : tn[1]; o[11] = raw_time ? 0.0f : tn[2];
 }
 
 // tutorial-style fields (variant switches of snsde_model / a caller-supplied noise table): the lean 4-row-tile kernels only
@@ -239,7 +240,8 @@ MfmaPlan make_plan(const snsde_solve* s, const SnsdeNet& net, int flavor_hint) {
     const bool y_noise = (no >= 7 && no <= 10);      // raw = phi(y): sqrt y, y^3, sigmoid y, relu y
     if (!(no == 0 || tab_noise || y_noise || noise_net)) return p;
     // SRK / Milstein through a diffusion net: the 4-row-tile kernels of snsde_m4n_kernel.h (embedded or latent-only drifts)
-    const bool m4n = noise_net && s->method != SNSDE_EULER;
+    const bool variant_m = m.activation != 0 || m.drift_output != 0 || m.diffusion_output != 0 || m.time_feature != 0;
+    const bool m4n = noise_net && (s->method != SNSDE_EULER || variant_m);      // (field variants with a net: these kernels, every method)
     const int kuxn = (io == 2 || io == 4 || io == 6) ? (m.input_channels > 32 ? 5 : 2) : 0;
     if (m4n && (flavor_hint == 0 || io == 0 || m.num_hidden_layers > 4 ||
                 !m4n_instantiated(H, kuxn, m.num_hidden_layers - 1, no >= 18 ? 2 : 1, s->method)))
@@ -277,9 +279,15 @@ MfmaPlan make_plan(const snsde_solve* s, const SnsdeNet& net, int flavor_hint) {
     p.LEAN = (p.FL == 1 && !srk && !m4n && p.NN == 0 && (!emb || p.FOLD) && kuxt <= 6 && lean_fits(H, nhid, kuxt, io != 0)) ? 1 : 0;
     const bool variant = m.activation != 0 || m.drift_output != 0 || m.diffusion_output != 0 || m.time_feature != 0 ||
                          s->noise_table != nullptr;
-    if (variant && !(p.LEAN && (s->noise_table == nullptr || no == 12 || no == 13) && (no == 0 || tab_noise) && kuxt <= 3 &&
-                     io != 0 && io != 5 && io != 6))
-        return p;      // tutorial-style fields: lean kernel instantiations with an activation switch only
+    // tutorial-style fields: lean kernel instantiations with an activation switch (Euler / Milstein), or the general kernel's
+    // SRK variant (embedded drifts, C <= 32, H <= 128, a supplied table at the four stage times or no diffusion)
+    if (variant && m4n && (s->noise_table || io == 0)) return p;
+    const bool variant_net = variant && m4n;      // NeuralSDEFunc-shaped fields: snsde_m4n_kernel.h carries the switches
+    const bool variant_srk = variant && srk && !m4n && emb && H <= 128 && p.KUX == 2 && (no == 0 || ((no == 12 || no == 13) && s->noise_table));
+    if (variant && !variant_srk && !variant_net &&
+        !(p.LEAN && (s->noise_table == nullptr || no == 12 || no == 13) && (no == 0 || tab_noise) && kuxt <= 3 &&
+          io != 0 && io != 5 && io != 6))
+        return p;
     // workspace layout: bias rows | time-only diffusion table | SRK pass table | packed fragments | fold temps.  The first
     // three do not depend on the tile flavour / kernel variant, so the backward finds the table whatever forward ran.
     int n = 0, rows = 0, woff = 0;
@@ -495,8 +503,8 @@ int snsde_mfma_launch(const snsde_solve* s, const SnsdeNet& net, hipStream_t str
         if (p.SRK) {
             if (!s->srk_tab) return SNSDE_ERR_NULL;
             hipLaunchKernelGGL(snsde_srk_expand_kernel, dim3((3 * s->n_steps + 127) / 128), dim3(128), 0, stream, s->step_tab,
-                               s->srk_tab, ws + p.srk_tab_off, s->n_steps);
-            if (p.gt_off >= 0) {
+                               s->srk_tab, ws + p.srk_tab_off, s->n_steps, s->model.time_feature == SNSDE_TIME_RAW ? 1 : 0);
+            if (p.gt_off >= 0 && !s->noise_table) {
                 const int rc = snsde_time_table_srk_launch(s->params, s->srk_tab, ws + p.gt_off, net, p.H,
                                                            s->model.noise_option, s->n_steps * 4, stream);
                 if (rc) return rc;
@@ -514,6 +522,8 @@ int snsde_mfma_launch(const snsde_solve* s, const SnsdeNet& net, hipStream_t str
     if (p.SRK) {
         if (s->dW && !s->dU) return SNSDE_ERR_NULL;
         a.step_tab = ws + p.srk_tab_off; a.dU = s->dU; a.dU_out = s->dU_out;
+        a.act = s->model.activation; a.f_out = s->model.drift_output; a.g_out = s->model.diffusion_output;
+        a.raw_time = s->model.time_feature; a.gt_ext = s->noise_table;       // (N, 4, H): the table at the four stage times
     }
     a.row_offset = s->row_offset; a.seed = s->seed; a.seed_dev = s->seed_dev;
     a.B = s->batch; a.L = s->knots; a.C = s->model.input_channels; a.N = s->n_steps; a.T = s->n_out;
@@ -522,6 +532,8 @@ int snsde_mfma_launch(const snsde_solve* s, const SnsdeNet& net, hipStream_t str
     for (int i = 0; i < p.n_layers; ++i) a.w_off[i] = p.layer[i].dst;
     if (p.M4N) {
         a.lean_geo = (p.IO == 5 || p.IO == 6) ? 1 : 0;
+        a.act = s->model.activation; a.f_out = s->model.drift_output; a.g_out = s->model.diffusion_output;
+        a.raw_time = s->model.time_feature;
         if (p.H == 128) return dispatch_m4n_h128(p, a, stream);
         if (p.H == 64) return dispatch_m4n_h64(p, a, stream);
         if (p.H == 32) return dispatch_m4n_h32(p, a, stream);

@@ -421,7 +421,7 @@ __global__ void __launch_bounds__(CF::NT, CF::WPS) snsde_mfma_kernel(MfmaArgs a)
 
     const float sig_theta = snsde_sigmoid(a.params[a.off_theta]);
     const int no = a.no;
-    const float* gt = a.ws + a.gt_off;
+    const float* gt = a.gt_ext ? a.gt_ext : a.ws + a.gt_off;     // (a caller-supplied time-only table: field variants)
 
     // owned state: tile t covers features 32*wave.. ; element e of this lane = feature f0(t) + fsub + (FL ? s : e)
     float yv[TPW][EPT];
@@ -505,7 +505,14 @@ __global__ void __launch_bounds__(CF::NT, CF::WPS) snsde_mfma_kernel(MfmaArgs a)
     auto store_frag = [&](float* buf, int ld, int col0, f32x4 v, bool relu, int save_slot, int lyr) {
         if constexpr (FL) {
             float o = finish(lyr, v);
-            if (relu) o = fmaxf(o, 0.0f);
+            if (relu) {
+                if (__builtin_expect(a.act != 0, 0)) {     // field variants (SRK of the tutorial-style fields): LipSwish / SiLU
+                    const float sg = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(o * -1.4426950408889634f));
+                    o = (a.act == SNSDE_ACT_LIPSWISH ? 0.909f : 1.0f) * o * sg;
+                } else {
+                    o = fmaxf(o, 0.0f);
+                }
+            }
             buf[r * ld + col0 + fsub + s] = o;
             if (save_slot >= 0 && a.act_save && row_ok)
                 a.act_save[(((size_t)save_step * CF::NSAVE + save_slot) * B + row) * H + wave * 16 + fsub + s] = o;
@@ -611,7 +618,7 @@ __global__ void __launch_bounds__(CF::NT, CF::WPS) snsde_mfma_kernel(MfmaArgs a)
                             sk_dw[e] = a.dW[off];
                             sk_du[e] = a.dU[off];
                         }
-                        if (a.gt_off >= 0) {
+                        if (a.gt_off >= 0 || a.gt_ext) {
                             const float* gp = gt + (size_t)ns * 4 * H + fcol[0] + e;
                             sk_t0[e] = gp[0]; sk_t1[e] = gp[H]; sk_t3[e] = gp[3 * H];
                         }
@@ -814,11 +821,14 @@ __global__ void __launch_bounds__(CF::NT, CF::WPS) snsde_mfma_kernel(MfmaArgs a)
                 zsave[e] = z;
                 const float y = yv[t][e];
                 if constexpr (CF::GEO) z *= fast_tanh(y);
-                const float f = fast_tanh(z);
+                float f = fast_tanh(z);
                 if constexpr (CF::SRK) {
+                    // field variants (tutorial-style fields): f = z or z * (the pass's input state), g = raw
+                    if (__builtin_expect(a.f_out != 0, 0)) f = a.f_out == SNSDE_DRIFT_TIMES_Y ? z * y : z;
                     auto gfun = [&](float gq, float yy) {
                         float q1, q2;
                         const float raw = yfun ? snsde_phi(no, yy, q1, q2) : (mul_y ? gq * yy : gq);
+                        if (__builtin_expect(a.g_out != 0, 0)) return raw;
                         return fast_tanh(sig_theta * snsde_nan_to_num(raw));
                     };
                     const float yb = sk_y[e], f0 = sk_f0[e], g0 = sk_g0[e];

@@ -290,6 +290,13 @@ def srk_table(grid):
     return grid._d_srk
 
 
+def srk_stage_times(grid):
+    """Device (4 N,) tensor of the SRID2 stage times t0 + {0, 1/4, 1/2, 1} h of every step (column 0 of the stage table)."""
+    if getattr(grid, '_d_srk_times', None) is None:
+        grid._d_srk_times = srk_table(grid)[:, :, 0].reshape(-1).contiguous()
+    return grid._d_srk_times
+
+
 def step_grid(ts_host, dt, times_host, device):
     key = (np.asarray(ts_host, dtype=np.float32).tobytes(), float(dt),
            np.asarray(times_host, dtype=np.float32).tobytes(), str(device))
@@ -337,8 +344,8 @@ class SolveCall:
         if row_out is not None:
             if row_out.dtype != torch.int32 or not row_out.is_cuda or not row_out.is_contiguous() or tuple(row_out.shape) != (B,):
                 raise ValueError('row_out must be a contiguous int32 CUDA tensor of shape (batch,)')
-        if noise_table is not None:
-            _check_f32('noise_table', noise_table, (grid.N, H))
+        if noise_table is not None:      # the time-only diffusion factor per step (SRK: at the step's four stage times)
+            _check_f32('noise_table', noise_table, (4 * grid.N if method == 'srk' else grid.N, H))
         if z0_linear is not None:     # (weight (H, C), bias (H)): y0 is then an output, filled by the solve's prepare launch
             _check_f32('z0 weight', z0_linear[0], (H, C_))
             _check_f32('z0 bias', z0_linear[1], (H,))

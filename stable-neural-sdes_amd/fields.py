@@ -23,7 +23,7 @@ from . import _lib, engine
 
 ACT_RELU, ACT_LIPSWISH, ACT_SILU = 0, 1, 2
 DRIFT_TANH, DRIFT_LINEAR, DRIFT_TIMES_Y = 0, 1, 2
-DIFFUSION_TANH, DIFFUSION_RAW = 0, 1
+DIFFUSION_TANH, DIFFUSION_RAW, DIFFUSION_RAW_NET = 0, 1, 2
 TIME_SINCOS, TIME_RAW = 0, 1
 
 _PROBE = torch.tensor([-3.0, -1.0, -0.25, 0.0, 0.5, 1.0, 2.5])
@@ -83,7 +83,11 @@ class ComposedField:
     def __init__(self, sde, model, layout, numel, parts, additive):
         self.sde, self.model, self.layout, self.numel = sde, model, layout, numel
         self.parts, self.additive = parts, additive
+        # tabulated: the diffusion is (a function of time alone) x {1, y}, handed to the kernel as a per-step table; False: the
+        # NeuralSDEFunc shape, whose diffusion is an MLP of [t, y] evaluated by the net kernels from the composed block
+        self.tabulated = 'noise_first' not in parts
         self.verified = {}        # device -> bool (one-step probe through the kernel)
+        self.trust_versions = False
         self._flat_cache = None
         self._tab_cache = None
         self._proj = None
@@ -94,6 +98,8 @@ class ComposedField:
         parameters, two small launches and one host read - because in-place updates through `param.data` (p.data.add_(..),
         clamp_ ...) leave the version counter untouched."""
         params = list(self.sde.parameters())
+        if self.trust_versions:      # caller's promise (options={'trust_versions': True}): parameters change through autograd /
+            return (str(dev),) + tuple((q.data_ptr(), q._version) for q in params)      # optimizers only - no host read-back
         vec = torch.cat([q.detach().reshape(-1).to(device=dev, dtype=torch.float32) for q in params])
         if self._proj is None or self._proj.numel() != vec.numel() or self._proj.device != vec.device:
             gen = torch.Generator().manual_seed(0x5DE)
@@ -128,9 +134,41 @@ class ComposedField:
             with torch.no_grad():
                 hit = (key, self._flat(dev, False))
             self._flat_cache = hit
-        return hit[1], self.noise_table(t0s, dev, param_key=key)
+        return hit[1], (self.noise_table(t0s, dev, param_key=key) if self.tabulated else None)
+
+    def _flat_net(self, dev, grad):
+        """NeuralSDEFunc: f = f_net(linear_in([t, y])), g = g_net(noise_in([t, y])) as the block of (input_option 3,
+        noise_option 18): linear_in' = f_net[0] o linear_in on [t, 0, y], hidden `linears`, linear_out' = f_net[-1];
+        noise_y.0' = g_net[0] o noise_in, noise_y.2 = g_net[1]."""
+        p = self.parts
+        H, C_ = self.model.hidden_channels, self.model.input_channels
+        f64 = dict(device=dev, dtype=torch.float32 if grad else torch.float64)
+        W = lambda lin: (lin.weight if grad else lin.weight.detach()).to(**f64)
+        b = lambda lin: (lin.bias if grad else lin.bias.detach()).to(**f64)
+
+        def first(outer, inner):      # outer o inner, inner on [t, y] -> columns [t, 0, y]
+            w = W(outer) @ W(inner)
+            return torch.cat([w[:, :1], torch.zeros(w.shape[0], 1, **f64), w[:, 1:]], dim=1), W(outer) @ b(inner) + b(outer)
+        vals = {'theta': torch.zeros(1, 1, **f64),
+                'initial_network.weight': torch.zeros(H, C_, **f64), 'initial_network.bias': torch.zeros(H, **f64)}
+        vals['linear_in.weight'], vals['linear_in.bias'] = first(p['mlp'][0], p['linear_in'])
+        for i, lin in enumerate(p['mlp'][1:-1]):
+            vals[f'linears.{i}.weight'], vals[f'linears.{i}.bias'] = W(lin), b(lin)
+        vals['linear_out.weight'], vals['linear_out.bias'] = W(p['mlp'][-1]), b(p['mlp'][-1])
+        vals['noise_y.0.weight'], vals['noise_y.0.bias'] = first(p['noise_first'], p['noise_in'])
+        vals['noise_y.2.weight'], vals['noise_y.2.bias'] = W(p['noise_last']), b(p['noise_last'])
+        pieces = []
+        for name, off, shape in self.layout:
+            v = vals[name]
+            assert tuple(v.shape) == tuple(shape), (name, tuple(v.shape), shape)
+            pieces.append(v.reshape(-1).to(torch.float32))
+        out = torch.cat(pieces)
+        assert out.numel() == self.numel
+        return out
 
     def _flat(self, dev, grad):
+        if not self.tabulated:
+            return self._flat_net(dev, grad)
         p = self.parts
         H = self.model.hidden_channels
         # float64 products for the (cached) inference block; training composes in float32: a third of the launches, and the
@@ -194,6 +232,8 @@ def compose(sde):
     if cached is not None:
         return cached[0]
     result = _compose(sde)
+    if not torch.is_tensor(getattr(sde, 'coeffs', None)):
+        return result          # (before set_X: the control path's channel count is not known yet - do not memoise)
     try:
         object.__setattr__(sde, '_snsde_composed', (result,))
     except Exception:
@@ -206,8 +246,12 @@ def _compose(sde):
         return None
     if getattr(sde, 'sde_type', None) != 'ito' or getattr(sde, 'noise_type', None) != 'diagonal':
         return None
+    if hasattr(sde, 'input_option'):
+        return None
+    if all(hasattr(sde, a) for a in ('linear_in', 'f_net', 'noise_in', 'g_net', 'f', 'g')) and not hasattr(sde, 'emb'):
+        return _compose_net(sde)
     need = ('linear_X', 'emb', 'f_net', 'linear_out', 'noise_in', 'g_net', 'f', 'g')
-    if not all(hasattr(sde, a) for a in need) or hasattr(sde, 'input_option'):
+    if not all(hasattr(sde, a) for a in need):
         return None
     lin_X, emb, lin_out = sde.linear_X, sde.emb, sde.linear_out
     if not isinstance(lin_X, torch.nn.Linear) or lin_X.bias is None:
@@ -260,6 +304,34 @@ def _compose(sde):
     return field
 
 
+def _compose_net(sde):
+    """tutorial/simple OU process - Neural SDE.ipynb, NeuralSDEFunc: drift AND diffusion are MLPs of [t, y] (no control path
+    inside the field).  Maps onto (input_option 3, noise_option 18) with the variant switches; the kernels evaluate two-layer
+    nets, so g_net must be Linear, act, Linear (the notebook's num_layers = 1) and every width the hidden size."""
+    lin_in, noise_in = sde.linear_in, sde.noise_in
+    if not isinstance(lin_in, torch.nn.Linear) or lin_in.bias is None:
+        return None
+    H = lin_in.out_features
+    if not _is_linear(lin_in, H + 1, H) or not _is_linear(noise_in, H + 1, H):
+        return None
+    fc, gc = _mlp_chain(sde.f_net), _mlp_chain(sde.g_net)
+    if fc is None or gc is None or fc[1] != gc[1] or len(gc[0]) != 2 or len(fc[0]) > 4:
+        return None
+    mlp, act = fc
+    if any(m.in_features != H or m.out_features != H for m in mlp + gc[0]):
+        return None
+    coeffs = getattr(sde, 'coeffs', None)
+    C_ = int(coeffs.shape[-1]) // 4 if torch.is_tensor(coeffs) and coeffs.dim() == 3 else 1
+    model = engine.model_struct(C_, H, H, len(mlp) - 1, 3, 18, activation=act, drift_output=DRIFT_LINEAR,
+                                diffusion_output=DIFFUSION_RAW_NET, time_feature=TIME_RAW)
+    try:
+        layout, numel = _lib.param_layout(model)
+    except _lib.SnsdeError:
+        return None
+    parts = dict(linear_in=lin_in, mlp=mlp, noise_in=noise_in, noise_first=gc[0][0], noise_last=gc[0][1])
+    return ComposedField(sde, model, layout, numel, parts, additive=False)
+
+
 @torch.no_grad()
 def verify(field, coeffs, times_host, dev):
     """One-step probe THROUGH THE KERNEL against the module's own f / g on the first rows of the batch: fixes
@@ -289,7 +361,7 @@ def verify(field, coeffs, times_host, dev):
         hh = float(grid.t1[0] - grid.t0[0])
         tt = torch.tensor(float(grid.t0[0]), device=dev)
         f_ref, g_ref = sde.f(tt, y0).float(), sde.g(tt, y0).float()
-        tab = field.noise_table(torch.from_numpy(grid.t0), dev)
+        tab = field.noise_table(torch.from_numpy(grid.t0), dev) if field.tabulated else None
         flat = field.flat(dev)
         scale_f = float(f_ref.abs().max()) + 1e-6
         scale_g = float(g_ref.abs().max()) + 1e-6
@@ -306,7 +378,7 @@ def verify(field, coeffs, times_host, dev):
 
     try:
         sde.set_X(c, sde.times) if hasattr(sde, 'set_X') else None
-        for drift in (DRIFT_LINEAR, DRIFT_TIMES_Y):
+        for drift in ((DRIFT_LINEAR, DRIFT_TIMES_Y) if field.tabulated else (DRIFT_LINEAR,)):
             if probe(0.31, drift) and probe(0.67, drift):
                 ok = True
                 break

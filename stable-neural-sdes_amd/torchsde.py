@@ -161,7 +161,7 @@ def sdeint(sde, y0, ts, bm=None, method=None, dt=1e-3, adaptive=False, rtol=1e-5
         if not y0.is_cuda:
             raise ValueError("the HIP engine needs CUDA (ROCm) tensors")
         return _sdeint_hip(sde, rec, y0, ts, bm, method, float(dt), options)
-    if default_names and rec is None and backend == 'auto' and y0.is_cuda and method in ('euler', 'milstein'):
+    if default_names and rec is None and backend == 'auto' and y0.is_cuda:
         ys = _sdeint_composed(sde, y0, ts, bm, method, float(dt), options)     # tutorial-style fields (fields.py)
         if ys is not None:
             return ys
@@ -325,10 +325,17 @@ def _sdeint_composed(sde, y0, ts, bm, method, dt, options):
     if not fields.verify(field, coeffs, times_host, dev):
         return None
     grid = engine.step_grid(_HostTimes.get(ts), dt, times_host, dev)
-    dW = None
+    dW = dU = None
     if bm is not None:
         t0, t1 = torch.from_numpy(grid.t0), torch.from_numpy(grid.t1)
-        dW = torch.stack([bm(t0[n], t1[n]).to(device=dev, dtype=torch.float32) for n in range(grid.N)]).contiguous()
+        if method == 'srk':
+            pairs = [bm(t0[n], t1[n], return_U=True) for n in range(grid.N)]
+            dW = torch.stack([p[0].to(device=dev, dtype=torch.float32) for p in pairs]).contiguous()
+            dU = torch.stack([p[1].to(device=dev, dtype=torch.float32) for p in pairs]).contiguous()
+        else:
+            dW = torch.stack([bm(t0[n], t1[n]).to(device=dev, dtype=torch.float32) for n in range(grid.N)]).contiguous()
+    # the times the time-only diffusion factor is tabulated at: the step times; SRK: the four stage times of every step
+    tab_times = grid.d_t0 if method != 'srk' else engine.srk_stage_times(grid)
     seed = options.get('seed')
     if seed is None:     # recorded solves read a device-resident key that the recording itself advances: fresh noise per replay
         seed = _capture_seed(dev) if capturing else _fresh_seed()
@@ -345,13 +352,17 @@ def _sdeint_composed(sde, y0, ts, bm, method, dt, options):
     if needs_grad:
         # training: the composition and the module's own g stay in the autograd graph; the solve between them is the fused
         # forward + adjoint + weight-gradient pass (flat-block and table gradients flow back through those graphs)
-        if engine.backward_mode(field.model, int(y0.shape[0]), coeffs.shape[1] + 1, grid, method, table=True) != 1:
+        if engine.backward_mode(field.model, int(y0.shape[0]), coeffs.shape[1] + 1, grid, method, table=field.tabulated) != 1:
             return None
         flat = field.flat(dev, grad=True)
-        tab = field.noise_table(grid.d_t0, dev, grad=True)
+        tab = field.noise_table(tab_times, dev, grad=True) if field.tabulated else None
         return _ComposedSolve.apply(field.model, coeffs, grid, dW, method, seed, int(row_offset), row_out, y0, flat, tab)
-    flat, tab = field.inference_inputs(grid.d_t0, dev)
-    call = engine.SolveCall(field.model, flat, coeffs, grid, y0.detach().to(torch.float32).contiguous(), dW=dW,
+    # options={'trust_versions': True}: the cached composed block / table are keyed on the parameters' addresses and version
+    # counters alone (no content fingerprint = no device->host read per solve); in-place edits through `.data` are then the
+    # caller's to avoid
+    field.trust_versions = bool(options.get('trust_versions', False))
+    flat, tab = field.inference_inputs(tab_times, dev)
+    call = engine.SolveCall(field.model, flat, coeffs, grid, y0.detach().to(torch.float32).contiguous(), dW=dW, dU=dU,
                             method=method, seed=seed, row_offset=int(row_offset), row_out=row_out, noise_table=tab)
     try:
         return call.launch().to(y0.dtype)

@@ -296,9 +296,30 @@ def g4(ref, ref_fc, ists, interp, tsde, out):
 
 
 # ------------------------------------------------------------------------------------------------
-def torch_step_grid_and_solve(model, y0, ts, dt, dW, method):
+def _srid2_step(model, t0, h, y, I_k, I_k0):
+    """One SRID2 step (torchsde's `srk` for diagonal noise; tableau restated in oracle/sde_oracle.py) on the module's f / g."""
+    sys.path.insert(0, os.path.dirname(os.path.dirname(HERE))) if os.path.dirname(os.path.dirname(HERE)) not in sys.path else None
+    from oracle import sde_oracle as O
+    rdt = h ** 0.5
+    I_kk = (I_k * I_k - h) / 2
+    I_kkk = (I_k ** 3 - 3 * h * I_k) / 6
+    fs, gs = [], []
+    y1 = y
+    for s_ in range(4):
+        H0, H1 = y, y
+        for j in range(s_):
+            H0 = H0 + O.SRK_A0[s_][j] * fs[j] * h + O.SRK_B0[s_][j] * gs[j] * I_k0 / h
+            H1 = H1 + O.SRK_A1[s_][j] * fs[j] * h + O.SRK_B1[s_][j] * gs[j] * rdt
+        fs.append(model.f(t0 + O.SRK_C0[s_] * h, H0))
+        gs.append(model.g(t0 + O.SRK_C1[s_] * h, H1))
+        gw = O.SRK_BETA1[s_] * I_k + O.SRK_BETA2[s_] * I_kk / rdt + O.SRK_BETA3[s_] * I_k0 / h + O.SRK_BETA4[s_] * I_kkk / h
+        y1 = y1 + O.SRK_ALPHA[s_] * fs[s_] * h + gw * gs[s_]
+    return y1
+
+
+def torch_step_grid_and_solve(model, y0, ts, dt, dW, method, dU=None):
     """torchsde 0.2.5 fixed-step integrate semantics written with torch ops,
-    driving the REFERENCE module's f/g.  dW[n] plays bm(t0_n, t1_n)."""
+    driving the REFERENCE module's f/g.  dW[n] plays bm(t0_n, t1_n) (SRK: dU[n] the space-time Levy integral)."""
     curr_t = ts[0]
     prev_t = ts[0]
     curr_y = prev_y = y0
@@ -314,6 +335,8 @@ def torch_step_grid_and_solve(model, y0, ts, dt, dW, method):
                 f = model.f(curr_t, curr_y)
                 g = model.g(curr_t, curr_y)
                 curr_y = curr_y + f * h + g * I
+            elif method == 'srk':
+                curr_y = _srid2_step(model, curr_t, h, curr_y, I, dU[n])
             else:
                 with torch.enable_grad():
                     yy = curr_y.detach().requires_grad_(True)

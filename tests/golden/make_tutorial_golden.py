@@ -30,6 +30,11 @@ NOTEBOOKS = [
      'euler'),
     ('gsde', 'simple OU process - Neural GSDE.ipynb', 'NeuralGSDEFunc', 'gsde', 32, 2, 'lipswish', 'euler'),
     ('gsde_milstein', 'simple OU process - Neural GSDE.ipynb', 'NeuralGSDEFunc', 'gsde', 64, 1, 'lipswish', 'milstein'),
+    ('gsde_srk', 'simple OU process - Neural GSDE (srk solver).ipynb', 'NeuralGSDEFunc', 'gsde', 32, 1, 'lipswish', 'srk'),
+    ('lnsde_srk', 'simple OU process - Neural LNSDE.ipynb', 'NeuralLNSDEFunc', 'lnsde', 64, 2, 'lipswish', 'srk'),
+    ('nsde', 'simple OU process - Neural SDE.ipynb', 'NeuralSDEFunc', 'nsde', 32, 1, 'lipswish', 'euler'),
+    ('nsde_srk', 'simple OU process - Neural SDE.ipynb', 'NeuralSDEFunc', 'nsde', 64, 1, 'lipswish', 'srk'),
+    ('nsde_relu', 'simple OU process - Neural SDE.ipynb', 'NeuralSDEFunc', 'nsde', 16, 1, 'relu', 'milstein'),
 ]
 
 
@@ -75,17 +80,19 @@ def main():
                 nxt = min(curr + dt, ts[-1])
                 hs.append(nxt - curr)
                 curr = nxt
-        dW = torch.randn(N, B, H, generator=gen) * torch.stack(hs).sqrt().view(N, 1, 1)
+        hv = torch.stack(hs).view(N, 1, 1)
+        dW = torch.randn(N, B, H, generator=gen) * hv.sqrt()
+        dU = hv * (0.5 * dW + (hv / 12).sqrt() * torch.randn(N, B, H, generator=gen)) if method == 'srk' else None
         probe_t = torch.tensor([0.0, 0.37, 1.0])
         with torch.no_grad():
             fs = torch.stack([m.f(t, y0) for t in probe_t])
             gs = torch.stack([m.g(t, y0) for t in probe_t])
-            ys32, n32 = G.torch_step_grid_and_solve(m, y0, ts, dt, dW, method)
+            ys32, n32 = G.torch_step_grid_and_solve(m, y0, ts, dt, dW, method, dU)
         md = Func(C, H, H, layers, activation=act).double()
         md.load_state_dict({k: v.double() for k, v in sd.items()})
         md.set_X(coeffs.double(), times.double())
         with torch.no_grad():
-            ys64, n64 = G.torch_step_grid_and_solve(G._F64Times(md), y0.double(), ts, dt, dW.double(), method)
+            ys64, n64 = G.torch_step_grid_and_solve(G._F64Times(md), y0.double(), ts, dt, dW.double(), method, None if dU is None else dU.double())
         assert n32 == N and n64 == N
         k = f'T1/{key}'
         out[f'{k}/meta'] = np.array([C, H, layers])
@@ -96,6 +103,8 @@ def main():
         out[f'{k}/coeffs'] = G.npy(coeffs)
         out[f'{k}/y0'] = G.npy(y0)
         out[f'{k}/dW'] = G.npy(dW)
+        if dU is not None:
+            out[f'{k}/dU'] = G.npy(dU)
         out[f'{k}/dt'] = np.float64(dt)
         out[f'{k}/probe_t'] = G.npy(probe_t)
         out[f'{k}/f'] = G.npy(fs)

@@ -14,12 +14,14 @@ pytestmark = pytest.mark.gpu
 
 
 class Replay:
-    def __init__(self, dW):
-        self.dW, self.n = dW, 0
+    levy_area_approximation = 'space-time'
+
+    def __init__(self, dW, dU=None):
+        self.dW, self.dU, self.n = dW, dU, 0
 
     def __call__(self, ta, tb, return_U=False):
         i, self.n = self.n, self.n + 1
-        return self.dW[i]
+        return (self.dW[i], self.dU[i]) if return_U else self.dW[i]
 
 
 def problem(seed, B, H, C, L, kind, layers, act, dev):
@@ -276,11 +278,16 @@ def test_fused_path_vs_trajectories_of_the_reference_notebooks_fields(case):
     field = field.to(dev)
     times = torch.from_numpy(g['times']).to(dev)
     field.set_X(torch.from_numpy(g['coeffs']).to(dev), times)
+    method = str(g['method'])
+    dU = torch.from_numpy(g['dU']).to(dev) if 'dU' in g else None
     with torch.no_grad():
-        ys = S.sdeint(field, torch.from_numpy(g['y0']).to(dev), times, dt=float(g['dt']), method=str(g['method']),
-                      bm=Replay(torch.from_numpy(g['dW']).to(dev)))
+        ys = S.sdeint(field, torch.from_numpy(g['y0']).to(dev), times, dt=float(g['dt']), method=method,
+                      bm=Replay(torch.from_numpy(g['dW']).to(dev), dU))
     cf = fields.compose(field)
     assert cf is not None and any(v is True for v in cf.verified.values()), 'the field did not take the fused path'
+    B, L = g['y0'].shape[0], g['times'].shape[0]
+    assert S.engine.forward_path(cf.model, B, L, g['dW'].shape[0], method=method, kernel='auto', table=cf.tabulated) != 'none', \
+        f'no fused kernel for this field under {method}'
     ref = g['ys64']
     scale = np.abs(ref).max()
     err = np.abs(ys.double().cpu().numpy() - ref).max()

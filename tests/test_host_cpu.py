@@ -676,8 +676,12 @@ def test_c_abi_variant_fields_validate():
     L = _lib.lib()
     ok = engine.model_struct(3, 32, 32, 2, 4, 13, activation=1, drift_output=2, diffusion_output=1, time_feature=1)
     assert L.snsde_param_count(C.byref(ok)) > 0
-    for kw in (dict(activation=3), dict(drift_output=3), dict(diffusion_output=2), dict(time_feature=2), dict(activation=-1)):
+    for kw in (dict(activation=3), dict(drift_output=3), dict(diffusion_output=2), dict(diffusion_output=3), dict(time_feature=2),
+               dict(activation=-1)):
         assert L.snsde_param_count(C.byref(engine.model_struct(3, 32, 32, 2, 4, 13, **kw))) < 0
+    # SNSDE_DIFFUSION_RAW_NET (the un-rectified two-layer net of the tutorial's NeuralSDEFunc): noise_option 18 / 19 only
+    assert L.snsde_param_count(C.byref(engine.model_struct(3, 32, 32, 1, 3, 18, activation=1, drift_output=1, diffusion_output=2,
+                                                           time_feature=1))) > 0
 
 
 def test_forward_path_query_names_the_kernel_family():
@@ -859,9 +863,10 @@ def test_tutorial_field_class_reproduces_the_notebooks_fields(case):
 
     class Replay:
         n = 0
-        def __call__(self, ta, tb):
+        def __call__(self, ta, tb, return_U=False):
             self.n += 1
-            return torch.from_numpy(g['dW'][self.n - 1]).double()
+            w = torch.from_numpy(g['dW'][self.n - 1]).double()
+            return (w, torch.from_numpy(g['dU'][self.n - 1]).double()) if return_U else w
     with torch.no_grad():
         ys = S.sdeint(f64, y0.double(), times, bm=Replay(), dt=float(g['dt']), method=str(g['method']),
                       options={'backend': 'torch'})

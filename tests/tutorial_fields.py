@@ -31,7 +31,8 @@ class MLP(nn.Module):
 
 class TutorialField(nn.Module):
     """kind: 'lsde' (f on [y | X], additive g(t)), 'lnsde' (f on [t, y | X], g(t) * y with the saturating time
-    feature), 'lnsde_additive', 'gsde' (f * y, g(t) * y)."""
+    feature), 'lnsde_additive', 'gsde' (f * y, g(t) * y), 'nsde' (the Neural SDE notebook's NeuralSDEFunc: f and g both MLPs
+    of [t, y], no control path in the field)."""
 
     def __init__(self, kind, input_dim, hidden_dim, num_layers, activation='lipswish'):
         super().__init__()
@@ -39,11 +40,12 @@ class TutorialField(nn.Module):
         self.sde_type, self.noise_type = 'ito', 'diagonal'
         if kind != 'lsde':
             self.linear_in = nn.Linear(hidden_dim + 1, hidden_dim)
-        self.linear_X = nn.Linear(input_dim, hidden_dim)
-        self.emb = nn.Linear(2 * hidden_dim, hidden_dim)
+        if kind != 'nsde':
+            self.linear_X = nn.Linear(input_dim, hidden_dim)
+            self.emb = nn.Linear(2 * hidden_dim, hidden_dim)
         self.f_net = MLP(hidden_dim, hidden_dim, hidden_dim, num_layers, activation)
         self.linear_out = nn.Linear(hidden_dim, hidden_dim)
-        self.noise_in = nn.Linear(1, hidden_dim)
+        self.noise_in = nn.Linear(hidden_dim + 1 if kind == 'nsde' else 1, hidden_dim)
         self.g_net = MLP(hidden_dim, hidden_dim, hidden_dim, num_layers, activation)
         if kind.startswith('lnsde'):
             self.time_rate = nn.Parameter(torch.tensor(1.0))
@@ -58,6 +60,8 @@ class TutorialField(nn.Module):
         return t
 
     def f(self, t, y):
+        if self.kind == 'nsde':
+            return self.f_net(self.linear_in(torch.cat((self._t(t, y), y), dim=-1)))
         Xt = self.linear_X(self.X.evaluate(t))
         if self.kind == 'lsde':
             yy = y
@@ -68,6 +72,8 @@ class TutorialField(nn.Module):
 
     def g(self, t, y):
         t = self._t(t, y)
+        if self.kind == 'nsde':
+            return self.g_net(self.noise_in(torch.cat((t, y), dim=-1)))
         if self.kind.startswith('lnsde'):
             t = 1.0 - torch.exp(-torch.nn.functional.softplus(self.time_rate) * t)
         s = self.g_net(self.noise_in(t))
