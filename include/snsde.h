@@ -213,13 +213,15 @@ typedef struct snsde_backward {
 int    snsde_act_slots(const snsde_model* m);             /* activation tensors saved per step, or <0: layer outputs (first, hidden.., */
                                                           /* pre-tanh drift) [+ diffusion-net slots]; models with a smooth activation  */
                                                           /* (SNSDE_ACT_LIPSWISH / SILU) also save every pre-activation (NL more slots) */
-int    snsde_save_layout(const snsde_solve* s, int32_t* act_slots, int32_t* stage_planes);
+int    snsde_save_layout(const snsde_solve* s, int32_t* act_slots, int32_t* stage_planes, int32_t* delta_slots);
                                                           /* training-mode buffers of THIS solve (model + method): act_save /     */
                                                           /* delta_save are (passes, act_slots, B, H), stage_save (passes + 1,     */
                                                           /* stage_planes, B, H); passes = N (3N for SRK).  SRK through a          */
                                                           /* diffusion net (noise_option 14/15/18/19) saves a second set of net    */
                                                           /* slots (the step's fourth diffusion evaluation) and three stage planes */
-                                                          /* (drift input H0 | diffusion input H1 | H1 of the fourth evaluation)   */
+                                                          /* (drift input H0 | diffusion input H1 | H1 of the fourth evaluation);  */
+                                                          /* delta_save is (passes, delta_slots, B, H): act_slots, plus the tangent */
+                                                          /* factors of Milstein through a diffusion net                            */
 int    snsde_backward_supported(const snsde_solve* s);    /* 1 / 2 / 0, see above                          */
 size_t snsde_backward_workspace_bytes(const snsde_backward* b);
 int    snsde_solve_backward(const snsde_backward* b, void* hip_stream);

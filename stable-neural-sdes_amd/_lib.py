@@ -103,7 +103,7 @@ def lib():
                                              C.c_size_t, C.c_void_p]
     L.snsde_hermite_coeffs.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p]
     L.snsde_act_slots.argtypes = [C.POINTER(Model)]
-    L.snsde_save_layout.argtypes = [C.POINTER(Solve), C.POINTER(C.c_int32), C.POINTER(C.c_int32)]
+    L.snsde_save_layout.argtypes = [C.POINTER(Solve), C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_int32)]
     L.snsde_param_gradients_workspace_bytes.argtypes = [C.POINTER(Backward)]
     L.snsde_param_gradients_workspace_bytes.restype = C.c_size_t
     L.snsde_param_gradients.argtypes = [C.POINTER(Backward), C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]

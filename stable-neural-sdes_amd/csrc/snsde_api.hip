@@ -428,7 +428,7 @@ int snsde_act_slots(const snsde_model* m) {
            (m->activation != SNSDE_ACT_RELU ? m->num_hidden_layers : 0);
 }
 
-int snsde_save_layout(const snsde_solve* s, int32_t* act_slots, int32_t* stage_planes) {
+int snsde_save_layout(const snsde_solve* s, int32_t* act_slots, int32_t* stage_planes, int32_t* delta_slots) {
     if (!s) return SNSDE_ERR_NULL;
     int slots = snsde_act_slots(&s->model);
     if (slots < 0) return slots;
@@ -438,6 +438,8 @@ int snsde_save_layout(const snsde_solve* s, int32_t* act_slots, int32_t* stage_p
     if (s->method == SNSDE_SRK && nn > 0) { slots += nn; planes = 3; }
     if (act_slots) *act_slots = slots;
     if (stage_planes) *stage_planes = planes;
+    // Milstein through a diffusion net: the adjoint also leaves the tangent pass's factors (second-order parameter terms)
+    if (delta_slots) *delta_slots = slots + ((s->method == SNSDE_MILSTEIN && nn > 0) ? (nn == 2 ? 3 : 1) : 0);
     return SNSDE_OK;
 }
 

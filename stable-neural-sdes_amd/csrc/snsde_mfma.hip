@@ -27,7 +27,7 @@
 #include <stddef.h>
 
 #include "snsde_m4_kernel.h"
-#include "snsde_m4n_rev_kernel.h"
+#include "snsde_m4n_mil_rev_kernel.h"
 
 using namespace snsde_mfma;
 
@@ -385,9 +385,12 @@ RevPlan make_rev_plan(const snsde_solve* s, const SnsdeNet& net, const MfmaPlan&
     p.ok = false;
     if (!fp.ok || (s->method != SNSDE_EULER && s->method != SNSDE_MILSTEIN && s->method != SNSDE_SRK)) return p;
     // diffusion nets: Euler on the general adjoint kernel, SRK on snsde_m4n_rev_kernel.h (Milstein: the generic adjoint)
-    const bool m4n_rev = fp.M4N && s->method == SNSDE_SRK && m4n_rev_instantiated(fp.H, fp.NHID, fp.NN);
+    const bool m4n_rev = fp.M4N && !variant_of(s) &&
+                         ((s->method == SNSDE_SRK && m4n_rev_instantiated(fp.H, fp.NHID, fp.NN)) ||
+                          (s->method == SNSDE_MILSTEIN && m4n_mil_rev_instantiated(fp.H, fp.NHID, fp.NN)));
     if (fp.NN != 0 && s->method != SNSDE_EULER && !m4n_rev) return p;
-    p.M4N = m4n_rev ? 1 : 0;
+    if (fp.M4N && s->method == SNSDE_EULER) return p;       // (Euler on the net kernels = the field variants: no fused backward)
+    p.M4N = m4n_rev ? (s->method == SNSDE_SRK ? 1 : 2) : 0;
     // tutorial-style fields: the register-resident lean forward (its training-mode instantiations), Euler / Milstein
     if (variant_of(s) && !(fp.LEAN && fp.FL == 1 && fp.H <= 128 && !fp.SRK && s->method != SNSDE_SRK &&
                            (s->model.activation == SNSDE_ACT_RELU || lean_act_save_fits(fp.H, fp.NHID, fp.KUXT)) &&
@@ -411,13 +414,27 @@ RevPlan make_rev_plan(const snsde_solve* s, const SnsdeNet& net, const MfmaPlan&
     };
     // fold temp first (so its offset is known to the pack job)
     int fold_tmp = -1;
-    const int packed = (p.NHID + 2 + p.NN) * p.NW * (H / 16) * 256;
+    const int packed = (p.NHID + 2 + (p.M4N == 2 ? 2 * p.NN : p.NN)) * p.NW * (H / 16) * 256;
     if (p.emb) fold_tmp = packed;
     add_t(net.out, 0, -1);
     for (int l = p.NHID - 1; l >= 0; --l) add_t(net.hid[l], 0, -1);
     if (!p.IO0) add_t(net.in, net.in.tshift, fold_tmp);      // the y-free drift has no first_y^T
-    if (p.NN == 2) add_t(net.ny1, 0, -1);                   // diffusion net, output layer first
-    if (p.NN >= 1) add_t(net.ny0, net.ny0.tshift, -1);      // its y columns
+    if (p.M4N == 2) {
+        // Milstein through the net (snsde_m4n_mil_rev_kernel.h): forward-layout W1_y, [W2], then [W2^T], W1_y^T
+        auto add_f = [&](const SnsdeLayer& L, int tshift) {
+            MfmaLayerPack& q = p.layer[n++];
+            q = MfmaLayerPack{};
+            q.src_w = L.src_w; q.src_b = L.src_b; q.K = L.K; q.N = H; q.KU = H / 16; q.dst = off; q.tshift = tshift;
+            q.bias_row = -1; q.fold_tmp = -1;        // (KU = H / 16 blocks: the y columns only, the rotated time columns fall off)
+            off += p.NW * (H / 16) * 256;
+        };
+        add_f(net.ny0, net.ny0.tshift);
+        if (p.NN == 2) { add_f(net.ny1, 0); add_t(net.ny1, 0, -1); }
+        add_t(net.ny0, net.ny0.tshift, -1);
+    } else {
+        if (p.NN == 2) add_t(net.ny1, 0, -1);                   // diffusion net, output layer first
+        if (p.NN >= 1) add_t(net.ny0, net.ny0.tshift, -1);      // its y columns
+    }
     p.n_layers = n;
     p.fold_tmp = fold_tmp;
     p.total_floats = packed + (p.emb ? H * net.in.K + H : 0) + 16;
@@ -631,6 +648,14 @@ int snsde_mfma_backward_launch(const snsde_backward* b, const SnsdeNet& net, hip
     a.dth_part = p.dth_off ? ws + p.dth_off : nullptr;
     a.B = s->batch; a.N = s->n_steps; a.T = s->n_out; a.no = s->model.noise_option; a.off_theta = net.off_theta; a.method = s->method;
     for (int i = 0; i < p.n_layers; ++i) a.w_off[i] = p.layer[i].dst;
+    if (p.M4N == 2) {
+        a.geo = p.GEO;
+        if (p.H == 128) return dispatch_m4n_mil_rev_h128(p, a, stream);
+        if (p.H == 64) return dispatch_m4n_mil_rev_h64(p, a, stream);
+        if (p.H == 32) return dispatch_m4n_mil_rev_h32(p, a, stream);
+        if (p.H == 16) return dispatch_m4n_mil_rev_h16(p, a, stream);
+        return SNSDE_ERR_UNSUPPORTED;
+    }
     if (p.M4N) {
         a.geo = p.GEO;
         if (p.H == 128) return dispatch_m4n_rev_h128(p, a, stream);

@@ -36,7 +36,8 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 struct WTile {
     int32_t d_slot;   // delta slot of the left factor D
     int32_t h0;       // first D feature (output row) of this tile
-    int32_t x_kind;   // 0 = act_save slot, 1 = trajectory y, 2 = control-path columns [sin t, cos t][X(t) channels] (xaux)
+    int32_t x_kind;   // 0 = act_save slot, 1 = trajectory y, 2 = control-path columns [sin t, cos t][X(t) channels] (xaux),
+                      // 3 = delta_save slot x_slot (a tangent the adjoint kernel left there), 4 = the adjoint a_{n+1}
     int32_t x_slot;
     int32_t k0;       // first X column of this tile (source)
     int32_t kd;       // first destination column of this tile in the job matrix
@@ -57,7 +58,7 @@ struct WTile {
 };
 
 struct WArgs {
-    const float* delta; const float* act; const float* traj; const float* xaux;
+    const float* delta; const float* act; const float* traj; const float* xaux; const float* adj;
     float* part;       // [tile][split][TILE_FLOATS]
     float* sums;       // dense job matrices
     int32_t B, H, N, NG, NSAVE, ldx, R, ntiles, NP;
@@ -118,6 +119,10 @@ __device__ __forceinline__ void wgrad_body(const WArgs& a, const WTile& t, float
                         xv = *reinterpret_cast<const float4*>(a.act + (((size_t)n * a.NSAVE + t.x_slot) * B + b) * H + t.k0 + c4);
                     else if (t.x_kind == 1)
                         xv = *reinterpret_cast<const float4*>(a.traj + (((size_t)n * a.NP + t.xplane) * B + b) * H + t.k0 + c4);
+                    else if (t.x_kind == 3)
+                        xv = *reinterpret_cast<const float4*>(a.delta + (((size_t)n * a.NG + t.x_slot) * B + b) * H + t.k0 + c4);
+                    else if (t.x_kind == 4)
+                        xv = *reinterpret_cast<const float4*>(a.adj + ((size_t)(n + 1) * B + b) * H + t.k0 + c4);
                     else
                         xv = *reinterpret_cast<const float4*>(a.xaux + ((size_t)n * B + b) * a.ldx + t.k0 + c4);
                 }
@@ -372,10 +377,11 @@ __global__ void __launch_bounds__(256) snsde_assemble_kernel(AArgs a) {
             const float sg = snsde_sigmoid(a.params[net.off_theta]);
             val = a.dth[0] * sg * (1.0f - sg);
         }
-    } else if (a.nn >= 1 && inside(net.ny0.src_w, H * (H + 2), rel)) val = a.sums[a.o_ny0 + rel] + (a.tail ? a.sums[a.o_ny0b + rel] : 0.0f);
-    else if (a.nn >= 1 && inside(net.ny0.src_b, H, rel)) val = a.sums[a.b_ny0 + rel] + (a.tail ? a.sums[a.b_ny0b + rel] : 0.0f);
+    } else if (a.nn >= 1 && inside(net.ny0.src_w, H * (H + 2), rel))      // tail 1: SRK's fourth evaluation; 2: Milstein's second-order
+        val = a.sums[a.o_ny0 + rel] + ((a.tail == 1 || (a.tail == 2 && rel % (H + 2) >= 2)) ? a.sums[a.o_ny0b + rel] : 0.0f);   // term (y columns)
+    else if (a.nn >= 1 && inside(net.ny0.src_b, H, rel)) val = a.sums[a.b_ny0 + rel] + (a.tail == 1 ? a.sums[a.b_ny0b + rel] : 0.0f);
     else if (a.nn == 2 && inside(net.ny1.src_w, H * H, rel)) val = a.sums[a.o_ny1 + rel] + (a.tail ? a.sums[a.o_ny1b + rel] : 0.0f);
-    else if (a.nn == 2 && inside(net.ny1.src_b, H, rel)) val = a.sums[a.b_ny1 + rel] + (a.tail ? a.sums[a.b_ny1b + rel] : 0.0f);
+    else if (a.nn == 2 && inside(net.ny1.src_b, H, rel)) val = a.sums[a.b_ny1 + rel] + (a.tail == 1 ? a.sums[a.b_ny1b + rel] : 0.0f);
     else {
         for (int l = 0; l < a.nhid; ++l) {
             if (inside(net.hid[l].src_w, H * H, rel)) { val = a.sums[a.o_hid[l] + rel]; break; }
@@ -441,7 +447,7 @@ struct WPlan {
     int ntiles, max_split, naux, ldx, n_pass, n_trow;
     size_t part_floats, sums_floats, ds_off, dth_off, dz1_off, dz2_off, a1_off, xaux_off, total_floats;
     bool tnoise, has_dth;
-    int nact, xt, t_col0, x_col0, x_cols, n_col0, NP;
+    int nact, ndelta, xt, t_col0, x_col0, x_cols, n_col0, NP;
     AArgs aa;
     WTile tile[MAX_TILES];
 };
@@ -508,6 +514,7 @@ bool make_wplan(const snsde_backward* b, const SnsdeNet& net, WPlan* w) {
     // at the diffusion stage times (xaux columns n_col0 ..), and the step's fourth evaluation adds a second set of sums over
     // the passes 3n + 2 (delta / activation slots + nn, state plane 2, time columns n_col0 + 4 ..)
     const bool srknet = srk && nn > 0;
+    const bool milnet = s.method == SNSDE_MILSTEIN && nn > 0;
     const int n_col0 = srknet ? ((naux + 3) & ~3) : -1;
     aa.tail = srknet ? 1 : 0;
     if (ok && nn > 0) {     // diffusion net: first layer on [sin t, cos t | y] (delta slot nd + nn - 1), output layer on its hidden
@@ -532,6 +539,17 @@ bool make_wplan(const snsde_backward* b, const SnsdeNet& net, WPlan* w) {
             cur_pstride = 1; cur_poff = 0;
         }
         cur_plane = 0;
+        if (ok && milnet) {
+            // Milstein through the net (snsde_m4n_mil_rev_kernel.h): the tangent p = J_g a depends on W1_y and W2 too:
+            //   d W2 += sum eps2 hdot^T (delta slots nact, nact + 2),  d W1_y += sum eps1 a_{n+1}^T (slot nact + 1 | nact for one layer)
+            aa.tail = 2;
+            aa.o_ny0b = alloc((size_t)H * (H + 2));
+            ok = add_tiles(nhid + 2 + nn + (nn == 2 ? 1 : 0), 4, 0, H, aa.o_ny0b + 2, H + 2, -1, 1 << 30, 0);
+            if (ok && nn == 2) {
+                aa.o_ny1b = alloc((size_t)H * H);
+                ok = add_tiles(nhid + 2 + nn, 3, nhid + 2 + nn + 2, H, aa.o_ny1b, H, -1, 1 << 30, 0);
+            }
+        }
     }
     if (!ok) return false;
     w->ntiles = nt;
@@ -565,7 +583,8 @@ bool make_wplan(const snsde_backward* b, const SnsdeNet& net, WPlan* w) {
     w->ds_off = o; o += w->tnoise ? NH : 0;
     w->has_dth = w->tnoise || nn > 0 || (no >= 7 && no <= 10);
     w->t_col0 = t_col0; w->x_col0 = x_col0; w->x_cols = usex ? C : 0;
-    w->nact = nhid + 2 + nn + (srknet ? nn : 0);      // act_save / delta_save slots per pass (snsde_save_layout)
+    w->nact = nhid + 2 + nn + (srknet ? nn : 0);      // act_save slots per pass (snsde_save_layout)
+    w->ndelta = w->nact + (milnet ? (nn == 2 ? 3 : 1) : 0);      // delta_save slots per pass
     w->xt = xt;
     w->dth_off = o; o += 4;
     w->dz1_off = o; o += two ? NH : 0;
@@ -615,7 +634,8 @@ int snsde_wgrad_launch(const snsde_backward* b, const SnsdeNet& net, float* grad
         a.traj = s.stage_save;                     // first-layer inputs = the stage states
     }
     const bool smooth = s.model.activation != SNSDE_ACT_RELU;      // act_save then also holds the NL pre-activations per step
-    a.B = s.batch; a.H = H; a.N = wp->n_pass; a.NG = wp->nact; a.NSAVE = wp->nact + (smooth ? s.model.num_hidden_layers : 0);
+    a.B = s.batch; a.H = H; a.N = wp->n_pass; a.NG = wp->ndelta; a.NSAVE = wp->nact + (smooth ? s.model.num_hidden_layers : 0);
+    a.adj = b->adj;
     a.ldx = wp->ldx; a.R = wp->n_pass * s.batch; a.ntiles = wp->ntiles; a.NP = wp->NP;
     for (int i = 0; i < wp->ntiles; ++i) a.tile[i] = wp->tile[i];
     if (wp->naux > 0) {

@@ -360,8 +360,9 @@ class SolveCall:
         s.batch, s.knots, s.n_steps, s.n_out = B, L, grid.N, grid.T
         s.method = {'euler': _lib.EULER, 'milstein': _lib.MILSTEIN, 'srk': _lib.SRK}[method]
         if save_act:
-            slots, planes = C.c_int32(), C.c_int32()
-            _lib.check(_lib.lib().snsde_save_layout(C.byref(s), C.byref(slots), C.byref(planes)), 'snsde_save_layout')
+            slots, planes, dslots = C.c_int32(), C.c_int32(), C.c_int32()
+            _lib.check(_lib.lib().snsde_save_layout(C.byref(s), C.byref(slots), C.byref(planes), C.byref(dslots)), 'snsde_save_layout')
+            self.delta_slots = dslots.value
             passes = 3 * grid.N if method == 'srk' else grid.N      # SRK: three drift passes per step
             self.act_save = torch.empty((passes, slots.value, B, H), device=dev, dtype=torch.float32)
             if method == 'srk':
@@ -448,7 +449,10 @@ def solve_backward(call, grad_ys, stream=None, save_delta=False):
     b.fwd = call.desc
     b.fwd.flags = call.base_flags
     adj = torch.empty_like(call.traj)
-    delta = torch.empty_like(call.act_save) if (save_delta and call.act_save is not None) else None
+    delta = None
+    if save_delta and call.act_save is not None:      # (passes, delta slots, B, H): snsde_save_layout
+        shp = call.act_save.shape
+        delta = torch.empty((shp[0], getattr(call, 'delta_slots', shp[1]), shp[2], shp[3]), device=call.act_save.device, dtype=torch.float32)
     b.grad_ys, b.adj, b.delta_save = _ptr(grad_ys), _ptr(adj), _ptr(delta)
     nbytes = _lib.lib().snsde_backward_workspace_bytes(C.byref(b))
     ws = torch.empty(max(nbytes, 256), device=adj.device, dtype=torch.uint8)

@@ -757,6 +757,29 @@ def test_srk_backward_on_the_mfma_path(ci, kernel):
     _check_backward(4000 + ci, io, no, NL, B, H, C, L, ts, dt, 'srk', kernel, strict=True)
 
 
+MIL_NET_BWD_CASES = [
+    # io, no, NL, B, H, C, L, ts, dt     (Milstein through a diffusion net: snsde_m4n_mil_reverse_kernel - tangent + reverse pass
+    (1, 18, 2, 9, 16, 3, 8, [0, 7], 0.5),            #  through the net per step - and the second-order weight-gradient jobs)
+    (3, 15, 3, 8, 16, 4, 8, [0, 7], 1.0),
+    (1, 14, 1, 17, 32, 3, 9, [0, 2.5, 8], 0.5),
+    (3, 18, 2, 33, 64, 5, 12, [0, 2.5, 11], 0.5),
+    (5, 19, 2, 21, 64, 5, 9, [0, 8], 1.0),
+    (2, 14, 2, 13, 32, 7, 9, [0, 3.5, 8], 0.5),
+    (6, 15, 3, 9, 64, 40, 8, [0, 7], 1.0),
+    (6, 19, 4, 7, 32, 3, 8, [0, 7], 1.0),
+    (4, 14, 1, 11, 128, 21, 9, [0, 8], 1.0),         # H = 128, one-layer net: matrices parked in LDS
+    (4, 18, 2, 12, 64, 69, 9, [0, 4, 8], 1.0),       # the K4 channel count
+]
+
+
+@pytest.mark.parametrize('ci', range(len(MIL_NET_BWD_CASES)))
+def test_milstein_backward_through_a_diffusion_net_on_the_mfma_path(ci):
+    io, no, NL, B, H, C, L, ts, dt = MIL_NET_BWD_CASES[ci]
+    grid = S.engine.step_grid(np.asarray(ts, np.float32), dt, np.arange(L, dtype=np.float32), torch.device(DEV))
+    assert S.engine.backward_mode(S.engine.model_struct(C, H, H, NL, io, no), B, L, grid, 'milstein') == 1
+    _check_backward(4500 + ci, io, no, NL, B, H, C, L, ts, dt, 'milstein', 'auto', strict=True)
+
+
 @pytest.mark.parametrize('io', [0, 1, 2, 3, 4, 5, 6])
 @pytest.mark.parametrize('no', [0, 1, 2, 3, 4, 5, 6, 8, 9, 10, 11, 12, 13, 16, 17])   # 7 (sqrt y): autograd's own gradient is NaN for y < 0
 def test_backward_sweep_mfma_options(io, no):

@@ -18,16 +18,17 @@ bad = 0
 for ci, (io, no, NL, B, H, C, L, ts, dt) in enumerate(CASES):
     model = S.engine.model_struct(C, H, H, NL, io, no)
     grid = S.engine.step_grid(np.asarray(ts, np.float32), dt, np.arange(L, dtype=np.float32), dev)
-    mode = S.engine.backward_mode(model, B, L, grid, method, 'mfma4')
+    mode = S.engine.backward_mode(model, B, L, grid, method, 'auto')
     try:
-        _check_backward(5000 + ci, io, no, NL, B, H, C, L, ts, dt, method, 'mfma4', strict=True)
+        _check_backward(5000 + ci, io, no, NL, B, H, C, L, ts, dt, method, "auto", strict=True)
         print(f'{method} bwd case {ci} ({io},{no}) NL={NL} H={H} C={C}: mode {mode} ok')
     except Exception as e:
         bad += 1
         print(f'{method} bwd case {ci} ({io},{no}) NL={NL} H={H} C={C}: mode {mode} FAIL {type(e).__name__} {str(e)[:300]}')
 print('failures:', bad)
 
-for (io, no, B, H, C, L, meth) in ((1, 18, 1024, 128, 21, 50, 'srk'), (3, 18, 2048, 64, 69, 72, 'srk'), (1, 18, 512, 64, 5, 50, 'srk')):
+for (io, no, B, H, C, L, meth) in ((1, 18, 1024, 128, 21, 50, 'srk'), (3, 18, 2048, 64, 69, 72, 'srk'), (1, 18, 512, 64, 5, 50, 'srk'),
+                                  (3, 18, 2048, 64, 69, 72, 'milstein'), (1, 14, 1024, 128, 21, 50, 'milstein'), (1, 18, 512, 64, 5, 50, 'milstein')):
     if meth != method:
         continue
     pr = make_problem(7, io, no, 2, B, H, C, L, nan_frac=0.2)
