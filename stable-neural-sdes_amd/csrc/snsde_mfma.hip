@@ -241,8 +241,16 @@ MfmaPlan make_plan(const snsde_solve* s, const SnsdeNet& net, int flavor_hint) {
     if (!(no == 0 || tab_noise || y_noise || noise_net)) return p;
     // SRK / Milstein through a diffusion net: the 4-row-tile kernels of snsde_m4n_kernel.h (embedded or latent-only drifts)
     const bool variant_m = m.activation != 0 || m.drift_output != 0 || m.diffusion_output != 0 || m.time_feature != 0;
-    const bool m4n = noise_net && (s->method != SNSDE_EULER || variant_m);      // (field variants with a net: these kernels, every method)
     const int kuxn = (io == 2 || io == 4 || io == 6) ? (m.input_channels > 32 ? 5 : 2) : 0;
+    // Euler with a net takes them too where the general kernel has no (spill-free) instantiation: a wide control path behind
+    // the embedding (C > 32, e.g. the sepsis channels), and H = 128 on 4-row tiles (its five resident matrices spill there)
+    bool m4n = noise_net && (s->method != SNSDE_EULER || variant_m);      // (field variants with a net: these kernels, every method)
+    if (noise_net && !m4n && io != 0 && flavor_hint != 0 && m.num_hidden_layers <= 4 &&
+        m4n_instantiated(H, kuxn, m.num_hidden_layers - 1, no >= 18 ? 2 : 1, SNSDE_EULER)) {
+        const long r4 = ((s->batch + 3) / 4 + 255) / 256, r16 = ((s->batch + 15) / 16 + 255) / 256;
+        const bool m4_tiles = flavor_hint == 1 || 10 * r4 <= 22 * r16;
+        if (kuxn == 5 || (H == 128 && m4_tiles)) m4n = true;
+    }
     if (m4n && (flavor_hint == 0 || io == 0 || m.num_hidden_layers > 4 ||
                 !m4n_instantiated(H, kuxn, m.num_hidden_layers - 1, no >= 18 ? 2 : 1, s->method)))
         return p;
@@ -389,7 +397,7 @@ RevPlan make_rev_plan(const snsde_solve* s, const SnsdeNet& net, const MfmaPlan&
                          ((s->method == SNSDE_SRK && m4n_rev_instantiated(fp.H, fp.NHID, fp.NN)) ||
                           (s->method == SNSDE_MILSTEIN && m4n_mil_rev_instantiated(fp.H, fp.NHID, fp.NN)));
     if (fp.NN != 0 && s->method != SNSDE_EULER && !m4n_rev) return p;
-    if (fp.M4N && s->method == SNSDE_EULER) return p;       // (Euler on the net kernels = the field variants: no fused backward)
+    if (fp.M4N && s->method == SNSDE_EULER && variant_of(s)) return p;       // (field variants with a net: no fused backward)
     p.M4N = m4n_rev ? (s->method == SNSDE_SRK ? 1 : 2) : 0;
     // tutorial-style fields: the register-resident lean forward (its training-mode instantiations), Euler / Milstein
     if (variant_of(s) && !(fp.LEAN && fp.FL == 1 && fp.H <= 128 && !fp.SRK && s->method != SNSDE_SRK &&

@@ -453,7 +453,7 @@ def test_mfma_trajectory_vs_oracle(ci, kernel):
 
 
 def test_mfma_unsupported_configuration_is_refused_not_silently_rerouted():
-    pr = make_problem(1, 4, 18, 2, 8, 64, 40, 5)     # diffusion net with a wide control path: generic only
+    pr = make_problem(1, 0, 18, 2, 8, 64, 40, 5)     # diffusion net on a y-free drift with a wide control path: generic only
     with pytest.raises(S._lib.SnsdeError) as e:
         hip_solve(pr, [0, 4], 1.0, dW=draw_dW(1, [0, 4], 1.0, 8, 64), kernel='mfma')
     assert e.value.code == -4
@@ -755,6 +755,34 @@ def test_srk_backward_on_the_mfma_path(ci, kernel):
         grid = S.engine.step_grid(np.asarray(ts, np.float32), dt, np.arange(L, dtype=np.float32), torch.device(DEV))
         assert S.engine.backward_mode(S.engine.model_struct(C, H, H, NL, io, no), B, L, grid, 'srk', kernel) == 1
     _check_backward(4000 + ci, io, no, NL, B, H, C, L, ts, dt, 'srk', kernel, strict=True)
+
+
+EULER_NET_CASES = [
+    # io, no, NL, B, H, C, L     (Euler through a diffusion net on snsde_m4n_kernel.h: wide control paths behind the embedding - the
+    (4, 18, 2, 19, 64, 69, 9),   #  sepsis channel count - and H = 128 on 4-row tiles)
+    (6, 15, 3, 9, 128, 40, 8),
+    (2, 14, 1, 13, 32, 33, 8),
+    (1, 18, 2, 21, 128, 5, 9),
+    (5, 19, 2, 11, 128, 3, 8),
+]
+
+
+@pytest.mark.parametrize('ci', range(len(EULER_NET_CASES)))
+def test_euler_through_a_diffusion_net_on_the_net_kernels(ci):
+    io, no, NL, B, H, C, L = EULER_NET_CASES[ci]
+    pr = make_problem(800 + ci, io, no, NL, B, H, C, L)
+    ts, dt = [0, 2.5, L - 1], 0.5
+    model = S.engine.model_struct(C, H, H, NL, io, no)
+    grid = S.engine.step_grid(np.asarray(ts, np.float32), dt, pr['times'], torch.device(DEV))
+    assert S.engine.forward_path(model, B, L, grid.N) == 'mfma4' and S.engine.backward_mode(model, B, L, grid, 'euler') == 1
+    dW = draw_dW(800 + ci, ts, dt, B, H)
+    ys, _ = hip_solve(pr, ts, dt, dW=dW, kernel='auto')
+    ref64, _ = oracle_solve(pr, ts, dt, dW, 'euler', np.float64)
+    cpu32, _ = oracle_solve(pr, ts, dt, dW, 'euler', np.float32)
+    assert_parity(ys, ref64, cpu32, what=f'euler net case {ci}')
+    yg, _ = hip_solve(pr, ts, dt, dW=dW, kernel='generic')
+    assert np.abs(ys - yg).max() <= 2e-4 * (np.abs(yg).max() + 1e-9)
+    _check_backward(4700 + ci, io, no, NL, B, H, C, L, ts, dt, 'euler', 'auto', strict=True)
 
 
 MIL_NET_BWD_CASES = [
