@@ -208,7 +208,12 @@ typedef struct snsde_backward {
     size_t       workspace_bytes;
     float*       grad_noise_table; /* snsde_param_gradients with fwd.noise_table set: optional device (N, H) out,      */
                              /* dL/d noise_table (the caller back-propagates it through whatever produced the table) */
+    int32_t      flags;      /* SNSDE_BWD_ADJ0_ONLY: `adj` is (B, H) and receives dL/dy0 only - the MFMA adjoint kernels   */
+                             /* (mode 1) need no a_n in memory, except Milstein through a diffusion net, whose second-    */
+                             /* order weight-gradient jobs read them (there and in mode 2 the flag is refused: ERR_OPTION) */
+    int32_t      reserved;
 } snsde_backward;
+enum { SNSDE_BWD_ADJ0_ONLY = 1 };
 
 int    snsde_act_slots(const snsde_model* m);             /* activation tensors saved per step, or <0: layer outputs (first, hidden.., */
                                                           /* pre-tanh drift) [+ diffusion-net slots]; models with a smooth activation  */

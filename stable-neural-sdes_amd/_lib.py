@@ -15,6 +15,7 @@ SNSDE_SRK_STRIDE = 8
 KERNEL_AUTO, KERNEL_GENERIC, KERNEL_MFMA = 0, 1, 2
 FLAG_REUSE_PREPARED = 1
 FLAG_EXACT_ORDER = 2
+BWD_ADJ0_ONLY = 1
 PATHS = ('none', 'generic', 'mfma16', 'mfma4', 'lean', 'lean-streamed', 'generic-srk', 'mfma-srk')
 KERNELS = {'auto': KERNEL_AUTO, 'generic': KERNEL_GENERIC, 'mfma': KERNEL_MFMA, 'mfma16': 3, 'mfma4': 4}
 
@@ -42,7 +43,7 @@ class Solve(C.Structure):
 class Backward(C.Structure):
     _fields_ = [('fwd', Solve), ('grad_ys', C.c_void_p), ('adj', C.c_void_p), ('delta_save', C.c_void_p),
                 ('workspace', C.c_void_p),
-                ('workspace_bytes', C.c_size_t), ('grad_noise_table', C.c_void_p)]
+                ('workspace_bytes', C.c_size_t), ('grad_noise_table', C.c_void_p), ('flags', C.c_int32), ('reserved', C.c_int32)]
 
 
 class Head(C.Structure):

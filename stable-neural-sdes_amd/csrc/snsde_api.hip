@@ -476,6 +476,7 @@ int snsde_solve_backward(const snsde_backward* b, void* hip_stream) {
     const int mode = snsde_backward_supported(&b->fwd);
     if (mode == 0) return SNSDE_ERR_UNSUPPORTED;
     if (mode == 2) {
+        if (b->flags & SNSDE_BWD_ADJ0_ONLY) return SNSDE_ERR_OPTION;     // (its parameter pass reads every a_n)
         if (b->delta_save) return SNSDE_ERR_UNSUPPORTED;    // the generic adjoint writes adjoints only
         if (b->workspace_bytes < snsde_backward_workspace_bytes(b)) return SNSDE_ERR_WORKSPACE;
         return snsde_generic_backward_launch(b, net, static_cast<hipStream_t>(hip_stream));

@@ -196,7 +196,7 @@ __global__ void __launch_bounds__(CF::NT, CF::WPS) snsde_m4n_srk_reverse_kernel(
             if (w0o == 0.0f) adj += gk;
             else { adj = fmaf(w1o, gk, adj); carry = fmaf(w0o, gk, carry); }
         }
-        if (row_ok) a.adj[(size_t)(n + 1) * BH + goff] = adj;
+        if (row_ok && !a.adj0_only) a.adj[(size_t)(n + 1) * BH + goff] = adj;
 
         // ---- recompute the stage values of the step (own element) ----
         const float y = cur.y, ik = cur.ik, ik0 = cur.ik0;

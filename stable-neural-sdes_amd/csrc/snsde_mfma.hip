@@ -648,6 +648,8 @@ int snsde_mfma_backward_launch(const snsde_backward* b, const SnsdeNet& net, hip
     a.nsave = s->model.num_hidden_layers + 1 + fp.NN + (s->model.activation != SNSDE_ACT_RELU ? s->model.num_hidden_layers : 0);
     a.step_tab = s->step_tab; a.out_w = s->out_w; a.traj = s->traj; a.act = s->act_save; a.dW = s->dW_out;
     a.grad_ys = b->grad_ys; a.adj = b->adj; a.delta = b->delta_save; a.row_out = s->row_out;
+    a.adj0_only = (b->flags & SNSDE_BWD_ADJ0_ONLY) ? 1 : 0;
+    if (a.adj0_only && p.M4N == 2) return SNSDE_ERR_OPTION;      // (its weight-gradient jobs read every a_n)
     if (p.SRK) {
         if (!s->dU_out) return SNSDE_ERR_NULL;
         a.dU = s->dU_out;

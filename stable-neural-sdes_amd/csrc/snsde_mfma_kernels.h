@@ -1001,6 +1001,7 @@ struct RevArgs {
     int32_t nsave;                     // activation slots per step in `act` (snsde_act_slots)
     int32_t act_fn, f_out, g_out;      // field variants (SNSDE_ACT_*, SNSDE_DRIFT_*, SNSDE_DIFFUSION_*): 4-row tiles only
     int32_t geo;                       // snsde_m4n_rev_kernel.h: the drift is gated by tanh(y) (input_option 5 / 6)
+    int32_t adj0_only;                 // SNSDE_BWD_ADJ0_ONLY: `adj` is (B, H) = dL/dy0; the intermediate adjoints are not written
 };
 
 // d/dx [scale * x * sigmoid(x)]  (LipSwish: scale = 0.909, SiLU: 1)
@@ -1144,7 +1145,7 @@ __global__ void __launch_bounds__(CF::NT, CF::WPS) snsde_mfma_reverse_kernel(Rev
                 else { adj[e] = fmaf(w1, gk, adj[e]); carry[e] = fmaf(w0, gk, carry[e]); }
             }
         }
-        if (row_ok) {
+        if (row_ok && !a.adj0_only) {
 #pragma unroll
             for (int e = 0; e < EPT; ++e) a.adj[(size_t)(n + 1) * BH + goff + e] = adj[e];
         }
@@ -1503,7 +1504,7 @@ __global__ void __launch_bounds__(CF::NT, CF::WPS) snsde_mfma_srk_reverse_kernel
             if (w0 == 0.0f) adj += gk;
             else { adj = fmaf(w1, gk, adj); carry = fmaf(w0, gk, carry); }
         }
-        if (row_ok) a.adj[(size_t)(n + 1) * BH + goff] = adj;
+        if (row_ok && !a.adj0_only) a.adj[(size_t)(n + 1) * BH + goff] = adj;
         // ---- recompute the stage values of the step for the own element ----
         const float y = cur.y, ik = cur.ik, ik0 = cur.ik0, z0 = cur.z0, z1 = cur.z1, z2 = cur.z2;
         const float t0v = cur.t0v, t1v = cur.t1v, t3v = cur.t3v;

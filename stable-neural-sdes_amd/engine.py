@@ -268,7 +268,7 @@ def backward_recompute(call, grad_ys, chunk, stream=None):
         c = SolveCall(model, flat, coeffs, sub, call.traj[n0], dW=call.dW_out[n0:n1], method=method, kernel='auto',
                       save_traj=True, save_dW=True, save_act=True, exact_order=bool(call.base_flags & _lib.FLAG_EXACT_ORDER))
         c.launch(stream)
-        adj, delta = solve_backward(c, g, stream=stream, save_delta=True)
+        adj, delta = solve_backward(c, g, stream=stream, save_delta=True, adj0_only=adj0_suffices(c))
         part = param_gradients(c, adj, delta, stream=stream)
         total = part if total is None else total.add_(part)
         carry = adj[0]
@@ -439,16 +439,24 @@ def backward_mode(model, batch, knots, grid, method, kernel='auto', exact_order=
     return hit
 
 
-def solve_backward(call, grad_ys, stream=None, save_delta=False):
+def adj0_suffices(call):
+    """The MFMA adjoint + native weight-gradient pass of this solve never read the intermediate adjoints from memory (all but
+    Milstein through a diffusion net, whose second-order weight-gradient jobs do)."""
+    return not (call.desc.method == _lib.MILSTEIN and call.model.noise_option in (14, 15, 18, 19))
+
+
+def solve_backward(call, grad_ys, stream=None, save_delta=False, adj0_only=False):
     """Adjoint recursion over a finished training-mode solve (SolveCall with save_traj/save_dW/save_act):
-    returns adj (N+1, B, H), adj[n] = dL/dy_n; adj[0] is the gradient w.r.t. y0."""
+    returns adj (N+1, B, H), adj[n] = dL/dy_n; adj[0] is the gradient w.r.t. y0.  adj0_only (MFMA adjoint kernels, mode 1,
+    not Milstein through a diffusion net): adj is (1, B, H) - the intermediate adjoints stay on chip."""
     if call.traj is None or call.dW_out is None:
         raise ValueError('backward needs a solve run with save_traj and save_dW (and save_act on the MFMA path)')
     _check_f32('grad_ys', grad_ys, tuple(call.ys.shape))
     b = _lib.Backward()
     b.fwd = call.desc
     b.fwd.flags = call.base_flags
-    adj = torch.empty_like(call.traj)
+    adj = torch.empty_like(call.traj[:1]) if adj0_only else torch.empty_like(call.traj)
+    b.flags = _lib.BWD_ADJ0_ONLY if adj0_only else 0
     delta = None
     if save_delta and call.act_save is not None:      # (passes, delta slots, B, H): snsde_save_layout
         shp = call.act_save.shape

@@ -411,7 +411,8 @@ class _ComposedSolve(torch.autograd.Function):
     @staticmethod
     def backward(ctx, grad_ys):
         call = ctx.call
-        adj, delta = engine.solve_backward(call, grad_ys.to(torch.float32).contiguous(), save_delta=True)
+        adj, delta = engine.solve_backward(call, grad_ys.to(torch.float32).contiguous(), save_delta=True,
+                                           adj0_only=engine.adj0_suffices(call))
         if ctx.has_tab:
             gflat, gtab = engine.param_gradients(call, adj, delta, want_table_grad=True)
         else:
@@ -478,7 +479,8 @@ class _FusedSolve(torch.autograd.Function):
                 grads.append(flat[off:off + p.numel()].view_as(p).to(p.dtype))
             return (None,) * 9 + (g0.to(ctx.y0_dtype),) + tuple(grads)
         if ctx.mode == 1:     # MFMA adjoint kernel + native weight-gradient pass on the saved activations / deltas
-            adj, delta = engine.solve_backward(call, grad_ys.to(torch.float32).contiguous(), save_delta=True)
+            adj, delta = engine.solve_backward(call, grad_ys.to(torch.float32).contiguous(), save_delta=True,
+                                               adj0_only=ctx.param_pass != 'torch' and engine.adj0_suffices(call))
             if ctx.param_pass == 'torch':     # library-GEMM cross-check of the native pass
                 grads = _parameter_gradients_gemm(sde, call, grid, adj, delta, method=ctx.method)
             else:
