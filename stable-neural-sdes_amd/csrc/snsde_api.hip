@@ -469,13 +469,16 @@ int snsde_solve_backward(const snsde_backward* b, void* hip_stream) {
     if (!b) return SNSDE_ERR_NULL;
     int rc = validate_solve(&b->fwd, false);
     if (rc) return rc;
-    if (!b->grad_ys || !b->adj || !b->workspace || !b->fwd.traj || !b->fwd.dW_out) return SNSDE_ERR_NULL;
+    if (!b->grad_ys || !b->adj || !b->workspace || !b->fwd.traj) return SNSDE_ERR_NULL;
+    // increments: dW_out, or the supplied dW, or - MFMA Euler / Milstein adjoint, Philox with a host key - regenerated in-kernel
+    if (!b->fwd.dW_out && !b->fwd.dW && b->fwd.seed_dev) return SNSDE_ERR_NULL;
     SnsdeNet net;
     rc = snsde_build_net(b->fwd.model, b->fwd.n_steps, &net);
     if (rc) return rc;
     const int mode = snsde_backward_supported(&b->fwd);
     if (mode == 0) return SNSDE_ERR_UNSUPPORTED;
     if (mode == 2) {
+        if (!b->fwd.dW_out) return SNSDE_ERR_NULL;
         if (b->flags & SNSDE_BWD_ADJ0_ONLY) return SNSDE_ERR_OPTION;     // (its parameter pass reads every a_n)
         if (b->delta_save) return SNSDE_ERR_UNSUPPORTED;    // the generic adjoint writes adjoints only
         if (b->workspace_bytes < snsde_backward_workspace_bytes(b)) return SNSDE_ERR_WORKSPACE;
@@ -499,7 +502,7 @@ int snsde_param_gradients(const snsde_backward* b, float* grad_params, void* wor
     if (!b || !grad_params || !workspace) return SNSDE_ERR_NULL;
     int rc = validate_solve(&b->fwd, false);
     if (rc) return rc;
-    if (!b->adj || !b->delta_save || !b->fwd.traj || !b->fwd.dW_out || !b->fwd.act_save || !b->fwd.workspace)
+    if (!b->adj || !b->delta_save || !b->fwd.traj || !b->fwd.act_save || !b->fwd.workspace)
         return SNSDE_ERR_NULL;
     SnsdeNet net;
     rc = snsde_build_net(b->fwd.model, b->fwd.n_steps, &net);

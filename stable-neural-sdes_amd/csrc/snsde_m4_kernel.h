@@ -106,7 +106,9 @@ __device__ __forceinline__ void lean_gload(float& dst, uint32_t voff, const floa
 }
 // store through a scalar base + 32-bit lane offset as well: the training-mode saves then need no 64-bit address VGPRs
 __device__ __forceinline__ void lean_gstore(float v, uint32_t voff, const float* sbase) {
-    asm volatile("s_nop 4\n\tglobal_store_dword %1, %0, %2" :: "v"(v), "v"(voff), "s"(lean_uniform(sbase)) : "memory");
+    // (no "memory" clobber: these buffers are never read back by the kernel, and the clobber would pin every LDS access of the
+    //  step on one side of the store)
+    asm volatile("s_nop 4\n\tglobal_store_dword %1, %0, %2" :: "v"(v), "v"(voff), "s"(lean_uniform(sbase)));
 }
 __device__ __forceinline__ void lean_gload4(float& d0, float& d1, float& d2, float& d3, uint32_t v0, uint32_t v1, uint32_t v2,
                                             uint32_t v3, const float* sbase) {

@@ -646,7 +646,11 @@ int snsde_mfma_backward_launch(const snsde_backward* b, const SnsdeNet& net, hip
     a.gt = s->noise_table ? s->noise_table : (fp.gt_off >= 0 ? static_cast<const float*>(s->workspace) + fp.gt_off : nullptr);
     a.act_fn = s->model.activation; a.f_out = s->model.drift_output; a.g_out = s->model.diffusion_output;
     a.nsave = s->model.num_hidden_layers + 1 + fp.NN + (s->model.activation != SNSDE_ACT_RELU ? s->model.num_hidden_layers : 0);
-    a.step_tab = s->step_tab; a.out_w = s->out_w; a.traj = s->traj; a.act = s->act_save; a.dW = s->dW_out;
+    a.step_tab = s->step_tab; a.out_w = s->out_w; a.traj = s->traj; a.act = s->act_save;
+    // increments: the ones the forward wrote out, else the supplied ones, else (Philox, host key) regenerated by the kernel
+    a.dW = s->dW_out ? s->dW_out : s->dW;
+    a.seed = s->seed; a.row_offset = s->row_offset;
+    if (!a.dW && (p.SRK || p.M4N || s->seed_dev)) return SNSDE_ERR_NULL;      // (regeneration: the Euler / Milstein kernel, host key)
     a.grad_ys = b->grad_ys; a.adj = b->adj; a.delta = b->delta_save; a.row_out = s->row_out;
     a.adj0_only = (b->flags & SNSDE_BWD_ADJ0_ONLY) ? 1 : 0;
     if (a.adj0_only && p.M4N == 2) return SNSDE_ERR_OPTION;      // (its weight-gradient jobs read every a_n)

@@ -1002,6 +1002,10 @@ struct RevArgs {
     int32_t act_fn, f_out, g_out;      // field variants (SNSDE_ACT_*, SNSDE_DRIFT_*, SNSDE_DIFFUSION_*): 4-row tiles only
     int32_t geo;                       // snsde_m4n_rev_kernel.h: the drift is gated by tanh(y) (input_option 5 / 6)
     int32_t adj0_only;                 // SNSDE_BWD_ADJ0_ONLY: `adj` is (B, H) = dL/dy0; the intermediate adjoints are not written
+    // dW == null: the forward drew its increments from Philox with this key / row offset and did not write them out; the
+    // Euler / Milstein adjoint regenerates them (same call, same product z * sqrt h: bit-identical)
+    uint64_t seed;
+    int64_t row_offset;
 };
 
 // d/dx [scale * x * sigmoid(x)]  (LipSwish: scale = 0.909, SiLU: 1)
@@ -1085,12 +1089,27 @@ __global__ void __launch_bounds__(CF::NT, CF::WPS) snsde_mfma_reverse_kernel(Rev
     // M16: the writer lanes hold the relu masks of their four features (f32x4); M4: after the k-slot reduce-scatter every
     // lane owns ONE output (row r, feature fcol), so the mask is one float per lane (mask[g][0])
     struct StepIn { float y[EPT], z[EPT], dw[EPT], gq[EPT]; f32x4 mask[NM > 0 ? NM : 1]; f32x4 nmask; };
+    float zblk[EPT][4];                 // regenerated increments: the normals of the 4-step block being walked
+    int zblk_id = -1;
+    const uint32_t grow = (uint32_t)(a.row_offset + row);
     auto prefetch = [&](int n, StepIn& p) {
+        if (!a.dW) {                    // (wave-uniform)
+            if ((n >> 2) != zblk_id) {
+                zblk_id = n >> 2;
+#pragma unroll
+                for (int e = 0; e < EPT; ++e) snsde_philox_normal4(a.seed, grow, (uint32_t)zblk_id, (uint32_t)(fcol + e), zblk[e]);
+            }
+            const float sqh = a.step_tab[(size_t)n * SNSDE_STEP_STRIDE + 6];
+            const int k = n & 3;
+#pragma unroll
+            for (int e = 0; e < EPT; ++e)
+                p.dw[e] = (k == 0 ? zblk[e][0] : (k == 1 ? zblk[e][1] : (k == 2 ? zblk[e][2] : zblk[e][3]))) * sqh;
+        }
 #pragma unroll
         for (int e = 0; e < EPT; ++e) {
             p.y[e] = a.traj[(size_t)n * BH + goff + e];
             p.z[e] = a.act[(((size_t)n * NSAVE + CF::ZSLOT) * B) * H + goff + e];
-            p.dw[e] = a.dW[(size_t)n * BH + goff + e];
+            if (a.dW) p.dw[e] = a.dW[(size_t)n * BH + goff + e];
             if constexpr (NN > 0) p.gq[e] = a.act[(((size_t)n * NSAVE + NSAVE - 1) * B) * H + goff + e];   // diffusion-net output
             else p.gq[e] = a.gt ? a.gt[(size_t)n * H + fcol + e] : 0.0f;
         }

@@ -449,8 +449,8 @@ def solve_backward(call, grad_ys, stream=None, save_delta=False, adj0_only=False
     """Adjoint recursion over a finished training-mode solve (SolveCall with save_traj/save_dW/save_act):
     returns adj (N+1, B, H), adj[n] = dL/dy_n; adj[0] is the gradient w.r.t. y0.  adj0_only (MFMA adjoint kernels, mode 1,
     not Milstein through a diffusion net): adj is (1, B, H) - the intermediate adjoints stay on chip."""
-    if call.traj is None or call.dW_out is None:
-        raise ValueError('backward needs a solve run with save_traj and save_dW (and save_act on the MFMA path)')
+    if call.traj is None:
+        raise ValueError('backward needs a solve run with save_traj (and save_act on the MFMA path)')
     _check_f32('grad_ys', grad_ys, tuple(call.ys.shape))
     b = _lib.Backward()
     b.fwd = call.desc

@@ -436,9 +436,15 @@ class _FusedSolve(torch.autograd.Function):
         y0c = y0.detach().to(torch.float32).contiguous()
 
         def make(kernel, save_act):
+            # the increments are kept only where the backward cannot get them otherwise: the MFMA Euler / Milstein adjoint reads
+            # supplied ones in place and REGENERATES Philox ones (host key) - one (N, B, H) store and load less per step
+            nets = model.noise_option in (14, 15, 18, 19)
+            keep_dw = not (save_act and method in ('euler', 'milstein') and not (nets and method == 'milstein')
+                           and not torch.is_tensor(seed) and options.get('param_pass', 'hip') == 'hip'
+                           and os.environ.get('SNSDE_KEEP_INCREMENTS') != '1')
             return engine.SolveCall(model, flat, coeffs, grid, y0c, dW=dW, method=method, seed=seed,
                                     row_offset=int(options.get('row_offset', 0)), kernel=kernel, save_traj=True,
-                                    save_dW=True, save_act=save_act, exact_order=bool(options.get('exact_order', False)),
+                                    save_dW=keep_dw, save_act=save_act, exact_order=bool(options.get('exact_order', False)),
                                     row_out=options.get('row_out'), dU=dU)
         mode = engine.backward_mode(model, y0c.shape[0], coeffs.shape[1] + 1, grid, method, options.get('kernel', 'auto'),
                                     bool(options.get('exact_order', False)))
