@@ -288,7 +288,7 @@ def k2_training(dev, stream):
     path = os.path.join(ROOT, 'profiles', 'r03_train_traffic.txt')
     if os.path.exists(path):
         for line in open(path):
-            if line.startswith('saved activations'):
+            if line.startswith('current default'):
                 traffic = float(line.split('total')[1].split('MB')[0]) * 1e6
     sec = out["forward_backward"]["median_ms"] * 1e-3
     if traffic:

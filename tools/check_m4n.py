@@ -84,8 +84,10 @@ for (io, no, B, H, C, L, method) in ((1, 18, 1024, 128, 21, 50, 'srk'), (3, 18, 
     for kernel in ('auto', 'generic'):
         call = S.engine.SolveCall(model, flat, coeffs, grid, y0, method=method, kernel=kernel, seed=3)
         for _ in range(3): call.launch()
-        torch.cuda.synchronize(); t = time.perf_counter()
-        for _ in range(10): call.launch()
-        torch.cuda.synchronize()
+        ts_ = []
+        for _ in range(15):          # median of per-solve wall times
+            torch.cuda.synchronize(); t = time.perf_counter()
+            call.launch()
+            torch.cuda.synchronize(); ts_.append(time.perf_counter() - t)
         print(f'({io},{no}) {method} B={B} H={H} C={C} N={grid.N} kernel={kernel} path={S.engine.forward_path(model, B, L, grid.N, method=method, kernel=kernel)}: '
-              f'forward {(time.perf_counter() - t) / 10 * 1e3:.3f} ms')
+              f'forward {np.median(ts_) * 1e3:.3f} ms')

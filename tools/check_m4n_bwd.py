@@ -43,7 +43,9 @@ for (io, no, B, H, C, L, meth) in ((1, 18, 1024, 128, 21, 50, 'srk'), (3, 18, 20
             yy = y0.clone().requires_grad_(True)
             S.sdeint(m, yy, times, method=meth, dt=1.0, options=opts)[-1].square().mean().backward()
         for _ in range(3): fb()
-        torch.cuda.synchronize(); t = time.perf_counter()
-        for _ in range(10): fb()
-        torch.cuda.synchronize()
-        print(f'({io},{no}) {meth} B={B} H={H} C={C} N={L - 1} kernel={kernel}: fwd+bwd {(time.perf_counter() - t) / 10 * 1e3:.2f} ms')
+        ts_ = []
+        for _ in range(15):          # median of per-step wall times (a stray allocator / host hiccup does not move it)
+            torch.cuda.synchronize(); t = time.perf_counter()
+            fb()
+            torch.cuda.synchronize(); ts_.append(time.perf_counter() - t)
+        print(f'({io},{no}) {meth} B={B} H={H} C={C} N={L - 1} kernel={kernel}: fwd+bwd {np.median(ts_) * 1e3:.2f} ms')

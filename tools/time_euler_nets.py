@@ -24,7 +24,10 @@ for (io, no, B, H, C, L) in ((4, 18, 2048, 64, 69, 72), (1, 18, 1024, 128, 21, 5
         res = []
         for fn in (fw, fb):
             for _ in range(3): fn()
-            torch.cuda.synchronize(); t = time.perf_counter()
-            for _ in range(10): fn()
-            torch.cuda.synchronize(); res.append((time.perf_counter() - t) / 10 * 1e3)
+            ts_ = []
+            for _ in range(15):
+                torch.cuda.synchronize(); t = time.perf_counter()
+                fn()
+                torch.cuda.synchronize(); ts_.append(time.perf_counter() - t)
+            res.append(float(np.median(ts_)) * 1e3)
         print(f'({io},{no}) euler B={B} H={H} C={C} N={L - 1} kernel={kernel} path={S.engine.forward_path(model, B, L, L - 1, kernel=kernel)}: fwd {res[0]:.3f} ms, fwd+bwd {res[1]:.2f} ms')

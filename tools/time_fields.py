@@ -22,10 +22,12 @@ for kind in ('gsde', 'lnsde', 'nsde'):
             with torch.no_grad():
                 f = lambda: S.sdeint(field, y0, ts, dt=1.0 / n, method=method, options={'seed': 1, 'backend': backend})
                 for _ in range(3): f()
-                torch.cuda.synchronize(); t = time.perf_counter()
-                k = 10 if backend == 'auto' else 2
-                for _ in range(k): f()
-                torch.cuda.synchronize(); res.append((time.perf_counter() - t) / k * 1e3)
+                ts_ = []
+                for _ in range(11 if backend == 'auto' else 3):
+                    torch.cuda.synchronize(); t = time.perf_counter()
+                    f()
+                    torch.cuda.synchronize(); ts_.append(time.perf_counter() - t)
+                res.append(float(np.median(ts_)) * 1e3)
         cf = S.fields.compose(field)
         path = S.engine.forward_path(cf.model, rows, len(times), n, method=method, table=cf.tabulated) if cf is not None else None
         print(f'{kind:6s} {method:8s} fused path {path}: sdeint {res[0]:.3f} ms | tensor-op / graph stepper {res[1]:.1f} ms')
