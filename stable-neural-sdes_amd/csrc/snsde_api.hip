@@ -352,8 +352,9 @@ int snsde_solve_forward(const snsde_solve* s, void* hip_stream) {
         return snsde_mfma_launch(s, net, st, 1);
     }
     if (s->method == SNSDE_SRK) {   // SRK: MFMA variant (M4 tiles) where instantiated, else the generic (all-options) family
-        if (s->kernel == SNSDE_KERNEL_MFMA_M16) return SNSDE_ERR_UNSUPPORTED;
-        if (s->kernel == SNSDE_KERNEL_MFMA || s->kernel == SNSDE_KERNEL_MFMA_M4) return snsde_mfma_launch(s, net, st, 1);
+        if (s->kernel == SNSDE_KERNEL_MFMA_M16) return snsde_mfma_launch(s, net, st, 0);     // (H = 64 / 128, elementwise diffusions)
+        if (s->kernel == SNSDE_KERNEL_MFMA_M4) return snsde_mfma_launch(s, net, st, 1);
+        if (s->kernel == SNSDE_KERNEL_MFMA) return snsde_mfma_launch(s, net, st, -1);
         if (s->kernel == SNSDE_KERNEL_AUTO && snsde_mfma_supported(s, net)) return snsde_mfma_launch(s, net, st, -1);
         if (s->kernel != SNSDE_KERNEL_AUTO && s->kernel != SNSDE_KERNEL_GENERIC) return SNSDE_ERR_OPTION;
         if (s->z0_weight && (rc = snsde_z0_launch(s, st)) != SNSDE_OK) return rc;
@@ -389,8 +390,9 @@ int snsde_forward_path(const snsde_solve* s) {
     }
     const int hint = s->kernel == SNSDE_KERNEL_MFMA_M16 ? 0 : (s->kernel == SNSDE_KERNEL_MFMA_M4 ? 1 : -1);
     if (s->method == SNSDE_SRK) {
-        if (s->kernel == SNSDE_KERNEL_MFMA_M16) return SNSDE_PATH_NONE;
-        if (s->kernel == SNSDE_KERNEL_MFMA || s->kernel == SNSDE_KERNEL_MFMA_M4) return snsde_mfma_path(s, net, 1);
+        if (s->kernel == SNSDE_KERNEL_MFMA_M16) return snsde_mfma_path(s, net, 0);
+        if (s->kernel == SNSDE_KERNEL_MFMA_M4) return snsde_mfma_path(s, net, 1);
+        if (s->kernel == SNSDE_KERNEL_MFMA) return snsde_mfma_path(s, net, -1);
         if (s->kernel == SNSDE_KERNEL_AUTO && snsde_mfma_supported(s, net)) return snsde_mfma_path(s, net, -1);
         return SNSDE_PATH_GENERIC_SRK;
     }

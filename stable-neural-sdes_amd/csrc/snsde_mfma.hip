@@ -231,7 +231,10 @@ MfmaPlan make_plan(const snsde_solve* s, const SnsdeNet& net, int flavor_hint) {
     p.ok = false;
     if (m.hidden_hidden_channels != H) return p;
     const bool srk = s->method == SNSDE_SRK;
-    if (srk && flavor_hint == 0) return p;                   // SRK variant: M4 tiles
+    // SRK: 4-row tiles; 16-row tiles for the elementwise diffusions at H = 64 / 128, C <= 32 (large batches)
+    const bool srk_m16_ok = srk && (H == 64 || H == 128) && !(no == 14 || no == 15 || no == 18 || no == 19) && m.input_channels <= 32 &&
+                            m.activation == 0 && m.drift_output == 0 && m.diffusion_output == 0 && m.time_feature == 0 && !s->noise_table;
+    if (srk && flavor_hint == 0 && !srk_m16_ok) return p;
     if (!(H == 256 || H == 128 || H == 64 || H == 32 || H == 16)) return p;
     if (!(io >= 0 && io <= 6)) return p;
     const bool noise_net = (no == 14 || no == 15 || no == 18 || no == 19);
@@ -274,7 +277,7 @@ MfmaPlan make_plan(const snsde_solve* s, const SnsdeNet& net, int flavor_hint) {
         p.FL = flavor_hint >= 0 ? flavor_hint : (10 * r4 > 22 * r16 ? 0 : 1);
     }
     p.SRK = srk ? 1 : 0;
-    if (srk || m4n) p.FL = 1;
+    if ((srk && !srk_m16_ok) || m4n) p.FL = 1;
     p.M4N = m4n ? 1 : 0; p.KUXN = kuxn;
     p.FOLD = (emb && (nhid > 1 || p.KUX > 2 || srk || noise_net || !(s->flags & SNSDE_FLAG_EXACT_ORDER))) ? 1 : 0;   // exact order: NL <= 2, C <= 32 only
     // lean M4 kernel (snsde_m4_kernel.h): 4-row tiles, Euler / Milstein, elementwise diffusions, 32 <= H <= 128; the time
@@ -408,7 +411,7 @@ RevPlan make_rev_plan(const snsde_solve* s, const SnsdeNet& net, const MfmaPlan&
     p.SRK = fp.SRK;
     const int H = fp.H, io = fp.IO;
     if (p.SRK && io == 0) return p;      // (the SRK adjoint kernel has no y-free variant: the generic adjoint takes it)
-    p.H = H; p.NHID = fp.NHID; p.GEO = (io == 5 || io == 6) ? 1 : 0; p.FL = fp.FL; p.NW = fp.NW; p.NN = fp.NN;
+    p.H = H; p.NHID = fp.NHID; p.GEO = (io == 5 || io == 6) ? 1 : 0; p.FL = fp.SRK ? 1 : fp.FL; p.NW = fp.NW; p.NN = fp.NN;      // (the SRK adjoint: 4-row tiles, whatever tiles the forward ran on)
     p.emb = (io == 2 || io == 4 || io == 6) ? 1 : 0;
     p.IO0 = io == 0 ? 1 : 0;
     int off = 0, n = 0;

@@ -444,6 +444,7 @@ __global__ void __launch_bounds__(CF::NT, CF::WPS) snsde_mfma_kernel(MfmaArgs a)
             if (row_ok) {
                 *reinterpret_cast<f32x4*>(a.ys + (size_t)row * H + fcol[t]) = v;
                 if (a.traj) *reinterpret_cast<f32x4*>(a.traj + (size_t)row * H + fcol[t]) = v;
+                if constexpr (CF::SRK) { if (a.stage_save) *reinterpret_cast<f32x4*>(a.stage_save + (size_t)row * H + fcol[t]) = v; }
             }
         }
     }
@@ -901,6 +902,7 @@ __global__ void __launch_bounds__(CF::NT, CF::WPS) snsde_mfma_kernel(MfmaArgs a)
             } else {
                 const f32x4 vn = {ynew[0], ynew[1], ynew[2], ynew[3]};
                 *reinterpret_cast<f32x4*>(ybuf + r * LDY + fcol[t]) = vn;
+                if constexpr (CF::SRK) { if (a.stage_save && row_ok) *reinterpret_cast<f32x4*>(a.stage_save + (size_t)(n + 1) * BH + goff) = vn; }
                 if (row_ok && (!CF::SRK || stage == 2)) {
                     if (a.traj) *reinterpret_cast<f32x4*>(a.traj + (size_t)(ns + 1) * BH + goff) = vn;
                     if (a.dW_out) *reinterpret_cast<f32x4*>(a.dW_out + (size_t)ns * BH + goff) =
@@ -1691,11 +1693,11 @@ int dispatch_io(const MfmaPlan& p, const MfmaArgs& a, hipStream_t st) {
     if (p.IO == 4 && p.NHID == 1 && p.NN == 0) return dispatch_var<H, 2, 1, 4, FL, 0>(p, a, st);
     return SNSDE_ERR_UNSUPPORTED;
 #else
-    if (p.SRK) {           // SRID2 stepper: M4 tiles, folded first layer, C <= 32, elementwise diffusions
-        if constexpr (FL == 1) {
+    if (p.SRK) {           // SRID2 stepper: folded first layer, elementwise diffusions; 4-row tiles, and 16-row tiles at H = 64 / 128 (C <= 32)
+        if constexpr (FL == 1 || H == 64 || H == 128) {
 #define SNSDE_SRKC(IO_, NHID_) \
-    if (p.IO == IO_ && p.NHID == NHID_ && p.KUX != 5) return launch_cfg<Cfg<H, (IO_ % 2 == 0 ? 2 : 1), NHID_, IO_, 1, 1, (IO_ != 0 ? 1 : 0), 0, 1>>(a, st); \
-    if (p.IO == IO_ && p.NHID == NHID_ && p.KUX == 5 && IO_ % 2 == 0 && IO_ != 0 && NHID_ <= 2) return launch_cfg<Cfg<H, (IO_ % 2 == 0 && IO_ != 0 && NHID_ <= 2 ? 5 : 1), NHID_, IO_, 1, 1, 1, 0, 1>>(a, st);
+    if (p.IO == IO_ && p.NHID == NHID_ && p.KUX != 5) return launch_cfg<Cfg<H, (IO_ % 2 == 0 ? 2 : 1), NHID_, IO_, FL, 1, (IO_ != 0 ? 1 : 0), 0, 1>>(a, st); \
+    if (FL == 1 && p.IO == IO_ && p.NHID == NHID_ && p.KUX == 5 && IO_ % 2 == 0 && IO_ != 0 && NHID_ <= 2) return launch_cfg<Cfg<H, (IO_ % 2 == 0 && IO_ != 0 && NHID_ <= 2 ? 5 : 1), NHID_, IO_, 1, 1, 1, 0, 1>>(a, st);
 #define SNSDE_SRKS(IO_) SNSDE_SRKC(IO_, 0) SNSDE_SRKC(IO_, 1) SNSDE_SRKC(IO_, 2) SNSDE_SRKC(IO_, 3)
             SNSDE_SRKS(0) SNSDE_SRKS(1) SNSDE_SRKS(2) SNSDE_SRKS(3) SNSDE_SRKS(4) SNSDE_SRKS(5) SNSDE_SRKS(6)
 #undef SNSDE_SRKS

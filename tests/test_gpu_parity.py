@@ -1251,6 +1251,30 @@ def test_srk_diffusion_nets_take_the_mfma_net_kernels(ci):
     assert np.array_equal(y_auto, y_m4)
 
 
+SRK_M16_ROWS = [i for i, c in enumerate(SRK_CASES) if c[4] in (64, 128) and c[5] <= 32 and c[1] not in (14, 15, 18, 19) and c[7] is not None]
+
+
+@pytest.mark.parametrize('ci', SRK_M16_ROWS)
+def test_srk_on_16_row_tiles_vs_oracle_and_backward(ci):
+    """SRID2 on the 16-row-tile flavour (large batches; H = 64 / 128, elementwise diffusions): forward against the fp64 oracle,
+    identical Philox paths as the 4-row tiles, and a training step whose adjoint runs on 4-row tiles over the same saves."""
+    io, no, NL, B, H, C, L, ts, dt = SRK_CASES[ci]
+    pr = make_problem(700 + ci, io, no, NL, B, H, C, L)
+    dW = draw_dW(700 + ci, ts, dt, B, H)
+    dU = _draw_dU(700 + ci, dW, ts, dt)
+    ys, _ = hip_solve(pr, ts, dt, dW=dW, dU=dU, method='srk', kernel='mfma16')
+    ref64, _ = O.solve_diffusion_model(pr['params'], io, no, pr['coeffs'], pr['times'], pr['y0'], np.asarray(ts, np.float32), dt, dW,
+                                       method='srk', dtype=np.float64, dU=dU)
+    cpu32, _ = O.solve_diffusion_model(pr['params'], io, no, pr['coeffs'], pr['times'], pr['y0'], np.asarray(ts, np.float32), dt, dW,
+                                       method='srk', dtype=np.float32, dU=dU)
+    assert_parity(ys, ref64, cpu32, what=f'srk m16 case {ci}')
+    y16, _ = hip_solve(pr, ts, dt, method='srk', kernel='mfma16', seed=5)
+    y4, _ = hip_solve(pr, ts, dt, method='srk', kernel='mfma4', seed=5)
+    assert np.abs(y16 - y4).max() <= 2e-4 * (np.abs(y4).max() + 1e-9)
+    if io != 0:
+        _check_backward(4800 + ci, io, no, NL, B, H, C, L, ts, dt, 'srk', 'mfma16', strict=True)
+
+
 def test_srk_philox_levy_area_matches_specification_and_shards():
     pr = make_problem(41, 6, 17, 2, 24, 32, 5, 9)
     ts, dt = [0, 8], 0.5
