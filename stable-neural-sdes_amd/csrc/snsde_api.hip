@@ -426,8 +426,9 @@ int snsde_act_slots(const snsde_model* m) {
     if (rc) return rc;
     const int no = m->noise_option;   // + the diffusion net's activations (hidden for 18/19, output)
     // smooth activations (tutorial fields): the pre-activations of the NL activated layers as well (their derivative)
+    // (+ the hidden pre-activation of a two-layer diffusion net, the last slot)
     return m->num_hidden_layers + 1 + ((no == 18 || no == 19) ? 2 : ((no == 14 || no == 15) ? 1 : 0)) +
-           (m->activation != SNSDE_ACT_RELU ? m->num_hidden_layers : 0);
+           (m->activation != SNSDE_ACT_RELU ? m->num_hidden_layers + ((no == 18 || no == 19) ? 1 : 0) : 0);
 }
 
 int snsde_save_layout(const snsde_solve* s, int32_t* act_slots, int32_t* stage_planes, int32_t* delta_slots) {

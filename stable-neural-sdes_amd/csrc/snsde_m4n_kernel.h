@@ -296,8 +296,14 @@ __global__ void __launch_bounds__(CF::NT, CF::WPS) snsde_m4n_kernel(MfmaArgs a) 
         if (__builtin_expect(g_raw, 0)) return raw;
         return fast_tanh(sig_theta * snsde_nan_to_num(raw));
     };
+    // smooth activations (field variants, Euler / Milstein): the NL drift pre-activations and the net's hidden pre-activation
+    // follow the regular slots (snsde_act_slots)
+    const int nsave_rt = (!SRK && act_fn != 0) ? NSAVE + NHID + 1 + (NN == 2 ? 1 : 0) : NSAVE;
     auto save_act = [&](int pass, int slot, float v) {
-        if (a.act_save && row_ok) a.act_save[((size_t)pass * NSAVE + slot) * BH + (size_t)row * H + fcol] = v;
+        if (a.act_save && row_ok) a.act_save[((size_t)pass * nsave_rt + slot) * BH + (size_t)row * H + fcol] = v;
+    };
+    auto save_pre = [&](int pass, int idx, float v) {      // idx: drift layer 0 .. NHID, NHID + 1 = the net's hidden layer
+        if (!SRK && act_fn != 0) save_act(pass, NSAVE + idx, v);
     };
     // one net evaluation's layer 1 (reads gyrow): NN == 2 -> relu'd hidden into nbuf (returned); NN == 1 -> the output q
     auto net_l1 = [&](int pass, int slot0, float& q) {
@@ -308,6 +314,7 @@ __global__ void __launch_bounds__(CF::NT, CF::WPS) snsde_m4n_kernel(MfmaArgs a) 
         if constexpr (NN == 2) {
             o = actf(o);
             nbuf[r * LDA + fcol] = o;
+            save_pre(pass, NHID + 1, pre);
         } else {
             q = o;
         }
@@ -347,9 +354,11 @@ __global__ void __launch_bounds__(CF::NT, CF::WPS) snsde_m4n_kernel(MfmaArgs a) 
             f32x4 c = {0.f, 0.f, 0.f, 0.f}, d = c;
             gemm4<KUY>(wy, yrow, c, d);
             if constexpr (CF::EMB) gemm4<CF::EMB ? KUX : 1>(wx, xrow, c, d);
-            const float o = actf(m4_reduce_scatter(c + d) + bias_own[0]);
+            const float pre = m4_reduce_scatter(c + d) + bias_own[0];
+            const float o = actf(pre);
             bufA[r * LDA + fcol] = o;
             save_act(n, 0, o);
+            save_pre(n, 0, pre);
         }
         const float nhid_own = net_l1(n, CF::ZSLOT + 1, q);      // (NN == 2: this lane's hidden pre-activation of the net)
         __syncthreads();
@@ -433,9 +442,11 @@ __global__ void __launch_bounds__(CF::NT, CF::WPS) snsde_m4n_kernel(MfmaArgs a) 
             if (l == 0) gemm4<KUH>(wh0, cur, c, d);
             else if (l == 1) gemm4<KUH>(wh1, cur, c, d);
             else gemm4<KUH>(wh2, cur, c, d);
-            const float o = actf(m4_reduce_scatter(c + d) + bias_own[1 + l]);
+            const float pre = m4_reduce_scatter(c + d) + bias_own[1 + l];
+            const float o = actf(pre);
             (toB ? bufB : bufA)[r * LDA + fcol] = o;
             save_act(n, 1 + l, o);
+            save_pre(n, 1 + l, pre);
             if constexpr (MIL) { if (tdone < NTR) net_t(); }
             __syncthreads();
             tsync = true;

@@ -400,10 +400,14 @@ RevPlan make_rev_plan(const snsde_solve* s, const SnsdeNet& net, const MfmaPlan&
                          ((s->method == SNSDE_SRK && m4n_rev_instantiated(fp.H, fp.NHID, fp.NN)) ||
                           (s->method == SNSDE_MILSTEIN && m4n_mil_rev_instantiated(fp.H, fp.NHID, fp.NN)));
     if (fp.NN != 0 && s->method != SNSDE_EULER && !m4n_rev) return p;
-    if (fp.M4N && s->method == SNSDE_EULER && variant_of(s)) return p;       // (field variants with a net: no fused backward)
+    // field variants with a net (NeuralSDEFunc-shaped, fields.py): Euler on the general adjoint kernel's 4-row tiles
+    const bool variant_net_rev = fp.M4N && variant_of(s) && s->method == SNSDE_EULER && fp.FL == 1 && fp.H <= 128 && fp.IO != 0 &&
+                                 !s->noise_table && s->model.diffusion_output != SNSDE_DIFFUSION_TANH &&
+                                 s->model.drift_output != SNSDE_DRIFT_TIMES_Y;
+    if (fp.M4N && variant_of(s) && !variant_net_rev) return p;
     p.M4N = m4n_rev ? (s->method == SNSDE_SRK ? 1 : 2) : 0;
     // tutorial-style fields: the register-resident lean forward (its training-mode instantiations), Euler / Milstein
-    if (variant_of(s) && !(fp.LEAN && fp.FL == 1 && fp.H <= 128 && !fp.SRK && s->method != SNSDE_SRK &&
+    if (variant_of(s) && !variant_net_rev && !(fp.LEAN && fp.FL == 1 && fp.H <= 128 && !fp.SRK && s->method != SNSDE_SRK &&
                            (s->model.activation == SNSDE_ACT_RELU || lean_act_save_fits(fp.H, fp.NHID, fp.KUXT)) &&
                            (s->model.diffusion_output == SNSDE_DIFFUSION_RAW || s->model.noise_option == 0) &&
                            (s->noise_table != nullptr || s->model.noise_option == 0)))
@@ -648,7 +652,7 @@ int snsde_mfma_backward_launch(const snsde_backward* b, const SnsdeNet& net, hip
     a.params = s->params; a.ws = ws;
     a.gt = s->noise_table ? s->noise_table : (fp.gt_off >= 0 ? static_cast<const float*>(s->workspace) + fp.gt_off : nullptr);
     a.act_fn = s->model.activation; a.f_out = s->model.drift_output; a.g_out = s->model.diffusion_output;
-    a.nsave = s->model.num_hidden_layers + 1 + fp.NN + (s->model.activation != SNSDE_ACT_RELU ? s->model.num_hidden_layers : 0);
+    a.nsave = s->model.num_hidden_layers + 1 + fp.NN + (s->model.activation != SNSDE_ACT_RELU ? s->model.num_hidden_layers + (fp.NN == 2 ? 1 : 0) : 0);
     a.step_tab = s->step_tab; a.out_w = s->out_w; a.traj = s->traj; a.act = s->act_save;
     // increments: the ones the forward wrote out, else the supplied ones, else (Philox, host key) regenerated by the kernel
     a.dW = s->dW_out ? s->dW_out : s->dW;

@@ -1112,15 +1112,15 @@ __global__ void __launch_bounds__(CF::NT, CF::WPS) snsde_mfma_reverse_kernel(Rev
             p.y[e] = a.traj[(size_t)n * BH + goff + e];
             p.z[e] = a.act[(((size_t)n * NSAVE + CF::ZSLOT) * B) * H + goff + e];
             if (a.dW) p.dw[e] = a.dW[(size_t)n * BH + goff + e];
-            if constexpr (NN > 0) p.gq[e] = a.act[(((size_t)n * NSAVE + NSAVE - 1) * B) * H + goff + e];   // diffusion-net output
+            if constexpr (NN > 0) p.gq[e] = a.act[(((size_t)n * NSAVE + CF::ZSLOT + NN) * B) * H + goff + e];   // diffusion-net output
             else p.gq[e] = a.gt ? a.gt[(size_t)n * H + fcol + e] : 0.0f;
         }
         if constexpr (FL) {
 #pragma unroll
             for (int g = 0; g < NM; ++g)     // relu mask of the forward activation feeding transposed GEMM g + 1
-                p.mask[g][0] = a.act[((size_t)n * NSAVE + (NHID - g) + (a.act_fn != 0 ? NHID + 2 : 0)) * BH + goff];
-            if constexpr (NN == 2)               // hidden activation of the diffusion net
-                p.nmask[0] = a.act[((size_t)n * NSAVE + CF::ZSLOT + 1) * BH + goff];
+                p.mask[g][0] = a.act[((size_t)n * NSAVE + (NHID - g) + (a.act_fn != 0 ? NHID + 2 + NN : 0)) * BH + goff];     // (smooth activations: the PRE-activation slots, behind the net's)
+            if constexpr (NN == 2)               // hidden activation of the diffusion net (smooth: its pre-activation, the last slot)
+                p.nmask[0] = a.act[((size_t)n * NSAVE + (a.act_fn != 0 ? NSAVE - 1 : CF::ZSLOT + 1)) * BH + goff];
         } else if (writer) {
 #pragma unroll
             for (int g = 0; g < NM; ++g)
@@ -1185,6 +1185,14 @@ __global__ void __launch_bounds__(CF::NT, CF::WPS) snsde_mfma_reverse_kernel(Rev
                 dz[e] = av * h * fz;
                 const float qq = mil * fmaf(dw, dw, -h);
                 float d = 0.0f;
+                if constexpr (NN > 0) {
+                    // NeuralSDEFunc-shaped fields (Euler): g = raw = q {y}, q the net's output (linear for SNSDE_DIFFUSION_RAW_NET,
+                    // rectified for SNSDE_DIFFUSION_RAW); the cotangent of q enters the net's transposed chain
+                    float dqv = mul_y ? av * dw * y : av * dw;
+                    if (mul_y) acc = fmaf(av * dw, gq, acc);
+                    if (NN == 2 && a.g_out != SNSDE_DIFFUSION_RAW_NET) dqv = gq > 0.0f ? dqv : 0.0f;
+                    dq[e] = dqv;
+                } else
                 if (a.g_out == SNSDE_DIFFUSION_RAW) {
                     if (mul_y) { acc = fmaf(av * gq, fmaf(qq, gq, dw), acc); d = av * rowf * y * fmaf(2.0f * qq, gq, dw); }
                     else d = av * rowf * dw;

@@ -634,7 +634,8 @@ int snsde_wgrad_launch(const snsde_backward* b, const SnsdeNet& net, float* grad
         a.traj = s.stage_save;                     // first-layer inputs = the stage states
     }
     const bool smooth = s.model.activation != SNSDE_ACT_RELU;      // act_save then also holds the NL pre-activations per step
-    a.B = s.batch; a.H = H; a.N = wp->n_pass; a.NG = wp->ndelta; a.NSAVE = wp->nact + (smooth ? s.model.num_hidden_layers : 0);
+    a.B = s.batch; a.H = H; a.N = wp->n_pass; a.NG = wp->ndelta;
+    a.NSAVE = wp->nact + (smooth ? s.model.num_hidden_layers + ((no == 18 || no == 19) ? 1 : 0) : 0);
     a.adj = b->adj;
     a.ldx = wp->ldx; a.R = wp->n_pass * s.batch; a.ntiles = wp->ntiles; a.NP = wp->NP;
     for (int i = 0; i < wp->ntiles; ++i) a.tile[i] = wp->tile[i];

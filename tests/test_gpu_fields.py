@@ -114,6 +114,9 @@ GRAD_CASES = [(kind, H, layers, act, method)
               for kind in ('lsde', 'lnsde', 'lnsde_additive', 'gsde')
               for H, layers, act, method in ((32, 1, 'lipswish', 'euler'), (64, 2, 'lipswish', 'milstein'), (128, 2, 'silu', 'euler'),
                                              (32, 3, 'relu', 'milstein'))]
+# NeuralSDEFunc-shaped fields (drift and diffusion both MLPs of [t, y]): Euler, the net kernels + the general adjoint kernel
+GRAD_CASES += [('nsde', H, 1, act, 'euler') for H, act in ((16, 'lipswish'), (32, 'lipswish'), (64, 'relu'), (64, 'silu'),
+                                                            (128, 'lipswish'), (128, 'relu'))]
 
 
 @pytest.mark.parametrize('kind,H,layers,act,method', GRAD_CASES)
