@@ -231,6 +231,34 @@ def sub_grid(grid, n0, n1):
     return g, [k + 1 for k in ks]
 
 
+def every_step_grid(grid):
+    """`grid`'s solver steps with an output after EVERY step (T = N + 1, no interpolation): the solve then returns the whole
+    trajectory as its result, so a caller can attach cotangents to any state (torchsde._sdeint_latent: the KL path integral of
+    a latent SDE is a quadrature over all of them).  Memoised on the grid."""
+    g = grid.__dict__.get('_every_step')
+    if g is not None:
+        return g
+    g = StepGrid.__new__(StepGrid)
+    N = grid.N
+    tab = grid.step_tab.copy()
+    tab[:, 8] = np.ones(N, dtype=np.int32).view(np.float32)
+    tab[:, 9] = np.arange(N, dtype=np.int32).view(np.float32)
+    g.N, g.T = N, N + 1
+    g.step_tab = tab
+    g.out_step = np.arange(N, dtype=np.int32)
+    g.out_w = np.tile(np.array([[0.0, 1.0]], dtype=np.float32), (N, 1))
+    g._times32, g._d_srk = grid._times32, None
+    g.t0, g.t1 = tab[:, 0].copy(), tab[:, 7].copy()
+    g.device = grid.device
+    if grid.device is not None and grid.device.type == 'cuda':
+        g.d_step_tab = torch.from_numpy(tab).to(grid.device)
+        g.d_t0 = torch.from_numpy(g.t0).to(grid.device)
+        g.d_out_step = torch.from_numpy(g.out_step).to(grid.device)
+        g.d_out_w = torch.from_numpy(g.out_w).to(grid.device)
+    grid.__dict__['_every_step'] = g
+    return g
+
+
 def chunk_plan(grid, chunk):
     """[(n0, n1, sub grid, parent output numbers)] for the recompute-mode backward (memoised on the grid)."""
     cache = grid.__dict__.setdefault('_chunks', {})

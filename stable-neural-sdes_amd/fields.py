@@ -166,7 +166,40 @@ class ComposedField:
         assert out.numel() == self.numel
         return out
 
+    def _flat_latent(self, dev, grad):
+        """LatentSDE-shaped posterior drift f = linear_out(relu(.. relu(linear_in([sin t, cos t, y])))) on the latent channels,
+        zero-padded to the instantiated width P, as the block of (input_option 4, noise_option 12) with an identity embedding:
+        emb = [I | 0] makes z = linear_in([tau, y]) (the folded first layer multiplies it out exactly), the control path is a
+        dummy channel with zero weights."""
+        p = self.parts
+        P, Hl = self.model.hidden_channels, p['latent']
+        f64 = dict(device=dev, dtype=torch.float32)
+        W = lambda lin: (lin.weight if grad else lin.weight.detach()).to(**f64)
+        b = lambda lin: (lin.bias if grad else lin.bias.detach()).to(**f64)
+        pad2 = lambda w, rows, cols: torch.nn.functional.pad(w, (0, cols - w.shape[1], 0, rows - w.shape[0]))
+        pad1 = lambda v, n: torch.nn.functional.pad(v, (0, n - v.shape[0]))
+        w_in = W(p['linear_in'])                           # (HH, 2 + Hl): [sin t, cos t, y]
+        vals = {'theta': torch.zeros(1, 1, **f64),
+                'initial_network.weight': torch.zeros(P, self.model.input_channels, **f64),
+                'initial_network.bias': torch.zeros(P, **f64),
+                'linear_in.weight': pad2(w_in, P, P + 2), 'linear_in.bias': pad1(b(p['linear_in']), P),
+                'emb.weight': torch.cat([torch.eye(P, **f64), torch.zeros(P, P, **f64)], dim=1), 'emb.bias': torch.zeros(P, **f64),
+                'linear_out.weight': pad2(W(p['linear_out']), P, P), 'linear_out.bias': pad1(b(p['linear_out']), P),
+                'noise_t.weight': torch.zeros(P, 2, **f64), 'noise_t.bias': torch.zeros(P, **f64)}
+        for i, lin in enumerate(p['linears']):
+            vals[f'linears.{i}.weight'], vals[f'linears.{i}.bias'] = pad2(W(lin), P, P), pad1(b(lin), P)
+        pieces = []
+        for name, off, shape in self.layout:
+            v = vals[name]
+            assert tuple(v.shape) == tuple(shape), (name, tuple(v.shape), shape)
+            pieces.append(v.reshape(-1))
+        out = torch.cat(pieces)
+        assert out.numel() == self.numel
+        return out
+
     def _flat(self, dev, grad):
+        if 'latent' in self.parts:
+            return self._flat_latent(dev, grad)
         if not self.tabulated:
             return self._flat_net(dev, grad)
         p = self.parts
@@ -330,6 +363,101 @@ def _compose_net(sde):
         return None
     parts = dict(linear_in=lin_in, mlp=mlp, noise_in=noise_in, noise_first=gc[0][0], noise_last=gc[0][1])
     return ComposedField(sde, model, layout, numel, parts, additive=False)
+
+
+class _LatentView:
+    """The latent channels of a LatentSDE-shaped module as a field of their own, zero-padded to the kernels' width: what
+    `verify` probes and `ComposedField` tabulates.  f / g are the MODULE'S OWN posterior drift and shared diffusion."""
+
+    def __init__(self, sde, Hl, P):
+        self.sde, self.Hl, self.P = sde, Hl, P
+        self.coeffs = self.times = None
+
+    def parameters(self):
+        yield from self.sde.parameters()
+        for name in ('sigma', 'theta', 'mu'):      # buffers of the prior / diffusion: part of the cached inputs' identity
+            v = getattr(self.sde, name, None)
+            if torch.is_tensor(v):
+                yield v
+
+    def _pad(self, v):
+        return torch.nn.functional.pad(v, (0, self.P - self.Hl))
+
+    def f(self, t, y):
+        return self._pad(self.sde.f(t, y[:, :self.Hl]))
+
+    def g(self, t, y):
+        return self._pad(self.sde.g(t, y[:, :self.Hl]))
+
+
+_WIDTHS = (16, 32, 64, 128, 256)
+
+
+def compose_latent(sde, names, width):
+    """torch-ists' LatentSDE (diff_module/NSDE/latent_sde.py:31-89) and modules of its shape, solved through
+    names={'drift': 'f_aug', 'diffusion': 'g_aug'}: the state is [latent (width - 1) | KL accumulator]; the latent channels
+    follow the posterior drift f = MLP([sin t, cos t, y]) (relu) with the constant shared diffusion g, and the accumulator
+    integrates 0.5 |(f - h) / g|^2 without feeding back.  Returns the ComposedField of the LATENT dynamics (the fused solve's
+    part; torchsde._sdeint_latent adds the accumulator as one batched quadrature over the solve's states), or None."""
+    if not isinstance(sde, torch.nn.Module) or not isinstance(names, dict):
+        return None
+    if names.get('drift') != 'f_aug' or names.get('diffusion') != 'g_aug' or (set(names) - {'drift', 'diffusion'}):
+        return None
+    cached = sde.__dict__.get('_snsde_latent')
+    if cached is not None and cached[0] == width:
+        return cached[1]
+    result = _compose_latent(sde, width)
+    sde.__dict__['_snsde_latent'] = (width, result)
+    return result
+
+
+def _compose_latent(sde, width):
+    if getattr(sde, 'sde_type', None) != 'ito' or getattr(sde, 'noise_type', None) != 'diagonal':
+        return None
+    if not all(callable(getattr(sde, a, None)) for a in ('f', 'g', 'f_aug', 'g_aug')):
+        return None
+    lin_in, lin_out, linears = getattr(sde, 'linear_in', None), getattr(sde, 'linear_out', None), getattr(sde, 'linears', None)
+    if not isinstance(lin_in, torch.nn.Linear) or not isinstance(lin_out, torch.nn.Linear) or lin_in.bias is None or lin_out.bias is None:
+        return None
+    if not isinstance(linears, (torch.nn.ModuleList, list, tuple)):
+        return None
+    linears = list(linears)
+    Hl, HH = width - 1, lin_in.out_features
+    if Hl < 1 or lin_in.in_features != Hl + 2 or lin_out.in_features != HH or lin_out.out_features != Hl or len(linears) > 3:
+        return None
+    if any(not _is_linear(m, HH, HH) for m in linears):
+        return None
+    # what the split relies on, checked on the module's own functions: the augmented drift / diffusion restricted to the
+    # latent channels are f / g, neither depends on the accumulator, g depends on neither y nor the accumulator, and the
+    # accumulator carries no noise
+    try:
+        with torch.no_grad():
+            p0 = lin_in.weight
+            gen = torch.Generator().manual_seed(5)
+            y = torch.randn(3, Hl, generator=gen).to(p0)
+            a1, a2 = torch.zeros(3, 1).to(p0), torch.full((3, 1), 1.7).to(p0)
+            t = torch.tensor(0.41).to(p0)
+            fa1, fa2 = sde.f_aug(t, torch.cat([y, a1], dim=1)), sde.f_aug(t, torch.cat([y, a2], dim=1))
+            ga1, ga2 = sde.g_aug(t, torch.cat([y, a1], dim=1)), sde.g_aug(t, torch.cat([-2.0 * y, a2], dim=1))
+            f, g = sde.f(t, y), sde.g(t, y)
+    except Exception:
+        return None
+    if tuple(fa1.shape) != (3, width) or tuple(ga1.shape) != (3, width) or tuple(f.shape) != (3, Hl) or tuple(g.shape) != (3, Hl):
+        return None
+    if not (torch.allclose(fa1, fa2) and torch.allclose(fa1[:, :Hl], f) and torch.allclose(ga1, ga2)
+            and torch.allclose(ga1[:, :Hl], g) and float(ga1[:, -1].abs().max()) == 0.0):
+        return None
+    P = next((w for w in _WIDTHS if w >= max(Hl, HH)), None)
+    if P is None or P > 128:       # (the SRK variant and the training-mode lean kernels: H <= 128)
+        return None
+    model = engine.model_struct(1, P, P, len(linears) + 1, 4, 12, activation=ACT_RELU, drift_output=DRIFT_LINEAR,
+                                diffusion_output=DIFFUSION_RAW, time_feature=TIME_SINCOS)
+    try:
+        layout, numel = _lib.param_layout(model)
+    except _lib.SnsdeError:
+        return None
+    parts = dict(latent=Hl, linear_in=lin_in, linears=linears, linear_out=lin_out)
+    return ComposedField(_LatentView(sde, Hl, P), model, layout, numel, parts, additive=True)
 
 
 @torch.no_grad()

@@ -165,6 +165,8 @@ def sdeint(sde, y0, ts, bm=None, method=None, dt=1e-3, adaptive=False, rtol=1e-5
         ys = _sdeint_composed(sde, y0, ts, bm, method, float(dt), options)     # tutorial-style fields (fields.py)
         if ys is not None:
             return ys
+    if not default_names and rec is None and backend == 'auto' and y0.is_cuda:
+        return _sdeint_latent(sde, y0, ts, bm, method, float(dt), options, names)    # LatentSDE-shaped modules (falls back itself)
     return _sdeint_torch(sde, y0, ts, bm, method, float(dt), options, names)
 
 
@@ -370,6 +372,114 @@ def _sdeint_composed(sde, y0, ts, bm, method, dt, options):
         if exc.code != -4:
             raise
         return None
+
+
+def _draw_increments(bm, grid, y0, method, options):
+    """Every increment of a solve up front, (N, B, H) I_k (and I_k0 for SRK): from the caller's Brownian object, in step
+    order, or from a torch generator (options['seed'])."""
+    dev = y0.device
+    t0s, t1s = torch.from_numpy(grid.t0).to(dev), torch.from_numpy(grid.t1).to(dev)
+    hs = (t1s - t0s).to(y0.dtype)
+    if bm is None:
+        gen = torch.Generator(device=dev)
+        seed = options.get('seed')
+        gen.manual_seed(int(seed) if seed is not None and not torch.is_tensor(seed) else _fresh_seed())
+        hcol = hs.reshape(-1, *([1] * y0.dim()))
+        dW = torch.randn((grid.N,) + tuple(y0.shape), dtype=y0.dtype, device=dev, generator=gen) * hcol.sqrt()
+        dU = None
+        if method == 'srk':      # I_k0 = h (I_k / 2 + sqrt(h / 12) xi): the space-time Levy integral
+            xi = torch.randn((grid.N,) + tuple(y0.shape), dtype=y0.dtype, device=dev, generator=gen)
+            dU = hcol * (0.5 * dW + (hcol / 12).sqrt() * xi)
+        return dW, dU
+    if method == 'srk':
+        pairs = [bm(t0s[n], t1s[n], return_U=True) for n in range(grid.N)]
+        return (torch.stack([p[0].to(device=dev, dtype=y0.dtype) for p in pairs]),
+                torch.stack([p[1].to(device=dev, dtype=y0.dtype) for p in pairs]))
+    return torch.stack([bm(t0s[n], t1s[n]).to(device=dev, dtype=y0.dtype) for n in range(grid.N)]), None
+
+
+def _sdeint_latent(sde, y0, ts, bm, method, dt, options, names):
+    """torch-ists' LatentSDE through names={'drift': 'f_aug', 'diffusion': 'g_aug'} (latent_sde.py:60-89, 134-141): the state
+    is [latent | KL accumulator] and the accumulator never feeds back, so the solve splits into
+      * the LATENT dynamics - posterior-drift MLP of [sin t, cos t, y], constant shared diffusion - on the fused kernels
+        (fields.compose_latent: forward, adjoint and weight gradients as for the tutorial fields), returning every state, and
+      * the accumulator = the scheme's own update of the last channel, evaluated for ALL steps at once: one batched call of the
+        module's f_aug / g_aug (the same `_srk_step` / Euler update the tensor-op loop runs) on the (N B) states of the solve.
+    Autograd joins the two: the batched step's graph gives d/d parameters and the cotangents of every state, which enter the
+    fused adjoint as output gradients.  N sequential launches of ~25-100 kernels become one solve + one batched step.
+    Falls back to the tensor-op loop (same increments) for anything it does not recognise."""
+    from . import fields
+    field = None
+    if y0.dim() == 2 and y0.shape[1] >= 2 and not torch.cuda.is_current_stream_capturing() and 'row_out' not in options:
+        field = fields.compose_latent(sde, names, int(y0.shape[1]))
+    if field is None:
+        return _sdeint_torch(sde, y0, ts, bm, method, dt, options, names)
+    dev, B = y0.device, int(y0.shape[0])
+    Hl, P = field.parts['latent'], field.model.hidden_channels
+    ts_host = _HostTimes.get(ts)
+    times_host = np.array([ts_host[0], ts_host[-1]], dtype=np.float32)
+    grid = engine.step_grid(ts_host, dt, times_host, dev)
+    dW, dU = _draw_increments(bm, grid, y0, method, options)
+    drawn = _DrawnIncrements(dW, dU)
+
+    def fallback():
+        return _sdeint_torch(sde, y0, ts, drawn, method, dt, options, names)
+    view = field.sde
+    cache = field.__dict__.setdefault('_dummy_control', {})
+    key = (B, str(dev))
+    if key not in cache:        # the field has no control path: one zero channel on the knots [ts[0], ts[-1]]
+        cache.clear()
+        cache[key] = torch.zeros(B, 1, 4, device=dev, dtype=torch.float32)
+    coeffs = cache[key]
+    view.coeffs, view.times = coeffs, torch.from_numpy(times_host).to(dev)
+    try:
+        if not fields.verify(field, coeffs, times_host, dev):
+            return fallback()
+    except RuntimeError:
+        return fallback()
+    full = engine.every_step_grid(grid)
+    needs_grad = torch.is_grad_enabled() and (y0.requires_grad or any(p.requires_grad for p in sde.parameters()))
+    widen = lambda t: None if t is None else torch.nn.functional.pad(t[..., :Hl].to(torch.float32), (0, P - Hl)).contiguous()
+    tab_times = full.d_t0 if method != 'srk' else engine.srk_stage_times(full)
+    y0p = torch.nn.functional.pad(y0[:, :Hl], (0, P - Hl))
+    if needs_grad:
+        if engine.backward_mode(field.model, B, 2, full, method, table=True) != 1:
+            return fallback()
+        flat = field.flat(dev, grad=True)
+        tab = field.noise_table(tab_times, dev)           # (the shared diffusion is a buffer: no gradient)
+        Y = _ComposedSolve.apply(field.model, coeffs, full, widen(dW), method, 0, 0, None, y0p, flat, tab, widen(dU))
+    else:
+        flat, tab = field.inference_inputs(tab_times, dev)
+        call = engine.SolveCall(field.model, flat, coeffs, full, y0p.detach().to(torch.float32).contiguous(), dW=widen(dW),
+                                dU=widen(dU), method=method, seed=0, noise_table=tab)
+        try:
+            Y = call.launch()
+        except engine._lib.SnsdeError as exc:
+            if exc.code != -4:
+                raise
+            return fallback()
+    N = grid.N
+    lat = Y[:, :, :Hl].to(y0.dtype)                               # (N + 1, B, Hl)
+    f_aug, g_aug = _call(sde, names, 'drift', 'f'), _call(sde, names, 'diffusion', 'g')
+    t_rows = full.d_t0.to(y0.dtype).reshape(N, 1, 1).expand(N, B, 1).reshape(N * B, 1)
+    h_rows = torch.from_numpy(grid.t1 - grid.t0).to(device=dev, dtype=y0.dtype).reshape(N, 1, 1).expand(N, B, 1).reshape(N * B, 1)
+    ya = torch.cat([lat[:-1], torch.zeros(N, B, 1, device=dev, dtype=y0.dtype)], dim=-1).reshape(N * B, Hl + 1)
+    try:
+        if method == 'srk':
+            inc = _srk_step(f_aug, g_aug, t_rows, h_rows, ya, dW.reshape(N * B, -1), dU.reshape(N * B, -1))[:, -1]
+        else:            # Euler; Milstein's correction g dg/dy vanishes for the constant diffusion (checked by the probe's g)
+            inc = f_aug(t_rows, ya)[:, -1] * h_rows[:, 0] + g_aug(t_rows, ya)[:, -1] * dW.reshape(N * B, -1)[:, -1]
+    except (RuntimeError, ValueError, TypeError, IndexError):
+        return fallback()
+    acc = torch.cat([y0[:, Hl].unsqueeze(0), y0[:, Hl].unsqueeze(0) + torch.cumsum(inc.reshape(N, B), dim=0)], dim=0)
+    aug = torch.cat([lat, acc.unsqueeze(-1)], dim=-1)             # (N + 1, B, Hl + 1): every state of the augmented solve
+    idx = torch.from_numpy(grid.out_step.astype(np.int64)).to(dev)
+    w = torch.from_numpy(grid.out_w).to(device=dev, dtype=y0.dtype)
+    if bool((grid.out_w[:, 0] == 0).all()):
+        outs = aug.index_select(0, idx + 1)
+    else:          # outputs inside a step: torchsde's linear interpolation between the step's end states
+        outs = w[:, 0].reshape(-1, 1, 1) * aug.index_select(0, idx) + w[:, 1].reshape(-1, 1, 1) * aug.index_select(0, idx + 1)
+    return torch.cat([y0.unsqueeze(0).to(aug.dtype), outs], dim=0)
 
 
 def _sdeint_padded(sde, rec, pad, coeffs, grid, y0, dW, dU, method, seed, options, row_out, needs_grad):
@@ -808,8 +918,11 @@ def _sdeint_torch(sde, y0, ts, bm, method, dt, options, names):
             with torch.enable_grad():
                 yy = y if y.requires_grad else y.detach().requires_grad_(True)
                 gv = g(t0, yy)
-                gdg, = torch.autograd.grad(gv, yy, grad_outputs=(gv if diff else gv.detach()) * v, allow_unused=True,
-                                           create_graph=diff)
+                if gv.requires_grad:
+                    gdg, = torch.autograd.grad(gv, yy, grad_outputs=(gv if diff else gv.detach()) * v, allow_unused=True,
+                                               create_graph=diff)
+                else:            # a diffusion that depends on neither the state nor a parameter (a constant buffer): no correction
+                    gdg = None
             gv = gv if diff else gv.detach()
             gdg = torch.zeros_like(y) if gdg is None else gdg
             y = y + f(t0, y) * h + gv * I + 0.5 * gdg

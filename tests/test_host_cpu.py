@@ -871,3 +871,64 @@ def test_tutorial_field_class_reproduces_the_notebooks_fields(case):
         ys = S.sdeint(f64, y0.double(), times, bm=Replay(), dt=float(g['dt']), method=str(g['method']),
                       options={'backend': 'torch'})
     np.testing.assert_allclose(ys.numpy(), g['ys64'], rtol=1e-7, atol=1e-8)
+
+
+# ---- torch-ists' LatentSDE (tests/golden/latent.npz: generated by importing the reference class) ------------------------------
+LAT = load('latent.npz')
+L1_CASES = sorted({k.split('/')[1] for k in LAT.files if k.startswith('L1/')})
+
+
+def _latent_case(case, dtype=torch.float32):
+    from tests.latent_field import LatentField
+    g = group(LAT, f'L1/{case}')
+    C, H, HH, NL = (int(v) for v in g['meta'])
+    sd = {k: torch.from_numpy(v.copy()) for k, v in params_of(LAT, f'L1/{case}').items()}
+    m = LatentField(C, H, HH, NL).to(dtype)
+    m.load_state_dict({k: v.to(dtype) for k, v in sd.items()}, strict=True)
+    return g, m
+
+
+@pytest.mark.parametrize('case', L1_CASES)
+def test_latent_field_class_reproduces_the_reference_latent_sde(case):
+    """The test-side LatentField loads the reference LatentSDE's state_dict strictly (buffers included), gives the same
+    f_aug / g_aug, and the tensor-op loop through names={'drift': 'f_aug', 'diffusion': 'g_aug'} reproduces the float64
+    trajectory of the augmented system; the latent composition (fields.compose_latent) accepts the module."""
+    from stable_neural_sdes_amd import fields
+    g, m = _latent_case(case)
+    y0 = torch.from_numpy(g['y0'])
+    with torch.no_grad():
+        for i, t in enumerate(torch.from_numpy(g['probe_t'])):
+            np.testing.assert_allclose(m.f_aug(t, y0).numpy(), g['f_aug'][i], rtol=2e-5, atol=2e-5)
+            np.testing.assert_allclose(m.g_aug(t, y0).numpy(), g['g_aug'][i], rtol=0, atol=0)
+    names = {'drift': 'f_aug', 'diffusion': 'g_aug'}
+    cf = fields.compose_latent(m, names, y0.shape[1])
+    assert cf is not None and cf.parts['latent'] == y0.shape[1] - 1
+    assert cf.model.hidden_channels in (16, 32, 64, 128) and cf.model.hidden_channels >= y0.shape[1] - 1
+    flat = cf.flat(torch.device('cpu'))
+    assert flat.numel() == cf.numel and bool(torch.isfinite(flat).all())
+    assert fields.compose_latent(m, {'drift': 'f', 'diffusion': 'g'}, y0.shape[1]) is None
+    _, m64 = _latent_case(case, torch.float64)
+
+    class Replay:
+        n = 0
+        def __call__(self, ta, tb, return_U=False):
+            self.n += 1
+            w = torch.from_numpy(g['dW'][self.n - 1]).double()
+            return (w, torch.from_numpy(g['dU'][self.n - 1]).double()) if return_U else w
+    with torch.no_grad():
+        ys = S.sdeint(m64, y0.double(), torch.from_numpy(g['ts']), bm=Replay(), dt=float(g['dt']), method=str(g['method']), names=names)
+    np.testing.assert_allclose(ys.numpy(), g['ys64'], rtol=1e-7, atol=1e-7)
+
+
+def test_latent_composition_rejects_modules_whose_accumulator_feeds_back():
+    from stable_neural_sdes_amd import fields
+    from tests.latent_field import LatentField
+
+    class Coupled(LatentField):
+        def f_aug(self, t, y):
+            out = super().f_aug(t, y)
+            return torch.cat([out[:, :-1] + 0.1 * y[:, -1:], out[:, -1:]], dim=1)
+    names = {'drift': 'f_aug', 'diffusion': 'g_aug'}
+    assert fields.compose_latent(Coupled(2, 9, 16, 2), names, 9) is None
+    assert fields.compose_latent(LatentField(2, 9, 16, 2), names, 9) is not None
+    assert fields.compose_latent(LatentField(2, 9, 16, 2), names, 10) is None          # state width != latent + 1
