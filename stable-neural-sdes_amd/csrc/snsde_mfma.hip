@@ -406,8 +406,14 @@ RevPlan make_rev_plan(const snsde_solve* s, const SnsdeNet& net, const MfmaPlan&
                                  s->model.drift_output != SNSDE_DRIFT_TIMES_Y;
     if (fp.M4N && variant_of(s) && !variant_net_rev) return p;
     p.M4N = m4n_rev ? (s->method == SNSDE_SRK ? 1 : 2) : 0;
+    // tutorial-style fields under SRK (the general kernel's SRK variant ran the forward): the SRK adjoint kernel carries the
+    // switches; a raw diffusion from a supplied table (rows = the four stage times of every step) or none
+    const bool variant_srk_rev = fp.SRK && s->method == SNSDE_SRK && variant_of(s) && !fp.M4N && fp.FL == 1 && fp.H <= 128 &&
+                                 fp.IO != 5 && fp.IO != 6 && fp.IO != 0 &&
+                                 ((s->model.diffusion_output == SNSDE_DIFFUSION_RAW && s->noise_table != nullptr) ||
+                                  s->model.noise_option == 0);
     // tutorial-style fields: the register-resident lean forward (its training-mode instantiations), Euler / Milstein
-    if (variant_of(s) && !variant_net_rev && !(fp.LEAN && fp.FL == 1 && fp.H <= 128 && !fp.SRK && s->method != SNSDE_SRK &&
+    if (variant_of(s) && !variant_net_rev && !variant_srk_rev && !(fp.LEAN && fp.FL == 1 && fp.H <= 128 && !fp.SRK && s->method != SNSDE_SRK &&
                            (s->model.activation == SNSDE_ACT_RELU || lean_act_save_fits(fp.H, fp.NHID, fp.KUXT)) &&
                            (s->model.diffusion_output == SNSDE_DIFFUSION_RAW || s->model.noise_option == 0) &&
                            (s->noise_table != nullptr || s->model.noise_option == 0)))

@@ -498,6 +498,8 @@ __global__ void __launch_bounds__(CF::NT, CF::WPS) snsde_mfma_kernel(MfmaArgs a)
 
     // store one layer output fragment (bias came in through the accumulator init) as 16 B per lane
     int save_step = 0;   // current step, for the optional activation save
+    // field variants with a smooth activation (4-row tiles): the NHID + 1 pre-activations follow the regular slots (snsde_act_slots)
+    const int nsave_rt = (FL && a.act != 0) ? CF::NSAVE + NHID + 1 : CF::NSAVE;
     // M4: the layer's bias is added after the k-slot reduction, from a register (one value per lane and layer)
     float bias_own[CF::NLAYER];
 #pragma unroll
@@ -506,6 +508,7 @@ __global__ void __launch_bounds__(CF::NT, CF::WPS) snsde_mfma_kernel(MfmaArgs a)
     auto store_frag = [&](float* buf, int ld, int col0, f32x4 v, bool relu, int save_slot, int lyr) {
         if constexpr (FL) {
             float o = finish(lyr, v);
+            const float pre = o;
             if (relu) {
                 if (__builtin_expect(a.act != 0, 0)) {     // field variants (SRK of the tutorial-style fields): LipSwish / SiLU
                     const float sg = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(o * -1.4426950408889634f));
@@ -515,8 +518,11 @@ __global__ void __launch_bounds__(CF::NT, CF::WPS) snsde_mfma_kernel(MfmaArgs a)
                 }
             }
             buf[r * ld + col0 + fsub + s] = o;
-            if (save_slot >= 0 && a.act_save && row_ok)
-                a.act_save[(((size_t)save_step * CF::NSAVE + save_slot) * B + row) * H + wave * 16 + fsub + s] = o;
+            if (save_slot >= 0 && a.act_save && row_ok) {
+                a.act_save[(((size_t)save_step * nsave_rt + save_slot) * B + row) * H + wave * 16 + fsub + s] = o;
+                if (relu && a.act != 0)      // smooth activations: the pre-activation as well (slots behind the regular ones)
+                    a.act_save[(((size_t)save_step * nsave_rt + CF::NSAVE + save_slot) * B + row) * H + wave * 16 + fsub + s] = pre;
+            }
             return;
         }
         if (relu) {
@@ -881,7 +887,7 @@ __global__ void __launch_bounds__(CF::NT, CF::WPS) snsde_mfma_kernel(MfmaArgs a)
             }
             const size_t goff = (size_t)row * H + fcol[t];
             if (a.act_save && row_ok) {
-                float* zp = a.act_save + (((size_t)n * CF::NSAVE + CF::ZSLOT) * B) * H + goff;
+                float* zp = a.act_save + (((size_t)n * nsave_rt + CF::ZSLOT) * B) * H + goff;
                 if constexpr (FL) zp[0] = zsave[0];
                 else *reinterpret_cast<f32x4*>(zp) = f32x4{zsave[0], zsave[1], zsave[2], zsave[3]};
             }
@@ -1406,7 +1412,8 @@ template <class CF>
 __global__ void __launch_bounds__(CF::NT, CF::WPS) snsde_mfma_srk_reverse_kernel(RevArgs a) {
     static_assert(CF::FL == 1 && CF::NN == 0, "SRK adjoint: M4 tiles, elementwise diffusions");
     constexpr int H = CF::H, TPW = 1, M = CF::M, NT = CF::NT, NHID = CF::NHID, NG = CF::NG;
-    constexpr int KUH = CF::KUH, LDA = CF::LDA, NSAVE = CF::NSAVE;
+    constexpr int KUH = CF::KUH, LDA = CF::LDA;
+    const int NSAVE = a.nsave;                   // activation slots per pass (the smooth-activation variants save more)
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -1430,6 +1437,11 @@ __global__ void __launch_bounds__(CF::NT, CF::WPS) snsde_mfma_srk_reverse_kernel
     const bool yfun = (a.no >= 7 && a.no <= 10);
     const bool dsum = a.ds_part != nullptr && a.gt != nullptr;
     const bool tsum = dsum || yfun;       // d/d sigmoid(theta) wanted
+    // field variants (tutorial-style fields, fields.py): f = tanh z | z | z y, g = the table row {y} itself, LipSwish / SiLU
+    const bool variant = a.act_fn != 0 || a.f_out != 0 || a.g_out != 0;
+    const bool g_raw = a.g_out == SNSDE_DIFFUSION_RAW;
+    const float act_scale = a.act_fn == SNSDE_ACT_LIPSWISH ? 0.909f : 1.0f;
+    const float sgt = g_raw ? 1.0f : sig_theta;       // d raw -> d g chain factor (RAW: none, and no theta gradient)
     const float rowf = row_ok ? 1.0f : 0.0f;
     const int rslot = a.row_out ? a.row_out[rowc] : -1;
     const float gfin = a.row_out ? a.grad_ys[goff] : 0.0f;
@@ -1437,6 +1449,12 @@ __global__ void __launch_bounds__(CF::NT, CF::WPS) snsde_mfma_srk_reverse_kernel
 
     // g = tanh(sigmoid(theta) nan_to_num(raw)), raw = s(t) or s(t) y;  returns g, sets dg/dy, the clipped raw and its finiteness
     auto gfun = [&](float tv, float yy, float& gp, float& rc, bool& fin) {
+        if (__builtin_expect(g_raw, 0)) {
+            fin = true;
+            rc = mul_y ? tv * yy : tv;
+            gp = mul_y ? tv : 0.0f;
+            return rc;
+        }
         float q1 = mul_y ? tv : 0.0f, q2 = 0.0f;
         const float raw = yfun ? snsde_phi(a.no, yy, q1, q2) : (mul_y ? tv * yy : tv);
         fin = snsde_finite(raw);
@@ -1459,7 +1477,8 @@ __global__ void __launch_bounds__(CF::NT, CF::WPS) snsde_mfma_srk_reverse_kernel
         if (writer) {
 #pragma unroll
             for (int g = 0; g < NG - 1; ++g)
-                dst[g] = *reinterpret_cast<const f32x4*>(a.act + (((size_t)p * NSAVE + (NHID - g)) * B + rowc) * H + wave * 16 + fsub);
+                dst[g] = *reinterpret_cast<const f32x4*>(a.act + (((size_t)p * NSAVE + (NHID - g) + (a.act_fn != 0 ? NHID + 2 : 0)) * B + rowc) * H +
+                                                         wave * 16 + fsub);     // (smooth activations: the PRE-activation slots)
         }
     };
     load_masks(3 * a.N - 1, mk);
@@ -1468,9 +1487,13 @@ __global__ void __launch_bounds__(CF::NT, CF::WPS) snsde_mfma_srk_reverse_kernel
         float ty = 1.0f;
         if constexpr (CF::GEO) ty = fast_tanh(hin);
         const float dzt = cot * (1.0f - F * F);
-        const float dz = dzt * ty;
+        float dz = dzt * ty;
         float direct = 0.0f;
         if constexpr (CF::GEO) direct = dzt * z * (1.0f - ty * ty);
+        if (__builtin_expect(variant, 0)) {
+            if (a.f_out == SNSDE_DRIFT_TIMES_Y) { dz = cot * hin; direct = cot * z; }
+            else if (a.f_out == SNSDE_DRIFT_LINEAR) dz = cot;
+        }
         lds[r * LDA + fcol] = dz;
         if (a.delta && row_ok) a.delta[((size_t)p * NG * B) * H + goff] = dz;
         __syncthreads();
@@ -1487,7 +1510,8 @@ __global__ void __launch_bounds__(CF::NT, CF::WPS) snsde_mfma_srk_reverse_kernel
                 if (writer) {
                     const f32x4 zsv = mk[g];
 #pragma unroll
-                    for (int i = 0; i < 4; ++i) v[i] = zsv[i] > 0.0f ? v[i] : 0.0f;
+                    for (int i = 0; i < 4; ++i)
+                        v[i] = __builtin_expect(a.act_fn != 0, 0) ? v[i] * swish_grad(zsv[i], act_scale) : (zsv[i] > 0.0f ? v[i] : 0.0f);
                     *reinterpret_cast<f32x4*>(lds + (g + 1) * M * LDA + r * LDA + wave * 16 + fsub) = v;
                     if (a.delta && row_ok)
                         *reinterpret_cast<f32x4*>(a.delta + (((size_t)p * NG + g + 1) * B + row) * H + wave * 16 + fsub) = v;
@@ -1538,16 +1562,24 @@ __global__ void __launch_bounds__(CF::NT, CF::WPS) snsde_mfma_srk_reverse_kernel
         const float y = cur.y, ik = cur.ik, ik0 = cur.ik0, z0 = cur.z0, z1 = cur.z1, z2 = cur.z2;
         const float t0v = cur.t0v, t1v = cur.t1v, t3v = cur.t3v;
         auto gate = [&](float hv) { return CF::GEO ? fast_tanh(hv) : 1.0f; };
+        auto fout = [&](float z, float hv) {
+            if (__builtin_expect(variant, 0)) {
+                if (a.f_out == SNSDE_DRIFT_TIMES_Y) return z * hv;
+                if (a.f_out == SNSDE_DRIFT_LINEAR) return z;
+                return fast_tanh(z);
+            }
+            return fast_tanh(z * gate(hv));
+        };
         float g0p, g1p, g2p, g3p, rc0, rc1, rc2, rc3;
         bool fi0, fi1, fi2, fi3;
-        const float f0 = fast_tanh(z0 * gate(y));
+        const float f0 = fout(z0, y);
         const float g0 = gfun(t0v, y, g0p, rc0, fi0);
         const float h01 = y + f0 * h;
-        const float f1 = fast_tanh(z1 * gate(h01));
+        const float f1 = fout(z1, h01);
         const float h11 = y + 0.25f * f0 * h + 0.5f * g0 * rdt;
         const float g1 = gfun(t1v, h11, g1p, rc1, fi1);
         const float h02 = y + 0.25f * f0 * h + 0.25f * f1 * h + g0 * ik0 / h + 0.5f * g1 * ik0 / h;
-        const float f2 = fast_tanh(z2 * gate(h02));
+        const float f2 = fout(z2, h02);
         const float h12 = y + f0 * h - g0 * rdt;
         const float g2 = gfun(t3v, h12, g2p, rc2, fi2);
         const float h13 = y + 0.25f * f2 * h + (-5.0f * g0 + 3.0f * g1 + 0.5f * g2) * rdt;
@@ -1572,11 +1604,11 @@ __global__ void __launch_bounds__(CF::NT, CF::WPS) snsde_mfma_srk_reverse_kernel
         // parameter side of G3 (slot 1, completed below with G1) and G2 (slot 3)
         float ds1 = 0.0f;
         if (tsum) {
-            const float c3 = gb3 * (1.0f - g3 * g3) * rowf, c2 = gb2 * (1.0f - g2 * g2) * rowf;
-            th_acc = fmaf(c3, rc3, fmaf(c2, rc2, th_acc));
+            const float c3 = gb3 * (g_raw ? 1.0f : 1.0f - g3 * g3) * rowf, c2 = gb2 * (g_raw ? 1.0f : 1.0f - g2 * g2) * rowf;
+            if (!g_raw) th_acc = fmaf(c3, rc3, fmaf(c2, rc2, th_acc));
             if (dsum) {
-                ds1 = fi3 ? c3 * sig_theta * (mul_y ? h13 : 1.0f) : 0.0f;
-                const float ds3 = quad_sum(fi2 ? c2 * sig_theta * (mul_y ? h12 : 1.0f) : 0.0f);
+                ds1 = fi3 ? c3 * sgt * (mul_y ? h13 : 1.0f) : 0.0f;
+                const float ds3 = quad_sum(fi2 ? c2 * sgt * (mul_y ? h12 : 1.0f) : 0.0f);
                 if (r == 0) a.ds_part[((size_t)blockIdx.x * 4 * a.N + 4 * n + 3) * H + fcol] = ds3;
             }
         }
@@ -1589,10 +1621,10 @@ __global__ void __launch_bounds__(CF::NT, CF::WPS) snsde_mfma_srk_reverse_kernel
         hb = gb1 * g1p;
         yb += hb; fb0 = fmaf(0.25f * h, hb, fb0); gb0 = fmaf(0.5f * rdt, hb, gb0);
         if (tsum) {
-            const float c1 = gb1 * (1.0f - g1 * g1) * rowf;
-            th_acc = fmaf(c1, rc1, th_acc);
+            const float c1 = gb1 * (g_raw ? 1.0f : 1.0f - g1 * g1) * rowf;
+            if (!g_raw) th_acc = fmaf(c1, rc1, th_acc);
             if (dsum) {
-                ds1 += fi1 ? c1 * sig_theta * (mul_y ? h11 : 1.0f) : 0.0f;
+                ds1 += fi1 ? c1 * sgt * (mul_y ? h11 : 1.0f) : 0.0f;
                 ds1 = quad_sum(ds1);
                 if (r == 0) a.ds_part[((size_t)blockIdx.x * 4 * a.N + 4 * n + 1) * H + fcol] = ds1;
             }
@@ -1602,9 +1634,9 @@ __global__ void __launch_bounds__(CF::NT, CF::WPS) snsde_mfma_srk_reverse_kernel
         // ---- stage 0: both at (t0, y) ----
         yb = fmaf(gb0, g0p, yb);
         if (tsum) {
-            const float c0 = gb0 * (1.0f - g0 * g0) * rowf;
-            th_acc = fmaf(c0, rc0, th_acc);
-            const float ds0 = dsum ? quad_sum(fi0 ? c0 * sig_theta * (mul_y ? y : 1.0f) : 0.0f) : 0.0f;
+            const float c0 = gb0 * (g_raw ? 1.0f : 1.0f - g0 * g0) * rowf;
+            if (!g_raw) th_acc = fmaf(c0, rc0, th_acc);
+            const float ds0 = dsum ? quad_sum(fi0 ? c0 * sgt * (mul_y ? y : 1.0f) : 0.0f) : 0.0f;
             if (dsum && r == 0) {
                 a.ds_part[((size_t)blockIdx.x * 4 * a.N + 4 * n) * H + fcol] = ds0;
                 a.ds_part[((size_t)blockIdx.x * 4 * a.N + 4 * n + 2) * H + fcol] = 0.0f;   // slot t0 + h/2: no diffusion evaluation

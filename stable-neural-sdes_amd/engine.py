@@ -503,14 +503,15 @@ def solve_backward(call, grad_ys, stream=None, save_delta=False, adj0_only=False
 def param_gradients(call, adj, delta, stream=None, want_table_grad=False):
     """Flat parameter gradient (the C ABI's layout) of a finished MFMA-path solve + adjoint: snsde_param_gradients
     (split-R MFMA weight-gradient GEMMs, diffusion reductions, first-layer algebra), all on the device.
-    want_table_grad (solves with a supplied noise_table): returns (grad, dL/d noise_table (N, H))."""
+    want_table_grad (solves with a supplied noise_table): returns (grad, dL/d noise_table (N, H); SRK: (4 N, H))."""
     b = _lib.Backward()
     b.fwd = call.desc
     b.fwd.flags = call.base_flags
     b.adj, b.delta_save = _ptr(adj), _ptr(delta)
     tab_grad = None
     if want_table_grad:
-        tab_grad = torch.zeros((call.grid.N, call.model.hidden_channels), device=adj.device, dtype=torch.float32)
+        rows = call.grid.N * (4 if call.desc.method == _lib.SRK else 1)      # SRK: one row per stage time
+        tab_grad = torch.zeros((rows, call.model.hidden_channels), device=adj.device, dtype=torch.float32)
         b.grad_noise_table = _ptr(tab_grad)
     bws = call.keep_bwd[0]          # the adjoint's workspace: holds its per-workgroup diffusion-side sums
     b.workspace, b.workspace_bytes = _ptr(bws), bws.numel()

@@ -358,7 +358,7 @@ def _sdeint_composed(sde, y0, ts, bm, method, dt, options):
             return None
         flat = field.flat(dev, grad=True)
         tab = field.noise_table(tab_times, dev, grad=True) if field.tabulated else None
-        return _ComposedSolve.apply(field.model, coeffs, grid, dW, method, seed, int(row_offset), row_out, y0, flat, tab)
+        return _ComposedSolve.apply(field.model, coeffs, grid, dW, method, seed, int(row_offset), row_out, y0, flat, tab, dU)
     # options={'trust_versions': True}: the cached composed block / table are keyed on the parameters' addresses and version
     # counters alone (no content fingerprint = no device->host read per solve); in-place edits through `.data` are then the
     # caller's to avoid

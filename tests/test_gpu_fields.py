@@ -114,6 +114,9 @@ GRAD_CASES = [(kind, H, layers, act, method)
               for kind in ('lsde', 'lnsde', 'lnsde_additive', 'gsde')
               for H, layers, act, method in ((32, 1, 'lipswish', 'euler'), (64, 2, 'lipswish', 'milstein'), (128, 2, 'silu', 'euler'),
                                              (32, 3, 'relu', 'milstein'))]
+# SRK (the GSDE-SRK notebook trains with it): the general kernel's SRK variant + the SRK adjoint kernel's variant switches
+GRAD_CASES += [(kind, H, layers, act, 'srk') for kind in ('lsde', 'lnsde', 'lnsde_additive', 'gsde')
+               for H, layers, act in ((32, 1, 'lipswish'), (64, 2, 'relu'), (128, 1, 'silu'), (64, 3, 'lipswish'))]
 # NeuralSDEFunc-shaped fields (drift and diffusion both MLPs of [t, y]): Euler, the net kernels + the general adjoint kernel
 GRAD_CASES += [('nsde', H, 1, act, 'euler') for H, act in ((16, 'lipswish'), (32, 'lipswish'), (64, 'relu'), (64, 'silu'),
                                                             (128, 'lipswish'), (128, 'relu'))]
@@ -132,12 +135,16 @@ def test_tutorial_field_training_step_fused_vs_fp64_autograd(kind, H, layers, ac
     h = (grid.t1 - grid.t0).astype(np.float64)
     rng = np.random.default_rng(4)
     dW = torch.from_numpy(rng.standard_normal((grid.N, B, H)) * np.sqrt(h)[:, None, None] * 0.5)
+    dU = None
+    if method == 'srk':       # the space-time Levy integral that goes with dW
+        hc = torch.from_numpy(h)[:, None, None]
+        dU = hc * (0.5 * dW + (hc / 12).sqrt() * torch.from_numpy(rng.standard_normal((grid.N, B, H))) * 0.5)
     wsum = torch.from_numpy(rng.standard_normal((L, B, H)))
     f64 = TutorialField(kind, C, H, layers, act).double()
     f64.load_state_dict({k: v.double() for k, v in field.state_dict().items()})
     f64.set_X(coeffs.double(), times.double())
     y64 = y0.double().requires_grad_(True)
-    want = S.sdeint(f64, y64, times.double(), bm=Replay(dW), dt=dt, method=method, options={'backend': 'torch'})
+    want = S.sdeint(f64, y64, times.double(), bm=Replay(dW, dU), dt=dt, method=method, options={'backend': 'torch'})
     (want * wsum).sum().backward()
 
     field = field.to(dev)
@@ -146,7 +153,8 @@ def test_tutorial_field_training_step_fused_vs_fp64_autograd(kind, H, layers, ac
     generic = S.torchsde._sdeint_torch
     S.torchsde._sdeint_torch = lambda *a, **k: (_ for _ in ()).throw(AssertionError('fell back to the tensor-op loop'))
     try:
-        got = S.sdeint(field, yg, times.to(dev), bm=Replay(dW.float().to(dev)), dt=dt, method=method)
+        got = S.sdeint(field, yg, times.to(dev), bm=Replay(dW.float().to(dev), None if dU is None else dU.float().to(dev)), dt=dt,
+                       method=method)
         (got * wsum.float().to(dev)).sum().backward()
     finally:
         S.torchsde._sdeint_torch = generic

@@ -69,7 +69,8 @@ def test_latent_sde_fused_vs_the_reference_trajectories(case):
 
 
 GRAD_CASES = [(H, HH, NL, method, aligned) for H, HH, NL, method, aligned in
-              ((32, 32, 2, 'euler', True), (17, 24, 3, 'euler', False), (64, 48, 1, 'milstein', True), (129, 100, 2, 'euler', True))]
+              ((32, 32, 2, 'euler', True), (17, 24, 3, 'euler', False), (64, 48, 1, 'milstein', True), (129, 100, 2, 'euler', True),
+               (32, 32, 2, 'srk', True), (17, 24, 3, 'srk', False), (65, 64, 1, 'srk', True))]
 
 
 @pytest.mark.parametrize('H,HH,NL,method,aligned', GRAD_CASES)
@@ -87,19 +88,24 @@ def test_latent_sde_training_step_fused_vs_fp64_autograd(H, HH, NL, method, alig
     rng = np.random.default_rng(3)
     h = (grid.t1 - grid.t0).astype(np.float64)
     dW = torch.from_numpy(rng.standard_normal((grid.N, B, H)) * np.sqrt(h)[:, None, None])
+    dU = None
+    if method == 'srk':
+        hc = torch.from_numpy(h)[:, None, None]
+        dU = hc * (0.5 * dW + (hc / 12).sqrt() * torch.from_numpy(rng.standard_normal((grid.N, B, H))))
     y0 = torch.cat([0.5 * torch.randn(B, H - 1), torch.zeros(B, 1)], dim=1)
     wsum = torch.from_numpy(rng.standard_normal((len(ts), B, H)))
     wsum[..., -1] = torch.from_numpy(rng.uniform(0.5, 1.0, (len(ts), B))) * 0.05        # (the KL channel is ~100x the latent's)
     m64 = LatentField(3, H, HH, NL, theta=0.7, mu=0.2, sigma=0.4).double()
     m64.load_state_dict({k: v.double() for k, v in m.state_dict().items()})
     y64 = y0.double().requires_grad_(True)
-    want = S.sdeint(m64, y64, ts.double(), bm=Replay(dW), dt=dt, method=method, names=NAMES, options={'backend': 'torch'})
+    want = S.sdeint(m64, y64, ts.double(), bm=Replay(dW, dU), dt=dt, method=method, names=NAMES, options={'backend': 'torch'})
     (want * wsum).sum().backward()
 
     m = m.to(dev)
     yg = y0.to(dev).requires_grad_(True)
     with no_tensor_loop():
-        got = S.torchsde.sdeint_adjoint(m, yg, ts.to(dev), bm=Replay(dW.float().to(dev)), dt=dt, method=method, names=NAMES)
+        got = S.torchsde.sdeint_adjoint(m, yg, ts.to(dev), bm=Replay(dW.float().to(dev), None if dU is None else dU.float().to(dev)), dt=dt,
+                                       method=method, names=NAMES)
         (got * wsum.float().to(dev)).sum().backward()
     for sl in (slice(0, -1), slice(-1, None)):
         scale = max(float(want.detach()[..., sl].abs().max()), 1.0)
