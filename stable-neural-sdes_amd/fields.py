@@ -85,7 +85,7 @@ class ComposedField:
         self.parts, self.additive = parts, additive
         # tabulated: the diffusion is (a function of time alone) x {1, y}, handed to the kernel as a per-step table; False: the
         # NeuralSDEFunc shape, whose diffusion is an MLP of [t, y] evaluated by the net kernels from the composed block
-        self.tabulated = 'noise_first' not in parts
+        self.tabulated = 'noise_first' not in parts and not parts.get('ode', False)      # (the ODE field: no diffusion at all)
         self.verified = {}        # device -> bool (one-step probe through the kernel)
         self.trust_versions = False
         self._flat_cache = None
@@ -155,8 +155,9 @@ class ComposedField:
         for i, lin in enumerate(p['mlp'][1:-1]):
             vals[f'linears.{i}.weight'], vals[f'linears.{i}.bias'] = W(lin), b(lin)
         vals['linear_out.weight'], vals['linear_out.bias'] = W(p['mlp'][-1]), b(p['mlp'][-1])
-        vals['noise_y.0.weight'], vals['noise_y.0.bias'] = first(p['noise_first'], p['noise_in'])
-        vals['noise_y.2.weight'], vals['noise_y.2.bias'] = W(p['noise_last']), b(p['noise_last'])
+        if 'noise_first' in p:
+            vals['noise_y.0.weight'], vals['noise_y.0.bias'] = first(p['noise_first'], p['noise_in'])
+            vals['noise_y.2.weight'], vals['noise_y.2.bias'] = W(p['noise_last']), b(p['noise_last'])
         pieces = []
         for name, off, shape in self.layout:
             v = vals[name]
@@ -277,7 +278,11 @@ def compose(sde):
 def _compose(sde):
     if not isinstance(sde, torch.nn.Module):
         return None
-    if getattr(sde, 'sde_type', None) != 'ito' or getattr(sde, 'noise_type', None) != 'diagonal':
+    if getattr(sde, 'sde_type', None) != 'ito':
+        return None
+    if getattr(sde, 'noise_type', None) == 'scalar':
+        return _compose_ode(sde)
+    if getattr(sde, 'noise_type', None) != 'diagonal':
         return None
     if hasattr(sde, 'input_option'):
         return None
@@ -335,6 +340,41 @@ def _compose(sde):
     field = ComposedField(sde, model, layout, numel, parts, additive)
     # f = z or z * y: decided by the probe in verify() (two candidates, the kernel's result must match one)
     return field
+
+
+def _compose_ode(sde):
+    """tutorial/simple OU process - Neural ODE.ipynb, NeuralODEFunc: f = f_net(linear_in([t, y])), noise_type 'scalar' with
+    g = zeros (B, H, 1) - an ODE solved through sdeint.  Maps onto (input_option 3, noise_option 0) with the variant switches."""
+    if hasattr(sde, 'input_option') or hasattr(sde, 'emb') or hasattr(sde, 'g_net'):
+        return None
+    lin_in = getattr(sde, 'linear_in', None)
+    if not isinstance(lin_in, torch.nn.Linear) or lin_in.bias is None or not callable(getattr(sde, 'f', None)) \
+            or not callable(getattr(sde, 'g', None)):
+        return None
+    H = lin_in.out_features
+    fc = _mlp_chain(getattr(sde, 'f_net', None))
+    if not _is_linear(lin_in, H + 1, H) or fc is None or len(fc[0]) > 4:
+        return None
+    mlp, act = fc
+    if any(m.in_features != H or m.out_features != H for m in mlp):
+        return None
+    try:      # the diffusion must be identically zero, in torchsde's scalar-noise shape (B, H, 1)
+        with torch.no_grad():
+            p0 = lin_in.weight
+            gv = sde.g(torch.tensor(0.3).to(p0), torch.ones(3, H).to(p0))
+    except Exception:
+        return None
+    if tuple(gv.shape) != (3, H, 1) or float(gv.abs().max()) != 0.0:
+        return None
+    coeffs = getattr(sde, 'coeffs', None)
+    C_ = int(coeffs.shape[-1]) // 4 if torch.is_tensor(coeffs) and coeffs.dim() == 3 else 1
+    model = engine.model_struct(C_, H, H, len(mlp) - 1, 3, 0, activation=act, drift_output=DRIFT_LINEAR,
+                                diffusion_output=DIFFUSION_RAW, time_feature=TIME_RAW)
+    try:
+        layout, numel = _lib.param_layout(model)
+    except _lib.SnsdeError:
+        return None
+    return ComposedField(sde, model, layout, numel, dict(linear_in=lin_in, mlp=mlp, ode=True), additive=True)
 
 
 def _compose_net(sde):
@@ -489,6 +529,8 @@ def verify(field, coeffs, times_host, dev):
         hh = float(grid.t1[0] - grid.t0[0])
         tt = torch.tensor(float(grid.t0[0]), device=dev)
         f_ref, g_ref = sde.f(tt, y0).float(), sde.g(tt, y0).float()
+        if g_ref.dim() == 3:           # scalar noise (the ODE field): (rows, H, 1)
+            g_ref = g_ref.squeeze(-1)
         tab = field.noise_table(torch.from_numpy(grid.t0), dev) if field.tabulated else None
         flat = field.flat(dev)
         scale_f = float(f_ref.abs().max()) + 1e-6

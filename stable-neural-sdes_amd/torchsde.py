@@ -328,7 +328,7 @@ def _sdeint_composed(sde, y0, ts, bm, method, dt, options):
         return None
     grid = engine.step_grid(_HostTimes.get(ts), dt, times_host, dev)
     dW = dU = None
-    if bm is not None:
+    if bm is not None and not field.parts.get('ode', False):      # (the ODE field has no diffusion: nothing to draw)
         t0, t1 = torch.from_numpy(grid.t0), torch.from_numpy(grid.t1)
         if method == 'srk':
             pairs = [bm(t0[n], t1[n], return_U=True) for n in range(grid.N)]
@@ -863,8 +863,17 @@ def _sdeint_torch(sde, y0, ts, bm, method, dt, options, names):
     """Unfused scheme on tensor ops (arbitrary sde, CPU plumbing, autograd)."""
     f = _call(sde, names, 'drift', 'f')
     g = _call(sde, names, 'diffusion', 'g')
-    if getattr(sde, 'noise_type', 'diagonal') != 'diagonal':
-        raise NotImplementedError("only diagonal noise is implemented")
+    noise_type = getattr(sde, 'noise_type', 'diagonal')
+    if noise_type == 'scalar':
+        # torchsde's scalar noise: g is (B, H, 1), one Brownian motion per row, g_prod = g[..., 0] * I with I (B, 1)
+        # (the tutorial's Neural ODE notebook solves an ODE this way, g = 0).  Euler only: the higher-order schemes need
+        # the dense Jacobian-vector product of g there.
+        if method != 'euler':
+            raise NotImplementedError("scalar noise: only method='euler' is implemented")
+        g_scalar = g
+        g = lambda t, y: g_scalar(t, y).squeeze(-1)
+    elif noise_type != 'diagonal':
+        raise NotImplementedError("only diagonal (and, under Euler, scalar) noise is implemented")
     if getattr(sde, 'sde_type', 'ito') != 'ito':
         raise NotImplementedError("only Ito SDEs are implemented")
     ts_host = _HostTimes.get(ts)
@@ -879,7 +888,8 @@ def _sdeint_torch(sde, y0, ts, bm, method, dt, options, names):
         seed = options.get('seed')
         gen.manual_seed(int(seed) if seed is not None and not torch.is_tensor(seed) else _fresh_seed())
         hcol = hs.reshape(-1, *([1] * y0.dim()))
-        dW_all = torch.randn((grid.N,) + tuple(y0.shape), dtype=y0.dtype, device=y0.device, generator=gen) * hcol.sqrt()
+        wshape = (grid.N, y0.shape[0], 1) if noise_type == 'scalar' else (grid.N,) + tuple(y0.shape)
+        dW_all = torch.randn(wshape, dtype=y0.dtype, device=y0.device, generator=gen) * hcol.sqrt()
         dU_all = None
         if method == 'srk':      # I_k0 = h (I_k / 2 + sqrt(h / 12) xi): the space-time Levy integral
             xi = torch.randn((grid.N,) + tuple(y0.shape), dtype=y0.dtype, device=y0.device, generator=gen)

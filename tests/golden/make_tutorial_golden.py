@@ -35,6 +35,7 @@ NOTEBOOKS = [
     ('nsde', 'simple OU process - Neural SDE.ipynb', 'NeuralSDEFunc', 'nsde', 32, 1, 'lipswish', 'euler'),
     ('nsde_srk', 'simple OU process - Neural SDE.ipynb', 'NeuralSDEFunc', 'nsde', 64, 1, 'lipswish', 'srk'),
     ('nsde_relu', 'simple OU process - Neural SDE.ipynb', 'NeuralSDEFunc', 'nsde', 16, 1, 'relu', 'milstein'),
+    ('ode', 'simple OU process - Neural ODE.ipynb', 'NeuralODEFunc', 'ode', 32, 2, 'lipswish', 'euler'),
 ]
 
 
@@ -47,6 +48,19 @@ def field_class(nb_file, cls, torchcde):
     ns = {'torch': torch, 'nn': torch.nn, 'torchcde': torchcde}
     exec(compile(src, nb_file, 'exec'), ns)
     return ns[cls]
+
+
+class _squeezed:
+    """torchsde's scalar-noise shape (the Neural ODE notebook: g = zeros (B, H, 1)) as a diagonal field for the step loop."""
+
+    def __init__(self, m):
+        self.m = m
+
+    def f(self, t, y):
+        return self.m.f(t, y)
+
+    def g(self, t, y):
+        return self.m.g(t, y).squeeze(-1)
 
 
 def main():
@@ -87,12 +101,13 @@ def main():
         with torch.no_grad():
             fs = torch.stack([m.f(t, y0) for t in probe_t])
             gs = torch.stack([m.g(t, y0) for t in probe_t])
-            ys32, n32 = G.torch_step_grid_and_solve(m, y0, ts, dt, dW, method, dU)
+            ys32, n32 = G.torch_step_grid_and_solve(_squeezed(m) if kind == 'ode' else m, y0, ts, dt, dW, method, dU)
         md = Func(C, H, H, layers, activation=act).double()
         md.load_state_dict({k: v.double() for k, v in sd.items()})
         md.set_X(coeffs.double(), times.double())
         with torch.no_grad():
-            ys64, n64 = G.torch_step_grid_and_solve(G._F64Times(md), y0.double(), ts, dt, dW.double(), method, None if dU is None else dU.double())
+            ys64, n64 = G.torch_step_grid_and_solve(G._F64Times(_squeezed(md) if kind == 'ode' else md), y0.double(), ts, dt, dW.double(),
+                                                    method, None if dU is None else dU.double())
         assert n32 == N and n64 == N
         k = f'T1/{key}'
         out[f'{k}/meta'] = np.array([C, H, layers])

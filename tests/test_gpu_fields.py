@@ -114,6 +114,8 @@ GRAD_CASES = [(kind, H, layers, act, method)
               for kind in ('lsde', 'lnsde', 'lnsde_additive', 'gsde')
               for H, layers, act, method in ((32, 1, 'lipswish', 'euler'), (64, 2, 'lipswish', 'milstein'), (128, 2, 'silu', 'euler'),
                                              (32, 3, 'relu', 'milstein'))]
+# the Neural ODE notebook's field (drift only, scalar-noise shape)
+GRAD_CASES += [('ode', H, layers, act, 'euler') for H, layers, act in ((32, 2, 'lipswish'), (64, 1, 'relu'), (128, 2, 'silu'))]
 # SRK (the GSDE-SRK notebook trains with it): the general kernel's SRK variant + the SRK adjoint kernel's variant switches
 GRAD_CASES += [(kind, H, layers, act, 'srk') for kind in ('lsde', 'lnsde', 'lnsde_additive', 'gsde')
                for H, layers, act in ((32, 1, 'lipswish'), (64, 2, 'relu'), (128, 1, 'silu'), (64, 3, 'lipswish'))]

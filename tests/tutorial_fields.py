@@ -32,14 +32,18 @@ class MLP(nn.Module):
 class TutorialField(nn.Module):
     """kind: 'lsde' (f on [y | X], additive g(t)), 'lnsde' (f on [t, y | X], g(t) * y with the saturating time
     feature), 'lnsde_additive', 'gsde' (f * y, g(t) * y), 'nsde' (the Neural SDE notebook's NeuralSDEFunc: f and g both MLPs
-    of [t, y], no control path in the field)."""
+    of [t, y], no control path in the field), 'ode' (the Neural ODE notebook's NeuralODEFunc: f = MLP of [t, y], noise_type
+    'scalar' with g = zeros (B, H, 1))."""
 
     def __init__(self, kind, input_dim, hidden_dim, num_layers, activation='lipswish'):
         super().__init__()
         self.kind = kind
-        self.sde_type, self.noise_type = 'ito', 'diagonal'
+        self.sde_type, self.noise_type = 'ito', ('scalar' if kind == 'ode' else 'diagonal')
         if kind != 'lsde':
             self.linear_in = nn.Linear(hidden_dim + 1, hidden_dim)
+        if kind == 'ode':            # the Neural ODE notebook's NeuralODEFunc: drift only, scalar-noise shape with g = 0
+            self.f_net = MLP(hidden_dim, hidden_dim, hidden_dim, num_layers, activation)
+            return
         if kind != 'nsde':
             self.linear_X = nn.Linear(input_dim, hidden_dim)
             self.emb = nn.Linear(2 * hidden_dim, hidden_dim)
@@ -60,7 +64,7 @@ class TutorialField(nn.Module):
         return t
 
     def f(self, t, y):
-        if self.kind == 'nsde':
+        if self.kind in ('nsde', 'ode'):
             return self.f_net(self.linear_in(torch.cat((self._t(t, y), y), dim=-1)))
         Xt = self.linear_X(self.X.evaluate(t))
         if self.kind == 'lsde':
@@ -71,6 +75,8 @@ class TutorialField(nn.Module):
         return z * y if self.kind == 'gsde' else z
 
     def g(self, t, y):
+        if self.kind == 'ode':
+            return torch.zeros(y.size(0), y.size(1), 1, dtype=y.dtype, device=y.device)
         t = self._t(t, y)
         if self.kind == 'nsde':
             return self.g_net(self.noise_in(torch.cat((t, y), dim=-1)))
