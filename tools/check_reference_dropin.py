@@ -147,6 +147,16 @@ def main():
     ys = torchsde.sdeint_adjoint(lat, torch.zeros(3, 8), torch.tensor([0.0, 0.5, 1.0]), dt=0.25, method='euler',
                                  names={'drift': 'f_aug', 'diffusion': 'g_aug'})
     assert ys.shape == (3, 3, 8) and bool(torch.isfinite(ys).all())
+    # the reference class itself is what fields.compose_latent recognises (the split solve of DESIGN 3.8b on CUDA), and its own
+    # forward (spline start, sdeint_adjoint with names, KL) runs over the mirrors
+    from stable_neural_sdes_amd import fields as _fields
+    cf = _fields.compose_latent(lat, {'drift': 'f_aug', 'diffusion': 'g_aug'}, 8)
+    assert cf is not None and cf.parts['latent'] == 7 and cf.model.hidden_channels == 16
+    lt = torch.linspace(0, 1, 6)
+    lx = torch.cumsum(0.2 * torch.randn(3, 6, C), dim=1)
+    lcoeffs = S.torchcde.hermite_cubic_coefficients_with_backward_differences(lx, lt)
+    lout, llat, lkl = lat(lcoeffs, lt, method='euler')
+    assert lout.shape == (3, 6, 8) and llat.shape == (3, 6, 7) and lkl.dim() == 0 and bool(torch.isfinite(lkl))
 
     # ---- the reference's TRAINING LOOP itself (benchmark_classification/common_sde.py:_train_loop / _evaluate_metrics) over the
     #      mirrors: two epochs on a small synthetic binary problem, CPU.  common_sde.py does `import models_sde`, whose package
