@@ -19,6 +19,7 @@
 #include <stddef.h>
 #include <stdio.h>
 #include <stdlib.h>
+#include <mutex>
 
 #include "snsde_internal.h"
 
@@ -153,6 +154,8 @@ __device__ __forceinline__ void wgrad_body(const WArgs& a, const WTile& t, float
     int buf = 0;
     if (r_begin < r_end) { fetch(r_begin); stash(0); }
     __syncthreads();
+    // (measured, not adopted: a second register set keeping the chunk after next in flight as well - 0.188 ms either way at K2:
+    // the two resident workgroups per CU already cover the load latency)
     for (int r0 = r_begin; r0 < r_end; r0 += RC) {
         const bool more = r0 + RC < r_end;
         if (more) fetch(r0 + RC);
@@ -609,6 +612,33 @@ bool make_wplan(const snsde_backward* b, const SnsdeNet& net, WPlan* w) {
     return true;
 }
 
+// The diffusion-side reductions (per-workgroup sums of the adjoint kernel -> ds, dth -> the time-only noise MLP's hidden gradient)
+// depend on the adjoint kernel only, not on the weight-gradient GEMMs: they run on a library-owned side stream beside
+// xaux -> wgrad -> wgrad_reduce and are joined before the epilogue that reads both (event fork / join: legal under stream capture,
+// no host synchronisation).  One side stream and event pair per device, created on first use; the enqueue sequence of a call holds
+// a lock, so concurrent callers see consistent event records.  SNSDE_NO_SIDE_STREAM=1: everything on the caller's stream.
+struct SideLane { hipStream_t stream = nullptr; hipEvent_t fork = nullptr, join = nullptr; bool tried = false; };
+constexpr int MAX_DEVICES = 16;
+SideLane g_side[MAX_DEVICES];
+std::mutex g_side_mutex;
+
+SideLane* side_lane() {      // (call with g_side_mutex held)
+    static const bool off = getenv("SNSDE_NO_SIDE_STREAM") != nullptr && getenv("SNSDE_NO_SIDE_STREAM")[0] == '1';
+    int dev = 0;
+    if (off || hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= MAX_DEVICES) return nullptr;
+    SideLane& l = g_side[dev];
+    if (!l.tried) {
+        l.tried = true;
+        if (hipStreamCreateWithFlags(&l.stream, hipStreamNonBlocking) != hipSuccess ||
+            hipEventCreateWithFlags(&l.fork, hipEventDisableTiming) != hipSuccess ||
+            hipEventCreateWithFlags(&l.join, hipEventDisableTiming) != hipSuccess) {
+            l.stream = nullptr;
+            (void)hipGetLastError();
+        }
+    }
+    return l.stream ? &l : nullptr;
+}
+
 }  // namespace
 
 size_t snsde_wgrad_workspace_floats(const snsde_backward* b, const SnsdeNet& net) {
@@ -639,25 +669,6 @@ int snsde_wgrad_launch(const snsde_backward* b, const SnsdeNet& net, float* grad
     a.adj = b->adj;
     a.ldx = wp->ldx; a.R = wp->n_pass * s.batch; a.ntiles = wp->ntiles; a.NP = wp->NP;
     for (int i = 0; i < wp->ntiles; ++i) a.tile[i] = wp->tile[i];
-    if (wp->naux > 0) {
-        XArgs x{};
-        x.coeffs = s.coeffs; x.step_tab = pass_tab; x.xaux = ws + wp->xaux_off;
-        x.B = s.batch; x.C = C; x.Lm1 = s.knots - 1; x.t_col0 = wp->t_col0; x.t_cols = wp->xt; x.x_col0 = wp->x_col0;
-        x.x_cols = wp->x_cols; x.ldx = wp->ldx; x.R = a.R; x.raw_time = s.model.time_feature == SNSDE_TIME_RAW ? 1 : 0;
-        x.n_col0 = wp->n_col0;
-        const size_t total = (size_t)a.R * wp->ldx;
-        hipLaunchKernelGGL(snsde_xaux_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, x);
-    }
-    const size_t lds_bytes = (size_t)2 * 2 * RC * LD * sizeof(float);
-    static bool attr_done = false;
-    if (!attr_done) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(snsde_wgrad_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                (int)lds_bytes) != hipSuccess) return SNSDE_ERR_LDS;
-        attr_done = true;
-    }
-    hipLaunchKernelGGL(snsde_wgrad_kernel, dim3(wp->max_split, wp->ntiles), dim3(NT), lds_bytes, stream, a);
-    hipLaunchKernelGGL(snsde_wgrad_reduce_kernel, dim3((TILE_FLOATS + 255) / 256, wp->ntiles), dim3(256), 0, stream, a);
-
     AArgs aa = wp->aa;
     const float* gt = snsde_mfma_gt_table(&s, net);
     float* ds = ws + wp->ds_off;
@@ -667,6 +678,15 @@ int snsde_wgrad_launch(const snsde_backward* b, const SnsdeNet& net, float* grad
     aa.tau = srk ? s.srk_tab + 1 : s.step_tab + 2;
     aa.tau_stride = srk ? SNSDE_SRK_STRIDE : SNSDE_STEP_STRIDE;
     const bool two = (no == 16 || no == 17);
+    const size_t lds_bytes = (size_t)2 * 2 * RC * LD * sizeof(float);
+    static bool attr_done = false;
+    if (!attr_done) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(snsde_wgrad_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                (int)lds_bytes) != hipSuccess) return SNSDE_ERR_LDS;
+        attr_done = true;
+    }
+    std::unique_lock<std::mutex> side_lock(g_side_mutex, std::defer_lock);
+    SideLane* lane = nullptr;
     if (wp->has_dth) {
         int nwg = 0, waves = 0; size_t ds_off = 0, dth_off = 0;
         if ((wp->tnoise && !gt) || !b->workspace || !snsde_mfma_backward_partials(&s, net, &nwg, &waves, &ds_off, &dth_off))
@@ -676,10 +696,41 @@ int snsde_wgrad_launch(const snsde_backward* b, const SnsdeNet& net, float* grad
         d.ds_part = bws + ds_off; d.dth_part = bws + dth_off; d.ds = ds; d.dth = ws + wp->dth_off;
         if (s.noise_table && b->grad_noise_table) d.ds = b->grad_noise_table;     // dL/d(supplied table): the caller's to propagate
         d.nwg = nwg; d.n_dth = nwg * waves; d.NH = wp->tnoise ? wp->n_trow * H : 0;
-        hipLaunchKernelGGL(snsde_dsum_reduce_kernel, dim3((d.NH + 63) / 64 + 1), dim3(256), 0, stream, d);
+        hipStream_t ss = stream;
+        if (wp->tnoise) {      // (the bare theta sum of the other families is too small to pay for a fork / join: measured +25 us)
+            side_lock.lock();
+            lane = side_lane();
+        }
+        if (lane) {
+            if (hipEventRecord(lane->fork, stream) == hipSuccess && hipStreamWaitEvent(lane->stream, lane->fork, 0) == hipSuccess) ss = lane->stream;
+            else { lane = nullptr; (void)hipGetLastError(); }
+        }
+        if (!lane && side_lock.owns_lock()) side_lock.unlock();
+        hipLaunchKernelGGL(snsde_dsum_reduce_kernel, dim3((d.NH + 63) / 64 + 1), dim3(256), 0, ss, d);
         if (two)      // (two implies the noise MLP of 16/17)
             hipLaunchKernelGGL(snsde_noise_hidden_kernel, dim3(wp->n_trow, (H + 63) / 64), dim3(256), (H + 256) * sizeof(float),
-                               stream, aa);
+                               ss, aa);
+        if (lane) {      // joined below, in front of the epilogue
+            const bool ok = hipEventRecord(lane->join, lane->stream) == hipSuccess;
+            if (!ok) { side_lock.unlock(); return SNSDE_ERR_LAUNCH; }
+        }
+    }
+    if (wp->naux > 0) {
+        XArgs x{};
+        x.coeffs = s.coeffs; x.step_tab = pass_tab; x.xaux = ws + wp->xaux_off;
+        x.B = s.batch; x.C = C; x.Lm1 = s.knots - 1; x.t_col0 = wp->t_col0; x.t_cols = wp->xt; x.x_col0 = wp->x_col0;
+        x.x_cols = wp->x_cols; x.ldx = wp->ldx; x.R = a.R; x.raw_time = s.model.time_feature == SNSDE_TIME_RAW ? 1 : 0;
+        x.n_col0 = wp->n_col0;
+        const size_t total = (size_t)a.R * wp->ldx;
+        hipLaunchKernelGGL(snsde_xaux_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, x);
+    }
+    hipLaunchKernelGGL(snsde_wgrad_kernel, dim3(wp->max_split, wp->ntiles), dim3(NT), lds_bytes, stream, a);
+    hipLaunchKernelGGL(snsde_wgrad_reduce_kernel, dim3((TILE_FLOATS + 255) / 256, wp->ntiles), dim3(256), 0, stream, a);
+
+    if (lane) {
+        const bool ok = hipStreamWaitEvent(stream, lane->join, 0) == hipSuccess;
+        side_lock.unlock();
+        if (!ok) return SNSDE_ERR_LAUNCH;
     }
     // small products straight into the flat gradient (after the assemble kernel has written every other entry)
     int nj = 0;
