@@ -328,10 +328,33 @@ def tutorial_field(dev, stream, kind='lnsde', rows=1024, hh=128, n=100):
         return fn
     fused_train = event_times_ms(train_step('auto'), stream, 20, 5)
     loop_train = event_times_ms(train_step('torch'), stream, 2, 1)
+    # the whole optimisation step (forward, loss, backward, Adam) recorded into ONE hipGraph and replayed: the composed path is
+    # capturable in training as well (fresh increments per replay from the device-resident Philox key)
+    graphed = None
+    try:
+        S.torchsde.prepare_graph_capture(dev)
+        opt = torch.optim.Adam(field.parameters(), lr=1e-4, capturable=True)
+
+        def opt_step():
+            ys = S.sdeint(field, y0, ts, dt=1.0 / n, method='euler')
+            ys[-1].square().mean().backward()
+            opt.step()
+            opt.zero_grad(set_to_none=True)
+        for _ in range(3):
+            opt_step()
+        torch.cuda.synchronize(dev)
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):       # (records on torch's capture stream; replays go to the current one)
+            opt_step()
+        graphed = spread(event_times_ms(graph.replay, stream, 30, 5))
+        eager_opt = spread(event_times_ms(opt_step, stream, 20, 3))
+    except Exception as exc:      # (reported, never fatal for the bench line)
+        graphed, eager_opt = {"error": f"{type(exc).__name__}: {exc}"}, None
     return {"workload": f"tutorial Neural{kind.upper()}Func-shaped field (LipSwish, num_layers=1), {rows} rows, H={hh}, C={cc}, {n} Euler "
                         "steps, whole sdeint() call incl. weight composition + noise table",
             "fused": spread(fused), "generic_graph_stepper": spread(generic),
             "fused_forward_backward": spread(fused_train), "tensor_loop_forward_backward": spread(loop_train),
+            "optimizer_step_eager": eager_opt, "optimizer_step_graph_replayed": graphed,
             "value": rows * n / (float(np.median(fused)) * 1e-3), "unit": "row-steps/s"}
 
 

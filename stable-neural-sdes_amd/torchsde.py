@@ -320,8 +320,8 @@ def _sdeint_composed(sde, y0, ts, bm, method, dt, options):
         return None
     dev = y0.device
     capturing = torch.cuda.is_current_stream_capturing()
-    if capturing and (needs_grad or bm is not None or field.verified.get(str(dev)) is not True):
-        return None      # graph capture: no-grad solves of a mapping that was verified before the capture (a warm-up solve)
+    if capturing and (bm is not None or field.verified.get(str(dev)) is not True):
+        return None      # graph capture: solves (training ones too) of a mapping that was verified before the capture (a warm-up solve)
     coeffs = coeffs.detach().to(device=dev, dtype=torch.float32).contiguous()
     times_host = _HostTimes.get(sde.times)
     if not fields.verify(field, coeffs, times_host, dev):
