@@ -932,3 +932,57 @@ def test_latent_composition_rejects_modules_whose_accumulator_feeds_back():
     assert fields.compose_latent(Coupled(2, 9, 16, 2), names, 9) is None
     assert fields.compose_latent(LatentField(2, 9, 16, 2), names, 9) is not None
     assert fields.compose_latent(LatentField(2, 9, 16, 2), names, 10) is None          # state width != latent + 1
+
+
+def test_every_step_grid_outputs_every_state_of_the_same_steps():
+    """engine.every_step_grid: the caller's solver steps, one exact output after each (the LatentSDE split solve reads the whole
+    trajectory through it)."""
+    ts = np.array([0.0, 0.13, 0.4, 0.77, 1.0], dtype=np.float32)
+    grid = S.engine.StepGrid(ts, 0.06, np.array([0.0, 1.0], dtype=np.float32), None)
+    full = S.engine.every_step_grid(grid)
+    assert full is S.engine.every_step_grid(grid)                       # memoised
+    assert full.N == grid.N and full.T == grid.N + 1
+    np.testing.assert_array_equal(full.t0, grid.t0)
+    np.testing.assert_array_equal(full.t1, grid.t1)
+    np.testing.assert_array_equal(full.step_tab[:, :8], grid.step_tab[:, :8])
+    np.testing.assert_array_equal(full.out_step, np.arange(grid.N))
+    np.testing.assert_array_equal(full.out_w, np.tile([[0.0, 1.0]], (grid.N, 1)).astype(np.float32))
+    np.testing.assert_array_equal(full.step_tab[:, 8].view(np.int32), np.ones(grid.N, dtype=np.int32))
+    np.testing.assert_array_equal(full.step_tab[:, 9].view(np.int32), np.arange(grid.N, dtype=np.int32))
+
+
+def test_scalar_noise_euler_in_the_tensor_loop():
+    """torchsde's scalar noise (g (B, H, 1), one Brownian motion per row): Euler y + f h + g[..., 0] I with I of shape (B, 1);
+    the other schemes refuse (they need the dense Jacobian-vector product of g).  The tutorial's Neural ODE notebook uses this
+    shape with g = 0."""
+    class Scalar(torch.nn.Module):
+        sde_type, noise_type = 'ito', 'scalar'
+
+        def f(self, t, y):
+            return -0.5 * y + t
+
+        def g(self, t, y):
+            return (0.3 * y).unsqueeze(-1)
+    B, H = 4, 3
+    ts = torch.tensor([0.0, 0.5, 1.0], dtype=torch.float64)
+    y0 = torch.linspace(0.1, 1.2, B * H, dtype=torch.float64).reshape(B, H)
+    rng = np.random.default_rng(0)
+    dW = torch.from_numpy(rng.standard_normal((4, B, 1)) * 0.5)
+
+    class Replay:
+        n = 0
+        def __call__(self, ta, tb):
+            self.n += 1
+            return dW[self.n - 1]
+    ys = S.sdeint(Scalar(), y0, ts, bm=Replay(), dt=0.25, method='euler')
+    y, want, t = y0, [y0], 0.0
+    for n in range(4):
+        y = y + (-0.5 * y + t) * 0.25 + 0.3 * y * dW[n]
+        t += 0.25
+        if n % 2 == 1:
+            want.append(y)
+    np.testing.assert_allclose(ys.numpy(), torch.stack(want).numpy(), rtol=1e-12, atol=1e-12)
+    free = S.sdeint(Scalar(), y0, ts, dt=0.25, method='euler', options={'seed': 5})
+    assert tuple(free.shape) == (3, B, H) and bool(torch.isfinite(free).all())
+    with pytest.raises(NotImplementedError):
+        S.sdeint(Scalar(), y0, ts, dt=0.25, method='srk')
