@@ -25,7 +25,11 @@
 
 namespace {
 
-constexpr int RC = 32;        // reduction rows per LDS chunk
+#ifndef SNSDE_WGRAD_RC
+#define SNSDE_WGRAD_RC 32
+#endif
+constexpr int RC = SNSDE_WGRAD_RC;        // reduction rows per LDS chunk
+constexpr int PR = RC / 16;   // rows per lane and chunk in the staging assignment
 constexpr int LD = 144;       // LDS row stride in floats (== 16 mod 64: the four r-groups of an operand read hit distinct banks)
 constexpr int NT = 512;       // 8 waves: one 16-row strip of the 128 x 128 tile each
 constexpr int TILE = 128;
@@ -104,38 +108,56 @@ __device__ __forceinline__ void wgrad_body(const WArgs& a, const WTile& t, float
     // staging assignment: rows (tid >> 5) and (tid >> 5) + 16 of the chunk, float4 column 4 * (tid & 31), for D and X
     const int c4 = (tid & 31) * 4;
     const bool dcol = t.h0 + c4 < H, xcol = c4 < t.ncols;
-    float4 dreg[2], xreg[2];
+    float4 dreg[PR], xreg[PR];
     float4 bsum = make_float4(0.f, 0.f, 0.f, 0.f);
-    auto fetch = [&](int r0) {
+    // Row r of the reduction = (pass r / B, batch row r % B); the chunks visit consecutive rows, so the lane's (pass, row) and its
+    // two element offsets ADVANCE from chunk to chunk (one integer division per kernel instead of two per chunk and lane: the
+    // division and the 64-bit address products were ~3 VALU instructions per MFMA on the issue port the MFMAs share).
+    // offset(n0, b) = base + n0 * sn + b * sb per operand; moving on by RC rows adds RC * sb, a wrap into the next pass adds sn - B * sb.
+    const size_t BH = (size_t)B * H;
+    const float* dbase = a.delta + ((size_t)t.poff * a.NG + t.d_slot) * BH + t.h0 + c4;
+    const size_t dsn = (size_t)t.pstride * a.NG * BH;
+    const float* xbase;
+    size_t xsn, xsb = H;
+    if (t.x_kind == 0) { xbase = a.act + ((size_t)t.poff * a.NSAVE + t.x_slot) * BH + t.k0 + c4; xsn = (size_t)t.pstride * a.NSAVE * BH; }
+    else if (t.x_kind == 1) { xbase = a.traj + ((size_t)t.poff * a.NP + t.xplane) * BH + t.k0 + c4; xsn = (size_t)t.pstride * a.NP * BH; }
+    else if (t.x_kind == 3) { xbase = a.delta + ((size_t)t.poff * a.NG + t.x_slot) * BH + t.k0 + c4; xsn = (size_t)t.pstride * a.NG * BH; }
+    else if (t.x_kind == 4) { xbase = a.adj + ((size_t)t.poff + 1) * BH + t.k0 + c4; xsn = (size_t)t.pstride * BH; }
+    else { xbase = a.xaux + (size_t)t.poff * B * a.ldx + t.k0 + c4; xsn = (size_t)t.pstride * B * a.ldx; xsb = a.ldx; }
+    const size_t dwrap = dsn - (size_t)B * H, xwrap = xsn - (size_t)B * xsb;
+    int row_r = r_begin + (tid >> 5);                 // the lane's first row of the coming chunk
+    int row_b;
+    size_t doff, xoff;
+    {
+        const int n0 = row_r / B;
+        row_b = row_r - n0 * B;
+        doff = (size_t)n0 * dsn + (size_t)row_b * H;
+        xoff = (size_t)n0 * xsn + (size_t)row_b * xsb;
+    }
+    auto fetch = [&]() {
+        int b1 = row_b;
+        size_t d1 = doff, x1 = xoff;
 #pragma unroll
-        for (int p = 0; p < 2; ++p) {
-            const int r = r0 + (tid >> 5) + 16 * p;
+        for (int p = 0; p < PR; ++p) {
             float4 dv = make_float4(0.f, 0.f, 0.f, 0.f), xv = dv;
-            if (r < r_end) {
-                const int n0 = r / B, b = r - n0 * B;
-                const int n = n0 * t.pstride + t.poff;
-                if (dcol) dv = *reinterpret_cast<const float4*>(a.delta + (((size_t)n * a.NG + t.d_slot) * B + b) * H + t.h0 + c4);
-                if (xcol) {
-                    if (t.x_kind == 0)
-                        xv = *reinterpret_cast<const float4*>(a.act + (((size_t)n * a.NSAVE + t.x_slot) * B + b) * H + t.k0 + c4);
-                    else if (t.x_kind == 1)
-                        xv = *reinterpret_cast<const float4*>(a.traj + (((size_t)n * a.NP + t.xplane) * B + b) * H + t.k0 + c4);
-                    else if (t.x_kind == 3)
-                        xv = *reinterpret_cast<const float4*>(a.delta + (((size_t)n * a.NG + t.x_slot) * B + b) * H + t.k0 + c4);
-                    else if (t.x_kind == 4)
-                        xv = *reinterpret_cast<const float4*>(a.adj + ((size_t)(n + 1) * B + b) * H + t.k0 + c4);
-                    else
-                        xv = *reinterpret_cast<const float4*>(a.xaux + ((size_t)n * B + b) * a.ldx + t.k0 + c4);
-                }
+            if (row_r + 16 * p < r_end) {
+                if (dcol) dv = *reinterpret_cast<const float4*>(dbase + d1);
+                if (xcol) xv = *reinterpret_cast<const float4*>(xbase + x1);
             }
             dreg[p] = dv; xreg[p] = xv;
+            if (p + 1 < PR) {       // the lane's next row: 16 further on
+                b1 += 16; d1 += (size_t)16 * H; x1 += 16 * xsb;
+                while (b1 >= B) { b1 -= B; d1 += dwrap; x1 += xwrap; }
+            }
         }
+        row_r += RC; row_b += RC; doff += (size_t)RC * H; xoff += RC * xsb;
+        while (row_b >= B) { row_b -= B; doff += dwrap; xoff += xwrap; }
     };
     auto stash = [&](int buf) {
         float* Dl = lds + buf * (2 * RC * LD);
         float* Xl = Dl + RC * LD;
 #pragma unroll
-        for (int p = 0; p < 2; ++p) {
+        for (int p = 0; p < PR; ++p) {
             const int rr = (tid >> 5) + 16 * p;
             *reinterpret_cast<float4*>(Dl + rr * LD + c4) = dreg[p];
             *reinterpret_cast<float4*>(Xl + rr * LD + c4) = xreg[p];
@@ -152,25 +174,41 @@ __device__ __forceinline__ void wgrad_body(const WArgs& a, const WTile& t, float
     const int li = lane & 15, lq = lane >> 4;
 
     int buf = 0;
-    if (r_begin < r_end) { fetch(r_begin); stash(0); }
+    if (r_begin < r_end) { fetch(); stash(0); }
     __syncthreads();
     // (measured, not adopted: a second register set keeping the chunk after next in flight as well - 0.188 ms either way at K2:
     // the two resident workgroups per CU already cover the load latency)
     for (int r0 = r_begin; r0 < r_end; r0 += RC) {
         const bool more = r0 + RC < r_end;
-        if (more) fetch(r0 + RC);
+        if (more) fetch();
         if (active) {
             const float* Dl = lds + buf * (2 * RC * LD);
             const float* Xl = Dl + RC * LD;
-#pragma unroll
-            for (int q = 0; q < RC / 4; ++q) {
+            // operands of the NEXT 4-row group are read while the current group's MFMAs issue (two register sets, the order pinned
+            // by sched_barriers): hipcc's own schedule read each operand pair right in front of its two MFMAs and waited a full LDS
+            // round trip every 64 MFMA cycles (55 % MFMA-busy, profiles/r03_pmc_train_kernels.txt)
+            auto ldq = [&](int q, float& av, float (&bv)[NKT]) {
                 const int rr = 4 * q + lq;
-                const float av = Dl[rr * LD + 16 * wave + li];
-                float bv[NKT];
+                av = Dl[rr * LD + 16 * wave + li];
 #pragma unroll
                 for (int i = 0; i < NKT; ++i) bv[i] = Xl[rr * LD + 16 * i + li];
+            };
+            auto mm = [&](float av, const float (&bv)[NKT]) {
 #pragma unroll
                 for (int i = 0; i < NKT; ++i) acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv[i], acc[i], 0, 0, 0);
+            };
+            float av0, av1, bv0[NKT], bv1[NKT];
+            ldq(0, av0, bv0);
+#pragma unroll
+            for (int q = 0; q < RC / 4; q += 2) {
+                ldq(q + 1, av1, bv1);
+                __builtin_amdgcn_sched_barrier(0);
+                mm(av0, bv0);
+                __builtin_amdgcn_sched_barrier(0);
+                if (q + 2 < RC / 4) ldq(q + 2, av0, bv0);
+                __builtin_amdgcn_sched_barrier(0);
+                mm(av1, bv1);
+                __builtin_amdgcn_sched_barrier(0);
             }
         }
         if (more) stash(buf ^ 1);
@@ -557,8 +595,10 @@ bool make_wplan(const snsde_backward* b, const SnsdeNet& net, WPlan* w) {
     if (!ok) return false;
     w->ntiles = nt;
     // R-splits per tile proportional to its work (MFMAs per slab + staging), ~2 workgroups per CU in total
+    static const int wbias = getenv("SNSDE_WGRAD_BIAS") ? atoi(getenv("SNSDE_WGRAD_BIAS")) : 4;
+    static const long wtotal = getenv("SNSDE_WGRAD_WGS") ? atol(getenv("SNSDE_WGRAD_WGS")) : 512L;
     long wsum = 0;
-    for (int i = 0; i < nt; ++i) wsum += (long)(nkt_class(w->tile[i].ncols) + 4) * (w->tile[i].rows / s.batch);
+    for (int i = 0; i < nt; ++i) wsum += (long)(nkt_class(w->tile[i].ncols) + wbias) * (w->tile[i].rows / s.batch);
     if (wsum < 1) wsum = 1;
     int nparts = 0;
     w->max_split = 1;
@@ -567,7 +607,7 @@ bool make_wplan(const snsde_backward* b, const SnsdeNet& net, WPlan* w) {
         const int nk = nkt_class(t.ncols);
         const int chunks = (t.rows + RC - 1) / RC;
         t.cls = (nk == 8 ? 0 : (nk == 4 ? 2 : (nk == 2 ? 4 : 6))) + (t.bias >= 0 ? 0 : 1);
-        int ns = (int)((512L * (nk + 4) * (t.rows / s.batch) + wsum / 2) / wsum);
+        int ns = (int)((wtotal * (nk + wbias) * (t.rows / s.batch) + wsum / 2) / wsum);
         if (ns < 1) ns = 1;
         if (ns > chunks) ns = chunks;
         t.rows_per_split = ((chunks + ns - 1) / ns) * RC;
