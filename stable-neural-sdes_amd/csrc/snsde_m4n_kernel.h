@@ -300,7 +300,7 @@ __global__ void __launch_bounds__(CF::NT, CF::WPS) snsde_m4n_kernel(MfmaArgs a) 
     // follow the regular slots (snsde_act_slots)
     const int nsave_rt = (!SRK && act_fn != 0) ? NSAVE + NHID + 1 + (NN == 2 ? 1 : 0) : NSAVE;
     auto save_act = [&](int pass, int slot, float v) {
-        if (a.act_save && row_ok) a.act_save[((size_t)pass * nsave_rt + slot) * BH + (size_t)row * H + fcol] = v;
+        if (a.act_save && row_ok) (a.act_save + uoff(pass, (uint32_t)nsave_rt * (uint32_t)BH, slot, (uint32_t)BH))[(uint32_t)(row * H + fcol)] = v;
     };
     auto save_pre = [&](int pass, int idx, float v) {      // idx: drift layer 0 .. NHID, NHID + 1 = the net's hidden layer
         if (!SRK && act_fn != 0) save_act(pass, NSAVE + idx, v);

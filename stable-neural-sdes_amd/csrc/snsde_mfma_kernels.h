@@ -160,6 +160,14 @@ __device__ __forceinline__ float fast_tanh(float x) {
     return ax < 0.25f ? p : copysignf(q, x);
 }
 
+// Wave-uniform element offset  n * stride + slot * bh  from 32 x 32 -> 64-bit products (s_mul_i32 / s_mul_hi_u32 on the scalar unit).
+// Written as 64 x 64-bit products of size_t values, hipcc evaluates them on the VALU (v_mad_u64_u32 + two quarter-rate v_mul_lo_u32
+// per product) - ~25 of them per step in the adjoint loop, on the issue port the MFMAs share.  stride, bh < 2^32 (B H times the slots
+// per step: checked by the launcher).
+__device__ __forceinline__ size_t uoff(int n, uint32_t stride, uint32_t slot = 0, uint32_t bh = 0) {
+    return (size_t)((uint64_t)(uint32_t)n * stride + (uint64_t)slot * bh);
+}
+
 template <int KU, int TPW>
 __device__ __forceinline__ void load_weights(float (&w)[TPW][KU * 4], const float* __restrict__ g, int wave, int lane) {
 #pragma unroll
@@ -519,9 +527,9 @@ __global__ void __launch_bounds__(CF::NT, CF::WPS) snsde_mfma_kernel(MfmaArgs a)
             }
             buf[r * ld + col0 + fsub + s] = o;
             if (save_slot >= 0 && a.act_save && row_ok) {
-                a.act_save[(((size_t)save_step * nsave_rt + save_slot) * B + row) * H + wave * 16 + fsub + s] = o;
+                (a.act_save + uoff(save_step, (uint32_t)nsave_rt * (uint32_t)(B * H), save_slot, (uint32_t)(B * H)))[(uint32_t)(row * H + wave * 16 + fsub + s)] = o;
                 if (relu && a.act != 0)      // smooth activations: the pre-activation as well (slots behind the regular ones)
-                    a.act_save[(((size_t)save_step * nsave_rt + CF::NSAVE + save_slot) * B + row) * H + wave * 16 + fsub + s] = pre;
+                    (a.act_save + uoff(save_step, (uint32_t)nsave_rt * (uint32_t)(B * H), CF::NSAVE + save_slot, (uint32_t)(B * H)))[(uint32_t)(row * H + wave * 16 + fsub + s)] = pre;
             }
             return;
         }
@@ -887,7 +895,7 @@ __global__ void __launch_bounds__(CF::NT, CF::WPS) snsde_mfma_kernel(MfmaArgs a)
             }
             const size_t goff = (size_t)row * H + fcol[t];
             if (a.act_save && row_ok) {
-                float* zp = a.act_save + (((size_t)n * nsave_rt + CF::ZSLOT) * B) * H + goff;
+                float* zp = a.act_save + uoff(n, (uint32_t)nsave_rt * (uint32_t)(B * H), CF::ZSLOT, (uint32_t)(B * H)) + goff;
                 if constexpr (FL) zp[0] = zsave[0];
                 else *reinterpret_cast<f32x4*>(zp) = f32x4{zsave[0], zsave[1], zsave[2], zsave[3]};
             }
@@ -1047,7 +1055,7 @@ __global__ void __launch_bounds__(CF::NT, CF::WPS) snsde_mfma_reverse_kernel(Rev
     const bool writer = FL ? (s == 0) : true;
     const bool s1 = (s == 1), s2 = (s == 2), s3 = (s == 3);
     const int fcol = wave * 16 + fsub + (FL ? s : 0);
-    const size_t goff = (size_t)rowc * H + fcol;
+    const uint32_t goff = (uint32_t)(rowc * H + fcol);     // (32-bit lane offset: loads take the scalar-base form)
 
     Wt<CF::STREAM, KUH, TPW> wt[NG];
     uint64_t sbr[NG];                 // RING: this wave's slice of every transposed matrix (SGPR pairs)
@@ -1100,6 +1108,8 @@ __global__ void __launch_bounds__(CF::NT, CF::WPS) snsde_mfma_reverse_kernel(Rev
     float zblk[EPT][4];                 // regenerated increments: the normals of the 4-step block being walked
     int zblk_id = -1;
     const uint32_t grow = (uint32_t)(a.row_offset + row);
+    const uint32_t BH32 = (uint32_t)BH, SBH = (uint32_t)NSAVE * BH32, NSBH = (uint32_t)NS * BH32;     // uniform strides (see uoff)
+    const uint32_t pre0 = a.act_fn != 0 ? (uint32_t)(NHID + 2 + NN) : 0u;      // smooth activations: first PRE-activation slot
     auto prefetch = [&](int n, StepIn& p) {
         if (!a.dW) {                    // (wave-uniform)
             if ((n >> 2) != zblk_id) {
@@ -1107,7 +1117,7 @@ __global__ void __launch_bounds__(CF::NT, CF::WPS) snsde_mfma_reverse_kernel(Rev
 #pragma unroll
                 for (int e = 0; e < EPT; ++e) snsde_philox_normal4(a.seed, grow, (uint32_t)zblk_id, (uint32_t)(fcol + e), zblk[e]);
             }
-            const float sqh = a.step_tab[(size_t)n * SNSDE_STEP_STRIDE + 6];
+            const float sqh = a.step_tab[uoff(n, SNSDE_STEP_STRIDE) + 6];
             const int k = n & 3;
 #pragma unroll
             for (int e = 0; e < EPT; ++e)
@@ -1115,26 +1125,26 @@ __global__ void __launch_bounds__(CF::NT, CF::WPS) snsde_mfma_reverse_kernel(Rev
         }
 #pragma unroll
         for (int e = 0; e < EPT; ++e) {
-            p.y[e] = a.traj[(size_t)n * BH + goff + e];
-            p.z[e] = a.act[(((size_t)n * NSAVE + CF::ZSLOT) * B) * H + goff + e];
-            if (a.dW) p.dw[e] = a.dW[(size_t)n * BH + goff + e];
-            if constexpr (NN > 0) p.gq[e] = a.act[(((size_t)n * NSAVE + CF::ZSLOT + NN) * B) * H + goff + e];   // diffusion-net output
-            else p.gq[e] = a.gt ? a.gt[(size_t)n * H + fcol + e] : 0.0f;
+            p.y[e] = (a.traj + uoff(n, BH32))[goff + e];
+            p.z[e] = (a.act + uoff(n, SBH, CF::ZSLOT, BH32))[goff + e];
+            if (a.dW) p.dw[e] = (a.dW + uoff(n, BH32))[goff + e];
+            if constexpr (NN > 0) p.gq[e] = (a.act + uoff(n, SBH, CF::ZSLOT + NN, BH32))[goff + e];   // diffusion-net output
+            else p.gq[e] = a.gt ? (a.gt + uoff(n, H))[fcol + e] : 0.0f;
         }
         if constexpr (FL) {
 #pragma unroll
             for (int g = 0; g < NM; ++g)     // relu mask of the forward activation feeding transposed GEMM g + 1
-                p.mask[g][0] = a.act[((size_t)n * NSAVE + (NHID - g) + (a.act_fn != 0 ? NHID + 2 + NN : 0)) * BH + goff];     // (smooth activations: the PRE-activation slots, behind the net's)
+                p.mask[g][0] = (a.act + uoff(n, SBH, (uint32_t)(NHID - g) + pre0, BH32))[goff];     // (smooth activations: the PRE-activation slots, behind the net's)
             if constexpr (NN == 2)               // hidden activation of the diffusion net (smooth: its pre-activation, the last slot)
-                p.nmask[0] = a.act[((size_t)n * NSAVE + (a.act_fn != 0 ? NSAVE - 1 : CF::ZSLOT + 1)) * BH + goff];
+                p.nmask[0] = (a.act + uoff(n, SBH, a.act_fn != 0 ? (uint32_t)NSAVE - 1u : (uint32_t)(CF::ZSLOT + 1), BH32))[goff];
         } else if (writer) {
 #pragma unroll
             for (int g = 0; g < NM; ++g)
                 p.mask[g] = *reinterpret_cast<const f32x4*>(
-                    a.act + (((size_t)n * NSAVE + (NHID - g)) * B + rowc) * H + wave * 16 + fsub);
+                    a.act + uoff(n, SBH, NHID - g, BH32) + (uint32_t)(rowc * H + wave * 16 + fsub));
             if constexpr (NN == 2)
                 p.nmask = *reinterpret_cast<const f32x4*>(
-                    a.act + (((size_t)n * NSAVE + CF::ZSLOT + 1) * B + rowc) * H + wave * 16 + fsub);
+                    a.act + uoff(n, SBH, CF::ZSLOT + 1, BH32) + (uint32_t)(rowc * H + wave * 16 + fsub));
         }
     };
     constexpr bool AHEAD = !CF::STREAM || CF::RING;   // (the M16 streamed-weight variant has no registers to spare for it)
@@ -1167,14 +1177,14 @@ __global__ void __launch_bounds__(CF::NT, CF::WPS) snsde_mfma_reverse_kernel(Rev
             const float w0 = a.out_w[2 * k], w1 = a.out_w[2 * k + 1];
 #pragma unroll
             for (int e = 0; e < EPT; ++e) {
-                const float gk = a.row_out ? (rslot == k + 1 ? gfin[e] : 0.0f) : a.grad_ys[(size_t)(k + 1) * BH + goff + e];
+                const float gk = a.row_out ? (rslot == k + 1 ? gfin[e] : 0.0f) : (a.grad_ys + uoff(k + 1, BH32))[goff + e];
                 if (w0 == 0.0f) adj[e] += gk;
                 else { adj[e] = fmaf(w1, gk, adj[e]); carry[e] = fmaf(w0, gk, carry[e]); }
             }
         }
         if (row_ok && !a.adj0_only) {
 #pragma unroll
-            for (int e = 0; e < EPT; ++e) a.adj[(size_t)(n + 1) * BH + goff + e] = adj[e];
+            for (int e = 0; e < EPT; ++e) (a.adj + uoff(n + 1, BH32))[goff + e] = adj[e];
         }
         // ---- elementwise: d(f h + g dW)/d(zout, y) applied to the adjoint ----
         float ay[EPT], dz[EPT], dsv[EPT], dq[EPT];
@@ -1298,7 +1308,7 @@ __global__ void __launch_bounds__(CF::NT, CF::WPS) snsde_mfma_reverse_kernel(Rev
         if constexpr (FL) buf[r * LDA + fcol] = dz[0];
         else *reinterpret_cast<f32x4*>(buf + r * LDA + fcol) = f32x4{dz[0], dz[1], dz[2], dz[3]};
         if (a.delta && row_ok) {
-            float* dp = a.delta + ((size_t)n * NS * B) * H + goff;
+            float* dp = a.delta + uoff(n, NSBH) + goff;
             if constexpr (FL) dp[0] = dz[0];
             else *reinterpret_cast<f32x4*>(dp) = f32x4{dz[0], dz[1], dz[2], dz[3]};
         }
@@ -1307,7 +1317,7 @@ __global__ void __launch_bounds__(CF::NT, CF::WPS) snsde_mfma_reverse_kernel(Rev
             if constexpr (FL) nb[r * LDA + fcol] = dq[0];
             else *reinterpret_cast<f32x4*>(nb + r * LDA + fcol) = f32x4{dq[0], dq[1], dq[2], dq[3]};
             if (a.delta && row_ok) {
-                float* dp = a.delta + (((size_t)n * NS + NB0) * B) * H + goff;
+                float* dp = a.delta + uoff(n, NSBH, NB0, BH32) + goff;
                 if constexpr (FL) dp[0] = dq[0];
                 else *reinterpret_cast<f32x4*>(dp) = f32x4{dq[0], dq[1], dq[2], dq[3]};
             }
@@ -1336,7 +1346,7 @@ __global__ void __launch_bounds__(CF::NT, CF::WPS) snsde_mfma_reverse_kernel(Rev
                     const float zs = g < ND ? cur.mask[g < NM ? g : 0][0] : cur.nmask[0];
                     const float dv = __builtin_expect(a.act_fn != 0, 0) ? o * swish_grad(zs, act_scale) : (zs > 0.0f ? o : 0.0f);
                     lds[(bi + 1) * M * LDA + r * LDA + fcol] = dv;
-                    if (a.delta && row_ok) a.delta[((size_t)n * NS + bi + 1) * BH + goff] = dv;
+                    if (a.delta && row_ok) (a.delta + uoff(n, NSBH, bi + 1, BH32))[goff] = dv;
                     __syncthreads();
                 } else if (g == ND - 1) {
                     adj[0] = ay[0] + o + carry[0];      // end of the drift chain
@@ -1354,7 +1364,7 @@ __global__ void __launch_bounds__(CF::NT, CF::WPS) snsde_mfma_reverse_kernel(Rev
                     for (int i = 0; i < 4; ++i) v[i] = zsv[i] > 0.0f ? v[i] : 0.0f;
                     *reinterpret_cast<f32x4*>(lds + (bi + 1) * M * LDA + r * LDA + wave * 16 + fsub) = v;
                     if (a.delta && row_ok)
-                        *reinterpret_cast<f32x4*>(a.delta + (((size_t)n * NS + bi + 1) * B + row) * H + wave * 16 + fsub) = v;
+                        *reinterpret_cast<f32x4*>(a.delta + uoff(n, NSBH, bi + 1, BH32) + (uint32_t)(row * H + wave * 16 + fsub)) = v;
                 }
                 __syncthreads();
             } else {
@@ -1414,6 +1424,7 @@ __global__ void __launch_bounds__(CF::NT, CF::WPS) snsde_mfma_srk_reverse_kernel
     constexpr int H = CF::H, TPW = 1, M = CF::M, NT = CF::NT, NHID = CF::NHID, NG = CF::NG;
     constexpr int KUH = CF::KUH, LDA = CF::LDA;
     const int NSAVE = a.nsave;                   // activation slots per pass (the smooth-activation variants save more)
+    const uint32_t SBH = (uint32_t)NSAVE * (uint32_t)(a.B * H), NGBH = (uint32_t)NG * (uint32_t)(a.B * H);
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -1425,7 +1436,8 @@ __global__ void __launch_bounds__(CF::NT, CF::WPS) snsde_mfma_srk_reverse_kernel
     const bool writer = (s == 0);
     const bool s1 = (s == 1), s2 = (s == 2), s3 = (s == 3);
     const int fcol = wave * 16 + fsub + s;
-    const size_t goff = (size_t)rowc * H + fcol;
+    const uint32_t goff = (uint32_t)(rowc * H + fcol);
+    const uint32_t BH32 = (uint32_t)BH;                 // uniform strides as 32-bit factors (uoff: scalar-unit products)
 
     Wt<CF::STREAM, KUH, TPW> wt[NG];
 #pragma unroll
@@ -1477,8 +1489,8 @@ __global__ void __launch_bounds__(CF::NT, CF::WPS) snsde_mfma_srk_reverse_kernel
         if (writer) {
 #pragma unroll
             for (int g = 0; g < NG - 1; ++g)
-                dst[g] = *reinterpret_cast<const f32x4*>(a.act + (((size_t)p * NSAVE + (NHID - g) + (a.act_fn != 0 ? NHID + 2 : 0)) * B + rowc) * H +
-                                                         wave * 16 + fsub);     // (smooth activations: the PRE-activation slots)
+                dst[g] = *reinterpret_cast<const f32x4*>(a.act + uoff(p, SBH, (uint32_t)(NHID - g) + (a.act_fn != 0 ? (uint32_t)(NHID + 2) : 0u), BH32) +
+                                                         (uint32_t)(rowc * H + wave * 16 + fsub));     // (smooth activations: the PRE-activation slots)
         }
     };
     load_masks(3 * a.N - 1, mk);
@@ -1495,7 +1507,7 @@ __global__ void __launch_bounds__(CF::NT, CF::WPS) snsde_mfma_srk_reverse_kernel
             else if (a.f_out == SNSDE_DRIFT_LINEAR) dz = cot;
         }
         lds[r * LDA + fcol] = dz;
-        if (a.delta && row_ok) a.delta[((size_t)p * NG * B) * H + goff] = dz;
+        if (a.delta && row_ok) (a.delta + uoff(p, NGBH))[goff] = dz;
         __syncthreads();
         float d = 0.0f;
         f32x4 acc[TPW], acc2[TPW];
@@ -1514,7 +1526,7 @@ __global__ void __launch_bounds__(CF::NT, CF::WPS) snsde_mfma_srk_reverse_kernel
                         v[i] = __builtin_expect(a.act_fn != 0, 0) ? v[i] * swish_grad(zsv[i], act_scale) : (zsv[i] > 0.0f ? v[i] : 0.0f);
                     *reinterpret_cast<f32x4*>(lds + (g + 1) * M * LDA + r * LDA + wave * 16 + fsub) = v;
                     if (a.delta && row_ok)
-                        *reinterpret_cast<f32x4*>(a.delta + (((size_t)p * NG + g + 1) * B + row) * H + wave * 16 + fsub) = v;
+                        *reinterpret_cast<f32x4*>(a.delta + uoff(p, NGBH, g + 1, BH32) + (uint32_t)(row * H + wave * 16 + fsub)) = v;
                 }
                 __syncthreads();
             } else {
@@ -1530,14 +1542,14 @@ __global__ void __launch_bounds__(CF::NT, CF::WPS) snsde_mfma_srk_reverse_kernel
     // per-step inputs (state, increments, saved pre-tanh drifts, table rows) are fetched one step ahead
     struct SrkIn { float y, ik, ik0, z0, z1, z2, t0v, t1v, t3v; };
     auto fetch = [&](int n, SrkIn& q) {
-        const size_t so = (size_t)n * BH + goff;
-        q.y = a.traj[so]; q.ik = a.dW[so]; q.ik0 = a.dU[so];
-        q.z0 = a.act[(((size_t)(3 * n) * NSAVE + CF::ZSLOT) * B) * H + goff];
-        q.z1 = a.act[(((size_t)(3 * n + 1) * NSAVE + CF::ZSLOT) * B) * H + goff];
-        q.z2 = a.act[(((size_t)(3 * n + 2) * NSAVE + CF::ZSLOT) * B) * H + goff];
+        const size_t so = uoff(n, BH32);
+        q.y = (a.traj + so)[goff]; q.ik = (a.dW + so)[goff]; q.ik0 = (a.dU + so)[goff];
+        q.z0 = (a.act + uoff(3 * n, SBH, CF::ZSLOT, BH32))[goff];
+        q.z1 = (a.act + uoff(3 * n + 1, SBH, CF::ZSLOT, BH32))[goff];
+        q.z2 = (a.act + uoff(3 * n + 2, SBH, CF::ZSLOT, BH32))[goff];
         q.t0v = q.t1v = q.t3v = 0.0f;
         if (a.gt) {
-            const float* gp = a.gt + (size_t)n * 4 * H + fcol;
+            const float* gp = a.gt + uoff(n, 4 * H) + fcol;
             q.t0v = gp[0]; q.t1v = gp[H]; q.t3v = gp[3 * H];
         }
     };
@@ -1547,17 +1559,17 @@ __global__ void __launch_bounds__(CF::NT, CF::WPS) snsde_mfma_srk_reverse_kernel
     for (int n = a.N - 1; n >= 0; --n) {
         nxt = cur;
         if (n > 0) fetch(n - 1, nxt);
-        const float* st = a.step_tab + (size_t)n * SNSDE_STEP_STRIDE;
+        const float* st = a.step_tab + uoff(n, SNSDE_STEP_STRIDE);
         const float h = st[1], rdt = st[6];
         const int nout = __float_as_int(st[8]), kfirst = __float_as_int(st[9]);
         float carry = 0.0f;
         for (int k = kfirst; k < kfirst + nout; ++k) {
             const float w0 = a.out_w[2 * k], w1 = a.out_w[2 * k + 1];
-            const float gk = a.row_out ? (rslot == k + 1 ? gfin : 0.0f) : a.grad_ys[(size_t)(k + 1) * BH + goff];
+            const float gk = a.row_out ? (rslot == k + 1 ? gfin : 0.0f) : (a.grad_ys + uoff(k + 1, BH32))[goff];
             if (w0 == 0.0f) adj += gk;
             else { adj = fmaf(w1, gk, adj); carry = fmaf(w0, gk, carry); }
         }
-        if (row_ok && !a.adj0_only) a.adj[(size_t)(n + 1) * BH + goff] = adj;
+        if (row_ok && !a.adj0_only) (a.adj + uoff(n + 1, BH32))[goff] = adj;
         // ---- recompute the stage values of the step for the own element ----
         const float y = cur.y, ik = cur.ik, ik0 = cur.ik0, z0 = cur.z0, z1 = cur.z1, z2 = cur.z2;
         const float t0v = cur.t0v, t1v = cur.t1v, t3v = cur.t3v;
