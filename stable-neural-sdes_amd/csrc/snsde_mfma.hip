@@ -503,6 +503,8 @@ size_t snsde_mfma_workspace_floats(const snsde_solve* s, const SnsdeNet& net) {
 int snsde_mfma_launch(const snsde_solve* s, const SnsdeNet& net, hipStream_t stream, int flavor_hint) {
     MfmaPlan p = make_plan(s, net, flavor_hint);
     if (!p.ok) return SNSDE_ERR_UNSUPPORTED;
+    // the kernels form their per-step save offsets from 32-bit uniform factors (uoff): slots x B x H must fit
+    if ((uint64_t)16 * (uint64_t)s->batch * (uint64_t)s->model.hidden_channels >= (1ull << 32)) return SNSDE_ERR_UNSUPPORTED;
     float* ws = static_cast<float*>(s->workspace);
     if (!(s->flags & SNSDE_FLAG_REUSE_PREPARED)) {
         MfmaPackJob job{};
@@ -641,6 +643,7 @@ int snsde_mfma_backward_launch(const snsde_backward* b, const SnsdeNet& net, hip
     MfmaPlan fp = make_plan(s, net, hint);
     RevPlan p = make_rev_plan(s, net, fp);
     if (!p.ok) return SNSDE_ERR_UNSUPPORTED;
+    if ((uint64_t)16 * (uint64_t)s->batch * (uint64_t)s->model.hidden_channels >= (1ull << 32)) return SNSDE_ERR_UNSUPPORTED;   // (uoff)
     float* ws = static_cast<float*>(b->workspace);
     if (p.emb) {   // first_y = emb[:, 0:H] . linear_in  (all columns; the pack step picks the y columns)
         FoldJob fj{};
