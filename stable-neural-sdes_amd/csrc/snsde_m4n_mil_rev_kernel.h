@@ -72,7 +72,8 @@ __global__ void __launch_bounds__(CF::NT, CF::WPS) snsde_m4n_mil_reverse_kernel(
     const bool row_ok = row < B;
     const size_t BH = (size_t)B * H;
     const int fcol = wave * 16 + fsub + s;
-    const size_t goff = (size_t)rowc * H + fcol;
+    const uint32_t goff = (uint32_t)(rowc * H + fcol);
+    const uint32_t BH32 = (uint32_t)BH;      // uniform strides as 32-bit factors (uoff: scalar-unit products)
     const int lrow = r * LDA + fcol, brow = r * LDA + 4 * s;
 
     // matrices: drift chain (out^T, hid^T.., first_y^T) | W1_y | [W2 | W2^T] | W1_y^T
@@ -117,20 +118,20 @@ __global__ void __launch_bounds__(CF::NT, CF::WPS) snsde_m4n_mil_reverse_kernel(
         else gemm4<KUH>(w4, in, c, d);
     };
     auto put_delta = [&](int n, int slot, float v) {
-        if (a.delta && row_ok) a.delta[((size_t)n * NDEL + slot) * BH + goff] = v;
+        if (a.delta && row_ok) (a.delta + uoff(n, (uint32_t)NDEL * BH32, slot, BH32))[goff] = v;
     };
 
     struct StepIn { float y, z, dw, q, h1, dm[NHID + 1]; float h; int nout, kfirst; };
     auto fetch = [&](int n, StepIn& p) {
-        const size_t so = (size_t)n * BH + goff;
-        const float* ap = a.act + ((size_t)n * NSAVE) * BH + goff;
+        const size_t so = uoff(n, BH32) + goff;
+        const float* ap = a.act + uoff(n, (uint32_t)NSAVE * BH32) + goff;
         p.y = a.traj[so]; p.dw = a.dW[so];
         p.z = ap[(size_t)ZSLOT * BH];
         p.q = ap[(size_t)(ZSLOT + NN) * BH];
         p.h1 = NN == 2 ? ap[(size_t)(ZSLOT + 1) * BH] : 0.0f;
 #pragma unroll
         for (int g = 0; g < NHID + 1; ++g) p.dm[g] = ap[(size_t)(NHID - g) * BH];
-        const float* stp = a.step_tab + (size_t)n * SNSDE_STEP_STRIDE;
+        const float* stp = a.step_tab + uoff(n, SNSDE_STEP_STRIDE);
         p.h = stp[1]; p.nout = __float_as_int(stp[8]); p.kfirst = __float_as_int(stp[9]);
     };
 
@@ -143,11 +144,11 @@ __global__ void __launch_bounds__(CF::NT, CF::WPS) snsde_m4n_mil_reverse_kernel(
         float carry = 0.0f;
         for (int k = cur.kfirst; k < cur.kfirst + cur.nout; ++k) {
             const float w0o = a.out_w[2 * k], w1o = a.out_w[2 * k + 1];
-            const float gk = a.row_out ? (rslot == k + 1 ? gfin : 0.0f) : a.grad_ys[(size_t)(k + 1) * BH + goff];
+            const float gk = a.row_out ? (rslot == k + 1 ? gfin : 0.0f) : (a.grad_ys + uoff(k + 1, BH32))[goff];
             if (w0o == 0.0f) adj += gk;
             else { adj = fmaf(w1o, gk, adj); carry = fmaf(w0o, gk, carry); }
         }
-        if (row_ok) a.adj[(size_t)(n + 1) * BH + goff] = adj;
+        if (row_ok) (a.adj + uoff(n + 1, BH32))[goff] = adj;
         const float av = adj, y = cur.y, dw = cur.dw, q = cur.q;
 
         // drift: F = tanh(z gate(y)); cotangent a h

@@ -65,7 +65,8 @@ __global__ void __launch_bounds__(CF::NT, CF::WPS) snsde_m4n_srk_reverse_kernel(
     const bool row_ok = row < B;
     const size_t BH = (size_t)B * H;
     const int fcol = wave * 16 + fsub + s;
-    const size_t goff = (size_t)rowc * H + fcol;
+    const uint32_t goff = (uint32_t)(rowc * H + fcol);
+    const uint32_t BH32 = (uint32_t)BH, SLBH = (uint32_t)NSLOT * BH32;      // uniform strides as 32-bit factors (uoff: scalar-unit products)
     const int lrow = r * LDA + fcol;               // own element inside an LDS buffer
     const int brow = r * LDA + 4 * s;              // this lane's B-operand row inside an LDS buffer
 
@@ -112,11 +113,11 @@ __global__ void __launch_bounds__(CF::NT, CF::WPS) snsde_m4n_srk_reverse_kernel(
         float h, rdt; int nout, kfirst;
     };
     auto fetch = [&](int n, StepIn& p) {
-        const size_t so = (size_t)n * BH + goff;
+        const size_t so = uoff(n, BH32) + goff;
         p.y = a.traj[so]; p.ik = a.dW[so]; p.ik0 = a.dU[so];
 #pragma unroll
         for (int st = 0; st < 3; ++st) {
-            const float* ap = a.act + ((size_t)(3 * n + st) * NSLOT) * BH + goff;
+            const float* ap = a.act + uoff(3 * n + st, SLBH) + goff;
             p.z[st] = ap[(size_t)ZSLOT * BH];
             p.q[st] = ap[(size_t)(ZSLOT + NN) * BH];
             if constexpr (NN == 2) p.nh[st] = ap[(size_t)(ZSLOT + 1) * BH];
@@ -127,7 +128,7 @@ __global__ void __launch_bounds__(CF::NT, CF::WPS) snsde_m4n_srk_reverse_kernel(
                 if constexpr (NN == 2) p.nh[3] = ap[(size_t)(ZSLOT + NN + 1) * BH];
             }
         }
-        const float* stp = a.step_tab + (size_t)n * SNSDE_STEP_STRIDE;
+        const float* stp = a.step_tab + uoff(n, SNSDE_STEP_STRIDE);
         p.h = stp[1]; p.rdt = stp[6]; p.nout = __float_as_int(stp[8]); p.kfirst = __float_as_int(stp[9]);
     };
 
@@ -140,11 +141,11 @@ __global__ void __launch_bounds__(CF::NT, CF::WPS) snsde_m4n_srk_reverse_kernel(
         float* nbB = nb1;
         if (do_d) {
             lds[lrow] = dz;
-            if (a.delta && row_ok) a.delta[((size_t)p * NSLOT) * BH + goff] = dz;
+            if (a.delta && row_ok) (a.delta + uoff(p, SLBH))[goff] = dz;
         }
         if (do_n) {
             nbA[lrow] = qb;
-            if (a.delta && row_ok) a.delta[((size_t)pn * NSLOT + ns0) * BH + goff] = qb;
+            if (a.delta && row_ok) (a.delta + uoff(pn, SLBH, ns0, BH32))[goff] = qb;
             if constexpr (NN == 1) nsel ^= 1;
         }
         __syncthreads();
@@ -159,7 +160,7 @@ __global__ void __launch_bounds__(CF::NT, CF::WPS) snsde_m4n_srk_reverse_kernel(
                 if (k < ND - 1) {
                     const float dv = dm[k] > 0.0f ? o : 0.0f;
                     lds[(k + 1) * M * LDA + lrow] = dv;
-                    if (a.delta && row_ok) a.delta[((size_t)p * NSLOT + k + 1) * BH + goff] = dv;
+                    if (a.delta && row_ok) (a.delta + uoff(p, SLBH, k + 1, BH32))[goff] = dv;
                     more = true;
                 } else {
                     d_res = o;
@@ -173,7 +174,7 @@ __global__ void __launch_bounds__(CF::NT, CF::WPS) snsde_m4n_srk_reverse_kernel(
                 if (k < NN - 1) {
                     const float dv = nm > 0.0f ? o : 0.0f;
                     nbB[lrow] = dv;
-                    if (a.delta && row_ok) a.delta[((size_t)pn * NSLOT + ns0 + 1) * BH + goff] = dv;
+                    if (a.delta && row_ok) (a.delta + uoff(pn, SLBH, ns0 + 1, BH32))[goff] = dv;
                     more = true;
                 } else {
                     n_res = o;
@@ -192,11 +193,11 @@ __global__ void __launch_bounds__(CF::NT, CF::WPS) snsde_m4n_srk_reverse_kernel(
         float carry = 0.0f;
         for (int k = cur.kfirst; k < cur.kfirst + cur.nout; ++k) {
             const float w0o = a.out_w[2 * k], w1o = a.out_w[2 * k + 1];
-            const float gk = a.row_out ? (rslot == k + 1 ? gfin : 0.0f) : a.grad_ys[(size_t)(k + 1) * BH + goff];
+            const float gk = a.row_out ? (rslot == k + 1 ? gfin : 0.0f) : (a.grad_ys + uoff(k + 1, BH32))[goff];
             if (w0o == 0.0f) adj += gk;
             else { adj = fmaf(w1o, gk, adj); carry = fmaf(w0o, gk, carry); }
         }
-        if (row_ok && !a.adj0_only) a.adj[(size_t)(n + 1) * BH + goff] = adj;
+        if (row_ok && !a.adj0_only) (a.adj + uoff(n + 1, BH32))[goff] = adj;
 
         // ---- recompute the stage values of the step (own element) ----
         const float y = cur.y, ik = cur.ik, ik0 = cur.ik0;
