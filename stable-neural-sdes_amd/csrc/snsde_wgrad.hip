@@ -134,17 +134,26 @@ __device__ __forceinline__ void wgrad_body(const WArgs& a, const WTile& t, float
         doff = (size_t)n0 * dsn + (size_t)row_b * H;
         xoff = (size_t)n0 * xsn + (size_t)row_b * xsb;
     }
-    auto fetch = [&]() {
+#pragma unroll
+    for (int p = 0; p < PR; ++p) dreg[p] = xreg[p] = make_float4(0.f, 0.f, 0.f, 0.f);
+    // full: every row of the chunk is inside the split (all chunks but possibly the last): the loads are predicated by the lane's
+    // column only and lanes outside keep their zeros - no per-chunk re-zeroing of the staging registers (40 v_mov per chunk)
+    auto fetch = [&](const bool full) {
         int b1 = row_b;
         size_t d1 = doff, x1 = xoff;
 #pragma unroll
         for (int p = 0; p < PR; ++p) {
-            float4 dv = make_float4(0.f, 0.f, 0.f, 0.f), xv = dv;
-            if (row_r + 16 * p < r_end) {
-                if (dcol) dv = *reinterpret_cast<const float4*>(dbase + d1);
-                if (xcol) xv = *reinterpret_cast<const float4*>(xbase + x1);
+            if (full) {
+                if (dcol) dreg[p] = *reinterpret_cast<const float4*>(dbase + d1);
+                if (xcol) xreg[p] = *reinterpret_cast<const float4*>(xbase + x1);
+            } else {
+                float4 dv = make_float4(0.f, 0.f, 0.f, 0.f), xv = dv;
+                if (row_r + 16 * p < r_end) {
+                    if (dcol) dv = *reinterpret_cast<const float4*>(dbase + d1);
+                    if (xcol) xv = *reinterpret_cast<const float4*>(xbase + x1);
+                }
+                dreg[p] = dv; xreg[p] = xv;
             }
-            dreg[p] = dv; xreg[p] = xv;
             if (p + 1 < PR) {       // the lane's next row: 16 further on
                 b1 += 16; d1 += (size_t)16 * H; x1 += 16 * xsb;
                 while (b1 >= B) { b1 -= B; d1 += dwrap; x1 += xwrap; }
@@ -174,13 +183,14 @@ __device__ __forceinline__ void wgrad_body(const WArgs& a, const WTile& t, float
     const int li = lane & 15, lq = lane >> 4;
 
     int buf = 0;
-    if (r_begin < r_end) { fetch(); stash(0); }
+    if (r_begin < r_end) { fetch(false); stash(0); }
     __syncthreads();
     // (measured, not adopted: a second register set keeping the chunk after next in flight as well - 0.188 ms either way at K2:
     // the two resident workgroups per CU already cover the load latency)
     for (int r0 = r_begin; r0 < r_end; r0 += RC) {
         const bool more = r0 + RC < r_end;
-        if (more) fetch();
+        if (r0 + 2 * RC <= r_end) fetch(true);
+        else if (more) fetch(false);
         if (active) {
             const float* Dl = lds + buf * (2 * RC * LD);
             const float* Xl = Dl + RC * LD;
