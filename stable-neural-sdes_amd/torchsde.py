@@ -446,7 +446,7 @@ def _sdeint_latent(sde, y0, ts, bm, method, dt, options, names):
         if engine.backward_mode(field.model, B, 2, full, method, table=True) != 1:
             return fallback()
         flat = field.flat(dev, grad=True)
-        tab = field.noise_table(tab_times, dev)           # (the shared diffusion is a buffer: no gradient)
+        tab = field.noise_table(tab_times, dev, grad=True).detach()     # (a buffer: no gradient; grad=True = no cache key, i.e. no host read-back)
         Y = _ComposedSolve.apply(field.model, coeffs, full, widen(dW), method, 0, 0, None, y0p, flat, tab, widen(dU))
     else:
         flat, tab = field.inference_inputs(tab_times, dev)
