@@ -97,8 +97,12 @@ __global__ void __launch_bounds__(256) snsde_xaux_kernel(XArgs a) {
 }
 
 // NKT = 16-column sub-tiles of X per wave (compile time: the MFMA chain is branch-free); BIAS: also the column sums of D
-template <int NKT, bool BIAS>
+// G = column groups: hidden sizes below 128 fill only H / 16 of the eight 16-row strips, so the waves are arranged as
+// (8 / G strips) x (G groups of NKT / G column sub-tiles) and every wave issues MFMAs (H = 64: G = 2, H <= 32: G = 4)
+template <int NKT, bool BIAS, int G>
 __device__ __forceinline__ void wgrad_body(const WArgs& a, const WTile& t, float* lds) {
+    static_assert(NKT % G == 0 && NKT / G >= 1, "column groups must divide the sub-tiles");
+    constexpr int NKTG = NKT / G;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int split = blockIdx.x;
     const int r_begin = split * t.rows_per_split;
@@ -176,10 +180,11 @@ __device__ __forceinline__ void wgrad_body(const WArgs& a, const WTile& t, float
         }
     };
 
-    f32x4 acc[NKT];
+    f32x4 acc[NKTG];
 #pragma unroll
-    for (int i = 0; i < NKT; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
-    const bool active = t.h0 + 16 * wave < H;
+    for (int i = 0; i < NKTG; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const int strip = wave & (8 / G - 1), cg = wave / (8 / G);       // this wave's 16-row strip of D and its column group
+    const bool active = t.h0 + 16 * strip < H;
     const int li = lane & 15, lq = lane >> 4;
 
     int buf = 0;
@@ -197,17 +202,17 @@ __device__ __forceinline__ void wgrad_body(const WArgs& a, const WTile& t, float
             // operands of the NEXT 4-row group are read while the current group's MFMAs issue (two register sets, the order pinned
             // by sched_barriers): hipcc's own schedule read each operand pair right in front of its two MFMAs and waited a full LDS
             // round trip every 64 MFMA cycles (55 % MFMA-busy, profiles/r03_pmc_train_kernels.txt)
-            auto ldq = [&](int q, float& av, float (&bv)[NKT]) {
+            auto ldq = [&](int q, float& av, float (&bv)[NKTG]) {
                 const int rr = 4 * q + lq;
-                av = Dl[rr * LD + 16 * wave + li];
+                av = Dl[rr * LD + 16 * strip + li];
 #pragma unroll
-                for (int i = 0; i < NKT; ++i) bv[i] = Xl[rr * LD + 16 * i + li];
+                for (int i = 0; i < NKTG; ++i) bv[i] = Xl[rr * LD + 16 * (cg * NKTG + i) + li];
             };
-            auto mm = [&](float av, const float (&bv)[NKT]) {
+            auto mm = [&](float av, const float (&bv)[NKTG]) {
 #pragma unroll
-                for (int i = 0; i < NKT; ++i) acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv[i], acc[i], 0, 0, 0);
+                for (int i = 0; i < NKTG; ++i) acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv[i], acc[i], 0, 0, 0);
             };
-            float av0, av1, bv0[NKT], bv1[NKT];
+            float av0, av1, bv0[NKTG], bv1[NKTG];
             ldq(0, av0, bv0);
 #pragma unroll
             for (int q = 0; q < RC / 4; q += 2) {
@@ -225,12 +230,14 @@ __device__ __forceinline__ void wgrad_body(const WArgs& a, const WTile& t, float
         __syncthreads();
         buf ^= 1;
     }
-    // partial tile out: rows 16*wave + 4*lq + v, columns 16*i + li
+    // partial tile out: rows 16*strip + 4*lq + v, columns 16*(cg*NKTG + i) + li (strips beyond H: never read by the reduce kernel)
     float* out = a.part + (size_t)(t.part + split) * TILE_FLOATS;
+    if (active) {
 #pragma unroll
-    for (int i = 0; i < NKT; ++i)
+        for (int i = 0; i < NKTG; ++i)
 #pragma unroll
-        for (int v = 0; v < 4; ++v) out[(16 * wave + 4 * lq + v) * TILE + 16 * i + li] = acc[i][v];
+            for (int v = 0; v < 4; ++v) out[(16 * strip + 4 * lq + v) * TILE + 16 * (cg * NKTG + i) + li] = acc[i][v];
+    }
     if constexpr (BIAS) {      // column sums of D: 16 row-threads per float4 column, summed through LDS
         float* red = lds;      // all MFMA reads of the buffers are behind the loop's last barrier
         *reinterpret_cast<float4*>(red + (tid >> 5) * TILE + c4) = bsum;
@@ -244,19 +251,27 @@ __device__ __forceinline__ void wgrad_body(const WArgs& a, const WTile& t, float
     }
 }
 
+template <int NKT, bool BIAS>
+__device__ __forceinline__ void wgrad_groups(const WArgs& a, const WTile& t, float* lds, int g) {
+    if constexpr (NKT >= 4) { if (g == 4) { wgrad_body<NKT, BIAS, 4>(a, t, lds); return; } }
+    if constexpr (NKT >= 2) { if (g >= 2) { wgrad_body<NKT, BIAS, 2>(a, t, lds); return; } }
+    wgrad_body<NKT, BIAS, 1>(a, t, lds);
+}
+
 __global__ void __launch_bounds__(NT, 4) snsde_wgrad_kernel(WArgs a) {
     extern __shared__ __attribute__((aligned(16))) float lds[];   // [2 buffers][D | X][RC][LD]
     const WTile t = snsde_kernarg_element<WTile>(offsetof(WArgs, tile), blockIdx.y);     // (not a.tile[blockIdx.y]: see the helper)
     if ((int)blockIdx.x >= t.nsplit) return;
+    const int g = a.H >= 128 ? 1 : (a.H >= 64 ? 2 : 4);      // column groups (uniform per launch)
     switch (t.cls) {     // uniform per workgroup
-        case 0: wgrad_body<8, true>(a, t, lds); break;
-        case 1: wgrad_body<8, false>(a, t, lds); break;
-        case 2: wgrad_body<4, true>(a, t, lds); break;
-        case 3: wgrad_body<4, false>(a, t, lds); break;
-        case 4: wgrad_body<2, true>(a, t, lds); break;
-        case 5: wgrad_body<2, false>(a, t, lds); break;
-        case 6: wgrad_body<1, true>(a, t, lds); break;
-        default: wgrad_body<1, false>(a, t, lds); break;
+        case 0: wgrad_groups<8, true>(a, t, lds, g); break;
+        case 1: wgrad_groups<8, false>(a, t, lds, g); break;
+        case 2: wgrad_groups<4, true>(a, t, lds, g); break;
+        case 3: wgrad_groups<4, false>(a, t, lds, g); break;
+        case 4: wgrad_groups<2, true>(a, t, lds, g); break;
+        case 5: wgrad_groups<2, false>(a, t, lds, g); break;
+        case 6: wgrad_groups<1, true>(a, t, lds, g); break;
+        default: wgrad_groups<1, false>(a, t, lds, g); break;
     }
 }
 
@@ -608,7 +623,10 @@ bool make_wplan(const snsde_backward* b, const SnsdeNet& net, WPlan* w) {
     static const int wbias = getenv("SNSDE_WGRAD_BIAS") ? atoi(getenv("SNSDE_WGRAD_BIAS")) : 4;
     static const long wtotal = getenv("SNSDE_WGRAD_WGS") ? atol(getenv("SNSDE_WGRAD_WGS")) : 512L;
     long wsum = 0;
-    for (int i = 0; i < nt; ++i) wsum += (long)(nkt_class(w->tile[i].ncols) + wbias) * (w->tile[i].rows / s.batch);
+    // (the weights stay proportional to the tile's columns although the kernel's column groups divide the MFMAs per wave at H < 128:
+    //  there the kernel is bound by the bytes it stages, which scale the same way; measured at the K4 shape: 130 vs 151 us)
+    auto nk_eff = [&](int nk) { return nk; };
+    for (int i = 0; i < nt; ++i) wsum += (long)(nk_eff(nkt_class(w->tile[i].ncols)) + wbias) * (w->tile[i].rows / s.batch);
     if (wsum < 1) wsum = 1;
     int nparts = 0;
     w->max_split = 1;
@@ -617,7 +635,7 @@ bool make_wplan(const snsde_backward* b, const SnsdeNet& net, WPlan* w) {
         const int nk = nkt_class(t.ncols);
         const int chunks = (t.rows + RC - 1) / RC;
         t.cls = (nk == 8 ? 0 : (nk == 4 ? 2 : (nk == 2 ? 4 : 6))) + (t.bias >= 0 ? 0 : 1);
-        int ns = (int)((wtotal * (nk + wbias) * (t.rows / s.batch) + wsum / 2) / wsum);
+        int ns = (int)((wtotal * (nk_eff(nk) + wbias) * (t.rows / s.batch) + wsum / 2) / wsum);
         if (ns < 1) ns = 1;
         if (ns > chunks) ns = chunks;
         t.rows_per_split = ((chunks + ns - 1) / ns) * RC;
