@@ -358,6 +358,31 @@ def tutorial_field(dev, stream, kind='lnsde', rows=1024, hh=128, n=100):
             "value": rows * n / (float(np.median(fused)) * 1e-3), "unit": "row-steps/s"}
 
 
+def latent_sde(dev, stream, rows=1024, hidden=32, L=50):
+    """torch-ists' LatentSDE shape (tests/latent_field.LatentField: the reference wrapper's forward - spline start,
+    sdeint_adjoint(names f_aug / g_aug), KL) under its default `srk`: the split solve (fused latent dynamics + batched KL quadrature,
+    torchsde._sdeint_latent) next to the tensor-op loop, inference and one training step (wall clock per call, HIP events)."""
+    from tests.latent_field import LatentField
+    torch.manual_seed(1)
+    m = LatentField(4, hidden, hidden, 2).to(dev)
+    times = torch.linspace(0, 1, L, device=dev)
+    X = torch.cumsum(0.2 * torch.randn(rows, L, 4, device=dev), dim=1)
+    coeffs = S.torchcde.hermite_cubic_coefficients_with_backward_differences(X, times)
+    out = {"workload": f"LatentSDE-shaped module ({hidden - 1} latent channels + KL accumulator, 2 hidden layers), {rows} rows, {L} output times, "
+                       "srk, whole wrapper forward / training step"}
+    for backend, key, n in (('auto', 'fused', 10), ('torch', 'tensor_loop', 2)):
+        opts = {'seed': 3, 'backend': backend}
+        with torch.no_grad():
+            out[key + "_forward"] = spread(event_times_ms(lambda: m(coeffs, times, method='srk', options=opts), stream, n, 2))
+
+        def step():
+            m.zero_grad(set_to_none=True)
+            o, latent, kl = m(coeffs, times, method='srk', options=opts)
+            (o.square().mean() + 1e-3 * kl).backward()
+        out[key + "_training_step"] = spread(event_times_ms(step, stream, n, 2))
+    return out
+
+
 def self_launch(args):
     """`python bench.py --gpus N` without torchrun: re-execute under torch.distributed.run, one rank per GPU."""
     with socket.socket() as s:
@@ -446,6 +471,7 @@ def main():
             extra["NSDE_3_18_milstein_K4_shape"] = train_leg(dev, stream, 3, 18, 2048, 64, 69, 72, 'milstein', 'neuralsde_3_18, milstein')
             extra["tutorial_field"] = tutorial_field(dev, stream)
             extra["K1_tutorial_lsde"] = tutorial_field(dev, stream, kind='lsde', rows=256, hh=32, n=50)
+            extra["latent_sde_srk"] = latent_sde(dev, stream)
 
     if rank == 0:
         rowsteps = B * NSTEP
