@@ -841,6 +841,8 @@ _SRK = dict(C0=(0.0, 1.0, 0.5, 0.0), C1=(0.0, 0.25, 1.0, 0.25),
 
 
 def _srk_step(f, g, t0, h, y, I_k, I_k0):
+    """One SRID2 step.  Terms whose tableau coefficient is zero are not formed (x + 0 * z = x exactly for finite z: same values,
+    a third of the tensor ops), nor is the drift of the last stage, which no later term reads (alpha[3] = 0)."""
     T = _SRK
     rdt = h.sqrt()
     I_kk = (I_k * I_k - h) / 2
@@ -850,12 +852,26 @@ def _srk_step(f, g, t0, h, y, I_k, I_k0):
     for s in range(4):
         H0, H1 = y, y
         for j in range(s):
-            H0 = H0 + T['A0'][s][j] * fs[j] * h + T['B0'][s][j] * gs[j] * I_k0 / h
-            H1 = H1 + T['A1'][s][j] * fs[j] * h + T['B1'][s][j] * gs[j] * rdt
-        fs.append(f(t0 + T['C0'][s] * h, H0))
+            if T['A0'][s][j] != 0.0:
+                H0 = H0 + T['A0'][s][j] * fs[j] * h
+            if T['B0'][s][j] != 0.0:
+                H0 = H0 + T['B0'][s][j] * gs[j] * I_k0 / h
+            if T['A1'][s][j] != 0.0:
+                H1 = H1 + T['A1'][s][j] * fs[j] * h
+            if T['B1'][s][j] != 0.0:
+                H1 = H1 + T['B1'][s][j] * gs[j] * rdt
+        need_f = T['alpha'][s] != 0.0 or any(T['A0'][r][s] != 0.0 or T['A1'][r][s] != 0.0 for r in range(s + 1, 4))
+        fs.append(f(t0 + T['C0'][s] * h, H0) if need_f else None)
         gs.append(g(t0 + T['C1'][s] * h, H1))
-        gw = T['beta1'][s] * I_k + T['beta2'][s] * I_kk / rdt + T['beta3'][s] * I_k0 / h + T['beta4'][s] * I_kkk / h
-        y1 = y1 + T['alpha'][s] * fs[s] * h + gw * gs[s]
+        gw = None
+        for coef, term in ((T['beta1'][s], lambda c: c * I_k), (T['beta2'][s], lambda c: c * I_kk / rdt),
+                           (T['beta3'][s], lambda c: c * I_k0 / h), (T['beta4'][s], lambda c: c * I_kkk / h)):
+            if coef != 0.0:        # (same expression forms as the unskipped sum: bit-identical values)
+                gw = term(coef) if gw is None else gw + term(coef)
+        if T['alpha'][s] != 0.0:
+            y1 = y1 + T['alpha'][s] * fs[s] * h
+        if gw is not None:
+            y1 = y1 + gw * gs[s]
     return y1
 
 
