@@ -217,7 +217,8 @@ enum { SNSDE_BWD_ADJ0_ONLY = 1 };
 
 int    snsde_act_slots(const snsde_model* m);             /* activation tensors saved per step, or <0: layer outputs (first, hidden.., */
                                                           /* pre-tanh drift) [+ diffusion-net slots]; models with a smooth activation  */
-                                                          /* (SNSDE_ACT_LIPSWISH / SILU) also save every pre-activation (NL more slots) */
+                                                          /* (SNSDE_ACT_LIPSWISH / SILU) also save every pre-activation (NL more slots,  */
+                                                          /* + the hidden pre-activation of a two-layer diffusion net, the last slot)   */
 int    snsde_save_layout(const snsde_solve* s, int32_t* act_slots, int32_t* stage_planes, int32_t* delta_slots);
                                                           /* training-mode buffers of THIS solve (model + method): act_save /     */
                                                           /* delta_save are (passes, act_slots, B, H), stage_save (passes + 1,     */
