@@ -357,3 +357,51 @@ def test_fused_path_vs_trajectories_of_the_reference_notebooks_fields(case):
     assert err <= 2e-4 * max(scale, 1.0), (err, scale)
     # no further from the float64 trajectory than the float32 tensor-op evaluation of the notebook's module (x4)
     assert err <= 4 * np.abs(g['ys32'].astype(np.float64) - ref).max() + 1e-5 * scale
+
+
+@pytest.mark.parametrize('kind,method', [('gsde', 'srk'), ('nsde', 'euler')])
+def test_field_training_step_at_the_timed_size_vs_fp64_autograd(kind, method):
+    """The sizes tools/time_fields.py / bench.py time (1024 rows, H = 128; 40 steps here to bound the float64 loop): loss.backward()
+    through the fused solve against float64 autograd through the tensor-op loop on the same increments."""
+    dev = torch.device('cuda')
+    B, H, C, L, n = 1024, 128, 2, 5, 40
+    field, times, coeffs, y0 = problem(123, B, H, C, L, kind, 1, 'lipswish', dev)
+    times = torch.linspace(0.0, 1.0, L, dtype=torch.float64)
+    dt = 1.0 / n
+    grid = S.engine.StepGrid(times.numpy().astype(np.float32), dt, times.numpy().astype(np.float32), None)
+    h = (grid.t1 - grid.t0).astype(np.float64)
+    gen = torch.Generator(device=dev).manual_seed(9)
+    hc = torch.from_numpy(h).to(dev)[:, None, None]
+    dW = torch.randn(grid.N, B, H, generator=gen, device=dev, dtype=torch.float64) * hc.sqrt() * 0.5
+    dU = hc * (0.5 * dW + (hc / 12).sqrt() * torch.randn(grid.N, B, H, generator=gen, device=dev, dtype=torch.float64) * 0.5) if method == 'srk' else None
+    wsum = torch.randn(L, B, H, generator=gen, device=dev, dtype=torch.float64)
+    f64 = TutorialField(kind, C, H, 1, 'lipswish').double().to(dev)
+    f64.load_state_dict({k: v.double() for k, v in field.state_dict().items()})
+    f64.set_X(coeffs.double().to(dev), times.to(dev))
+    y64 = y0.double().to(dev).requires_grad_(True)
+    want = S.sdeint(f64, y64, times.to(dev), bm=Replay(dW, dU), dt=dt, method=method, options={'backend': 'torch'})
+    (want * wsum).sum().backward()
+    field = field.to(dev)
+    field.set_X(coeffs.to(dev), times.float().to(dev))
+    yg = y0.to(dev).requires_grad_(True)
+    generic = S.torchsde._sdeint_torch
+    S.torchsde._sdeint_torch = lambda *a, **k: (_ for _ in ()).throw(AssertionError('fell back to the tensor-op loop'))
+    try:
+        got = S.sdeint(field, yg, times.float().to(dev), bm=Replay(dW.float(), None if dU is None else dU.float()), dt=dt, method=method)
+        (got * wsum.float()).sum().backward()
+    finally:
+        S.torchsde._sdeint_torch = generic
+    assert float((got.detach().double() - want.detach()).abs().max()) <= 2e-4 * max(float(want.detach().abs().max()), 1.0)
+
+    def close(g, ref, name):
+        scale = float(ref.abs().max()) + 1e-12
+        err = float((g.double() - ref).abs().max()) / scale
+        assert err < 2e-3, (name, err, scale)
+    close(yg.grad, y64.grad, 'y0')
+    ref = dict(f64.named_parameters())
+    for name, p in field.named_parameters():
+        gr = ref[name].grad
+        if gr is None or float(gr.abs().max()) == 0.0:
+            continue
+        assert p.grad is not None, name
+        close(p.grad, gr, name)

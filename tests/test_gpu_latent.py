@@ -145,3 +145,24 @@ def test_latent_sde_forward_of_the_wrapper_matches_the_tensor_loop_on_the_same_s
     assert float((latent - latent2).abs().max()) <= 2e-4 * max(float(latent2.abs().max()), 1.0)
     assert float((out - out2).abs().max()) <= 2e-4 * max(float(out2.abs().max()), 1.0)
     assert abs(float(kl) - float(kl2)) <= 2e-4 * max(abs(float(kl2)), 1.0)
+
+
+def test_latent_sde_at_the_bench_size_matches_the_tensor_loop():
+    """bench.py's `latent_sde_srk` leg (1024 rows, 31 latent channels + accumulator, 50 output times, srk): the split solve against the
+    tensor-op loop on the same generator stream - latent path, readout and KL."""
+    dev = torch.device('cuda')
+    torch.manual_seed(1)
+    rows, hidden, L = 1024, 32, 50
+    m = LatentField(4, hidden, hidden, 2).to(dev)
+    times = torch.linspace(0, 1, L, device=dev)
+    X = torch.cumsum(0.2 * torch.randn(rows, L, 4, device=dev), dim=1)
+    coeffs = S.torchcde.hermite_cubic_coefficients_with_backward_differences(X, times)
+    with torch.no_grad():
+        with no_tensor_loop():
+            out, latent, kl = m(coeffs, times, method='srk', options={'seed': 3})
+        out2, latent2, kl2 = m(coeffs, times, method='srk', options={'seed': 3, 'backend': 'torch'})
+    scale = max(float(latent2.abs().max()), 1.0)
+    assert float((latent - latent2).abs().max()) <= 2e-4 * scale
+    assert float((latent - latent2).abs().mean()) <= 1e-5 * scale
+    assert float((out - out2).abs().max()) <= 2e-4 * max(float(out2.abs().max()), 1.0)
+    assert abs(float(kl) - float(kl2)) <= 2e-4 * max(abs(float(kl2)), 1.0)
