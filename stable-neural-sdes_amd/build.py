@@ -51,7 +51,7 @@ def check_lean_resources(src, remarks):
                            f'csrc/snsde_mfma_kernels.h): {bad}')
 
 
-def build(force=False, verbose=False, defines=(), out=None):
+def build(force=False, verbose=False, defines=(), out=None, check_resources=True):
     """Compile every csrc/*.hip to an object file (in parallel: the MFMA kernels are split by hidden size) and
     link libsnsde.so."""
     from concurrent.futures import ThreadPoolExecutor
@@ -75,7 +75,7 @@ def build(force=False, verbose=False, defines=(), out=None):
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError('hipcc failed for ' + src + ':\n' + r.stdout + r.stderr)
-        if lean:
+        if lean and check_resources:
             check_lean_resources(src, r.stderr)
         return obj
 
@@ -93,5 +93,10 @@ if __name__ == '__main__':
     import sys
     if len(sys.argv) > 1 and sys.argv[1] == 'trace':
         print(build(force=True, defines=('-DSNSDE_TRACE',), out=os.path.join(HERE, 'libsnsde_trace.so')))
+    elif len(sys.argv) > 1 and sys.argv[1] == 'leantrace':
+        # cycle timeline of the lean kernel (tools/lean_trace.py): headline configurations only; the training-mode variant of the
+        # trace build spills two registers and is not used by the tool, hence no resource check
+        print(build(force=True, defines=('-DLEAN_TRACE', '-DSNSDE_DEV_SUBSET'), out=os.path.join(HERE, 'libsnsde_leantrace.so'),
+                    check_resources=False))
     else:
         print(build(force=True, verbose=True))

@@ -219,17 +219,31 @@ __device__ __forceinline__ void lean_gemm(const float (&w)[KU * 4], LeanB<KU>& b
     lean_gemm_from<Y, KU, 0>(w, b, c, d);
 }
 
-// Cycle timeline (development builds, -DLEAN_TRACE): s_memtime stamps at LT(i) are left in flight (no s_waitcnt) and only
-// collected after the step's closing barrier, so they do not drain the LDS queue the way TRACE() does.
+// Cycle timeline (development builds, -DLEAN_TRACE): s_memtime stamps at LT(i) are left in flight (no s_waitcnt) and collected
+// in three groups behind the step's barriers (whose own s_waitcnt lgkmcnt(0) has already drained the queue there), so they do
+// not drain the LDS queue the way TRACE() does.  The kernel has no registers to spare (251 of 256 VGPRs, SGPRs at the limit, and
+// loop-carried scalars of this loop are VGPRs to hipcc), so nothing is carried: each collected stamp's low word is added into a
+// per-lane LDS slot with a fire-and-forget ds_add_u32 (conflict-free, 12 x NT words behind the kernel's own LDS); phase i =
+// sum_i - sum_{i-1} (mod 2^32); the wrap-around phase 9 -> 0 from the sums of stamp 0 over steps >= 1 and stamp 9 over steps
+// <= N - 2 (slots 10 / 11).  Cost: 2 instructions per stamp and step (the traced kernel runs ~15 % slower than the plain one).
 #ifdef LEAN_TRACE
-#define LT_DECL unsigned long long lt[10]; float lt_acc[10] = {0,0,0,0,0,0,0,0,0,0}; unsigned long long lt_prev = 0;
+#define LT_DECL unsigned long long lt[10]; uint32_t* const ltl = reinterpret_cast<uint32_t*>(lds + CF::LDS_FLOATS) + tid; \
+    for (int i_ = 0; i_ < 12; ++i_) ltl[i_ * NT] = 0u;
 #define LT(i) asm volatile("s_memtime %0" : "=s"(lt[i]));
-#define LT_COLLECT { asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(lt[0]), "+s"(lt[1]), "+s"(lt[2]), "+s"(lt[3]), "+s"(lt[4]), "+s"(lt[5]), "+s"(lt[6]), "+s"(lt[7]), "+s"(lt[8]), "+s"(lt[9])); \
-    if (lt_prev) lt_acc[0] += (float)(uint32_t)(lt[0] - lt_prev); _Pragma("unroll") for (int i_ = 1; i_ < 10; ++i_) lt_acc[i_] += (float)(uint32_t)(lt[i_] - lt[i_ - 1]); lt_prev = lt[9]; }
+#define LT_ADD(slot, i) __hip_atomic_fetch_add(ltl + (slot) * NT, (uint32_t)lt[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+#define LT_COLLECT_A { asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(lt[0]), "+s"(lt[1]), "+s"(lt[2]), "+s"(lt[3])); \
+    LT_ADD(0, 0) LT_ADD(1, 1) LT_ADD(2, 2) LT_ADD(3, 3) if (n > 0) LT_ADD(10, 0) }
+#define LT_COLLECT_B { asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(lt[4]), "+s"(lt[5]), "+s"(lt[6])); LT_ADD(4, 4) LT_ADD(5, 5) LT_ADD(6, 6) }
+#define LT_COLLECT { asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(lt[7]), "+s"(lt[8]), "+s"(lt[9])); LT_ADD(7, 7) LT_ADD(8, 8) LT_ADD(9, 9) \
+    if (n + 1 < N) LT_ADD(11, 9) }
+#define LT_LDS_EXTRA (12 * CF::NT * sizeof(uint32_t))
 #else
 #define LT_DECL
 #define LT(i)
+#define LT_COLLECT_A
+#define LT_COLLECT_B
 #define LT_COLLECT
+#define LT_LDS_EXTRA 0
 #endif
 
 #ifndef LEAN_TANH_F
@@ -466,6 +480,16 @@ __global__ void __launch_bounds__(CF::NT, CF::WPS) snsde_m4_kernel(MfmaArgs a) {
             __syncthreads();
         }
         const bool more = n + 1 < N;
+        // training-mode stores: per-step bases as SCALAR values (readfirstlane makes the step number an SGPR to hipcc, uoff's
+        // 32 x 32 -> 64-bit products then run on the scalar unit).  Formed from the loop counter directly, every store paid two
+        // quarter-rate v_mul_lo_u32, a v_mad_u64_u32 and four more VALU instructions for its address (~40 VALU instructions per
+        // wave-step for five stores, on the issue port the MFMAs share).
+        [[maybe_unused]] float* act_n = nullptr;
+        [[maybe_unused]] uint32_t nu = 0;
+        if constexpr (SAVE) {
+            nu = (uint32_t)__builtin_amdgcn_readfirstlane(n);
+            act_n = a.act_save + uoff((int)nu, (uint32_t)CF::NSAVE * (uint32_t)BH);
+        }
         LT(0)
         // ---- top: the first layer's B operands, then the table quads of the coming steps (asm: the compiler never waits
         //      on them; they have landed once the first layer's last s_waitcnt has passed) ------------------------------------
@@ -492,13 +516,14 @@ __global__ void __launch_bounds__(CF::NT, CF::WPS) snsde_m4_kernel(MfmaArgs a) {
             *aown = o;
             if constexpr (SAVE) {
                 if (a.act_save && row_ok) {
-                    lean_gstore(o, goff4, a.act_save + ((size_t)n * CF::NSAVE) * BH);
-                    if constexpr (CF::SWISH) lean_gstore(pre, goff4, a.act_save + ((size_t)n * CF::NSAVE + CF::PRE0) * BH);
+                    lean_gstore(o, goff4, act_n);
+                    if constexpr (CF::SWISH) lean_gstore(pre, goff4, act_n + uoff(0, 0, CF::PRE0, (uint32_t)BH));
                 }
             }
         }
         LT(3)
         __syncthreads();
+        LT_COLLECT_A
         LT(4)
         // ---- hidden layers; the next step's increment and diffusion-table entry are produced in the first window -------------
         float dw_nxt = 0.0f, gt_nxt = 0.0f;
@@ -526,13 +551,13 @@ __global__ void __launch_bounds__(CF::NT, CF::WPS) snsde_m4_kernel(MfmaArgs a) {
             *(toB ? bown : aown) = o;
             if constexpr (SAVE) {
                 if (a.act_save && row_ok) {
-                    lean_gstore(o, goff4, a.act_save + ((size_t)n * CF::NSAVE + 1 + l) * BH);
-                    if constexpr (CF::SWISH) lean_gstore(pre, goff4, a.act_save + ((size_t)n * CF::NSAVE + CF::PRE0 + 1 + l) * BH);
+                    lean_gstore(o, goff4, act_n + uoff(0, 0, 1 + l, (uint32_t)BH));
+                    if constexpr (CF::SWISH) lean_gstore(pre, goff4, act_n + uoff(0, 0, CF::PRE0 + 1 + l, (uint32_t)BH));
                 }
             }
             if (l == NHID - 1) { LT(6) }
             __syncthreads();
-            if (l == NHID - 1) { LT(7) }
+            if (l == NHID - 1) { LT_COLLECT_B LT(7) }
             cur = toB ? brow : arow;
         }
         // ---- output layer, f, update -------------------------------------------------------------------------------
@@ -548,7 +573,7 @@ __global__ void __launch_bounds__(CF::NT, CF::WPS) snsde_m4_kernel(MfmaArgs a) {
         LT(8)
         vm_wait(dw_nxt, gt_nxt);      // this step's prefetches (issued one to three phases ago)
         float z = m4_reduce_scatter(c + d);
-        if constexpr (SAVE) { if (a.act_save && row_ok) lean_gstore(z, goff4, a.act_save + ((size_t)n * CF::NSAVE + CF::ZSLOT) * BH); }
+        if constexpr (SAVE) { if (a.act_save && row_ok) lean_gstore(z, goff4, act_n + uoff(0, 0, CF::ZSLOT, (uint32_t)BH)); }
         if (__builtin_expect(geo, 0)) z *= fast_tanh(yv);
         float f;
         if (__builtin_expect(f_out != SNSDE_DRIFT_TANH, 0)) f = f_out == SNSDE_DRIFT_TIMES_Y ? z * yv : z;
@@ -559,8 +584,8 @@ __global__ void __launch_bounds__(CF::NT, CF::WPS) snsde_m4_kernel(MfmaArgs a) {
         ybuf[r * LDY + fo] = ynew;
         if constexpr (SAVE) {
             if (row_ok) {
-                if (a.traj) lean_gstore(ynew, goff4, a.traj + (size_t)(n + 1) * BH);
-                if (a.dW_out) lean_gstore(dw_cur, goff4, a.dW_out + (size_t)n * BH);
+                if (a.traj) lean_gstore(ynew, goff4, a.traj + uoff((int)nu + 1, (uint32_t)BH));
+                if (a.dW_out) lean_gstore(dw_cur, goff4, a.dW_out + uoff((int)nu, (uint32_t)BH));
             }
         }
         dw_cur = dw_nxt; gt_cur = gt_nxt;
@@ -581,15 +606,18 @@ __global__ void __launch_bounds__(CF::NT, CF::WPS) snsde_m4_kernel(MfmaArgs a) {
     }
     }
 #ifdef LEAN_TRACE
-    if (blockIdx.x == 0 && lane == 0 && a.dW_out) {
-        for (int i = 0; i < 10; ++i) a.dW_out[wave * 16 + i] = lt_acc[i];
+    __syncthreads();       // the timeline goes out through row 0 of the last output plane (trace builds only: that row is garbage then)
+    if (blockIdx.x == 0 && lane == 0) {
+        float* o = a.ys + (a.row_out ? 0 : (size_t)(a.T - 1) * BH);
+        o[wave * 16] = (float)(uint32_t)(ltl[10 * NT] - ltl[11 * NT]);
+        for (int i = 1; i < 10; ++i) o[wave * 16 + i] = (float)(uint32_t)(ltl[i * NT] - ltl[(i - 1) * NT]);
     }
 #endif
 }
 
 template <class CF>
 int launch_lean(const MfmaArgs& a, hipStream_t stream) {
-    const size_t lds_bytes = (size_t)CF::LDS_FLOATS * sizeof(float);
+    const size_t lds_bytes = (size_t)CF::LDS_FLOATS * sizeof(float) + LT_LDS_EXTRA;
     static bool attr_set = false;   // per instantiation
     if (lds_bytes > 64 * 1024 && !attr_set) {
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(snsde_m4_kernel<CF>),
@@ -625,7 +653,8 @@ int dispatch_lean(const MfmaPlan& p, const MfmaArgs& a, hipStream_t st) {
 #ifdef SNSDE_DEV_SUBSET
     if (p.NHID == 1 && p.KUXT == 2 && p.IO != 0)
         return save ? launch_lean<CfgL<H, 1, 2, 1, 1>>(a, st) : launch_lean<CfgL<H, 1, 2, 1, 0>>(a, st);
-    if (p.NHID == 1 && p.KUXT == 1 && p.IO != 0) return launch_lean<CfgL<H, 1, 1, 1, 1>>(a, st);
+    if (p.NHID == 1 && p.KUXT == 1 && p.IO != 0)
+        return save ? launch_lean<CfgL<H, 1, 1, 1, 1>>(a, st) : launch_lean<CfgL<H, 1, 1, 1, 0>>(a, st);
     return SNSDE_ERR_UNSUPPORTED;
 #else
 #define SNSDE_LEAN(NH_, KX_, Y_) \
