@@ -30,7 +30,14 @@
 extern "C" {
 #endif
 
-#define SNSDE_VERSION 1
+/* ABI version.  2 (round 4): every descriptor struct starts with `struct_size` = sizeof(the struct) as the CALLER compiled it;
+ * the library compares it with its own sizeof and refuses a mismatch with SNSDE_ERR_ABI, so a binding built against an older
+ * header (the structs grew fields in rounds 2 - 3 while the version stayed 1) fails loudly instead of being read past its end.
+ * snsde_abi_check() lets a binding verify all of its struct sizes once, at load time.                                        */
+#define SNSDE_VERSION 2
+
+/* exported entry points: the library is built with -fvisibility=hidden, only these names are in its dynamic symbol table */
+#define SNSDE_API __attribute__((visibility("default")))
 
 enum {
     SNSDE_OK = 0,
@@ -42,7 +49,8 @@ enum {
     SNSDE_ERR_LDS = -6,          /* configuration exceeds the 160 KiB LDS budget of a CU        */
     SNSDE_ERR_TS = -7,           /* ts not strictly increasing / dt <= 0 / no fp32 progress     */
     SNSDE_ERR_LAUNCH = -8,       /* hipLaunchKernel reported an error                           */
-    SNSDE_ERR_INDEX = -9         /* index out of range                                          */
+    SNSDE_ERR_INDEX = -9,        /* index out of range                                          */
+    SNSDE_ERR_ABI = -10          /* struct_size / version of the caller's binding differs from the library's */
 };
 
 enum { SNSDE_EULER = 0, SNSDE_MILSTEIN = 1, SNSDE_SRK = 2 /* SRID2, strong order 1.5, diagonal noise */ };
@@ -100,9 +108,9 @@ typedef struct snsde_model {
  *   linear_in.{weight (HH, H or H+2),bias} | emb.{weight (H,2H),bias} | linears.i.{weight,bias} |
  *   linear_out.{weight (H,HH),bias} | noise_t[.0/.2].* | noise_y[.0/.2].*
  * (neuralsde.py:142-179).  These functions describe that layout so a host can fill it. */
-int     snsde_param_count(const snsde_model* m);                 /* number of tensors, or <0 */
-int64_t snsde_param_numel(const snsde_model* m);                 /* total floats, or <0      */
-int     snsde_param_info(const snsde_model* m, int index, char* name, int name_cap,
+SNSDE_API int     snsde_param_count(const snsde_model* m);                 /* number of tensors, or <0 */
+SNSDE_API int64_t snsde_param_numel(const snsde_model* m);                 /* total floats, or <0      */
+SNSDE_API int     snsde_param_info(const snsde_model* m, int index, char* name, int name_cap,
                          int64_t* offset, int32_t* rows, int32_t* cols);
 
 /* ---- fixed-step time grid (host, CPU) --------------------------------------------------------
@@ -117,20 +125,21 @@ int     snsde_param_info(const snsde_model* m, int index, char* name, int name_c
  * out_step[k] = index of the solver step after which output k+1 is emitted; out_w[2k], out_w[2k+1] =
  * linear_interp weights (t1-t)/(t1-t0), (t-t0)/(t1-t0).                                          */
 #define SNSDE_STEP_STRIDE 12
-int snsde_grid_count(const float* ts, int32_t n_out, double dt, int32_t* n_steps);
-int snsde_grid_build(const float* ts, int32_t n_out, double dt, const float* times, int32_t knots,
+SNSDE_API int snsde_grid_count(const float* ts, int32_t n_out, double dt, int32_t* n_steps);
+SNSDE_API int snsde_grid_build(const float* ts, int32_t n_out, double dt, const float* times, int32_t knots,
                      int32_t n_steps, float* step_tab, int32_t* out_step, float* out_w);
 /* Stage times of the SRK scheme: per solver step the four evaluation times t0 + c*h, c = 0, 1/4, 1/2, 1
  * (float32 arithmetic as torchsde's `t0 + c * dt`), each as SNSDE_SRK_STRIDE floats:
  * t, sin t, cos t, frac, idx (int32 bits), 0, 0, 0.   srk_tab is (n_steps, 4, SNSDE_SRK_STRIDE). */
 #define SNSDE_SRK_STRIDE 8
-int snsde_grid_srk_build(const float* step_tab, int32_t n_steps, const float* times, int32_t knots, float* srk_tab);
+SNSDE_API int snsde_grid_srk_build(const float* step_tab, int32_t n_steps, const float* times, int32_t knots, float* srk_tab);
 
 /* ---- the solve --------------------------------------------------------------------------------
  * Replaces torchsde.sdeint(sde=Diffusion_model, y0, ts, dt, method) (neuralsde.py:78-82):
  * every solver step fuses X(t) (A10), f (A7), g (A8), the Brownian increment (A5) and the
  * Euler / Milstein update (A4/A6) for a tile of batch rows; rows are independent.            */
 typedef struct snsde_solve {
+    uint32_t struct_size;  /* = sizeof(snsde_solve) of the caller's header (SNSDE_ERR_ABI otherwise)              */
     snsde_model model;
     int32_t  batch;        /* B: rows on this device                                             */
     int32_t  knots;        /* L: len(times); coeffs has L-1 intervals                            */
@@ -179,8 +188,8 @@ typedef struct snsde_solve {
     size_t         workspace_bytes;
 } snsde_solve;
 
-size_t snsde_workspace_bytes(const snsde_solve* s);
-int    snsde_solve_forward(const snsde_solve* s, void* hip_stream);
+SNSDE_API size_t snsde_workspace_bytes(const snsde_solve* s);
+SNSDE_API int    snsde_solve_forward(const snsde_solve* s, void* hip_stream);
 
 /* ---- backward of the solve (discretise-then-optimise adjoint of the fixed-step scheme) ------
  * Replaces autograd THROUGH the unrolled solver loop (`loss.backward()` in
@@ -188,9 +197,10 @@ int    snsde_solve_forward(const snsde_solve* s, void* hip_stream);
  * recursion of the scheme (Euler: a_n = a_{n+1} + h (df/dy)^T a_{n+1} + (dg/dy)^T (a_{n+1} * dW_n); Milstein and SRID2: the
  * reverse of their step formulas) backwards over the saved trajectory and writes EVERY a_n (adj[0] = dL/dy0).
  * snsde_backward_supported:
- *   1 = MFMA adjoint kernels: forward on the MFMA path with traj, dW_out (+ dU_out, stage_save for SRK) and act_save;
- *       Euler, Milstein and SRK for the elementwise diffusions, Euler and SRK for the diffusion nets (noise_option
- *       14/15/18/19); fills delta_save, and snsde_param_gradients then forms every parameter gradient ON THE DEVICE
+ *   1 = MFMA adjoint kernels: forward on the MFMA path with traj (+ dW_out unless the increments are supplied or Philox ones
+ *       can be regenerated; + dU_out, stage_save for SRK) and act_save; Euler, Milstein and SRK, for the elementwise diffusions
+ *       AND through the diffusion nets (noise_option 14/15/18/19; Milstein through a two-layer net at H = 128 and the nets at
+ *       H = 256 excepted: mode 2); fills delta_save, and snsde_param_gradients then forms every parameter gradient ON THE DEVICE
  *       (split-R MFMA weight-gradient GEMMs over the saved activations / deltas, diffusion-side reductions, the folded
  *       first layer's algebra) in the flat layout of `params`;
  *   2 = generic adjoint kernels (forward on any kernel; traj + dW_out (+ dU_out for SRK) only; Euler, Milstein and SRK, any
@@ -198,6 +208,7 @@ int    snsde_solve_forward(const snsde_solve* s, void* hip_stream);
  *       host layer takes the parameter gradients from one batched evaluation of the step function;
  *   0 = none. */
 typedef struct snsde_backward {
+    uint32_t     struct_size;/* = sizeof(snsde_backward)                                                            */
     snsde_solve  fwd;        /* the forward descriptor (traj, dW_out, act_save filled by the forward)      */
     const float* grad_ys;    /* device (T, B, H): dL/d ys                                                 */
     float*       adj;        /* device (N+1, B, H) out: adjoint of every solver state                     */
@@ -215,11 +226,11 @@ typedef struct snsde_backward {
 } snsde_backward;
 enum { SNSDE_BWD_ADJ0_ONLY = 1 };
 
-int    snsde_act_slots(const snsde_model* m);             /* activation tensors saved per step, or <0: layer outputs (first, hidden.., */
+SNSDE_API int    snsde_act_slots(const snsde_model* m);             /* activation tensors saved per step, or <0: layer outputs (first, hidden.., */
                                                           /* pre-tanh drift) [+ diffusion-net slots]; models with a smooth activation  */
                                                           /* (SNSDE_ACT_LIPSWISH / SILU) also save every pre-activation (NL more slots,  */
                                                           /* + the hidden pre-activation of a two-layer diffusion net, the last slot)   */
-int    snsde_save_layout(const snsde_solve* s, int32_t* act_slots, int32_t* stage_planes, int32_t* delta_slots);
+SNSDE_API int    snsde_save_layout(const snsde_solve* s, int32_t* act_slots, int32_t* stage_planes, int32_t* delta_slots);
                                                           /* training-mode buffers of THIS solve (model + method): act_save /     */
                                                           /* delta_save are (passes, act_slots, B, H), stage_save (passes + 1,     */
                                                           /* stage_planes, B, H); passes = N (3N for SRK).  SRK through a          */
@@ -228,9 +239,9 @@ int    snsde_save_layout(const snsde_solve* s, int32_t* act_slots, int32_t* stag
                                                           /* (drift input H0 | diffusion input H1 | H1 of the fourth evaluation);  */
                                                           /* delta_save is (passes, delta_slots, B, H): act_slots, plus the tangent */
                                                           /* factors of Milstein through a diffusion net                            */
-int    snsde_backward_supported(const snsde_solve* s);    /* 1 / 2 / 0, see above                          */
-size_t snsde_backward_workspace_bytes(const snsde_backward* b);
-int    snsde_solve_backward(const snsde_backward* b, void* hip_stream);
+SNSDE_API int    snsde_backward_supported(const snsde_solve* s);    /* 1 / 2 / 0, see above                          */
+SNSDE_API size_t snsde_backward_workspace_bytes(const snsde_backward* b);
+SNSDE_API int    snsde_solve_backward(const snsde_backward* b, void* hip_stream);
 
 /* Parameter gradients of the fused solve (mode 1 = MFMA path only): after snsde_solve_forward (traj, dW_out, act_save
  * kept; fwd.workspace untouched since) and snsde_solve_backward (adj, delta_save; b->workspace still the buffer that
@@ -239,32 +250,32 @@ int    snsde_solve_backward(const snsde_backward* b, void* hip_stream);
  * accumulates through the unrolled loop (benchmark_classification/common_sde.py:158-160): split-R MFMA GEMMs
  * sum_r delta^T . input with per-workgroup partials and one deterministic reduction, the elementwise diffusion
  * reductions (theta, the time-only noise MLP; Euler and Milstein) and the first-layer/emb algebra. */
-size_t snsde_param_gradients_workspace_bytes(const snsde_backward* b);
-int    snsde_param_gradients(const snsde_backward* b, float* grad_params, void* workspace, size_t workspace_bytes,
+SNSDE_API size_t snsde_param_gradients_workspace_bytes(const snsde_backward* b);
+SNSDE_API int    snsde_param_gradients(const snsde_backward* b, float* grad_params, void* workspace, size_t workspace_bytes,
                              void* hip_stream);
 
 /* ---- cubic spline evaluation (A10) -----------------------------------------------------------
  * out[b, c] = a + (b + (0.5*two_c + three_d*frac/3)*frac)*frac   on interval `index`
  * (derivative != 0: b + (two_c + three_d*frac)*frac), operation order as
  * controldiffeq/interpolate.py:270-283 (bit-exact with the CPU reference).                      */
-int snsde_spline_evaluate(const float* coeffs, int32_t batch, int32_t knots, int32_t channels,
+SNSDE_API int snsde_spline_evaluate(const float* coeffs, int32_t batch, int32_t knots, int32_t channels,
                           int32_t index, float frac, int32_t derivative, float* out, void* hip_stream);
 
 /* ---- spline coefficient construction (A11 / A12; offline preprocessing in the reference) ------------
  * natural: controldiffeq.natural_cubic_spline_coeffs (interpolate.py:161-228) incl. its missing-value handling;
  * hermite: torchcde.hermite_cubic_coefficients_with_backward_differences (datasets/common.py:82-84).
  * times (L) and X (B, L, C) device float32, NaN = missing; coeffs (B, L-1, 4C) = cat[a, b, two_c, three_d] out. */
-size_t snsde_spline_workspace_bytes(int32_t batch, int32_t knots, int32_t channels);
-int snsde_natural_cubic_coeffs(const float* times, const float* X, int32_t batch, int32_t knots, int32_t channels,
+SNSDE_API size_t snsde_spline_workspace_bytes(int32_t batch, int32_t knots, int32_t channels);
+SNSDE_API int snsde_natural_cubic_coeffs(const float* times, const float* X, int32_t batch, int32_t knots, int32_t channels,
                                float* coeffs, void* workspace, size_t workspace_bytes, void* hip_stream);
-int snsde_hermite_coeffs(const float* times, const float* X, int32_t batch, int32_t knots, int32_t channels,
+SNSDE_API int snsde_hermite_coeffs(const float* times, const float* X, int32_t batch, int32_t knots, int32_t channels,
                          float* coeffs, void* hip_stream);
 
 /* vector-field probe: one evaluation of f(t,y) and g(t,y) (neuralsde.py:295-307) through the same
  * device code the solver uses.  `step_row` = one step_tab row (device, SNSDE_STEP_STRIDE floats)
  * describing t; y, f_out, g_out are device (B, H).  Uses s->model/batch/knots/params/coeffs/
  * workspace only.                                                                             */
-int snsde_eval_fg(const snsde_solve* s, const float* step_row, const float* y, float* f_out,
+SNSDE_API int snsde_eval_fg(const snsde_solve* s, const float* step_row, const float* y, float* f_out,
                   float* g_out, void* hip_stream);
 
 /* Kernel family a forward solve of this descriptor runs on (host-side query, no device access): the coverage table in
@@ -277,7 +288,7 @@ enum { SNSDE_PATH_NONE = 0,          /* no kernel: snsde_solve_forward returns S
        SNSDE_PATH_LEAN_STREAMED = 5, /* MFMA, 4-row tiles, lean kernel with L2 -> LDS streamed weights (H = 256)     */
        SNSDE_PATH_GENERIC_SRK = 6,   /* SRK on the generic family                                                   */
        SNSDE_PATH_MFMA_SRK = 7 };    /* SRK on the MFMA 4-row tiles                                                 */
-int snsde_forward_path(const snsde_solve* s);
+SNSDE_API int snsde_forward_path(const snsde_solve* s);
 
 /* Readout head of the wrappers in one launch (inference; replaces the 4-5 tensor ops of `self.linear(z)`,
  * benchmark_classification/models_sde/neuralsde.py:59-61,119; benchmark_forecasting/models_sde/neuralsde.py:186; torch_ists
@@ -285,6 +296,7 @@ int snsde_forward_path(const snsde_solve* s);
  * BatchNorm1d inference transform (v - mean) / sqrt(var + eps) * weight + bias when bn_mean is set.  All pointers device,
  * fp32, row-major contiguous; nn.Linear layout (out_features, in_features).                                              */
 typedef struct snsde_head {
+    uint32_t struct_size;    /* = sizeof(snsde_head)                                  */
     int32_t rows, in_features, hidden, out_features;
     int32_t input_tanh;
     float   bn_eps;
@@ -299,10 +311,13 @@ typedef struct snsde_head {
     const float* b2;         /* (out_features) or NULL                                */
     float*       out;        /* (rows, out_features)                                  */
 } snsde_head;
-int snsde_readout_head(const snsde_head* h, void* hip_stream);
+SNSDE_API int snsde_readout_head(const snsde_head* h, void* hip_stream);
 
-int         snsde_version(void);
-const char* snsde_strerror(int code);
+SNSDE_API int         snsde_version(void);
+/* SNSDE_OK when `version` == SNSDE_VERSION and the four sizes equal the library's sizeof(snsde_model / snsde_solve /
+ * snsde_backward / snsde_head); SNSDE_ERR_ABI otherwise.  A binding calls it once after loading the library.            */
+SNSDE_API int         snsde_abi_check(int version, size_t sizeof_model, size_t sizeof_solve, size_t sizeof_backward, size_t sizeof_head);
+SNSDE_API const char* snsde_strerror(int code);
 
 #ifdef __cplusplus
 }

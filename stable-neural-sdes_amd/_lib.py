@@ -27,8 +27,17 @@ class Model(C.Structure):
                 ('drift_output', C.c_int32), ('diffusion_output', C.c_int32), ('time_feature', C.c_int32)]
 
 
-class Solve(C.Structure):
-    _fields_ = [('model', Model), ('batch', C.c_int32), ('knots', C.c_int32), ('n_steps', C.c_int32),
+class _Sized(C.Structure):
+    """Descriptor structs start with struct_size = sizeof(the struct as THIS binding declares it): the library compares it with
+    its own sizeof and returns SNSDE_ERR_ABI (-10) for a stale binding instead of reading past the struct."""
+
+    def __init__(self, *args, **kw):
+        super().__init__(*args, **kw)
+        self.struct_size = C.sizeof(type(self))
+
+
+class Solve(_Sized):
+    _fields_ = [('struct_size', C.c_uint32), ('model', Model), ('batch', C.c_int32), ('knots', C.c_int32), ('n_steps', C.c_int32),
                 ('n_out', C.c_int32), ('method', C.c_int32), ('kernel', C.c_int32), ('flags', C.c_int32),
                 ('reserved', C.c_int32),
                 ('row_offset', C.c_int64), ('seed', C.c_uint64),
@@ -40,14 +49,14 @@ class Solve(C.Structure):
                 ('workspace', C.c_void_p), ('workspace_bytes', C.c_size_t)]
 
 
-class Backward(C.Structure):
-    _fields_ = [('fwd', Solve), ('grad_ys', C.c_void_p), ('adj', C.c_void_p), ('delta_save', C.c_void_p),
+class Backward(_Sized):
+    _fields_ = [('struct_size', C.c_uint32), ('fwd', Solve), ('grad_ys', C.c_void_p), ('adj', C.c_void_p), ('delta_save', C.c_void_p),
                 ('workspace', C.c_void_p),
                 ('workspace_bytes', C.c_size_t), ('grad_noise_table', C.c_void_p), ('flags', C.c_int32), ('reserved', C.c_int32)]
 
 
-class Head(C.Structure):
-    _fields_ = [('rows', C.c_int32), ('in_features', C.c_int32), ('hidden', C.c_int32), ('out_features', C.c_int32),
+class Head(_Sized):
+    _fields_ = [('struct_size', C.c_uint32), ('rows', C.c_int32), ('in_features', C.c_int32), ('hidden', C.c_int32), ('out_features', C.c_int32),
                 ('input_tanh', C.c_int32), ('bn_eps', C.c_float),
                 ('x', C.c_void_p), ('w1', C.c_void_p), ('b1', C.c_void_p), ('bn_mean', C.c_void_p), ('bn_var', C.c_void_p),
                 ('bn_weight', C.c_void_p), ('bn_bias', C.c_void_p), ('w2', C.c_void_p), ('b2', C.c_void_p), ('out', C.c_void_p)]
@@ -62,7 +71,8 @@ class SnsdeError(RuntimeError):
 
 _lib = None
 
-EXPORTS = ('snsde_version', 'snsde_strerror', 'snsde_param_count', 'snsde_param_numel', 'snsde_param_info',
+ABI_VERSION = 2
+EXPORTS = ('snsde_version', 'snsde_abi_check', 'snsde_strerror', 'snsde_param_count', 'snsde_param_numel', 'snsde_param_info',
            'snsde_grid_count', 'snsde_grid_build', 'snsde_grid_srk_build', 'snsde_workspace_bytes', 'snsde_solve_forward',
            'snsde_spline_evaluate', 'snsde_eval_fg', 'snsde_act_slots', 'snsde_backward_supported',
            'snsde_backward_workspace_bytes', 'snsde_solve_backward', 'snsde_spline_workspace_bytes',
@@ -114,6 +124,11 @@ def lib():
     L.snsde_backward_workspace_bytes.argtypes = [C.POINTER(Backward)]
     L.snsde_backward_workspace_bytes.restype = C.c_size_t
     L.snsde_solve_backward.argtypes = [C.POINTER(Backward), C.c_void_p]
+    L.snsde_abi_check.argtypes = [C.c_int, C.c_size_t, C.c_size_t, C.c_size_t, C.c_size_t]
+    rc = L.snsde_abi_check(ABI_VERSION, C.sizeof(Model), C.sizeof(Solve), C.sizeof(Backward), C.sizeof(Head))
+    if rc != 0:
+        raise RuntimeError(f'{LIB_PATH}: ABI mismatch (library version {L.snsde_version()}, binding version {ABI_VERSION}, code {rc}): '
+                           f'rebuild the library (__graft_entry__.build()) or update the binding to include/snsde.h')
     _lib = L
     return L
 

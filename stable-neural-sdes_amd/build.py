@@ -64,7 +64,8 @@ def build(force=False, verbose=False, defines=(), out=None, check_resources=True
     cc = hipcc()
     # --offload-compress: the device code objects (~24 of the library's 27 MB uncompressed) are stored zstd-compressed
     # and inflated by the HIP runtime when the library is loaded
-    base = [cc, '--offload-arch=gfx950', '--offload-compress', '-O3', '-std=c++17', '-fPIC', '-I', INCLUDE, '-I', CSRC] + list(defines)
+    # -fvisibility=hidden: only the SNSDE_API entry points of include/snsde.h are in the dynamic symbol table
+    base = [cc, '--offload-arch=gfx950', '--offload-compress', '-O3', '-std=c++17', '-fPIC', '-fvisibility=hidden', '-I', INCLUDE, '-I', CSRC] + list(defines)
 
     def compile_one(src):
         obj = os.path.join(objdir, os.path.basename(src)[:-4] + '.o')
@@ -81,7 +82,15 @@ def build(force=False, verbose=False, defines=(), out=None, check_resources=True
 
     with ThreadPoolExecutor(max_workers=min(8, len(srcs))) as ex:
         objs = list(ex.map(compile_one, srcs))
-    cmd = [cc, '--offload-arch=gfx950', '-shared', '-fPIC', '-o', out + '.tmp'] + objs
+    # dynamic symbol table = the SNSDE_API entry points declared in include/snsde.h, nothing else: -fvisibility=hidden covers the
+    # internal launchers / dispatchers, the version script also localises the weak kernel-handle objects hipcc emits for template
+    # kernels (they are only referenced from inside the library)
+    import re
+    names = sorted(set(re.findall(r'\b(snsde_[a-z_0-9]+)\s*\(', open(os.path.join(INCLUDE, 'snsde.h')).read())))
+    vs = os.path.join(objdir, 'exports.map')
+    with open(vs, 'w') as f:
+        f.write('{\n  global:\n' + ''.join(f'    {n};\n' for n in names) + '  local:\n    *;\n};\n')
+    cmd = [cc, '--offload-arch=gfx950', '-shared', '-fPIC', '-Wl,--version-script=' + vs, '-o', out + '.tmp'] + objs
     r = subprocess.run(cmd, capture_output=True, text=True)
     if r.returncode != 0:
         raise RuntimeError('link failed:\n' + r.stdout + r.stderr)

@@ -143,6 +143,11 @@ extern "C" {
 
 int snsde_version(void) { return SNSDE_VERSION; }
 
+int snsde_abi_check(int version, size_t sizeof_model, size_t sizeof_solve, size_t sizeof_backward, size_t sizeof_head) {
+    return (version == SNSDE_VERSION && sizeof_model == sizeof(snsde_model) && sizeof_solve == sizeof(snsde_solve) &&
+            sizeof_backward == sizeof(snsde_backward) && sizeof_head == sizeof(snsde_head)) ? SNSDE_OK : SNSDE_ERR_ABI;
+}
+
 const char* snsde_strerror(int code) {
     switch (code) {
         case SNSDE_OK: return "ok";
@@ -155,6 +160,7 @@ const char* snsde_strerror(int code) {
         case SNSDE_ERR_TS: return "ts must be strictly increasing, dt > 0 and representable progress in float32";
         case SNSDE_ERR_LAUNCH: return "HIP kernel launch failed";
         case SNSDE_ERR_INDEX: return "index out of range";
+        case SNSDE_ERR_ABI: return "struct_size / version mismatch: the binding was built against another include/snsde.h";
         default: return "unknown error";
     }
 }
@@ -306,6 +312,8 @@ static bool is_variant(const snsde_model& m) {
 
 static int validate_solve(const snsde_solve* s, bool eval) {
     if (!s) return SNSDE_ERR_NULL;
+    if (s->struct_size != sizeof(snsde_solve)) return SNSDE_ERR_ABI;      // stale binding: refuse before reading any field
+    if (!s) return SNSDE_ERR_NULL;
     int rc = validate_model(&s->model);
     if (rc) return rc;
     if (s->batch <= 0 || s->knots < 2) return SNSDE_ERR_DIMS;
@@ -327,7 +335,7 @@ static int validate_solve(const snsde_solve* s, bool eval) {
 }
 
 size_t snsde_workspace_bytes(const snsde_solve* s) {
-    if (!s) return 0;
+    if (!s || s->struct_size != sizeof(snsde_solve)) return 0;
     SnsdeNet net;
     if (snsde_build_net(s->model, s->n_steps, &net)) return 0;
     size_t f = 0;
@@ -378,7 +386,7 @@ int snsde_solve_forward(const snsde_solve* s, void* hip_stream) {
 // n_steps, method, kernel, flags, input dims; no device pointers).  SNSDE_PATH_NONE = no kernel covers the request
 // (snsde_solve_forward returns SNSDE_ERR_UNSUPPORTED and the host layer takes its tensor loop).
 int snsde_forward_path(const snsde_solve* s) {
-    if (!s || validate_model(&s->model) || s->batch <= 0 || s->knots < 2 || s->n_steps <= 0) return SNSDE_PATH_NONE;
+    if (!s || s->struct_size != sizeof(snsde_solve) || validate_model(&s->model) || s->batch <= 0 || s->knots < 2 || s->n_steps <= 0) return SNSDE_PATH_NONE;
     const int no = s->model.noise_option;
     if (s->method == SNSDE_MILSTEIN && no == 7) return SNSDE_PATH_NONE;
     SnsdeNet net;
@@ -433,6 +441,7 @@ int snsde_act_slots(const snsde_model* m) {
 
 int snsde_save_layout(const snsde_solve* s, int32_t* act_slots, int32_t* stage_planes, int32_t* delta_slots) {
     if (!s) return SNSDE_ERR_NULL;
+    if (s->struct_size != sizeof(snsde_solve)) return SNSDE_ERR_ABI;
     int slots = snsde_act_slots(&s->model);
     if (slots < 0) return slots;
     const int no = s->model.noise_option;
@@ -447,7 +456,7 @@ int snsde_save_layout(const snsde_solve* s, int32_t* act_slots, int32_t* stage_p
 }
 
 int snsde_backward_supported(const snsde_solve* s) {
-    if (!s || validate_model(&s->model)) return 0;
+    if (!s || s->struct_size != sizeof(snsde_solve) || validate_model(&s->model)) return 0;
     if (s->method == SNSDE_MILSTEIN && s->model.noise_option == 7) return 0;     // no forward kernel either (validate_solve)
     SnsdeNet net;
     if (snsde_build_net(s->model, s->n_steps, &net)) return 0;
@@ -460,7 +469,7 @@ int snsde_backward_supported(const snsde_solve* s) {
 }
 
 size_t snsde_backward_workspace_bytes(const snsde_backward* b) {
-    if (!b) return 0;
+    if (!b || b->struct_size != sizeof(snsde_backward) || b->fwd.struct_size != sizeof(snsde_solve)) return 0;
     SnsdeNet net;
     if (snsde_build_net(b->fwd.model, b->fwd.n_steps, &net)) return 0;
     size_t f = snsde_mfma_backward_workspace_floats(&b->fwd, net), g = 0;
@@ -470,6 +479,7 @@ size_t snsde_backward_workspace_bytes(const snsde_backward* b) {
 
 int snsde_solve_backward(const snsde_backward* b, void* hip_stream) {
     if (!b) return SNSDE_ERR_NULL;
+    if (b->struct_size != sizeof(snsde_backward)) return SNSDE_ERR_ABI;
     int rc = validate_solve(&b->fwd, false);
     if (rc) return rc;
     if (!b->grad_ys || !b->adj || !b->workspace || !b->fwd.traj) return SNSDE_ERR_NULL;
@@ -493,7 +503,7 @@ int snsde_solve_backward(const snsde_backward* b, void* hip_stream) {
 }
 
 size_t snsde_param_gradients_workspace_bytes(const snsde_backward* b) {
-    if (!b) return 0;
+    if (!b || b->struct_size != sizeof(snsde_backward) || b->fwd.struct_size != sizeof(snsde_solve)) return 0;
     SnsdeNet net;
     if (snsde_build_net(b->fwd.model, b->fwd.n_steps, &net)) return 0;
     if (snsde_backward_supported(&b->fwd) != 1) return 0;
@@ -503,6 +513,7 @@ size_t snsde_param_gradients_workspace_bytes(const snsde_backward* b) {
 int snsde_param_gradients(const snsde_backward* b, float* grad_params, void* workspace, size_t workspace_bytes,
                           void* hip_stream) {
     if (!b || !grad_params || !workspace) return SNSDE_ERR_NULL;
+    if (b->struct_size != sizeof(snsde_backward)) return SNSDE_ERR_ABI;
     int rc = validate_solve(&b->fwd, false);
     if (rc) return rc;
     if (!b->adj || !b->delta_save || !b->fwd.traj || !b->fwd.act_save || !b->fwd.workspace)

@@ -129,7 +129,9 @@ __global__ void __launch_bounds__(HT) snsde_head_kernel(snsde_head h) {
 }  // namespace
 
 extern "C" int snsde_readout_head(const snsde_head* h, void* hip_stream) {
-    if (!h || !h->x || !h->w1 || !h->w2 || !h->out) return SNSDE_ERR_NULL;
+    if (!h) return SNSDE_ERR_NULL;
+    if (h->struct_size != sizeof(snsde_head)) return SNSDE_ERR_ABI;
+    if (!h->x || !h->w1 || !h->w2 || !h->out) return SNSDE_ERR_NULL;
     if (h->rows <= 0 || h->in_features <= 0 || h->hidden <= 0 || h->out_features <= 0) return SNSDE_ERR_DIMS;
     if ((h->bn_mean != nullptr) != (h->bn_var != nullptr)) return SNSDE_ERR_NULL;
     if (h->hidden > 2 * HT) return SNSDE_ERR_DIMS;       // at most two output features per thread

@@ -243,4 +243,19 @@ __device__ __forceinline__ void snsde_time_table_row(const float* __restrict__ p
     }
 }
 
+// Dynamic LDS above 64 KiB must be enabled per kernel function AND per device (hipFuncSetAttribute acts on the current device's
+// copy of the function): remembered per device, so a process that drives several GPUs does not launch the second device's kernel
+// without it.  One hipGetDevice per launch (~50 ns); `bytes` may grow between launches of the same function.
+struct SnsdeLdsAttr { size_t enabled[16] = {}; };
+inline int snsde_lds_attr(const void* fn, size_t bytes, SnsdeLdsAttr& seen) {
+    if (bytes <= 64 * 1024) return SNSDE_OK;
+    if (bytes > 160 * 1024) return SNSDE_ERR_LDS;
+    int dev = -1;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) dev = -1;
+    if (dev >= 0 && seen.enabled[dev] >= bytes) return SNSDE_OK;
+    if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes) != hipSuccess) return SNSDE_ERR_LDS;
+    if (dev >= 0) seen.enabled[dev] = bytes;
+    return SNSDE_OK;
+}
+
 #endif  // __HIPCC__

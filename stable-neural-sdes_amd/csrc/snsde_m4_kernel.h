@@ -618,13 +618,8 @@ __global__ void __launch_bounds__(CF::NT, CF::WPS) snsde_m4_kernel(MfmaArgs a) {
 template <class CF>
 int launch_lean(const MfmaArgs& a, hipStream_t stream) {
     const size_t lds_bytes = (size_t)CF::LDS_FLOATS * sizeof(float) + LT_LDS_EXTRA;
-    static bool attr_set = false;   // per instantiation
-    if (lds_bytes > 64 * 1024 && !attr_set) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(snsde_m4_kernel<CF>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes) != hipSuccess)
-            return SNSDE_ERR_LDS;
-        attr_set = true;
-    }
+    static SnsdeLdsAttr lds_attr;   // per instantiation and device
+    if (const int rc = snsde_lds_attr(reinterpret_cast<const void*>(snsde_m4_kernel<CF>), lds_bytes, lds_attr)) return rc;
     const int grid = (a.B + 3) / 4;
     hipLaunchKernelGGL(snsde_m4_kernel<CF>, dim3(grid), dim3(CF::NT), lds_bytes, stream, a);
     return hipGetLastError() == hipSuccess ? SNSDE_OK : SNSDE_ERR_LAUNCH;

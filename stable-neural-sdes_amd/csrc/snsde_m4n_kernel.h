@@ -571,13 +571,8 @@ int launch_m4n(const MfmaArgs& a, hipStream_t stream) {
     if constexpr (!CF::FITS) return SNSDE_ERR_UNSUPPORTED;
     else {
         const size_t lds_bytes = (size_t)CF::LDS_FLOATS * sizeof(float);
-        static bool attr_set = false;
-        if (lds_bytes > 64 * 1024 && !attr_set) {
-            if (hipFuncSetAttribute(reinterpret_cast<const void*>(snsde_m4n_kernel<CF>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                    (int)lds_bytes) != hipSuccess)
-                return SNSDE_ERR_LDS;
-            attr_set = true;
-        }
+        static SnsdeLdsAttr lds_attr;   // per instantiation and device
+        if (const int rc = snsde_lds_attr(reinterpret_cast<const void*>(snsde_m4n_kernel<CF>), lds_bytes, lds_attr)) return rc;
         hipLaunchKernelGGL(snsde_m4n_kernel<CF>, dim3((a.B + 3) / 4), dim3(CF::NT), lds_bytes, stream, a);
         return hipGetLastError() == hipSuccess ? SNSDE_OK : SNSDE_ERR_LAUNCH;
     }

@@ -327,13 +327,8 @@ __global__ void __launch_bounds__(CF::NT, 1) snsde_m4s_kernel(MfmaArgs a) {
 template <class CF>
 int launch_stream(const MfmaArgs& a, hipStream_t stream) {
     const size_t lds_bytes = (size_t)CF::LDS_FLOATS * sizeof(float);
-    static bool attr_set = false;
-    if (!attr_set) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(snsde_m4s_kernel<CF>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes) != hipSuccess)
-            return SNSDE_ERR_LDS;
-        attr_set = true;
-    }
+    static SnsdeLdsAttr lds_attr;   // per instantiation and device
+    if (const int rc = snsde_lds_attr(reinterpret_cast<const void*>(snsde_m4s_kernel<CF>), lds_bytes, lds_attr)) return rc;
     const int grid = (a.B + 3) / 4;
     hipLaunchKernelGGL(snsde_m4s_kernel<CF>, dim3(grid), dim3(CF::NT), lds_bytes, stream, a);
     return hipGetLastError() == hipSuccess ? SNSDE_OK : SNSDE_ERR_LAUNCH;

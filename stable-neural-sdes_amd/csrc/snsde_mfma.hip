@@ -230,6 +230,10 @@ MfmaPlan make_plan(const snsde_solve* s, const SnsdeNet& net, int flavor_hint) {
     const int H = m.hidden_channels, io = m.input_option, no = m.noise_option;
     p.ok = false;
     if (m.hidden_hidden_channels != H) return p;
+    // the MFMA kernels form their per-step save offsets from 32-bit uniform factors (uoff): slots x B x H must fit.  Refused HERE
+    // (not only in the launchers) so that `auto` falls through to the generic kernels and snsde_backward_supported reports what the
+    // launchers accept
+    if ((uint64_t)16 * (uint64_t)(s->batch > 0 ? s->batch : 0) * (uint64_t)H >= (1ull << 32)) return p;
     const bool srk = s->method == SNSDE_SRK;
     // SRK: 4-row tiles; 16-row tiles for the elementwise diffusions at H = 64 / 128, C <= 32 (large batches)
     const bool srk_m16_ok = srk && (H == 64 || H == 128) && !(no == 14 || no == 15 || no == 18 || no == 19) && m.input_channels <= 32 &&

@@ -950,13 +950,8 @@ __global__ void __launch_bounds__(CF::NT, CF::WPS) snsde_mfma_kernel(MfmaArgs a)
 template <class CF>
 int launch_cfg(const MfmaArgs& a, hipStream_t stream) {
     const size_t lds_bytes = (size_t)(a.dW ? CF::LDS_BASE : CF::LDS_FLOATS) * sizeof(float);
-    static size_t attr_bytes = 0;   // per instantiation: the largest dynamic LDS size enabled so far
-    if (lds_bytes > 64 * 1024 && lds_bytes > attr_bytes) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(snsde_mfma_kernel<CF>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes) != hipSuccess)
-            return SNSDE_ERR_LDS;
-        attr_bytes = lds_bytes;
-    }
+    static SnsdeLdsAttr lds_attr;   // per instantiation and device
+    if (const int rc = snsde_lds_attr(reinterpret_cast<const void*>(snsde_mfma_kernel<CF>), lds_bytes, lds_attr)) return rc;
     const int grid = (a.B + CF::M - 1) / CF::M;
     hipLaunchKernelGGL(snsde_mfma_kernel<CF>, dim3(grid), dim3(CF::NT), lds_bytes, stream, a);
     return hipGetLastError() == hipSuccess ? SNSDE_OK : SNSDE_ERR_LAUNCH;
@@ -1394,13 +1389,8 @@ __global__ void __launch_bounds__(CF::NT, CF::WPS) snsde_mfma_reverse_kernel(Rev
 template <class CF>
 int launch_rev(const RevArgs& a, hipStream_t stream) {
     const size_t lds_bytes = (size_t)CF::LDS_FLOATS * sizeof(float);
-    static bool attr_set = false;   // per instantiation
-    if (lds_bytes > 64 * 1024 && !attr_set) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(snsde_mfma_reverse_kernel<CF>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes) != hipSuccess)
-            return SNSDE_ERR_LDS;
-        attr_set = true;
-    }
+    static SnsdeLdsAttr lds_attr;   // per instantiation and device
+    if (const int rc = snsde_lds_attr(reinterpret_cast<const void*>(snsde_mfma_reverse_kernel<CF>), lds_bytes, lds_attr)) return rc;
     const int grid = (a.B + CF::M - 1) / CF::M;
     hipLaunchKernelGGL(snsde_mfma_reverse_kernel<CF>, dim3(grid), dim3(CF::NT), lds_bytes, stream, a);
     return hipGetLastError() == hipSuccess ? SNSDE_OK : SNSDE_ERR_LAUNCH;

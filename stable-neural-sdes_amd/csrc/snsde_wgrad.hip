@@ -687,24 +687,49 @@ bool make_wplan(const snsde_backward* b, const SnsdeNet& net, WPlan* w) {
 // a lock, so concurrent callers see consistent event records.  SNSDE_NO_SIDE_STREAM=1: everything on the caller's stream.
 struct SideLane { hipStream_t stream = nullptr; hipEvent_t fork = nullptr, join = nullptr; bool tried = false; };
 constexpr int MAX_DEVICES = 16;
-SideLane g_side[MAX_DEVICES];
+SideLane g_side[MAX_DEVICES];                  // eager calls: one lane per device, shared under g_side_mutex
+thread_local SideLane t_capture[MAX_DEVICES];  // calls recorded into a hipGraph: the CALLING THREAD's own lane per device
 std::mutex g_side_mutex;
 
-SideLane* side_lane() {      // (call with g_side_mutex held)
+// (call with g_side_mutex held)  The lane belongs to the device of the caller's `stream` (hipStreamGetDevice), not to whatever
+// device happens to be current.  A stream capture pulls every stream it forks onto into capture mode until EndCapture, so a
+// recorded call must not take the shared lane - an eager call of another thread on the same device would then launch into a
+// capturing stream: recorded calls use a per-thread lane, created by this thread's earlier EAGER calls only (creating
+// a stream while a capture is active is not capture-safe); a thread that records without ever having run eagerly keeps everything
+// on the caller's stream.
+SideLane* side_lane(hipStream_t stream, bool* capturing) {
     static const bool off = getenv("SNSDE_NO_SIDE_STREAM") != nullptr && getenv("SNSDE_NO_SIDE_STREAM")[0] == '1';
-    int dev = 0;
-    if (off || hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= MAX_DEVICES) return nullptr;
-    SideLane& l = g_side[dev];
-    if (!l.tried) {
+    *capturing = false;
+    if (off) return nullptr;
+    int dev = -1;
+    if (stream == nullptr || hipStreamGetDevice(stream, &dev) != hipSuccess) {      // (the legacy null stream: the current device's)
+        (void)hipGetLastError();
+        if (hipGetDevice(&dev) != hipSuccess) return nullptr;
+    }
+    if (dev < 0 || dev >= MAX_DEVICES) return nullptr;
+    hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
+    if (stream != nullptr && hipStreamIsCapturing(stream, &st) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+    *capturing = st != hipStreamCaptureStatusNone;
+    auto make = [&](SideLane& l) {
+        if (l.tried) return;
         l.tried = true;
+        int cur = -1;
+        const bool switched = hipGetDevice(&cur) == hipSuccess && cur != dev && hipSetDevice(dev) == hipSuccess;
         if (hipStreamCreateWithFlags(&l.stream, hipStreamNonBlocking) != hipSuccess ||
             hipEventCreateWithFlags(&l.fork, hipEventDisableTiming) != hipSuccess ||
             hipEventCreateWithFlags(&l.join, hipEventDisableTiming) != hipSuccess) {
             l.stream = nullptr;
             (void)hipGetLastError();
         }
+        if (switched) (void)hipSetDevice(cur);
+    };
+    if (*capturing) {
+        SideLane& l = t_capture[dev];
+        return (l.tried && l.stream) ? &l : nullptr;
     }
-    return l.stream ? &l : nullptr;
+    make(g_side[dev]);
+    make(t_capture[dev]);        // ready for this thread's later recordings
+    return g_side[dev].stream ? &g_side[dev] : nullptr;
 }
 
 }  // namespace
@@ -747,12 +772,8 @@ int snsde_wgrad_launch(const snsde_backward* b, const SnsdeNet& net, float* grad
     aa.tau_stride = srk ? SNSDE_SRK_STRIDE : SNSDE_STEP_STRIDE;
     const bool two = (no == 16 || no == 17);
     const size_t lds_bytes = (size_t)2 * 2 * RC * LD * sizeof(float);
-    static bool attr_done = false;
-    if (!attr_done) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(snsde_wgrad_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                (int)lds_bytes) != hipSuccess) return SNSDE_ERR_LDS;
-        attr_done = true;
-    }
+    static SnsdeLdsAttr lds_attr;
+    if (const int rc = snsde_lds_attr(reinterpret_cast<const void*>(snsde_wgrad_kernel), lds_bytes, lds_attr)) return rc;
     std::unique_lock<std::mutex> side_lock(g_side_mutex, std::defer_lock);
     SideLane* lane = nullptr;
     if (wp->has_dth) {
@@ -766,8 +787,10 @@ int snsde_wgrad_launch(const snsde_backward* b, const SnsdeNet& net, float* grad
         d.nwg = nwg; d.n_dth = nwg * waves; d.NH = wp->tnoise ? wp->n_trow * H : 0;
         hipStream_t ss = stream;
         if (wp->tnoise) {      // (the bare theta sum of the other families is too small to pay for a fork / join: measured +25 us)
+            bool capturing = false;
             side_lock.lock();
-            lane = side_lane();
+            lane = side_lane(stream, &capturing);
+            if (capturing) side_lock.unlock();      // a per-thread lane: nothing shared to serialise
         }
         if (lane) {
             if (hipEventRecord(lane->fork, stream) == hipSuccess && hipStreamWaitEvent(lane->stream, lane->fork, 0) == hipSuccess) ss = lane->stream;
@@ -780,7 +803,7 @@ int snsde_wgrad_launch(const snsde_backward* b, const SnsdeNet& net, float* grad
                                ss, aa);
         if (lane) {      // joined below, in front of the epilogue
             const bool ok = hipEventRecord(lane->join, lane->stream) == hipSuccess;
-            if (!ok) { side_lock.unlock(); return SNSDE_ERR_LAUNCH; }
+            if (!ok) { if (side_lock.owns_lock()) side_lock.unlock(); return SNSDE_ERR_LAUNCH; }
         }
     }
     if (wp->naux > 0) {
@@ -797,7 +820,7 @@ int snsde_wgrad_launch(const snsde_backward* b, const SnsdeNet& net, float* grad
 
     if (lane) {
         const bool ok = hipStreamWaitEvent(stream, lane->join, 0) == hipSuccess;
-        side_lock.unlock();
+        if (side_lock.owns_lock()) side_lock.unlock();
         if (!ok) return SNSDE_ERR_LAUNCH;
     }
     // small products straight into the flat gradient (after the assemble kernel has written every other entry)

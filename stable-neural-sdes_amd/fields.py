@@ -262,17 +262,42 @@ class ComposedField:
 def compose(sde):
     """ComposedField of a tutorial-style module, or None.  Cached on the module (its structure is fixed after
     construction; the composed weights are rebuilt per solve)."""
-    cached = getattr(sde, '_snsde_composed', None)
-    if cached is not None:
-        return cached[0]
+    slot = _slot(sde)
+    if slot is not None and slot.composed is not None:
+        return slot.composed[0]
     result = _compose(sde)
     if not torch.is_tensor(getattr(sde, 'coeffs', None)):
         return result          # (before set_X: the control path's channel count is not known yet - do not memoise)
-    try:
-        object.__setattr__(sde, '_snsde_composed', (result,))
-    except Exception:
-        pass
+    if slot is not None:
+        slot.composed = (result,)
     return result
+
+
+class _CacheSlot:
+    """What this package memoises on a user's module (the structural mapping, its probe results, device tensors, ctypes
+    structs).  It lives in the module's __dict__ but does not travel: copy.deepcopy / pickle / torch.save of the module carry an
+    EMPTY slot, so a copy is recognised afresh and no CUDA tensor or ctypes object rides along."""
+
+    def __init__(self):
+        self.composed = None      # (ComposedField or None,)
+        self.latent = None        # (key, ComposedField or None)
+
+    def __deepcopy__(self, memo):
+        return _CacheSlot()
+
+    def __reduce__(self):
+        return (_CacheSlot, ())
+
+
+def _slot(sde):
+    try:
+        d = sde.__dict__
+    except AttributeError:
+        return None
+    s = d.get('_snsde_cache')
+    if not isinstance(s, _CacheSlot):
+        s = d['_snsde_cache'] = _CacheSlot()
+    return s
 
 
 def _compose(sde):
@@ -443,11 +468,19 @@ def compose_latent(sde, names, width):
         return None
     if names.get('drift') != 'f_aug' or names.get('diffusion') != 'g_aug' or (set(names) - {'drift', 'diffusion'}):
         return None
-    cached = sde.__dict__.get('_snsde_latent')
-    if cached is not None and cached[0] == width:
-        return cached[1]
+    # keyed on what the structural probes looked at: the layer objects and the functions themselves (a module whose layers are
+    # replaced or whose f / g / f_aug / g_aug are re-bound later is recognised again instead of being solved on a stale mapping)
+    fn = lambda name: (id(sde.__dict__.get(name)), id(getattr(type(sde), name, None)))
+    lins = getattr(sde, 'linears', None)
+    key = (width, id(getattr(sde, 'linear_in', None)), id(getattr(sde, 'linear_out', None)), id(lins),
+           tuple(id(m) for m in lins) if isinstance(lins, (torch.nn.ModuleList, list, tuple)) else None,
+           fn('f'), fn('g'), fn('f_aug'), fn('g_aug'))
+    slot = _slot(sde)
+    if slot is not None and slot.latent is not None and slot.latent[0] == key:
+        return slot.latent[1]
     result = _compose_latent(sde, width)
-    sde.__dict__['_snsde_latent'] = (width, result)
+    if slot is not None:
+        slot.latent = (key, result)
     return result
 
 

@@ -369,7 +369,7 @@ def _sdeint_composed(sde, y0, ts, bm, method, dt, options):
     try:
         return call.launch().to(y0.dtype)
     except engine._lib.SnsdeError as exc:
-        if exc.code != -4:
+        if exc.code not in (-4, -6):
             raise
         return None
 
@@ -446,8 +446,17 @@ def _sdeint_latent(sde, y0, ts, bm, method, dt, options, names):
         if engine.backward_mode(field.model, B, 2, full, method, table=True) != 1:
             return fallback()
         flat = field.flat(dev, grad=True)
-        tab = field.noise_table(tab_times, dev, grad=True).detach()     # (a buffer: no gradient; grad=True = no cache key, i.e. no host read-back)
-        Y = _ComposedSolve.apply(field.model, coeffs, full, widen(dW), method, 0, 0, None, y0p, flat, tab, widen(dU))
+        # grad=True = no cache key, i.e. no host read-back.  The reference's sigma is a buffer (no gradient); a module whose diffusion
+        # is learnable keeps the table in the autograd graph, and _ComposedSolve returns dL/d table like it does for the tutorial fields
+        tab = field.noise_table(tab_times, dev, grad=True)
+        if not tab.requires_grad:
+            tab = tab.detach()
+        try:
+            Y = _ComposedSolve.apply(field.model, coeffs, full, widen(dW), method, 0, 0, None, y0p, flat, tab, widen(dU))
+        except engine._lib.SnsdeError as exc:
+            if exc.code not in (-4, -6):      # no kernel / LDS budget: the tensor-op loop on the increments already drawn
+                raise
+            return fallback()
     else:
         flat, tab = field.inference_inputs(tab_times, dev)
         call = engine.SolveCall(field.model, flat, coeffs, full, y0p.detach().to(torch.float32).contiguous(), dW=widen(dW),
@@ -455,7 +464,7 @@ def _sdeint_latent(sde, y0, ts, bm, method, dt, options, names):
         try:
             Y = call.launch()
         except engine._lib.SnsdeError as exc:
-            if exc.code != -4:
+            if exc.code not in (-4, -6):
                 raise
             return fallback()
     N = grid.N

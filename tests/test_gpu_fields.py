@@ -218,19 +218,17 @@ def test_composed_block_and_table_caches_follow_parameter_updates():
         field.g_net._model[0].bias.add_(0.05)
     b1 = solve(field)
     fresh = copy.deepcopy(field)
-    fresh.__dict__.pop('_snsde_composed', None)       # no cache at all
+    assert fresh.__dict__['_snsde_cache'].composed is None      # the memoised mapping / device tensors do not travel with a copy
     fresh.set_X(coeffs.to(dev), times.to(dev))
     assert not torch.equal(a1, b1) and torch.equal(b1, solve(fresh))
     field.emb.bias.data.add_(0.2)                    # through .data: no version bump - caught by the content fingerprint
     fresh3 = copy.deepcopy(field)
-    fresh3.__dict__.pop('_snsde_composed', None)
     fresh3.set_X(coeffs.to(dev), times.to(dev))
     c1 = solve(field)
     assert not torch.equal(c1, b1) and torch.equal(c1, solve(fresh3))
     b1 = c1
     field.linear_X.weight = torch.nn.Parameter(field.linear_X.weight.detach() * 0.5)     # re-assigned parameter: new address
     fresh2 = copy.deepcopy(field)
-    fresh2.__dict__.pop('_snsde_composed', None)
     fresh2.set_X(coeffs.to(dev), times.to(dev))
     assert torch.equal(solve(field), solve(fresh2)) and not torch.equal(solve(field), b1)
 

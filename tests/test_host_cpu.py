@@ -26,8 +26,68 @@ def test_library_exports_every_declared_symbol():
     lib = _lib.lib()
     for name in declared:
         assert hasattr(lib, name), name
-    assert lib.snsde_version() == 1
+    assert lib.snsde_version() == 2
     assert lib.snsde_strerror(-7).decode().startswith('ts must')
+
+
+def test_dynamic_symbol_table_is_the_header():
+    """-fvisibility=hidden: the shared library exports the SNSDE_API entry points of include/snsde.h and nothing else (no mangled
+    internal launchers / dispatchers)."""
+    import subprocess
+    out = subprocess.run(['nm', '-D', '--defined-only', _lib.LIB_PATH], capture_output=True, text=True, check=True).stdout
+    names = {line.split()[-1] for line in out.splitlines() if line.split() and line.split()[-2] in ('T', 'W', 'D', 'B', 'V', 'R')}
+    ours = {n for n in names if 'snsde' in n}
+    assert ours == set(_lib.EXPORTS), sorted(ours ^ set(_lib.EXPORTS))
+    assert not [n for n in names if n.startswith('_Z')], [n for n in names if n.startswith('_Z')][:5]
+
+
+def test_batches_beyond_the_32_bit_save_offsets_take_the_generic_kernels():
+    """16 B H >= 2^32 exceeds the MFMA kernels' 32-bit uniform offset factors; the plan refuses it, so `auto` reports
+    (and takes) the generic family for forward AND backward instead of failing at launch."""
+    import ctypes as C
+    lib = _lib.lib()
+
+    def q(batch, kernel='auto'):
+        s = _lib.Solve()
+        s.model = S.engine.model_struct(21, 128, 128, 2, 4, 17)
+        s.batch, s.knots, s.n_steps, s.n_out, s.method, s.kernel = batch, 101, 100, 2, _lib.EULER, _lib.KERNELS[kernel]
+        return _lib.PATHS[lib.snsde_forward_path(C.byref(s))], lib.snsde_backward_supported(C.byref(s))
+    assert q(1024) == ('lean', 1)
+    assert q((1 << 21) - 4) == ('mfma16', 1)
+    assert q(1 << 21) == ('generic', 2)
+    assert q(1 << 21, 'mfma') == ('none', 2)
+
+
+def test_stale_binding_is_refused():
+    """A descriptor whose struct_size is not the library's sizeof (a binding compiled against an older header) is refused with
+    SNSDE_ERR_ABI before any field is read; snsde_abi_check verifies a binding's sizes at load time."""
+    import ctypes as C
+    lib = _lib.lib()
+    s = _lib.Solve()
+    assert s.struct_size == C.sizeof(_lib.Solve)
+    s.model = S.engine.model_struct(3, 8, 8, 2, 4, 17)
+    s.batch, s.knots, s.n_steps, s.n_out = 4, 5, 3, 2
+    a, b, c = C.c_int32(), C.c_int32(), C.c_int32()
+    assert lib.snsde_save_layout(C.byref(s), C.byref(a), C.byref(b), C.byref(c)) == 0
+    assert lib.snsde_workspace_bytes(C.byref(s)) > 0
+    s.struct_size -= 8              # as if built before the last pointer field was added
+    assert lib.snsde_save_layout(C.byref(s), C.byref(a), C.byref(b), C.byref(c)) == -10
+    assert lib.snsde_workspace_bytes(C.byref(s)) == 0
+    assert lib.snsde_solve_forward(C.byref(s), None) == -10
+    assert lib.snsde_forward_path(C.byref(s)) == 0 and lib.snsde_backward_supported(C.byref(s)) == 0
+    bw = _lib.Backward()
+    bw.fwd = s
+    assert lib.snsde_solve_backward(C.byref(bw), None) == -10
+    bw.struct_size += 4
+    assert lib.snsde_solve_backward(C.byref(bw), None) == -10
+    h = _lib.Head()
+    h.struct_size = 8
+    assert lib.snsde_readout_head(C.byref(h), None) == -10
+    sizes = (C.sizeof(_lib.Model), C.sizeof(_lib.Solve), C.sizeof(_lib.Backward), C.sizeof(_lib.Head))
+    assert lib.snsde_abi_check(2, *sizes) == 0
+    assert lib.snsde_abi_check(1, *sizes) == -10
+    assert lib.snsde_abi_check(2, sizes[0], sizes[1] - 8, sizes[2], sizes[3]) == -10
+    assert b'struct_size' in lib.snsde_strerror(-10)
 
 
 @pytest.mark.parametrize('io', range(7))
@@ -932,6 +992,36 @@ def test_latent_composition_rejects_modules_whose_accumulator_feeds_back():
     assert fields.compose_latent(Coupled(2, 9, 16, 2), names, 9) is None
     assert fields.compose_latent(LatentField(2, 9, 16, 2), names, 9) is not None
     assert fields.compose_latent(LatentField(2, 9, 16, 2), names, 10) is None          # state width != latent + 1
+
+
+def test_memoised_mapping_does_not_travel_and_follows_rebound_functions():
+    """the latent mapping is memoised on the module, keyed on the layer objects and the functions the structural
+    probes looked at - re-binding f_aug to something the split cannot express drops the mapping - and copy.deepcopy / pickle of
+    the module carry an empty cache (no device tensors or ctypes structs ride along)."""
+    import copy, pickle, types
+    from stable_neural_sdes_amd import fields
+    from tests.latent_field import LatentField
+    names = {'drift': 'f_aug', 'diffusion': 'g_aug'}
+    m = LatentField(2, 9, 16, 2)
+    cf = fields.compose_latent(m, names, 9)
+    assert cf is not None and fields.compose_latent(m, names, 9) is cf                 # memoised
+    for clone in (copy.deepcopy(m), pickle.loads(pickle.dumps(m))):
+        slot = clone.__dict__['_snsde_cache']
+        assert slot.latent is None and slot.composed is None
+        cf2 = fields.compose_latent(clone, names, 9)
+        assert cf2 is not None and cf2 is not cf and cf2.sde.sde is clone
+    orig = type(m).f_aug
+
+    def coupled(self, t, y):          # the accumulator feeds back into the latent drift: not splittable
+        out = orig(self, t, y)
+        return torch.cat([out[:, :-1] + 0.1 * y[:, -1:], out[:, -1:]], dim=1)
+    m.f_aug = types.MethodType(coupled, m)
+    assert fields.compose_latent(m, names, 9) is None
+    del m.f_aug
+    assert fields.compose_latent(m, names, 9) is not None
+    m.linears[0] = torch.nn.Linear(16, 16)                                            # a replaced layer: recognised again
+    cf3 = fields.compose_latent(m, names, 9)
+    assert cf3 is not None and cf3 is not cf and cf3.parts['linears'][0] is m.linears[0]
 
 
 def test_every_step_grid_outputs_every_state_of_the_same_steps():
