@@ -254,6 +254,13 @@ SNSDE_API size_t snsde_param_gradients_workspace_bytes(const snsde_backward* b);
 SNSDE_API int    snsde_param_gradients(const snsde_backward* b, float* grad_params, void* workspace, size_t workspace_bytes,
                              void* hip_stream);
 
+/* snsde_solve_backward followed by snsde_param_gradients as ONE call (mode 1 solves only; same arguments, same results bit for
+ * bit): one transition from the host language and one validation instead of two, the launches back to back on the stream.
+ * Enqueue-only and capturable like the two calls it replaces; returns SNSDE_ERR_UNSUPPORTED where snsde_backward_supported()
+ * != 1 (the caller then uses the separate calls).                                                                            */
+SNSDE_API int snsde_backward_with_gradients(const snsde_backward* b, float* grad_params, void* pg_workspace, size_t pg_workspace_bytes,
+                                            void* hip_stream);
+
 /* ---- cubic spline evaluation (A10) -----------------------------------------------------------
  * out[b, c] = a + (b + (0.5*two_c + three_d*frac/3)*frac)*frac   on interval `index`
  * (derivative != 0: b + (two_c + three_d*frac)*frac), operation order as

@@ -77,7 +77,7 @@ EXPORTS = ('snsde_version', 'snsde_abi_check', 'snsde_strerror', 'snsde_param_co
            'snsde_spline_evaluate', 'snsde_eval_fg', 'snsde_act_slots', 'snsde_backward_supported',
            'snsde_backward_workspace_bytes', 'snsde_solve_backward', 'snsde_spline_workspace_bytes',
            'snsde_natural_cubic_coeffs', 'snsde_hermite_coeffs', 'snsde_param_gradients_workspace_bytes',
-           'snsde_param_gradients', 'snsde_forward_path', 'snsde_readout_head', 'snsde_save_layout')
+           'snsde_param_gradients', 'snsde_backward_with_gradients', 'snsde_forward_path', 'snsde_readout_head', 'snsde_save_layout')
 
 
 def lib():
@@ -118,6 +118,7 @@ def lib():
     L.snsde_param_gradients_workspace_bytes.argtypes = [C.POINTER(Backward)]
     L.snsde_param_gradients_workspace_bytes.restype = C.c_size_t
     L.snsde_param_gradients.argtypes = [C.POINTER(Backward), C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]
+    L.snsde_backward_with_gradients.argtypes = [C.POINTER(Backward), C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]
     L.snsde_backward_supported.argtypes = [C.POINTER(Solve)]
     L.snsde_forward_path.argtypes = [C.POINTER(Solve)]
     L.snsde_readout_head.argtypes = [C.POINTER(Head), C.c_void_p]

@@ -527,6 +527,27 @@ int snsde_param_gradients(const snsde_backward* b, float* grad_params, void* wor
                               static_cast<hipStream_t>(hip_stream));
 }
 
+int snsde_backward_with_gradients(const snsde_backward* b, float* grad_params, void* pg_workspace, size_t pg_workspace_bytes,
+                                  void* hip_stream) {
+    if (!b || !grad_params || !pg_workspace) return SNSDE_ERR_NULL;
+    if (b->struct_size != sizeof(snsde_backward)) return SNSDE_ERR_ABI;
+    int rc = validate_solve(&b->fwd, false);
+    if (rc) return rc;
+    if (!b->grad_ys || !b->adj || !b->workspace || !b->delta_save || !b->fwd.traj || !b->fwd.act_save || !b->fwd.workspace)
+        return SNSDE_ERR_NULL;
+    if (!b->fwd.dW_out && !b->fwd.dW && b->fwd.seed_dev) return SNSDE_ERR_NULL;
+    SnsdeNet net;
+    rc = snsde_build_net(b->fwd.model, b->fwd.n_steps, &net);
+    if (rc) return rc;
+    if (snsde_backward_supported(&b->fwd) != 1) return SNSDE_ERR_UNSUPPORTED;
+    if (b->workspace_bytes < snsde_backward_workspace_bytes(b)) return SNSDE_ERR_WORKSPACE;
+    if (pg_workspace_bytes < snsde_param_gradients_workspace_bytes(b)) return SNSDE_ERR_WORKSPACE;
+    hipStream_t st = static_cast<hipStream_t>(hip_stream);
+    rc = snsde_mfma_backward_launch(b, net, st);
+    if (rc) return rc;
+    return snsde_wgrad_launch(b, net, grad_params, (int32_t)snsde_param_numel(&b->fwd.model), static_cast<float*>(pg_workspace), st);
+}
+
 int snsde_spline_evaluate(const float* coeffs, int32_t batch, int32_t knots, int32_t channels, int32_t index,
                           float frac, int32_t derivative, float* out, void* hip_stream) {
     if (!coeffs || !out) return SNSDE_ERR_NULL;

@@ -38,8 +38,10 @@ namespace {
 // (snsde_prepare_kernel), this pass only writes their zero padding.
 __device__ __forceinline__ int packed_index(int flavor, int KU, int feat, int k);
 
-__device__ __forceinline__ void pack_layer(const float* __restrict__ params, float* __restrict__ ws, const MfmaPackJob& job,
-                                           const MfmaLayerPack& L, int bx, int nbx, bool direct) {
+// fsrc: where the folded products live (fold_tmp offsets): the workspace being packed into, or - backward pack after a folded forward -
+// the FORWARD's workspace, whose prepare launch already formed emb[:, 0:H] . linear_in (no second fold launch in the backward)
+__device__ __forceinline__ void pack_layer(const float* __restrict__ params, float* __restrict__ ws, const float* __restrict__ fsrc,
+                                           const MfmaPackJob& job, const MfmaLayerPack& L, int bx, int nbx, bool direct) {
     const int per_wave = job.TPW * L.KU * 256;
     const int total = job.NW * per_wave;
     const bool skip = direct && L.fold && !L.transpose;
@@ -55,11 +57,11 @@ __device__ __forceinline__ void pack_layer(const float* __restrict__ params, flo
         float v = 0.0f;
         if (L.transpose) {
             if (feat < L.N && k < L.K)
-                v = L.fold ? ws[L.fold_tmp + k * L.src_ld + L.col_off + feat] : params[L.src_w + k * L.src_ld + L.col_off + feat];
+                v = L.fold ? fsrc[L.fold_tmp + k * L.src_ld + L.col_off + feat] : params[L.src_w + k * L.src_ld + L.col_off + feat];
         } else if (feat < L.N && k < Kown) {
             const int sk = L.t_on ? k + L.tshift : ((k < L.K - L.tshift) ? k + L.tshift : k - (L.K - L.tshift));
             if (skip) continue;
-            v = L.fold ? ws[L.fold_tmp + feat * L.K + sk] : params[L.src_w + feat * L.K + sk];
+            v = L.fold ? fsrc[L.fold_tmp + feat * L.K + sk] : params[L.src_w + feat * L.K + sk];
         } else if (k >= L.hole0 && k < L.hole1) {
             continue;                                   // columns another piece owns (the redirected time columns)
         }
@@ -69,7 +71,7 @@ __device__ __forceinline__ void pack_layer(const float* __restrict__ params, flo
         for (int i = bx * blockDim.x + threadIdx.x; i < L.N * L.tshift; i += nbx * blockDim.x) {
             const int feat = i / L.tshift, j = i - feat * L.tshift;
             ws[L.t_dst + packed_index(job.flavor, L.t_KU, feat, L.t_col0 + j)] =
-                L.fold ? ws[L.fold_tmp + feat * L.K + j] : params[L.src_w + feat * L.K + j];
+                L.fold ? fsrc[L.fold_tmp + feat * L.K + j] : params[L.src_w + feat * L.K + j];
         }
     }
     // bias table [row][H]
@@ -89,13 +91,14 @@ __device__ __forceinline__ void pack_layer(const float* __restrict__ params, flo
 }
 
 // kernarg offsets of the by-value job structs (their `layer` arrays are indexed by blockIdx.y: snsde_kernarg_element)
-constexpr size_t PACK_JOB_OFF = 16;      // snsde_mfma_pack_kernel(params, ws, job)
+constexpr size_t PACK_JOB_OFF = 24;      // snsde_mfma_pack_kernel(params, ws, fold_src, job)
 constexpr size_t PREP_JOB_OFF = (16 + sizeof(FoldJob) + alignof(MfmaPackJob) - 1) / alignof(MfmaPackJob) * alignof(MfmaPackJob);
 static_assert(alignof(FoldJob) == 8 && alignof(MfmaPackJob) == 4, "kernarg layout of snsde_prepare_kernel");
 
-__global__ void snsde_mfma_pack_kernel(const float* __restrict__ params, float* __restrict__ ws, MfmaPackJob job) {
+__global__ void snsde_mfma_pack_kernel(const float* __restrict__ params, float* __restrict__ ws, const float* __restrict__ fold_src,
+                                       MfmaPackJob job) {
     const MfmaLayerPack L = snsde_kernarg_element<MfmaLayerPack>(PACK_JOB_OFF + offsetof(MfmaPackJob, layer), blockIdx.y);
-    pack_layer(params, ws, job, L, blockIdx.x, gridDim.x, false);
+    pack_layer(params, ws, fold_src ? fold_src : ws, job, L, blockIdx.x, gridDim.x, false);
 }
 
 // position of weight (feature, k) inside a layer's packed fragment block (inverse of the pack loop's index map)
@@ -194,7 +197,7 @@ __global__ void snsde_prepare_kernel(const float* __restrict__ params, float* __
     if ((int)blockIdx.y == 3 + job.n_layers) { snsde_z0_rows(fj.z0, blockIdx.x, gridDim.x); return; }   // y0 = W0 X(ts[0]) + b0
     if (blockIdx.x < 16) {
         const MfmaLayerPack L = snsde_kernarg_element<MfmaLayerPack>(PREP_JOB_OFF + offsetof(MfmaPackJob, layer), blockIdx.y - 3);
-        pack_layer(params, ws, job, L, blockIdx.x, 16, fj.fold_on != 0);
+        pack_layer(params, ws, ws, job, L, blockIdx.x, 16, fj.fold_on != 0);
     }
 }
 
@@ -649,7 +652,17 @@ int snsde_mfma_backward_launch(const snsde_backward* b, const SnsdeNet& net, hip
     if (!p.ok) return SNSDE_ERR_UNSUPPORTED;
     if ((uint64_t)16 * (uint64_t)s->batch * (uint64_t)s->model.hidden_channels >= (1ull << 32)) return SNSDE_ERR_UNSUPPORTED;   // (uoff)
     float* ws = static_cast<float*>(b->workspace);
-    if (p.emb) {   // first_y = emb[:, 0:H] . linear_in  (all columns; the pack step picks the y columns)
+    // first_y = emb[:, 0:H] . linear_in (all columns; the pack step picks the y columns).  A forward that ran with the folded first
+    // layer left exactly this product in ITS workspace (piece `in` of snsde_prepare_kernel, same (H, K_in) layout): the pack
+    // reads it there and the backward needs no fold launch of its own (6.4 us + a launch gap per K2 training step)
+    const float* fold_src = nullptr;
+    int fwd_fold_tmp = -1;
+    if (p.emb && fp.FOLD && s->workspace) {
+        for (int i = 0; i < fp.n_layers; ++i)
+            if (fp.layer[i].fold && fp.layer[i].src_w == net.in.src_w && !fp.layer[i].transpose) fwd_fold_tmp = fp.layer[i].fold_tmp;
+        if (fwd_fold_tmp >= 0) fold_src = static_cast<const float*>(s->workspace);
+    }
+    if (p.emb && !fold_src) {
         FoldJob fj{};
         fj.emb_w = net.emb.src_w; fj.H = p.H; fj.n_pieces = 1; fj.fold_on = 1;
         fj.src_w[0] = net.in.src_w; fj.K[0] = net.in.K; fj.col[0] = 0; fj.tmp[0] = p.fold_tmp;
@@ -658,9 +671,12 @@ int snsde_mfma_backward_launch(const snsde_backward* b, const SnsdeNet& net, hip
         hipLaunchKernelGGL(snsde_fold_kernel, dim3(p.H, 1), dim3(256), 2 * p.H * sizeof(float), stream, s->params, ws, fj);
     }
     MfmaPackJob job{};
-    for (int i = 0; i < p.n_layers; ++i) job.layer[i] = p.layer[i];
+    for (int i = 0; i < p.n_layers; ++i) {
+        job.layer[i] = p.layer[i];
+        if (fold_src && job.layer[i].fold) job.layer[i].fold_tmp = fwd_fold_tmp;
+    }
     job.n_layers = p.n_layers; job.flavor = p.FL; job.TPW = 1; job.NW = p.NW; job.bias_off = 0; job.H = p.H;
-    hipLaunchKernelGGL(snsde_mfma_pack_kernel, dim3(16, p.n_layers), dim3(256), 0, stream, s->params, ws, job);
+    hipLaunchKernelGGL(snsde_mfma_pack_kernel, dim3(16, p.n_layers), dim3(256), 0, stream, s->params, ws, fold_src, job);
     RevArgs a{};
     a.params = s->params; a.ws = ws;
     a.gt = s->noise_table ? s->noise_table : (fp.gt_off >= 0 ? static_cast<const float*>(s->workspace) + fp.gt_off : nullptr);

@@ -528,6 +528,43 @@ def param_gradients(call, adj, delta, stream=None, want_table_grad=False):
     return (grad, tab_grad) if want_table_grad else grad
 
 
+def backward_with_gradients(call, grad_ys, stream=None, adj0_only=True, want_table_grad=False):
+    """solve_backward + param_gradients as ONE C call (snsde_backward_with_gradients; mode 1 solves): same results, one
+    host -> library transition.  Returns (adj, flat gradient[, dL/d noise_table])."""
+    if call.traj is None or call.act_save is None:
+        raise ValueError('backward needs a solve run with save_traj and save_act')
+    _check_f32('grad_ys', grad_ys, tuple(call.ys.shape))
+    dev = call.traj.device
+    b = _lib.Backward()
+    b.fwd = call.desc
+    b.fwd.flags = call.base_flags
+    adj = torch.empty_like(call.traj[:1]) if adj0_only else torch.empty_like(call.traj)
+    b.flags = _lib.BWD_ADJ0_ONLY if adj0_only else 0
+    shp = call.act_save.shape
+    delta = torch.empty((shp[0], getattr(call, 'delta_slots', shp[1]), shp[2], shp[3]), device=dev, dtype=torch.float32)
+    b.grad_ys, b.adj, b.delta_save = _ptr(grad_ys), _ptr(adj), _ptr(delta)
+    L = _lib.lib()
+    ws = torch.empty(max(L.snsde_backward_workspace_bytes(C.byref(b)), 256), device=dev, dtype=torch.uint8)
+    b.workspace, b.workspace_bytes = _ptr(ws), ws.numel()
+    tab_grad = None
+    if want_table_grad:
+        rows = call.grid.N * (4 if call.desc.method == _lib.SRK else 1)      # SRK: one row per stage time
+        tab_grad = torch.zeros((rows, call.model.hidden_channels), device=dev, dtype=torch.float32)
+        b.grad_noise_table = _ptr(tab_grad)
+    nbytes = L.snsde_param_gradients_workspace_bytes(C.byref(b))
+    if nbytes == 0:
+        raise NotImplementedError('snsde_backward_with_gradients covers the MFMA-path configurations only')
+    pws = torch.empty(nbytes, device=dev, dtype=torch.uint8)
+    grad = torch.empty(call.keep[0].numel(), device=dev, dtype=torch.float32)
+    stream = torch.cuda.current_stream(dev) if stream is None else stream
+    _lib.check(L.snsde_backward_with_gradients(C.byref(b), _ptr(grad), _ptr(pws), pws.numel(), C.c_void_p(stream.cuda_stream)),
+               'snsde_backward_with_gradients')
+    call.keep_bwd = (ws, grad_ys)
+    call.keep_pg = (pws, adj, delta, tab_grad)
+    call.bwd_desc = b
+    return (adj, grad, tab_grad) if want_table_grad else (adj, grad)
+
+
 def eval_fg(model, flat_params, coeffs, times_host, t, y, kernel='auto'):
     """f(t, y), g(t, y) through the solver's device code (snsde_eval_fg)."""
     B, H = y.shape

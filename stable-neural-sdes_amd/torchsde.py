@@ -530,12 +530,9 @@ class _ComposedSolve(torch.autograd.Function):
     @staticmethod
     def backward(ctx, grad_ys):
         call = ctx.call
-        adj, delta = engine.solve_backward(call, grad_ys.to(torch.float32).contiguous(), save_delta=True,
-                                           adj0_only=engine.adj0_suffices(call))
-        if ctx.has_tab:
-            gflat, gtab = engine.param_gradients(call, adj, delta, want_table_grad=True)
-        else:
-            gflat, gtab = engine.param_gradients(call, adj, delta), None
+        out = engine.backward_with_gradients(call, grad_ys.to(torch.float32).contiguous(), adj0_only=engine.adj0_suffices(call),
+                                             want_table_grad=ctx.has_tab)
+        adj, gflat, gtab = out if ctx.has_tab else (out + (None,))
         return (None,) * 8 + (adj[0].to(ctx.y0_dtype), gflat, gtab, None)
 
 
@@ -559,7 +556,7 @@ class _FusedSolve(torch.autograd.Function):
             # supplied ones in place and REGENERATES Philox ones (host key) - one (N, B, H) store and load less per step
             nets = model.noise_option in (14, 15, 18, 19)
             keep_dw = not (save_act and method in ('euler', 'milstein') and not (nets and method == 'milstein')
-                           and not torch.is_tensor(seed) and options.get('param_pass', 'hip') == 'hip'
+                           and not torch.is_tensor(seed) and options.get('param_pass', 'hip') in ('hip', 'split')
                            and os.environ.get('SNSDE_KEEP_INCREMENTS') != '1')
             return engine.SolveCall(model, flat, coeffs, grid, y0c, dW=dW, method=method, seed=seed,
                                     row_offset=int(options.get('row_offset', 0)), kernel=kernel, save_traj=True,
@@ -604,12 +601,17 @@ class _FusedSolve(torch.autograd.Function):
                 grads.append(flat[off:off + p.numel()].view_as(p).to(p.dtype))
             return (None,) * 9 + (g0.to(ctx.y0_dtype),) + tuple(grads)
         if ctx.mode == 1:     # MFMA adjoint kernel + native weight-gradient pass on the saved activations / deltas
-            adj, delta = engine.solve_backward(call, grad_ys.to(torch.float32).contiguous(), save_delta=True,
-                                               adj0_only=ctx.param_pass != 'torch' and engine.adj0_suffices(call))
             if ctx.param_pass == 'torch':     # library-GEMM cross-check of the native pass
+                adj, delta = engine.solve_backward(call, grad_ys.to(torch.float32).contiguous(), save_delta=True, adj0_only=False)
                 grads = _parameter_gradients_gemm(sde, call, grid, adj, delta, method=ctx.method)
             else:
-                flat = engine.param_gradients(call, adj, delta)
+                if ctx.param_pass == 'split':     # the two C calls one after the other (what the fused call must reproduce bit for bit)
+                    adj, delta = engine.solve_backward(call, grad_ys.to(torch.float32).contiguous(), save_delta=True,
+                                                       adj0_only=engine.adj0_suffices(call))
+                    flat = engine.param_gradients(call, adj, delta)
+                else:
+                    adj, flat = engine.backward_with_gradients(call, grad_ys.to(torch.float32).contiguous(),
+                                                               adj0_only=engine.adj0_suffices(call))
                 layout, _ = ctx.layout
                 offs = {name: (off, shape) for name, off, shape in layout}
                 grads = []

@@ -971,6 +971,36 @@ def test_native_parameter_pass_matches_library_gemm_pass(case):
         assert np.abs(got - ref).max() / scale < 2e-4, (k, np.abs(got - ref).max() / scale)
 
 
+@pytest.mark.parametrize('case', [(4, 17, 2, 300, 128, 21, 13, 'euler'), (6, 17, 3, 70, 64, 7, 9, 'milstein'), (1, 0, 1, 33, 16, 3, 8, 'euler'),
+                                  (2, 16, 2, 130, 256, 14, 9, 'milstein'), (4, 13, 2, 37, 64, 5, 9, 'srk'), (3, 18, 2, 33, 64, 5, 12, 'srk'),
+                                  (3, 18, 2, 21, 32, 69, 9, 'milstein'), (0, 16, 2, 19, 32, 5, 8, 'euler')])
+def test_fused_backward_call_equals_the_two_separate_calls(case):
+    """snsde_backward_with_gradients (adjoint + parameter pass in one C call, the forward-only parts of the parameter pass on the side
+    stream beside the adjoint kernel) against snsde_solve_backward followed by snsde_param_gradients: bit-identical gradients."""
+    io, no, NL, B, H, C, L, method = case
+    pr = make_problem(78, io, no, NL, B, H, C, L)
+    ts = np.asarray([0, (L - 1) / 2, L - 1], np.float32)
+    wsum = torch.from_numpy(np.random.default_rng(8).standard_normal((len(ts), B, H)).astype(np.float32)).to(DEV)
+    out = {}
+    for mode in ('hip', 'split', 'hip'):
+        m = S.Diffusion_model(C, H, H, NL, input_option=io, noise_option=no)
+        m.load_state_dict({k: torch.from_numpy(v.copy()) for k, v in pr['params'].items()})
+        m = m.to(DEV)
+        m.set_X(torch.from_numpy(pr['coeffs']).to(DEV), torch.from_numpy(pr['times']).to(DEV))
+        y0 = torch.from_numpy(pr['y0']).to(DEV).requires_grad_(True)
+        ys = S.sdeint(m, y0, torch.from_numpy(ts).to(DEV), method=method, dt=1.0, options={'param_pass': mode, 'seed': 5, 'strict': True})
+        (ys * wsum).sum().backward()
+        got = {k: p.grad.detach().cpu().numpy() for k, p in m.named_parameters() if p.grad is not None}
+        got['y0'] = y0.grad.detach().cpu().numpy()
+        if mode in out:
+            for k in got:
+                np.testing.assert_array_equal(got[k], out[mode][k], err_msg=f'{k}: fused call not reproducible')
+        out[mode] = got
+    assert out['hip'].keys() == out['split'].keys()
+    for k in out['hip']:
+        np.testing.assert_array_equal(out['hip'][k], out['split'][k], err_msg=k)
+
+
 def test_backward_without_a_fused_adjoint_falls_back_to_the_tensor_loop_or_raises_when_strict():
     # Milstein with sqrt(y) (noise_option 7) is the one family without kernels: no finite dg/dy at the clipped values
     pr = make_problem(9, 1, 7, 2, 8, 64, 3, 5)
