@@ -105,21 +105,26 @@ __device__ __forceinline__ XStep xaux_step(const XInfo& a, int n) {
     return x;
 }
 
-__device__ __forceinline__ float xaux_value(const XInfo& a, const XStep& x, int b, int j) {
-    float val = 0.0f;
+// One control-path column of row (pass described by x, batch row b) as the four cubic pieces (a, b, two_c, three_d) of its
+// channel - LOADED here, evaluated later (xaux_eval, after the chunk's MFMAs: evaluating at once would make the staging wave wait
+// for the coefficient loads in front of its MFMAs).  Time / stage-time columns and padding come back as (value, 0, 0, 0), which the
+// cubic evaluates to `value` exactly.
+__device__ __forceinline__ float4 xaux_raw(const XInfo& a, const XStep& x, int b, int j) {
+    float4 r = make_float4(0.f, 0.f, 0.f, 0.f);
     if (a.n_col0 >= 0 && j >= a.n_col0) {
         const int jj = j - a.n_col0;
-        if (jj < 2) val = jj == 0 ? x.n0 : x.n1;
-        else if ((jj == 4 || jj == 5) && x.tail) val = jj == 4 ? x.m0 : x.m1;
+        if (jj < 2) r.x = jj == 0 ? x.n0 : x.n1;
+        else if ((jj == 4 || jj == 5) && x.tail) r.x = jj == 4 ? x.m0 : x.m1;
     } else
-    if (j >= a.t_col0 && j < a.t_col0 + a.t_cols) val = j == a.t_col0 ? x.t0 : x.t1;
+    if (j >= a.t_col0 && j < a.t_col0 + a.t_cols) r.x = j == a.t_col0 ? x.t0 : x.t1;
     else if (j >= a.x_col0 && j < a.x_col0 + a.x_cols) {
         const int c = j - a.x_col0;
         const float* cr = a.coeffs + ((size_t)b * a.Lm1 + x.idx) * 4 * a.C;
-        val = snsde_spline_eval(cr[c], cr[a.C + c], cr[2 * a.C + c], cr[3 * a.C + c], x.frac);
+        r = make_float4(cr[c], cr[a.C + c], cr[2 * a.C + c], cr[3 * a.C + c]);
     }
-    return val;
+    return r;
 }
+__device__ __forceinline__ float xaux_eval(const float4& r, float frac) { return snsde_spline_eval(r.x, r.y, r.z, r.w, frac); }
 
 // ---- epilogue descriptors (declared here: the reduce launch also carries the noise MLP's hidden-gradient blocks) ----
 struct GJob {     // C (M x N) = A . B^T (trans 0: A (M, K), B (N, K)) or A^T . B (trans 1: A (K, M), B (K, N); B null = ones)
@@ -239,7 +244,8 @@ __device__ __forceinline__ void wgrad_body(const WArgs& a, const WTile& t, const
     // each, all independent: the pass's step values sit in registers and are re-read only when the row enters another pass)
     const int xr0 = tid >> 4, xc0 = tid & 15;
     int xrow_r = r_begin + xr0, xrow_b = 0, xrow_n = 0;
-    [[maybe_unused]] float xv[NKT];
+    [[maybe_unused]] float4 xv[NKT];
+    [[maybe_unused]] float xfr = 0.0f;             // the interval fraction of the staged row (xs moves on to the next chunk's pass)
     [[maybe_unused]] XStep xs{};
     if constexpr (XFLY) {
         const int n0 = xrow_r / B;
@@ -276,10 +282,11 @@ __device__ __forceinline__ void wgrad_body(const WArgs& a, const WTile& t, const
         while (row_b >= B) { row_b -= B; doff += dwrap; xoff += xwrap; }
         if constexpr (XFLY) {
             const bool ok = xrow_r < r_end;
+            xfr = xs.frac;
 #pragma unroll
             for (int i = 0; i < NKT; ++i) {
                 const int col = xc0 + 16 * i;
-                xv[i] = (ok && col < t.ncols) ? xaux_value(xi, xs, xrow_b, t.k0 + col) : 0.0f;
+                xv[i] = (ok && col < t.ncols) ? xaux_raw(xi, xs, xrow_b, t.k0 + col) : make_float4(0.f, 0.f, 0.f, 0.f);
             }
             xrow_r += RC; xrow_b += RC;
             while (xrow_b >= B) {
@@ -302,7 +309,7 @@ __device__ __forceinline__ void wgrad_body(const WArgs& a, const WTile& t, const
         }
         if constexpr (XFLY) {
 #pragma unroll
-            for (int i = 0; i < NKT; ++i) Xl[xr0 * LD + xc0 + 16 * i] = xv[i];
+            for (int i = 0; i < NKT; ++i) Xl[xr0 * LD + xc0 + 16 * i] = xaux_eval(xv[i], xfr);
         }
     };
 
@@ -386,12 +393,16 @@ __device__ __forceinline__ void wgrad_groups(const WArgs& a, const WTile& t, con
 
 __global__ void __launch_bounds__(NT, 4) snsde_wgrad_kernel(WArgs a) {
     extern __shared__ __attribute__((aligned(16))) float lds[];   // [2 buffers][D | X][RC][LD]
-    if ((int)blockIdx.y == a.ntiles) {      // the diffusion-side reductions (dsum_block)
+    // dispatch order = blockIdx.y ascending: the latency-bound riders go FIRST (they would otherwise start when the GEMM workgroups
+    // drain and form a 25 - 50 us tail): y = 0 the diffusion-side reductions (when present), then the tiles in REVERSE plan order
+    // (the control-path tiles, whose staging evaluates spline pieces, were planned last)
+    const int y0 = a.dsum_blocks > 0 ? 1 : 0;
+    if ((int)blockIdx.y < y0) {             // the diffusion-side reductions (dsum_block)
         const DArgs d = snsde_kernarg_element<DArgs>(offsetof(WArgs, dsum), 0);
         for (int blk = blockIdx.x; blk < a.dsum_blocks; blk += gridDim.x) dsum_block<NT>(d, blk, a.dsum_blocks, lds);
         return;
     }
-    const WTile t = snsde_kernarg_element<WTile>(offsetof(WArgs, tile), blockIdx.y);     // (not a.tile[blockIdx.y]: see the helper)
+    const WTile t = snsde_kernarg_element<WTile>(offsetof(WArgs, tile), a.ntiles - 1 - ((int)blockIdx.y - y0));     // (not a.tile[..]: see the helper)
     if ((int)blockIdx.x >= t.nsplit) return;
     const int g = a.H >= 128 ? 1 : (a.H >= 64 ? 2 : 4);      // column groups (uniform per launch)
     if (t.x_kind == 2) {     // control-path columns built while staging; the descriptor through scalar loads (see snsde_kernarg_element)
@@ -473,12 +484,13 @@ __device__ __forceinline__ void noise_hidden_block(const NHArgs& a, int n, int b
 // ~500 partial tiles = 34 MB at K2 and took 14 us as one thread per element, most of it load latency).
 __global__ void __launch_bounds__(256) snsde_wgrad_reduce_kernel(WArgs a, NHArgs nh) {
     __shared__ float4 red[256];             // (= 1024 floats: the noise blocks use H + 256 <= 512 of them)
-    if ((int)blockIdx.y == a.ntiles) {      // hidden gradient of the time-only noise MLP: nh.rows x nh.nby virtual blocks
+    const int y0 = nh.rows > 0 ? 1 : 0;     // (riders first, as in the GEMM launch)
+    if ((int)blockIdx.y < y0) {             // hidden gradient of the time-only noise MLP: nh.rows x nh.nby virtual blocks
         for (int v = blockIdx.x; v < nh.rows * nh.nby; v += gridDim.x)
             noise_hidden_block(nh, v / nh.nby, v % nh.nby, reinterpret_cast<float*>(red));
         return;
     }
-    const WTile t = snsde_kernarg_element<WTile>(offsetof(WArgs, tile), blockIdx.y);     // (not a.tile[blockIdx.y]: see the helper)
+    const WTile t = snsde_kernarg_element<WTile>(offsetof(WArgs, tile), (int)blockIdx.y - y0);     // (not a.tile[..]: see the helper)
     const int tid = threadIdx.x, g = tid >> 6;
     const int e = (blockIdx.x * 64 + (tid & 63)) * 4;           // first of this thread's four elements (TILE_FLOATS is a multiple of 4)
     float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -766,7 +778,8 @@ bool make_wplan(const snsde_backward* b, const SnsdeNet& net, WPlan* w) {
     // (the weights stay proportional to the tile's columns although the kernel's column groups divide the MFMAs per wave at H < 128:
     //  there the kernel is bound by the bytes it stages, which scale the same way; measured at the K4 shape: 130 vs 151 us)
     auto nk_eff = [&](int nk) { return nk; };
-    for (int i = 0; i < nt; ++i) wsum += (long)(nk_eff(nkt_class(w->tile[i].ncols)) + wbias) * (w->tile[i].rows / s.batch);
+    auto tile_w = [&](const WTile& t) { return t.x_kind == 2 ? 8 : nk_eff(nkt_class(t.ncols)); };      // (control-path tiles: their staging is latency-bound)
+    for (int i = 0; i < nt; ++i) wsum += (long)(tile_w(w->tile[i]) + wbias) * (w->tile[i].rows / s.batch);
     if (wsum < 1) wsum = 1;
     int nparts = 0;
     w->max_split = 1;
@@ -775,7 +788,7 @@ bool make_wplan(const snsde_backward* b, const SnsdeNet& net, WPlan* w) {
         const int nk = nkt_class(t.ncols);
         const int chunks = (t.rows + RC - 1) / RC;
         t.cls = (nk == 8 ? 0 : (nk == 4 ? 2 : (nk == 2 ? 4 : 6))) + (t.bias >= 0 ? 0 : 1);
-        int ns = (int)((wtotal * (nk_eff(nk) + wbias) * (t.rows / s.batch) + wsum / 2) / wsum);
+        int ns = (int)((wtotal * (tile_w(t) + wbias) * (t.rows / s.batch) + wsum / 2) / wsum);
         if (ns < 1) ns = 1;
         if (ns > chunks) ns = chunks;
         t.rows_per_split = ((chunks + ns - 1) / ns) * RC;

@@ -44,6 +44,62 @@ def recognise(sde):
     return result
 
 
+class ParamIndex:
+    """The module's parameters resolved ONCE: in named_parameters() order (what autograd.Function.apply receives and backward
+    returns) and in the C ABI's layout order, with the per-parameter (offset, numel, shape) of the flat block.  A training step
+    walked named_parameters() six times (~25 us each: half of the host time of sdeint() on the K2 step, which is host-bound);
+    the cached lists are validated by identity against the owning submodules' _parameters dicts (~2 us), so a re-assigned
+    parameter (module.weight = nn.Parameter(...)) or a replaced layer rebuilds them."""
+
+    def __init__(self, sde, layout):
+        named = list(sde.named_parameters())
+        self.names = [n for n, _ in named]
+        self.params = [p for _, p in named]
+        by_name = dict(named)
+        self.layout_params = [by_name[name] for name, _, _ in layout]
+        offs = {name: (off, shape) for name, off, shape in layout}
+        self.sizes = [by_name[name].numel() for name, _, _ in layout]              # split sizes of the flat block (layout order)
+        order = {name: i for i, (name, _, _) in enumerate(layout)}
+        self.to_layout = [order[n] for n in self.names]                             # named order -> index in the layout
+        self.shapes = [tuple(offs[n][1]) for n in self.names]
+        self.owners = []
+        for n in self.names:
+            mod, parts = sde, n.split('.')
+            for q in parts[:-1]:
+                mod = mod._modules[q]
+            self.owners.append((mod._parameters, parts[-1]))
+        self.all_f32 = all(p.dtype == torch.float32 for p in self.params)
+        self.layout_id = id(layout)
+
+    def valid(self, layout):
+        if self.layout_id != id(layout):
+            return False
+        for (d, k), p in zip(self.owners, self.params):
+            if d.get(k) is not p:
+                return False
+        return True
+
+    def grads_from_flat(self, flat):
+        """Per-parameter views of a flat gradient in the C ABI's layout, in named_parameters() order."""
+        pieces = flat.split(self.sizes)
+        out = []
+        for i, shape, p in zip(self.to_layout, self.shapes, self.params):
+            g = pieces[i].view(shape)
+            out.append(g if p.dtype == torch.float32 else g.to(p.dtype))
+        return out
+
+
+def param_index(sde, layout):
+    idx = sde.__dict__.get('_snsde_pidx') if hasattr(sde, '__dict__') else None
+    if idx is None or not idx.valid(layout):
+        idx = ParamIndex(sde, layout)
+        try:
+            sde.__dict__['_snsde_pidx'] = idx
+        except Exception:
+            pass
+    return idx
+
+
 def _recognise(sde):
     if getattr(sde, 'sde_type', 'ito') != 'ito' or getattr(sde, 'noise_type', 'diagonal') != 'diagonal':
         return None
@@ -145,8 +201,7 @@ def flatten_params(sde, layout, numel, device):
     `param.data` at its slice of that buffer, so later calls — including after in-place optimizer steps, which now
     write straight into the buffer — return it without launching anything.  Anything that re-allocates a parameter
     (`.to()`, `.double()`, a new nn.Parameter) is detected by the address check and triggers a fresh flatten."""
-    params = dict(sde.named_parameters())
-    plist = [params[name] for name, _, _ in layout]
+    plist = param_index(sde, layout).layout_params
     arena = getattr(sde, '_snsde_flat', None)
     if arena is not None and arena.device == device:
         base = arena.data_ptr()
@@ -387,14 +442,22 @@ class SolveCall:
         s.model = model
         s.batch, s.knots, s.n_steps, s.n_out = B, L, grid.N, grid.T
         s.method = {'euler': _lib.EULER, 'milstein': _lib.MILSTEIN, 'srk': _lib.SRK}[method]
+        # host-side queries of the library (save layout, workspace sizes) depend on the configuration only: memoised
+        self.cfg_key = (model.input_channels, model.hidden_channels, model.hidden_hidden_channels, model.num_hidden_layers,
+                        model.input_option, model.noise_option, model.activation, model.drift_output, model.diffusion_output,
+                        model.time_feature, B, L, grid.N, grid.T, method, kernel, bool(exact_order), noise_table is not None,
+                        dW is not None, row_out is not None)
         if save_act:
-            slots, planes, dslots = C.c_int32(), C.c_int32(), C.c_int32()
-            _lib.check(_lib.lib().snsde_save_layout(C.byref(s), C.byref(slots), C.byref(planes), C.byref(dslots)), 'snsde_save_layout')
-            self.delta_slots = dslots.value
+            lay = _SIZE_CACHE.get(('layout',) + self.cfg_key)
+            if lay is None:
+                slots, planes, dslots = C.c_int32(), C.c_int32(), C.c_int32()
+                _lib.check(_lib.lib().snsde_save_layout(C.byref(s), C.byref(slots), C.byref(planes), C.byref(dslots)), 'snsde_save_layout')
+                lay = _SIZE_CACHE[('layout',) + self.cfg_key] = (slots.value, planes.value, dslots.value)
+            nslots, nplanes, self.delta_slots = lay
             passes = 3 * grid.N if method == 'srk' else grid.N      # SRK: three drift passes per step
-            self.act_save = torch.empty((passes, slots.value, B, H), device=dev, dtype=torch.float32)
+            self.act_save = torch.empty((passes, nslots, B, H), device=dev, dtype=torch.float32)
             if method == 'srk':
-                shape = (passes + 1, B, H) if planes.value == 1 else (passes + 1, planes.value, B, H)
+                shape = (passes + 1, B, H) if nplanes == 1 else (passes + 1, nplanes, B, H)
                 self.stage_save = torch.empty(shape, device=dev, dtype=torch.float32)
         if method == 'srk':
             s.srk_tab = _ptr(srk_table(grid))
@@ -422,7 +485,9 @@ class SolveCall:
         s.noise_table = _ptr(noise_table)
         if z0_linear is not None:
             s.z0_weight, s.z0_bias = _ptr(z0_linear[0]), _ptr(z0_linear[1])
-        nbytes = _lib.lib().snsde_workspace_bytes(C.byref(s))
+        nbytes = _SIZE_CACHE.get(('fwd',) + self.cfg_key)
+        if nbytes is None:
+            nbytes = _SIZE_CACHE[('fwd',) + self.cfg_key] = int(_lib.lib().snsde_workspace_bytes(C.byref(s)))
         self.workspace = torch.empty(max(nbytes, 256), device=dev, dtype=torch.uint8)
         s.workspace = _ptr(self.workspace)
         s.workspace_bytes = self.workspace.numel()
@@ -445,6 +510,7 @@ def backward_supported(call):
 
 
 _MODE_CACHE = {}
+_SIZE_CACHE = {}      # host-side size queries of the library per configuration (SolveCall.cfg_key)
 
 
 def backward_mode(model, batch, knots, grid, method, kernel='auto', exact_order=False, table=False):
@@ -544,17 +610,22 @@ def backward_with_gradients(call, grad_ys, stream=None, adj0_only=True, want_tab
     delta = torch.empty((shp[0], getattr(call, 'delta_slots', shp[1]), shp[2], shp[3]), device=dev, dtype=torch.float32)
     b.grad_ys, b.adj, b.delta_save = _ptr(grad_ys), _ptr(adj), _ptr(delta)
     L = _lib.lib()
-    ws = torch.empty(max(L.snsde_backward_workspace_bytes(C.byref(b)), 256), device=dev, dtype=torch.uint8)
-    b.workspace, b.workspace_bytes = _ptr(ws), ws.numel()
     tab_grad = None
     if want_table_grad:
         rows = call.grid.N * (4 if call.desc.method == _lib.SRK else 1)      # SRK: one row per stage time
         tab_grad = torch.zeros((rows, call.model.hidden_channels), device=dev, dtype=torch.float32)
         b.grad_noise_table = _ptr(tab_grad)
-    nbytes = L.snsde_param_gradients_workspace_bytes(C.byref(b))
-    if nbytes == 0:
+    key = ('bwd', adj0_only, want_table_grad) + call.cfg_key
+    sizes = _SIZE_CACHE.get(key)
+    if sizes is None:
+        b.workspace, b.workspace_bytes = C.c_void_p(16), 1 << 40      # (only its presence matters to the size queries)
+        sizes = _SIZE_CACHE[key] = (max(int(L.snsde_backward_workspace_bytes(C.byref(b))), 256),
+                                    int(L.snsde_param_gradients_workspace_bytes(C.byref(b))))
+    if sizes[1] == 0:
         raise NotImplementedError('snsde_backward_with_gradients covers the MFMA-path configurations only')
-    pws = torch.empty(nbytes, device=dev, dtype=torch.uint8)
+    ws = torch.empty(sizes[0], device=dev, dtype=torch.uint8)
+    b.workspace, b.workspace_bytes = _ptr(ws), ws.numel()
+    pws = torch.empty(sizes[1], device=dev, dtype=torch.uint8)
     grad = torch.empty(call.keep[0].numel(), device=dev, dtype=torch.float32)
     stream = torch.cuda.current_stream(dev) if stream is None else stream
     _lib.check(L.snsde_backward_with_gradients(C.byref(b), _ptr(grad), _ptr(pws), pws.numel(), C.c_void_p(stream.cuda_stream)),

@@ -226,7 +226,8 @@ def _sdeint_hip(sde, rec, y0, ts, bm, method, dt, options):
             z0_lin = options.pop('z0_linear')
         else:
             y0 = _materialise_z0(sde, y0, ts, options)
-    needs_grad = torch.is_grad_enabled() and (y0.requires_grad or any(p.requires_grad for p in sde.parameters()))
+    pidx = engine.param_index(sde, layout)
+    needs_grad = torch.is_grad_enabled() and (y0.requires_grad or any(p.requires_grad for p in pidx.params))
     dev = y0.device
     coeffs = sde.coeffs
     if coeffs.dim() != 3 or coeffs.shape[0] != y0.shape[0]:
@@ -283,8 +284,7 @@ def _sdeint_hip(sde, rec, y0, ts, bm, method, dt, options):
                 warnings.warn(f"sdeint: no fused backward for input_option={key[0]}, noise_option={key[1]}, method={method!r}; "
                               "differentiating through the unfused tensor-op loop (slow).")
             return _sdeint_torch(sde, y0, ts, bm if dW is None else _DrawnIncrements(dW, dU), method, dt, options, None)
-        return _FusedSolve.apply(sde, rec, coeffs, grid, times_host, (dW, dU), method, seed, options, y0,
-                                      *[p for _, p in sde.named_parameters()])
+        return _FusedSolve.apply(sde, rec, coeffs, grid, times_host, (dW, dU), method, seed, options, y0, *pidx.params)
     flat = engine.flatten_params(sde, layout, numel, dev)
     call = engine.SolveCall(model, flat, coeffs, grid, y0c, dW=dW, method=method, seed=seed,
                             row_offset=int(options.get('row_offset', 0)), kernel=options.get('kernel', 'auto'),
@@ -582,7 +582,6 @@ class _FusedSolve(torch.autograd.Function):
         ctx.layout = (layout, numel)
         ys = call.launch()
         ctx.call, ctx.sde, ctx.grid, ctx.times_host = call, sde, grid, times_host
-        ctx.names = [n for n, _ in sde.named_parameters()]
         ctx.y0_dtype = y0.dtype
         # a NEW tensor object for the output: returning call.ys itself would give it this node as grad_fn, and the node
         # holds the call: a reference cycle that keeps every saved tensor of the solve alive until the cyclic collector runs
@@ -593,12 +592,7 @@ class _FusedSolve(torch.autograd.Function):
         call, sde, grid = ctx.call, ctx.sde, ctx.grid
         if ctx.mode == 1 and ctx.recompute:
             g0, flat = engine.backward_recompute(call, grad_ys.to(torch.float32).contiguous(), ctx.recompute)
-            layout, _ = ctx.layout
-            offs = {name: (off, shape) for name, off, shape in layout}
-            grads = []
-            for name, p in sde.named_parameters():
-                off, shape = offs[name]
-                grads.append(flat[off:off + p.numel()].view_as(p).to(p.dtype))
+            grads = engine.param_index(sde, ctx.layout[0]).grads_from_flat(flat)
             return (None,) * 9 + (g0.to(ctx.y0_dtype),) + tuple(grads)
         if ctx.mode == 1:     # MFMA adjoint kernel + native weight-gradient pass on the saved activations / deltas
             if ctx.param_pass == 'torch':     # library-GEMM cross-check of the native pass
@@ -612,12 +606,7 @@ class _FusedSolve(torch.autograd.Function):
                 else:
                     adj, flat = engine.backward_with_gradients(call, grad_ys.to(torch.float32).contiguous(),
                                                                adj0_only=engine.adj0_suffices(call))
-                layout, _ = ctx.layout
-                offs = {name: (off, shape) for name, off, shape in layout}
-                grads = []
-                for name, p in sde.named_parameters():
-                    off, shape = offs[name]
-                    grads.append(flat[off:off + p.numel()].view_as(p).to(p.dtype))
+                grads = engine.param_index(sde, ctx.layout[0]).grads_from_flat(flat)
         else:                 # generic adjoint kernels (any dims; Euler / Milstein / SRK) + batched autograd parameter pass
             adj = engine.solve_backward(call, grad_ys.to(torch.float32).contiguous())
             grads = _parameter_gradients(sde, call, grid, adj, method=ctx.method)
