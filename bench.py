@@ -50,12 +50,16 @@ PEAK_HBM_GBS = 8000.0
 # HBM bytes per launch of the solve kernel from rocprofv3 PMC passes (FETCH_SIZE doubled per the gfx950 correction
 # in MI355X_MICROARCH.md, + WRITE_SIZE; profiles/r02_pmc_counters.txt); re-measure when the kernel's memory behaviour changes.
 HBM_TRAFFIC_BYTES_PER_LAUNCH = 38085632   # K2, lean M4 kernel: (2 x 18084.5 + 1024.0) KB
+HBM_TRAFFIC_KERNEL = ('lean', 'snsde_m4_kernel<CfgL<128, 1, 2, 1, 0, 0>>')     # the path / instantiation the profile was taken on
 HBM_TRAFFIC_SOURCE = ("profiles/r03_pmc_counters.txt: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes over this bench command, "
                       "mean of 127 dispatches of the solve kernel), 2 x FETCH_SIZE + WRITE_SIZE per the gfx950 correction of "
                       "MI355X_MICROARCH.md; a constant of the kernel's memory behaviour, not re-measured in this run")
-# L2-fabric bytes of one K2 training step (forward + adjoint + weight gradients): profiles/r03_train_traffic.txt
-TRAIN_TRAFFIC_BYTES_PER_STEP = None       # filled from the profile below when present
-TRAIN_TRAFFIC_SOURCE = "profiles/r03_train_traffic.txt (tools/pmc_train_modes.sh: FETCH_SIZE / WRITE_SIZE summed over every kernel of 10 steps)"
+# L2-fabric bytes of one K2 training step (forward + adjoint + weight gradients): profiles/r04_train_traffic.txt
+TRAIN_TRAFFIC_FILE = 'r04_train_traffic.txt'
+TRAIN_TRAFFIC_SOURCE = ("profiles/r04_train_traffic.txt (tools/pmc_train_modes.sh: FETCH_SIZE / WRITE_SIZE summed over every kernel of 10 "
+                        "steps; a constant of the path's memory behaviour taken under rocprofv3, not re-measured in this run - valid while the "
+                        "forward path reported beside it is the profiled one)")
+TRAIN_TRAFFIC_PATHS = ('lean', 1)          # forward path / backward mode the profile was taken on
 
 
 def flops_drift(io, h, c, nl):
@@ -245,9 +249,23 @@ def _module(dev, io, no, rows, hh, cc, ll, seed, nan_frac=0.3):
     return sde, times, torch.from_numpy(pr['y0']).to(dev)
 
 
+def solve_kernel_ms(sde, y0, ts_host, method, stream, n=20, training=False, noise_table=None, model=None, flat=None, dt=1.0):
+    """HIP-event times of the SOLVE LAUNCH alone: a prepared engine.SolveCall relaunched with REUSE_PREPARED (no weight packing, no
+    host plumbing) - the kernel time the roofline fractions of the extra legs are computed from."""
+    if model is None:
+        model, layout, numel = S.engine.recognise(sde)
+        flat = S.engine.flatten_params(sde, layout, numel, y0.device)
+    grid = S.engine.step_grid(ts_host, dt, S.torchsde._HostTimes.get(sde.times), y0.device)
+    call = S.engine.SolveCall(model, flat, sde.coeffs, grid, y0, method=method, seed=5, save_traj=training, save_act=training,
+                              noise_table=noise_table)
+    call.launch(stream)
+    return event_times_ms(lambda: call.launch(stream, reuse_prepared=True), stream, n, 3)
+
+
 def train_leg(dev, stream, io, no, rows, hh, cc, ll, method, label, outputs='ends'):
     """sdeint forward and forward + backward (fused adjoint + native weight-gradient pass) of one Diffusion_model shape:
-    HIP-event medians of the whole calls, FLOP roofline (3 x forward for the training step)."""
+    HIP-event medians of the whole calls AND of the solve launch alone; the forward's roofline fraction is computed from the
+    kernel time (comparable with the headline's), the whole-call fraction is kept beside it."""
     sde, times, y0 = _module(dev, io, no, rows, hh, cc, ll, 77)
     ts = times if outputs == 'knots' else times[[0, -1]]
     params = list(sde.parameters())
@@ -265,17 +283,24 @@ def train_leg(dev, stream, io, no, rows, hh, cc, ll, method, label, outputs='end
 
     t_f = event_times_ms(fwd, stream, 20, 5)
     t_s = event_times_ms(step, stream, 20, 5)
+    t_k = solve_kernel_ms(sde, y0, ts.cpu().numpy(), method, stream)
+    t_kt = solve_kernel_ms(sde, y0, ts.cpu().numpy(), method, stream, training=True)
     n = ll - 1
     per_eval = flops_drift(io, hh, cc, 2)
     fl = (3 * per_eval + 4 * flops_net(no, hh)) if method == 'srk' else per_eval + flops_net(no, hh) * (2 if method == 'milstein' else 1)      # Milstein: + the VJP through the net
     model = S.engine.model_struct(cc, hh, hh, 2, io, no)
     out = {"workload": f"{label}: Diffusion_model (io={io},no={no}) NL=2, {rows} rows, H={hh}, C={cc}, {n} {method} steps, Philox increments",
            "forward_path": S.engine.forward_path(model, rows, ll, n, method=method),
+           "backward_mode": S.engine.backward_mode(model, rows, ll, S.engine.step_grid(ts.cpu().numpy(), 1.0, times.cpu().numpy(), dev), method),
            "forward": spread(t_f), "forward_backward": spread(t_s),
+           "forward_kernel": spread(t_k), "training_mode_forward_kernel": spread(t_kt),
            "value": rows * n / (float(np.median(t_f)) * 1e-3), "unit": "row-steps/s (forward)",
            "flop_per_rowstep": fl,
-           "roofline_forward": roofline_obj(rows * n * fl, float(np.median(t_f)) * 1e-3, "whole sdeint() forward call (HIP events); "
-                                            "algorithmic FLOPs per step: drift evaluations + diffusion-net evaluations of the scheme"),
+           "roofline_forward": roofline_obj(rows * n * fl, float(np.median(t_k)) * 1e-3, "the solve launch alone (HIP events around a "
+                                            "REUSE_PREPARED relaunch: same basis as the headline's roofline.frac); algorithmic FLOPs per "
+                                            "step: drift evaluations + diffusion-net evaluations of the scheme"),
+           "roofline_forward_whole_call": roofline_obj(rows * n * fl, float(np.median(t_f)) * 1e-3, "whole sdeint() forward call incl. "
+                                                       "weight packing and host plumbing (HIP events)"),
            "roofline_training": roofline_obj(3 * rows * n * fl, float(np.median(t_s)) * 1e-3, "whole forward + backward call: 3 x forward FLOPs")}
     return out
 
@@ -285,15 +310,18 @@ def k2_training(dev, stream):
     traffic (from the committed PMC profile; the step is neither FLOP- nor HBM-bound but a chain of latency-bound launches)."""
     out = train_leg(dev, stream, IO, NO, B, H, C, L, 'euler', 'K2 training step')
     traffic = None
-    path = os.path.join(ROOT, 'profiles', 'r03_train_traffic.txt')
+    path = os.path.join(ROOT, 'profiles', TRAIN_TRAFFIC_FILE)
     if os.path.exists(path):
         for line in open(path):
             if line.startswith('current default'):
                 traffic = float(line.split('total')[1].split('MB')[0]) * 1e6
     sec = out["forward_backward"]["median_ms"] * 1e-3
-    if traffic:
+    if traffic and (out["forward_path"], out["backward_mode"]) == TRAIN_TRAFFIC_PATHS:      # (the profiled kernels are the launched ones)
         out["roofline_bytes"] = {"bound": "hbm", "achieved": traffic / sec / 1e9, "peak": PEAK_HBM_GBS, "unit": "GB/s",
                                  "frac": traffic / sec / 1e9 / PEAK_HBM_GBS, "traffic": traffic, "traffic_source": TRAIN_TRAFFIC_SOURCE}
+    elif traffic:
+        out["roofline_bytes"] = {"error": f"forward path / backward mode {(out['forward_path'], out['backward_mode'])} differ from the "
+                                          f"profiled {TRAIN_TRAFFIC_PATHS}: the constant of {TRAIN_TRAFFIC_FILE} does not apply"}
     return out
 
 
@@ -350,8 +378,20 @@ def tutorial_field(dev, stream, kind='lnsde', rows=1024, hh=128, n=100):
         eager_opt = spread(event_times_ms(opt_step, stream, 20, 3))
     except Exception as exc:      # (reported, never fatal for the bench line)
         graphed, eager_opt = {"error": f"{type(exc).__name__}: {exc}"}, None
+    cf = S.fields.compose(field)
+    ts_host = ts.cpu().numpy()
+    grid = S.engine.step_grid(ts_host, 1.0 / n, times, dev)
+    with torch.no_grad():
+        flat_c, tab_c = cf.inference_inputs(grid.d_t0, dev)
+    t_k = solve_kernel_ms(field, y0, ts_host, 'euler', stream, model=cf.model, flat=flat_c, noise_table=tab_c, dt=1.0 / n)
+    fl = flops_drift(cf.model.input_option, hh, cc, cf.model.num_hidden_layers)      # the composed block the kernel evaluates
     return {"workload": f"tutorial Neural{kind.upper()}Func-shaped field (LipSwish, num_layers=1), {rows} rows, H={hh}, C={cc}, {n} Euler "
                         "steps, whole sdeint() call incl. weight composition + noise table",
+            "forward_path": S.engine.forward_path(cf.model, rows, len(times), n, table=True),
+            "fused_kernel": spread(t_k), "flop_per_rowstep": fl,
+            "roofline": roofline_obj(rows * n * fl, float(np.median(t_k)) * 1e-3, "the solve launch alone; FLOPs of the composed "
+                                     "(input_option, NL) block the kernel evaluates per step (the time-only diffusion is a per-solve table)"),
+            "roofline_whole_call": roofline_obj(rows * n * fl, float(np.median(fused)) * 1e-3, "whole sdeint() call incl. composition + table"),
             "fused": spread(fused), "generic_graph_stepper": spread(generic),
             "fused_forward_backward": spread(fused_train), "tensor_loop_forward_backward": spread(loop_train),
             "optimizer_step_eager": eager_opt, "optimizer_step_graph_replayed": graphed,
@@ -380,6 +420,13 @@ def latent_sde(dev, stream, rows=1024, hidden=32, L=50):
             o, latent, kl = m(coeffs, times, method='srk', options=opts)
             (o.square().mean() + 1e-3 * kl).backward()
         out[key + "_training_step"] = spread(event_times_ms(step, stream, n, 2))
+    hl, hh_ = hidden - 1, hidden
+    fl = 3 * 2 * ((hl + 2) * hh_ + hh_ * hh_ + hh_ * hl)       # SRID2: three drift evaluations of the posterior MLP per step (constant diffusion)
+    steps = L - 1
+    out["flop_per_rowstep"] = fl
+    out["roofline"] = roofline_obj(rows * steps * fl, out["fused_forward"]["median_ms"] * 1e-3,
+                                   "whole wrapper forward (spline start, solve, KL): the module's algorithmic drift FLOPs; "
+                                   "at 31 latent channels the solve is latency-bound and the call is dominated by launches, not FLOPs")
     return out
 
 
@@ -479,6 +526,8 @@ def main():
         ach_tf = rowsteps * FLOP_PER_ROWSTEP / (kern_ms * 1e-3) / 1e12
         exe_tf = rowsteps * EXECUTED_FLOP_PER_ROWSTEP / (kern_ms * 1e-3) / 1e12
         ach_gbs = rowsteps * BYTES_PER_ROWSTEP / (kern_ms * 1e-3) / 1e9
+        launched = S.engine.forward_path(model, B, L, NSTEP, kernel=args.kernel)
+        traffic = HBM_TRAFFIC_BYTES_PER_LAUNCH if launched == HBM_TRAFFIC_KERNEL[0] and not args.exact_order else None
         out = {
             "metric": "SDE solver steps/sec (batch x steps / s), forward solve",
             "value": value, "unit": "row-steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -491,8 +540,9 @@ def main():
             "timing": {"solve_call": spread(t_call), "solve_kernel": spread(t_kern),
                        "method": "HIP events on the launch stream, one pair per solve, after 10 warm-ups (SURVEY 8d)"},
             "roofline": {"bound": "mfma", "achieved": ach_tf, "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s",
-                         "frac": ach_tf / PEAK_FP32_TFLOPS, "traffic": HBM_TRAFFIC_BYTES_PER_LAUNCH,
-                         "traffic_source": HBM_TRAFFIC_SOURCE,
+                         "frac": ach_tf / PEAK_FP32_TFLOPS, "traffic": traffic,
+                         "traffic_source": HBM_TRAFFIC_SOURCE if traffic else f"none: the launched path {launched!r} is not the profiled one",
+                         "launched_path": launched, "profiled_kernel": HBM_TRAFFIC_KERNEL[1],
                          "kernel_ms": kern_ms, "flop_per_rowstep": FLOP_PER_ROWSTEP,
                          "executed_flop_per_rowstep": EXECUTED_FLOP_PER_ROWSTEP, "executed_frac": exe_tf / PEAK_FP32_TFLOPS,
                          "mfma_issue_cycles_per_simd_step": MFMA_CYCLES_PER_STEP,
