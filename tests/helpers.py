@@ -96,6 +96,10 @@ def make_problem(seed, io, no, NL, B, H, C, L, times=None, nan_frac=0.2, y0_scal
         mask = rng.random((B, L, C)) < nan_frac
         mask[:, :, 0] = False
         X[mask] = np.nan
+    # The coefficients of the parity inputs are built with THIS package's CPU construction (the batched tensor-op version of
+    # controldiffeq.natural_cubic_spline_coeffs / the Hermite formula).  That is not circular for the solver tests: the same
+    # coefficient array goes to the kernels and to the oracle, and the construction itself is pinned bit-level to the
+    # reference's own vendored code by the G1 fixtures (tests/test_oracle_golden.py, test_gpu_parity.py::test_natural_spline_*).
     Xt, tt = torch.from_numpy(X), torch.from_numpy(times)
     if hermite:
         coeffs = S.torchcde.hermite_cubic_coefficients_with_backward_differences(Xt, tt)
@@ -139,6 +143,23 @@ def assert_parity(got, ref64, cpu32=None, what='', amplifying=False):
         rep.update(p999=float(np.quantile(e, 0.999)), cpu_p999=float(np.quantile(e32, 0.999)))
         assert rep['mean'] <= 4 * rep['cpu_mean'] + 1e-7, (what, rep)
         assert rep['p999'] <= 4 * rep['cpu_p999'] + 1e-6, (what, rep)
+        # ... and SURVEY 8c's ABSOLUTE bounds on the rows where fp32 arithmetic itself stays on the fp64 trajectory.  Which rows
+        # leave it is a property of the row, not of the rounding: at the K3 shape (512 rows, 200 GSDE steps) the CPU-fp32 run
+        # leaves the tolerance band on 96 rows, a second fp32 run with every increment moved by one ulp on 95, 92 of them the same
+        # (a saturating step late in the horizon turns an error of 1e-4 into 0.6; measured with the numpy oracle, round 4).  So:
+        # on the rows the CPU-fp32 run keeps inside the band, mean <= 1e-5, at most 3 % of those rows may leave the band in the
+        # kernel's run (its own few flips), and on the rows inside the band in both runs max <= 5e-3.
+        tol = 1e-4 + 1e-4 * np.abs(ref64)
+        other = tuple(i for i in range(e.ndim) if i != e.ndim - 2)
+        stable = ~((e32 > tol).any(axis=other))
+        got_out = (e > tol).any(axis=other)
+        both = stable & ~got_out
+        rep.update(stable_rows=int(stable.sum()), rows=int(stable.size), stable_rows_left_by_kernel=int((stable & got_out).sum()),
+                   stable_mean=float(np.take(e, np.nonzero(both)[0], axis=e.ndim - 2).mean()) if both.any() else 0.0,
+                   stable_max=float(np.take(e, np.nonzero(both)[0], axis=e.ndim - 2).max()) if both.any() else 0.0)
+        assert rep['stable_rows'] >= 0.5 * rep['rows'], (what, rep)
+        assert rep['stable_rows_left_by_kernel'] <= 0.03 * rep['stable_rows'] + 1, (what, rep)
+        assert rep['stable_mean'] <= 1e-5 and rep['stable_max'] <= 5e-3, (what, rep)
         return rep
     assert rep['mean'] <= 1e-5, (what, rep)
     assert rep['frac_ok'] >= 0.9999, (what, rep)

@@ -196,34 +196,57 @@ FD_CASES = [
     (3, 18, 2, 7, 128, 4, 6, 'srk', 'mfma4'),           # README's neuralsde_3_18 at H = 128 (net matrices parked in LDS)
     (3, 18, 2, 8, 64, 4, 6, 'milstein', 'auto'),        # Milstein through a diffusion net (dense dg/dy)
     (5, 15, 1, 8, 32, 4, 6, 'milstein', 'auto'),
+    # round 4: per-row output selection (the fused gather of NeuralSDE.forward), SRK with the forward on 16-row
+    # tiles (the adjoint walks the same saves on 4-row tiles), a 50-step solve with sparse outputs, more than 9 knots
+    (4, 17, 2, 11, 64, 5, 9, 'euler', 'auto', {'row_out': True}),
+    (3, 18, 2, 10, 64, 6, 8, 'srk', 'auto', {'row_out': True}),
+    (4, 17, 2, 20, 64, 5, 7, 'srk', 'mfma16'),
+    (6, 17, 2, 19, 128, 7, 8, 'srk', 'mfma16'),
+    (4, 17, 2, 8, 32, 4, 51, 'euler', 'auto', {'ts': [0.0, 25.0, 50.0]}),
+    (2, 16, 2, 9, 64, 5, 14, 'milstein', 'auto', {'ts': [0.0, 4.5, 13.0]}),
 ]
 
 
 @pytest.mark.parametrize('case', FD_CASES)
 def test_fused_backward_vs_finite_differences_of_the_numpy_oracle(case):
-    io, no, NL, B, H, C, L, method, kernel = case
+    io, no, NL, B, H, C, L, method, kernel = case[:9]
+    extra = case[9] if len(case) > 9 else {}
     pr = make_problem(900 + io + no, io, no, NL, B, H, C, L)
-    ts = pr['times']
+    ts = np.asarray(extra['ts'], np.float32) if 'ts' in extra else pr['times']
     dW = draw_dW(900, ts, 1.0, B, H)
     rng = np.random.default_rng(901)
-    wsum = rng.standard_normal((L, B, H))
+    T = len(ts)
+    row_out = rng.integers(0, T, size=B).astype(np.int32) if extra.get('row_out') else None
+    if row_out is not None:
+        row_out[:2] = (0, T - 1)                 # the initial state and the last output are both somebody's row
+    wsum = rng.standard_normal((B, H) if row_out is not None else (T, B, H))
     spec = param_spec(io, no, NL, C, H)
     dU = None
     if method == 'srk':      # space-time Levy integrals on the scale of the increments (h = 1)
         dU = (0.5 * dW + np.sqrt(1.0 / 12) * rng.standard_normal(dW.shape)).astype(np.float32)
 
     def oracle_loss(params, y0):
-        ys, _ = O.solve_diffusion_model(params, io, no, pr['coeffs'], ts, y0, ts, 1.0, dW, method=method, dtype=np.float64, dU=dU)
+        ys, _ = O.solve_diffusion_model(params, io, no, pr['coeffs'], pr['times'], y0, ts, 1.0, dW, method=method, dtype=np.float64, dU=dU)
+        if row_out is not None:                  # NeuralSDE.forward's gather (neuralsde.py:115-116): row b reads output row_out[b]
+            ys = ys[row_out, np.arange(B)]
         return float((ys * wsum).sum())
 
     m = S.Diffusion_model(C, H, H, NL, input_option=io, noise_option=no)
     m.load_state_dict({k: torch.from_numpy(v.copy()) for k, v in pr['params'].items()})
     m = m.to(DEV)
-    m.set_X(torch.from_numpy(pr['coeffs']).to(DEV), torch.from_numpy(ts).to(DEV))
+    m.set_X(torch.from_numpy(pr['coeffs']).to(DEV), torch.from_numpy(pr['times']).to(DEV))
     y0 = torch.from_numpy(pr['y0']).to(DEV).requires_grad_(True)
+    opts = {'kernel': kernel, 'strict': True}
+    if row_out is not None:
+        opts['row_out'] = torch.from_numpy(row_out).to(DEV)
     ys = S.sdeint(m, y0, torch.from_numpy(ts).to(DEV),
                   bm=_ReplayBM(torch.from_numpy(dW).to(DEV), None if dU is None else torch.from_numpy(dU).to(DEV)), method=method, dt=1.0,
-                  options={'kernel': kernel, 'strict': True})
+                  options=opts)
+    assert tuple(ys.shape) == tuple(wsum.shape)
+    if kernel == 'mfma16' and method == 'srk':       # the configuration under test really is the 16-row-tile SRK forward
+        model = S.engine.model_struct(C, H, H, NL, io, no)
+        assert S.engine.forward_path(model, B, L, dW.shape[0], method='srk', kernel='mfma16') == 'mfma-srk'
+        assert S.engine.backward_mode(model, B, L, S.engine.step_grid(ts, 1.0, pr['times'], DEV), 'srk', 'mfma16') == 1
     (ys * torch.from_numpy(wsum.astype(np.float32)).to(DEV)).sum().backward()
     grads = {n: p.grad.detach().cpu().numpy().astype(np.float64) for n, p in m.named_parameters() if p.grad is not None}
     gy0 = y0.grad.cpu().numpy().astype(np.float64)

@@ -58,6 +58,30 @@ def test_batches_beyond_the_32_bit_save_offsets_take_the_generic_kernels():
     assert q(1 << 21, 'mfma') == ('none', 2)
 
 
+@pytest.mark.parametrize('pair', [(1, 0), (1, 18), (2, 16), (4, 17), (6, 17)])
+def test_make_model_configurations_stay_on_the_mfma_families(pair):
+    """The five (input_option, noise_option) pairs the reference's make_model builds (benchmark_classification/common_sde.py:301-342)
+    x {euler, srk, milstein} x H in {16, 32, 64, 128} x the benchmark batch sizes x narrow / sepsis-wide control paths: the forward
+    takes an MFMA kernel family and the backward is mode 1 (MFMA adjoint + native parameter pass).  Host-side queries of the
+    library (snsde_forward_path / snsde_backward_supported), so a silent fall to the generic kernels fails CI on every round, GPU
+    or not.  The one known hole is listed: Milstein through a TWO-layer diffusion net at H = 128 (its four net matrices + the drift
+    exceed registers + LDS; the reference never uses Milstein: SURVEY 0.4)."""
+    io, no = pair
+    known_generic = {(1, 18, 'milstein', 128)}
+    for method in ('euler', 'srk', 'milstein'):
+        for H in (16, 32, 64, 128):
+            for B in (256, 1024, 4096):
+                for C_, L in ((21, 101), (69, 72)):
+                    model = S.engine.model_struct(C_, H, H, 2, io, no)
+                    path = S.engine.forward_path(model, B, L, L - 1, method=method)
+                    grid = S.engine.step_grid(np.array([0.0, L - 1.0], np.float32), 1.0, np.arange(L, dtype=np.float32), None)
+                    mode = S.engine.backward_mode(model, B, L, grid, method)
+                    if (io, no, method, H) in known_generic:
+                        assert (path, mode) == ('generic', 2), (io, no, method, H, B, C_, path, mode)
+                    else:
+                        assert path in ('lean', 'mfma4', 'mfma16', 'mfma-srk') and mode == 1, (io, no, method, H, B, C_, path, mode)
+
+
 def test_stale_binding_is_refused():
     """A descriptor whose struct_size is not the library's sizeof (a binding compiled against an older header) is refused with
     SNSDE_ERR_ABI before any field is read; snsde_abi_check verifies a binding's sizes at load time."""
