@@ -186,6 +186,18 @@ typedef struct snsde_solve {
                               /* buffer, the library fills it in the same launch that packs the weights.                   */
     void*          workspace; /* device scratch, >= snsde_workspace_bytes()                      */
     size_t         workspace_bytes;
+    /* Path-integral accumulator column (torch-ists LatentSDE.f_aug / g_aug, diff_module/NSDE/latent_sde.py:60-89): when
+     * kl_column1 = 1 + c > 0, state column c is NOT driven by the drift net but integrates, with the scheme's own drift
+     * weights and no noise,  u(t, y) = 1/2 sum_{j < c} ((f_j(t, y) - (kl_prior_a y_j + kl_prior_b)) / g_j)^2  - the KL rate
+     * between the posterior drift f and the linear prior drift theta (mu - y) (a = -theta, b = theta mu) under the shared
+     * diagonal diffusion g (the solve's additive noise_table, |g| floored at 1e-7 as the reference's _stable_division).
+     * Columns above c must be padding (zero weights).  Field variants on the 4-row-tile kernels only (SNSDE_DRIFT_LINEAR,
+     * SNSDE_DIFFUSION_RAW with a noise_table, noise_option 12): Euler / Milstein on the lean kernel, SRK on the SRK variant;
+     * the MFMA adjoints carry the accumulator's cotangent back into the drift (snsde_backward_supported == 1).            */
+    int32_t        kl_column1;
+    float          kl_prior_a;
+    float          kl_prior_b;
+    int32_t        reserved2;  /* must be 0                                                          */
 } snsde_solve;
 
 SNSDE_API size_t snsde_workspace_bytes(const snsde_solve* s);

@@ -46,7 +46,8 @@ class Solve(_Sized):
                 ('ys', C.c_void_p), ('traj', C.c_void_p), ('dW_out', C.c_void_p), ('srk_tab', C.c_void_p), ('dU', C.c_void_p),
                 ('dU_out', C.c_void_p), ('act_save', C.c_void_p), ('stage_save', C.c_void_p), ('seed_dev', C.c_void_p), ('noise_table', C.c_void_p), ('row_out', C.c_void_p),
                 ('z0_weight', C.c_void_p), ('z0_bias', C.c_void_p),
-                ('workspace', C.c_void_p), ('workspace_bytes', C.c_size_t)]
+                ('workspace', C.c_void_p), ('workspace_bytes', C.c_size_t),
+                ('kl_column1', C.c_int32), ('kl_prior_a', C.c_float), ('kl_prior_b', C.c_float), ('reserved2', C.c_int32)]
 
 
 class Backward(_Sized):

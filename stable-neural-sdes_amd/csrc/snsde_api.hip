@@ -330,6 +330,7 @@ static int validate_solve(const snsde_solve* s, bool eval) {
         if (s->method == SNSDE_MILSTEIN && no == 7) return SNSDE_ERR_UNSUPPORTED;
         if (s->noise_table && no != 12 && no != 13) return SNSDE_ERR_OPTION;   // a supplied table is the time-only factor
         if ((s->z0_weight != nullptr) != (s->z0_bias != nullptr)) return SNSDE_ERR_NULL;
+        if (s->kl_column1 < 0 || s->kl_column1 > s->model.hidden_channels || s->reserved2 != 0) return SNSDE_ERR_DIMS;
     }
     return SNSDE_OK;
 }

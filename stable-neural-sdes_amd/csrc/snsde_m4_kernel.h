@@ -27,8 +27,9 @@
 
 namespace snsde_mfma {
 
-template <int H_, int NHID_, int KUXT_, int YIN_, int SAVE_, int ACT_ = 0>
+template <int H_, int NHID_, int KUXT_, int YIN_, int SAVE_, int ACT_ = 0, int ACC_ = 0>
 struct CfgL {
+    static constexpr bool ACC = ACC_ != 0;      // path-integral accumulator column (snsde.h: kl_column1): the LatentSDE mapping's instantiations
     static constexpr bool SWISH = ACT_ != 0;    // hidden activation scale * x * sigmoid(x) (LipSwish / SiLU) instead of relu
     static constexpr int H = H_, NHID = NHID_, KUXT = KUXT_;
     static constexpr bool YIN = YIN_ != 0;      // the first layer reads y (every input_option but 0)
@@ -49,7 +50,8 @@ struct CfgL {
     static constexpr int ROWCH = 128;
     static constexpr int XI = KUXT > 0 ? (4 * 16 * KUXT + NT - 1) / NT : 1;   // [X(t) | sin t, cos t] entries per lane (4 rows, spread over ALL waves)
     static constexpr int RS = 8;                              // floats per step in the kernel's own table: quad A, quad B
-    static constexpr int LDS_FLOATS = 4 * (LDY + 2 * LDX + 2 * LDA) + (ROWCH + 3) * RS + NW * ZSTASH;
+    static constexpr int ACCF = 64;                           // per-wave row sums of the path-integral accumulator (4 x NW <= 64)
+    static constexpr int LDS_FLOATS = 4 * (LDY + 2 * LDX + 2 * LDA) + (ROWCH + 3) * RS + NW * ZSTASH + ACCF;
 };
 
 // tanh(x) = copysign((1 - t) / (1 + t), x), t = 2^(-2 log2(e) |x|) in (0, 1]: no cancellation beyond the rounding of t
@@ -265,6 +267,7 @@ __global__ void __launch_bounds__(CF::NT, CF::WPS) snsde_m4_kernel(MfmaArgs a) {
     float* bufB = bufA + 4 * LDA;            // [4][LDA]
     float* rowtab = bufB + 4 * LDA;          // [ROWCH + 3][RS]  step i: (h_i, sqrt h_{i+1}, -, - | sin t, cos t, frac of step i+1, idx of step i+2)
     float* zstash_all = rowtab + (CF::ROWCH + 3) * RS;
+    float* accbuf = zstash_all + CF::NW * CF::ZSTASH;      // [NW][4]
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -578,6 +581,26 @@ __global__ void __launch_bounds__(CF::NT, CF::WPS) snsde_m4_kernel(MfmaArgs a) {
         float f;
         if (__builtin_expect(f_out != SNSDE_DRIFT_TANH, 0)) f = f_out == SNSDE_DRIFT_TIMES_Y ? z * yv : z;
         else f = LEAN_TANH_F(z);
+        if constexpr (CF::ACC) {
+            // path-integral accumulator column (snsde.h: kl_column1; the field variants' LatentSDE mapping): its drift is the KL rate
+            // u = 1/2 sum_j ((f_j - a y_j - b) / g_j)^2 over the latent columns j < acc_col of the tile row: per-wave row sums
+            // through LDS and one more barrier per step; the owner lane takes u as its drift value
+            if (__builtin_expect(a.acc_col >= 0, 0)) {
+                float ev = 0.0f;
+                if (fo < a.acc_col) {
+                    const float qv = (f - fmaf(a.acc_a, yv, a.acc_b)) * snsde_stable_inv(gt_cur);
+                    ev = 0.5f * qv * qv;
+                }
+                ev = m4_row_sum(ev);
+                if (lane < 4) accbuf[wave * 4 + lane] = ev;
+                __syncthreads();
+                if (fo == a.acc_col) {
+                    float u = 0.0f;
+                    for (int w = 0; w < CF::NW; ++w) u += accbuf[w * 4 + r];
+                    f = u;
+                }
+            }
+        }
         const float ynew = fmaf(f, h, ypart);
         yold = yv;
         yv = ynew;
@@ -629,6 +652,17 @@ int launch_lean(const MfmaArgs& a, hipStream_t stream) {
 template <int H>
 int dispatch_lean(const MfmaPlan& p, const MfmaArgs& a, hipStream_t st) {
     const bool save = a.act_save || a.traj || a.dW_out;
+    if (a.acc_col >= 0) {               // the LatentSDE mapping (fields.compose_latent): relu, one control k-block, y-dependent drift
+#ifndef SNSDE_DEV_SUBSET
+#define SNSDE_LEAN_ACC(NH_) \
+    if constexpr (lean_fits(H, NH_, 1, true) && lean_act_save_fits(H, NH_, 1)) { \
+        if (p.NHID == NH_ && p.KUXT == 1 && p.IO != 0 && a.act == SNSDE_ACT_RELU) \
+            return save ? launch_lean<CfgL<H, NH_, 1, 1, 1, 0, 1>>(a, st) : launch_lean<CfgL<H, NH_, 1, 1, 0, 0, 1>>(a, st); }
+        SNSDE_LEAN_ACC(0) SNSDE_LEAN_ACC(1) SNSDE_LEAN_ACC(2) SNSDE_LEAN_ACC(3)
+#undef SNSDE_LEAN_ACC
+#endif
+        return SNSDE_ERR_UNSUPPORTED;
+    }
     if (a.act != SNSDE_ACT_RELU) {      // tutorial fields (LipSwish / SiLU): y-dependent drift on [y | X, t], C + 1 <= 48
     // (training mode also stores the pre-activations: one more live register, so the fullest configurations are inference-only)
 #define SNSDE_LEAN_ACT(NH_, KX_) \

@@ -394,6 +394,14 @@ MfmaPlan make_plan(const snsde_solve* s, const SnsdeNet& net, int flavor_hint) {
         off = (off + 3) & ~3;
     }
     p.total_floats = off;
+    // path-integral accumulator column (snsde.h: kl_column1): the lean 4-row-tile kernel (Euler / Milstein, H <= 128) and the SRK
+    // variant of the general kernel on 4-row tiles, for the LatentSDE mapping only: linear drift output, raw additive table
+    if (s->kl_column1 != 0) {
+        const bool shape_ok = s->kl_column1 >= 2 && s->kl_column1 <= H && m.drift_output == SNSDE_DRIFT_LINEAR &&
+                              m.diffusion_output == SNSDE_DIFFUSION_RAW && s->noise_table != nullptr && no == 12 && p.NN == 0 && io != 0;
+        const bool kernel_ok = (p.LEAN && H <= 128 && !srk) || (srk && p.FL == 1 && !m4n);
+        if (!shape_ok || !kernel_ok) return p;
+    }
     p.ok = true;
     return p;
 }
@@ -573,6 +581,7 @@ int snsde_mfma_launch(const snsde_solve* s, const SnsdeNet& net, hipStream_t str
         a.raw_time = s->model.time_feature; a.gt_ext = s->noise_table;       // (N, 4, H): the table at the four stage times
     }
     a.row_offset = s->row_offset; a.seed = s->seed; a.seed_dev = s->seed_dev;
+    a.acc_col = s->kl_column1 - 1; a.acc_a = s->kl_prior_a; a.acc_b = s->kl_prior_b;
     a.B = s->batch; a.L = s->knots; a.C = s->model.input_channels; a.N = s->n_steps; a.T = s->n_out;
     a.method = s->method; a.no = s->model.noise_option;
     a.off_theta = net.off_theta; a.gt_off = p.gt_off; a.bias_off = p.bias_off;
@@ -689,6 +698,8 @@ int snsde_mfma_backward_launch(const snsde_backward* b, const SnsdeNet& net, hip
     if (!a.dW && (p.SRK || p.M4N || s->seed_dev)) return SNSDE_ERR_NULL;      // (regeneration: the Euler / Milstein kernel, host key)
     a.grad_ys = b->grad_ys; a.adj = b->adj; a.delta = b->delta_save; a.row_out = s->row_out;
     a.adj0_only = (b->flags & SNSDE_BWD_ADJ0_ONLY) ? 1 : 0;
+    a.acc_col = s->kl_column1 - 1; a.acc_a = s->kl_prior_a; a.acc_b = s->kl_prior_b;
+    if (a.acc_col >= 0 && (p.FL != 1 || p.M4N || p.H > 128)) return SNSDE_ERR_UNSUPPORTED;      // (the 4-row-tile Euler / SRK adjoints carry it)
     if (a.adj0_only && p.M4N == 2) return SNSDE_ERR_OPTION;      // (its weight-gradient jobs read every a_n)
     if (p.SRK) {
         if (!s->dU_out) return SNSDE_ERR_NULL;

@@ -96,6 +96,8 @@ struct MfmaArgs {
     int32_t lean_xc, lean_time, lean_geo;   // lean M4 kernel: control channels in the xt block, time features on, z *= tanh(y)
     int32_t act, f_out, g_out, raw_time;    // field variants (include/snsde.h: SNSDE_ACT_*, SNSDE_DRIFT_*, SNSDE_DIFFUSION_*, SNSDE_TIME_*)
     const float* gt_ext;                    // caller-supplied time-only diffusion table (N, H) or null
+    int32_t acc_col;                        // path-integral accumulator column (snsde_solve.kl_column1 - 1), -1: none
+    float acc_a, acc_b;                     // its linear prior drift a y + b
 };
 
 __host__ __device__ constexpr int ld_for(int K, int pad) { return ((K - pad + 63) / 64) * 64 + pad; }
@@ -135,6 +137,17 @@ __device__ __forceinline__ float m4_reduce_scatter(f32x4 v) {
 }
 
 // y-only closed-form diffusions (noise_option 7..10, neuralsde.py:250-261): raw = phi(y) with its first two derivatives
+// 1 / g with |g| floored at 1e-7 (the reference's _stable_division, latent_sde.py:25-27)
+__device__ __forceinline__ float snsde_stable_inv(float g) {
+    const float gs = fabsf(g) > 1e-7f ? g : copysignf(1e-7f, g) * (g != 0.0f ? 1.0f : 0.0f);
+    return 1.0f / gs;
+}
+// sum of v over the lanes of a 4-row-tile wave that share the batch row (lane & 3): the wave's 16 features
+__device__ __forceinline__ float m4_row_sum(float v) {
+    v += __shfl_xor(v, 4, 64); v += __shfl_xor(v, 8, 64); v += __shfl_xor(v, 16, 64); v += __shfl_xor(v, 32, 64);
+    return v;
+}
+
 __device__ __forceinline__ float snsde_phi(int no, float y, float& r1, float& r2) {
     if (no == 7) { const float q = sqrtf(y); r1 = 0.5f / q; r2 = -0.25f / (q * y); return q; }
     if (no == 8) { r1 = 3.0f * y * y; r2 = 6.0f * y; return y * y * y; }
@@ -840,6 +853,27 @@ __global__ void __launch_bounds__(CF::NT, CF::WPS) snsde_mfma_kernel(MfmaArgs a)
                 if constexpr (CF::SRK) {
                     // field variants (tutorial-style fields): f = z or z * (the pass's input state), g = raw
                     if (__builtin_expect(a.f_out != 0, 0)) f = a.f_out == SNSDE_DRIFT_TIMES_Y ? z * y : z;
+                    if constexpr (FL && CF::NN == 0) {
+                        // path-integral accumulator column (snsde.h: kl_column1): its drift at this pass's (t, H0) is the KL rate
+                        // u = 1/2 sum_j ((f_j - a y_j - b) / g_j)^2 over the latent columns j < acc_col - a sum over the tile row,
+                        // i.e. over the lanes of every wave: per-wave row sums through LDS (nbuf is free without a diffusion net),
+                        // one more barrier per pass; the owner lane takes u as ITS drift value and the scheme does the rest
+                        if (__builtin_expect(a.acc_col >= 0, 0)) {
+                            float ev = 0.0f;
+                            if (fcol[t] < a.acc_col) {
+                                const float q = (f - fmaf(a.acc_a, y, a.acc_b)) * snsde_stable_inv(sk_t0[e]);
+                                ev = 0.5f * q * q;
+                            }
+                            ev = m4_row_sum(ev);
+                            if (lane < 4) nbuf[wave * 4 + lane] = ev;
+                            __syncthreads();
+                            if (fcol[t] == a.acc_col) {
+                                float u = 0.0f;
+                                for (int w = 0; w < CF::NW; ++w) u += nbuf[w * 4 + r];
+                                f = u;
+                            }
+                        }
+                    }
                     auto gfun = [&](float gq, float yy) {
                         float q1, q2;
                         const float raw = yfun ? snsde_phi(no, yy, q1, q2) : (mul_y ? gq * yy : gq);
@@ -987,7 +1021,8 @@ struct CfgR {
     static constexpr int ROWCH = 128;
     static constexpr bool STREAM = H > 128;
     static constexpr bool RING = STREAM && FL;   // transposed weights through the per-wave LDS ring (as snsde_m4s_kernel.h)
-    static constexpr int RING0 = NBUF * M * LDA + (ROWCH + 1) * SNSDE_STEP_STRIDE;        // multiple of 4 floats
+    static constexpr int ACC0 = NBUF * M * LDA + (ROWCH + 1) * SNSDE_STEP_STRIDE;         // 16 floats: the accumulator column's cotangent per tile row
+    static constexpr int RING0 = ACC0 + 16;                                                // multiple of 4 floats
     static constexpr int LDS_FLOATS = RING0 + (RING ? NW * 8 * 256 : 0);
 };
 
@@ -1017,6 +1052,8 @@ struct RevArgs {
     // Euler / Milstein adjoint regenerates them (same call, same product z * sqrt h: bit-identical)
     uint64_t seed;
     int64_t row_offset;
+    int32_t acc_col;                   // path-integral accumulator column (-1: none) and its prior drift a y + b
+    float acc_a, acc_b;
 };
 
 // d/dx [scale * x * sigmoid(x)]  (LipSwish: scale = 0.909, SiLU: 1)
@@ -1181,6 +1218,17 @@ __global__ void __launch_bounds__(CF::NT, CF::WPS) snsde_mfma_reverse_kernel(Rev
 #pragma unroll
             for (int e = 0; e < EPT; ++e) (a.adj + uoff(n + 1, BH32))[goff + e] = adj[e];
         }
+        // path-integral accumulator column (snsde.h: kl_column1): its state adjoint x h is the cotangent of the KL rate u of this step;
+        // the owner lane publishes it to the tile row (one more barrier per step), every latent lane adds d u / d f_j and d u / d y_j
+        float fbA = 0.0f;
+        if constexpr (FL) {
+            if (__builtin_expect(a.acc_col >= 0, 0)) {
+                float* accb = lds + CF::ACC0;
+                if ((int)fcol == a.acc_col) accb[r] = adj[0] * h;
+                __syncthreads();
+                fbA = accb[r];
+            }
+        }
         // ---- elementwise: d(f h + g dW)/d(zout, y) applied to the adjoint ----
         float ay[EPT], dz[EPT], dsv[EPT], dq[EPT];
 #pragma unroll
@@ -1194,6 +1242,16 @@ __global__ void __launch_bounds__(CF::NT, CF::WPS) snsde_mfma_reverse_kernel(Rev
                 if (a.f_out == SNSDE_DRIFT_TANH) { const float f = fast_tanh(z); fz = 1.0f - f * f; }
                 else if (a.f_out == SNSDE_DRIFT_TIMES_Y) { fz = y; acc = fmaf(av * h, z, acc); }
                 dz[e] = av * h * fz;
+                if (FL && __builtin_expect(a.acc_col >= 0, 0)) {      // (linear drift output: f = z)
+                    if ((int)fcol < a.acc_col) {
+                        const float inv = snsde_stable_inv(gq);
+                        const float ue = (z - fmaf(a.acc_a, y, a.acc_b)) * inv * inv * fbA;      // fbA d u / d f_j
+                        dz[e] += ue;
+                        acc = fmaf(-a.acc_a, ue, acc);                                           // fbA d u / d y_j
+                    } else if ((int)fcol == a.acc_col) {
+                        dz[e] = 0.0f;                                  // the owner's drift is u, not the net's output
+                    }
+                }
                 const float qq = mil * fmaf(dw, dw, -h);
                 float d = 0.0f;
                 if constexpr (NN > 0) {
@@ -1484,6 +1542,7 @@ __global__ void __launch_bounds__(CF::NT, CF::WPS) snsde_mfma_srk_reverse_kernel
         }
     };
     load_masks(3 * a.N - 1, mk);
+    float acc_inv = 0.0f;          // accumulator column: 1 / g of the own column (additive table, constant over the step)
     auto chain = [&](int p, float cot, float hin, float z, float F) {
         if (p > 0) load_masks(p - 1, mk_next);
         float ty = 1.0f;
@@ -1495,6 +1554,21 @@ __global__ void __launch_bounds__(CF::NT, CF::WPS) snsde_mfma_srk_reverse_kernel
         if (__builtin_expect(variant, 0)) {
             if (a.f_out == SNSDE_DRIFT_TIMES_Y) { dz = cot * hin; direct = cot * z; }
             else if (a.f_out == SNSDE_DRIFT_LINEAR) dz = cot;
+        }
+        if (__builtin_expect(a.acc_col >= 0, 0)) {
+            // path-integral accumulator column: the owner's cotangent of ITS drift value of this pass (= of the KL rate u(t_s, H0_s))
+            // is published to the tile row; the latent lanes add fbA d u / d F_j to their drift cotangent and fbA d u / d H0_j directly
+            float* accb = lds + CF::ACC0;
+            if (fcol == a.acc_col) accb[r] = cot;
+            __syncthreads();
+            const float fbA = accb[r];
+            if (fcol < a.acc_col) {
+                const float ue = (F - fmaf(a.acc_a, hin, a.acc_b)) * acc_inv * acc_inv * fbA;
+                dz += ue;
+                direct = fmaf(-a.acc_a, ue, direct);
+            } else if (fcol == a.acc_col) {
+                dz = 0.0f; direct = 0.0f;
+            }
         }
         lds[r * LDA + fcol] = dz;
         if (a.delta && row_ok) (a.delta + uoff(p, NGBH))[goff] = dz;
@@ -1563,6 +1637,7 @@ __global__ void __launch_bounds__(CF::NT, CF::WPS) snsde_mfma_srk_reverse_kernel
         // ---- recompute the stage values of the step for the own element ----
         const float y = cur.y, ik = cur.ik, ik0 = cur.ik0, z0 = cur.z0, z1 = cur.z1, z2 = cur.z2;
         const float t0v = cur.t0v, t1v = cur.t1v, t3v = cur.t3v;
+        if (__builtin_expect(a.acc_col >= 0, 0)) acc_inv = snsde_stable_inv(t0v);
         auto gate = [&](float hv) { return CF::GEO ? fast_tanh(hv) : 1.0f; };
         auto fout = [&](float z, float hv) {
             if (__builtin_expect(variant, 0)) {

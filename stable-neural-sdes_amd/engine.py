@@ -411,7 +411,7 @@ class SolveCall:
 
     def __init__(self, model, flat_params, coeffs, grid, y0, dW=None, method='euler', seed=0, row_offset=0,
                  kernel='auto', save_traj=False, save_dW=False, exact_order=False, save_act=False, dU=None, row_out=None,
-                 noise_table=None, z0_linear=None):
+                 noise_table=None, z0_linear=None, kl_column=None):
         B, H = y0.shape
         C_ = model.input_channels
         L = coeffs.shape[1] + 1
@@ -446,7 +446,7 @@ class SolveCall:
         self.cfg_key = (model.input_channels, model.hidden_channels, model.hidden_hidden_channels, model.num_hidden_layers,
                         model.input_option, model.noise_option, model.activation, model.drift_output, model.diffusion_output,
                         model.time_feature, B, L, grid.N, grid.T, method, kernel, bool(exact_order), noise_table is not None,
-                        dW is not None, row_out is not None)
+                        dW is not None, row_out is not None, None if kl_column is None else int(kl_column[0]))
         if save_act:
             lay = _SIZE_CACHE.get(('layout',) + self.cfg_key)
             if lay is None:
@@ -485,6 +485,8 @@ class SolveCall:
         s.noise_table = _ptr(noise_table)
         if z0_linear is not None:
             s.z0_weight, s.z0_bias = _ptr(z0_linear[0]), _ptr(z0_linear[1])
+        if kl_column is not None:     # (column, a, b): path-integral accumulator column with the linear prior drift a y + b (snsde.h)
+            s.kl_column1, s.kl_prior_a, s.kl_prior_b = int(kl_column[0]) + 1, float(kl_column[1]), float(kl_column[2])
         nbytes = _SIZE_CACHE.get(('fwd',) + self.cfg_key)
         if nbytes is None:
             nbytes = _SIZE_CACHE[('fwd',) + self.cfg_key] = int(_lib.lib().snsde_workspace_bytes(C.byref(s)))
@@ -513,12 +515,12 @@ _MODE_CACHE = {}
 _SIZE_CACHE = {}      # host-side size queries of the library per configuration (SolveCall.cfg_key)
 
 
-def backward_mode(model, batch, knots, grid, method, kernel='auto', exact_order=False, table=False):
+def backward_mode(model, batch, knots, grid, method, kernel='auto', exact_order=False, table=False, kl_column=None):
     """backward_supported for a solve that has not been allocated yet (memoised per configuration); table: the solve
     supplies a noise_table."""
     key = (table, model.input_channels, model.hidden_channels, model.hidden_hidden_channels, model.num_hidden_layers,
            model.input_option, model.noise_option, model.activation, model.drift_output, model.diffusion_output,
-           model.time_feature, batch, knots, grid.N, grid.T, method, kernel, exact_order)
+           model.time_feature, batch, knots, grid.N, grid.T, method, kernel, exact_order, kl_column)
     hit = _MODE_CACHE.get(key)
     if hit is None:
         s = _lib.Solve()
@@ -528,6 +530,8 @@ def backward_mode(model, batch, knots, grid, method, kernel='auto', exact_order=
         s.kernel = _lib.KERNELS[kernel]
         s.flags = _lib.FLAG_EXACT_ORDER if exact_order else 0
         s.noise_table = C.c_void_p(16) if table else None      # (only its presence matters to the query)
+        if kl_column is not None:
+            s.kl_column1 = int(kl_column) + 1
         hit = int(_lib.lib().snsde_backward_supported(C.byref(s)))
         _MODE_CACHE[key] = hit
     return hit

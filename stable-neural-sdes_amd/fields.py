@@ -520,7 +520,30 @@ def _compose_latent(sde, width):
     if not (torch.allclose(fa1, fa2) and torch.allclose(fa1[:, :Hl], f) and torch.allclose(ga1, ga2)
             and torch.allclose(ga1[:, :Hl], g) and float(ga1[:, -1].abs().max()) == 0.0):
         return None
-    P = next((w for w in _WIDTHS if w >= max(Hl, HH)), None)
+    # The KL accumulator as a state column of the fused solve (snsde.h: kl_column1): f_aug's last channel must be
+    # 1/2 sum_j ((f_j - (a y_j + b)) / g_j)^2 with a time-independent scalar linear prior drift a y + b (the module's own h) and a
+    # diffusion that is constant in time - checked on the module's own functions; otherwise the accumulator stays the batched
+    # quadrature of torchsde._sdeint_latent
+    acc = None
+    h_fn = getattr(sde, 'h', None)
+    if callable(h_fn):
+        try:
+            with torch.no_grad():
+                t2 = torch.tensor(0.83).to(p0)
+                z, o = torch.zeros(3, Hl).to(p0), torch.ones(3, Hl).to(p0)
+                h0, h1, h2, h0b = h_fn(t, z), h_fn(t, o), h_fn(t, y), h_fn(t2, z)
+                a_, b_ = float((h1 - h0).flatten()[0]), float(h0.flatten()[0])
+                gs = torch.where(g.abs() > 1e-7, g, 1e-7 * g.sign())
+                u = 0.5 * (((f - (a_ * y + b_)) / gs) ** 2).sum(dim=1)
+                if (tuple(h0.shape) == (3, Hl) and torch.allclose(h1 - h0, torch.full_like(h0, a_)) and torch.allclose(h0, torch.full_like(h0, b_))
+                        and torch.allclose(h2, a_ * y + b_, rtol=1e-5, atol=1e-6) and torch.allclose(h0b, h0)
+                        and torch.allclose(sde.g(t2, y), g) and torch.allclose(fa1[:, -1], u, rtol=1e-4, atol=1e-6)):
+                    acc = (a_, b_)
+        except Exception:
+            acc = None
+    P = next((w for w in _WIDTHS if w >= max(Hl + (1 if acc is not None else 0), HH)), None)
+    if acc is not None and (P is None or P > 128):      # no spare column below the widest kernel: keep the split solve
+        acc, P = None, next((w for w in _WIDTHS if w >= max(Hl, HH)), None)
     if P is None or P > 128:       # (the SRK variant and the training-mode lean kernels: H <= 128)
         return None
     model = engine.model_struct(1, P, P, len(linears) + 1, 4, 12, activation=ACT_RELU, drift_output=DRIFT_LINEAR,
@@ -529,7 +552,7 @@ def _compose_latent(sde, width):
         layout, numel = _lib.param_layout(model)
     except _lib.SnsdeError:
         return None
-    parts = dict(latent=Hl, linear_in=lin_in, linears=linears, linear_out=lin_out)
+    parts = dict(latent=Hl, linear_in=lin_in, linears=linears, linear_out=lin_out, acc=acc)
     return ComposedField(_LatentView(sde, Hl, P), model, layout, numel, parts, additive=True)
 
 

@@ -437,9 +437,34 @@ def _sdeint_latent(sde, y0, ts, bm, method, dt, options, names):
             return fallback()
     except RuntimeError:
         return fallback()
-    full = engine.every_step_grid(grid)
     needs_grad = torch.is_grad_enabled() and (y0.requires_grad or any(p.requires_grad for p in sde.parameters()))
     widen = lambda t: None if t is None else torch.nn.functional.pad(t[..., :Hl].to(torch.float32), (0, P - Hl)).contiguous()
+    # (1) the accumulator INSIDE the solve (snsde.h: kl_column1): column Hl of the padded state integrates the KL rate with the
+    #     scheme's own drift weights, the adjoint kernels carry its cotangent back into the drift net - one solve over the
+    #     caller's grid, no quadrature launches.  Needs the module's prior drift in the form fields.compose_latent recognised,
+    #     a diffusion without gradient (the reference's sigma is a buffer) and a spare padded column.
+    acc = field.parts.get('acc')
+    if acc is not None and P > Hl and os.environ.get('SNSDE_LATENT_SPLIT') != '1':
+        kl = (Hl, acc[0], acc[1])
+        tt = grid.d_t0 if method != 'srk' else engine.srk_stage_times(grid)
+        y0a = torch.nn.functional.pad(y0[:, :Hl + 1], (0, P - Hl - 1))
+        try:
+            if needs_grad:
+                tab = field.noise_table(tt, dev, grad=True)
+                if not tab.requires_grad and engine.backward_mode(field.model, B, 2, grid, method, table=True, kl_column=Hl) == 1:
+                    Y = _ComposedSolve.apply(field.model, coeffs, grid, widen(dW), method, 0, 0, None, y0a, field.flat(dev, grad=True),
+                                             tab.detach(), widen(dU), kl)
+                    return Y[:, :, :Hl + 1].to(y0.dtype)
+            else:
+                flat, tab = field.inference_inputs(tt, dev)
+                call = engine.SolveCall(field.model, flat, coeffs, grid, y0a.detach().to(torch.float32).contiguous(), dW=widen(dW),
+                                        dU=widen(dU), method=method, seed=0, noise_table=tab, kl_column=kl)
+                return call.launch()[:, :, :Hl + 1].to(y0.dtype)
+        except engine._lib.SnsdeError as exc:
+            if exc.code not in (-4, -6):      # (no kernel for this shape: the split solve below)
+                raise
+    # (2) the split solve: latent dynamics fused, the accumulator as one batched quadrature over every state
+    full = engine.every_step_grid(grid)
     tab_times = full.d_t0 if method != 'srk' else engine.srk_stage_times(full)
     y0p = torch.nn.functional.pad(y0[:, :Hl], (0, P - Hl))
     if needs_grad:
@@ -517,12 +542,12 @@ class _ComposedSolve(torch.autograd.Function):
     gradients this node returns (dL/dy0, dL/d block, dL/d table) on to the module."""
 
     @staticmethod
-    def forward(ctx, model, coeffs, grid, dW, method, seed, row_offset, row_out, y0, flat, tab, dU=None):
+    def forward(ctx, model, coeffs, grid, dW, method, seed, row_offset, row_out, y0, flat, tab, dU=None, kl_column=None):
         y0c = y0.detach().to(torch.float32).contiguous()
         call = engine.SolveCall(model, flat.detach().contiguous(), coeffs, grid, y0c, dW=dW, method=method, seed=seed,
                                 row_offset=row_offset, row_out=row_out, dU=dU,
                                 noise_table=None if tab is None else tab.detach().contiguous(),
-                                save_traj=True, save_dW=True, save_act=True)
+                                save_traj=True, save_dW=True, save_act=True, kl_column=kl_column)
         ys = call.launch()
         ctx.call, ctx.y0_dtype, ctx.has_tab = call, y0.dtype, tab is not None
         return ys.to(y0.dtype) if y0.dtype != ys.dtype else ys.detach()
@@ -533,7 +558,7 @@ class _ComposedSolve(torch.autograd.Function):
         out = engine.backward_with_gradients(call, grad_ys.to(torch.float32).contiguous(), adj0_only=engine.adj0_suffices(call),
                                              want_table_grad=ctx.has_tab)
         adj, gflat, gtab = out if ctx.has_tab else (out + (None,))
-        return (None,) * 8 + (adj[0].to(ctx.y0_dtype), gflat, gtab, None)
+        return (None,) * 8 + (adj[0].to(ctx.y0_dtype), gflat, gtab, None, None)
 
 
 class _FusedSolve(torch.autograd.Function):
