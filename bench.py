@@ -400,8 +400,8 @@ def tutorial_field(dev, stream, kind='lnsde', rows=1024, hh=128, n=100):
 
 def latent_sde(dev, stream, rows=1024, hidden=32, L=50):
     """torch-ists' LatentSDE shape (tests/latent_field.LatentField: the reference wrapper's forward - spline start,
-    sdeint_adjoint(names f_aug / g_aug), KL) under its default `srk`: the split solve (fused latent dynamics + batched KL quadrature,
-    torchsde._sdeint_latent) next to the tensor-op loop, inference and one training step (wall clock per call, HIP events)."""
+    sdeint_adjoint(names f_aug / g_aug), KL) under its default `srk`: the fused solve with the KL accumulator as a state column
+    (torchsde._sdeint_latent, snsde_solve.kl_column1) next to the tensor-op loop, inference and one training step (HIP events)."""
     from tests.latent_field import LatentField
     torch.manual_seed(1)
     m = LatentField(4, hidden, hidden, 2).to(dev)
@@ -411,7 +411,7 @@ def latent_sde(dev, stream, rows=1024, hidden=32, L=50):
     out = {"workload": f"LatentSDE-shaped module ({hidden - 1} latent channels + KL accumulator, 2 hidden layers), {rows} rows, {L} output times, "
                        "srk, whole wrapper forward / training step"}
     for backend, key, n in (('auto', 'fused', 10), ('torch', 'tensor_loop', 2)):
-        opts = {'seed': 3, 'backend': backend}
+        opts = {'backend': backend}      # (unseeded: the fused path draws Philox increments in the kernel, the loop torch.randn)
         with torch.no_grad():
             out[key + "_forward"] = spread(event_times_ms(lambda: m(coeffs, times, method='srk', options=opts), stream, n, 2))
 

@@ -419,11 +419,23 @@ def _sdeint_latent(sde, y0, ts, bm, method, dt, options, names):
     ts_host = _HostTimes.get(ts)
     times_host = np.array([ts_host[0], ts_host[-1]], dtype=np.float32)
     grid = engine.step_grid(ts_host, dt, times_host, dev)
-    dW, dU = _draw_increments(bm, grid, y0, method, options)
-    drawn = _DrawnIncrements(dW, dU)
+    # Increments: the caller's `bm` or, with options['seed'], the generator stream the tensor-op loop draws (same results on both
+    # paths) are drawn up front; an unseeded call of the in-solve accumulator path lets the kernels draw Philox increments
+    # (no (N, B, H) tensors of normals at all) and only draws here if it has to fall back
+    acc = field.parts.get('acc')
+    in_solve = acc is not None and P > Hl and os.environ.get('SNSDE_LATENT_SPLIT') != '1'
+    philox = in_solve and bm is None and options.get('seed') is None
+    drawn_box = []
+
+    def increments():
+        if not drawn_box:
+            dW_, dU_ = _draw_increments(bm, grid, y0, method, options)
+            drawn_box.append((dW_, dU_, _DrawnIncrements(dW_, dU_)))
+        return drawn_box[0]
+    dW, dU = (None, None) if philox else increments()[:2]
 
     def fallback():
-        return _sdeint_torch(sde, y0, ts, drawn, method, dt, options, names)
+        return _sdeint_torch(sde, y0, ts, increments()[2], method, dt, options, names)
     view = field.sde
     cache = field.__dict__.setdefault('_dummy_control', {})
     key = (B, str(dev))
@@ -443,27 +455,28 @@ def _sdeint_latent(sde, y0, ts, bm, method, dt, options, names):
     #     scheme's own drift weights, the adjoint kernels carry its cotangent back into the drift net - one solve over the
     #     caller's grid, no quadrature launches.  Needs the module's prior drift in the form fields.compose_latent recognised,
     #     a diffusion without gradient (the reference's sigma is a buffer) and a spare padded column.
-    acc = field.parts.get('acc')
-    if acc is not None and P > Hl and os.environ.get('SNSDE_LATENT_SPLIT') != '1':
+    if in_solve:
         kl = (Hl, acc[0], acc[1])
+        key = _fresh_seed() if philox else 0
         tt = grid.d_t0 if method != 'srk' else engine.srk_stage_times(grid)
         y0a = torch.nn.functional.pad(y0[:, :Hl + 1], (0, P - Hl - 1))
         try:
             if needs_grad:
                 tab = field.noise_table(tt, dev, grad=True)
                 if not tab.requires_grad and engine.backward_mode(field.model, B, 2, grid, method, table=True, kl_column=Hl) == 1:
-                    Y = _ComposedSolve.apply(field.model, coeffs, grid, widen(dW), method, 0, 0, None, y0a, field.flat(dev, grad=True),
+                    Y = _ComposedSolve.apply(field.model, coeffs, grid, widen(dW), method, key, 0, None, y0a, field.flat(dev, grad=True),
                                              tab.detach(), widen(dU), kl)
                     return Y[:, :, :Hl + 1].to(y0.dtype)
             else:
                 flat, tab = field.inference_inputs(tt, dev)
                 call = engine.SolveCall(field.model, flat, coeffs, grid, y0a.detach().to(torch.float32).contiguous(), dW=widen(dW),
-                                        dU=widen(dU), method=method, seed=0, noise_table=tab, kl_column=kl)
+                                        dU=widen(dU), method=method, seed=key, noise_table=tab, kl_column=kl)
                 return call.launch()[:, :, :Hl + 1].to(y0.dtype)
         except engine._lib.SnsdeError as exc:
             if exc.code not in (-4, -6):      # (no kernel for this shape: the split solve below)
                 raise
     # (2) the split solve: latent dynamics fused, the accumulator as one batched quadrature over every state
+    dW, dU = increments()[:2]
     full = engine.every_step_grid(grid)
     tab_times = full.d_t0 if method != 'srk' else engine.srk_stage_times(full)
     y0p = torch.nn.functional.pad(y0[:, :Hl], (0, P - Hl))

@@ -166,3 +166,95 @@ def test_latent_sde_at_the_bench_size_matches_the_tensor_loop():
     assert float((latent - latent2).abs().mean()) <= 1e-5 * scale
     assert float((out - out2).abs().max()) <= 2e-4 * max(float(out2.abs().max()), 1.0)
     assert abs(float(kl) - float(kl2)) <= 2e-4 * max(abs(float(kl2)), 1.0)
+
+
+@pytest.mark.parametrize('method', ['euler', 'milstein', 'srk'])
+def test_accumulator_column_inside_the_solve_equals_the_split_solve(method, monkeypatch):
+    """Round 4: the KL accumulator as a state column of the fused solve (snsde_solve.kl_column1: drift override by per-wave row
+    sums in the forward kernels, cotangent broadcast in the adjoints) against the split solve (fused latent dynamics + batched
+    quadrature over every state) on the same increments: states, dL/dy0 and every parameter gradient.  The in-solve path must
+    not build the every-step grid the quadrature needs."""
+    dev = torch.device('cuda')
+    B, H, HH, NL = 37, 32, 32, 2
+    torch.manual_seed(11)
+    m = LatentField(3, H, HH, NL, theta=0.9, mu=-0.1, sigma=0.5).to(dev)
+    ts = torch.tensor([0.0, 0.3, 0.55, 1.0], device=dev)
+    dt = 0.05
+    grid = S.engine.StepGrid(ts.cpu().numpy(), dt, np.array([0.0, 1.0], dtype=np.float32), None)
+    rng = np.random.default_rng(5)
+    h = (grid.t1 - grid.t0).astype(np.float64)
+    dW = torch.from_numpy((rng.standard_normal((grid.N, B, H)) * np.sqrt(h)[:, None, None]).astype(np.float32)).to(dev)
+    dU = None
+    if method == 'srk':
+        hc = torch.from_numpy(h.astype(np.float32))[:, None, None].to(dev)
+        dU = hc * (0.5 * dW + (hc / 12).sqrt() * torch.from_numpy(rng.standard_normal((grid.N, B, H)).astype(np.float32)).to(dev))
+    y0 = torch.cat([0.5 * torch.randn(B, H - 1), torch.zeros(B, 1)], dim=1).to(dev)
+    wsum = torch.from_numpy(rng.standard_normal((len(ts), B, H)).astype(np.float32)).to(dev)
+    wsum[..., -1] *= 0.05
+    cf = fields.compose_latent(m, NAMES, H)
+    assert cf is not None and cf.parts['acc'] is not None and cf.model.hidden_channels > H - 1
+    np.testing.assert_allclose(cf.parts['acc'], (-0.9, 0.9 * -0.1), rtol=1e-6)
+
+    def run(split):
+        monkeypatch.setenv('SNSDE_LATENT_SPLIT', '1' if split else '0')
+        calls = []
+        real = S.engine.every_step_grid
+        monkeypatch.setattr(S.engine, 'every_step_grid', lambda g: (calls.append(1), real(g))[1])
+        m.zero_grad(set_to_none=True)
+        yy = y0.clone().requires_grad_(True)
+        with no_tensor_loop():
+            ys = S.torchsde.sdeint_adjoint(m, yy, ts, bm=Replay(dW, dU), dt=dt, method=method, names=NAMES)
+            (ys * wsum).sum().backward()
+        monkeypatch.setattr(S.engine, 'every_step_grid', real)
+        assert bool(calls) == split, 'the in-solve accumulator path must not need every state'
+        return ys.detach(), yy.grad.clone(), {k: p.grad.clone() for k, p in m.named_parameters() if p.grad is not None}
+
+    ys_a, g0_a, gp_a = run(False)
+    ys_s, g0_s, gp_s = run(True)
+    for sl in (slice(0, -1), slice(-1, None)):
+        scale = max(float(ys_s[..., sl].abs().max()), 1.0)
+        assert float((ys_a - ys_s)[..., sl].abs().max()) <= 1e-4 * scale
+    assert float((g0_a - g0_s).abs().max()) <= 1e-3 * float(g0_s.abs().max())
+    assert gp_a.keys() == gp_s.keys()
+    for k in gp_s:
+        assert float((gp_a[k] - gp_s[k]).abs().max()) <= 1e-3 * (float(gp_s[k].abs().max()) + 1e-12), k
+
+
+def test_learnable_diffusion_keeps_its_gradient_on_the_split_solve():
+    """a LatentSDE-shaped module whose sigma is an nn.Parameter.  The in-solve accumulator carries no
+    d/d sigma of the KL rate, so such a module takes the split solve, whose table gradient reaches sigma - checked against float64
+    autograd through the tensor-op loop (the round-3 code detached the table and dropped it silently)."""
+    dev = torch.device('cuda')
+
+    class Learnable(LatentField):
+        def __init__(self, *a, **k):
+            super().__init__(*a, **k)
+            sig = self.sigma.clone()
+            del self._buffers['sigma']
+            self.sigma = torch.nn.Parameter(sig)
+    B, H = 9, 17
+    torch.manual_seed(2)
+    m = Learnable(3, H, 24, 2, theta=0.7, mu=0.2, sigma=0.4)
+    m64 = Learnable(3, H, 24, 2, theta=0.7, mu=0.2, sigma=0.4).double()
+    m64.load_state_dict({k: v.double() for k, v in m.state_dict().items()})
+    ts = torch.linspace(0, 1, 6)
+    grid = S.engine.StepGrid(ts.numpy(), 0.1, np.array([0.0, 1.0], dtype=np.float32), None)
+    rng = np.random.default_rng(8)
+    dW = torch.from_numpy(rng.standard_normal((grid.N, B, H)) * np.sqrt((grid.t1 - grid.t0).astype(np.float64))[:, None, None])
+    y0 = torch.cat([0.5 * torch.randn(B, H - 1), torch.zeros(B, 1)], dim=1)
+    wsum = torch.from_numpy(rng.standard_normal((len(ts), B, H)))
+    wsum[..., -1] *= 0.05
+    y64 = y0.double().requires_grad_(True)
+    (S.sdeint(m64, y64, ts.double(), bm=Replay(dW), dt=0.1, method='euler', names=NAMES, options={'backend': 'torch'}) * wsum).sum().backward()
+    m = m.to(dev)
+    yg = y0.to(dev).requires_grad_(True)
+    with no_tensor_loop():
+        (S.sdeint(m, yg, ts.to(dev), bm=Replay(dW.float().to(dev)), dt=0.1, method='euler', names=NAMES) * wsum.float().to(dev)).sum().backward()
+    assert m.sigma.grad is not None and float(m64.sigma.grad.abs().max()) > 0
+    ref = dict(m64.named_parameters())
+    for name, p in m.named_parameters():
+        gr = ref[name].grad
+        if gr is None or float(gr.abs().max()) == 0.0:
+            continue
+        err = float((p.grad.double().cpu() - gr).abs().max()) / (float(gr.abs().max()) + 1e-12)
+        assert err < 2e-3, (name, err)
