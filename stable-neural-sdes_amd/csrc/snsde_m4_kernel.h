@@ -371,6 +371,10 @@ __global__ void __launch_bounds__(CF::NT, CF::WPS) snsde_m4_kernel(MfmaArgs a) {
         }
     };
     // every asm-issued load has landed: ties the registers they fill
+    // (round 4, measured and dropped: s_waitcnt vmcnt(k) that leaves the k hidden-layer activation stores issued after the step's last
+    //  prefetch in flight - the training-mode forward did not move (203.2 vs 203.1 us at K2), and with supplied increments the states
+    //  came out wrong (test_backward_matches_fp64_autograd_through_the_unrolled_loop[0-mfma4]): a store's acknowledgement can overtake
+    //  an older load's return on this part, so a counted wait does not cover the loads while stores are outstanding.)
     auto vm_wait = [&](float& dwn, float& gtn) {
         asm volatile("s_waitcnt vmcnt(0)" : "+v"(dwn), "+v"(gtn));
 #pragma unroll

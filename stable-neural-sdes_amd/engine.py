@@ -348,13 +348,19 @@ def backward_recompute(call, grad_ys, chunk, stream=None):
             else:
                 g[j + 1] = grad_ys[k]
         g[sub.T - 1] += carry                     # everything behind the chunk acts on its last state
+        # the chunk reads the parent's increments in place (no second copy: the adjoint takes `dW` where there is no `dW_out`), and
+        # its adjoint + weight-gradient pass are one C call
         c = SolveCall(model, flat, coeffs, sub, call.traj[n0], dW=call.dW_out[n0:n1], method=method, kernel='auto',
-                      save_traj=True, save_dW=True, save_act=True, exact_order=bool(call.base_flags & _lib.FLAG_EXACT_ORDER))
+                      save_traj=True, save_dW=False, save_act=True, exact_order=bool(call.base_flags & _lib.FLAG_EXACT_ORDER))
         c.launch(stream)
-        adj, delta = solve_backward(c, g, stream=stream, save_delta=True, adj0_only=adj0_suffices(c))
-        part = param_gradients(c, adj, delta, stream=stream)
+        adj, part = backward_with_gradients(c, g, stream=stream, adj0_only=adj0_suffices(c))
         total = part if total is None else total.add_(part)
-        carry = adj[0]
+        carry = adj[0].clone()
+        # drop this chunk's activations / deltas / workspaces BEFORE the next chunk allocates its own: the caching allocator then
+        # hands the same blocks out again, and the peak is ONE chunk's buffers (two chunks were alive at once before: 50 steps per
+        # chunk at K2 peaked above the saved-activation mode)
+        c.keep_bwd = c.keep_pg = None
+        del c, adj, part, g
     if per_row:
         g0 = torch.where((row_out == 0).unsqueeze(1), grad_ys, torch.zeros_like(grad_ys))
     else:

@@ -613,6 +613,8 @@ class _FusedSolve(torch.autograd.Function):
         ctx.recompute = 0
         if mode == 1 and method != 'srk':
             ctx.recompute = max(int(options.get('recompute', os.environ.get('SNSDE_RECOMPUTE_STEPS', 0)) or 0), 0)
+            if ctx.recompute >= grid.N:      # one chunk = the whole solve: the saved-activation mode with a second forward on top
+                ctx.recompute = 0            # (and the parent's states / increments kept beside the chunk's: MORE memory, K5 N = 49)
         # mode 2: the generic adjoint prepares its own weights, so the forward takes whatever kernel is fastest
         call = make(options.get('kernel', 'auto'), mode == 1 and not ctx.recompute)
         ctx.mode, ctx.method = mode, method
