@@ -493,6 +493,7 @@ __global__ void __launch_bounds__(CF::NT, CF::WPS) snsde_m4_kernel(MfmaArgs a) {
         // wave-step for five stores, on the issue port the MFMAs share).
         [[maybe_unused]] float* act_n = nullptr;
         [[maybe_unused]] uint32_t nu = 0;
+        [[maybe_unused]] uint32_t sgn = 0;
         if constexpr (SAVE) {
             nu = (uint32_t)__builtin_amdgcn_readfirstlane(n);
             act_n = a.act_save + uoff((int)nu, (uint32_t)CF::NSAVE * (uint32_t)BH);
@@ -526,6 +527,7 @@ __global__ void __launch_bounds__(CF::NT, CF::WPS) snsde_m4_kernel(MfmaArgs a) {
                     lean_gstore(o, goff4, act_n);
                     if constexpr (CF::SWISH) lean_gstore(pre, goff4, act_n + uoff(0, 0, CF::PRE0, (uint32_t)BH));
                 }
+                if constexpr (!CF::SWISH) sgn = o > 0.0f ? 1u : 0u;      // relu signs of this lane's element (snsde_pack_signs)
             }
         }
         LT(3)
@@ -561,6 +563,7 @@ __global__ void __launch_bounds__(CF::NT, CF::WPS) snsde_m4_kernel(MfmaArgs a) {
                     lean_gstore(o, goff4, act_n + uoff(0, 0, 1 + l, (uint32_t)BH));
                     if constexpr (CF::SWISH) lean_gstore(pre, goff4, act_n + uoff(0, 0, CF::PRE0 + 1 + l, (uint32_t)BH));
                 }
+                if constexpr (!CF::SWISH) sgn |= (o > 0.0f ? 1u : 0u) << (1 + l);
             }
             if (l == NHID - 1) { LT(6) }
             __syncthreads();
@@ -580,7 +583,9 @@ __global__ void __launch_bounds__(CF::NT, CF::WPS) snsde_m4_kernel(MfmaArgs a) {
         LT(8)
         vm_wait(dw_nxt, gt_nxt);      // this step's prefetches (issued one to three phases ago)
         float z = m4_reduce_scatter(c + d);
-        if constexpr (SAVE) { if (a.act_save && row_ok) lean_gstore(z, goff4, act_n + uoff(0, 0, CF::ZSLOT, (uint32_t)BH)); }
+        if constexpr (SAVE) {      // the saved pre-tanh drift carries the step's relu signs in its low NHID + 1 bits (the adjoint's masks)
+            if (a.act_save && row_ok) lean_gstore(CF::SWISH ? z : snsde_pack_signs(z, sgn, NHID + 1), goff4, act_n + uoff(0, 0, CF::ZSLOT, (uint32_t)BH));
+        }
         if (__builtin_expect(geo, 0)) z *= fast_tanh(yv);
         float f;
         if (__builtin_expect(f_out != SNSDE_DRIFT_TANH, 0)) f = f_out == SNSDE_DRIFT_TIMES_Y ? z * yv : z;

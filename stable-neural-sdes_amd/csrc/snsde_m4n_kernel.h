@@ -350,6 +350,7 @@ __global__ void __launch_bounds__(CF::NT, CF::WPS) snsde_m4n_kernel(MfmaArgs a) 
 
         // ---- phase 0: first layers of the drift (on yrow [+ xrow]) and of the net (on gyrow) ----
         float q = 0.0f, z = 0.0f, dw = 0.0f;
+        uint32_t sgn = 0;
         {
             f32x4 c = {0.f, 0.f, 0.f, 0.f}, d = c;
             gemm4<KUY>(wy, yrow, c, d);
@@ -359,6 +360,7 @@ __global__ void __launch_bounds__(CF::NT, CF::WPS) snsde_m4n_kernel(MfmaArgs a) 
             bufA[r * LDA + fcol] = o;
             save_act(n, 0, o);
             save_pre(n, 0, pre);
+            sgn = o > 0.0f ? 1u : 0u;      // relu signs of this lane's element (Euler: folded into the saved z, snsde_pack_signs)
         }
         const float nhid_own = net_l1(n, CF::ZSLOT + 1, q);      // (NN == 2: this lane's hidden pre-activation of the net)
         __syncthreads();
@@ -447,6 +449,7 @@ __global__ void __launch_bounds__(CF::NT, CF::WPS) snsde_m4n_kernel(MfmaArgs a) 
             (toB ? bufB : bufA)[r * LDA + fcol] = o;
             save_act(n, 1 + l, o);
             save_pre(n, 1 + l, pre);
+            sgn |= (o > 0.0f ? 1u : 0u) << (1 + l);
             if constexpr (MIL) { if (tdone < NTR) net_t(); }
             __syncthreads();
             tsync = true;
@@ -466,7 +469,8 @@ __global__ void __launch_bounds__(CF::NT, CF::WPS) snsde_m4n_kernel(MfmaArgs a) 
                 }
             }
         }
-        save_act(n, CF::ZSLOT, z);
+        // Euler on these kernels is differentiated by snsde_mfma_reverse_kernel, which takes the relu masks of the drift chain from z
+        save_act(n, CF::ZSLOT, (CF::METHOD == SNSDE_EULER && act_fn == 0) ? snsde_pack_signs(z, sgn, NHID + 1) : z);
 
         // ---- f, g and the update (own element) ----
         const float yin = SRK ? sk_y : yv;         // (the drift pass's input state is yv)

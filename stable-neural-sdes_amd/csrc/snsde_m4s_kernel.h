@@ -246,6 +246,7 @@ __global__ void __launch_bounds__(CF::NT, 1) snsde_m4s_kernel(MfmaArgs a) {
             __syncthreads();
         }
         const bool more = n + 1 < N;
+        [[maybe_unused]] uint32_t sgn = 0;
         asm volatile("" : "+v"(qa), "+v"(qb));
         const float h = qa[0];
         // ---- first layer: the [X(t_n) | tau_n] part from registers, then the streamed y part ------------------------------
@@ -261,6 +262,9 @@ __global__ void __launch_bounds__(CF::NT, 1) snsde_m4s_kernel(MfmaArgs a) {
             const float o = CF::SWISH ? lean_swish(pre, act_scale) : fmaxf(pre, 0.0f);
             *aown = o;
             if constexpr (SAVE) { if (a.act_save && row_ok) lean_gstore(o, goff4, a.act_save + ((size_t)n * CF::NSAVE) * BH); }
+            // relu signs of this lane's element (snsde_pack_signs).  NHID == 1: both rectified outputs are still in this lane's LDS slots
+            // when z is stored and are read back there (the 128-register budget of this kernel has no room to carry them: (1, 3) spilled)
+            if constexpr (SAVE && !CF::SWISH && NHID != 1) sgn = o > 0.0f ? 1u : 0u;
         }
         __syncthreads();
         // ---- hidden layers; the next step's increment and diffusion-table entry are fetched in the first window -------------
@@ -283,6 +287,7 @@ __global__ void __launch_bounds__(CF::NT, 1) snsde_m4s_kernel(MfmaArgs a) {
             const float o = CF::SWISH ? lean_swish(pre, act_scale) : fmaxf(pre, 0.0f);
             *(toB ? bown : aown) = o;
             if constexpr (SAVE) { if (a.act_save && row_ok) lean_gstore(o, goff4, a.act_save + ((size_t)n * CF::NSAVE + 1 + l) * BH); }
+            if constexpr (SAVE && !CF::SWISH && NHID != 1) sgn |= (o > 0.0f ? 1u : 0u) << (1 + l);
             __syncthreads();
         }
         // ---- output layer (its last two chunks refill the ring with the NEXT step's first blocks), f, update ------------------
@@ -293,7 +298,12 @@ __global__ void __launch_bounds__(CF::NT, 1) snsde_m4s_kernel(MfmaArgs a) {
         else stream_layer<OFFB>(yrow, ra, m0v, vo_lo, vo_hi, sb[NHID + 1], sb[0], c, d);
         vm_wait(dw_nxt, gt_nxt);
         float z = m4_reduce_scatter(c + d) + bias_own[NHID + 1];
-        if constexpr (SAVE) { if (a.act_save && row_ok) lean_gstore(z, goff4, a.act_save + ((size_t)n * CF::NSAVE + CF::ZSLOT) * BH); }
+        if constexpr (SAVE) {      // the saved pre-tanh drift carries the step's relu signs in its low NHID + 1 bits (the adjoint's masks)
+            if (a.act_save && row_ok) {
+                if constexpr (!CF::SWISH && NHID == 1) sgn = (*aown > 0.0f ? 1u : 0u) | (*bown > 0.0f ? 2u : 0u);
+                lean_gstore(CF::SWISH ? z : snsde_pack_signs(z, sgn, NHID + 1), goff4, a.act_save + ((size_t)n * CF::NSAVE + CF::ZSLOT) * BH);
+            }
+        }
         if (__builtin_expect(geo, 0)) z *= fast_tanh(yv);
         float f;
         if (__builtin_expect(f_out != SNSDE_DRIFT_TANH, 0)) f = f_out == SNSDE_DRIFT_TIMES_Y ? z * yv : z;

@@ -173,6 +173,18 @@ __device__ __forceinline__ float fast_tanh(float x) {
     return ax < 0.25f ? p : copysignf(q, x);
 }
 
+// Relu signs inside the saved pre-tanh drift (round 4).  The MFMA adjoint needs [activation > 0] of every rectified layer output of a
+// step; it used to re-read the saved activation planes for that - two of the seven (N, B, H) planes a K2 adjoint step moves.  A lane
+// owns the SAME (row, feature) element of every layer's output and of the drift output z, so the Euler / Milstein forward kernels fold
+// the signs of that element's NHID + 1 rectified outputs (act_save slots 0 .. NHID) into the low NHID + 1 mantissa bits of the z they
+// save (slot NHID + 1; bit k = [slot k > 0]) and the adjoint takes its masks from the z it loads anyway: no extra store, load or
+// buffer.  The saved z is used for tanh'(z) only (its low <= 4 bits are noise of <= 1e-6 relative; the forward itself computes with
+// the exact register value, so states are bit-identical); models with a smooth activation keep their pre-activation planes.
+__device__ __forceinline__ float snsde_pack_signs(float z, uint32_t signs, int nbits) {
+    const uint32_t m = (1u << nbits) - 1u;
+    return __uint_as_float((__float_as_uint(z) & ~m) | (signs & m));
+}
+
 // Wave-uniform element offset  n * stride + slot * bh  from 32 x 32 -> 64-bit products (s_mul_i32 / s_mul_hi_u32 on the scalar unit).
 // Written as 64 x 64-bit products of size_t values, hipcc evaluates them on the VALU (v_mad_u64_u32 + two quarter-rate v_mul_lo_u32
 // per product) - ~25 of them per step in the adjoint loop, on the issue port the MFMAs share.  stride, bh < 2^32 (B H times the slots
@@ -519,6 +531,10 @@ __global__ void __launch_bounds__(CF::NT, CF::WPS) snsde_mfma_kernel(MfmaArgs a)
 
     // store one layer output fragment (bias came in through the accumulator init) as 16 B per lane
     int save_step = 0;   // current step, for the optional activation save
+    // relu signs of this lane's elements of the step's rectified layers (snsde_pack_signs): bit (slot) on 4-row tiles, bit
+    // (slot + 8 i) for fragment element i on 16-row tiles; folded into the saved z and cleared at the end of the step
+    [[maybe_unused]] uint32_t sgn = 0;
+    const bool pack_signs = !CF::SRK && a.act == 0 && a.act_save != nullptr;
     // field variants with a smooth activation (4-row tiles): the NHID + 1 pre-activations follow the regular slots (snsde_act_slots)
     const int nsave_rt = (FL && a.act != 0) ? CF::NSAVE + NHID + 1 : CF::NSAVE;
     // M4: the layer's bias is added after the k-slot reduction, from a register (one value per lane and layer)
@@ -539,6 +555,7 @@ __global__ void __launch_bounds__(CF::NT, CF::WPS) snsde_mfma_kernel(MfmaArgs a)
                 }
             }
             buf[r * ld + col0 + fsub + s] = o;
+            if constexpr (!CF::SRK) { if (relu && save_slot >= 0 && save_slot <= NHID) sgn |= (o > 0.0f ? 1u : 0u) << save_slot; }
             if (save_slot >= 0 && a.act_save && row_ok) {
                 (a.act_save + uoff(save_step, (uint32_t)nsave_rt * (uint32_t)(B * H), save_slot, (uint32_t)(B * H)))[(uint32_t)(row * H + wave * 16 + fsub + s)] = o;
                 if (relu && a.act != 0)      // smooth activations: the pre-activation as well (slots behind the regular ones)
@@ -549,6 +566,12 @@ __global__ void __launch_bounds__(CF::NT, CF::WPS) snsde_mfma_kernel(MfmaArgs a)
         if (relu) {
 #pragma unroll
             for (int i = 0; i < 4; ++i) v[i] = fmaxf(v[i], 0.0f);
+            if constexpr (!CF::SRK) {
+                if (save_slot >= 0 && save_slot <= NHID) {
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) sgn |= (v[i] > 0.0f ? 1u : 0u) << (save_slot + 8 * i);
+                }
+            }
         }
         if (writer) {
             *reinterpret_cast<f32x4*>(buf + r * ld + col0 + fsub) = v;
@@ -930,9 +953,14 @@ __global__ void __launch_bounds__(CF::NT, CF::WPS) snsde_mfma_kernel(MfmaArgs a)
             const size_t goff = (size_t)row * H + fcol[t];
             if (a.act_save && row_ok) {
                 float* zp = a.act_save + uoff(n, (uint32_t)nsave_rt * (uint32_t)(B * H), CF::ZSLOT, (uint32_t)(B * H)) + goff;
+                if (pack_signs) {
+#pragma unroll
+                    for (int e = 0; e < EPT; ++e) zsave[e] = snsde_pack_signs(zsave[e], sgn >> (8 * e), NHID + 1);
+                }
                 if constexpr (FL) zp[0] = zsave[0];
                 else *reinterpret_cast<f32x4*>(zp) = f32x4{zsave[0], zsave[1], zsave[2], zsave[3]};
             }
+            sgn = 0;
             if constexpr (FL) {
                 ybuf[r * LDY + fcol[t]] = ynew[0];
                 if constexpr (CF::SRK) { if (a.stage_save && row_ok) a.stage_save[(size_t)(n + 1) * BH + goff] = ynew[0]; }
@@ -1135,8 +1163,22 @@ __global__ void __launch_bounds__(CF::NT, CF::WPS) snsde_mfma_reverse_kernel(Rev
 
     // per-step inputs from HBM are fetched one step ahead, so their latency hides behind the previous step's GEMM chain
     // M16: the writer lanes hold the relu masks of their four features (f32x4); M4: after the k-slot reduce-scatter every
-    // lane owns ONE output (row r, feature fcol), so the mask is one float per lane (mask[g][0])
-    struct StepIn { float y[EPT], z[EPT], dw[EPT], gq[EPT]; f32x4 mask[NM > 0 ? NM : 1]; f32x4 nmask; };
+    // lane owns ONE output (row r, feature fcol).  Relu: the drift chain's masks are bits of z (snsde_pack_signs); `mask` holds the
+    // pre-activations of the smooth-activation variants (4-row tiles only), `nmask` the hidden activation of a two-layer diffusion net.
+    struct StepIn { f32x4 nmask; float mask[4]; float y[EPT], z[EPT], dw[EPT], gq[EPT]; };
+    static_assert(NM <= 4, "mask slots");
+    // cur <-> nxt move member by member, and only the members this flavour uses: a whole-struct assignment also copies the members a
+    // flavour never touches, and those bytes travel through scratch memory every step (16 bytes of nmask each way before round 4; 48
+    // when the 16-row-tile kernel's mask planes went away: 1437 -> 1867 us at K3 until this was found)
+    auto step_copy = [&](StepIn& d, const StepIn& sfrom) {
+#pragma unroll
+        for (int e = 0; e < EPT; ++e) { d.y[e] = sfrom.y[e]; d.z[e] = sfrom.z[e]; d.dw[e] = sfrom.dw[e]; d.gq[e] = sfrom.gq[e]; }
+        if constexpr (FL) {
+#pragma unroll
+            for (int g = 0; g < NM; ++g) d.mask[g] = sfrom.mask[g];
+        }
+        if constexpr (NN == 2) d.nmask = sfrom.nmask;
+    };
     float zblk[EPT][4];                 // regenerated increments: the normals of the 4-step block being walked
     int zblk_id = -1;
     const uint32_t grow = (uint32_t)(a.row_offset + row);
@@ -1164,16 +1206,14 @@ __global__ void __launch_bounds__(CF::NT, CF::WPS) snsde_mfma_reverse_kernel(Rev
             else p.gq[e] = a.gt ? (a.gt + uoff(n, H))[fcol + e] : 0.0f;
         }
         if constexpr (FL) {
+            if (__builtin_expect(a.act_fn != 0, 0)) {      // relu: the signs ride in z's low bits (snsde_pack_signs)
 #pragma unroll
-            for (int g = 0; g < NM; ++g)     // relu mask of the forward activation feeding transposed GEMM g + 1
-                p.mask[g][0] = (a.act + uoff(n, SBH, (uint32_t)(NHID - g) + pre0, BH32))[goff];     // (smooth activations: the PRE-activation slots, behind the net's)
+            for (int g = 0; g < NM; ++g)     // smooth activations: the PRE-activation of the forward activation feeding transposed GEMM g + 1 (slots behind the net's)
+                p.mask[g] = (a.act + uoff(n, SBH, (uint32_t)(NHID - g) + pre0, BH32))[goff];
+            }
             if constexpr (NN == 2)               // hidden activation of the diffusion net (smooth: its pre-activation, the last slot)
                 p.nmask[0] = (a.act + uoff(n, SBH, a.act_fn != 0 ? (uint32_t)NSAVE - 1u : (uint32_t)(CF::ZSLOT + 1), BH32))[goff];
-        } else if (writer) {
-#pragma unroll
-            for (int g = 0; g < NM; ++g)
-                p.mask[g] = *reinterpret_cast<const f32x4*>(
-                    a.act + uoff(n, SBH, NHID - g, BH32) + (uint32_t)(rowc * H + wave * 16 + fsub));
+        } else if (writer) {      // (16-row tiles: relu only - the drift chain's masks come out of z)
             if constexpr (NN == 2)
                 p.nmask = *reinterpret_cast<const f32x4*>(
                     a.act + uoff(n, SBH, CF::ZSLOT + 1, BH32) + (uint32_t)(rowc * H + wave * 16 + fsub));
@@ -1185,7 +1225,7 @@ __global__ void __launch_bounds__(CF::NT, CF::WPS) snsde_mfma_reverse_kernel(Rev
 
     for (int n = a.N - 1; n >= 0; --n) {
         if constexpr (AHEAD) {
-            nxt = cur;
+            step_copy(nxt, cur);
             if (n > 0) prefetch(n - 1, nxt);
         } else {
             prefetch(n, cur);
@@ -1231,10 +1271,12 @@ __global__ void __launch_bounds__(CF::NT, CF::WPS) snsde_mfma_reverse_kernel(Rev
         }
         // ---- elementwise: d(f h + g dW)/d(zout, y) applied to the adjoint ----
         float ay[EPT], dz[EPT], dsv[EPT], dq[EPT];
+        uint32_t zb[EPT];      // bit pattern of the saved z: its low NHID + 1 bits are the relu signs of the step (snsde_pack_signs)
 #pragma unroll
         for (int e = 0; e < EPT; ++e) {
             dsv[e] = 0.0f; dq[e] = 0.0f;
             const float y = cur.y[e], z = cur.z[e], dw = cur.dw[e], gq = cur.gq[e];
+            zb[e] = __builtin_bit_cast(uint32_t, z);
             const float av = adj[e];
             if (__builtin_expect(variant, 0)) {
                 // f = tanh z | z | z y;  g = raw = s_n or s_n y (SNSDE_DIFFUSION_RAW), else the reference's tanh(sigmoid(theta) raw)
@@ -1396,8 +1438,11 @@ __global__ void __launch_bounds__(CF::NT, CF::WPS) snsde_mfma_reverse_kernel(Rev
                 // k-slot reduce-scatter (6 DPP ops): this lane's single output (row r, feature fcol)
                 const float o = m4_reduce_scatter(v);
                 if (mid) {
-                    const float zs = g < ND ? cur.mask[g < NM ? g : 0][0] : cur.nmask[0];
-                    const float dv = __builtin_expect(a.act_fn != 0, 0) ? o * swish_grad(zs, act_scale) : (zs > 0.0f ? o : 0.0f);
+                    const float zs = g < ND ? cur.mask[g < NM ? g : 0] : cur.nmask[0];
+                    float dv;
+                    if (__builtin_expect(a.act_fn != 0, 0)) dv = o * swish_grad(zs, act_scale);
+                    else if (g < ND) dv = ((zb[0] >> (NHID - g)) & 1u) ? o : 0.0f;      // sign of act slot NHID - g
+                    else dv = zs > 0.0f ? o : 0.0f;
                     lds[(bi + 1) * M * LDA + r * LDA + fcol] = dv;
                     if (a.delta && row_ok) (a.delta + uoff(n, NSBH, bi + 1, BH32))[goff] = dv;
                     __syncthreads();
@@ -1412,9 +1457,14 @@ __global__ void __launch_bounds__(CF::NT, CF::WPS) snsde_mfma_reverse_kernel(Rev
                 // relu mask of the forward activation that produced this gradient's input: slot NHID - g (drift chain),
                 // the diffusion net's hidden activation (first GEMM of its chain, noise_option 18/19)
                 if (writer) {
-                    const f32x4 zsv = g < ND ? cur.mask[g < NM ? g : 0] : cur.nmask;
+                    if (g < ND) {
 #pragma unroll
-                    for (int i = 0; i < 4; ++i) v[i] = zsv[i] > 0.0f ? v[i] : 0.0f;
+                        for (int i = 0; i < 4; ++i) v[i] = ((zb[i < EPT ? i : 0] >> (NHID - g)) & 1u) ? v[i] : 0.0f;
+                    } else {
+                        const f32x4 zsv = cur.nmask;
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) v[i] = zsv[i] > 0.0f ? v[i] : 0.0f;
+                    }
                     *reinterpret_cast<f32x4*>(lds + (bi + 1) * M * LDA + r * LDA + wave * 16 + fsub) = v;
                     if (a.delta && row_ok)
                         *reinterpret_cast<f32x4*>(a.delta + uoff(n, NSBH, bi + 1, BH32) + (uint32_t)(row * H + wave * 16 + fsub)) = v;
@@ -1430,7 +1480,7 @@ __global__ void __launch_bounds__(CF::NT, CF::WPS) snsde_mfma_reverse_kernel(Rev
                 }
             }
         }
-        if constexpr (AHEAD) cur = nxt;
+        if constexpr (AHEAD) step_copy(cur, nxt);
     }
     if (row_ok) {     // ys[0] = y0
 #pragma unroll
