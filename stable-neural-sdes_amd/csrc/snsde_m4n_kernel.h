@@ -333,6 +333,9 @@ __global__ void __launch_bounds__(CF::NT, CF::WPS) snsde_m4n_kernel(MfmaArgs a) 
     float sk_y = yv, sk_f0 = 0.f, sk_f1 = 0.f, sk_g0 = 0.f, sk_g1 = 0.f, sk_g2 = 0.f, sk_dw = 0.f, sk_du = 0.f, sk_h1 = yv;
     float sk_z[4] = {0.f, 0.f, 0.f, 0.f}, sk_x[4] = {0.f, 0.f, 0.f, 0.f};
     float tail_sn = 0.f, tail_cs = 0.f;      // time features of t0 + h/4 (the tail evaluation's)
+    // 1 / h and 1 / sqrt h of the step in hand (two IEEE divisions per step at stage 0; the stage formulas below multiply by them:
+    // written with `/ h` and `/ sqh` they cost seven divisions of ~11 VALU instructions each per step on the issue port the MFMAs share)
+    float sk_rh = 0.f, sk_rsqh = 0.f;
 
     for (int n = 0; n < n_loop; ++n) {
         const bool more = n + 1 < n_loop;
@@ -501,6 +504,7 @@ __global__ void __launch_bounds__(CF::NT, CF::WPS) snsde_m4n_kernel(MfmaArgs a) 
             const float yb = yin, f0 = sk_f0, g0 = sk_g0;
             float h0n, h1n;       // next drift input / next net input
             if (stage == 0) {            // F0, G0 at (t0, y)
+                sk_rh = 1.0f / h; sk_rsqh = 1.0f / sqh;
                 sk_f0 = f;
                 sk_g0 = gfun(q, yb);
                 h0n = yb + f * h;
@@ -510,7 +514,7 @@ __global__ void __launch_bounds__(CF::NT, CF::WPS) snsde_m4n_kernel(MfmaArgs a) 
                 const float g1 = gfun(q, sk_h1);
                 sk_g1 = g1;
                 const float du = sk_du;
-                h0n = yb + 0.25f * f0 * h + 0.25f * f * h + g0 * du / h + 0.5f * g1 * du / h;
+                h0n = yb + 0.25f * f0 * h + 0.25f * f * h + (g0 + 0.5f * g1) * (du * sk_rh);
                 h1n = yb + f0 * h - g0 * sqh;
             } else {                     // F2 at (t0 + h/2, H0_2), G2 at (t0 + h, H1_2); H1_3 for the tail
                 sk_g2 = gfun(q, sk_h1);
@@ -539,12 +543,12 @@ __global__ void __launch_bounds__(CF::NT, CF::WPS) snsde_m4n_kernel(MfmaArgs a) 
                 const float g3 = gfun(q3, h1n);
                 const float f1 = sk_f1, g1 = sk_g1, g2 = sk_g2, ik = sk_dw, ik0 = sk_du;
                 const float ikk = 0.5f * (ik * ik - h);
-                const float ikkk = (ik * ik * ik - 3.0f * h * ik) / 6.0f;
-                const float a1 = ik, a2 = ikk / sqh, a3 = ik0 / h, a4 = ikkk / h;
+                const float ikkk = (ik * ik * ik - 3.0f * h * ik) * (1.0f / 6.0f);
+                const float a1 = ik, a2 = ikk * sk_rsqh, a3 = ik0 * sk_rh, a4 = ikkk * sk_rh;
                 const float w0 = -a1 - a2 + 2.0f * a3 - 2.0f * a4;
                 const float w1 = (4.0f / 3.0f) * a1 + (4.0f / 3.0f) * a2 - (4.0f / 3.0f) * a3 + (5.0f / 3.0f) * a4;
                 const float w2 = (2.0f / 3.0f) * a1 - (1.0f / 3.0f) * a2 - (2.0f / 3.0f) * a3 - (2.0f / 3.0f) * a4;
-                float yn1 = yb + (f0 + f1) * (h / 6.0f) + f * (2.0f * h / 3.0f);
+                float yn1 = yb + (f0 + f1) * (h * (1.0f / 6.0f)) + f * (h * (2.0f / 3.0f));
                 yn1 += w0 * g0 + w1 * g1 + w2 * g2 + a4 * g3;
                 sk_y = yn1; sk_h1 = yn1; yv = yn1;
                 ybuf[r * LDY + fcol] = yn1;

@@ -219,7 +219,9 @@ __global__ void __launch_bounds__(CF::NT, CF::WPS) snsde_m4n_srk_reverse_kernel(
         const float h11 = y + 0.25f * f0 * h + 0.5f * g0 * rdt;
         const float f1 = fast_tanh(cur.z[1] * gate(h01));
         const float g1 = gfun(cur.q[1], h11, om1, rc1, fi1);
-        const float h02 = y + 0.25f * f0 * h + 0.25f * f1 * h + g0 * ik0 / h + 0.5f * g1 * ik0 / h;
+        const float rh = 1.0f / h, rrdt = 1.0f / rdt;      // (the forward's two divisions per step; every `/ h`, `/ rdt` below multiplies)
+        const float ik0h = ik0 * rh;
+        const float h02 = y + 0.25f * f0 * h + 0.25f * f1 * h + (g0 + 0.5f * g1) * ik0h;
         const float f2 = fast_tanh(cur.z[2] * gate(h02));
         const float h12 = y + f0 * h - g0 * rdt;
         const float g2 = gfun(cur.q[2], h12, om2, rc2, fi2);
@@ -229,13 +231,13 @@ __global__ void __launch_bounds__(CF::NT, CF::WPS) snsde_m4n_srk_reverse_kernel(
 
         const float av = adj;
         const float ikk = 0.5f * (ik * ik - h);
-        const float ikkk = (ik * ik * ik - 3.0f * h * ik) / 6.0f;
-        const float a1 = ik, a2 = ikk / rdt, a3 = ik0 / h, a4 = ikkk / h;
+        const float ikkk = (ik * ik * ik - 3.0f * h * ik) * (1.0f / 6.0f);
+        const float a1 = ik, a2 = ikk * rrdt, a3 = ik0h, a4 = ikkk * rh;
         const float wg0 = -a1 - a2 + 2.0f * a3 - 2.0f * a4;
         const float wg1 = (4.0f / 3.0f) * a1 + (4.0f / 3.0f) * a2 - (4.0f / 3.0f) * a3 + (5.0f / 3.0f) * a4;
         const float wg2 = (2.0f / 3.0f) * a1 - (1.0f / 3.0f) * a2 - (2.0f / 3.0f) * a3 - (2.0f / 3.0f) * a4;
         float yb = carry + av;
-        float fb0 = av * (h / 6.0f), fb1 = fb0, fb2 = av * (2.0f * h / 3.0f);
+        float fb0 = av * (h * (1.0f / 6.0f)), fb1 = fb0, fb2 = av * (h * (2.0f / 3.0f));
         float gb0 = wg0 * av, gb1 = wg1 * av, gb2 = wg2 * av;
         const float gb3 = a4 * av;
 
@@ -272,7 +274,7 @@ __global__ void __launch_bounds__(CF::NT, CF::WPS) snsde_m4n_srk_reverse_kernel(
         yb += hb; fb0 = fmaf(h, hb, fb0); gb0 = fmaf(-rdt, hb, gb0);
         yb += d;
         fb0 = fmaf(0.25f * h, d, fb0); fb1 = fmaf(0.25f * h, d, fb1);
-        gb0 = fmaf(ik0 / h, d, gb0); gb1 = fmaf(0.5f * ik0 / h, d, gb1);
+        gb0 = fmaf(ik0h, d, gb0); gb1 = fmaf(0.5f * ik0h, d, gb1);
         // ---- G1 = g(t0 + h/4, H1_1) beside the drift at (t0 + h, H0_1) ----
         qb = net_in(gb1, om1, rc1, fi1, cur.q[1], h11, nd);
         dz = drift_in(fb1, f1, cur.z[1], h01, dd);
