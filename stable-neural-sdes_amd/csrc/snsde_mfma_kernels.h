@@ -1272,12 +1272,14 @@ __global__ void __launch_bounds__(CF::NT, CF::WPS) snsde_mfma_reverse_kernel(Rev
         }
         // ---- elementwise: d(f h + g dW)/d(zout, y) applied to the adjoint ----
         float ay[EPT], dz[EPT], dsv[EPT], dq[EPT];
+        const uint32_t zclear = a.act_fn == 0 ? ~((1u << (NHID + 1)) - 1u) : ~0u;
         uint32_t zb[EPT];      // bit pattern of the saved z: its low NHID + 1 bits are the relu signs of the step (snsde_pack_signs)
 #pragma unroll
         for (int e = 0; e < EPT; ++e) {
             dsv[e] = 0.0f; dq[e] = 0.0f;
-            const float y = cur.y[e], z = cur.z[e], dw = cur.dw[e], gq = cur.gq[e];
-            zb[e] = __builtin_bit_cast(uint32_t, z);
+            zb[e] = __builtin_bit_cast(uint32_t, cur.z[e]);
+            // (the sign bits are cleared before z is used: an infinite z of a diverged solve stays infinite instead of becoming a NaN)
+            const float y = cur.y[e], z = __builtin_bit_cast(float, zb[e] & zclear), dw = cur.dw[e], gq = cur.gq[e];
             const float av = adj[e];
             if (__builtin_expect(variant, 0)) {
                 // f = tanh z | z | z y;  g = raw = s_n or s_n y (SNSDE_DIFFUSION_RAW), else the reference's tanh(sigmoid(theta) raw)

@@ -902,6 +902,50 @@ RECOMPUTE_CASES = [
 ]
 
 
+SIGN_CASES = [
+    # io, no, NL, B, H, C, L, method, kernel: every Euler / Milstein forward kernel that feeds the MFMA adjoint
+    (4, 17, 2, 37, 128, 21, 9, 'euler', 'auto'),        # lean 4-row tiles (K2 model)
+    (6, 17, 4, 11, 64, 5, 9, 'milstein', 'auto'),       # lean, three hidden layers: four sign bits
+    (4, 17, 2, 37, 128, 21, 9, 'euler', 'mfma16'),      # general kernel, 16-row tiles
+    (4, 17, 2, 21, 256, 14, 8, 'milstein', 'auto'),     # streamed H = 256 (K5 model)
+    (4, 17, 3, 21, 256, 14, 8, 'euler', 'mfma16'),      # H = 256 on 16-row tiles
+    (3, 18, 2, 21, 64, 5, 9, 'euler', 'auto'),          # diffusion net, general 4-row tiles
+    (3, 19, 2, 9, 128, 3, 8, 'euler', 'auto'),          # diffusion net at H = 128: the net kernels' Euler variant
+    (4, 18, 2, 13, 64, 69, 9, 'euler', 'auto'),         # nets behind a wide control path
+    (0, 17, 2, 9, 64, 5, 8, 'euler', 'auto'),           # y-free drift
+]
+
+
+@pytest.mark.parametrize('ci', range(len(SIGN_CASES)))
+def test_saved_drift_carries_the_relu_signs_of_its_step(ci):
+    """Training-mode forward (include/snsde.h, act_save): the saved pre-tanh drift z (slot NL) carries [slot k > 0] of the same element
+    in mantissa bit k, k < NL, and is otherwise the exact z (the adjoint takes its relu masks from these bits instead of re-reading the
+    activation planes).  Checked on every forward kernel family against the activation planes of the same call, and z itself against
+    an inference-mode-identical solve whose bits are cleared: the forward's states do not depend on the packing."""
+    io, no, NL, B, H, C, L, method, kernel = SIGN_CASES[ci]
+    pr = make_problem(300 + ci, io, no, NL, B, H, C, L, nan_frac=0.2)
+    model = S.engine.model_struct(C, H, H, NL, io, no)
+    flat = flat_params(pr['params'], io, no, NL, C, H)
+    grid = S.engine.step_grid(np.asarray([0.0, float(L - 1)], np.float32), 1.0, pr['times'], torch.device(DEV))
+    args = (model, flat, torch.from_numpy(pr['coeffs']).to(DEV), grid, torch.from_numpy(pr['y0']).to(DEV))
+    call = S.engine.SolveCall(*args, method=method, seed=5, kernel=kernel, save_traj=True, save_dW=True, save_act=True)
+    if S.engine.backward_supported(call) != 1:
+        pytest.skip('not an MFMA-adjoint configuration')
+    ys = call.launch().clone()
+    plain = S.engine.SolveCall(*args, method=method, seed=5, kernel=kernel)
+    assert torch.equal(ys, plain.launch()), 'training-mode states differ from the inference solve'
+    act = call.act_save.cpu().numpy()                       # (N, slots, B, H)
+    zbits = act[:, NL].view(np.uint32)
+    for k in range(NL):
+        want = act[:, k] > 0
+        got = ((zbits >> k) & 1).astype(bool)
+        assert np.array_equal(got, want), f'sign bit {k}'
+        assert 0.02 < want.mean() < 0.98                    # (both signs occur: the check is not vacuous)
+    zc = (zbits & ~np.uint32((1 << NL) - 1)).view(np.float32)
+    z = act[:, NL]
+    assert np.all(np.abs(z - zc) <= np.abs(zc) * 2.0 ** (-23 + NL) + 1e-44)
+
+
 @pytest.mark.parametrize('ci', range(len(RECOMPUTE_CASES)))
 def test_recompute_mode_backward_equals_saved_activation_backward(ci):
     """options={'recompute': K}: states and increments kept, activations re-created chunk by chunk in backward
