@@ -470,6 +470,10 @@ __global__ void __launch_bounds__(CF::NT, CF::WPS) snsde_m4_kernel(MfmaArgs a) {
     float* const aown = bufA + r * LDA + fo;
     float* const bown = bufB + r * LDA + fo;
     const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+    // (round 4, measured and dropped: the trajectory plane stored TILE-WIDE out of ybuf by one wave of the younger half - H lanes x 16
+    //  bytes = the tile's 4 H contiguous bytes, instead of one dword per lane from all eight waves: 216.7 -> 217.8 us for the training-
+    //  mode forward at K2.  With the counted-vmcnt experiment at vm_wait this rules out both the store instruction count / segment
+    //  width and the acknowledgement drain as the source of the ~4 us per plane and 100 steps that every per-step store costs here.)
 
     LeanB<(KUXT > 0 ? KUXT : 1)> bx{};    // [X(t_n) | tau_n] operands of the step about to start
     if constexpr (KUXT > 0) lean_read_b_carried(xrow, bx);

@@ -337,6 +337,7 @@ __global__ void __launch_bounds__(CF::NT, CF::WPS) snsde_m4n_kernel(MfmaArgs a) 
     // written with `/ h` and `/ sqh` they cost seven divisions of ~11 VALU instructions each per step on the issue port the MFMAs share)
     float sk_rh = 0.f, sk_rsqh = 0.f;
 
+    Row row_next = get_row(0, 0);
     for (int n = 0; n < n_loop; ++n) {
         const bool more = n + 1 < n_loop;
         const int stage = SRK ? n % 3 : 0;
@@ -346,7 +347,10 @@ __global__ void __launch_bounds__(CF::NT, CF::WPS) snsde_m4n_kernel(MfmaArgs a) 
             fill_rows(rbase);
             __syncthreads();
         }
-        const Row cur_row = get_row(n, rbase), nxt = get_row(more ? n + 1 : n, rbase);
+        // (the row of pass n was read as `nxt` by the previous pass: one LDS fetch + scalarisation per pass instead of two - its
+        //  ds_read -> s_waitcnt -> v_readfirstlane chain sits at the top of every pass, in front of the first layers' operand reads)
+        const Row cur_row = row_next, nxt = get_row(more ? n + 1 : n, rbase);
+        row_next = nxt;
         if constexpr (CF::EMB) { if (more) load_coeffs(nxt.idx); }
         const float h = cur_row.h, sqh = cur_row.sqh;
         if constexpr (SRK) { if (stage == 1) { tail_sn = cur_row.nsn; tail_cs = cur_row.ncs; } }

@@ -622,6 +622,7 @@ __global__ void __launch_bounds__(CF::NT, CF::WPS) snsde_mfma_kernel(MfmaArgs a)
     const int n_loop = CF::SRK ? 3 * a.N : a.N;
 
     TRACE_DECL
+    Row row_next = get_row(0, 0);
     for (int n = 0; n < n_loop; ++n) {
         TRACE(0)
         const bool more = n + 1 < n_loop;
@@ -633,7 +634,8 @@ __global__ void __launch_bounds__(CF::NT, CF::WPS) snsde_mfma_kernel(MfmaArgs a)
             fill_rows(rbase);
             __syncthreads();
         }
-        const Row cur_row = get_row(n, rbase), nxt = get_row(more ? n + 1 : n, rbase);
+        const Row cur_row = row_next, nxt = get_row(more ? n + 1 : n, rbase);      // (row n was read as `nxt` by the previous pass)
+        row_next = nxt;
         const float n_sin = nxt.sn, n_cos = nxt.cs, n_frac = nxt.frac;
         const int n_idx = nxt.idx;
         const int c_nout = cur_row.nout, c_kfirst = cur_row.kfirst;
