@@ -773,7 +773,12 @@ bool make_wplan(const snsde_backward* b, const SnsdeNet& net, WPlan* w) {
     w->ntiles = nt;
     // R-splits per tile proportional to its work (MFMAs per slab + staging), ~2 workgroups per CU in total
     static const int wbias = getenv("SNSDE_WGRAD_BIAS") ? atoi(getenv("SNSDE_WGRAD_BIAS")) : 4;
-    static const long wtotal = getenv("SNSDE_WGRAD_WGS") ? atol(getenv("SNSDE_WGRAD_WGS")) : 512L;
+    // total workgroups of the GEMM launch.  Measured (profiles/r04_sweep_wgrad.txt, whole parameter pass): 512 (two resident per CU) is
+    // best at H = 128 below ~4e5 reduction rows (K2 0.167 ms; 1024: 0.173) and at H <= 32; H = 256 wants 1024 (its 256 x 256 jobs are
+    // four tiles each: K5 0.387 -> 0.281 ms), H = 64 1536 (64-wide tiles move half the bytes per workgroup: K4-shaped srk 0.558 ->
+    // 0.441 ms), long reductions at H = 128 1024 (K3 at 4096 rows 0.969 -> 0.928 ms)
+    static const long wenv = getenv("SNSDE_WGRAD_WGS") ? atol(getenv("SNSDE_WGRAD_WGS")) : 0L;
+    const long wtotal = wenv > 0 ? wenv : (H >= 256 ? 1024L : (H == 64 ? 1536L : (H == 128 && (long)R >= 400000L ? 1024L : 512L)));
     long wsum = 0;
     // (the weights stay proportional to the tile's columns although the kernel's column groups divide the MFMAs per wave at H < 128:
     //  there the kernel is bound by the bytes it stages, which scale the same way; measured at the K4 shape: 130 vs 151 us)
