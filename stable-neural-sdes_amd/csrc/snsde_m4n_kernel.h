@@ -83,19 +83,33 @@ __host__ __device__ constexpr int m4n_mat_ku(int H, int KUX, int NHID, int i) {
     j -= NHID + 1;
     return j == 0 ? H / 16 + 1 : H / 16;    // ny0 on [y | sin t, cos t]; ny1 and the transposed matrices
 }
-__host__ __device__ constexpr int m4n_reg_budget(int H) { return H >= 128 ? 136 : 144; }     // weight registers per lane
+// Weight registers per lane.  H = 128 under SRK: the SRID2 state, the two reciprocals and the sign word of the step push the working
+// set past what 136 weight registers leave (13 - 31 spilled registers per instantiation, scratch traffic inside the pass loop), so the
+// placement first tries a tighter budget (SNSDE_M4N_SRK_BUDGET: one more matrix parked in LDS) and keeps 136 where that does not fit the
+// LDS cap - no configuration loses its instantiation.
+#ifndef SNSDE_M4N_SRK_BUDGET
+#define SNSDE_M4N_SRK_BUDGET 120
+#endif
+__host__ __device__ constexpr int m4n_reg_budget(int H) { return H >= 128 ? 136 : 144; }
 __host__ __device__ constexpr int m4n_lds_cap_blocks(int H) { return (H >= 128 ? 136 : 56) / (H / 16); }   // 1 KB blocks per wave
-__host__ __device__ constexpr int m4n_nlds(int H, int KUX, int NHID, int NN, int METHOD) {
+__host__ __device__ constexpr int m4n_nlds_for(int H, int KUX, int NHID, int NN, int METHOD, int budget) {
     const int nm = m4n_nmat(KUX, NHID, NN, METHOD);
     int regs = 0;
     for (int i = 0; i < nm; ++i) regs += 4 * m4n_mat_ku(H, KUX, NHID, i);
     int nl = 0, blocks = 0;
-    while (regs > m4n_reg_budget(H) && nl < nm) {
+    while (regs > budget && nl < nm) {
         const int ku = m4n_mat_ku(H, KUX, NHID, nm - 1 - nl);
         if (blocks + ku > m4n_lds_cap_blocks(H)) break;
         regs -= 4 * ku; blocks += ku; ++nl;
     }
-    return regs > m4n_reg_budget(H) ? -1 : nl;
+    return regs > budget ? -1 : nl;
+}
+__host__ __device__ constexpr int m4n_nlds(int H, int KUX, int NHID, int NN, int METHOD) {
+    if (H >= 128 && METHOD == SNSDE_SRK) {
+        const int tight = m4n_nlds_for(H, KUX, NHID, NN, METHOD, SNSDE_M4N_SRK_BUDGET);
+        if (tight >= 0) return tight;
+    }
+    return m4n_nlds_for(H, KUX, NHID, NN, METHOD, m4n_reg_budget(H));
 }
 
 template <int H_, int KUX_, int NHID_, int NN_, int METHOD_>
@@ -370,6 +384,7 @@ __global__ void __launch_bounds__(CF::NT, CF::WPS) snsde_m4n_kernel(MfmaArgs a) 
             sgn = o > 0.0f ? 1u : 0u;      // relu signs of this lane's element (Euler: folded into the saved z, snsde_pack_signs)
         }
         const float nhid_own = net_l1(n, CF::ZSLOT + 1, q);      // (NN == 2: this lane's hidden pre-activation of the net)
+        if constexpr (SRK && NN == 2) sgn |= (nhid_own > 0.0f ? 1u : 0u) << (NHID + 1);      // SRK: the net's hidden sign rides in z as well
         __syncthreads();
         // ---- phase 1: net output; increments; next pass's control values / time features ----
         if constexpr (NN == 2) net_l2(n, CF::ZSLOT + 2, q);
@@ -476,8 +491,12 @@ __global__ void __launch_bounds__(CF::NT, CF::WPS) snsde_m4n_kernel(MfmaArgs a) 
                 }
             }
         }
-        // Euler on these kernels is differentiated by snsde_mfma_reverse_kernel, which takes the relu masks of the drift chain from z
-        save_act(n, CF::ZSLOT, (CF::METHOD == SNSDE_EULER && act_fn == 0) ? snsde_pack_signs(z, sgn, NHID + 1) : z);
+        // Euler on these kernels is differentiated by snsde_mfma_reverse_kernel, which takes the relu masks of the drift chain from z.
+        // SRK (snsde_m4n_rev_kernel.h): every pass's z carries the pass's drift signs, the hidden sign of the net evaluation beside it
+        // (bit NHID + 1) and - pass 3n + 2 - of the step's fourth evaluation (bit NHID + 2, known after the tail: stored there)
+        constexpr int SRK_BITS = NHID + 1 + (NN == 2 ? 2 : 0);
+        if (CF::METHOD == SNSDE_EULER) save_act(n, CF::ZSLOT, act_fn == 0 ? snsde_pack_signs(z, sgn, NHID + 1) : z);
+        else if (!SRK || stage != 2) save_act(n, CF::ZSLOT, (SRK && act_fn == 0) ? snsde_pack_signs(z, sgn, SRK_BITS) : z);
 
         // ---- f, g and the update (own element) ----
         const float yin = SRK ? sk_y : yv;         // (the drift pass's input state is yv)
@@ -540,7 +559,9 @@ __global__ void __launch_bounds__(CF::NT, CF::WPS) snsde_m4n_kernel(MfmaArgs a) 
                 __syncthreads();
                 // ---- tail: G3 = g(t0 + h/4, H1_3) ----
                 float q3 = 0.0f;
-                net_l1(n, CF::ZSLOT + NN + 1, q3);
+                const float nh3 = net_l1(n, CF::ZSLOT + NN + 1, q3);
+                if constexpr (NN == 2) sgn |= (nh3 > 0.0f ? 1u : 0u) << (NHID + 2);
+                save_act(n, CF::ZSLOT, act_fn == 0 ? snsde_pack_signs(z, sgn, SRK_BITS) : z);
                 __syncthreads();
                 if constexpr (NN == 2) net_l2(n, CF::ZSLOT + NN + 2, q3);
                 if (tid < M) { gybuf[tid * LDY + H] = nxt.nsn; gybuf[tid * LDY + H + 1] = nxt.ncs; }

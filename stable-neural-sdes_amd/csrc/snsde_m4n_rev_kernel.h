@@ -108,10 +108,13 @@ __global__ void __launch_bounds__(CF::NT, CF::WPS) snsde_m4n_srk_reverse_kernel(
         else gemm4<KUH>(w4, in, c, d);
     };
 
+    // (round 4: the relu masks - drift chain of every pass, hidden layer of every net evaluation - are sign bits in the low mantissa
+    //  bits of the pass's saved z, snsde_m4n_kernel.h; they were ten of the twenty (N, B, H) planes this kernel read per step)
     struct StepIn {
-        float y, ik, ik0, z[3], q[4], nh[4], dm[3][NHID + 1];
+        float y, ik, ik0, z[3], q[4];
         float h, rdt; int nout, kfirst;
     };
+    constexpr int SRK_BITS = NHID + 1 + (NN == 2 ? 2 : 0);
     auto fetch = [&](int n, StepIn& p) {
         const size_t so = uoff(n, BH32) + goff;
         p.y = a.traj[so]; p.ik = a.dW[so]; p.ik0 = a.dU[so];
@@ -120,13 +123,7 @@ __global__ void __launch_bounds__(CF::NT, CF::WPS) snsde_m4n_srk_reverse_kernel(
             const float* ap = a.act + uoff(3 * n + st, SLBH) + goff;
             p.z[st] = ap[(size_t)ZSLOT * BH];
             p.q[st] = ap[(size_t)(ZSLOT + NN) * BH];
-            if constexpr (NN == 2) p.nh[st] = ap[(size_t)(ZSLOT + 1) * BH];
-#pragma unroll
-            for (int g = 0; g < NHID + 1; ++g) p.dm[st][g] = ap[(size_t)(NHID - g) * BH];     // relu mask behind transposed GEMM g
-            if (st == 2) {
-                p.q[3] = ap[(size_t)(ZSLOT + 2 * NN) * BH];
-                if constexpr (NN == 2) p.nh[3] = ap[(size_t)(ZSLOT + NN + 1) * BH];
-            }
+            if (st == 2) p.q[3] = ap[(size_t)(ZSLOT + 2 * NN) * BH];
         }
         const float* stp = a.step_tab + uoff(n, SNSDE_STEP_STRIDE);
         p.h = stp[1]; p.rdt = stp[6]; p.nout = __float_as_int(stp[8]); p.kfirst = __float_as_int(stp[9]);
@@ -135,8 +132,8 @@ __global__ void __launch_bounds__(CF::NT, CF::WPS) snsde_m4n_srk_reverse_kernel(
     // Two independent chains under common barriers.  Drift: input cotangent dz at the pre-tanh output of pass p (delta slot
     // 0), relu masks dm[]; returns first_y^T(..) for the own element.  Net: input cotangent qb at the net's output
     // pre-activation of an evaluation whose deltas go to pass pn, slots ns0 / ns0 + 1; hidden mask nm; returns ny0_y^T(..).
-    auto chains = [&](bool do_d, int p, float dz, const float* dm, bool do_n, int pn, int ns0, float qb, float nm,
-                      float& d_res, float& n_res) {
+    auto chains = [&](bool do_d, int p, float dz, uint32_t dmbits, bool do_n, int pn, int ns0, float qb, bool nm,
+                      float& d_res, float& n_res) {      // dmbits: bit (NHID - k) = relu mask behind transposed GEMM k; nm: the net's hidden mask
         float* nbA = (NN == 1 && nsel) ? nb1 : nb0;
         float* nbB = nb1;
         if (do_d) {
@@ -158,7 +155,7 @@ __global__ void __launch_bounds__(CF::NT, CF::WPS) snsde_m4n_srk_reverse_kernel(
                 drift_gemm(k, lds + k * M * LDA + brow, c, d);
                 const float o = m4_reduce_scatter(c + d);
                 if (k < ND - 1) {
-                    const float dv = dm[k] > 0.0f ? o : 0.0f;
+                    const float dv = ((dmbits >> (NHID - k)) & 1u) ? o : 0.0f;
                     lds[(k + 1) * M * LDA + lrow] = dv;
                     if (a.delta && row_ok) (a.delta + uoff(p, SLBH, k + 1, BH32))[goff] = dv;
                     more = true;
@@ -172,7 +169,7 @@ __global__ void __launch_bounds__(CF::NT, CF::WPS) snsde_m4n_srk_reverse_kernel(
                 else gemm4<KUH>(wnB, nbB + brow, c, d);
                 const float o = m4_reduce_scatter(c + d);
                 if (k < NN - 1) {
-                    const float dv = nm > 0.0f ? o : 0.0f;
+                    const float dv = nm ? o : 0.0f;
                     nbB[lrow] = dv;
                     if (a.delta && row_ok) (a.delta + uoff(pn, SLBH, ns0 + 1, BH32))[goff] = dv;
                     more = true;
@@ -213,16 +210,23 @@ __global__ void __launch_bounds__(CF::NT, CF::WPS) snsde_m4n_srk_reverse_kernel(
         };
         float om0, om1, om2, om3, rc0, rc1, rc2, rc3;
         bool fi0, fi1, fi2, fi3;
-        const float f0 = fast_tanh(cur.z[0] * gate(y));
+        uint32_t zb[3];
+        float zc[3];
+#pragma unroll
+        for (int st = 0; st < 3; ++st) {
+            zb[st] = __builtin_bit_cast(uint32_t, cur.z[st]);
+            zc[st] = __builtin_bit_cast(float, zb[st] & ~((1u << SRK_BITS) - 1u));
+        }
+        const float f0 = fast_tanh(zc[0] * gate(y));
         const float g0 = gfun(cur.q[0], y, om0, rc0, fi0);
         const float h01 = y + f0 * h;
         const float h11 = y + 0.25f * f0 * h + 0.5f * g0 * rdt;
-        const float f1 = fast_tanh(cur.z[1] * gate(h01));
+        const float f1 = fast_tanh(zc[1] * gate(h01));
         const float g1 = gfun(cur.q[1], h11, om1, rc1, fi1);
         const float rh = 1.0f / h, rrdt = 1.0f / rdt;      // (the forward's two divisions per step; every `/ h`, `/ rdt` below multiplies)
         const float ik0h = ik0 * rh;
         const float h02 = y + 0.25f * f0 * h + 0.25f * f1 * h + (g0 + 0.5f * g1) * ik0h;
-        const float f2 = fast_tanh(cur.z[2] * gate(h02));
+        const float f2 = fast_tanh(zc[2] * gate(h02));
         const float h12 = y + f0 * h - g0 * rdt;
         const float g2 = gfun(cur.q[2], h12, om2, rc2, fi2);
         const float h13 = y + 0.25f * f2 * h + (-5.0f * g0 + 3.0f * g1 + 0.5f * g2) * rdt;
@@ -261,14 +265,14 @@ __global__ void __launch_bounds__(CF::NT, CF::WPS) snsde_m4n_srk_reverse_kernel(
 
         // ---- G3 = g(t0 + h/4, H1_3): the tail evaluation (second set of net slots of pass 3n + 2) ----
         float qb = net_in(gb3, om3, rc3, fi3, cur.q[3], h13, nd);
-        chains(false, 0, 0.0f, cur.dm[2], true, 3 * n + 2, NB0 + NN, qb, cur.nh[3], dres, nres);
+        chains(false, 0, 0.0f, zb[2], true, 3 * n + 2, NB0 + NN, qb, ((zb[2] >> (NHID + 2)) & 1u) != 0, dres, nres);
         float hb = nres + nd;
         yb += hb; fb2 = fmaf(0.25f * h, hb, fb2);
         gb0 = fmaf(-5.0f * rdt, hb, gb0); gb1 = fmaf(3.0f * rdt, hb, gb1); gb2 = fmaf(0.5f * rdt, hb, gb2);
         // ---- G2 = g(t0 + h, H1_2) beside the drift at (t0 + h/2, H0_2) ----
         qb = net_in(gb2, om2, rc2, fi2, cur.q[2], h12, nd);
-        float dz = drift_in(fb2, f2, cur.z[2], h02, dd);
-        chains(true, 3 * n + 2, dz, cur.dm[2], true, 3 * n + 2, NB0, qb, cur.nh[2], dres, nres);
+        float dz = drift_in(fb2, f2, zc[2], h02, dd);
+        chains(true, 3 * n + 2, dz, zb[2], true, 3 * n + 2, NB0, qb, ((zb[2] >> (NHID + 1)) & 1u) != 0, dres, nres);
         hb = nres + nd;
         float d = dres + dd;
         yb += hb; fb0 = fmaf(h, hb, fb0); gb0 = fmaf(-rdt, hb, gb0);
@@ -277,16 +281,16 @@ __global__ void __launch_bounds__(CF::NT, CF::WPS) snsde_m4n_srk_reverse_kernel(
         gb0 = fmaf(ik0h, d, gb0); gb1 = fmaf(0.5f * ik0h, d, gb1);
         // ---- G1 = g(t0 + h/4, H1_1) beside the drift at (t0 + h, H0_1) ----
         qb = net_in(gb1, om1, rc1, fi1, cur.q[1], h11, nd);
-        dz = drift_in(fb1, f1, cur.z[1], h01, dd);
-        chains(true, 3 * n + 1, dz, cur.dm[1], true, 3 * n + 1, NB0, qb, cur.nh[1], dres, nres);
+        dz = drift_in(fb1, f1, zc[1], h01, dd);
+        chains(true, 3 * n + 1, dz, zb[1], true, 3 * n + 1, NB0, qb, ((zb[1] >> (NHID + 1)) & 1u) != 0, dres, nres);
         hb = nres + nd;
         d = dres + dd;
         yb += hb; fb0 = fmaf(0.25f * h, hb, fb0); gb0 = fmaf(0.5f * rdt, hb, gb0);
         yb += d; fb0 = fmaf(h, d, fb0);
         // ---- G0 and F0, both at (t0, y) ----
         qb = net_in(gb0, om0, rc0, fi0, cur.q[0], y, nd);
-        dz = drift_in(fb0, f0, cur.z[0], y, dd);
-        chains(true, 3 * n, dz, cur.dm[0], true, 3 * n, NB0, qb, cur.nh[0], dres, nres);
+        dz = drift_in(fb0, f0, zc[0], y, dd);
+        chains(true, 3 * n, dz, zb[0], true, 3 * n, NB0, qb, ((zb[0] >> (NHID + 1)) & 1u) != 0, dres, nres);
         adj = yb + (nres + nd) + (dres + dd);
         cur = nxt;
     }

@@ -913,6 +913,9 @@ SIGN_CASES = [
     (3, 19, 2, 9, 128, 3, 8, 'euler', 'auto'),          # diffusion net at H = 128: the net kernels' Euler variant
     (4, 18, 2, 13, 64, 69, 9, 'euler', 'auto'),         # nets behind a wide control path
     (0, 17, 2, 9, 64, 5, 8, 'euler', 'auto'),           # y-free drift
+    (3, 18, 2, 21, 64, 5, 9, 'srk', 'auto'),            # SRK through a two-layer net: every pass's z, + the net's hidden signs
+    (1, 18, 2, 13, 128, 3, 8, 'srk', 'auto'),
+    (1, 14, 3, 9, 32, 3, 8, 'srk', 'auto'),             # one-layer net: drift signs only
 ]
 
 
@@ -934,16 +937,23 @@ def test_saved_drift_carries_the_relu_signs_of_its_step(ci):
     ys = call.launch().clone()
     plain = S.engine.SolveCall(*args, method=method, seed=5, kernel=kernel)
     assert torch.equal(ys, plain.launch()), 'training-mode states differ from the inference solve'
-    act = call.act_save.cpu().numpy()                       # (N, slots, B, H)
+    act = call.act_save.cpu().numpy()                       # (passes, slots, B, H): passes = N, 3 N under SRK
     zbits = act[:, NL].view(np.uint32)
     for k in range(NL):
         want = act[:, k] > 0
         got = ((zbits >> k) & 1).astype(bool)
         assert np.array_equal(got, want), f'sign bit {k}'
         assert 0.02 < want.mean() < 0.98                    # (both signs occur: the check is not vacuous)
-    zc = (zbits & ~np.uint32((1 << NL) - 1)).view(np.float32)
+    nbits = NL
+    if method == 'srk' and no in (18, 19):
+        # bit NL: the hidden layer of the net evaluation beside the pass (slot NL + 1); bit NL + 1 on the passes 3 n + 2: the hidden
+        # layer of the step's fourth evaluation (slot NL + 3)
+        nbits = NL + 2
+        assert np.array_equal(((zbits >> NL) & 1).astype(bool), act[:, NL + 1] > 0)
+        assert np.array_equal(((zbits[2::3] >> (NL + 1)) & 1).astype(bool), act[2::3, NL + 3] > 0)
+    zc = (zbits & ~np.uint32((1 << nbits) - 1)).view(np.float32)
     z = act[:, NL]
-    assert np.all(np.abs(z - zc) <= np.abs(zc) * 2.0 ** (-23 + NL) + 1e-44)
+    assert np.all(np.abs(z - zc) <= np.abs(zc) * 2.0 ** (-23 + nbits) + 1e-44)
 
 
 @pytest.mark.parametrize('ci', range(len(RECOMPUTE_CASES)))
