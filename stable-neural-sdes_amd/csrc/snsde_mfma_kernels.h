@@ -532,9 +532,9 @@ __global__ void __launch_bounds__(CF::NT, CF::WPS) snsde_mfma_kernel(MfmaArgs a)
     // store one layer output fragment (bias came in through the accumulator init) as 16 B per lane
     int save_step = 0;   // current step, for the optional activation save
     // relu signs of this lane's elements of the step's rectified layers (snsde_pack_signs): bit (slot) on 4-row tiles, bit
-    // (slot + 8 i) for fragment element i on 16-row tiles; folded into the saved z and cleared at the end of the step
+    // (slot + 8 i) for fragment element i on 16-row tiles; folded into the saved z and cleared at the end of the step / SRK pass
     [[maybe_unused]] uint32_t sgn = 0;
-    const bool pack_signs = !CF::SRK && a.act == 0 && a.act_save != nullptr;
+    const bool pack_signs = a.act == 0 && a.act_save != nullptr;      // (SRK: every pass's z carries the pass's signs)
     // field variants with a smooth activation (4-row tiles): the NHID + 1 pre-activations follow the regular slots (snsde_act_slots)
     const int nsave_rt = (FL && a.act != 0) ? CF::NSAVE + NHID + 1 : CF::NSAVE;
     // M4: the layer's bias is added after the k-slot reduction, from a register (one value per lane and layer)
@@ -555,7 +555,7 @@ __global__ void __launch_bounds__(CF::NT, CF::WPS) snsde_mfma_kernel(MfmaArgs a)
                 }
             }
             buf[r * ld + col0 + fsub + s] = o;
-            if constexpr (!CF::SRK) { if (relu && save_slot >= 0 && save_slot <= NHID) sgn |= (o > 0.0f ? 1u : 0u) << save_slot; }
+            if (relu && save_slot >= 0 && save_slot <= NHID) sgn |= (o > 0.0f ? 1u : 0u) << save_slot;
             if (save_slot >= 0 && a.act_save && row_ok) {
                 (a.act_save + uoff(save_step, (uint32_t)nsave_rt * (uint32_t)(B * H), save_slot, (uint32_t)(B * H)))[(uint32_t)(row * H + wave * 16 + fsub + s)] = o;
                 if (relu && a.act != 0)      // smooth activations: the pre-activation as well (slots behind the regular ones)
@@ -566,11 +566,9 @@ __global__ void __launch_bounds__(CF::NT, CF::WPS) snsde_mfma_kernel(MfmaArgs a)
         if (relu) {
 #pragma unroll
             for (int i = 0; i < 4; ++i) v[i] = fmaxf(v[i], 0.0f);
-            if constexpr (!CF::SRK) {
-                if (save_slot >= 0 && save_slot <= NHID) {
+            if (save_slot >= 0 && save_slot <= NHID) {
 #pragma unroll
-                    for (int i = 0; i < 4; ++i) sgn |= (v[i] > 0.0f ? 1u : 0u) << (save_slot + 8 * i);
-                }
+                for (int i = 0; i < 4; ++i) sgn |= (v[i] > 0.0f ? 1u : 0u) << (save_slot + 8 * i);
             }
         }
         if (writer) {
@@ -1596,10 +1594,13 @@ __global__ void __launch_bounds__(CF::NT, CF::WPS) snsde_mfma_srk_reverse_kernel
                                                          (uint32_t)(rowc * H + wave * 16 + fsub));     // (smooth activations: the PRE-activation slots)
         }
     };
-    load_masks(3 * a.N - 1, mk);
+    if (a.act_fn != 0) load_masks(3 * a.N - 1, mk);
     float acc_inv = 0.0f;          // accumulator column: 1 / g of the own column (additive table, constant over the step)
-    auto chain = [&](int p, float cot, float hin, float z, float F) {
-        if (p > 0) load_masks(p - 1, mk_next);
+    // relu: the masks of pass p are the low NHID + 1 bits of its saved z (zbp; snsde_pack_signs) and every lane masks, hands on and
+    // stores ITS OWN element of the all-reduced gradient; smooth activations: the writer lanes work on float4s of pre-activations
+    const bool relu_bits = a.act_fn == 0;
+    auto chain = [&](int p, float cot, float hin, float z, float F, uint32_t zbp) {
+        if (!relu_bits && p > 0) load_masks(p - 1, mk_next);
         float ty = 1.0f;
         if constexpr (CF::GEO) ty = fast_tanh(hin);
         const float dzt = cot * (1.0f - F * F);
@@ -1638,11 +1639,16 @@ __global__ void __launch_bounds__(CF::NT, CF::WPS) snsde_mfma_srk_reverse_kernel
 #pragma unroll
             for (int i = 0; i < 4; ++i) v[i] = row_ror_add(v[i]);
             if (g < NG - 1) {
-                if (writer) {
+                if (relu_bits) {
+                    float mine = v[0];
+                    mine = s1 ? v[1] : mine; mine = s2 ? v[2] : mine; mine = s3 ? v[3] : mine;
+                    mine = ((zbp >> (NHID - g)) & 1u) ? mine : 0.0f;      // sign of act slot NHID - g of the own element
+                    lds[(g + 1) * M * LDA + r * LDA + fcol] = mine;
+                    if (a.delta && row_ok) (a.delta + uoff(p, NGBH, g + 1, BH32))[goff] = mine;
+                } else if (writer) {
                     const f32x4 zsv = mk[g];
 #pragma unroll
-                    for (int i = 0; i < 4; ++i)
-                        v[i] = __builtin_expect(a.act_fn != 0, 0) ? v[i] * swish_grad(zsv[i], act_scale) : (zsv[i] > 0.0f ? v[i] : 0.0f);
+                    for (int i = 0; i < 4; ++i) v[i] = v[i] * swish_grad(zsv[i], act_scale);
                     *reinterpret_cast<f32x4*>(lds + (g + 1) * M * LDA + r * LDA + wave * 16 + fsub) = v;
                     if (a.delta && row_ok)
                         *reinterpret_cast<f32x4*>(a.delta + uoff(p, NGBH, g + 1, BH32) + (uint32_t)(row * H + wave * 16 + fsub)) = v;
@@ -1690,7 +1696,10 @@ __global__ void __launch_bounds__(CF::NT, CF::WPS) snsde_mfma_srk_reverse_kernel
         }
         if (row_ok && !a.adj0_only) (a.adj + uoff(n + 1, BH32))[goff] = adj;
         // ---- recompute the stage values of the step for the own element ----
-        const float y = cur.y, ik = cur.ik, ik0 = cur.ik0, z0 = cur.z0, z1 = cur.z1, z2 = cur.z2;
+        const float y = cur.y, ik = cur.ik, ik0 = cur.ik0;
+        const uint32_t zclear = a.act_fn == 0 ? ~((1u << (NHID + 1)) - 1u) : ~0u;      // (the sign bits are cleared before z is used)
+        const uint32_t zb0 = __builtin_bit_cast(uint32_t, cur.z0), zb1 = __builtin_bit_cast(uint32_t, cur.z1), zb2 = __builtin_bit_cast(uint32_t, cur.z2);
+        const float z0 = __builtin_bit_cast(float, zb0 & zclear), z1 = __builtin_bit_cast(float, zb1 & zclear), z2 = __builtin_bit_cast(float, zb2 & zclear);
         const float t0v = cur.t0v, t1v = cur.t1v, t3v = cur.t3v;
         if (__builtin_expect(a.acc_col >= 0, 0)) acc_inv = snsde_stable_inv(t0v);
         auto gate = [&](float hv) { return CF::GEO ? fast_tanh(hv) : 1.0f; };
@@ -1747,7 +1756,7 @@ __global__ void __launch_bounds__(CF::NT, CF::WPS) snsde_mfma_srk_reverse_kernel
             }
         }
         // ---- stage 2: drift at (t0 + h/2, H0_2) ----
-        float d = chain(3 * n + 2, fb2, h02, z2, f2);
+        float d = chain(3 * n + 2, fb2, h02, z2, f2, zb2);
         yb += d;
         fb0 = fmaf(0.25f * h, d, fb0); fb1 = fmaf(0.25f * h, d, fb1);
         gb0 = fmaf(ik0h, d, gb0); gb1 = fmaf(0.5f * ik0h, d, gb1);
@@ -1763,7 +1772,7 @@ __global__ void __launch_bounds__(CF::NT, CF::WPS) snsde_mfma_srk_reverse_kernel
                 if (r == 0) a.ds_part[((size_t)blockIdx.x * 4 * a.N + 4 * n + 1) * H + fcol] = ds1;
             }
         }
-        d = chain(3 * n + 1, fb1, h01, z1, f1);
+        d = chain(3 * n + 1, fb1, h01, z1, f1, zb1);
         yb += d; fb0 = fmaf(h, d, fb0);
         // ---- stage 0: both at (t0, y) ----
         yb = fmaf(gb0, g0p, yb);
@@ -1776,7 +1785,7 @@ __global__ void __launch_bounds__(CF::NT, CF::WPS) snsde_mfma_srk_reverse_kernel
                 a.ds_part[((size_t)blockIdx.x * 4 * a.N + 4 * n + 2) * H + fcol] = 0.0f;   // slot t0 + h/2: no diffusion evaluation
             }
         }
-        d = chain(3 * n, fb0, y, z0, f0);
+        d = chain(3 * n, fb0, y, z0, f0, zb0);
         adj = yb + d;
         cur = nxt;
     }

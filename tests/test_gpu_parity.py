@@ -916,6 +916,8 @@ SIGN_CASES = [
     (3, 18, 2, 21, 64, 5, 9, 'srk', 'auto'),            # SRK through a two-layer net: every pass's z, + the net's hidden signs
     (1, 18, 2, 13, 128, 3, 8, 'srk', 'auto'),
     (1, 14, 3, 9, 32, 3, 8, 'srk', 'auto'),             # one-layer net: drift signs only
+    (4, 17, 2, 37, 128, 21, 9, 'srk', 'auto'),          # SRK, elementwise diffusion (general kernel's SRK variant, 4-row tiles)
+    (6, 17, 3, 21, 64, 5, 9, 'srk', 'mfma16'),          # ... on 16-row tiles (the SRK adjoint reads the same saves)
 ]
 
 
