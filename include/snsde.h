@@ -167,11 +167,13 @@ typedef struct snsde_solve {
                               /* supplied dW), or NULL: h*(dW/2 + sqrt(h/12) xi), xi from Philox      */
     float*         dU_out;    /* optional device (N, B, H): the I_k0 actually used                    */
     float*         act_save;  /* optional device (N, snsde_act_slots, B, H): per-step activations the MFMA adjoint */
-                              /* needs (training mode; see snsde_solve_backward).  Euler / Milstein with the relu   */
-                              /* activation: the last drift slot (the pre-tanh drift output z) carries, in its low  */
-                              /* num_hidden_layers mantissa bits, the signs of the step's rectified layer outputs   */
-                              /* (bit k = [slot k > 0] of the same element) - the adjoint's relu masks, so that it  */
-                              /* does not re-read the activation planes; z itself is exact to ~1e-6 relative there  */
+                              /* needs (training mode; see snsde_solve_backward).  Models with the relu activation: */
+                              /* the last drift slot (the pre-tanh drift output z; one per pass under SRK) carries, */
+                              /* in its low num_hidden_layers mantissa bits, the signs of the step's / pass's        */
+                              /* rectified layer outputs (bit k = [slot k > 0] of the same element; through a two-  */
+                              /* layer diffusion net under SRK / Milstein also the net's hidden signs, one or two    */
+                              /* bits above) - the adjoints' relu masks, so that they do not re-read the activation  */
+                              /* planes; z itself is exact to 1e-6 .. 1e-5 relative there                            */
     float*         stage_save;/* SRK training on the MFMA path: optional device (3N + 1, planes, B, H), the input state of */
                               /* every drift pass (act_save / delta_save are then indexed by pass, 3N of them); planes = 1, */
                               /* or 3 with a diffusion net (snsde_save_layout)                                              */

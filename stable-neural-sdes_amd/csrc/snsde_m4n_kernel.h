@@ -384,7 +384,7 @@ __global__ void __launch_bounds__(CF::NT, CF::WPS) snsde_m4n_kernel(MfmaArgs a) 
             sgn = o > 0.0f ? 1u : 0u;      // relu signs of this lane's element (Euler: folded into the saved z, snsde_pack_signs)
         }
         const float nhid_own = net_l1(n, CF::ZSLOT + 1, q);      // (NN == 2: this lane's hidden pre-activation of the net)
-        if constexpr (SRK && NN == 2) sgn |= (nhid_own > 0.0f ? 1u : 0u) << (NHID + 1);      // SRK: the net's hidden sign rides in z as well
+        if constexpr ((SRK || MIL) && NN == 2) sgn |= (nhid_own > 0.0f ? 1u : 0u) << (NHID + 1);      // SRK / Milstein: the net's hidden sign rides in z as well
         __syncthreads();
         // ---- phase 1: net output; increments; next pass's control values / time features ----
         if constexpr (NN == 2) net_l2(n, CF::ZSLOT + 2, q);
@@ -496,7 +496,8 @@ __global__ void __launch_bounds__(CF::NT, CF::WPS) snsde_m4n_kernel(MfmaArgs a) 
         // (bit NHID + 1) and - pass 3n + 2 - of the step's fourth evaluation (bit NHID + 2, known after the tail: stored there)
         constexpr int SRK_BITS = NHID + 1 + (NN == 2 ? 2 : 0);
         if (CF::METHOD == SNSDE_EULER) save_act(n, CF::ZSLOT, act_fn == 0 ? snsde_pack_signs(z, sgn, NHID + 1) : z);
-        else if (!SRK || stage != 2) save_act(n, CF::ZSLOT, (SRK && act_fn == 0) ? snsde_pack_signs(z, sgn, SRK_BITS) : z);
+        else if (MIL) save_act(n, CF::ZSLOT, act_fn == 0 ? snsde_pack_signs(z, sgn, NHID + 1 + (NN == 2 ? 1 : 0)) : z);      // (snsde_m4n_mil_rev_kernel.h)
+        else if (stage != 2) save_act(n, CF::ZSLOT, act_fn == 0 ? snsde_pack_signs(z, sgn, SRK_BITS) : z);
 
         // ---- f, g and the update (own element) ----
         const float yin = SRK ? sk_y : yv;         // (the drift pass's input state is yv)

@@ -121,16 +121,15 @@ __global__ void __launch_bounds__(CF::NT, CF::WPS) snsde_m4n_mil_reverse_kernel(
         if (a.delta && row_ok) (a.delta + uoff(n, (uint32_t)NDEL * BH32, slot, BH32))[goff] = v;
     };
 
-    struct StepIn { float y, z, dw, q, h1, dm[NHID + 1]; float h; int nout, kfirst; };
+    // (round 4: the relu masks - drift chain, the net's hidden layer - are sign bits in the low mantissa bits of the saved z)
+    struct StepIn { float y, z, dw, q; float h; int nout, kfirst; };
+    constexpr int MIL_BITS = NHID + 1 + (NN == 2 ? 1 : 0);
     auto fetch = [&](int n, StepIn& p) {
         const size_t so = uoff(n, BH32) + goff;
         const float* ap = a.act + uoff(n, (uint32_t)NSAVE * BH32) + goff;
         p.y = a.traj[so]; p.dw = a.dW[so];
         p.z = ap[(size_t)ZSLOT * BH];
         p.q = ap[(size_t)(ZSLOT + NN) * BH];
-        p.h1 = NN == 2 ? ap[(size_t)(ZSLOT + 1) * BH] : 0.0f;
-#pragma unroll
-        for (int g = 0; g < NHID + 1; ++g) p.dm[g] = ap[(size_t)(NHID - g) * BH];
         const float* stp = a.step_tab + uoff(n, SNSDE_STEP_STRIDE);
         p.h = stp[1]; p.nout = __float_as_int(stp[8]); p.kfirst = __float_as_int(stp[9]);
     };
@@ -150,13 +149,16 @@ __global__ void __launch_bounds__(CF::NT, CF::WPS) snsde_m4n_mil_reverse_kernel(
         }
         if (row_ok) (a.adj + uoff(n + 1, BH32))[goff] = adj;
         const float av = adj, y = cur.y, dw = cur.dw, q = cur.q;
+        const uint32_t zb = __builtin_bit_cast(uint32_t, cur.z);
+        const float zc = __builtin_bit_cast(float, zb & ~((1u << MIL_BITS) - 1u));      // z with its sign bits cleared
+        const bool h1pos = NN == 2 && ((zb >> (NHID + 1)) & 1u) != 0;                       // [h1 > 0]: the net's hidden mask
 
         // drift: F = tanh(z gate(y)); cotangent a h
         const float ty = geo ? fast_tanh(y) : 1.0f;
-        const float F = fast_tanh(cur.z * ty);
+        const float F = fast_tanh(zc * ty);
         const float dzt = av * h * (1.0f - F * F);
         const float dz = dzt * ty;
-        const float direct_d = geo ? dzt * cur.z * (1.0f - ty * ty) : 0.0f;
+        const float direct_d = geo ? dzt * zc * (1.0f - ty * ty) : 0.0f;
         // diffusion value and its derivatives in raw
         const float raw = mul_y ? q * y : q;
         const bool fin = snsde_finite(raw);
@@ -178,7 +180,7 @@ __global__ void __launch_bounds__(CF::NT, CF::WPS) snsde_m4n_mil_reverse_kernel(
             drift_gemm(k, lds + k * M * LDA + brow, c, d);
             const float o = m4_reduce_scatter(c + d);
             if (k < ND - 1) {
-                const float dv = cur.dm[k] > 0.0f ? o : 0.0f;
+                const float dv = ((zb >> (NHID - k)) & 1u) ? o : 0.0f;
                 lds[(k + 1) * M * LDA + lrow] = dv;
                 put_delta(n, k + 1, dv);
                 return true;
@@ -210,7 +212,7 @@ __global__ void __launch_bounds__(CF::NT, CF::WPS) snsde_m4n_mil_reverse_kernel(
                 f32x4 c = {0.f, 0.f, 0.f, 0.f}, d = c;
                 gemm4<KUH>(n1f, bTA + brow, c, d);
                 const float hd_all = m4_reduce_scatter(c + d);      // (DPP: every lane takes part - never inside a select's branch)
-                const float hd = cur.h1 > 0.0f ? hd_all : 0.0f;
+                const float hd = h1pos ? hd_all : 0.0f;
                 bTB[lrow] = hd;
                 put_delta(n, NSAVE + 2, hd);
             }
@@ -231,13 +233,13 @@ __global__ void __launch_bounds__(CF::NT, CF::WPS) snsde_m4n_mil_reverse_kernel(
                 f32x4 c = {0.f, 0.f, 0.f, 0.f}, d = c;
                 gemm4<KUH>(n2t, bRA + brow, c, d);
                 const float d1_all = m4_reduce_scatter(c + d);
-                const float d1 = cur.h1 > 0.0f ? d1_all : 0.0f;
+                const float d1 = h1pos ? d1_all : 0.0f;
                 bRC[lrow] = d1;
                 put_delta(n, NB0 + 1, d1);
                 f32x4 c2 = {0.f, 0.f, 0.f, 0.f}, d2 = c2;
                 gemm4<KUH>(n2t, bRB + brow, c2, d2);
                 const float e1_all = m4_reduce_scatter(c2 + d2);
-                put_delta(n, NSAVE + 1, cur.h1 > 0.0f ? e1_all : 0.0f);
+                put_delta(n, NSAVE + 1, h1pos ? e1_all : 0.0f);
             }
             __syncthreads();
             // phase 4: drift 3 || dy = W1_y^T delta1

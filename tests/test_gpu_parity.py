@@ -916,6 +916,7 @@ SIGN_CASES = [
     (3, 18, 2, 21, 64, 5, 9, 'srk', 'auto'),            # SRK through a two-layer net: every pass's z, + the net's hidden signs
     (1, 18, 2, 13, 128, 3, 8, 'srk', 'auto'),
     (1, 14, 3, 9, 32, 3, 8, 'srk', 'auto'),             # one-layer net: drift signs only
+    (3, 18, 2, 21, 64, 5, 9, 'milstein', 'auto'),       # Milstein through a two-layer net: drift signs + the net's hidden sign
     (4, 17, 2, 37, 128, 21, 9, 'srk', 'auto'),          # SRK, elementwise diffusion (general kernel's SRK variant, 4-row tiles)
     (6, 17, 3, 21, 64, 5, 9, 'srk', 'mfma16'),          # ... on 16-row tiles (the SRK adjoint reads the same saves)
 ]
@@ -947,6 +948,9 @@ def test_saved_drift_carries_the_relu_signs_of_its_step(ci):
         assert np.array_equal(got, want), f'sign bit {k}'
         assert 0.02 < want.mean() < 0.98                    # (both signs occur: the check is not vacuous)
     nbits = NL
+    if method == 'milstein' and no in (18, 19):
+        nbits = NL + 1                                      # bit NL: the net's hidden layer (slot NL + 1)
+        assert np.array_equal(((zbits >> NL) & 1).astype(bool), act[:, NL + 1] > 0)
     if method == 'srk' and no in (18, 19):
         # bit NL: the hidden layer of the net evaluation beside the pass (slot NL + 1); bit NL + 1 on the passes 3 n + 2: the hidden
         # layer of the step's fourth evaluation (slot NL + 3)
