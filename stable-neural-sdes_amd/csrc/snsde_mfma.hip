@@ -283,7 +283,7 @@ MfmaPlan make_plan(const snsde_solve* s, const SnsdeNet& net, int flavor_hint) {
         const long r4 = ((s->batch + 3) / 4 + slots - 1) / slots, r16 = ((s->batch + 15) / 16 + slots - 1) / slots;
         // (round 4, profiles/r04_sweep_flavour.txt: the ratio of an M16 round to an M4 round is 3.5 at H = 256 - streamed weights - and
         //  1.8 at H = 64, where two co-resident 4-row workgroups slow each other down; 2.2 elsewhere)
-        const long ratio10 = H == 256 ? 35 : (H == 64 ? 18 : 22);
+        const long ratio10 = H == 256 ? 35 : ((H == 64 && !srk) ? 18 : 22);      // (measured under Euler; the SRK variant keeps 2.2)
         p.FL = flavor_hint >= 0 ? flavor_hint : (10 * r4 > ratio10 * r16 ? 0 : 1);
     }
     p.SRK = srk ? 1 : 0;
