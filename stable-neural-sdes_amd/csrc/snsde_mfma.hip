@@ -280,7 +280,8 @@ MfmaPlan make_plan(const snsde_solve* s, const SnsdeNet& net, int flavor_hint) {
     // two rounds per M16 round.  Narrow models (H <= 64: 4 or fewer waves per workgroup) co-reside on a CU.
     {
         const int slots = 256 * (p.NW <= 4 ? 8 / (p.NW < 2 ? 2 : p.NW) : 1);
-        const long r4 = ((s->batch + 3) / 4 + slots - 1) / slots, r16 = ((s->batch + 15) / 16 + slots - 1) / slots;
+        const int slots16 = srk ? 256 : slots;      // (the SRK variant's 16-row workgroups do not co-reside: H = 64 at 6144 rows ran two rounds)
+        const long r4 = ((s->batch + 3) / 4 + slots - 1) / slots, r16 = ((s->batch + 15) / 16 + slots16 - 1) / slots16;
         // (round 4, profiles/r04_sweep_flavour.txt: the ratio of an M16 round to an M4 round is 3.5 at H = 256 - streamed weights - and
         //  1.8 at H = 64, where two co-resident 4-row workgroups slow each other down; 2.2 elsewhere)
         const long ratio10 = H == 256 ? 35 : ((H == 64 && !srk) ? 18 : 22);      // (measured under Euler; the SRK variant keeps 2.2)
