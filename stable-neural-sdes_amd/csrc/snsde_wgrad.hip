@@ -494,7 +494,10 @@ __global__ void __launch_bounds__(256) snsde_wgrad_reduce_kernel(WArgs a, NHArgs
     const int tid = threadIdx.x, g = tid >> 6;
     const int e = (blockIdx.x * 64 + (tid & 63)) * 4;           // first of this thread's four elements (TILE_FLOATS is a multiple of 4)
     float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (e < TILE_FLOATS) {
+    // elements the GEMM tile never wrote (columns beyond the tile's ncols, rows beyond H: 64-wide tiles fill a quarter of the partial,
+    // the control-path tile a fifth) are not read either; a float4 never straddles a tile row (TILE is a multiple of 4)
+    const bool live = e < TILE * TILE ? ((e % TILE) < t.ncols && t.h0 + e / TILE < a.H) : (e < TILE_FLOATS && t.bias >= 0);
+    if (live) {
         const float* p = a.part + (size_t)t.part * TILE_FLOATS + e;
         int s = g;
         for (; s + 12 < t.nsplit; s += 16) {      // four loads in flight, added in split order
