@@ -130,29 +130,7 @@ __device__ __forceinline__ void fold_block(const float* __restrict__ params, flo
     const float* W = params + job.src_w[pc];
     const int K = job.K[pc];
     const float* ec = erow + job.col[pc];
-    for (int k = threadIdx.x; k < K; k += blockDim.x) {
-        float a0 = 0.0f, a1 = 0.0f, a2 = 0.0f, a3 = 0.0f;   // four independent chains hide the load latency
-        int j = 0;
-        for (; j + 15 < H; j += 16) {      // 16 loads in flight per round trip (same accumulation order as the 4-wide loop)
-            float wv[16];
-#pragma unroll
-            for (int i = 0; i < 16; ++i) wv[i] = W[(size_t)(j + i) * K + k];
-#pragma unroll
-            for (int i = 0; i < 16; i += 4) {
-                a0 = fmaf(ec[j + i], wv[i], a0);
-                a1 = fmaf(ec[j + i + 1], wv[i + 1], a1);
-                a2 = fmaf(ec[j + i + 2], wv[i + 2], a2);
-                a3 = fmaf(ec[j + i + 3], wv[i + 3], a3);
-            }
-        }
-        for (; j + 3 < H; j += 4) {
-            a0 = fmaf(ec[j], W[(size_t)j * K + k], a0);
-            a1 = fmaf(ec[j + 1], W[(size_t)(j + 1) * K + k], a1);
-            a2 = fmaf(ec[j + 2], W[(size_t)(j + 2) * K + k], a2);
-            a3 = fmaf(ec[j + 3], W[(size_t)(j + 3) * K + k], a3);
-        }
-        for (; j < H; ++j) a0 = fmaf(ec[j], W[(size_t)j * K + k], a0);
-        const float val = (a0 + a1) + (a2 + a3);
+    auto emit = [&](int k, float val) {
         ws[job.tmp[pc] + f * K + k] = val;
         if (pk) {     // forward prepare: straight into the packed MFMA fragment layout (source column k -> packed column kp)
             const MfmaLayerPack& L = *pkL;
@@ -163,6 +141,59 @@ __device__ __forceinline__ void fold_block(const float* __restrict__ params, flo
                 ws[L.dst + packed_index(pk->flavor, L.KU, f, kp)] = val;
             }
         }
+    };
+    // A thread owns columns k and k + blockDim (K > 256: H = 256 with its two time columns) and walks them TOGETHER: the walk is a chain
+    // of H / 16 dependent round trips, and a second pass for two leftover columns doubled it (prepare launch 24 us at K5, 7 us at K2)
+    for (int k = threadIdx.x; k < K; k += 2 * blockDim.x) {
+        const int k2 = k + blockDim.x;
+        const bool two = k2 < K;
+        float a0 = 0.0f, a1 = 0.0f, a2 = 0.0f, a3 = 0.0f;   // four independent chains hide the load latency
+        float b0 = 0.0f, b1 = 0.0f, b2 = 0.0f, b3 = 0.0f;
+        int j = 0;
+        for (; j + 15 < H; j += 16) {      // 16 (32) loads in flight per round trip (same accumulation order as the 4-wide loop;
+                                           // 32 / 64 in flight measured 3x slower: the kernel's 256-thread blocks lose their registers to it)
+            float wv[16], xv[16];
+#pragma unroll
+            for (int i = 0; i < 16; ++i) wv[i] = W[(size_t)(j + i) * K + k];
+            if (two) {
+#pragma unroll
+                for (int i = 0; i < 16; ++i) xv[i] = W[(size_t)(j + i) * K + k2];
+            }
+#pragma unroll
+            for (int i = 0; i < 16; i += 4) {
+                a0 = fmaf(ec[j + i], wv[i], a0);
+                a1 = fmaf(ec[j + i + 1], wv[i + 1], a1);
+                a2 = fmaf(ec[j + i + 2], wv[i + 2], a2);
+                a3 = fmaf(ec[j + i + 3], wv[i + 3], a3);
+            }
+            if (two) {
+#pragma unroll
+                for (int i = 0; i < 16; i += 4) {
+                    b0 = fmaf(ec[j + i], xv[i], b0);
+                    b1 = fmaf(ec[j + i + 1], xv[i + 1], b1);
+                    b2 = fmaf(ec[j + i + 2], xv[i + 2], b2);
+                    b3 = fmaf(ec[j + i + 3], xv[i + 3], b3);
+                }
+            }
+        }
+        for (; j + 3 < H; j += 4) {
+            a0 = fmaf(ec[j], W[(size_t)j * K + k], a0);
+            a1 = fmaf(ec[j + 1], W[(size_t)(j + 1) * K + k], a1);
+            a2 = fmaf(ec[j + 2], W[(size_t)(j + 2) * K + k], a2);
+            a3 = fmaf(ec[j + 3], W[(size_t)(j + 3) * K + k], a3);
+            if (two) {
+                b0 = fmaf(ec[j], W[(size_t)j * K + k2], b0);
+                b1 = fmaf(ec[j + 1], W[(size_t)(j + 1) * K + k2], b1);
+                b2 = fmaf(ec[j + 2], W[(size_t)(j + 2) * K + k2], b2);
+                b3 = fmaf(ec[j + 3], W[(size_t)(j + 3) * K + k2], b3);
+            }
+        }
+        for (; j < H; ++j) {
+            a0 = fmaf(ec[j], W[(size_t)j * K + k], a0);
+            if (two) b0 = fmaf(ec[j], W[(size_t)j * K + k2], b0);
+        }
+        emit(k, (a0 + a1) + (a2 + a3));
+        if (two) emit(k2, (b0 + b1) + (b2 + b3));
     }
     if (pc == 0 && threadIdx.x < 64) {   // folded bias: b_emb + E1 b_in + E2 b_init (one wave, shuffle reduction)
         float acc = 0.0f;
