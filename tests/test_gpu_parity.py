@@ -902,6 +902,35 @@ RECOMPUTE_CASES = [
 ]
 
 
+def test_recompute_mode_peaks_below_the_saved_activation_mode():
+    """options={'recompute': K} is a CAPACITY mode: at the K2 size a step with 50- and 25-step chunks must peak below the saved-activation
+    step (round 3 it peaked ABOVE at 50: two chunks' buffers were alive at once and every chunk copied its increments)."""
+    io, no, NL, B, H, C, L = 4, 17, 2, 1024, 128, 21, 101
+    pr = make_problem(7, io, no, NL, B, H, C, L, nan_frac=0.2)
+    m = S.Diffusion_model(C, H, H, NL, input_option=io, noise_option=no)
+    m.load_state_dict({k: torch.from_numpy(v.copy()) for k, v in pr['params'].items()})
+    m = m.to(DEV)
+    times = torch.from_numpy(pr['times']).to(DEV)
+    m.set_X(torch.from_numpy(pr['coeffs']).to(DEV), times)
+    y0 = torch.from_numpy(pr['y0']).to(DEV)
+    peak = {}
+    for chunk in (0, 50, 25):
+        def step():
+            for p in m.parameters():
+                p.grad = None
+            yy = y0.clone().requires_grad_(True)
+            S.sdeint(m, yy, times[[0, -1]], method='euler', dt=1.0, options={'seed': 1, 'recompute': chunk})[-1].square().mean().backward()
+        step(); step()
+        torch.cuda.synchronize()
+        base = torch.cuda.memory_allocated()
+        torch.cuda.reset_peak_memory_stats()
+        step()
+        torch.cuda.synchronize()
+        peak[chunk] = torch.cuda.max_memory_allocated() - base
+    assert peak[50] < 0.9 * peak[0], peak
+    assert peak[25] < peak[50], peak
+
+
 SIGN_CASES = [
     # io, no, NL, B, H, C, L, method, kernel: every Euler / Milstein forward kernel that feeds the MFMA adjoint
     (4, 17, 2, 37, 128, 21, 9, 'euler', 'auto'),        # lean 4-row tiles (K2 model)
