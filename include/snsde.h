@@ -340,7 +340,9 @@ SNSDE_API int snsde_readout_head(const snsde_head* h, void* hip_stream);
 
 SNSDE_API int         snsde_version(void);
 /* SNSDE_OK when `version` == SNSDE_VERSION and the four sizes equal the library's sizeof(snsde_model / snsde_solve /
- * snsde_backward / snsde_head); SNSDE_ERR_ABI otherwise.  A binding calls it once after loading the library.            */
+ * snsde_backward / snsde_head); SNSDE_ERR_ABI otherwise.  A size of 0 means "this binding does not declare that struct"
+ * (a forward-only binding has no snsde_backward / snsde_head) and is not compared.  A binding calls it once after loading
+ * the library.                                                                                                          */
 SNSDE_API int         snsde_abi_check(int version, size_t sizeof_model, size_t sizeof_solve, size_t sizeof_backward, size_t sizeof_head);
 SNSDE_API const char* snsde_strerror(int code);
 

@@ -51,7 +51,7 @@ def check_lean_resources(src, remarks):
                            f'csrc/snsde_mfma_kernels.h): {bad}')
 
 
-def build(force=False, verbose=False, defines=(), out=None, check_resources=True):
+def build(force=False, verbose=False, defines=(), out=None, check_resources=True, incremental=False):
     """Compile every csrc/*.hip to an object file (in parallel: the MFMA kernels are split by hidden size) and
     link libsnsde.so."""
     from concurrent.futures import ThreadPoolExecutor
@@ -67,8 +67,12 @@ def build(force=False, verbose=False, defines=(), out=None, check_resources=True
     # -fvisibility=hidden: only the SNSDE_API entry points of include/snsde.h are in the dynamic symbol table
     base = [cc, '--offload-arch=gfx950', '--offload-compress', '-O3', '-std=c++17', '-fPIC', '-fvisibility=hidden', '-I', INCLUDE, '-I', CSRC] + list(defines)
 
+    hdr_time = max(os.path.getmtime(h) for h in glob.glob(os.path.join(CSRC, '*.h')) + [os.path.join(INCLUDE, 'snsde.h')])
+
     def compile_one(src):
         obj = os.path.join(objdir, os.path.basename(src)[:-4] + '.o')
+        if incremental and os.path.exists(obj) and os.path.getmtime(obj) > max(os.path.getmtime(src), hdr_time):
+            return obj          # (development: `python build.py inc`; the lean resource check only sees what was recompiled)
         lean = os.path.basename(src).startswith(('snsde_m4_h', 'snsde_m4s_h'))
         cmd = base + (['-Rpass-analysis=kernel-resource-usage'] if lean else []) + ['-c', src, '-o', obj]
         if verbose:
@@ -86,11 +90,12 @@ def build(force=False, verbose=False, defines=(), out=None, check_resources=True
     # internal launchers / dispatchers, the version script also localises the weak kernel-handle objects hipcc emits for template
     # kernels (they are only referenced from inside the library)
     import re
-    names = sorted(set(re.findall(r'\b(snsde_[a-z_0-9]+)\s*\(', open(os.path.join(INCLUDE, 'snsde.h')).read())))
+    # (only declarations: lines that start with SNSDE_API, not names mentioned in the header's prose)
+    names = sorted(set(re.findall(r'^SNSDE_API\s[^;(]*?\b(snsde_[a-z_0-9]+)\s*\(', open(os.path.join(INCLUDE, 'snsde.h')).read(), re.M)))
     vs = os.path.join(objdir, 'exports.map')
     with open(vs, 'w') as f:
         f.write('{\n  global:\n' + ''.join(f'    {n};\n' for n in names) + '  local:\n    *;\n};\n')
-    cmd = [cc, '--offload-arch=gfx950', '-shared', '-fPIC', '-Wl,--version-script=' + vs, '-o', out + '.tmp'] + objs
+    cmd = [cc, '--offload-arch=gfx950', '-shared', '-fPIC', '-Wl,--version-script=' + vs, '-Wl,--undefined-version', '-o', out + '.tmp'] + objs
     r = subprocess.run(cmd, capture_output=True, text=True)
     if r.returncode != 0:
         raise RuntimeError('link failed:\n' + r.stdout + r.stderr)
@@ -107,5 +112,10 @@ if __name__ == '__main__':
         # trace build spills two registers and is not used by the tool, hence no resource check
         print(build(force=True, defines=('-DLEAN_TRACE', '-DSNSDE_DEV_SUBSET'), out=os.path.join(HERE, 'libsnsde_leantrace.so'),
                     check_resources=False))
+    elif len(sys.argv) > 1 and sys.argv[1] == 'inc':
+        print(build(force=True, verbose=True, incremental=True))
+    elif len(sys.argv) > 1 and sys.argv[1] == 'devtuning':
+        # the weight-gradient split heuristic's sweep knobs (tools/sweep_wgrad.sh); the product library reads no environment
+        print(build(force=True, defines=('-DSNSDE_DEV_TUNING',), out=os.path.join(HERE, 'libsnsde_devtuning.so')))
     else:
         print(build(force=True, verbose=True))

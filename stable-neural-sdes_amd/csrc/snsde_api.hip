@@ -144,8 +144,10 @@ extern "C" {
 int snsde_version(void) { return SNSDE_VERSION; }
 
 int snsde_abi_check(int version, size_t sizeof_model, size_t sizeof_solve, size_t sizeof_backward, size_t sizeof_head) {
-    return (version == SNSDE_VERSION && sizeof_model == sizeof(snsde_model) && sizeof_solve == sizeof(snsde_solve) &&
-            sizeof_backward == sizeof(snsde_backward) && sizeof_head == sizeof(snsde_head)) ? SNSDE_OK : SNSDE_ERR_ABI;
+    // 0 = "this binding does not declare that struct" (a forward-only binding has no snsde_backward / snsde_head)
+    auto same = [](size_t got, size_t want) { return got == 0 || got == want; };
+    return (version == SNSDE_VERSION && same(sizeof_model, sizeof(snsde_model)) && same(sizeof_solve, sizeof(snsde_solve)) &&
+            same(sizeof_backward, sizeof(snsde_backward)) && same(sizeof_head, sizeof(snsde_head))) ? SNSDE_OK : SNSDE_ERR_ABI;
 }
 
 const char* snsde_strerror(int code) {

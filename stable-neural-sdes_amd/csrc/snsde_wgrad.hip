@@ -775,12 +775,19 @@ bool make_wplan(const snsde_backward* b, const SnsdeNet& net, WPlan* w) {
     if (!ok) return false;
     w->ntiles = nt;
     // R-splits per tile proportional to its work (MFMAs per slab + staging), ~2 workgroups per CU in total
+    // (the sweep knobs SNSDE_WGRAD_BIAS / SNSDE_WGRAD_WGS / SNSDE_DEBUG_WPLAN exist in -DSNSDE_DEV_TUNING builds only,
+    //  tools/sweep_wgrad.py: the product library reads no environment)
+#ifdef SNSDE_DEV_TUNING
     static const int wbias = getenv("SNSDE_WGRAD_BIAS") ? atoi(getenv("SNSDE_WGRAD_BIAS")) : 4;
+    static const long wenv = getenv("SNSDE_WGRAD_WGS") ? atol(getenv("SNSDE_WGRAD_WGS")) : 0L;
+#else
+    constexpr int wbias = 4;
+    constexpr long wenv = 0L;
+#endif
     // total workgroups of the GEMM launch.  Measured (profiles/r04_sweep_wgrad.txt, whole parameter pass): 512 (two resident per CU) is
     // best at H = 128 below ~4e5 reduction rows (K2 0.167 ms; 1024: 0.173) and at H <= 32; H = 256 wants 1024 (its 256 x 256 jobs are
     // four tiles each: K5 0.387 -> 0.281 ms), H = 64 1536 (64-wide tiles move half the bytes per workgroup: K4-shaped srk 0.558 ->
     // 0.441 ms), long reductions at H = 128 1024 (K3 at 4096 rows 0.969 -> 0.928 ms)
-    static const long wenv = getenv("SNSDE_WGRAD_WGS") ? atol(getenv("SNSDE_WGRAD_WGS")) : 0L;
     const long wtotal = wenv > 0 ? wenv : (H >= 256 ? 1024L : (H == 64 ? 1536L : (H == 128 && (long)R >= 400000L ? 1024L : 512L)));
     long wsum = 0;
     // (the weights stay proportional to the tile's columns although the kernel's column groups divide the MFMAs per wave at H < 128:
@@ -828,6 +835,7 @@ bool make_wplan(const snsde_backward* b, const SnsdeNet& net, WPlan* w) {
     w->xaux_off = o;        // (round 3: an (R, ldx) buffer of the control-path columns lived here; they are evaluated on the fly now)
     (void)R;
     w->total_floats = o + 16;
+#ifdef SNSDE_DEV_TUNING
     if (getenv("SNSDE_DEBUG_WPLAN")) {
         for (int i = 0; i < nt; ++i) {
             const WTile& t = w->tile[i];
@@ -838,6 +846,7 @@ bool make_wplan(const snsde_backward* b, const SnsdeNet& net, WPlan* w) {
         fprintf(stderr, "nact %d ldx %d naux %d n_col0 %d NP %d sums %zu part %zu xaux_off %zu total %zu\n", w->nact, w->ldx, w->naux, w->n_col0,
                 w->NP, w->sums_floats, w->part_floats, w->xaux_off, w->total_floats);
     }
+#endif
     aa.net = net; aa.H = H; aa.C = C; aa.N = n_trow; aa.io = io; aa.no = no; aa.nhid = nhid; aa.has_dth = w->has_dth ? 1 : 0;
     return true;
 }

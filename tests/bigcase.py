@@ -1,0 +1,168 @@
+"""Backward parity at the BASELINE sizes: shared driver of tests/test_gpu_backward_sizes.py and
+tools/grad_margins.py.
+
+One case = one (input_option, noise_option) model at a BASELINE.json size, solved three times on identical replayed
+increments and the same loss weights:
+  * HIP: the fused forward + adjoint + parameter pass (fp32), kernel as requested;
+  * loop32: the tensor-op loop in fp32 on the same device (the reference's way of differentiating, common_sde.py:158-160);
+  * ref64: the tensor-op loop in fp64 (the arbiter).
+Rows whose fp32 trajectory leaves the fp64 one (a relu / tanh kink flipped by round-off, SURVEY 8c's K3 note) make the
+gradient of ANY fp32 run differ from the fp64 one at first order; which rows do that is a property of the row.  The loss
+therefore weights only the rows that the fp32 LOOP keeps inside SURVEY 8c's band - chosen without looking at the kernel - and the
+report gives, per tensor, max|err| / max|ref| and mean|err| / mean|ref| of HIP and of loop32 against ref64.
+"""
+import numpy as np
+import torch
+
+import stable_neural_sdes_amd as S
+from oracle import sde_oracle as O
+from tests.helpers import draw_dW, make_problem
+
+
+class ReplayBM:
+    levy_area_approximation = 'space-time'
+
+    def __init__(self, dW, dU=None):
+        self.dW, self.dU, self.n = dW, dU, 0
+
+    def __call__(self, ta, tb, return_U=False):
+        i, self.n = self.n, self.n + 1
+        return (self.dW[i], self.dU[i]) if return_U else self.dW[i]
+
+
+CASES = {
+    # name: io, no, NL, B, H, C, L, method, every knot an output?, Hermite coefficients?, NaN fraction
+    'K2': (4, 17, 2, 1024, 128, 21, 101, 'euler', False, False, 0.3),
+    'K5': (4, 17, 2, 1024, 256, 14, 50, 'milstein', True, False, 0.3),
+    'K3': (6, 17, 2, 4096, 128, 21, 201, 'euler', False, True, 0.0),     # R = 819200 >= 400000: the long-reduction split of snsde_wgrad.hip
+    'K4': (3, 18, 2, 2048, 64, 69, 72, 'euler', True, False, 0.3),
+    'K4srk': (3, 18, 2, 2048, 64, 69, 72, 'srk', True, False, 0.3),
+}
+
+
+ROW_TOL = 1e-5          # a row's dL/dy0 error (max over its H entries) relative to the largest |dL/dy0| of the batch
+KINK_ROWS_FRAC = 0.005  # share of rows that may exceed it (relu kinks flipped by fp32 round-off: measured 0 - 3 rows per case)
+
+# K3's default-initialised weights (unit scale, dt = 1, 200 steps) make the adjoint of ANY fp32 run overflow: the fp64 arbiter's
+# adjoint peaks at 3e43 mid-horizon before it contracts again, fp32 autograd through the tensor loop returns NaN on more than half
+# of the rows (measured on the CPU, 32 rows: same rows as the kernels).  The backward case therefore halves the weight scale
+# (max |y| 36 instead of 200, adjoints below 1e4); the forward K3 cases keep the unit scale.
+CASE_OPTS = {'K3': {'weight_scale': 0.5}}
+
+
+def run_case(name, dev, kernel='auto', seed=None, loop32=True, rows=None, options=None, weight_scale=None):
+    """-> report dict.  Two passes: the first finds the rows whose dL/dy0 deviates (a relu pre-activation within round-off of
+    zero takes the other branch in fp32: the row's gradient then differs at first order, in the fp32 tensor loop exactly as
+    in the kernels - K2: the loop has such a row, the kernel none; K4: the 4-row-tile kernel has, the loop none); the second
+    repeats the backward with those rows' loss weights zeroed in the fp64 run and in the HIP run alike, so that the
+    parameter gradients (sums over rows) are compared on the remaining rows at the tolerance round-off alone explains."""
+    io, no, NL, B, H, C, L, method, every, hermite, nanf = CASES[name]
+    if rows is not None:
+        B = rows
+    seed = seed if seed is not None else 7000 + sum(map(ord, name))
+    if weight_scale is None:
+        weight_scale = CASE_OPTS.get(name, {}).get('weight_scale')
+    pr = make_problem(seed, io, no, NL, B, H, C, L, nan_frac=nanf, hermite=hermite, weight_scale=weight_scale)
+    ts = pr['times'] if every else np.array([pr['times'][0], pr['times'][-1]], np.float32)
+    dt = 1.0
+    dW = draw_dW(seed, ts, dt, B, H)
+    rng = np.random.default_rng(seed + 5)
+    dU = None
+    if method == 'srk':
+        dU = (0.5 * dW + np.sqrt(1.0 / 12) * rng.standard_normal(dW.shape).astype(np.float32)).astype(np.float32)
+    wsum = rng.standard_normal((len(ts), B, H)).astype(np.float32)
+
+    def build(dtype):
+        m = S.Diffusion_model(C, H, H, NL, input_option=io, noise_option=no)
+        m.load_state_dict({k: torch.from_numpy(v.copy()) for k, v in pr['params'].items()})
+        m = m.to(device=dev, dtype=dtype)
+        m.set_X(torch.from_numpy(pr['coeffs']).to(device=dev, dtype=dtype), torch.from_numpy(pr['times']).to(dev))
+        y0 = torch.from_numpy(pr['y0']).to(device=dev, dtype=dtype).requires_grad_(True)
+        return m, y0
+
+    def bm(dtype):
+        return ReplayBM(torch.from_numpy(dW).to(device=dev, dtype=dtype),
+                        None if dU is None else torch.from_numpy(dU).to(device=dev, dtype=dtype))
+
+    tsd = torch.from_numpy(ts).to(dev)
+    # forward passes first: the stable rows are those the fp32 LOOP keeps inside SURVEY 8c's band
+    m64, y64 = build(torch.float64)
+    ys64 = S.sdeint(m64, y64, tsd, bm=bm(torch.float64), method=method, dt=dt, options={'backend': 'torch'})
+    m32, y32 = build(torch.float32)
+    with torch.set_grad_enabled(loop32):
+        ys32 = S.sdeint(m32, y32, tsd, bm=bm(torch.float32), method=method, dt=dt, options={'backend': 'torch'})
+    e32 = (ys32.detach().double() - ys64.detach()).abs()
+    stable = ~((e32 > 1e-4 + 1e-4 * ys64.detach().abs()).any(dim=2).any(dim=0))          # (B,)
+    w = torch.from_numpy(wsum).to(dev) * stable.to(torch.float32)[None, :, None]
+    opts = {'kernel': kernel, 'strict': True}
+    opts.update(options or {})
+
+    def hip_pass(weights):
+        mh, yh = build(torch.float32)
+        ysh = S.sdeint(mh, yh, tsd, bm=bm(torch.float32), method=method, dt=dt, options=opts)
+        (ysh * weights).sum().backward()
+        return mh, yh, ysh.detach()
+
+    def zero_grads(m, y):
+        y.grad = None
+        for p in m.parameters():
+            p.grad = None
+
+    (ys64 * w.double()).sum().backward(retain_graph=True)
+    mh, yh, ysh = hip_pass(w)
+    gmax = float(y64.grad.abs().max()) + 1e-300
+    row_err = (yh.grad.double() - y64.grad).abs().amax(dim=1) / gmax
+    flagged = row_err > ROW_TOL
+    rep = {'stable_rows': int(stable.sum()), 'rows': B, 'tensors': {}, 'kink_rows': int(flagged.sum()),
+           'kink_rows_worst': float(row_err.max()), 'first_pass_y0_max_rel': float(row_err.max())}
+    if loop32:
+        (ys32 * w).sum().backward()
+        rep['loop32_kink_rows'] = int(((y32.grad.double() - y64.grad).abs().amax(dim=1) / gmax > ROW_TOL).sum())
+    if bool(flagged.any()):
+        w = w * (~flagged).to(torch.float32)[None, :, None]
+        zero_grads(m64, y64)
+        (ys64 * w.double()).sum().backward()
+        mh, yh, ysh = hip_pass(w)
+        if loop32:
+            m32, y32 = build(torch.float32)
+            ys32 = S.sdeint(m32, y32, tsd, bm=bm(torch.float32), method=method, dt=dt, options={'backend': 'torch'})
+            (ys32 * w).sum().backward()
+
+    def rel(got, ref):
+        ref = ref.detach().double()
+        err = (got.detach().double() - ref).abs()
+        return float(err.max() / (ref.abs().max() + 1e-300)), float(err.mean() / (ref.abs().mean() + 1e-300))
+
+    eh = (ysh.double() - ys64.detach()).abs()[:, stable]
+    rep['forward'] = dict(hip_max=float(eh.max()), hip_mean=float(eh.mean()), loop32_max=float(e32[:, stable].max()),
+                          loop32_mean=float(e32[:, stable].mean()),
+                          rows_left_by_kernel=int(((eh > 1e-4 + 1e-4 * ys64.detach().abs()[:, stable]).any(dim=2).any(dim=0)).sum()))
+    named = [('y0', yh.grad, y32.grad, y64.grad)]
+    r64, r32 = dict(m64.named_parameters()), dict(m32.named_parameters())
+    for n, p in mh.named_parameters():
+        named.append((n, p.grad, r32[n].grad, r64[n].grad))
+    for n, gh, g32, g64 in named:
+        if g64 is None or float(g64.abs().max()) == 0.0:
+            assert gh is None or float(gh.abs().max()) < 1e-6, n
+            continue
+        assert bool(torch.isfinite(g64).all()), 'fp64 arbiter not finite: ' + n
+        assert gh is not None and bool(torch.isfinite(gh).all()), n
+        hm, ha = rel(gh, g64)
+        lm, la = rel(g32, g64) if loop32 else (float('nan'), float('nan'))
+        rep['tensors'][n] = dict(hip_max=hm, hip_mean=ha, loop32_max=lm, loop32_mean=la)
+    rep['grads'] = {n: gh.detach() for n, gh, _, _ in named if gh is not None}
+    rep['model'], rep['y0'] = mh, yh
+    rep['inputs'] = dict(pr=pr, ts=ts, dW=dW, dU=dU, w=w, method=method)
+    return rep
+
+
+def format_report(name, rep):
+    lines = [f"{name}: rows whose dL/dy0 deviates by more than {ROW_TOL:g} of the batch maximum (first pass): {rep['kink_rows']} (worst "
+             f"{rep['kink_rows_worst']:.2e}; fp32 loop: {rep.get('loop32_kink_rows', 'n/a')}); second pass without them:",
+             f"{name}: stable rows {rep['stable_rows']} / {rep['rows']}; forward on them: hip max {rep['forward']['hip_max']:.2e} mean "
+             f"{rep['forward']['hip_mean']:.2e} | loop32 max {rep['forward']['loop32_max']:.2e} mean {rep['forward']['loop32_mean']:.2e}; "
+             f"stable rows the kernel leaves the band on: {rep['forward']['rows_left_by_kernel']}"]
+    for n, r in rep['tensors'].items():
+        lines.append(f"  {n:26s} hip max-rel {r['hip_max']:.2e} mean-rel {r['hip_mean']:.2e} | loop32 max-rel {r['loop32_max']:.2e} "
+                     f"mean-rel {r['loop32_mean']:.2e}")
+    return '\n'.join(lines)

@@ -81,12 +81,12 @@ def random_params(rng, io, no, NL, C, H, scale=None):
 # ---------------------------------------------------------------------------------------------------
 # synthetic problems + the stated fp32 parity criterion
 # ---------------------------------------------------------------------------------------------------
-def make_problem(seed, io, no, NL, B, H, C, L, times=None, nan_frac=0.2, y0_scale=0.5, hermite=False):
+def make_problem(seed, io, no, NL, B, H, C, L, times=None, nan_frac=0.2, y0_scale=0.5, hermite=False, weight_scale=None):
     """Seeded inputs for one solve: params (reference names), coeffs (B, L-1, 4C), times, y0."""
     import torch
     import stable_neural_sdes_amd as S
     rng = np.random.default_rng(seed)
-    p = random_params(rng, io, no, NL, C, H)
+    p = random_params(rng, io, no, NL, C, H, scale=weight_scale)
     if times is None:
         times = np.arange(L, dtype=np.float32)
     times = np.asarray(times, dtype=np.float32)
@@ -168,3 +168,19 @@ def assert_parity(got, ref64, cpu32=None, what='', amplifying=False):
         assert rep['mean'] <= 4 * rep['cpu_mean'] + 1e-7, (what, rep)
         assert rep['max'] <= 4 * rep['cpu_max'] + 1e-6, (what, rep)
     return rep
+
+
+def grad_close(got, ref, name, tol, tag=''):
+    """Gradient check per tensor (round 5): max |err| / max |ref| < tol AND mean |err| / mean |ref| < tol; with SNSDE_GRAD_MARGINS
+    set the measured values are appended to that file (the tolerances in the tests are set from such a run)."""
+    import torch
+    g = got.detach().double().cpu() if torch.is_tensor(got) else torch.as_tensor(got).double()
+    r = ref.detach().double().cpu() if torch.is_tensor(ref) else torch.as_tensor(ref).double()
+    e = (g - r).abs()
+    err = float(e.max()) / (float(r.abs().max()) + 1e-300)
+    mean_rel = float(e.mean()) / (float(r.abs().mean()) + 1e-300)
+    if os.environ.get('SNSDE_GRAD_MARGINS'):
+        with open(os.environ['SNSDE_GRAD_MARGINS'], 'a') as fh:
+            fh.write(f'{tag or "-"} - - - - - {name} {err:.3e} {mean_rel:.3e}\n')
+    assert err < tol, (tag, name, err)
+    assert mean_rel < tol, (tag, name, mean_rel)

@@ -20,7 +20,10 @@ import torch
 
 import stable_neural_sdes_amd as S
 from oracle import sde_oracle as O
-from tests.helpers import assert_parity, draw_dW, load, make_problem, param_spec
+from tests.helpers import assert_parity, draw_dW, grad_close, load, make_problem, param_spec
+
+FD_TOL = 2e-3
+GRAD_TOL = {'k5shard': 2e-3, 'pad': 2e-3}      # set from profiles/r05_grad_margins_small.txt
 
 pytestmark = pytest.mark.gpu
 DEV = 'cuda:0'
@@ -136,6 +139,33 @@ def test_dropin_fixture_ists_wrapper_default_srk_on_the_hip_path():
     np.testing.assert_allclose(out.cpu().numpy(), FIX['ists/out'], rtol=2e-4, atol=2e-5)
 
 
+def test_integration_md_ctypes_stub_reproduces_sdeint_bit_for_bit():
+    """The ctypes stub INTEGRATION.md section 3 prints for a maintainer of neuralsde.py:71-82, exec'd as written, against
+    S.torchsde.sdeint on the G6 classification fixture's foreign module (in-kernel Philox, same key): identical bits, Euler
+    and Milstein; a bad ts raises ValueError as torchsde does."""
+    from tests.test_host_cpu import integration_stub_namespace
+    ns = integration_stub_namespace()
+    B, H, C, L, NL, io, no, out_ch = (int(v) for v in FIX['cls/dims'])
+    field = ForeignField(C, H, NL, io)
+    sd = _sd('cls')
+    field.load_state_dict({k[len('func.'):]: v for k, v in sd.items() if k.startswith('func.')})
+    field = field.to(DEV)
+    times = torch.from_numpy(FIX['cls/times']).to(DEV)
+    field.set_X(torch.from_numpy(FIX['cls/coeffs']).to(DEV), times)
+    y0 = torch.randn(B, H, device=DEV, generator=torch.Generator(DEV).manual_seed(3))
+    ts = times[[0, L // 2, L - 1]]
+    dt = float((times[1:] - times[:-1]).min())
+    for code, method in ((0, 'euler'), (1, 'milstein')):
+        with torch.no_grad():
+            want = S.torchsde.sdeint(field, y0, ts, dt=dt, method=method, options={'seed': 77, 'backend': 'hip'})
+        got = ns['sdeint_diffusion_model'](field, y0, ts, dt, seed=77, method=code)
+        assert got.shape == want.shape == (3, B, H)
+        assert torch.equal(got, want), method
+        assert not torch.equal(got[-1], got[0])
+    with pytest.raises(ValueError):
+        ns['sdeint_diffusion_model'](field, y0, ts.flip(0), dt)
+
+
 # ---- K5 shard: NeuralSDE_forecasting end to end ------------------------------------------------------------------
 def test_forecasting_wrapper_k5_shard_forward_vs_oracle_and_gradients_vs_fp64_autograd():
     B, H, C, L, NL, out_time = 128, 256, 14, 50, 2, 10
@@ -179,9 +209,7 @@ def test_forecasting_wrapper_k5_shard_forward_vs_oracle_and_gradients_vs_fp64_au
         gref = ref[name].grad
         if gref is None or float(gref.abs().max()) == 0.0:
             continue
-        scale = float(gref.abs().max())
-        err = float((p.grad.double() - gref).abs().max()) / scale
-        assert err < 3e-3, (name, err, scale)
+        grad_close(p.grad, gref, name, GRAD_TOL['k5shard'], 'k5shard')
 
 
 # ---- backward against finite differences of the numpy oracle ----------------------------------------------------------
@@ -261,7 +289,10 @@ def test_fused_backward_vs_finite_differences_of_the_numpy_oracle(case):
         dn = oracle_loss({k: p64[k] - eps * vdir[k] for k in p64}, y64 - eps * vy)
         fd = (up - dn) / (2 * eps)
         an = sum(float((grads[k] * vdir[k]).sum()) for k in grads) + float((gy0 * vy).sum())
-        assert abs(an - fd) <= 2e-3 * max(abs(fd), 1.0), (case, trial, an, fd)
+        if os.environ.get('SNSDE_GRAD_MARGINS'):
+            with open(os.environ['SNSDE_GRAD_MARGINS'], 'a') as fh:
+                fh.write(f'fd - - - - - {case[:9]} {abs(an - fd) / max(abs(fd), 1.0):.3e} 0\n')
+        assert abs(an - fd) <= FD_TOL * max(abs(fd), 1.0), (case, trial, an, fd)
 
 
 # ---- DistributedDataParallel over NCCL (= RCCL) ----------------------------------------------------------------------------
@@ -400,9 +431,7 @@ def test_uninstantiated_hidden_sizes_run_zero_padded_on_the_mfma_kernels(ci, mon
     assert float((got.detach().double().cpu() - want.detach()).abs().max()) <= 2e-4 * scale
 
     def close(g, ref, name):
-        sc = float(ref.abs().max()) + 1e-12
-        err = float((g.double().cpu() - ref).abs().max()) / sc
-        assert err < 2e-3, (name, err, sc)
+        grad_close(g, ref, name, GRAD_TOL['pad'], f'pad{ci}')
     close(y0.grad, y64.grad, 'y0')
     ref = dict(m64.named_parameters())
     for name, p in m.named_parameters():

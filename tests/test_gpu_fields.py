@@ -7,7 +7,9 @@ import torch
 
 import stable_neural_sdes_amd as S
 from stable_neural_sdes_amd import fields
-from tests.helpers import make_problem
+from tests.helpers import grad_close, make_problem
+
+GRAD_TOL = 2e-3      # set from profiles/r05_grad_margins_small.txt
 from tests.tutorial_fields import TutorialField
 
 pytestmark = pytest.mark.gpu
@@ -163,9 +165,7 @@ def test_tutorial_field_training_step_fused_vs_fp64_autograd(kind, H, layers, ac
     assert float((got.detach().double().cpu() - want.detach()).abs().max()) <= 2e-4 * max(float(want.detach().abs().max()), 1.0)
 
     def close(g, ref, name):
-        scale = float(ref.abs().max()) + 1e-12
-        err = float((g.double().cpu() - ref).abs().max()) / scale
-        assert err < 2e-3, (name, err, scale)
+        grad_close(g, ref, name, GRAD_TOL, 'fields')
     close(yg.grad, y64.grad, 'y0')
     ref = dict(f64.named_parameters())
     for name, p in field.named_parameters():
@@ -393,9 +393,7 @@ def test_field_training_step_at_the_timed_size_vs_fp64_autograd(kind, method):
     assert float((got.detach().double() - want.detach()).abs().max()) <= 2e-4 * max(float(want.detach().abs().max()), 1.0)
 
     def close(g, ref, name):
-        scale = float(ref.abs().max()) + 1e-12
-        err = float((g.double() - ref).abs().max()) / scale
-        assert err < 2e-3, (name, err, scale)
+        grad_close(g, ref, name, GRAD_TOL, 'fields-big')
     close(yg.grad, y64.grad, 'y0')
     ref = dict(f64.named_parameters())
     for name, p in field.named_parameters():

@@ -837,6 +837,14 @@ def test_backward_sweep_generic_diffusion_nets(io, no, method):
                     strict=True)
 
 
+# Gradient tolerance per tensor: max|err| / max|ref| AND mean|err| / mean|ref| (round 5; it was 2e-3 on the maximum alone).  Measured over
+# the ~5500 tensors of the cases below (profiles/r05_grad_margins_small.txt): all but 37 within 2.5e-5, the largest 2.3e-4.  The five
+# cases above 5e-5 are listed with a 5e-4 bound: their fp64 gradients cancel to a small scalar (theta / sigma of 2009, 4006, 906) or the
+# scheme amplifies round-off (4009: srk with raw = t y; 907: Milstein through y^3-like closed forms on the generic kernels).
+GRAD_TOL_MAX, GRAD_TOL_MEAN = 1e-4, 1e-4
+GRAD_TOL_LOOSE = {2009: 5e-4, 4006: 5e-4, 4009: 5e-4, 906: 5e-4, 907: 5e-4}
+
+
 def _check_backward(seed, io, no, NL, B, H, C, L, ts, dt, method, kernel, strict=False):
     times = np.linspace(0, 1, L).astype(np.float32) if ts is None else None
     pr = make_problem(seed, io, no, NL, B, H, C, L, times=times)
@@ -875,8 +883,14 @@ def _check_backward(seed, io, no, NL, B, H, C, L, ts, dt, method, kernel, strict
     def close(got, ref, name):
         ref = ref.numpy()
         scale = np.abs(ref).max() + 1e-12
-        err = np.abs(got.cpu().numpy().astype(np.float64) - ref).max() / scale
-        assert err < 2e-3, (name, err, scale)
+        e = np.abs(got.cpu().numpy().astype(np.float64) - ref)
+        err = e.max() / scale
+        mean_rel = e.mean() / (np.abs(ref).mean() + 1e-300)
+        if os.environ.get('SNSDE_GRAD_MARGINS'):       # tools: measured margins of every case (profiles/r05_grad_margins_small.txt)
+            with open(os.environ['SNSDE_GRAD_MARGINS'], 'a') as fh:
+                fh.write(f'{seed} {io} {no} {H} {method} {kernel} {name} {err:.3e} {mean_rel:.3e}\n')
+        assert err < GRAD_TOL_LOOSE.get(seed, GRAD_TOL_MAX), (name, err, scale)
+        assert mean_rel < GRAD_TOL_LOOSE.get(seed, GRAD_TOL_MEAN), (name, mean_rel)
 
     fscale = float(ys_ref.detach().abs().max()) + 1e-12
     assert float((ys.detach().double().cpu() - ys_ref.detach()).abs().max()) / fscale < 2e-4, 'forward'

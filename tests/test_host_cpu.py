@@ -544,9 +544,53 @@ def test_ctypes_structs_follow_the_header_field_order():
     assert fields('snsde_solve') == [n for n, _ in _lib.Solve._fields_]
     assert fields('snsde_backward') == [n for n, _ in _lib.Backward._fields_]
     assert fields('snsde_model') == [n for n, _ in _lib.Model._fields_]
+
+
+def integration_stub_namespace():
+    """The python block INTEGRATION.md section 3 prints for a maintainer of the reference, executed as written (it loads
+    libsnsde.so and runs snsde_abi_check on its own struct declarations)."""
     doc = open(os.path.join(ROOT, 'INTEGRATION.md')).read()
-    stub = re.findall(r'"(\w+)"', re.search(r'\("params".*?"workspace"\)', doc, re.S).group(0))
-    assert stub == [n for n, t in _lib.Solve._fields_ if t is C.c_void_p]
+    block = re.search(r'```python\n(import ctypes as C, os, numpy as np, torch\n.*?)```', doc, re.S).group(1)
+    ns = {'__name__': 'integration_stub'}
+    cwd = os.getcwd()
+    os.chdir(ROOT)                      # the stub names the library relative to the repository root
+    try:
+        exec(compile(block, 'INTEGRATION.md#stub', 'exec'), ns)
+    finally:
+        os.chdir(cwd)
+    return ns
+
+
+def test_integration_md_stub_declares_the_library_structs_field_for_field():
+    """Round 4's stub lacked the four trailing snsde_solve fields and got SNSDE_ERR_ABI from the library; the test then only
+    compared the pointer run.  Now: the stub is executed (its own snsde_abi_check must pass against the built library) and
+    its WHOLE field lists, types, offsets and sizes are compared with the binding the package uses."""
+    if not os.path.exists(_lib.LIB_PATH):
+        pytest.skip('libsnsde.so not built')
+    ns = integration_stub_namespace()
+    for name in ('Model', 'Solve'):
+        stub, own = ns[name], getattr(_lib, name)
+        assert C.sizeof(stub) == C.sizeof(own), name
+
+        def flat(struct):
+            return [(n, t if not issubclass(t, C.Structure) else 'struct', getattr(struct, n).offset, getattr(struct, n).size)
+                    for n, t in struct._fields_]
+        assert flat(stub) == flat(own), name
+    assert ns['SNSDE_VERSION'] == _lib.ABI_VERSION == _lib.lib().snsde_version()
+    L = _lib.lib()
+    assert L.snsde_abi_check(2, C.sizeof(ns['Model']), C.sizeof(ns['Solve']), 0, 0) == 0
+    assert L.snsde_abi_check(2, C.sizeof(ns['Model']), C.sizeof(ns['Solve']) - 16, 0, 0) == -10      # round 4's stale stub
+    assert L.snsde_abi_check(1, C.sizeof(ns['Model']), C.sizeof(ns['Solve']), 0, 0) == -10
+    assert L.snsde_abi_check(2, 0, 0, C.sizeof(_lib.Backward) + 8, 0) == -10
+
+
+def test_product_library_reads_no_environment():
+    """The split heuristic's sweep knobs live in -DSNSDE_DEV_TUNING builds only (build.py devtuning)."""
+    if not os.path.exists(_lib.LIB_PATH):
+        pytest.skip('libsnsde.so not built')
+    import subprocess
+    und = subprocess.run(['nm', '-D', '--undefined-only', _lib.LIB_PATH], capture_output=True, text=True).stdout
+    assert 'getenv' not in und
 
 
 # ---- torchsde / controldiffeq mirror: the names the reference's other call sites need -----------------------------------
