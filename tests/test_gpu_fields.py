@@ -9,7 +9,7 @@ import stable_neural_sdes_amd as S
 from stable_neural_sdes_amd import fields
 from tests.helpers import grad_close, make_problem
 
-GRAD_TOL = 2e-3      # set from profiles/r05_grad_margins_small.txt
+GRAD_TOL = 1e-4      # measured <= 2.3e-5 over 887 tensors (profiles/r05_grad_margins_small.txt); it was 2e-3
 from tests.tutorial_fields import TutorialField
 
 pytestmark = pytest.mark.gpu
