@@ -165,11 +165,13 @@ def spread(t_ms):
             "p90_ms": float(np.percentile(t_ms, 90))}
 
 
-def strong_k3(dev, rank, world, stream, barrier, maxr):
+def strong_k3(dev, rank, world, stream, barrier, maxr, shard_of=None):
     """BASELINE config 3: Neural GSDE (6, 17), 4096 rows GLOBAL split over the ranks, H=128, C=21, Hermite coefficients
-    without missing values, times=arange(201) -> 200 Euler steps, ts=[0, 200]; forward solve, in-kernel Philox."""
+    without missing values, times=arange(201) -> 200 Euler steps, ts=[0, 200]; forward solve, in-kernel Philox.
+    shard_of = 8: ONE rank's share of an 8-GPU run (512 rows), timed on this GPU alone - what each GPU of the strong-scaling
+    run executes (no collective in the solver), so that DESIGN 5's 8-GPU prediction can be checked against a SCALE run."""
     rows_g, n_steps = 4096, 200
-    lo, hi = S.sharding.shard_rows(rows_g, world, rank)
+    lo, hi = S.sharding.shard_rows(rows_g, shard_of or world, 0 if shard_of else rank)
     pr, _, flat, coeffs, y0 = build_inputs(dev, rank, io=6, no=17, b=hi - lo, l=n_steps + 1, nan_frac=0.0, hermite=True)
     model = S.engine.model_struct(C, H, H, NL, 6, 17)
     grid = S.engine.step_grid(np.array([0.0, float(n_steps)], np.float32), 1.0, pr['times'], dev)
@@ -184,21 +186,23 @@ def strong_k3(dev, rank, world, stream, barrier, maxr):
     el = maxr(time.perf_counter() - t0)
     t_kern = event_times_ms(lambda: call.launch(stream, reuse_prepared=True), stream, 20, 3)
     kern_s = float(np.median(t_kern)) * 1e-3
+    done = (hi - lo) if shard_of else rows_g
     return {"workload": f"K3: Neural GSDE (io=6,no=17) {rows_g} rows global ({hi - lo}/GPU), H=128, 200 Euler steps, "
-                        "Hermite coeffs, forward", "scaling": "strong", "value": rows_g * n_steps * k / el,
+                        "Hermite coeffs, forward" + (f"; ONE rank's shard of a {shard_of}-GPU run on this GPU" if shard_of else ""),
+            "scaling": "strong", "value": done * n_steps * k / el, "kernel_ms": kern_s * 1e3,
             "unit": "row-steps/s", "ms_per_solve": el / k * 1e3, "solves": k,
             "roofline": roofline_obj((hi - lo) * n_steps * flops_drift(6, H, C, NL), kern_s,
                                      "this rank's solve kernel (HIP events, median of 20): SURVEY 8d algorithmic FLOPs of the drift, "
                                      "169 728 per row-step; the time-only diffusion is hoisted")}
 
 
-def strong_k5(dev, rank, world, stream, barrier, maxr, dist):
+def strong_k5(dev, rank, world, stream, barrier, maxr, dist, shard_of=None):
     """BASELINE config 5: Milstein + fused adjoint, MuJoCo-forecast-shaped: LNSDE (4, 17), 1024 rows GLOBAL split over the
     ranks, H=256, C=14, L=50 knots with dropped rows, 49 steps, every knot an output; loss = mean square of the last 10
     states; forward + backward + gradient all-reduce (RCCL) per step."""
     from tests.helpers import make_problem, param_spec
     rows_g, hh, cc, ll = 1024, 256, 14, 50
-    lo, hi = S.sharding.shard_rows(rows_g, world, rank)
+    lo, hi = S.sharding.shard_rows(rows_g, shard_of or world, 0 if shard_of else rank)      # shard_of: see strong_k3
     pr = make_problem(4321 + rank, 4, 17, 2, hi - lo, hh, cc, ll, nan_frac=0.3)
     p0 = make_problem(4321, 4, 17, 2, 1, hh, cc, ll, nan_frac=0.0)['params']
     sde = S.Diffusion_model(cc, hh, hh, 2, input_option=4, noise_option=17).to(dev)
@@ -216,7 +220,7 @@ def strong_k5(dev, rank, world, stream, barrier, maxr, dist):
         ys = S.torchsde.sdeint(sde, y0, times, dt=1.0, method='milstein', options={'seed': 7, 'row_offset': lo})
         loss = ys[-10:].square().mean() * ((hi - lo) / rows_g)
         loss.backward()
-        if dist is not None:
+        if dist is not None and not shard_of:
             flat = torch.cat([p.grad.reshape(-1) for p in params])
             dist.all_reduce(flat)
         return loss
@@ -229,9 +233,11 @@ def strong_k5(dev, rank, world, stream, barrier, maxr, dist):
         step()
     barrier()
     el = maxr(time.perf_counter() - t0)
+    done = (hi - lo) if shard_of else rows_g
     return {"workload": f"K5: LNSDE (io=4,no=17) Milstein + fused adjoint, {rows_g} rows global ({hi - lo}/GPU), H=256, "
-                        "C=14, 49 steps, 50 outputs, fwd+bwd+grad all-reduce", "scaling": "strong",
-            "value": rows_g * (ll - 1) * k / el, "unit": "row-steps/s (training steps)", "ms_per_step": el / k * 1e3,
+                        "C=14, 49 steps, 50 outputs, fwd+bwd" + (f"; ONE rank's shard of a {shard_of}-GPU run on this GPU, no all-reduce"
+                                                                   if shard_of else "+grad all-reduce"), "scaling": "strong",
+            "value": done * (ll - 1) * k / el, "unit": "row-steps/s (training steps)", "ms_per_step": el / k * 1e3,
             "steps": k,
             "roofline": roofline_obj(3 * (hi - lo) * (ll - 1) * flops_drift(4, hh, cc, 2), el / k,
                                      "whole training step of this rank (host + forward + adjoint + weight gradients + all-reduce, wall "
@@ -430,6 +436,29 @@ def latent_sde(dev, stream, rows=1024, hidden=32, L=50):
     return out
 
 
+def summary_of(out, extra):
+    """Compact last key of the line: per BASELINE leg the kernel time, the roofline fraction computed from it, and the training
+    step where the leg has one (ms, HIP-event medians; `frac` = algorithmic FLOPs / kernel time / 157.3 TF)."""
+    s = {"K2_forward": {"kernel_ms": round(out["roofline"]["kernel_ms"], 4), "frac": round(out["roofline"]["frac"], 4),
+                        "call_ms": round(out["ms_per_step"], 4)}}
+    for key in ("K2_train", "K4_3_18_euler", "NSDE_3_18_srk_K4_shape", "NSDE_3_18_milstein_K4_shape"):
+        e = extra.get(key)
+        if e:
+            s[key] = {"kernel_ms": round(e["forward_kernel"]["median_ms"], 4), "frac": round(e["roofline_forward"]["frac"], 4),
+                      "fwd_bwd_ms": round(e["forward_backward"]["median_ms"], 4), "train_frac": round(e["roofline_training"]["frac"], 4)}
+            if "roofline_bytes" in e and "traffic" in e["roofline_bytes"]:
+                s[key]["train_MB"] = round(e["roofline_bytes"]["traffic"] / 1e6, 1)
+    for key in ("K3_strong", "K3_shard_512"):
+        e = extra.get(key)
+        if e:
+            s[key] = {"kernel_ms": round(e["kernel_ms"], 4), "frac": round(e["roofline"]["frac"], 4), "call_ms": round(e["ms_per_solve"], 4)}
+    for key in ("K5_strong_train", "K5_shard_128_train"):
+        e = extra.get(key)
+        if e:
+            s[key] = {"step_ms": round(e["ms_per_step"], 4), "train_frac": round(e["roofline"]["frac"], 4)}
+    return s
+
+
 def self_launch(args):
     """`python bench.py --gpus N` without torchrun: re-execute under torch.distributed.run, one rank per GPU."""
     with socket.socket() as s:
@@ -505,20 +534,27 @@ def main():
     ys = call.ys
     assert bool(torch.isfinite(ys).all()), 'non-finite solver output'
 
+    # `extra`: the widened rows first, the BASELINE.json configurations LAST, and a compact `summary` of the latter as the very last
+    # key of the line - a record that keeps only the tail of stdout still carries every BASELINE leg
     extra = {}
     if not args.no_extra:
+        if world == 1:
+            extra["tutorial_field"] = tutorial_field(dev, stream)
+            extra["K1_tutorial_lsde"] = tutorial_field(dev, stream, kind='lsde', rows=256, hh=32, n=50)
+            extra["latent_sde_srk"] = latent_sde(dev, stream)
+            # torch_ists' neuralsde_1_18 at the K2 width: diffusion nets on the MFMA net kernels (snsde_m4n_kernel.h)
+            extra["NSDE_1_18_srk_H128"] = train_leg(dev, stream, 1, 18, 1024, 128, 21, 50, 'srk', 'neuralsde_1_18, srk')
+            # BASELINE config 4's shape (neuralsde_3_18, the README's headline Neural SDE, 2048 x H = 64, C = 69, 71 steps) under the
+            # benchmarks' Euler, torch_ists' default srk, and Milstein
+            extra["NSDE_3_18_milstein_K4_shape"] = train_leg(dev, stream, 3, 18, 2048, 64, 69, 72, 'milstein', 'neuralsde_3_18, milstein')
+            extra["NSDE_3_18_srk_K4_shape"] = train_leg(dev, stream, 3, 18, 2048, 64, 69, 72, 'srk', 'neuralsde_3_18, srk')
+            extra["K4_3_18_euler"] = train_leg(dev, stream, 3, 18, 2048, 64, 69, 72, 'euler', 'K4: neuralsde_3_18, euler', outputs='knots')
+            extra["K3_shard_512"] = strong_k3(dev, 0, 1, stream, barrier, maxr, shard_of=8)
+            extra["K5_shard_128_train"] = strong_k5(dev, 0, 1, stream, barrier, maxr, None, shard_of=8)
         extra["K3_strong"] = strong_k3(dev, rank, world, stream, barrier, maxr)
         extra["K5_strong_train"] = strong_k5(dev, rank, world, stream, barrier, maxr, dist)
         if world == 1:
             extra["K2_train"] = k2_training(dev, stream)
-            # the reference's headline Neural SDE (neuralsde_3_18, README.md:32) under torch_ists' default `srk`, K4 shape, and
-            # torch_ists' neuralsde_1_18 at the K2 width: diffusion nets on the MFMA net kernels (snsde_m4n_kernel.h)
-            extra["NSDE_3_18_srk_K4_shape"] = train_leg(dev, stream, 3, 18, 2048, 64, 69, 72, 'srk', 'neuralsde_3_18, srk')
-            extra["NSDE_1_18_srk_H128"] = train_leg(dev, stream, 1, 18, 1024, 128, 21, 50, 'srk', 'neuralsde_1_18, srk')
-            extra["NSDE_3_18_milstein_K4_shape"] = train_leg(dev, stream, 3, 18, 2048, 64, 69, 72, 'milstein', 'neuralsde_3_18, milstein')
-            extra["tutorial_field"] = tutorial_field(dev, stream)
-            extra["K1_tutorial_lsde"] = tutorial_field(dev, stream, kind='lsde', rows=256, hh=32, n=50)
-            extra["latent_sde_srk"] = latent_sde(dev, stream)
 
     if rank == 0:
         rowsteps = B * NSTEP
@@ -558,6 +594,8 @@ def main():
         if not args.no_cpu_baseline and world == 1:     # reported at N = 1 only (the other ranks would idle behind it)
             out["cpu_baseline"] = cpu_baseline(pr, params)
             out["speedup_vs_cpu"] = value / world / out["cpu_baseline"]["value"]
+        if extra:
+            out["summary"] = summary_of(out, extra)
         line = json.dumps(out)
     else:
         line = None

@@ -61,7 +61,8 @@ enum {
     SNSDE_KERNEL_GENERIC = 1,   /* VALU kernel: every (input_option, noise_option), any dims        */
     SNSDE_KERNEL_MFMA = 2,      /* MFMA fast path, tile flavour chosen from the batch size          */
     SNSDE_KERNEL_MFMA_M16 = 3,  /* 16-row tiles (v_mfma_f32_16x16x4_f32)                            */
-    SNSDE_KERNEL_MFMA_M4 = 4    /* 4-row tiles  (v_mfma_f32_4x4x1_16b_f32)                          */
+    SNSDE_KERNEL_MFMA_M4 = 4,   /* 4-row tiles  (v_mfma_f32_4x4x1_16b_f32)                          */
+    SNSDE_KERNEL_MFMA_W4 = 5    /* 4-row tiles owned by ONE wave (H = 64 with a diffusion net, Euler): drift wave + net wave */
 };
 
 /* flags: REUSE_PREPARED skips the weight packing / time-table kernels; legal when `params`,
@@ -312,7 +313,8 @@ enum { SNSDE_PATH_NONE = 0,          /* no kernel: snsde_solve_forward returns S
        SNSDE_PATH_LEAN = 4,          /* MFMA, 4-row tiles, lean kernel (register-resident weights, H = 32/64/128)    */
        SNSDE_PATH_LEAN_STREAMED = 5, /* MFMA, 4-row tiles, lean kernel with L2 -> LDS streamed weights (H = 256)     */
        SNSDE_PATH_GENERIC_SRK = 6,   /* SRK on the generic family                                                   */
-       SNSDE_PATH_MFMA_SRK = 7 };    /* SRK on the MFMA 4-row tiles                                                 */
+       SNSDE_PATH_MFMA_SRK = 7,      /* SRK on the MFMA 4-row tiles                                                 */
+       SNSDE_PATH_MFMA_W4 = 8 };     /* MFMA, 4 rows per wave pair (csrc/snsde_w4_kernel.h: H = 64, diffusion nets, Euler) */
 SNSDE_API int snsde_forward_path(const snsde_solve* s);
 
 /* Readout head of the wrappers in one launch (inference; replaces the 4-5 tensor ops of `self.linear(z)`,

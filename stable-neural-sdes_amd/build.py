@@ -112,6 +112,8 @@ if __name__ == '__main__':
         # trace build spills two registers and is not used by the tool, hence no resource check
         print(build(force=True, defines=('-DLEAN_TRACE', '-DSNSDE_DEV_SUBSET'), out=os.path.join(HERE, 'libsnsde_leantrace.so'),
                     check_resources=False))
+    elif len(sys.argv) > 1 and sys.argv[1] == 'w4trace':
+        print(build(force=True, defines=('-DW4_TRACE', '-DSNSDE_DEV_SUBSET'), out=os.path.join(HERE, 'libsnsde_w4trace.so'), check_resources=False))
     elif len(sys.argv) > 1 and sys.argv[1] == 'inc':
         print(build(force=True, verbose=True, incremental=True))
     elif len(sys.argv) > 1 and sys.argv[1] == 'devtuning':

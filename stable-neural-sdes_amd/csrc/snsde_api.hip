@@ -379,6 +379,7 @@ int snsde_solve_forward(const snsde_solve* s, void* hip_stream) {
         case SNSDE_KERNEL_MFMA: return snsde_mfma_launch(s, net, st, -1);
         case SNSDE_KERNEL_MFMA_M16: return snsde_mfma_launch(s, net, st, 0);
         case SNSDE_KERNEL_MFMA_M4: return snsde_mfma_launch(s, net, st, 1);
+        case SNSDE_KERNEL_MFMA_W4: return snsde_mfma_launch(s, net, st, 2);
         default: return SNSDE_ERR_OPTION;
     }
     if (s->z0_weight && (rc = snsde_z0_launch(s, st)) != SNSDE_OK) return rc;
@@ -399,7 +400,7 @@ int snsde_forward_path(const snsde_solve* s) {
         if (s->kernel == SNSDE_KERNEL_GENERIC || s->kernel == SNSDE_KERNEL_MFMA_M16) return SNSDE_PATH_NONE;
         return snsde_mfma_path(s, net, 1);
     }
-    const int hint = s->kernel == SNSDE_KERNEL_MFMA_M16 ? 0 : (s->kernel == SNSDE_KERNEL_MFMA_M4 ? 1 : -1);
+    const int hint = s->kernel == SNSDE_KERNEL_MFMA_M16 ? 0 : (s->kernel == SNSDE_KERNEL_MFMA_M4 ? 1 : (s->kernel == SNSDE_KERNEL_MFMA_W4 ? 2 : -1));
     if (s->method == SNSDE_SRK) {
         if (s->kernel == SNSDE_KERNEL_MFMA_M16) return snsde_mfma_path(s, net, 0);
         if (s->kernel == SNSDE_KERNEL_MFMA_M4) return snsde_mfma_path(s, net, 1);

@@ -67,6 +67,9 @@ const float* snsde_mfma_gt_table(const snsde_solve* s, const SnsdeNet& net);
 const float* snsde_mfma_srk_pass_table(const snsde_solve* s, const SnsdeNet& net);   // (3N, SNSDE_STEP_STRIDE) or null
 bool snsde_mfma_backward_partials(const snsde_solve* s, const SnsdeNet& net, int* nwg, int* waves, size_t* ds_off,
                                   size_t* dth_off);
+// launchers (snsde_w4.hip): wave-owns-rows forward kernels (H = 64, diffusion nets, Euler)
+bool snsde_w4_supported(const snsde_solve* s, const SnsdeNet& net);
+int snsde_w4_launch(const snsde_solve* s, const SnsdeNet& net, hipStream_t stream);
 // launchers (snsde_wgrad.hip)
 size_t snsde_wgrad_workspace_floats(const snsde_backward* b, const SnsdeNet& net);
 int snsde_wgrad_launch(const snsde_backward* b, const SnsdeNet& net, float* grad_params, int32_t n_params, float* ws,

@@ -260,6 +260,7 @@ static bool variant_of(const snsde_solve* s) {
 // Which configurations the fast path is instantiated for.
 MfmaPlan make_plan(const snsde_solve* s, const SnsdeNet& net, int flavor_hint) {
     MfmaPlan p{};
+    if (flavor_hint == 2) flavor_hint = 1;      // (the wave-owns-rows forward, snsde_w4.hip: every plan-side decision as for 4-row tiles)
     const snsde_model& m = s->model;
     const int H = m.hidden_channels, io = m.input_option, no = m.noise_option;
     p.ok = false;
@@ -530,10 +531,18 @@ RevPlan make_rev_plan(const snsde_solve* s, const SnsdeNet& net, const MfmaPlan&
 
 bool snsde_mfma_supported(const snsde_solve* s, const SnsdeNet& net) { return make_plan(s, net, -1).ok; }
 
+// Wave-owns-rows forward (snsde_w4.hip): forced by hint 2; under `auto` up to 6144 rows
+static bool w4_takes(const snsde_solve* s, const SnsdeNet& net, int flavor_hint) {
+    // measured at the K4 shape (tools/time_w4.py, profiles/r05_time_w4.txt): 2048 rows 109 us against 156 (4-row tiles) / 216 (16-row
+    // tiles), 6144 rows 275 against 316 (16-row tiles); from 8192 rows the 16-row tiles win (a third wave per SIMD does not fit)
+    return (flavor_hint == 2 || (flavor_hint == -1 && s->batch <= 6144)) && snsde_w4_supported(s, net);
+}
+
 // which MFMA kernel family a forward launch of this descriptor takes (SNSDE_PATH_*; 0: none)
 int snsde_mfma_path(const snsde_solve* s, const SnsdeNet& net, int flavor_hint) {
     const MfmaPlan p = make_plan(s, net, flavor_hint);
     if (!p.ok) return SNSDE_PATH_NONE;
+    if (flavor_hint != 0 && flavor_hint != 1 && w4_takes(s, net, flavor_hint)) return SNSDE_PATH_MFMA_W4;
     if (p.SRK) return SNSDE_PATH_MFMA_SRK;
     if (p.LEAN) return p.H == 256 ? SNSDE_PATH_LEAN_STREAMED : SNSDE_PATH_LEAN;
     return p.FL ? SNSDE_PATH_MFMA_M4 : SNSDE_PATH_MFMA_M16;
@@ -556,6 +565,13 @@ int snsde_mfma_launch(const snsde_solve* s, const SnsdeNet& net, hipStream_t str
     // the kernels form their per-step save offsets from 32-bit uniform factors (uoff): slots x B x H must fit
     if ((uint64_t)16 * (uint64_t)s->batch * (uint64_t)s->model.hidden_channels >= (1ull << 32)) return SNSDE_ERR_UNSUPPORTED;
     float* ws = static_cast<float*>(s->workspace);
+    const bool w4 = w4_takes(s, net, flavor_hint);
+    if (flavor_hint == 2 && !w4) return SNSDE_ERR_UNSUPPORTED;
+    if (w4 && !s->act_save) {
+        // inference on the wave-owns-rows kernel: it reads the nn.Linear layout of `params` itself - no packing, no tables
+        if (s->z0_weight) { const int rc = snsde_z0_launch(s, stream); if (rc) return rc; }
+        return snsde_w4_launch(s, net, stream);
+    }
     if (!(s->flags & SNSDE_FLAG_REUSE_PREPARED)) {
         MfmaPackJob job{};
         for (int i = 0; i < p.n_layers; ++i) job.layer[i] = p.layer[i];
@@ -604,6 +620,7 @@ int snsde_mfma_launch(const snsde_solve* s, const SnsdeNet& net, hipStream_t str
         const int rc = snsde_z0_launch(s, stream);
         if (rc) return rc;
     }
+    if (w4) return snsde_w4_launch(s, net, stream);      // (training: the prepare launch above keeps the workspace as the adjoint expects it)
     MfmaArgs a{};
     a.params = s->params; a.ws = ws; a.coeffs = s->coeffs; a.step_tab = s->step_tab; a.out_step = s->out_step;
     a.out_w = s->out_w; a.y0 = s->y0; a.dW = s->dW; a.ys = s->ys; a.traj = s->traj; a.dW_out = s->dW_out;

@@ -1,0 +1,55 @@
+// Host side of the wave-owns-rows forward kernels (snsde_w4_kernel.h): which solves they take, argument set-up, dispatch.
+#include "snsde_w4_kernel.h"
+
+namespace snsde_w4 {
+
+static bool shape_ok(const snsde_solve* s, const SnsdeNet& net) {
+    const snsde_model& m = s->model;
+    const int io = m.input_option, no = m.noise_option;
+    if (m.hidden_channels != 64 || m.hidden_hidden_channels != 64) return false;
+    if (!(io == 1 || io == 3 || io == 5)) return false;                      // latent-only drifts (no control path in f)
+    if (!(no == 14 || no == 15 || no == 18 || no == 19)) return false;       // diffusion nets
+    if (s->method != SNSDE_EULER) return false;
+    if (m.activation != 0 || m.drift_output != 0 || m.diffusion_output != 0 || m.time_feature != 0 || s->noise_table) return false;
+    if (m.num_hidden_layers < 1 || m.num_hidden_layers > 2) return false;      // (two hidden layers: 258 weight registers, spills)
+    if (s->kl_column1 != 0 || s->batch < 4) return false;      // (a tile is four rows; ragged tails overlap the previous tile)
+    if ((uint64_t)16 * (uint64_t)s->batch * 64u >= (1ull << 32)) return false;   // 32-bit save offsets (uoff)
+    if (net.ny0.K != 66 || net.in.K != (io >= 3 ? 66 : 64)) return false;
+    return true;
+}
+
+template <int NHID, int NN, bool TIME>
+static int launch(const W4Args& a, hipStream_t st) {
+    if (a.act_save) hipLaunchKernelGGL((snsde_w4_euler_kernel<CfgW<NHID, NN, TIME, true>>), dim3((a.B + 7) / 8), dim3(256), 0, st, a);
+    else hipLaunchKernelGGL((snsde_w4_euler_kernel<CfgW<NHID, NN, TIME, false>>), dim3((a.B + 7) / 8), dim3(256), 0, st, a);
+    return hipGetLastError() == hipSuccess ? SNSDE_OK : SNSDE_ERR_LAUNCH;
+}
+
+}  // namespace snsde_w4
+
+bool snsde_w4_supported(const snsde_solve* s, const SnsdeNet& net) { return snsde_w4::shape_ok(s, net); }
+
+int snsde_w4_launch(const snsde_solve* s, const SnsdeNet& net, hipStream_t stream) {
+    using namespace snsde_w4;
+    if (!shape_ok(s, net)) return SNSDE_ERR_UNSUPPORTED;
+    const snsde_model& m = s->model;
+    W4Args a{};
+    a.params = s->params; a.step_tab = s->step_tab; a.out_w = s->out_w; a.y0 = s->y0; a.dW = s->dW; a.ys = s->ys; a.traj = s->traj;
+    a.dW_out = s->dW_out; a.act_save = s->act_save; a.row_out = s->row_out; a.row_offset = s->row_offset; a.seed = s->seed;
+    a.seed_dev = s->seed_dev;
+    a.B = s->batch; a.N = s->n_steps; a.T = s->n_out; a.no = m.noise_option; a.geo = m.input_option == 5 ? 1 : 0;
+    a.nsave = snsde_act_slots(&m);
+    a.off_theta = net.off_theta;
+    a.w_in = net.in.src_w; a.b_in = net.in.src_b; a.k_in = net.in.K; a.t_in = net.in.tshift;
+    const int nhid = m.num_hidden_layers - 1;
+    for (int l = 0; l < nhid; ++l) { a.w_hid[l] = net.hid[l].src_w; a.b_hid[l] = net.hid[l].src_b; }
+    a.w_out = net.out.src_w; a.b_out = net.out.src_b;
+    a.w_n0 = net.ny0.src_w; a.b_n0 = net.ny0.src_b; a.w_n1 = net.ny1.src_w; a.b_n1 = net.ny1.src_b;
+    const int nn = (m.noise_option >= 18) ? 2 : 1;
+    const bool timef = m.input_option >= 3;
+#define W4_CASE(NH, N2, TM) if (nhid == NH && nn == N2 && timef == TM) return launch<NH, N2, TM>(a, stream);
+    W4_CASE(0, 1, false) W4_CASE(0, 1, true) W4_CASE(0, 2, false) W4_CASE(0, 2, true)
+    W4_CASE(1, 1, false) W4_CASE(1, 1, true) W4_CASE(1, 2, false) W4_CASE(1, 2, true)
+#undef W4_CASE
+    return SNSDE_ERR_UNSUPPORTED;
+}

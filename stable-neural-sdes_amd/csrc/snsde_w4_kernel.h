@@ -1,0 +1,434 @@
+// "Wave-owns-rows" forward kernels for H = 64 models with a diffusion net (noise_option 14 / 15 / 18 / 19; BASELINE config 4:
+// neuralsde_3_18, B = 2048, H = 64) - round 5.
+//
+// The 4-row tiles of snsde_mfma_kernel / snsde_m4n_kernel split a layer's OUTPUT FEATURES over the waves of a workgroup: at H = 64
+// a wave issues 16 - 20 MFMAs per layer and then pays the fixed per-layer hand-off (k-slot reduce-scatter by DPP, LDS store,
+// s_barrier, LDS operand reads) - 2.16 VALU instructions per MFMA on the issue port the f32 MFMAs share, three to eleven barriers
+// per step, MFMA-busy 28 % (profiles/r04_pmc_net_kernels.txt).  Here ONE WAVE owns all 64 features of its 4 rows:
+//
+//   * v_mfma_f32_4x4x1_16b_f32 as a rank-1 update of a 4 x 64 tile: the 16 blocks are the 16 feature quads, the A operand is the
+//     activation column k of the 4 rows - held by ONE lane quad and broadcast to all blocks by CBSZ = 4 / ABID = k / 4 -, the B
+//     operand is row k of W^T: lane l holds W[l][k].  D: lane l, register i = out[row i][feature l].  A layer is K MFMAs of one wave;
+//     a lane keeps ITS output feature's weight row in registers (64 - 66 per layer, read straight from the nn.Linear layout of
+//     `params`: no pack kernel, no workspace);
+//   * the hand-off to the next layer is a 4 x 4 transpose inside every lane quad (D layout: lane 4b + j, register i  ->  A layout:
+//     lane 4b + i, register j): eight v_cndmask_b32_dpp, NO LDS, NO barrier.  Bias enters through the accumulator;
+//   * drift chain and diffusion-net chain of a step are independent until the update: a workgroup is TWO waves on the same 4 rows -
+//     wave 0 the drift MLP, wave 1 the net, Philox and g - which exchange (f | g, dW) through 6 KB of LDS behind ONE s_barrier per
+//     step (double-buffered by step parity) and then both form y' = y + f h + g dW bit-identically.  2048 rows = 1024 waves = every
+//     SIMD of the chip, one wave each.
+//
+// Training-mode saves follow snsde_mfma_kernel's (act_save slots, relu signs folded into the saved z), so the adjoint and the
+// weight-gradient pass are unchanged.
+#pragma once
+#include <utility>
+
+#include "snsde_mfma_kernels.h"
+
+namespace snsde_w4 {
+
+using snsde_mfma::f32x4;
+using snsde_mfma::fast_tanh;
+using snsde_mfma::snsde_pack_signs;
+using snsde_mfma::uoff;
+
+struct W4Args {
+    const float* params;
+    const float* step_tab;
+    const float* out_w;
+    const float* y0;
+    const float* dW;
+    float* ys;
+    float* traj;
+    float* dW_out;
+    float* act_save;
+    const int32_t* row_out;
+    int64_t row_offset;
+    uint64_t seed;
+    const uint64_t* seed_dev;
+    int32_t B, N, T, no, geo, nsave;
+    int32_t off_theta;
+    int32_t w_in, b_in, k_in, t_in;       // linear_in: weight offset, bias offset, K (64 or 66), leading time columns (0 or 2)
+    int32_t w_hid[3], b_hid[3];
+    int32_t w_out, b_out;
+    int32_t w_n0, b_n0, w_n1, b_n1;       // noise_y[.0] (64, 66) and noise_y.2 (64, 64)
+};
+
+// D = A(4 rows, column k: block ABID of the A register, broadcast) x B(W^T row k) + C
+template <int ABID>
+__device__ __forceinline__ f32x4 mfma_bk(float a, float b, f32x4 c) { return __builtin_amdgcn_mfma_f32_4x4x1f32(a, b, c, 4, ABID, 0); }
+
+// out[4][lane] (+)= sum_{k < 64} xt[k % 4](block k / 4) * w[k]   - two accumulator chains
+template <int... KB>
+__device__ __forceinline__ void gemm64(const float (&xt)[4], const float* w, f32x4& c, f32x4& d, std::integer_sequence<int, KB...>) {
+    ((c = mfma_bk<KB>(xt[0], w[4 * KB], c), d = mfma_bk<KB>(xt[1], w[4 * KB + 1], d), c = mfma_bk<KB>(xt[2], w[4 * KB + 2], c),
+      d = mfma_bk<KB>(xt[3], w[4 * KB + 3], d)), ...);
+}
+
+// 4 x 4 transpose inside every lane quad: in: lane 4b + j, v[i] = X[i][4b + j]  ->  out: lane 4b + i, t[j] = X[i][4b + j].
+// Two butterfly stages of four v_cndmask_b32_dpp each (D = VCC ? src1 : dpp(src0)); the four lane masks arrive in SGPR pairs.
+// Inline asm on purpose: written as selects around __builtin_amdgcn_update_dpp, hipcc sinks the DPP moves INTO the select's
+// EXEC-masked region, where their source lanes are inactive and read as zero (tools/ubench/w4_probe.hip shows both forms).
+__device__ __forceinline__ void quad_transpose(const float (&v)[4], float (&t)[4]) {
+    float a0, a1, a2, a3;
+    asm volatile(
+        "s_mov_b64 vcc, %12\n\t"                                                                   // even lanes
+        "s_nop 1\n\t"                                                                              // (VALU write -> DPP read of v[])
+        "v_cndmask_b32_dpp %0, %9, %8, vcc quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"     // a0 = even ? v0 : v1[lane ^ 1]
+        "v_cndmask_b32_dpp %2, %11, %10, vcc quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"   // a2 = even ? v2 : v3[lane ^ 1]
+        "s_mov_b64 vcc, %13\n\t"                                                                   // odd lanes
+        "v_cndmask_b32_dpp %1, %8, %9, vcc quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"     // a1 = odd ? v1 : v0[lane ^ 1]
+        "v_cndmask_b32_dpp %3, %10, %11, vcc quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"   // a3 = odd ? v3 : v2[lane ^ 1]
+        "s_mov_b64 vcc, %14\n\t"                                                                   // lanes 0, 1 of every quad
+        "v_cndmask_b32_dpp %4, %2, %0, vcc quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"     // t0 = lo ? a0 : a2[lane ^ 2]
+        "s_nop 0\n\t"
+        "v_cndmask_b32_dpp %5, %3, %1, vcc quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"     // t1 = lo ? a1 : a3[lane ^ 2]
+        "s_mov_b64 vcc, %15\n\t"                                                                   // lanes 2, 3
+        "v_cndmask_b32_dpp %6, %0, %2, vcc quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"     // t2 = hi ? a2 : a0[lane ^ 2]
+        "v_cndmask_b32_dpp %7, %1, %3, vcc quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"     // t3 = hi ? a3 : a1[lane ^ 2]
+        : "=&v"(a0), "=&v"(a1), "=&v"(a2), "=&v"(a3), "=&v"(t[0]), "=&v"(t[1]), "=&v"(t[2]), "=&v"(t[3])
+        : "v"(v[0]), "v"(v[1]), "v"(v[2]), "v"(v[3]), "s"(0x5555555555555555ull), "s"(0xaaaaaaaaaaaaaaaaull), "s"(0x3333333333333333ull),
+          "s"(0xccccccccccccccccull)
+        : "vcc");
+}
+
+// LDS hand-off barrier: the exchange buffers are the only memory the waves share, so only the LDS queue is drained.  __syncthreads()
+// also waits for vmcnt(0) - every global store of the step (outputs, trajectory, training saves) would be waited for at the next
+// step's barrier: +25 us per 71-step solve with an output per step.
+__device__ __forceinline__ void pair_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+// fast_tanh (snsde_mfma_kernels.h: same polynomial / exponential branches, same operation order => the same bits) on a PAIR of values:
+// the multiplies and fmas as v_pk_mul_f32 / v_pk_fma_f32 (two lanes' worth per issue slot); exp2 / rcp stay per element.
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ f32x2 fast_tanh2(f32x2 x) {
+    const f32x2 ax = {fabsf(x[0]), fabsf(x[1])};
+    const f32x2 x2 = x * x;
+    f32x2 p = x2 * -0.0088632355299021967f + 0.021869488536155203f;
+    p = x2 * p + -0.053968253968253971f;
+    p = x2 * p + 0.13333333333333333f;
+    p = x2 * p + -0.33333333333333333f;
+    p = (x * x2) * p + x;
+    const f32x2 e = ax * -2.8853900817779268f;
+    const f32x2 t = {__builtin_amdgcn_exp2f(e[0]), __builtin_amdgcn_exp2f(e[1])};
+    const f32x2 den = t + 1.0f;
+    const f32x2 q = (1.0f - t) * f32x2{__builtin_amdgcn_rcpf(den[0]), __builtin_amdgcn_rcpf(den[1])};
+    return f32x2{ax[0] < 0.25f ? p[0] : copysignf(q[0], x[0]), ax[1] < 0.25f ? p[1] : copysignf(q[1], x[1])};
+}
+__device__ __forceinline__ void fast_tanh4(float (&x)[4]) {
+    const f32x2 a = fast_tanh2(f32x2{x[0], x[1]}), b = fast_tanh2(f32x2{x[2], x[3]});
+    x[0] = a[0]; x[1] = a[1]; x[2] = b[0]; x[3] = b[1];
+}
+
+template <int NHID_, int NN_, bool TIME_, bool SAVE_>
+struct CfgW {
+    static constexpr int NHID = NHID_, NN = NN_;
+    static constexpr bool TIME = TIME_, SAVE = SAVE_;       // SAVE: training mode (act_save planes, relu signs in the saved z)
+    static constexpr int H = 64, KIN = TIME ? 66 : 64;
+    static constexpr int ZSLOT = NHID + 1;
+};
+
+// -DW4_TRACE (tools/w4_trace.py): s_memtime stamps at the phase boundaries of a step, summed per wave of workgroup 0 and left in the
+// first floats of dW_out
+#ifdef W4_TRACE
+#define W4_T(i) { const long long t_ = __builtin_readcyclecounter(); tr_acc[i] += (float)(t_ - tr_last); tr_last = t_; }
+#else
+#define W4_T(i)
+#endif
+
+template <class CF>
+__global__ void __launch_bounds__(256, 2) snsde_w4_euler_kernel(W4Args a) {
+#ifdef W4_TRACE
+    float tr_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    long long tr_last = __builtin_readcyclecounter();
+#endif
+    constexpr int H = 64, NHID = CF::NHID, NN = CF::NN;
+    constexpr bool TIME = CF::TIME;
+    using Seq = std::make_integer_sequence<int, 16>;
+    // A workgroup = TWO wave pairs (two 4-row tiles): four waves land on the four SIMDs of a CU, one each, whatever the grid size
+    // (two-wave workgroups were placed two-deep on some SIMDs at 512 workgroups: 2048 rows 148 us against 97 us at 1024 rows); the
+    // pairs only share the s_barrier.
+    __shared__ float xchg_all[2][2][3][4][H];       // [pair][step parity][f | g | dW][row][feature]
+    __shared__ float zstash_all[2][2][4][4][H];     // [pair] Philox normals [block parity][row][step of the block][feature] (net wave only)
+
+    const int lane = threadIdx.x & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int wave = wv & 1, pair = wv >> 1;
+    float (*xchg)[3][4][H] = xchg_all[pair];
+    float (*zstash)[4][4][H] = zstash_all[pair];
+    // Ragged batches: the last tile (and the idle second pair of an odd tile count) is moved BACK onto the last four rows instead of
+    // masking rows - those rows are then solved twice, bit-identically (same global row => same inputs and Philox counters), and
+    // stored twice with the same values; no per-row validity tests, branches or SGPR masks anywhere in the loop (B >= 4: host side).
+    const int B = a.B;
+    const int row_t = (blockIdx.x * 2 + pair) * 4;
+    const int row0 = row_t + 4 <= B ? row_t : B - 4;
+    const uint32_t BH = (uint32_t)B * H;
+    const float* P = a.params;
+
+    float y[4], yt[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) y[i] = a.y0[(size_t)(row0 + i) * H + lane];
+    quad_transpose(y, yt);
+
+    const int n_steps = a.N;
+    // step-table row: [0] t0, [1] h, [2] sin, [3] cos, [6] sqrt h, [8] outputs after the step, [9] index of the first
+    struct Row { float h, sn, cs, sqh; int nout, kfirst; };
+    // step table / output weights through the CONSTANT address space: wave-uniform reads of memory the kernel never writes become
+    // scalar loads (s_load, lgkmcnt).  As plain global pointers hipcc cannot prove them invariant against the kernel's own stores and
+    // uses vector loads - whose s_waitcnt vmcnt(0) then also waits for every output / trajectory store in flight (+ 770 cycles per
+    // step with an output per step).
+    typedef const float __attribute__((address_space(4)))* CP;
+    const CP step_tab_c = (CP)(uintptr_t)a.step_tab, out_w_c = (CP)(uintptr_t)a.out_w;
+    auto load_row = [&](int n) {
+        CP st = step_tab_c + (size_t)n * SNSDE_STEP_STRIDE;
+        Row q;
+        q.h = st[1]; q.sn = st[2]; q.cs = st[3]; q.sqh = st[6];
+        q.nout = __float_as_int(st[8]); q.kfirst = __float_as_int(st[9]);
+        return q;
+    };
+    const uint32_t lo = (uint32_t)(row0 * H + lane);
+    auto store4 = [&](float* p, const float (&v)[4]) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) p[lo + (uint32_t)(i * H)] = v[i];
+    };
+    auto save = [&](int n, int slot, const float (&v)[4]) { store4(a.act_save + uoff(n, (uint32_t)a.nsave * BH, (uint32_t)slot, BH), v); };
+    // relu epilogue of a hidden layer: v = relu(c + d) in the D layout (the bias came in through c), transposed into the next
+    // layer's A layout; sign bit `bit` of every row's word
+    auto relu_hand_off = [&](const f32x4& c, const f32x4& d, float (&v)[4], float (&vt)[4]) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) v[i] = fmaxf(c[i] + d[i], 0.0f);
+        quad_transpose(v, vt);
+    };
+
+    // Philox normals: one call = the four steps of a block for one (row, feature).  Step n refills row n & 3 for the NEXT block (one
+    // call per step, by the net wave), through a wave-private LDS stash: ds traffic takes no VALU issue slots, a register stash costs
+    // ~28 selects per step.  A burst of four calls every fourth step instead would stall the drift wave at that step's barrier.
+    // (Measured and dropped: rows 0, 1 refilled by the drift wave - its 245 registers then spill; 2048 rows 113 -> 119 us.)
+    const bool phx = a.dW == nullptr;
+    const uint64_t seed = a.seed_dev ? *a.seed_dev : a.seed;
+    auto philox_refill = [&](int n) {
+        const int k = n & 3, blk = n >> 2;
+        float zz[4];
+        snsde_philox_normal4(seed, (uint32_t)(a.row_offset + row0 + k), (uint32_t)(blk + 1), (uint32_t)lane, zz, 0u);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) zstash[(blk + 1) & 1][k][e][lane] = zz[e];
+    };
+    if (wave == 0) {
+        // ================================ drift wave ================================
+        float wi[CF::KIN], wh[NHID > 0 ? NHID : 1][H], wo[H], bi, bh[NHID > 0 ? NHID : 1], bo;
+        {
+            const float* w = P + a.w_in + (size_t)lane * CF::KIN;
+#pragma unroll
+            for (int k = 0; k < H; ++k) wi[k] = w[(TIME ? 2 : 0) + k];
+            if constexpr (TIME) { wi[64] = w[0]; wi[65] = w[1]; }
+            bi = P[a.b_in + lane];
+#pragma unroll
+            for (int l = 0; l < NHID; ++l) {
+                const float* q = P + a.w_hid[l] + (size_t)lane * H;
+#pragma unroll
+                for (int k = 0; k < H; ++k) wh[l][k] = q[k];
+                bh[l] = P[a.b_hid[l] + lane];
+            }
+            const float* q = P + a.w_out + (size_t)lane * H;
+#pragma unroll
+            for (int k = 0; k < H; ++k) wo[k] = q[k];
+            bo = P[a.b_out + lane];
+        }
+        int rslot[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) rslot[i] = a.row_out ? a.row_out[row0 + i] : -1;
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+        {
+            if (!a.row_out || rslot[i] == 0) a.ys[(size_t)(row0 + i) * H + lane] = y[i];
+            if (a.traj) a.traj[(size_t)(row0 + i) * H + lane] = y[i];
+        }
+        const bool geo = a.geo != 0;
+        Row nxt = load_row(0);
+        for (int n = 0; n < n_steps; ++n) {
+            const Row cur = nxt;
+            nxt = load_row(n + 1 < n_steps ? n + 1 : n);
+            const int kf = cur.kfirst < a.T - 1 ? (cur.kfirst < 0 ? 0 : cur.kfirst) : a.T - 2;
+            const float ow0 = out_w_c[2 * kf], ow1 = out_w_c[2 * kf + 1];       // (consumed at the end of the step)
+            uint32_t sgn[4] = {0u, 0u, 0u, 0u};
+            float v[4], vt[4];
+            W4_T(0)
+
+            {   // first layer on [y | sin t, cos t]
+                f32x4 c = {bi, bi, bi, bi}, d = {0.f, 0.f, 0.f, 0.f};
+                gemm64(yt, wi, c, d, Seq{});
+                if constexpr (TIME) {
+                    c = mfma_bk<0>(cur.sn, wi[64], c);
+                    d = mfma_bk<0>(cur.cs, wi[65], d);
+                }
+                relu_hand_off(c, d, v, vt);
+                if constexpr (CF::SAVE) {
+                    save(n, 0, v);
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) sgn[i] = v[i] > 0.0f ? 1u : 0u;
+                }
+            }
+            W4_T(1)
+#pragma unroll
+            for (int l = 0; l < NHID; ++l) {
+                f32x4 c = {bh[l], bh[l], bh[l], bh[l]}, d = {0.f, 0.f, 0.f, 0.f};
+                gemm64(vt, wh[l], c, d, Seq{});
+                relu_hand_off(c, d, v, vt);
+                if constexpr (CF::SAVE) {
+                    save(n, 1 + l, v);
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) sgn[i] |= (v[i] > 0.0f ? 1u : 0u) << (1 + l);
+                }
+            }
+            W4_T(2)
+            float f[4], z[4];
+            {
+                f32x4 c = {bo, bo, bo, bo}, d = {0.f, 0.f, 0.f, 0.f};
+                gemm64(vt, wo, c, d, Seq{});
+#pragma unroll
+                for (int i = 0; i < 4; ++i) { z[i] = c[i] + d[i]; f[i] = z[i]; }
+                W4_T(3)
+                if (geo) {
+                    float ty[4] = {y[0], y[1], y[2], y[3]};
+                    fast_tanh4(ty);
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) f[i] = z[i] * ty[i];
+                }
+                fast_tanh4(f);
+            }
+            W4_T(4)
+            float* xp = &xchg[n & 1][0][0][0];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) xp[i * H + lane] = f[i];
+            if constexpr (CF::SAVE) {
+                float zs[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) zs[i] = snsde_pack_signs(z[i], sgn[i], NHID + 1);
+                save(n, CF::ZSLOT, zs);
+            }
+            pair_barrier();
+            W4_T(5)
+            float yn[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const float g = xp[(4 + i) * H + lane], dw = xp[(8 + i) * H + lane];
+                yn[i] = fmaf(g, dw, fmaf(f[i], cur.h, y[i]));
+            }
+            if (a.traj) store4(a.traj + uoff(n + 1, BH), yn);
+            if (cur.nout > 0) {          // (wave-uniform; the first output's weights were fetched at the top of the step)
+                auto emit = [&](int k, float w0, float w1) {
+                    float o[4];
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) o[i] = (w0 == 0.0f) ? yn[i] : w0 * y[i] + w1 * yn[i];
+                    if (!a.row_out) store4(a.ys + uoff(k + 1, BH), o);
+                    else {
+#pragma unroll
+                        for (int i = 0; i < 4; ++i)
+                            if (rslot[i] == k + 1) a.ys[lo + (uint32_t)(i * H)] = o[i];
+                    }
+                };
+                emit(kf, ow0, ow1);
+                for (int k = kf + 1; k < cur.kfirst + cur.nout; ++k) emit(k, out_w_c[2 * k], out_w_c[2 * k + 1]);   // (several outputs inside one step: rare)
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i) y[i] = yn[i];
+            quad_transpose(y, yt);
+            W4_T(6)
+        }
+#ifdef W4_TRACE
+        if (blockIdx.x == 0 && pair == 0 && lane == 0 && a.dW_out) for (int i = 0; i < 8; ++i) a.dW_out[i] = tr_acc[i];
+#endif
+    } else {
+        // ================================ diffusion-net wave ================================
+        float wn0[66], wn1[NN > 1 ? H : 1], b0, b1 = 0.0f;
+        {
+            const float* w = P + a.w_n0 + (size_t)lane * 66;
+#pragma unroll
+            for (int k = 0; k < H; ++k) wn0[k] = w[2 + k];
+            wn0[64] = w[0]; wn0[65] = w[1];
+            b0 = P[a.b_n0 + lane];
+            if constexpr (NN > 1) {
+                const float* q = P + a.w_n1 + (size_t)lane * H;
+#pragma unroll
+                for (int k = 0; k < H; ++k) wn1[k] = q[k];
+                b1 = P[a.b_n1 + lane];
+            }
+        }
+        const float sig_theta = snsde_sigmoid(P[a.off_theta]);
+        const bool mul_y = a.no == 15 || a.no == 19;
+        if (phx) {       // block 0 (the drift wave's first read of the stash is behind step 0's barrier)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                float zz[4];
+                snsde_philox_normal4(seed, (uint32_t)(a.row_offset + row0 + i), 0u, (uint32_t)lane, zz, 0u);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) zstash[0][i][e][lane] = zz[e];
+            }
+        }
+        Row nxt = load_row(0);
+        for (int n = 0; n < n_steps; ++n) {
+            const Row cur = nxt;
+            nxt = load_row(n + 1 < n_steps ? n + 1 : n);
+            float dw[4];
+            W4_T(0)
+            if (phx) {
+                const int k = n & 3, blk = n >> 2;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) dw[i] = zstash[blk & 1][i][k][lane] * cur.sqh;
+                philox_refill(n);
+            } else {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) dw[i] = (a.dW + uoff(n, BH))[lo + (uint32_t)(i * H)];
+            }
+            W4_T(1)
+            float q[4], v[4], vt[4];
+            {
+                f32x4 c = {b0, b0, b0, b0}, d = {0.f, 0.f, 0.f, 0.f};
+                gemm64(yt, wn0, c, d, Seq{});
+                c = mfma_bk<0>(cur.sn, wn0[64], c);
+                d = mfma_bk<0>(cur.cs, wn0[65], d);
+                if constexpr (NN == 2) {
+                    relu_hand_off(c, d, v, vt);
+                    if constexpr (CF::SAVE) save(n, CF::ZSLOT + 1, v);
+                } else {
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) q[i] = c[i] + d[i];
+                    if constexpr (CF::SAVE) save(n, CF::ZSLOT + 1, q);
+                }
+            }
+            W4_T(2)
+            if constexpr (NN == 2) {
+                f32x4 c = {b1, b1, b1, b1}, d = {0.f, 0.f, 0.f, 0.f};
+                gemm64(vt, wn1, c, d, Seq{});
+#pragma unroll
+                for (int i = 0; i < 4; ++i) q[i] = fmaxf(c[i] + d[i], 0.0f);
+                if constexpr (CF::SAVE) save(n, CF::ZSLOT + 2, q);
+            }
+            W4_T(3)
+            float g[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const float raw = q[i] * (mul_y ? y[i] : 1.0f);      // (a select, not a branch per element; q * 1 is exact)
+                g[i] = sig_theta * snsde_nan_to_num(raw);
+            }
+            fast_tanh4(g);
+            W4_T(4)
+            float* xp = &xchg[n & 1][0][0][0];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) { xp[(4 + i) * H + lane] = g[i]; xp[(8 + i) * H + lane] = dw[i]; }
+#ifndef W4_TRACE
+            if (a.dW_out) store4(a.dW_out + uoff(n, BH), dw);
+#endif
+            pair_barrier();
+            W4_T(5)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) y[i] = fmaf(g[i], dw[i], fmaf(xp[i * H + lane], cur.h, y[i]));
+            quad_transpose(y, yt);
+            W4_T(6)
+        }
+#ifdef W4_TRACE
+        if (blockIdx.x == 0 && pair == 0 && lane == 0 && a.dW_out) for (int i = 0; i < 8; ++i) a.dW_out[64 + i] = tr_acc[i];
+#endif
+    }
+}
+
+}  // namespace snsde_w4

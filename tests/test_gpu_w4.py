@@ -1,0 +1,99 @@
+"""GPU tests of the wave-owns-rows forward kernels (csrc/snsde_w4_kernel.h; run with -m gpu): H = 64 models with a diffusion net under
+Euler - BASELINE config 4's model family.  Forward against the fp64 numpy oracle on replayed increments, against the 4-row-tile kernels,
+Philox runs against the generic kernels, per-row outputs / interpolated outputs / ragged tiles, and the training-mode saves through the
+unchanged adjoint + weight-gradient pass against fp64 autograd."""
+import numpy as np
+import pytest
+import torch
+
+import stable_neural_sdes_amd as S
+from tests.helpers import assert_parity, draw_dW, make_problem
+from tests.test_gpu_parity import _check_backward, hip_solve, oracle_solve
+
+pytestmark = pytest.mark.gpu
+DEV = 'cuda:0'
+
+W4_CASES = [
+    # io, no, NL, B, C, L, ts, dt
+    (3, 18, 2, 37, 5, 9, [0, 3.5, 8], 1.0),          # BASELINE config 4's model; ragged last tile, an interpolated output
+    (1, 14, 1, 9, 3, 8, [0, 7], 0.5),                # one-layer drift, one-layer net, no time features in the drift
+    (5, 19, 2, 21, 3, 9, [0, 8], 1.0),               # geometric drift, raw = net * y
+    (3, 15, 1, 13, 4, 8, [0, 2.5, 7], 1.0),
+    (1, 18, 2, 64, 3, 12, None, None),               # every knot an output, linspace grid
+    (5, 14, 2, 8, 3, 8, [0, 7], 1.0),
+]
+
+
+@pytest.mark.parametrize('ci', range(len(W4_CASES)))
+def test_w4_forward_vs_oracle_and_the_tile_kernels(ci):
+    io, no, NL, B, C, L, ts, dt = W4_CASES[ci]
+    H = 64
+    times = np.linspace(0, 1, L).astype(np.float32) if ts is None else None
+    pr = make_problem(8800 + ci, io, no, NL, B, H, C, L, times=times)
+    ts = pr['times'] if ts is None else np.asarray(ts, np.float32)
+    dt = dt or float(np.diff(pr['times']).min())
+    model = S.engine.model_struct(C, H, H, NL, io, no)
+    grid = S.engine.step_grid(ts, dt, pr['times'], torch.device(DEV))
+    assert S.engine.forward_path(model, B, L, grid.N, kernel='w4') == 'w4'
+    assert S.engine.forward_path(model, B, L, grid.N) == 'w4'                  # ... and `auto` takes it
+    dW = draw_dW(8800 + ci, ts, dt, B, H)
+    ref64, _ = oracle_solve(pr, ts, dt, dW, 'euler', np.float64)
+    cpu32, _ = oracle_solve(pr, ts, dt, dW, 'euler', np.float32)
+    ys, _ = hip_solve(pr, ts, dt, dW=dW, kernel='w4', save_traj=True)
+    assert ys.shape == ref64.shape
+    assert_parity(ys, ref64, cpu32, what=f'w4 case {ci}')
+    y4, _ = hip_solve(pr, ts, dt, dW=dW, kernel='mfma4')
+    assert np.abs(ys - y4).max() <= 2e-5 * (np.abs(y4).max() + 1.0)
+    # in-kernel Philox: the same stream as every other kernel family (global row, step block, column)
+    yp, _ = hip_solve(pr, ts, dt, seed=77, row_offset=5, kernel='w4')
+    yg, _ = hip_solve(pr, ts, dt, seed=77, row_offset=5, kernel='generic')
+    assert np.isfinite(yp).all() and np.abs(yp - yg).max() <= 2e-4 * (np.abs(yg).max() + 1.0)
+    # row shards keep the global stream bit for bit
+    half = B // 2
+    ya, _ = hip_solve(pr, ts, dt, seed=77, row_offset=0, kernel='w4')
+    yb0, _ = hip_solve(pr, ts, dt, seed=77, row_offset=0, rows=slice(0, half), kernel='w4')
+    yb1, _ = hip_solve(pr, ts, dt, seed=77, row_offset=half, rows=slice(half, B), kernel='w4')
+    np.testing.assert_array_equal(np.concatenate([yb0, yb1], axis=1), ya)
+
+
+def test_w4_per_row_outputs_and_trajectory():
+    io, no, NL, B, C, L, H = 3, 18, 2, 19, 5, 9, 64
+    pr = make_problem(8900, io, no, NL, B, H, C, L)
+    ts = pr['times'][[0, 2, 5, 8]]
+    dW = draw_dW(8900, ts, 1.0, B, H)
+    ref64, traj64 = oracle_solve(pr, ts, 1.0, dW, 'euler', np.float64)
+    model = S.engine.model_struct(C, H, H, NL, io, no)
+    from tests.test_gpu_parity import flat_params
+    flat = flat_params(pr['params'], io, no, NL, C, H)
+    grid = S.engine.step_grid(ts, 1.0, pr['times'], torch.device(DEV))
+    row_out = torch.from_numpy(np.random.default_rng(1).integers(0, len(ts), size=B).astype(np.int32)).to(DEV)
+    call = S.engine.SolveCall(model, flat, torch.from_numpy(pr['coeffs']).to(DEV), grid, torch.from_numpy(pr['y0']).to(DEV),
+                              dW=torch.from_numpy(dW).to(DEV), kernel='w4', row_out=row_out, save_traj=True, save_dW=True)
+    ys = call.launch()
+    torch.cuda.synchronize()
+    want = ref64[row_out.cpu().numpy(), np.arange(B)]
+    assert_parity(ys.cpu().numpy(), want, what='w4 row_out')
+    assert_parity(call.traj.cpu().numpy(), traj64, what='w4 trajectory')
+    np.testing.assert_array_equal(call.dW_out.cpu().numpy(), dW)
+
+
+BWD = [
+    # io, no, NL, B, C, L, ts, dt
+    (3, 18, 2, 21, 5, 9, [0, 3.5, 8], 1.0),
+    (1, 14, 1, 9, 3, 8, [0, 7], 0.5),
+    (5, 19, 2, 13, 3, 9, [0, 8], 1.0),
+    (3, 15, 2, 11, 4, 8, [0, 2.5, 7], 1.0),
+    (1, 18, 1, 10, 3, 8, [0, 7], 1.0),
+]
+
+
+@pytest.mark.parametrize('ci', range(len(BWD)))
+def test_w4_training_saves_drive_the_fused_adjoint(ci):
+    """Forward on the wave-owns-rows kernel in training mode (act_save slots, relu signs in the saved z, increments), backward on the
+    unchanged MFMA adjoint + weight-gradient pass: gradients against fp64 autograd through the tensor loop."""
+    io, no, NL, B, C, L, ts, dt = BWD[ci]
+    grid = S.engine.step_grid(np.asarray(ts, np.float32), dt, np.arange(L, dtype=np.float32), torch.device(DEV))
+    model = S.engine.model_struct(C, 64, 64, NL, io, no)
+    assert S.engine.forward_path(model, B, L, grid.N) == 'w4' and S.engine.backward_mode(model, B, L, grid, 'euler') == 1
+    _check_backward(8950 + ci, io, no, NL, B, 64, C, L, ts, dt, 'euler', 'w4', strict=True)
+    _check_backward(8950 + ci, io, no, NL, B, 64, C, L, ts, dt, 'euler', 'auto', strict=True)
