@@ -365,6 +365,7 @@ int snsde_solve_forward(const snsde_solve* s, void* hip_stream) {
     if (s->method == SNSDE_SRK) {   // SRK: MFMA variant (M4 tiles) where instantiated, else the generic (all-options) family
         if (s->kernel == SNSDE_KERNEL_MFMA_M16) return snsde_mfma_launch(s, net, st, 0);     // (H = 64 / 128, elementwise diffusions)
         if (s->kernel == SNSDE_KERNEL_MFMA_M4) return snsde_mfma_launch(s, net, st, 1);
+        if (s->kernel == SNSDE_KERNEL_MFMA_W4) return snsde_mfma_launch(s, net, st, 2);
         if (s->kernel == SNSDE_KERNEL_MFMA) return snsde_mfma_launch(s, net, st, -1);
         if (s->kernel == SNSDE_KERNEL_AUTO && snsde_mfma_supported(s, net)) return snsde_mfma_launch(s, net, st, -1);
         if (s->kernel != SNSDE_KERNEL_AUTO && s->kernel != SNSDE_KERNEL_GENERIC) return SNSDE_ERR_OPTION;
@@ -404,6 +405,7 @@ int snsde_forward_path(const snsde_solve* s) {
     if (s->method == SNSDE_SRK) {
         if (s->kernel == SNSDE_KERNEL_MFMA_M16) return snsde_mfma_path(s, net, 0);
         if (s->kernel == SNSDE_KERNEL_MFMA_M4) return snsde_mfma_path(s, net, 1);
+        if (s->kernel == SNSDE_KERNEL_MFMA_W4) return snsde_mfma_path(s, net, 2);
         if (s->kernel == SNSDE_KERNEL_MFMA) return snsde_mfma_path(s, net, -1);
         if (s->kernel == SNSDE_KERNEL_AUTO && snsde_mfma_supported(s, net)) return snsde_mfma_path(s, net, -1);
         return SNSDE_PATH_GENERIC_SRK;

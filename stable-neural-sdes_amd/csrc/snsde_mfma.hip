@@ -535,7 +535,8 @@ bool snsde_mfma_supported(const snsde_solve* s, const SnsdeNet& net) { return ma
 static bool w4_takes(const snsde_solve* s, const SnsdeNet& net, int flavor_hint) {
     // measured at the K4 shape (tools/time_w4.py, profiles/r05_time_w4.txt): 2048 rows 109 us against 156 (4-row tiles) / 216 (16-row
     // tiles), 6144 rows 275 against 316 (16-row tiles); from 8192 rows the 16-row tiles win (a third wave per SIMD does not fit)
-    return (flavor_hint == 2 || (flavor_hint == -1 && s->batch <= 6144)) && snsde_w4_supported(s, net);
+    // SRK through a net has no 16-row flavour: the wave pair at every batch size (2048 rows 352 us against 456, 4096 rows 540 / 900)
+    return (flavor_hint == 2 || (flavor_hint == -1 && (s->batch <= 6144 || s->method == SNSDE_SRK))) && snsde_w4_supported(s, net);
 }
 
 // which MFMA kernel family a forward launch of this descriptor takes (SNSDE_PATH_*; 0: none)

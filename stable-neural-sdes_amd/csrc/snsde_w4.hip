@@ -9,7 +9,7 @@ static bool shape_ok(const snsde_solve* s, const SnsdeNet& net) {
     if (m.hidden_channels != 64 || m.hidden_hidden_channels != 64) return false;
     if (!(io == 1 || io == 3 || io == 5)) return false;                      // latent-only drifts (no control path in f)
     if (!(no == 14 || no == 15 || no == 18 || no == 19)) return false;       // diffusion nets
-    if (s->method != SNSDE_EULER) return false;
+    if (s->method != SNSDE_EULER && s->method != SNSDE_SRK) return false;
     if (m.activation != 0 || m.drift_output != 0 || m.diffusion_output != 0 || m.time_feature != 0 || s->noise_table) return false;
     if (m.num_hidden_layers < 1 || m.num_hidden_layers > 2) return false;      // (two hidden layers: 258 weight registers, spills)
     if (s->kl_column1 != 0 || s->batch < 4) return false;      // (a tile is four rows; ragged tails overlap the previous tile)
@@ -20,8 +20,12 @@ static bool shape_ok(const snsde_solve* s, const SnsdeNet& net) {
 
 template <int NHID, int NN, bool TIME>
 static int launch(const W4Args& a, hipStream_t st) {
-    if (a.act_save) hipLaunchKernelGGL((snsde_w4_euler_kernel<CfgW<NHID, NN, TIME, true>>), dim3((a.B + 7) / 8), dim3(256), 0, st, a);
-    else hipLaunchKernelGGL((snsde_w4_euler_kernel<CfgW<NHID, NN, TIME, false>>), dim3((a.B + 7) / 8), dim3(256), 0, st, a);
+    const dim3 grid((a.B + 7) / 8), block(256);
+    if (a.srk_tab) {
+        if (a.act_save) hipLaunchKernelGGL((snsde_w4_srk_kernel<CfgW<NHID, NN, TIME, true>>), grid, block, 0, st, a);
+        else hipLaunchKernelGGL((snsde_w4_srk_kernel<CfgW<NHID, NN, TIME, false>>), grid, block, 0, st, a);
+    } else if (a.act_save) hipLaunchKernelGGL((snsde_w4_euler_kernel<CfgW<NHID, NN, TIME, true>>), grid, block, 0, st, a);
+    else hipLaunchKernelGGL((snsde_w4_euler_kernel<CfgW<NHID, NN, TIME, false>>), grid, block, 0, st, a);
     return hipGetLastError() == hipSuccess ? SNSDE_OK : SNSDE_ERR_LAUNCH;
 }
 
@@ -32,6 +36,7 @@ bool snsde_w4_supported(const snsde_solve* s, const SnsdeNet& net) { return snsd
 int snsde_w4_launch(const snsde_solve* s, const SnsdeNet& net, hipStream_t stream) {
     using namespace snsde_w4;
     if (!shape_ok(s, net)) return SNSDE_ERR_UNSUPPORTED;
+    if (s->method == SNSDE_SRK && (!s->srk_tab || (s->dW && !s->dU))) return SNSDE_ERR_NULL;
     const snsde_model& m = s->model;
     W4Args a{};
     a.params = s->params; a.step_tab = s->step_tab; a.out_w = s->out_w; a.y0 = s->y0; a.dW = s->dW; a.ys = s->ys; a.traj = s->traj;
@@ -39,6 +44,7 @@ int snsde_w4_launch(const snsde_solve* s, const SnsdeNet& net, hipStream_t strea
     a.seed_dev = s->seed_dev;
     a.B = s->batch; a.N = s->n_steps; a.T = s->n_out; a.no = m.noise_option; a.geo = m.input_option == 5 ? 1 : 0;
     a.nsave = snsde_act_slots(&m);
+    if (s->method == SNSDE_SRK) { a.srk_tab = s->srk_tab; a.dU = s->dU; a.dU_out = s->dU_out; a.stage_save = s->stage_save; }
     a.off_theta = net.off_theta;
     a.w_in = net.in.src_w; a.b_in = net.in.src_b; a.k_in = net.in.K; a.t_in = net.in.tshift;
     const int nhid = m.num_hidden_layers - 1;

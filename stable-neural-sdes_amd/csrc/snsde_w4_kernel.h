@@ -42,6 +42,10 @@ struct W4Args {
     float* traj;
     float* dW_out;
     float* act_save;
+    const float* srk_tab;     // SRK: (N, 4, SNSDE_SRK_STRIDE) stage times t0 + {0, 1/4, 1/2, 1} h: [1] sin, [2] cos
+    const float* dU;          // SRK: supplied I_k0 (with dW) or null
+    float* dU_out;
+    float* stage_save;        // SRK training: (3N + 1, 3, B, H)  H0 | H1 | H1_3
     const int32_t* row_out;
     int64_t row_offset;
     uint64_t seed;
@@ -428,6 +432,357 @@ __global__ void __launch_bounds__(256, 2) snsde_w4_euler_kernel(W4Args a) {
 #ifdef W4_TRACE
         if (blockIdx.x == 0 && pair == 0 && lane == 0 && a.dW_out) for (int i = 0; i < 8; ++i) a.dW_out[64 + i] = tr_acc[i];
 #endif
+    }
+}
+
+// =====================================================================================================================================
+// SRK (torchsde's SRID2; torch_ists' default method, nsde_model.py:63-74) on the same wave pair.  Per solver step three drift
+// evaluations F0 = f(t0, y), F1 = f(t0 + h, H0_1), F2 = f(t0 + h/2, H0_2) - the drift wave - and four net evaluations G0 = g(t0, y),
+// G1 = g(t0 + h/4, H1_1), G2 = g(t0 + h, H1_2), G3 = g(t0 + h/4, H1_3) - the net wave, which also draws (I_k, I_k0), forms every H1
+// and the step's result and publishes it.  Five exchanges per step, each behind one s_barrier:
+//     B1: F0 ->, <- G0, I_k0     B2: F1 ->, <- G1     B3: F2 ->     (the net wave: G2 beside F2, then G3 alone)     B4: <- y'
+// (H0_1 needs F0 only; H0_2 needs F0, F1, G0, G1, I_k0; H1_2 needs F0, G0 only, so G1 and G2 do not wait for the drift wave.)
+// Training-mode saves = snsde_m4n_kernel's (act_save per pass 3n + s with 2 NN + NHID + 2 slots, the pass's drift signs and the hidden
+// signs of the net evaluation beside it / of the fourth evaluation in the low bits of the saved z, stage_save planes H0 | H1 | H1_3):
+// the adjoint (snsde_m4n_rev_kernel.h) and the weight-gradient pass are unchanged.
+// =====================================================================================================================================
+template <class CF>
+__global__ void __launch_bounds__(256, 2) snsde_w4_srk_kernel(W4Args a) {
+    constexpr int H = 64, NHID = CF::NHID, NN = CF::NN;
+    constexpr bool TIME = CF::TIME, SAVE = CF::SAVE;
+    constexpr int NSAVE = NHID + 2 + 2 * NN, ZSLOT = NHID + 1, NP = 3;
+    constexpr int SRK_BITS = NHID + 1 + (NN == 2 ? 2 : 0);
+    using Seq = std::make_integer_sequence<int, 16>;
+    // exchange planes of a pair: F0 F1 F2 | G0 G1 | I_k0 | y' | hidden-sign words of G0..G3 (training)
+    enum { XF0 = 0, XF1, XF2, XG0, XG1, XDU, XY, XS0, XS1, XS2, XS3, XN };
+    __shared__ float xchg_all[2][XN][4][H];
+    __shared__ float zstash_all[2][2][2][4][4][H];     // [pair][stream: I_k, xi][block parity][row][step of the block][feature]
+
+    const int lane = threadIdx.x & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int wave = wv & 1, pair = wv >> 1;
+    float (*xchg)[4][H] = xchg_all[pair];
+    float (*zstash)[2][4][4][H] = zstash_all[pair];
+    const int B = a.B;
+    const int row_t = (blockIdx.x * 2 + pair) * 4;
+    const int row0 = row_t + 4 <= B ? row_t : B - 4;       // (ragged tail: see snsde_w4_euler_kernel)
+    const uint32_t BH = (uint32_t)B * H;
+    const float* P = a.params;
+    typedef const float __attribute__((address_space(4)))* CP;
+    const CP step_tab_c = (CP)(uintptr_t)a.step_tab, out_w_c = (CP)(uintptr_t)a.out_w, srk_c = (CP)(uintptr_t)a.srk_tab;
+    const uint32_t lo = (uint32_t)(row0 * H + lane);
+    auto store4 = [&](float* p, const float (&v)[4]) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) p[lo + (uint32_t)(i * H)] = v[i];
+    };
+    auto save = [&](int pass, int slot, const float (&v)[4]) { store4(a.act_save + uoff(pass, (uint32_t)NSAVE * BH, (uint32_t)slot, BH), v); };
+    auto put = [&](int plane, const float (&v)[4]) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) xchg[plane][i][lane] = v[i];
+    };
+    auto get = [&](int plane, float (&v)[4]) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) v[i] = xchg[plane][i][lane];
+    };
+    auto relu_hand_off = [&](const f32x4& c, const f32x4& d, float (&v)[4], float (&vt)[4]) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) v[i] = fmaxf(c[i] + d[i], 0.0f);
+        quad_transpose(v, vt);
+    };
+
+    float y[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) y[i] = a.y0[(size_t)(row0 + i) * H + lane];
+    const int n_steps = a.N;
+
+    if (wave == 0) {
+        // ================================ drift wave ================================
+        float wi[CF::KIN], wh[NHID > 0 ? NHID : 1][H], wo[H], bi, bh[NHID > 0 ? NHID : 1], bo;
+        {
+            const float* w = P + a.w_in + (size_t)lane * CF::KIN;
+#pragma unroll
+            for (int k = 0; k < H; ++k) wi[k] = w[(TIME ? 2 : 0) + k];
+            if constexpr (TIME) { wi[64] = w[0]; wi[65] = w[1]; }
+            bi = P[a.b_in + lane];
+#pragma unroll
+            for (int l = 0; l < NHID; ++l) {
+                const float* q = P + a.w_hid[l] + (size_t)lane * H;
+#pragma unroll
+                for (int k = 0; k < H; ++k) wh[l][k] = q[k];
+                bh[l] = P[a.b_hid[l] + lane];
+            }
+            const float* q = P + a.w_out + (size_t)lane * H;
+#pragma unroll
+            for (int k = 0; k < H; ++k) wo[k] = q[k];
+            bo = P[a.b_out + lane];
+        }
+        const bool geo = a.geo != 0;
+        if constexpr (SAVE) { if (a.stage_save) store4(a.stage_save, y); }
+        // one drift evaluation at (sn, cs) on the state `x` (D layout): f into `f`, training: act_save slots of `pass`, z (kept) and signs
+        auto drift = [&](const float (&x)[4], float sn, float cs, int pass, float (&f)[4], float (&z)[4], uint32_t (&sgn)[4]) {
+            float xt[4], v[4], vt[4];
+            quad_transpose(x, xt);
+            {
+                f32x4 c = {bi, bi, bi, bi}, d = {0.f, 0.f, 0.f, 0.f};
+                gemm64(xt, wi, c, d, Seq{});
+                if constexpr (TIME) { c = mfma_bk<0>(sn, wi[64], c); d = mfma_bk<0>(cs, wi[65], d); }
+                relu_hand_off(c, d, v, vt);
+                if constexpr (SAVE) {
+                    save(pass, 0, v);
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) sgn[i] = v[i] > 0.0f ? 1u : 0u;
+                }
+            }
+#pragma unroll
+            for (int l = 0; l < NHID; ++l) {
+                f32x4 c = {bh[l], bh[l], bh[l], bh[l]}, d = {0.f, 0.f, 0.f, 0.f};
+                gemm64(vt, wh[l], c, d, Seq{});
+                relu_hand_off(c, d, v, vt);
+                if constexpr (SAVE) {
+                    save(pass, 1 + l, v);
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) sgn[i] |= (v[i] > 0.0f ? 1u : 0u) << (1 + l);
+                }
+            }
+            f32x4 c = {bo, bo, bo, bo}, d = {0.f, 0.f, 0.f, 0.f};
+            gemm64(vt, wo, c, d, Seq{});
+#pragma unroll
+            for (int i = 0; i < 4; ++i) { z[i] = c[i] + d[i]; f[i] = z[i]; }
+            if (geo) {
+                float tx[4] = {x[0], x[1], x[2], x[3]};
+                fast_tanh4(tx);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) f[i] = z[i] * tx[i];
+            }
+            fast_tanh4(f);
+        };
+        // training: the pass's saved z carries its drift signs and the hidden sign word(s) the net wave published
+        auto save_z = [&](int pass, const float (&z)[4], const uint32_t (&sgn)[4], int plane_a, int plane_b) {
+            float zs[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                uint32_t sg = sgn[i];
+                if constexpr (NN == 2) {
+                    sg |= __float_as_uint(xchg[plane_a][i][lane]) << (NHID + 1);
+                    if (plane_b >= 0) sg |= __float_as_uint(xchg[plane_b][i][lane]) << (NHID + 2);
+                }
+                zs[i] = snsde_pack_signs(z[i], sg, SRK_BITS);
+            }
+            save(pass, ZSLOT, zs);
+        };
+        for (int n = 0; n < n_steps; ++n) {
+            CP st = step_tab_c + (size_t)n * SNSDE_STEP_STRIDE;
+            CP sk = srk_c + (size_t)n * 4 * SNSDE_SRK_STRIDE;
+            const float h = st[1];
+            const float s0 = sk[1], c0 = sk[2], s1 = sk[3 * SNSDE_SRK_STRIDE + 1], c1 = sk[3 * SNSDE_SRK_STRIDE + 2],
+                        s2 = sk[2 * SNSDE_SRK_STRIDE + 1], c2 = sk[2 * SNSDE_SRK_STRIDE + 2];
+            const float rh = 1.0f / h;
+            float f0[4], f1[4], f2[4], z[4], g0[4], g1[4], du[4], x[4];
+            uint32_t sgn[4] = {0u, 0u, 0u, 0u};
+            // ---- pass 0: F0 at (t0, y) ----
+            drift(y, s0, c0, 3 * n, f0, z, sgn);
+            put(XF0, f0);
+            pair_barrier();                                   // B1
+            get(XG0, g0); get(XDU, du);
+            if constexpr (SAVE) save_z(3 * n, z, sgn, XS0, -1);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) x[i] = y[i] + f0[i] * h;                     // H0_1
+            if constexpr (SAVE) { if (a.stage_save) store4(a.stage_save + uoff(3 * n + 1, NP * BH), x); }
+            // ---- pass 1: F1 at (t0 + h, H0_1) ----
+            drift(x, s1, c1, 3 * n + 1, f1, z, sgn);
+            put(XF1, f1);
+            pair_barrier();                                   // B2
+            get(XG1, g1);
+            if constexpr (SAVE) save_z(3 * n + 1, z, sgn, XS1, -1);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) x[i] = y[i] + 0.25f * f0[i] * h + 0.25f * f1[i] * h + (g0[i] + 0.5f * g1[i]) * (du[i] * rh);   // H0_2
+            if constexpr (SAVE) { if (a.stage_save) store4(a.stage_save + uoff(3 * n + 2, NP * BH), x); }
+            // ---- pass 2: F2 at (t0 + h/2, H0_2) ----
+            drift(x, s2, c2, 3 * n + 2, f2, z, sgn);
+            put(XF2, f2);
+            pair_barrier();                                   // B3
+            pair_barrier();                                   // B4: the net wave's G3, the step's result
+            get(XY, y);
+            if constexpr (SAVE) save_z(3 * n + 2, z, sgn, XS2, XS3);
+        }
+    } else {
+        // ================================ diffusion-net wave ================================
+        float wn0[66], wn1[NN > 1 ? H : 1], b0, b1 = 0.0f;
+        {
+            const float* w = P + a.w_n0 + (size_t)lane * 66;
+#pragma unroll
+            for (int k = 0; k < H; ++k) wn0[k] = w[2 + k];
+            wn0[64] = w[0]; wn0[65] = w[1];
+            b0 = P[a.b_n0 + lane];
+            if constexpr (NN > 1) {
+                const float* q = P + a.w_n1 + (size_t)lane * H;
+#pragma unroll
+                for (int k = 0; k < H; ++k) wn1[k] = q[k];
+                b1 = P[a.b_n1 + lane];
+            }
+        }
+        const float sig_theta = snsde_sigmoid(P[a.off_theta]);
+        const bool mul_y = a.no == 15 || a.no == 19;
+        const bool phx = a.dW == nullptr;
+        const uint64_t seed = a.seed_dev ? *a.seed_dev : a.seed;
+        int rslot[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) rslot[i] = a.row_out ? a.row_out[row0 + i] : -1;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            if (!a.row_out || rslot[i] == 0) a.ys[(size_t)(row0 + i) * H + lane] = y[i];
+            if (a.traj) a.traj[(size_t)(row0 + i) * H + lane] = y[i];
+        }
+        if constexpr (SAVE) { if (a.stage_save) store4(a.stage_save + BH, y); }
+        // Philox: stream 0 = the increments' normals, stream 1 = xi of the space-time Levy area; step n refills row n & 3 of the next block
+        auto refill = [&](int row_k, int blk) {
+#pragma unroll
+            for (int sidx = 0; sidx < 2; ++sidx) {
+                float zz[4];
+                snsde_philox_normal4(seed, (uint32_t)(a.row_offset + row0 + row_k), (uint32_t)blk, (uint32_t)lane, zz, (uint32_t)sidx);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) zstash[sidx][blk & 1][row_k][e][lane] = zz[e];
+            }
+        };
+        if (phx) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) refill(i, 0);
+        }
+        // one net evaluation at (sn, cs) on the state x: g into `g`; training: the net slots of `pass` (slot0 / slot0 + 1) and the hidden
+        // sign word into exchange plane `splane`
+        auto net = [&](const float (&x)[4], float sn, float cs, int pass, int slot0, int splane, float (&g)[4]) {
+            float xt[4], v[4], vt[4], q[4];
+            quad_transpose(x, xt);
+            {
+                f32x4 c = {b0, b0, b0, b0}, d = {0.f, 0.f, 0.f, 0.f};
+                gemm64(xt, wn0, c, d, Seq{});
+                c = mfma_bk<0>(sn, wn0[64], c);
+                d = mfma_bk<0>(cs, wn0[65], d);
+                if constexpr (NN == 2) {
+                    relu_hand_off(c, d, v, vt);
+                    if constexpr (SAVE) {
+                        save(pass, slot0, v);
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) xchg[splane][i][lane] = __uint_as_float(v[i] > 0.0f ? 1u : 0u);
+                    }
+                } else {
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) q[i] = c[i] + d[i];
+                    if constexpr (SAVE) save(pass, slot0, q);
+                }
+            }
+            if constexpr (NN == 2) {
+                f32x4 c = {b1, b1, b1, b1}, d = {0.f, 0.f, 0.f, 0.f};
+                gemm64(vt, wn1, c, d, Seq{});
+#pragma unroll
+                for (int i = 0; i < 4; ++i) q[i] = fmaxf(c[i] + d[i], 0.0f);
+                if constexpr (SAVE) save(pass, slot0 + 1, q);
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const float raw = q[i] * (mul_y ? x[i] : 1.0f);
+                g[i] = sig_theta * snsde_nan_to_num(raw);
+            }
+            fast_tanh4(g);
+        };
+        for (int n = 0; n < n_steps; ++n) {
+            CP st = step_tab_c + (size_t)n * SNSDE_STEP_STRIDE;
+            CP sk = srk_c + (size_t)n * 4 * SNSDE_SRK_STRIDE;
+            const float h = st[1], sqh = st[6];
+            const int nout = __float_as_int(st[8]), kfirst = __float_as_int(st[9]);
+            const float s0 = sk[1], c0 = sk[2], sq = sk[SNSDE_SRK_STRIDE + 1], cq = sk[SNSDE_SRK_STRIDE + 2],
+                        s1 = sk[3 * SNSDE_SRK_STRIDE + 1], c1 = sk[3 * SNSDE_SRK_STRIDE + 2];
+            const int kf = kfirst < a.T - 1 ? (kfirst < 0 ? 0 : kfirst) : a.T - 2;
+            const float ow0 = out_w_c[2 * kf], ow1 = out_w_c[2 * kf + 1];
+            const float rh = 1.0f / h, rsqh = 1.0f / sqh;
+            float ik[4], ik0[4];
+            if (phx) {
+                const int k = n & 3, blk = n >> 2;
+                const float sh12 = sqrtf(h / 12.0f);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    ik[i] = zstash[0][blk & 1][i][k][lane] * sqh;
+                    ik0[i] = h * fmaf(sh12, zstash[1][blk & 1][i][k][lane], 0.5f * ik[i]);
+                }
+                refill(k, blk + 1);
+            } else {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) { ik[i] = (a.dW + uoff(n, BH))[lo + (uint32_t)(i * H)]; ik0[i] = (a.dU + uoff(n, BH))[lo + (uint32_t)(i * H)]; }
+            }
+            float g0[4], g1[4], g2[4], g3[4], f0[4], f1[4], f2[4], x[4];
+            // ---- G0 at (t0, y) ----
+            net(y, s0, c0, 3 * n, ZSLOT + 1, XS0, g0);
+            put(XG0, g0); put(XDU, ik0);
+            pair_barrier();                                   // B1
+            get(XF0, f0);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) x[i] = y[i] + 0.25f * f0[i] * h + 0.5f * g0[i] * sqh;      // H1_1
+            if constexpr (SAVE) { if (a.stage_save) store4(a.stage_save + uoff(3 * n + 1, NP * BH, 1, BH), x); }
+            // ---- G1 at (t0 + h/4, H1_1) ----
+            net(x, sq, cq, 3 * n + 1, ZSLOT + 1, XS1, g1);
+            put(XG1, g1);
+            pair_barrier();                                   // B2
+            get(XF1, f1);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) x[i] = y[i] + f0[i] * h - g0[i] * sqh;                     // H1_2
+            if constexpr (SAVE) { if (a.stage_save) store4(a.stage_save + uoff(3 * n + 2, NP * BH, 1, BH), x); }
+            // ---- G2 at (t0 + h, H1_2) ----
+            net(x, s1, c1, 3 * n + 2, ZSLOT + 1, XS2, g2);
+            // everything of the step's result that does not need F2 / G3, while the drift wave finishes F2 (same association as the
+            // other kernels' `y + (f0 + f1) h/6 + f2 2h/3;  += w0 g0 + w1 g1 + w2 g2 + a4 g3`)
+            float pa[4], ps[4], a4v[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const float ikk = 0.5f * (ik[i] * ik[i] - h);
+                const float ikkk = (ik[i] * ik[i] * ik[i] - 3.0f * h * ik[i]) * (1.0f / 6.0f);
+                const float a1 = ik[i], a2 = ikk * rsqh, a3 = ik0[i] * rh, a4 = ikkk * rh;
+                const float w0 = -a1 - a2 + 2.0f * a3 - 2.0f * a4;
+                const float w1 = (4.0f / 3.0f) * a1 + (4.0f / 3.0f) * a2 - (4.0f / 3.0f) * a3 + (5.0f / 3.0f) * a4;
+                const float w2 = (2.0f / 3.0f) * a1 - (1.0f / 3.0f) * a2 - (2.0f / 3.0f) * a3 - (2.0f / 3.0f) * a4;
+                pa[i] = y[i] + (f0[i] + f1[i]) * (h * (1.0f / 6.0f));
+                ps[i] = w0 * g0[i] + w1 * g1[i] + w2 * g2[i];
+                a4v[i] = a4;
+            }
+            pair_barrier();                                   // B3
+            get(XF2, f2);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) x[i] = y[i] + 0.25f * f2[i] * h + (-5.0f * g0[i] + 3.0f * g1[i] + 0.5f * g2[i]) * sqh;   // H1_3
+            if constexpr (SAVE) { if (a.stage_save) store4(a.stage_save + uoff(3 * n + 2, NP * BH, 2, BH), x); }
+            // ---- G3 at (t0 + h/4, H1_3), then the step ----
+            net(x, sq, cq, 3 * n + 2, ZSLOT + NN + 1, XS3, g3);
+            float yn[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                float v = pa[i] + f2[i] * (h * (2.0f / 3.0f));
+                v += ps[i] + a4v[i] * g3[i];
+                yn[i] = v;
+            }
+            put(XY, yn);
+            pair_barrier();                                   // B4
+            if constexpr (SAVE) {
+                if (a.stage_save) { store4(a.stage_save + uoff(3 * n + 3, NP * BH), yn); store4(a.stage_save + uoff(3 * n + 3, NP * BH, 1, BH), yn); }
+            }
+            if (a.traj) store4(a.traj + uoff(n + 1, BH), yn);
+            if (a.dW_out) store4(a.dW_out + uoff(n, BH), ik);
+            if (a.dU_out) store4(a.dU_out + uoff(n, BH), ik0);
+            if (nout > 0) {
+                auto emit = [&](int k, float w0, float w1) {
+                    float o[4];
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) o[i] = (w0 == 0.0f) ? yn[i] : w0 * y[i] + w1 * yn[i];
+                    if (!a.row_out) store4(a.ys + uoff(k + 1, BH), o);
+                    else {
+#pragma unroll
+                        for (int i = 0; i < 4; ++i)
+                            if (rslot[i] == k + 1) a.ys[lo + (uint32_t)(i * H)] = o[i];
+                    }
+                };
+                emit(kf, ow0, ow1);
+                for (int k = kf + 1; k < kfirst + nout; ++k) emit(k, out_w_c[2 * k], out_w_c[2 * k + 1]);
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i) y[i] = yn[i];
+        }
     }
 }
 

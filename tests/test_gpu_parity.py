@@ -842,7 +842,8 @@ def test_backward_sweep_generic_diffusion_nets(io, no, method):
 # cases above 5e-5 are listed with a 5e-4 bound: their fp64 gradients cancel to a small scalar (theta / sigma of 2009, 4006, 906) or the
 # scheme amplifies round-off (4009: srk with raw = t y; 907: Milstein through y^3-like closed forms on the generic kernels).
 GRAD_TOL_MAX, GRAD_TOL_MEAN = 1e-4, 1e-4
-GRAD_TOL_LOOSE = {2009: 5e-4, 4006: 5e-4, 4009: 5e-4, 906: 5e-4, 907: 5e-4}
+GRAD_TOL_LOOSE = {2009: 5e-4, 4006: 5e-4, 4009: 5e-4, 906: 5e-4, 907: 5e-4,
+                  9354: 5e-4}      # (tests/test_gpu_w4.py, srk (1,18) NL = 1: theta's gradient cancels to -0.012, measured 1.3e-4 on either kernel family)
 
 
 def _check_backward(seed, io, no, NL, B, H, C, L, ts, dt, method, kernel, strict=False):

@@ -97,3 +97,72 @@ def test_w4_training_saves_drive_the_fused_adjoint(ci):
     assert S.engine.forward_path(model, B, L, grid.N) == 'w4' and S.engine.backward_mode(model, B, L, grid, 'euler') == 1
     _check_backward(8950 + ci, io, no, NL, B, 64, C, L, ts, dt, 'euler', 'w4', strict=True)
     _check_backward(8950 + ci, io, no, NL, B, 64, C, L, ts, dt, 'euler', 'auto', strict=True)
+
+
+# ---- SRK (SRID2) on the wave pair -------------------------------------------------------------------------------------------------
+from oracle import sde_oracle as O      # noqa: E402
+
+SRK_W4 = [
+    # io, no, NL, B, C, L, ts, dt
+    (3, 18, 2, 37, 5, 9, [0, 3.5, 8], 1.0),          # the README's neuralsde_3_18 under torch_ists' default method
+    (1, 18, 2, 9, 3, 8, [0, 7], 0.5),
+    (5, 19, 2, 21, 3, 9, [0, 8], 1.0),
+    (3, 15, 1, 13, 4, 8, [0, 2.5, 7], 1.0),
+    (1, 14, 2, 16, 3, 12, None, None),
+]
+
+
+def _levy(seed, dW, ts, dt):
+    g0, g1 = O.step_grid(np.asarray(ts, np.float32), dt)[:2]
+    hh = (g1 - g0).astype(np.float32).reshape(-1, 1, 1)
+    xi = np.random.default_rng(seed).standard_normal(dW.shape).astype(np.float32)
+    return (hh * (0.5 * dW + np.sqrt(hh / 12) * xi)).astype(np.float32)
+
+
+@pytest.mark.parametrize('ci', range(len(SRK_W4)))
+def test_w4_srk_forward_vs_oracle_and_the_tile_kernels(ci):
+    io, no, NL, B, C, L, ts, dt = SRK_W4[ci]
+    H = 64
+    times = np.linspace(0, 1, L).astype(np.float32) if ts is None else None
+    pr = make_problem(9300 + ci, io, no, NL, B, H, C, L, times=times)
+    ts = pr['times'] if ts is None else np.asarray(ts, np.float32)
+    dt = dt or float(np.diff(pr['times']).min())
+    model = S.engine.model_struct(C, H, H, NL, io, no)
+    grid = S.engine.step_grid(ts, dt, pr['times'], torch.device(DEV))
+    assert S.engine.forward_path(model, B, L, grid.N, method='srk', kernel='w4') == 'w4'
+    assert S.engine.forward_path(model, B, L, grid.N, method='srk') == 'w4'
+    dW = draw_dW(9300 + ci, ts, dt, B, H)
+    dU = _levy(9300 + ci, dW, ts, dt)
+    ref64, _ = O.solve_diffusion_model(pr['params'], io, no, pr['coeffs'], pr['times'], pr['y0'], ts, dt, dW, method='srk', dtype=np.float64, dU=dU)
+    cpu32, _ = O.solve_diffusion_model(pr['params'], io, no, pr['coeffs'], pr['times'], pr['y0'], ts, dt, dW, method='srk', dtype=np.float32, dU=dU)
+    ys, _ = hip_solve(pr, ts, dt, dW=dW, dU=dU, method='srk', kernel='w4')
+    assert_parity(ys, ref64, cpu32, what=f'w4 srk case {ci}')
+    y4, _ = hip_solve(pr, ts, dt, dW=dW, dU=dU, method='srk', kernel='mfma4')
+    assert np.abs(ys - y4).max() <= 5e-5 * (np.abs(y4).max() + 1.0)
+    yp, _ = hip_solve(pr, ts, dt, seed=78, row_offset=3, method='srk', kernel='w4')
+    yg, _ = hip_solve(pr, ts, dt, seed=78, row_offset=3, method='srk', kernel='generic')
+    assert np.isfinite(yp).all() and np.abs(yp - yg).max() <= 5e-4 * (np.abs(yg).max() + 1.0)
+    half = B // 2
+    ya, _ = hip_solve(pr, ts, dt, seed=78, method='srk', kernel='w4')
+    yb0, _ = hip_solve(pr, ts, dt, seed=78, rows=slice(0, half), method='srk', kernel='w4')
+    yb1, _ = hip_solve(pr, ts, dt, seed=78, row_offset=half, rows=slice(half, B), method='srk', kernel='w4')
+    np.testing.assert_array_equal(np.concatenate([yb0, yb1], axis=1), ya)
+
+
+SRK_BWD = [
+    (3, 18, 2, 21, 5, 9, [0, 3.5, 8], 1.0),
+    (1, 14, 1, 9, 3, 8, [0, 7], 0.5),
+    (5, 19, 2, 13, 3, 9, [0, 8], 1.0),
+    (3, 15, 2, 11, 4, 8, [0, 2.5, 7], 1.0),
+    (1, 18, 1, 10, 3, 8, [0, 7], 1.0),
+]
+
+
+@pytest.mark.parametrize('ci', range(len(SRK_BWD)))
+def test_w4_srk_training_saves_drive_the_fused_srk_adjoint(ci):
+    io, no, NL, B, C, L, ts, dt = SRK_BWD[ci]
+    grid = S.engine.step_grid(np.asarray(ts, np.float32), dt, np.arange(L, dtype=np.float32), torch.device(DEV))
+    model = S.engine.model_struct(C, 64, 64, NL, io, no)
+    assert S.engine.forward_path(model, B, L, grid.N, method='srk') == 'w4' and S.engine.backward_mode(model, B, L, grid, 'srk') == 1
+    _check_backward(9350 + ci, io, no, NL, B, 64, C, L, ts, dt, 'srk', 'w4', strict=True)
+    _check_backward(9350 + ci, io, no, NL, B, 64, C, L, ts, dt, 'srk', 'auto', strict=True)
