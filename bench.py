@@ -48,11 +48,11 @@ BYTES_PER_ROWSTEP = 346             # SURVEY.md 8d algorithmic HBM bytes, Philox
 PEAK_FP32_TFLOPS = 157.3            # MI355X_MICROARCH.md: fp32 vector = fp32 MFMA peak
 PEAK_HBM_GBS = 8000.0
 # HBM bytes per launch of the solve kernel from rocprofv3 PMC passes (FETCH_SIZE doubled per the gfx950 correction
-# in MI355X_MICROARCH.md, + WRITE_SIZE; profiles/r04_pmc_counters.txt); re-measure when the kernel's memory behaviour changes.
+# in MI355X_MICROARCH.md, + WRITE_SIZE; profiles/r05_pmc_counters.txt); re-measure when the kernel's memory behaviour changes.
 HBM_TRAFFIC_BYTES_PER_LAUNCH = 38070272   # K2, lean M4 kernel: (2 x 18077.0 + 1024.0) KB
 HBM_TRAFFIC_KERNEL = ('lean', 'snsde_m4_kernel<CfgL<128, 1, 2, 1, 0, 0>>')     # the path / instantiation the profile was taken on
-HBM_TRAFFIC_SOURCE = ("profiles/r04_pmc_counters.txt: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes over this bench command, "
-                      "mean of 127 dispatches of the solve kernel), 2 x FETCH_SIZE + WRITE_SIZE per the gfx950 correction of "
+HBM_TRAFFIC_SOURCE = ("profiles/r05_pmc_counters.txt: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes over this bench command, "
+                      "mean of 187 dispatches of the solve kernel), 2 x FETCH_SIZE + WRITE_SIZE per the gfx950 correction of "
                       "MI355X_MICROARCH.md; a constant of the kernel's memory behaviour, not re-measured in this run")
 # L2-fabric bytes of one K2 training step (forward + adjoint + weight gradients): profiles/r04_train_traffic.txt
 TRAIN_TRAFFIC_FILE = 'r04_train_traffic.txt'
@@ -522,13 +522,14 @@ def main():
     barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        call.launch(stream)          # full call: weight pack + time table + fused solve
+        call.launch(stream)          # the engine's call: fused solve; the weight pack + time table launch runs when the parameter block moved
     barrier()
     elapsed = maxr(time.perf_counter() - t0)
 
     # per-solve HIP-event timings on the launch stream: the whole call, and the dominant kernel alone (prepared
     # workspace reused)
     t_call = event_times_ms(lambda: call.launch(stream), stream, max(50, args.steps), 10)
+    t_call_prep = event_times_ms(lambda: call.launch(stream, auto_reuse=False), stream, 50, 10)     # with the prepare launch every time
     t_kern = event_times_ms(lambda: call.launch(stream, reuse_prepared=True), stream, 50, 10)
     kern_ms = float(np.median(t_kern))
     ys = call.ys
@@ -573,7 +574,10 @@ def main():
                                    "coeffs 30% NaN, 100 Euler steps dt=1, ts=[0,100], in-kernel Philox dW",
                        "rows_per_gpu": B, "solver_steps": NSTEP, "global_rows": world * B,
                        "parallelism": f"row-shard x{world}, no collective in the solver", "kernel": args.kernel},
-            "timing": {"solve_call": spread(t_call), "solve_kernel": spread(t_kern),
+            "timing": {"solve_call": spread(t_call), "solve_call_with_prepare": spread(t_call_prep), "solve_kernel": spread(t_kern),
+                       "note": "solve_call: SolveCall.launch as timed in `value` - the prepared workspace (packed weights, time table) is "
+                               "reused while the parameter block's version counter stands (inference / evaluation epochs); "
+                               "solve_call_with_prepare: the same call with the prepare launch forced every time (a training step's forward)",
                        "method": "HIP events on the launch stream, one pair per solve, after 10 warm-ups (SURVEY 8d)"},
             "roofline": {"bound": "mfma", "achieved": ach_tf, "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s",
                          "frac": ach_tf / PEAK_FP32_TFLOPS, "traffic": traffic,
@@ -587,7 +591,7 @@ def main():
                          "note": "fp32 FMA/MFMA roof binds (intensity ~490 FLOP/B); frac counts the reference's algorithmic "
                                  "FLOPs, executed_frac the MFMA FLOPs the kernel issues (folded first layer); the kernel issues "
                                  "1664 MFMA cycles per SIMD and step (two waves x 104 x 8) - measured MFMA-busy share and clock: "
-                                 "profiles/r04_pmc_counters.txt (SQ_VALU_MFMA_BUSY_CYCLES / GRBM_GUI_ACTIVE); hbm_* = algorithmic 346 B/row-step"},
+                                 "profiles/r05_pmc_counters.txt (SQ_VALU_MFMA_BUSY_CYCLES / GRBM_GUI_ACTIVE); hbm_* = algorithmic 346 B/row-step"},
         }
         if extra:
             out["extra"] = extra

@@ -547,6 +547,28 @@ def test_solve_is_hip_graph_capturable_and_replayable():
     assert torch.equal(call.ys, eager)
 
 
+def test_solve_call_reuses_its_prepared_workspace_until_the_parameters_move():
+    """SolveCall.launch sets SNSDE_FLAG_REUSE_PREPARED itself from the second launch on (no weight packing / table launch) while the
+    parameter block's version counter stands; an in-place update of the block makes the next launch prepare again."""
+    pr = make_problem(43, 4, 17, 2, 64, 128, 21, 9)
+    io, no, NL, C, H = 4, 17, 2, 21, 128
+    model = S.engine.model_struct(C, H, H, NL, io, no)
+    flat = flat_params(pr['params'], io, no, NL, C, H)
+    grid = S.engine.step_grid(np.array([0, 3, 8], np.float32), 1.0, pr['times'], torch.device(DEV))
+    args = (torch.from_numpy(pr['coeffs']).to(DEV), grid, torch.from_numpy(pr['y0']).to(DEV))
+    call = S.engine.SolveCall(model, flat, *args, seed=3)
+    first = call.launch().clone()
+    assert not (call.desc.flags & S._lib.FLAG_REUSE_PREPARED)
+    second = call.launch().clone()
+    assert call.desc.flags & S._lib.FLAG_REUSE_PREPARED and torch.equal(first, second)
+    flat.mul_(1.05)                                   # an optimizer step on the block
+    third = call.launch().clone()
+    assert not (call.desc.flags & S._lib.FLAG_REUSE_PREPARED) and not torch.equal(third, first)
+    fresh = S.engine.SolveCall(model, flat, *args, seed=3).launch()
+    assert torch.equal(third, fresh)
+    assert torch.equal(call.launch(auto_reuse=False), fresh) and not (call.desc.flags & S._lib.FLAG_REUSE_PREPARED)
+
+
 # ---- the other BASELINE.json configurations as full-size parity cases (forward) --------------------------
 def test_k3_gsde_per_gpu_shard_full_size():
     """configs[2]: Neural GSDE (6,17), H=128, 200 steps, Hermite coefficients; 4096 rows over 8 GPUs = 512 per GPU."""
@@ -1376,13 +1398,17 @@ def test_srk_diffusion_nets_take_the_mfma_net_kernels(ci):
     pr = make_problem(700 + ci, io, no, NL, B, H, C, L)
     model = S.engine.model_struct(C, H, H, NL, io, no)
     grid = S.engine.step_grid(np.asarray(ts, np.float32), dt, pr['times'], torch.device(DEV))
-    assert S.engine.forward_path(model, B, L, grid.N, method='srk') == 'mfma-srk'
+    path = S.engine.forward_path(model, B, L, grid.N, method='srk')
+    assert path in ('mfma-srk', 'w4')       # (round 5: latent-only drifts at H = 64 take the wave-pair kernel, tests/test_gpu_w4.py)
     assert S.engine.backward_mode(model, B, L, grid, 'srk') == 1
     dW = draw_dW(700 + ci, ts, dt, B, H)
     dU = _draw_dU(700 + ci, dW, ts, dt)
     y_auto, _ = hip_solve(pr, ts, dt, dW=dW, dU=dU, method='srk', kernel='auto')
     y_m4, _ = hip_solve(pr, ts, dt, dW=dW, dU=dU, method='srk', kernel='mfma4')
-    assert np.array_equal(y_auto, y_m4)
+    if path == 'mfma-srk':
+        assert np.array_equal(y_auto, y_m4)
+    else:
+        assert np.abs(y_auto - y_m4).max() <= 5e-5 * (np.abs(y_m4).max() + 1.0)
 
 
 SRK_M16_ROWS = [i for i, c in enumerate(SRK_CASES) if c[4] in (64, 128) and c[5] <= 32 and c[1] not in (14, 15, 18, 19) and c[7] is not None]

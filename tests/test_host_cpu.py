@@ -79,7 +79,7 @@ def test_make_model_configurations_stay_on_the_mfma_families(pair):
                     if (io, no, method, H) in known_generic:
                         assert (path, mode) == ('generic', 2), (io, no, method, H, B, C_, path, mode)
                     else:
-                        assert path in ('lean', 'mfma4', 'mfma16', 'mfma-srk') and mode == 1, (io, no, method, H, B, C_, path, mode)
+                        assert path in ('lean', 'mfma4', 'mfma16', 'mfma-srk', 'w4') and mode == 1, (io, no, method, H, B, C_, path, mode)
 
 
 def test_stale_binding_is_refused():
@@ -827,7 +827,9 @@ def test_forward_path_query_names_the_kernel_family():
 
     assert path(128, 21, 4, 17, 1024, 'euler') == 'lean'                 # K2
     assert path(128, 21, 6, 17, 512, 'euler') == 'lean'                  # K3 shard
-    assert path(64, 69, 3, 18, 2048, 'euler') in ('mfma4', 'mfma16')     # K4: diffusion net
+    assert path(64, 69, 3, 18, 2048, 'euler') == 'w4'                    # K4: diffusion net at H = 64: a wave pair per 4 rows
+    assert path(64, 69, 3, 18, 2048, 'srk') == 'w4' and path(64, 69, 3, 18, 16384, 'euler') == 'mfma16'
+    assert path(64, 69, 3, 18, 2048, 'milstein') == 'mfma4'
     assert path(256, 14, 4, 17, 128, 'milstein') == 'lean-streamed'      # K5 shard
     assert path(256, 14, 4, 17, 16384, 'milstein') == 'mfma16'           # large batch: 16-row tiles
     assert path(128, 21, 4, 17, 1024, 'srk') == 'mfma-srk'

@@ -12,6 +12,7 @@ import stable_neural_sdes_amd as S
 from tests.helpers import make_problem
 dev = torch.device('cuda:0')
 SHAPES = [  # tag, io, no, B, H, C, L, method
+    ('K4_3_18_euler', 3, 18, 2048, 64, 69, 72, 'euler'),      # BASELINE config 4 (wave-owns-rows kernel, snsde_w4_kernel.h)
     ('K4_3_18_srk', 3, 18, 2048, 64, 69, 72, 'srk'),
     ('K4_3_18_milstein', 3, 18, 2048, 64, 69, 72, 'milstein'),
     ('naive_1_18_srk_H128', 1, 18, 1024, 128, 21, 50, 'srk'),

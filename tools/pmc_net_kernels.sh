@@ -24,7 +24,7 @@ for d in sorted(glob.glob(O + '/*/')):
     vals = collections.defaultdict(list)
     for r in csv.DictReader(open(f[0])):
         k = r['Kernel_Name']
-        if 'snsde_m4n' in k:
+        if 'snsde_m4n' in k or 'snsde_w4' in k:
             key = (k[:120], r['Grid_Size'])
             vals[(key, r['Counter_Name'])].append(float(r['Counter_Value']))
             meta[key] = (r['Workgroup_Size'], r['VGPR_Count'], r['Accum_VGPR_Count'], r['LDS_Block_Size'], r['Scratch_Size'])
@@ -52,4 +52,4 @@ print(open(os.path.join(O, tag + '_pmc_net_kernels.txt')).read())
 PY
 python $R/tools/net_steps.py time > $O/${tag}_net_host_share.txt 2>&1
 cat $O/${tag}_net_host_share.txt
-grep m4n $O/${tag}_net_kernel_stats.csv | cut -c1-200
+grep -E 'm4n|snsde_w4' $O/${tag}_net_kernel_stats.csv | cut -c1-200
