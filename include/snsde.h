@@ -260,6 +260,11 @@ SNSDE_API int    snsde_save_layout(const snsde_solve* s, int32_t* act_slots, int
                                                           /* factors of Milstein through a diffusion net                            */
 SNSDE_API int    snsde_backward_supported(const snsde_solve* s);    /* 1 / 2 / 0, see above                          */
 SNSDE_API size_t snsde_backward_workspace_bytes(const snsde_backward* b);
+/* INVARIANT between forward and backward (mode 1): `fwd.workspace` is untouched AND `fwd.params` holds the values the forward ran
+ * with.  The adjoint re-packs its transposed weights from the CURRENT params, but takes the folded first-layer product
+ * emb . linear_in (input_option 2 / 4 / 6) from the forward's workspace: an in-place parameter update between the two calls, or a
+ * second forward through the same workspace, mixes old and new weights without an error.  (torchsde.sdeint keeps both: the
+ * autograd node owns the workspace and runs before the optimizer step.)                                                        */
 SNSDE_API int    snsde_solve_backward(const snsde_backward* b, void* hip_stream);
 
 /* Parameter gradients of the fused solve (mode 1 = MFMA path only): after snsde_solve_forward (traj, dW_out, act_save

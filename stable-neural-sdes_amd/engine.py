@@ -69,15 +69,24 @@ class ParamIndex:
                 mod = mod._modules[q]
             self.owners.append((mod._parameters, parts[-1]))
         self.all_f32 = all(p.dtype == torch.float32 for p in self.params)
-        self.layout_id = id(layout)
+        self.layout_obj, self.layout_key = layout, tuple(layout)      # (name, offset, shape) triples: compared by VALUE when the object differs
+        self.n_params = sum(len(m._parameters) for m in sde.modules())
 
-    def valid(self, layout):
-        if self.layout_id != id(layout):
+    def valid(self, sde, layout):
+        if self.layout_obj is not layout and self.layout_key != tuple(layout):
             return False
         for (d, k), p in zip(self.owners, self.params):
             if d.get(k) is not p:
                 return False
-        return True
+        return self.n_params == sum(len(m._parameters) for m in sde.modules())      # (a parameter added or removed since)
+
+    # the index rides in the module's __dict__ but must not travel with copies of it: deepcopy / pickle / torch.save
+    # carry nothing, the copy is indexed afresh
+    def __deepcopy__(self, memo):
+        return None
+
+    def __reduce__(self):
+        return (type(None), ())
 
     def grads_from_flat(self, flat):
         """Per-parameter views of a flat gradient in the C ABI's layout, in named_parameters() order."""
@@ -91,7 +100,7 @@ class ParamIndex:
 
 def param_index(sde, layout):
     idx = sde.__dict__.get('_snsde_pidx') if hasattr(sde, '__dict__') else None
-    if idx is None or not idx.valid(layout):
+    if idx is None or not idx.valid(sde, layout):
         idx = ParamIndex(sde, layout)
         try:
             sde.__dict__['_snsde_pidx'] = idx
@@ -531,8 +540,19 @@ def backward_supported(call):
     return int(_lib.lib().snsde_backward_supported(C.byref(call.desc)))
 
 
-_MODE_CACHE = {}
-_SIZE_CACHE = {}      # host-side size queries of the library per configuration (SolveCall.cfg_key)
+class _BoundedCache(dict):
+    """Memo of host-side library queries per configuration; one entry per distinct (batch, knots, steps, outputs, ...) a process
+    solves - dropped wholesale past `cap` entries (ragged last batches of many lengths must not grow it without bound)."""
+    cap = 4096
+
+    def __setitem__(self, k, v):
+        if len(self) >= self.cap:
+            self.clear()
+        super().__setitem__(k, v)
+
+
+_MODE_CACHE = _BoundedCache()
+_SIZE_CACHE = _BoundedCache()      # host-side size queries of the library per configuration (SolveCall.cfg_key)
 
 
 def backward_mode(model, batch, knots, grid, method, kernel='auto', exact_order=False, table=False, kl_column=None):

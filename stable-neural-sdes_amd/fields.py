@@ -458,6 +458,45 @@ class _LatentView:
 _WIDTHS = (16, 32, 64, 128, 256)
 
 
+def _graph_leaves(out):
+    """Leaf tensors (parameters) an autograd result depends on."""
+    seen, leaves, stack = set(), [], [out.grad_fn] if out is not None and out.grad_fn is not None else []
+    while stack:
+        fn = stack.pop()
+        if fn is None or fn in seen:
+            continue
+        seen.add(fn)
+        v = getattr(fn, 'variable', None)
+        if torch.is_tensor(v):
+            leaves.append(v)
+        stack.extend(nf for nf, _ in fn.next_functions)
+    return leaves
+
+
+def prior_watch(sde, width):
+    """The tensors the prior drift h and the diffusion g of a LatentSDE-shaped module depend on: the parameters in their autograd
+    graphs (a learnable prior / diffusion) plus every buffer and plain tensor attribute (the reference's theta, mu, sigma).  The
+    in-solve KL accumulator keeps the prior's closed form as two Python floats (snsde_solve.kl_prior_a / _b), so these tensors'
+    versions belong to the identity of the cached mapping (load_state_dict / fill_ / training a learnable prior: ADVICE r4)."""
+    leaves = []
+    try:
+        p0 = next(sde.parameters())
+        with torch.enable_grad():
+            y = torch.zeros(2, width - 1, device=p0.device, dtype=p0.dtype)
+            t = torch.tensor(0.3, device=p0.device, dtype=p0.dtype)
+            outs = [fn(t, y) for fn in (getattr(sde, 'h', None), getattr(sde, 'g', None)) if callable(fn)]
+        for o in outs:
+            leaves += _graph_leaves(o)
+    except Exception:
+        leaves = list(sde.parameters())      # (cannot tell: every parameter counts)
+    plain = [v for v in sde.__dict__.values() if torch.is_tensor(v)]
+    return leaves, leaves + list(sde.buffers()) + plain
+
+
+def _versions(tensors):
+    return tuple((id(t), t.data_ptr(), t._version) for t in tensors)
+
+
 def compose_latent(sde, names, width):
     """torch-ists' LatentSDE (diff_module/NSDE/latent_sde.py:31-89) and modules of its shape, solved through
     names={'drift': 'f_aug', 'diffusion': 'g_aug'}: the state is [latent (width - 1) | KL accumulator]; the latent channels
@@ -474,13 +513,16 @@ def compose_latent(sde, names, width):
     lins = getattr(sde, 'linears', None)
     key = (width, id(getattr(sde, 'linear_in', None)), id(getattr(sde, 'linear_out', None)), id(lins),
            tuple(id(m) for m in lins) if isinstance(lins, (torch.nn.ModuleList, list, tuple)) else None,
-           fn('f'), fn('g'), fn('f_aug'), fn('g_aug'))
+           fn('f'), fn('g'), fn('f_aug'), fn('g_aug'), fn('h'))
     slot = _slot(sde)
-    if slot is not None and slot.latent is not None and slot.latent[0] == key:
+    if slot is not None and slot.latent is not None and slot.latent[0] == key and slot.latent[3] == _versions(slot.latent[2]):
         return slot.latent[1]
     result = _compose_latent(sde, width)
+    leaves, watch = prior_watch(sde, width)
+    if result is not None:
+        result.parts['prior_leaves'] = leaves      # parameters h() / g() depend on (a learnable prior or diffusion)
     if slot is not None:
-        slot.latent = (key, result)
+        slot.latent = (key, result, watch, _versions(watch))
     return result
 
 

@@ -423,7 +423,10 @@ def _sdeint_latent(sde, y0, ts, bm, method, dt, options, names):
     # paths) are drawn up front; an unseeded call of the in-solve accumulator path lets the kernels draw Philox increments
     # (no (N, B, H) tensors of normals at all) and only draws here if it has to fall back
     acc = field.parts.get('acc')
-    in_solve = acc is not None and P > Hl and os.environ.get('SNSDE_LATENT_SPLIT') != '1'
+    # (a learnable prior / diffusion - any tensor h() or g() can reach that requires grad - keeps the split solve below, whose
+    #  quadrature goes through the module's own f_aug and carries that gradient; the in-solve constants are plain floats)
+    in_solve = (acc is not None and P > Hl and os.environ.get('SNSDE_LATENT_SPLIT') != '1' and
+                not (torch.is_grad_enabled() and any(t.requires_grad for t in field.parts.get('prior_leaves', ()))))
     philox = in_solve and bm is None and options.get('seed') is None
     drawn_box = []
 

@@ -257,3 +257,63 @@ def test_learnable_diffusion_keeps_its_gradient_on_the_split_solve():
         if gr is None or float(gr.abs().max()) == 0.0:
             continue
         grad_close(p.grad, gr, name, GRAD_TOL, 'latent-sigma')
+
+
+def test_in_solve_prior_constants_follow_the_modules_buffers(monkeypatch):
+    """the in-solve accumulator keeps the prior drift as two floats read at compose time.  A buffer updated after
+    the first solve (fill_, load_state_dict) must reach the next solve: in-solve result == split solve (which evaluates the module's
+    own f_aug) before AND after the update, and the cached mapping reports the new constants."""
+    dev = torch.device('cuda')
+    B, H = 16, 32
+    torch.manual_seed(3)
+    m = LatentField(3, H, 32, 2, theta=0.9, mu=-0.1, sigma=0.5).to(dev)
+    ts = torch.tensor([0.0, 0.5, 1.0], device=dev)
+    y0 = torch.cat([0.5 * torch.randn(B, H - 1), torch.zeros(B, 1)], dim=1).to(dev)
+
+    def solve(split):
+        monkeypatch.setenv('SNSDE_LATENT_SPLIT', '1' if split else '0')
+        torch.manual_seed(7)
+        with torch.no_grad(), no_tensor_loop():
+            return S.sdeint(m, y0, ts, dt=0.05, method='euler', names=NAMES, options={'seed': 5})
+    a0, s0 = solve(False), solve(True)
+    assert float((a0 - s0).abs().max()) <= 1e-4 * max(float(s0.abs().max()), 1.0)
+    m.theta.fill_(2.5)
+    m.load_state_dict({**m.state_dict(), 'mu': torch.tensor([[0.6]], device=dev)})
+    a1, s1 = solve(False), solve(True)
+    assert float((s1 - s0)[..., -1].abs().max()) > 1e-2            # the KL rate did change
+    assert float((a1 - s1).abs().max()) <= 1e-4 * max(float(s1.abs().max()), 1.0)
+    np.testing.assert_allclose(fields.compose_latent(m, NAMES, H).parts['acc'], (-2.5, 2.5 * 0.6), rtol=1e-6)
+
+
+def test_learnable_prior_keeps_its_gradient():
+    """... and a prior whose theta / mu are nn.Parameters gets d KL / d theta, d mu (the in-solve path has no such gradient: the
+    autograd graph of h() names the parameters, and the call takes the split solve) - against float64 autograd through the loop."""
+    dev = torch.device('cuda')
+
+    class LearnablePrior(LatentField):
+        def __init__(self, *a, **k):
+            super().__init__(*a, **k)
+            for name in ('theta', 'mu'):
+                v = getattr(self, name).clone()
+                del self._buffers[name]
+                setattr(self, name, torch.nn.Parameter(v))
+    B, H = 9, 17
+    torch.manual_seed(2)
+    m = LearnablePrior(3, H, 24, 2, theta=0.7, mu=0.2, sigma=0.4)
+    m64 = LearnablePrior(3, H, 24, 2, theta=0.7, mu=0.2, sigma=0.4).double()
+    m64.load_state_dict({k: v.double() for k, v in m.state_dict().items()})
+    ts = torch.linspace(0, 1, 6)
+    grid = S.engine.StepGrid(ts.numpy(), 0.1, np.array([0.0, 1.0], dtype=np.float32), None)
+    rng = np.random.default_rng(8)
+    dW = torch.from_numpy(rng.standard_normal((grid.N, B, H)) * np.sqrt((grid.t1 - grid.t0).astype(np.float64))[:, None, None])
+    y0 = torch.cat([0.5 * torch.randn(B, H - 1), torch.zeros(B, 1)], dim=1)
+    wsum = torch.from_numpy(rng.standard_normal((len(ts), B, H)))
+    y64 = y0.double().requires_grad_(True)
+    (S.sdeint(m64, y64, ts.double(), bm=Replay(dW), dt=0.1, method='euler', names=NAMES, options={'backend': 'torch'}) * wsum).sum().backward()
+    m = m.to(dev)
+    yg = y0.to(dev).requires_grad_(True)
+    with no_tensor_loop():
+        (S.sdeint(m, yg, ts.to(dev), bm=Replay(dW.float().to(dev)), dt=0.1, method='euler', names=NAMES) * wsum.float().to(dev)).sum().backward()
+    for name in ('theta', 'mu'):
+        assert getattr(m, name).grad is not None and float(getattr(m64, name).grad.abs().max()) > 0
+        grad_close(getattr(m, name).grad, getattr(m64, name).grad, name, 1e-4, 'latent-prior')
