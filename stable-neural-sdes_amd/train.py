@@ -319,10 +319,12 @@ def make_model(name, input_channels, output_channels, hidden_channels, hidden_hi
 
 def main(name, model_name, times, train_dataloader, val_dataloader, test_dataloader, device, make_model, num_classes,
          max_epochs, lr, kwargs, step_mode, pos_weight=torch.tensor(1), results_dir=None, log=print, regularise='l2',
-         graph_steps=False):
+         graph_steps=None):
     """common_sde.main (common_sde.py:248-298): build, train, evaluate; `num_classes=None` trains a regression model with
     the mean-squared error (the forecasting benchmark).  Results are written only when `name` and `results_dir` are set.
-    graph_steps=True (one process on a GPU): the training step is replayed from a CUDA/HIP graph (GraphedStep)."""
+    graph_steps: replay the training step from a CUDA/HIP graph (GraphedStep) - the step of these models is bound by the host
+    (whole-model neurallnsde step: 1.43 ms eager, 0.88 ms replayed, 0.61 ms for its solve).  None (default) = wherever it is eligible:
+    one process, CUDA device; False = eager steps; True = required where eligible (still eager under DDP / on the CPU)."""
     device = torch.device(device)
     times = times.to(device)
     on_gpu = device.type == 'cuda'
@@ -346,7 +348,7 @@ def main(name, model_name, times, train_dataloader, val_dataloader, test_dataloa
         net = torch.nn.parallel.DistributedDataParallel(model, device_ids=[device.index] if on_gpu else None)
     # same update rule as the reference's Adam (common_sde.py:287); on the GPU the single-launch implementation instead of
     # the default multi-tensor one (~15 launches per step for these models)
-    graph_steps = bool(graph_steps) and on_gpu and dist is None
+    graph_steps = (graph_steps is None or bool(graph_steps)) and on_gpu and dist is None
     optimizer = torch.optim.Adam(net.parameters(), lr=lr, weight_decay=lr * 0.01, fused=True if on_gpu else None,
                                  capturable=graph_steps)
     history = train_loop(train_dataloader, val_dataloader, net, times, optimizer, loss_fn, max_epochs, num_classes, device,

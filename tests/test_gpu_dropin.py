@@ -326,7 +326,8 @@ def test_training_driver_on_gpu_uses_the_fused_path_and_learns(monkeypatch):
         raise AssertionError('the tensor-op loop ran on a CUDA training step')
     monkeypatch.setattr(S.torchsde, '_sdeint_torch', no_loop)
     factory = T.make_model('neurallnsde', C, 1, H, H, 2, initial=True)
-    res = T.main(None, 'neurallnsde', times, train, val, test, dev, factory, 2, 6, 1e-2, dict(method='euler'), 'valloss', log=None)
+    res = T.main(None, 'neurallnsde', times, train, val, test, dev, factory, 2, 6, 1e-2, dict(method='euler'), 'valloss', log=None,
+                 graph_steps=False)      # (eager steps; the default replays them from a graph: next test)
     losses = [h.train_metrics.loss for h in res.history]
     assert len(losses) == 6 and losses[-1] < losses[0], losses
     assert res.train_metrics.dataset_size == 256 and res.val_metrics.confusion.sum() == 128
@@ -357,7 +358,7 @@ def test_training_driver_with_graph_replayed_steps(monkeypatch):
     monkeypatch.setattr(T, 'GraphedStep', Spy)
     factory = T.make_model('neurallnsde', C, 1, H, H, 2, initial=True)
     res = T.main(None, 'neurallnsde', times, train, val, test, dev, factory, 2, 8, 1e-2, dict(method='euler'), 'valloss', log=None,
-                 graph_steps=True)
+                 )                     # graph_steps=None: replayed wherever eligible (one process, CUDA)
     losses = [h.train_metrics.loss for h in res.history]
     assert len(losses) == 8 and losses[-1] < losses[0], losses
     assert res.test_metrics.auroc > 0.7, res.test_metrics
