@@ -70,6 +70,8 @@ bool snsde_mfma_backward_partials(const snsde_solve* s, const SnsdeNet& net, int
 // launchers (snsde_w4.hip): wave-owns-rows forward kernels (H = 64, diffusion nets, Euler)
 bool snsde_w4_supported(const snsde_solve* s, const SnsdeNet& net);
 int snsde_w4_launch(const snsde_solve* s, const SnsdeNet& net, hipStream_t stream);
+bool snsde_w4_rev_supported(const snsde_solve* s, const SnsdeNet& net);       // adjoint of the Euler solve on the same wave pairs
+int snsde_w4_rev_launch(const snsde_backward* b, const SnsdeNet& net, float* dth_part, hipStream_t stream);
 // launchers (snsde_wgrad.hip)
 size_t snsde_wgrad_workspace_floats(const snsde_backward* b, const SnsdeNet& net);
 int snsde_wgrad_launch(const snsde_backward* b, const SnsdeNet& net, float* grad_params, int32_t n_params, float* ws,

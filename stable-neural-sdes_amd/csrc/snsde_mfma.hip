@@ -258,8 +258,17 @@ static bool variant_of(const snsde_solve* s) {
 }
 
 // Which configurations the fast path is instantiated for.
+// Wave-owns-rows forward (snsde_w4.hip): forced by hint 2; under `auto` up to 6144 rows
+static bool w4_takes(const snsde_solve* s, const SnsdeNet& net, int flavor_hint) {
+    // measured at the K4 shape (tools/time_w4.py, profiles/r05_time_w4.txt): 2048 rows 109 us against 156 (4-row tiles) / 216 (16-row
+    // tiles), 6144 rows 275 against 316 (16-row tiles); from 8192 rows the 16-row tiles win (a third wave per SIMD does not fit)
+    // SRK through a net has no 16-row flavour: the wave pair at every batch size (2048 rows 352 us against 456, 4096 rows 540 / 900)
+    return (flavor_hint == 2 || (flavor_hint == -1 && (s->batch <= 6144 || s->method == SNSDE_SRK))) && snsde_w4_supported(s, net);
+}
+
 MfmaPlan make_plan(const snsde_solve* s, const SnsdeNet& net, int flavor_hint) {
     MfmaPlan p{};
+    const int hint_in = flavor_hint;
     if (flavor_hint == 2) flavor_hint = 1;      // (the wave-owns-rows forward, snsde_w4.hip: every plan-side decision as for 4-row tiles)
     const snsde_model& m = s->model;
     const int H = m.hidden_channels, io = m.input_option, no = m.noise_option;
@@ -321,6 +330,8 @@ MfmaPlan make_plan(const snsde_solve* s, const SnsdeNet& net, int flavor_hint) {
     }
     p.SRK = srk ? 1 : 0;
     if ((srk && !srk_m16_ok) || m4n) p.FL = 1;
+    // the wave-pair kernels (snsde_w4.hip) take the forward AND the Euler adjoint: their per-tile partial sums are per 4 rows
+    if (hint_in < 0 && w4_takes(s, net, -1)) p.FL = 1;
     p.M4N = m4n ? 1 : 0; p.KUXN = kuxn;
     p.FOLD = (emb && (nhid > 1 || p.KUX > 2 || srk || noise_net || !(s->flags & SNSDE_FLAG_EXACT_ORDER))) ? 1 : 0;   // exact order: NL <= 2, C <= 32 only
     // lean M4 kernel (snsde_m4_kernel.h): 4-row tiles, Euler / Milstein, elementwise diffusions, 32 <= H <= 128; the time
@@ -531,12 +542,10 @@ RevPlan make_rev_plan(const snsde_solve* s, const SnsdeNet& net, const MfmaPlan&
 
 bool snsde_mfma_supported(const snsde_solve* s, const SnsdeNet& net) { return make_plan(s, net, -1).ok; }
 
-// Wave-owns-rows forward (snsde_w4.hip): forced by hint 2; under `auto` up to 6144 rows
-static bool w4_takes(const snsde_solve* s, const SnsdeNet& net, int flavor_hint) {
-    // measured at the K4 shape (tools/time_w4.py, profiles/r05_time_w4.txt): 2048 rows 109 us against 156 (4-row tiles) / 216 (16-row
-    // tiles), 6144 rows 275 against 316 (16-row tiles); from 8192 rows the 16-row tiles win (a third wave per SIMD does not fit)
-    // SRK through a net has no 16-row flavour: the wave pair at every batch size (2048 rows 352 us against 456, 4096 rows 540 / 900)
-    return (flavor_hint == 2 || (flavor_hint == -1 && (s->batch <= 6144 || s->method == SNSDE_SRK))) && snsde_w4_supported(s, net);
+// adjoint on the wave pairs: Euler, 4-row-tile plan, every a_n or dL/dy0 only
+static bool w4_rev_takes(const snsde_solve* s, const SnsdeNet& net, const MfmaPlan& fp, const RevPlan& p, int hint) {
+    return hint != 0 && hint != 1 && p.ok && p.FL == 1 && !p.M4N && !p.SRK && fp.NN > 0 && s->kl_column1 == 0 &&
+           (hint == 2 || s->batch <= 6144) && snsde_w4_rev_supported(s, net);
 }
 
 // which MFMA kernel family a forward launch of this descriptor takes (SNSDE_PATH_*; 0: none)
@@ -690,7 +699,7 @@ bool snsde_mfma_backward_supported(const snsde_solve* s, const SnsdeNet& net) {
 
 static int flavor_hint_of(const snsde_solve* s) {
     if (variant_of(s)) return 1;      // tutorial-style fields: 4-row tiles only (snsde_solve_forward launches them that way)
-    return s->kernel == SNSDE_KERNEL_MFMA_M16 ? 0 : (s->kernel == SNSDE_KERNEL_MFMA_M4 ? 1 : -1);
+    return s->kernel == SNSDE_KERNEL_MFMA_M16 ? 0 : (s->kernel == SNSDE_KERNEL_MFMA_M4 ? 1 : (s->kernel == SNSDE_KERNEL_MFMA_W4 ? 2 : -1));
 }
 
 bool snsde_mfma_backward_partials(const snsde_solve* s, const SnsdeNet& net, int* nwg, int* waves, size_t* ds_off,
@@ -714,6 +723,12 @@ int snsde_mfma_backward_launch(const snsde_backward* b, const SnsdeNet& net, hip
     if (!p.ok) return SNSDE_ERR_UNSUPPORTED;
     if ((uint64_t)16 * (uint64_t)s->batch * (uint64_t)s->model.hidden_channels >= (1ull << 32)) return SNSDE_ERR_UNSUPPORTED;   // (uoff)
     float* ws = static_cast<float*>(b->workspace);
+    if (w4_rev_takes(s, net, fp, p, hint)) {
+        // the wave-pair adjoint reads the nn.Linear layout of `params` itself (columns of the weights): no fold, no pack launch
+        if (b->flags & SNSDE_BWD_ADJ0_ONLY) { /* (every a_n or dL/dy0 only: both forms) */ }
+        if (!(s->dW_out ? s->dW_out : s->dW) && s->seed_dev) return SNSDE_ERR_NULL;
+        return snsde_w4_rev_launch(b, net, p.dth_off ? ws + p.dth_off : nullptr, stream);
+    }
     // first_y = emb[:, 0:H] . linear_in (all columns; the pack step picks the y columns).  A forward that ran with the folded first
     // layer left exactly this product in ITS workspace (piece `in` of snsde_prepare_kernel, same (H, K_in) layout): the pack
     // reads it there and the backward needs no fold launch of its own (6.4 us + a launch gap per K2 training step)

@@ -59,3 +59,35 @@ int snsde_w4_launch(const snsde_solve* s, const SnsdeNet& net, hipStream_t strea
 #undef W4_CASE
     return SNSDE_ERR_UNSUPPORTED;
 }
+
+// ---- adjoint of the Euler solve (snsde_w4_euler_reverse_kernel) --------------------------------------------------------------
+bool snsde_w4_rev_supported(const snsde_solve* s, const SnsdeNet& net) {
+    return s->method == SNSDE_EULER && snsde_w4::shape_ok(s, net) && !s->seed_dev;
+}
+
+int snsde_w4_rev_launch(const snsde_backward* b, const SnsdeNet& net, float* dth_part, hipStream_t stream) {
+    using namespace snsde_w4;
+    const snsde_solve* s = &b->fwd;
+    if (!snsde_w4_rev_supported(s, net)) return SNSDE_ERR_UNSUPPORTED;
+    if (!s->traj || !s->act_save || !b->grad_ys || !b->adj) return SNSDE_ERR_NULL;
+    const snsde_model& m = s->model;
+    W4RevArgs a{};
+    a.params = s->params; a.step_tab = s->step_tab; a.out_w = s->out_w; a.traj = s->traj; a.act = s->act_save;
+    a.dW = s->dW_out ? s->dW_out : s->dW;
+    a.grad_ys = b->grad_ys; a.adj = b->adj; a.delta = b->delta_save; a.dth_part = dth_part; a.row_out = s->row_out;
+    a.seed = s->seed; a.row_offset = s->row_offset;
+    a.B = s->batch; a.N = s->n_steps; a.T = s->n_out; a.no = m.noise_option; a.geo = m.input_option == 5 ? 1 : 0;
+    a.nsave = snsde_act_slots(&m); a.nslots = a.nsave;
+    a.adj0_only = (b->flags & SNSDE_BWD_ADJ0_ONLY) ? 1 : 0; a.off_theta = net.off_theta;
+    a.w_in = net.in.src_w; a.k_in = net.in.K; a.t_in = net.in.tshift;
+    const int nhid = m.num_hidden_layers - 1;
+    for (int l = 0; l < nhid; ++l) a.w_hid[l] = net.hid[l].src_w;
+    a.w_out = net.out.src_w; a.w_n0 = net.ny0.src_w; a.w_n1 = net.ny1.src_w;
+    const int nn = (m.noise_option >= 18) ? 2 : 1;
+    const dim3 grid((a.B + 7) / 8), block(256);
+#define W4R_CASE(NH, N2) if (nhid == NH && nn == N2) { hipLaunchKernelGGL((snsde_w4_euler_reverse_kernel<CfgW<NH, N2, false, false>>), grid, block, 0, stream, a); \
+                                                       return hipGetLastError() == hipSuccess ? SNSDE_OK : SNSDE_ERR_LAUNCH; }
+    W4R_CASE(0, 1) W4R_CASE(0, 2) W4R_CASE(1, 1) W4R_CASE(1, 2)
+#undef W4R_CASE
+    return SNSDE_ERR_UNSUPPORTED;
+}

@@ -786,4 +786,277 @@ __global__ void __launch_bounds__(256, 2) snsde_w4_srk_kernel(W4Args a) {
     }
 }
 
+// =====================================================================================================================================
+// Adjoint of the Euler solve on the same wave pair (discretise-then-optimise, the contract of snsde_mfma_reverse_kernel: every a_n or
+// dL/dy0 only, delta_save slots  dz | hidden deltas.. | first-layer delta | dq | net hidden delta  for the weight-gradient GEMMs, the
+// per-tile partial sums of dL/d sigmoid(theta)).  Walking a step backwards is two independent transposed chains on the step's
+// cotangent a_{n+1}:  drift  a h (1 - f^2){tanh y} -> W_out^T -> [h > 0] -> W_hid^T -> [z0 > 0] -> W_in,y^T   (drift wave: it owns
+// the adjoint, adds the output gradients and publishes a), net  a dW (1 - g^2) sigma(theta){y}[q > 0] -> W2^T -> [hn > 0] -> W1,y^T
+// (net wave, with the direct term of raw = q y); two exchanges per step.  A lane holds COLUMN k of a weight matrix (64 coalesced loads
+// from `params`): out[i][k] = sum_l delta[i][l] W[l][k] is the same rank-1 MFMA with the reduction over the forward's output features.
+// The relu masks of the drift chain are bits of the saved z (snsde_pack_signs), the net's hidden mask its saved activation.
+// =====================================================================================================================================
+struct W4RevArgs {
+    const float* params;
+    const float* step_tab;
+    const float* out_w;
+    const float* traj;
+    const float* act;
+    const float* dW;          // increments used by the forward, or null: regenerated from Philox (seed, row_offset)
+    const float* grad_ys;
+    float* adj;
+    float* delta;
+    float* dth_part;          // (tiles, 4): this kernel leaves the tile's sum in entry 0 and zeros in 1 .. 3
+    const int32_t* row_out;
+    uint64_t seed;
+    int64_t row_offset;
+    int32_t B, N, T, no, geo, nsave, nslots, adj0_only, off_theta;
+    int32_t w_in, k_in, t_in, w_hid[3], w_out, w_n0, w_n1;
+};
+
+template <class CF>
+__global__ void __launch_bounds__(256, 2) snsde_w4_euler_reverse_kernel(W4RevArgs a) {
+    constexpr int H = 64, NHID = CF::NHID, NN = CF::NN;
+    constexpr int ZSLOT = NHID + 1, NB0 = NHID + 2;
+    using Seq = std::make_integer_sequence<int, 16>;
+    enum { XA = 0, XN, XCNT };
+    __shared__ float xchg_all[2][XCNT][4][H];
+    __shared__ float zblk_all[2][4][4][H];      // regenerated Philox normals of the block of four steps being walked [pair][row][step][feature]
+
+    const int lane = threadIdx.x & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int wave = wv & 1, pair = wv >> 1;
+    float (*xchg)[4][H] = xchg_all[pair];
+    float (*zblk)[4][H] = zblk_all[pair];
+    const int B = a.B;
+    const int tile = blockIdx.x * 2 + pair;
+    const int row_t = tile * 4;
+    const int row0 = row_t + 4 <= B ? row_t : B - 4;       // ragged tail: moved back onto the last four rows (see the forward) ...
+    const bool live = row_t < B;                           // (the idle second pair of an odd tile count repeats the last tile)
+    float rowf[4];                                         // ... whose repeated rows must not enter the theta sum twice
+#pragma unroll
+    for (int i = 0; i < 4; ++i) rowf[i] = (live && row0 + i >= row_t) ? 1.0f : 0.0f;
+    const uint32_t BH = (uint32_t)B * H;
+    const uint32_t SBH = (uint32_t)a.nsave * BH, DBH = (uint32_t)a.nslots * BH;
+    const float* P = a.params;
+    typedef const float __attribute__((address_space(4)))* CP;
+    const CP step_tab_c = (CP)(uintptr_t)a.step_tab, out_w_c = (CP)(uintptr_t)a.out_w;
+    const uint32_t lo = (uint32_t)(row0 * H + lane);
+    auto load4 = [&](const float* p, float (&v)[4]) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) v[i] = p[lo + (uint32_t)(i * H)];
+    };
+    auto store4 = [&](float* p, const float (&v)[4]) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) p[lo + (uint32_t)(i * H)] = v[i];
+    };
+    auto put = [&](int plane, const float (&v)[4]) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) xchg[plane][i][lane] = v[i];
+    };
+    auto get = [&](int plane, float (&v)[4]) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) v[i] = xchg[plane][i][lane];
+    };
+    // column `lane` of a (64, K) nn.Linear weight, columns c0 .. c0 + 63: w[l] = W[l][c0 + lane]
+    auto load_col = [&](float (&w)[H], int off, int K, int c0) {
+        const float* q = P + off + c0 + lane;
+#pragma unroll
+        for (int l = 0; l < H; ++l) w[l] = q[(size_t)l * K];
+    };
+    const int N = a.N;
+
+    if (wave == 0) {
+        // ================================ drift wave: owns the adjoint ================================
+        float wo[H], wh[NHID > 0 ? NHID : 1][H], wi[H];
+        load_col(wo, a.w_out, H, 0);
+#pragma unroll
+        for (int l = 0; l < NHID; ++l) load_col(wh[l], a.w_hid[l], H, 0);
+        load_col(wi, a.w_in, a.k_in, a.t_in);
+        const bool geo = a.geo != 0;
+        int rslot[4];
+        float gfin[4], adj[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { rslot[i] = a.row_out ? a.row_out[row0 + i] : -1; gfin[i] = a.row_out ? a.grad_ys[lo + (uint32_t)(i * H)] : 0.0f; }
+        float y[4], z[4], yn[4], zn[4];
+        load4(a.traj + uoff(N - 1, BH), y);
+        load4(a.act + uoff(N - 1, SBH, ZSLOT, BH), z);
+        for (int n = N - 1; n >= 0; --n) {
+            if (n > 0) {                 // next step's inputs: a full step ahead of their use
+                load4(a.traj + uoff(n - 1, BH), yn);
+                load4(a.act + uoff(n - 1, SBH, ZSLOT, BH), zn);
+            }
+            CP st = step_tab_c + (size_t)n * SNSDE_STEP_STRIDE;
+            const float h = st[1];
+            const int nout = __float_as_int(st[8]), kfirst = __float_as_int(st[9]);
+            float carry[4] = {0.f, 0.f, 0.f, 0.f};
+            for (int k = kfirst; k < kfirst + nout; ++k) {      // outputs emitted after step n: ys[k + 1] = y_{n+1} or w0 y_n + w1 y_{n+1}
+                const float w0 = out_w_c[2 * k], w1 = out_w_c[2 * k + 1];
+                float gk[4];
+                if (a.row_out) {
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) gk[i] = rslot[i] == k + 1 ? gfin[i] : 0.0f;
+                } else load4(a.grad_ys + uoff(k + 1, BH), gk);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    if (w0 == 0.0f) adj[i] += gk[i];
+                    else { adj[i] = fmaf(w1, gk[i], adj[i]); carry[i] = fmaf(w0, gk[i], carry[i]); }
+                }
+            }
+            put(XA, adj);
+            pair_barrier();                                     // B1: the net wave takes a_{n+1}
+            if (!a.adj0_only) store4(a.adj + uoff(n + 1, BH), adj);
+            // dz = a h (1 - f^2) {tanh y};  direct y term of the gated drift
+            float dz[4], ay[4], zc[4], f[4], ty[4] = {1.f, 1.f, 1.f, 1.f};
+            uint32_t zb[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                zb[i] = __float_as_uint(z[i]);
+                zc[i] = __uint_as_float(zb[i] & ~((1u << (NHID + 1)) - 1u));
+                f[i] = zc[i];
+            }
+            if (geo) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) ty[i] = y[i];
+                fast_tanh4(ty);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) f[i] = zc[i] * ty[i];
+            }
+            fast_tanh4(f);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const float dzt = adj[i] * h * (1.0f - f[i] * f[i]);
+                dz[i] = dzt * ty[i];
+                ay[i] = geo ? fmaf(dzt * zc[i], 1.0f - ty[i] * ty[i], adj[i]) : adj[i];
+            }
+            if (a.delta) store4(a.delta + uoff(n, DBH), dz);
+            float v[4], vt[4];
+            quad_transpose(dz, vt);
+            {   // W_out^T, masked by the last hidden layer's relu sign (act slot NHID)
+                f32x4 c = {0.f, 0.f, 0.f, 0.f}, d = c;
+                gemm64(vt, wo, c, d, Seq{});
+#pragma unroll
+                for (int i = 0; i < 4; ++i) v[i] = ((zb[i] >> NHID) & 1u) ? c[i] + d[i] : 0.0f;
+                if (a.delta) store4(a.delta + uoff(n, DBH, 1, BH), v);
+                quad_transpose(v, vt);
+            }
+#pragma unroll
+            for (int l = NHID - 1; l >= 0; --l) {   // W_hid[l]^T, masked by the sign of act slot l
+                f32x4 c = {0.f, 0.f, 0.f, 0.f}, d = c;
+                gemm64(vt, wh[l], c, d, Seq{});
+#pragma unroll
+                for (int i = 0; i < 4; ++i) v[i] = ((zb[i] >> l) & 1u) ? c[i] + d[i] : 0.0f;
+                if (a.delta) store4(a.delta + uoff(n, DBH, (uint32_t)(NHID - l + 1), BH), v);
+                quad_transpose(v, vt);
+            }
+            float od[4];
+            {   // W_in[:, y columns]^T
+                f32x4 c = {0.f, 0.f, 0.f, 0.f}, d = c;
+                gemm64(vt, wi, c, d, Seq{});
+#pragma unroll
+                for (int i = 0; i < 4; ++i) od[i] = c[i] + d[i];
+            }
+            pair_barrier();                                     // B2: the net chain's share of a_n
+            float on[4];
+            get(XN, on);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) adj[i] = (ay[i] + od[i] + carry[i]) + on[i];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) { y[i] = yn[i]; z[i] = zn[i]; }
+        }
+        {   // ys[0] = y0
+            float g0[4];
+            if (a.row_out) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) g0[i] = rslot[i] == 0 ? gfin[i] : 0.0f;
+            } else load4(a.grad_ys, g0);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) adj[i] += g0[i];
+            store4(a.adj, adj);
+        }
+        if (a.dth_part && live && lane < 3) a.dth_part[(size_t)tile * 4 + 1 + lane] = 0.0f;
+    } else {
+        // ================================ diffusion-net wave ================================
+        float w1t[NN > 1 ? H : 1], w0t[H];
+        if constexpr (NN > 1) load_col(w1t, a.w_n1, H, 0);
+        load_col(w0t, a.w_n0, 66, 2);
+        const float sig_theta = snsde_sigmoid(P[a.off_theta]);
+        const bool mul_y = a.no == 15 || a.no == 19;
+        const bool phx = a.dW == nullptr;
+        float th_acc = 0.0f;
+        int zblk_id = -1;
+        float y[4], q[4], hm[4], dw[4], yn[4], qn[4], hmn[4], dwn[4];
+        auto fetch = [&](int n, float (&yy)[4], float (&qq)[4], float (&hh)[4], float (&ww)[4]) {
+            load4(a.traj + uoff(n, BH), yy);
+            load4(a.act + uoff(n, SBH, ZSLOT + NN, BH), qq);
+            if constexpr (NN == 2) load4(a.act + uoff(n, SBH, ZSLOT + 1, BH), hh);
+            if (!phx) load4(a.dW + uoff(n, BH), ww);
+            else {
+                if ((n >> 2) != zblk_id) {
+                    zblk_id = n >> 2;
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {      // (wave-private LDS: a register array indexed by n & 3 lands in scratch)
+                        float zz[4];
+                        snsde_philox_normal4(a.seed, (uint32_t)(a.row_offset + row0 + i), (uint32_t)zblk_id, (uint32_t)lane, zz);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) zblk[i][e][lane] = zz[e];
+                    }
+                }
+                const float sqh = (step_tab_c + (size_t)n * SNSDE_STEP_STRIDE)[6];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) ww[i] = zblk[i][n & 3][lane] * sqh;
+            }
+        };
+        fetch(N - 1, y, q, hm, dw);
+        for (int n = N - 1; n >= 0; --n) {
+            if (n > 0) fetch(n - 1, yn, qn, hmn, dwn);
+            // g and its factors do not need the adjoint: before the barrier
+            float g[4], raw[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) { raw[i] = q[i] * (mul_y ? y[i] : 1.0f); g[i] = sig_theta * snsde_nan_to_num(raw[i]); }
+            fast_tanh4(g);
+            pair_barrier();                                     // B1
+            float av[4], dq[4], dir[4], vt[4], v[4];
+            get(XA, av);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const float om = 1.0f - g[i] * g[i];
+                const bool fin = snsde_finite(raw[i]);
+                const float dr = fin ? av[i] * dw[i] * om * sig_theta : 0.0f;
+                float d = mul_y ? dr * y[i] : dr;
+                if constexpr (NN == 2) d = q[i] > 0.0f ? d : 0.0f;
+                dq[i] = d;
+                dir[i] = (mul_y && fin) ? av[i] * om * (sig_theta * q[i]) * dw[i] : 0.0f;      // d(q y)/dy = q: the direct term
+                th_acc = fmaf(av[i] * dw[i] * om * rowf[i], snsde_nan_to_num(raw[i]), th_acc);
+            }
+            if (a.delta) store4(a.delta + uoff(n, DBH, NB0, BH), dq);
+            quad_transpose(dq, vt);
+            if constexpr (NN == 2) {
+                f32x4 c = {0.f, 0.f, 0.f, 0.f}, d = c;
+                gemm64(vt, w1t, c, d, Seq{});
+#pragma unroll
+                for (int i = 0; i < 4; ++i) v[i] = hm[i] > 0.0f ? c[i] + d[i] : 0.0f;
+                if (a.delta) store4(a.delta + uoff(n, DBH, NB0 + 1, BH), v);
+                quad_transpose(v, vt);
+            }
+            float on[4];
+            {
+                f32x4 c = {0.f, 0.f, 0.f, 0.f}, d = c;
+                gemm64(vt, w0t, c, d, Seq{});
+#pragma unroll
+                for (int i = 0; i < 4; ++i) on[i] = (c[i] + d[i]) + dir[i];
+            }
+            put(XN, on);
+            pair_barrier();                                     // B2
+#pragma unroll
+            for (int i = 0; i < 4; ++i) { y[i] = yn[i]; q[i] = qn[i]; hm[i] = hmn[i]; dw[i] = dwn[i]; }
+        }
+        if (a.dth_part) {
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) th_acc += __shfl_down(th_acc, off, 64);
+            if (lane == 0 && live) a.dth_part[(size_t)tile * 4] = th_acc;
+        }
+    }
+}
+
 }  // namespace snsde_w4

@@ -89,14 +89,16 @@ BWD = [
 
 @pytest.mark.parametrize('ci', range(len(BWD)))
 def test_w4_training_saves_drive_the_fused_adjoint(ci):
-    """Forward on the wave-owns-rows kernel in training mode (act_save slots, relu signs in the saved z, increments), backward on the
-    unchanged MFMA adjoint + weight-gradient pass: gradients against fp64 autograd through the tensor loop."""
+    """Forward on the wave-owns-rows kernel in training mode (act_save slots, relu signs in the saved z, increments); backward: under
+    'auto' / 'w4' the wave-pair adjoint (snsde_w4_euler_reverse_kernel), under 'mfma4' the tile adjoint on the SAME saves - both with the
+    unchanged weight-gradient pass, against fp64 autograd through the tensor loop."""
     io, no, NL, B, C, L, ts, dt = BWD[ci]
     grid = S.engine.step_grid(np.asarray(ts, np.float32), dt, np.arange(L, dtype=np.float32), torch.device(DEV))
     model = S.engine.model_struct(C, 64, 64, NL, io, no)
     assert S.engine.forward_path(model, B, L, grid.N) == 'w4' and S.engine.backward_mode(model, B, L, grid, 'euler') == 1
     _check_backward(8950 + ci, io, no, NL, B, 64, C, L, ts, dt, 'euler', 'w4', strict=True)
     _check_backward(8950 + ci, io, no, NL, B, 64, C, L, ts, dt, 'euler', 'auto', strict=True)
+    _check_backward(8950 + ci, io, no, NL, B, 64, C, L, ts, dt, 'euler', 'mfma4', strict=True)
 
 
 # ---- SRK (SRID2) on the wave pair -------------------------------------------------------------------------------------------------
