@@ -168,3 +168,35 @@ def test_w4_srk_training_saves_drive_the_fused_srk_adjoint(ci):
     assert S.engine.forward_path(model, B, L, grid.N, method='srk') == 'w4' and S.engine.backward_mode(model, B, L, grid, 'srk') == 1
     _check_backward(9350 + ci, io, no, NL, B, 64, C, L, ts, dt, 'srk', 'w4', strict=True)
     _check_backward(9350 + ci, io, no, NL, B, 64, C, L, ts, dt, 'srk', 'auto', strict=True)
+
+
+@pytest.mark.parametrize('row_out', [False, True])
+def test_w4_adjoint_with_in_kernel_philox_and_row_outputs_equals_the_tile_adjoint(row_out):
+    """Training through sdeint with in-kernel Philox increments (the adjoint regenerates them or reads the forward's dW_out) and,
+    optionally, per-row output selection: the wave-pair path ('auto') against the 4-row-tile path ('mfma4') on the same key - same
+    Philox stream, so states and every gradient agree to round-off."""
+    io, no, NL, B, C, L, H = 3, 18, 2, 37, 5, 9, 64
+    pr = make_problem(9500, io, no, NL, B, H, C, L)
+    ts = torch.from_numpy(pr['times'][[0, 2, 5, 8]]).to(DEV)
+    ro = torch.from_numpy(np.random.default_rng(2).integers(0, 4, size=B).astype(np.int32)).to(DEV) if row_out else None
+    out = {}
+    for kernel in ('auto', 'mfma4'):
+        m = S.Diffusion_model(C, H, H, NL, input_option=io, noise_option=no)
+        m.load_state_dict({k: torch.from_numpy(v.copy()) for k, v in pr['params'].items()})
+        m = m.to(DEV)
+        m.set_X(torch.from_numpy(pr['coeffs']).to(DEV), torch.from_numpy(pr['times']).to(DEV))
+        y0 = torch.from_numpy(pr['y0']).to(DEV).requires_grad_(True)
+        opts = {'seed': 99, 'kernel': kernel, 'strict': True}
+        if ro is not None:
+            opts['row_out'] = ro
+        ys = S.sdeint(m, y0, ts, dt=0.5, method='euler', options=opts)
+        w = torch.from_numpy(np.random.default_rng(3).standard_normal(tuple(ys.shape)).astype(np.float32)).to(DEV)
+        (ys * w).sum().backward()
+        out[kernel] = (ys.detach(), y0.grad.clone(), {n: p.grad.clone() for n, p in m.named_parameters() if p.grad is not None})
+    ya, ga, pa = out['auto']
+    yb, gb, pb = out['mfma4']
+    assert float((ya - yb).abs().max()) <= 2e-5 * (float(yb.abs().max()) + 1.0)
+    assert float((ga - gb).abs().max()) <= 2e-5 * float(gb.abs().max())
+    assert pa.keys() == pb.keys()
+    for k in pb:
+        assert float((pa[k] - pb[k]).abs().max()) <= 5e-5 * (float(pb[k].abs().max()) + 1e-12), k
