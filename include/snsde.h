@@ -257,7 +257,10 @@ SNSDE_API int    snsde_save_layout(const snsde_solve* s, int32_t* act_slots, int
                                                           /* slots (the step's fourth diffusion evaluation) and three stage planes */
                                                           /* (drift input H0 | diffusion input H1 | H1 of the fourth evaluation);  */
                                                           /* delta_save is (passes, delta_slots, B, H): act_slots, plus the tangent */
-                                                          /* factors of Milstein through a diffusion net                            */
+                                                          /* factors of Milstein through a diffusion net; delta_slots == 0: the      */
+                                                          /* adjoint of this solve accumulates the weight gradients itself (Euler,   */
+                                                          /* H = 64 with a diffusion net: per-tile sums in the backward workspace),  */
+                                                          /* delta_save is not written and may be NULL                               */
 SNSDE_API int    snsde_backward_supported(const snsde_solve* s);    /* 1 / 2 / 0, see above                          */
 SNSDE_API size_t snsde_backward_workspace_bytes(const snsde_backward* b);
 /* INVARIANT between forward and backward (mode 1): `fwd.workspace` is untouched AND `fwd.params` holds the values the forward ran

@@ -457,7 +457,14 @@ int snsde_save_layout(const snsde_solve* s, int32_t* act_slots, int32_t* stage_p
     if (act_slots) *act_slots = slots;
     if (stage_planes) *stage_planes = planes;
     // Milstein through a diffusion net: the adjoint also leaves the tangent pass's factors (second-order parameter terms)
-    if (delta_slots) *delta_slots = slots + ((s->method == SNSDE_MILSTEIN && nn > 0) ? (nn == 2 ? 3 : 1) : 0);
+    if (delta_slots) {
+        *delta_slots = slots + ((s->method == SNSDE_MILSTEIN && nn > 0) ? (nn == 2 ? 3 : 1) : 0);
+        // 0: the adjoint of this solve accumulates the weight gradients itself (wave-pair adjoint, snsde_w4_kernel.h): no delta planes
+        SnsdeNet net;
+        if (nn > 0 && s->batch > 0 && s->n_steps > 0 && snsde_build_net(s->model, s->n_steps, &net) == SNSDE_OK &&
+            snsde_backward_supported(s) == 1 && snsde_mfma_w4_fused_solve(s, net, nullptr, nullptr))
+            *delta_slots = 0;
+    }
     return SNSDE_OK;
 }
 
@@ -522,12 +529,13 @@ int snsde_param_gradients(const snsde_backward* b, float* grad_params, void* wor
     if (b->struct_size != sizeof(snsde_backward)) return SNSDE_ERR_ABI;
     int rc = validate_solve(&b->fwd, false);
     if (rc) return rc;
-    if (!b->adj || !b->delta_save || !b->fwd.traj || !b->fwd.act_save || !b->fwd.workspace)
+    if (!b->adj || !b->fwd.traj || !b->fwd.act_save || !b->fwd.workspace)
         return SNSDE_ERR_NULL;
     SnsdeNet net;
     rc = snsde_build_net(b->fwd.model, b->fwd.n_steps, &net);
     if (rc) return rc;
     if (snsde_backward_supported(&b->fwd) != 1) return SNSDE_ERR_UNSUPPORTED;
+    if (!b->delta_save && !snsde_mfma_w4_fused(b, net, nullptr, nullptr)) return SNSDE_ERR_NULL;      // (delta_slots == 0: no planes)
     if (workspace_bytes < snsde_param_gradients_workspace_bytes(b)) return SNSDE_ERR_WORKSPACE;
     return snsde_wgrad_launch(b, net, grad_params, (int32_t)snsde_param_numel(&b->fwd.model), static_cast<float*>(workspace),
                               static_cast<hipStream_t>(hip_stream));
@@ -539,13 +547,14 @@ int snsde_backward_with_gradients(const snsde_backward* b, float* grad_params, v
     if (b->struct_size != sizeof(snsde_backward)) return SNSDE_ERR_ABI;
     int rc = validate_solve(&b->fwd, false);
     if (rc) return rc;
-    if (!b->grad_ys || !b->adj || !b->workspace || !b->delta_save || !b->fwd.traj || !b->fwd.act_save || !b->fwd.workspace)
+    if (!b->grad_ys || !b->adj || !b->workspace || !b->fwd.traj || !b->fwd.act_save || !b->fwd.workspace)
         return SNSDE_ERR_NULL;
     if (!b->fwd.dW_out && !b->fwd.dW && b->fwd.seed_dev) return SNSDE_ERR_NULL;
     SnsdeNet net;
     rc = snsde_build_net(b->fwd.model, b->fwd.n_steps, &net);
     if (rc) return rc;
     if (snsde_backward_supported(&b->fwd) != 1) return SNSDE_ERR_UNSUPPORTED;
+    if (!b->delta_save && !snsde_mfma_w4_fused(b, net, nullptr, nullptr)) return SNSDE_ERR_NULL;      // (delta_slots == 0: no planes)
     if (b->workspace_bytes < snsde_backward_workspace_bytes(b)) return SNSDE_ERR_WORKSPACE;
     if (pg_workspace_bytes < snsde_param_gradients_workspace_bytes(b)) return SNSDE_ERR_WORKSPACE;
     hipStream_t st = static_cast<hipStream_t>(hip_stream);

@@ -71,7 +71,16 @@ bool snsde_mfma_backward_partials(const snsde_solve* s, const SnsdeNet& net, int
 bool snsde_w4_supported(const snsde_solve* s, const SnsdeNet& net);
 int snsde_w4_launch(const snsde_solve* s, const SnsdeNet& net, hipStream_t stream);
 bool snsde_w4_rev_supported(const snsde_solve* s, const SnsdeNet& net);       // adjoint of the Euler solve on the same wave pairs
-int snsde_w4_rev_launch(const snsde_backward* b, const SnsdeNet& net, float* dth_part, hipStream_t stream);
+// gpart != null: the weight gradients are accumulated inside the adjoint (per-tile blocks in gpart, snsde_w4_grad_floats floats) and
+// snsde_w4_grad_reduce_launch forms dL/d params from them; no delta planes are written
+int snsde_w4_rev_launch(const snsde_backward* b, const SnsdeNet& net, float* dth_part, float* gpart, hipStream_t stream);
+size_t snsde_w4_grad_floats(const snsde_solve* s);
+int snsde_w4_grad_reduce_launch(const snsde_backward* b, const SnsdeNet& net, float* grad_params, int32_t n_params, float* gpart,
+                                const float* dth_part, hipStream_t stream);
+// (snsde_mfma.hip) does the backward of this solve take the wave-pair adjoint with fused weight gradients?  -> offsets (floats) of
+// the per-tile blocks and of the theta partial sums inside the backward workspace
+bool snsde_mfma_w4_fused(const snsde_backward* b, const SnsdeNet& net, size_t* gpart_off, size_t* dth_off);
+bool snsde_mfma_w4_fused_solve(const snsde_solve* s, const SnsdeNet& net, size_t* gpart_off, size_t* dth_off);
 // launchers (snsde_wgrad.hip)
 size_t snsde_wgrad_workspace_floats(const snsde_backward* b, const SnsdeNet& net);
 int snsde_wgrad_launch(const snsde_backward* b, const SnsdeNet& net, float* grad_params, int32_t n_params, float* ws,

@@ -710,9 +710,29 @@ bool snsde_mfma_backward_partials(const snsde_solve* s, const SnsdeNet& net, int
     return true;
 }
 
+static size_t w4_gpart_off(const RevPlan& p) { return ((size_t)p.total_floats + 63) & ~(size_t)63; }
+
 size_t snsde_mfma_backward_workspace_floats(const snsde_solve* s, const SnsdeNet& net) {
-    RevPlan p = make_rev_plan(s, net, make_plan(s, net, flavor_hint_of(s)));
-    return p.ok ? (size_t)p.total_floats : 0;
+    const int hint = flavor_hint_of(s);
+    const MfmaPlan fp = make_plan(s, net, hint);
+    RevPlan p = make_rev_plan(s, net, fp);
+    if (!p.ok) return 0;
+    if (w4_rev_takes(s, net, fp, p, hint)) return w4_gpart_off(p) + snsde_w4_grad_floats(s);
+    return (size_t)p.total_floats;
+}
+
+bool snsde_mfma_w4_fused(const snsde_backward* b, const SnsdeNet& net, size_t* gpart_off, size_t* dth_off) {
+    return snsde_mfma_w4_fused_solve(&b->fwd, net, gpart_off, dth_off);
+}
+
+bool snsde_mfma_w4_fused_solve(const snsde_solve* s, const SnsdeNet& net, size_t* gpart_off, size_t* dth_off) {
+    const int hint = flavor_hint_of(s);
+    const MfmaPlan fp = make_plan(s, net, hint);
+    const RevPlan p = make_rev_plan(s, net, fp);
+    if (!w4_rev_takes(s, net, fp, p, hint)) return false;
+    if (gpart_off) *gpart_off = w4_gpart_off(p);
+    if (dth_off) *dth_off = p.dth_off;
+    return true;
 }
 
 int snsde_mfma_backward_launch(const snsde_backward* b, const SnsdeNet& net, hipStream_t stream) {
@@ -724,10 +744,10 @@ int snsde_mfma_backward_launch(const snsde_backward* b, const SnsdeNet& net, hip
     if ((uint64_t)16 * (uint64_t)s->batch * (uint64_t)s->model.hidden_channels >= (1ull << 32)) return SNSDE_ERR_UNSUPPORTED;   // (uoff)
     float* ws = static_cast<float*>(b->workspace);
     if (w4_rev_takes(s, net, fp, p, hint)) {
-        // the wave-pair adjoint reads the nn.Linear layout of `params` itself (columns of the weights): no fold, no pack launch
-        if (b->flags & SNSDE_BWD_ADJ0_ONLY) { /* (every a_n or dL/dy0 only: both forms) */ }
+        // the wave-pair adjoint reads the nn.Linear layout of `params` itself (columns of the weights): no fold, no pack launch;
+        // its gradient waves leave the weight-gradient sums per tile behind the plan's own workspace (snsde_mfma_w4_fused)
         if (!(s->dW_out ? s->dW_out : s->dW) && s->seed_dev) return SNSDE_ERR_NULL;
-        return snsde_w4_rev_launch(b, net, p.dth_off ? ws + p.dth_off : nullptr, stream);
+        return snsde_w4_rev_launch(b, net, p.dth_off ? ws + p.dth_off : nullptr, ws + w4_gpart_off(p), stream);
     }
     // first_y = emb[:, 0:H] . linear_in (all columns; the pack step picks the y columns).  A forward that ran with the folded first
     // layer left exactly this product in ITS workspace (piece `in` of snsde_prepare_kernel, same (H, K_in) layout): the pack

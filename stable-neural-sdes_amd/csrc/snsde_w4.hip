@@ -65,7 +65,13 @@ bool snsde_w4_rev_supported(const snsde_solve* s, const SnsdeNet& net) {
     return s->method == SNSDE_EULER && snsde_w4::shape_ok(s, net) && !s->seed_dev;
 }
 
-int snsde_w4_rev_launch(const snsde_backward* b, const SnsdeNet& net, float* dth_part, hipStream_t stream) {
+size_t snsde_w4_grad_floats(const snsde_solve* s) {      // per-tile gradient blocks + the stage-1 sums of the reduction
+    const int nhid = s->model.num_hidden_layers - 1, nn = s->model.noise_option >= 18 ? 2 : 1;
+    const size_t block = (size_t)snsde_w4::w4g_block_floats(nhid, nn), tiles = (size_t)(s->batch + 3) / 4;
+    return (tiles + 16) * block;
+}
+
+int snsde_w4_rev_launch(const snsde_backward* b, const SnsdeNet& net, float* dth_part, float* gpart, hipStream_t stream) {
     using namespace snsde_w4;
     const snsde_solve* s = &b->fwd;
     if (!snsde_w4_rev_supported(s, net)) return SNSDE_ERR_UNSUPPORTED;
@@ -74,7 +80,9 @@ int snsde_w4_rev_launch(const snsde_backward* b, const SnsdeNet& net, float* dth
     W4RevArgs a{};
     a.params = s->params; a.step_tab = s->step_tab; a.out_w = s->out_w; a.traj = s->traj; a.act = s->act_save;
     a.dW = s->dW_out ? s->dW_out : s->dW;
-    a.grad_ys = b->grad_ys; a.adj = b->adj; a.delta = b->delta_save; a.dth_part = dth_part; a.row_out = s->row_out;
+    a.grad_ys = b->grad_ys; a.adj = b->adj; a.dth_part = dth_part; a.row_out = s->row_out;
+    a.gpart = gpart;
+    a.delta = gpart ? nullptr : b->delta_save;      // fused weight gradients: no delta planes are written
     a.seed = s->seed; a.row_offset = s->row_offset;
     a.B = s->batch; a.N = s->n_steps; a.T = s->n_out; a.no = m.noise_option; a.geo = m.input_option == 5 ? 1 : 0;
     a.nsave = snsde_act_slots(&m); a.nslots = a.nsave;
@@ -84,10 +92,41 @@ int snsde_w4_rev_launch(const snsde_backward* b, const SnsdeNet& net, float* dth
     for (int l = 0; l < nhid; ++l) a.w_hid[l] = net.hid[l].src_w;
     a.w_out = net.out.src_w; a.w_n0 = net.ny0.src_w; a.w_n1 = net.ny1.src_w;
     const int nn = (m.noise_option >= 18) ? 2 : 1;
-    const dim3 grid((a.B + 7) / 8), block(256);
-#define W4R_CASE(NH, N2) if (nhid == NH && nn == N2) { hipLaunchKernelGGL((snsde_w4_euler_reverse_kernel<CfgW<NH, N2, false, false>>), grid, block, 0, stream, a); \
-                                                       return hipGetLastError() == hipSuccess ? SNSDE_OK : SNSDE_ERR_LAUNCH; }
+    const dim3 grid((a.B + 7) / 8);
+#define W4R_CASE(NH, N2) if (nhid == NH && nn == N2) { \
+        if (gpart) hipLaunchKernelGGL((snsde_w4_euler_reverse_kernel<CfgW<NH, N2, false, false>, true>), grid, dim3(512), 0, stream, a); \
+        else hipLaunchKernelGGL((snsde_w4_euler_reverse_kernel<CfgW<NH, N2, false, false>, false>), grid, dim3(256), 0, stream, a); \
+        return hipGetLastError() == hipSuccess ? SNSDE_OK : SNSDE_ERR_LAUNCH; }
     W4R_CASE(0, 1) W4R_CASE(0, 2) W4R_CASE(1, 1) W4R_CASE(1, 2)
 #undef W4R_CASE
     return SNSDE_ERR_UNSUPPORTED;
+}
+
+// dL/d params from the per-tile blocks of the fused adjoint: zero fill, two reduction launches (deterministic association)
+int snsde_w4_grad_reduce_launch(const snsde_backward* b, const SnsdeNet& net, float* grad_params, int32_t n_params, float* gpart,
+                                const float* dth_part, hipStream_t stream) {
+    using namespace snsde_w4;
+    const snsde_solve* s = &b->fwd;
+    const snsde_model& m = s->model;
+    const int nhid = m.num_hidden_layers - 1, nn = m.noise_option >= 18 ? 2 : 1, nd = nhid + 2;
+    W4GReduce r{};
+    r.tiles = (s->batch + 3) / 4; r.block = w4g_block_floats(nhid, nn); r.nsplit = r.tiles < 16 ? r.tiles : 16;
+    r.gpart = gpart; r.part2 = gpart + (size_t)r.tiles * r.block; r.grad = grad_params; r.dth_part = dth_part; r.params = s->params;
+    r.off_theta = net.off_theta; r.n_dth = r.tiles * 4;
+    int n = 0;
+    auto weight = [&](int src, const SnsdeLayer& L, int col) { r.seg[n++] = W4GSeg{src, L.src_w, L.K, col, 0}; r.seg[n++] = W4GSeg{src + 4096, L.src_b, 0, 0, 1}; };
+    auto tcols = [&](int src, const SnsdeLayer& L) { r.seg[n++] = W4GSeg{src, L.src_w, L.K, 0, 2}; r.seg[n++] = W4GSeg{src + 64, L.src_w, L.K, 1, 2}; };
+    weight(0, net.out, 0);
+    for (int g = 1; g <= nhid; ++g) weight(g * w4g_layer_floats(), net.hid[nhid - g], 0);
+    weight((nd - 1) * w4g_layer_floats(), net.in, net.in.tshift);
+    if (net.in.tshift == 2) tcols(w4g_d_time(nhid), net.in);
+    if (nn == 2) { weight(w4g_n_off(nhid, 0), net.ny1, 0); weight(w4g_n_off(nhid, 1), net.ny0, 2); }
+    else weight(w4g_n_off(nhid, 0), net.ny0, 2);
+    tcols(w4g_n_time(nhid, nn), net.ny0);
+    r.nseg = n;
+    if (hipMemsetAsync(grad_params, 0, (size_t)n_params * sizeof(float), stream) != hipSuccess) return SNSDE_ERR_LAUNCH;
+    const int gx = (r.block + 255) / 256;
+    hipLaunchKernelGGL(snsde_w4_grad_reduce1_kernel, dim3(gx, r.nsplit), dim3(256), 0, stream, r);
+    hipLaunchKernelGGL(snsde_w4_grad_reduce2_kernel, dim3(gx + 1), dim3(256), 0, stream, r);
+    return hipGetLastError() == hipSuccess ? SNSDE_OK : SNSDE_ERR_LAUNCH;
 }

@@ -69,6 +69,16 @@ __device__ __forceinline__ void gemm64(const float (&xt)[4], const float* w, f32
       d = mfma_bk<KB>(xt[3], w[4 * KB + 3], d)), ...);
 }
 
+// ... with the weight column parked in the wave's private LDS slice ([k / 4][lane][4] floats: every lane reads back the 16 bytes it
+// wrote - conflict-free, no barrier; LDS as an extension of the register file, as snsde_m4n_kernel.h does)
+template <int... KB>
+__device__ __forceinline__ void gemm64_lds(const float (&xt)[4], const float* wl, f32x4& c, f32x4& d, std::integer_sequence<int, KB...>) {
+    f32x4 w[16];
+    ((w[KB] = *reinterpret_cast<const f32x4*>(wl + KB * 256)), ...);
+    ((c = mfma_bk<KB>(xt[0], w[KB][0], c), d = mfma_bk<KB>(xt[1], w[KB][1], d), c = mfma_bk<KB>(xt[2], w[KB][2], c),
+      d = mfma_bk<KB>(xt[3], w[KB][3], d)), ...);
+}
+
 // 4 x 4 transpose inside every lane quad: in: lane 4b + j, v[i] = X[i][4b + j]  ->  out: lane 4b + i, t[j] = X[i][4b + j].
 // Two butterfly stages of four v_cndmask_b32_dpp each (D = VCC ? src1 : dpp(src0)); the four lane masks arrive in SGPR pairs.
 // Inline asm on purpose: written as selects around __builtin_amdgcn_update_dpp, hipcc sinks the DPP moves INTO the select's
@@ -807,6 +817,7 @@ struct W4RevArgs {
     float* adj;
     float* delta;
     float* dth_part;          // (tiles, 4): this kernel leaves the tile's sum in entry 0 and zeros in 1 .. 3
+    float* gpart;             // FUSED: (tiles, w4g_block_floats) per-tile weight / bias gradient sums
     const int32_t* row_out;
     uint64_t seed;
     int64_t row_offset;
@@ -814,18 +825,53 @@ struct W4RevArgs {
     int32_t w_in, k_in, t_in, w_hid[3], w_out, w_n0, w_n1;
 };
 
-template <class CF>
-__global__ void __launch_bounds__(256, 2) snsde_w4_euler_reverse_kernel(W4RevArgs a) {
+// FUSED = the weight gradients inside the adjoint (round 5; VERDICT r4 item 4 in the form that fits this layout).  The tile adjoint
+// writes one delta plane per layer and step (five at the K4 shape) which the weight-gradient GEMMs read back together with the saved
+// activations: the adjoint is bound by that traffic (169 us for 450 MB), the GEMM launch takes another 130 us.  Here a tile is FOUR
+// waves: besides the drift and the net wave two GRADIENT waves that hold  G[l][k] = sum_{n, row} delta[row][l] in[row][k]  of every
+// layer in accumulator registers (64 per layer and lane).  The outer product of a row is the same rank-1 MFMA once more: A = the
+// layer INPUT of the row in the D layout (four consecutive k of lane quad kq, broadcast by CBSZ / ABID = kq), B = the delta of the row
+// in the D layout (lane l holds delta[row][l]) - plain registers, no staging: 16 MFMAs per row and layer, 64 per layer and step, as
+// many as the layer's transposed GEMM, on SIMDs the pair does not use.  The drift / net waves publish their deltas to LDS (double
+// buffered by step parity), the gradient waves walk one step behind, read the inputs (saved activations, states) straight from HBM
+// in the D layout, keep the bias and time-column sums, and leave one block per tile for snsde_w4_grad_reduce_kernel.  No delta_save.
+__host__ __device__ constexpr int w4g_layer_floats() { return 64 * 64 + 64; }                                // G^T [k][l] | bias [l]
+__host__ __device__ constexpr int w4g_block_floats(int NHID, int NN) { return (NHID + 2 + NN) * w4g_layer_floats() + 256; }
+__host__ __device__ constexpr int w4g_d_time(int NHID) { return (NHID + 2) * w4g_layer_floats(); }            // tsin | tcos of linear_in
+__host__ __device__ constexpr int w4g_n_off(int NHID, int e) { return w4g_d_time(NHID) + 128 + e * w4g_layer_floats(); }
+__host__ __device__ constexpr int w4g_n_time(int NHID, int NN) { return w4g_n_off(NHID, NN); }
+
+template <int ABID> __device__ __forceinline__ void outer4(const float (&in)[4], const float (&dl)[4], f32x4& acc) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) acc = mfma_bk<ABID>(in[i], dl[i], acc);
+}
+template <int... KQ>
+__device__ __forceinline__ void outer64(const float (&in)[4], const float (&dl)[4], f32x4 (&acc)[16], std::integer_sequence<int, KQ...>) {
+    (outer4<KQ>(in, dl, acc[KQ]), ...);
+}
+
+template <class CF, bool FUSED>
+__global__ void __launch_bounds__(FUSED ? 512 : 256, 2) snsde_w4_euler_reverse_kernel(W4RevArgs a) {
     constexpr int H = 64, NHID = CF::NHID, NN = CF::NN;
-    constexpr int ZSLOT = NHID + 1, NB0 = NHID + 2;
+    constexpr int ZSLOT = NHID + 1, NB0 = NHID + 2, ND = NHID + 2;
+    constexpr int WPT = FUSED ? 4 : 2;                 // waves per tile
     using Seq = std::make_integer_sequence<int, 16>;
     enum { XA = 0, XN, XCNT };
     __shared__ float xchg_all[2][XCNT][4][H];
+    __shared__ float dpl_all[FUSED ? 2 : 1][FUSED ? 2 : 1][FUSED ? ND + NN : 1][4][H];      // [pair][step parity][delta plane][row][feature]
+    // the drift wave's third matrix (W_in,y^T) is parked in LDS when the drift has a hidden layer: 192 resident weight registers
+    // spilled (24 - 56 bytes per lane, reloaded inside the step loop)
+    constexpr bool PARK = NHID >= 1;
+    __shared__ __attribute__((aligned(16))) float wpark_all[PARK ? 2 : 1][PARK ? 16 : 1][H][4];
     __shared__ float zblk_all[2][4][4][H];      // regenerated Philox normals of the block of four steps being walked [pair][row][step][feature]
 
     const int lane = threadIdx.x & 63;
     const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int wave = wv & 1, pair = wv >> 1;
+    // role (0 drift, 1 net, 2 / 3 the gradient waves) and tile of a wave.  FUSED: the dispatcher deals the eight waves of a workgroup
+    // round the four SIMDs (wave w and w + 4 share one), so a heavy wave (drift, drift gradients: 192 MFMAs per step) is paired with a
+    // light one of the OTHER tile (net, net gradients: 128): two drift waves on one SIMD cost 274 us per K4 adjoint against ...
+    const int wave = FUSED ? ((0x11332200u >> (4 * wv)) & 3) : wv % WPT;
+    const int pair = FUSED ? ((0x5Au >> wv) & 1) : wv / WPT;           // waves 0..7: D_A D_B GD_A GD_B | GN_B GN_A N_B N_A
     float (*xchg)[4][H] = xchg_all[pair];
     float (*zblk)[4][H] = zblk_all[pair];
     const int B = a.B;
@@ -858,6 +904,13 @@ __global__ void __launch_bounds__(256, 2) snsde_w4_euler_reverse_kernel(W4RevArg
 #pragma unroll
         for (int i = 0; i < 4; ++i) v[i] = xchg[plane][i][lane];
     };
+    // FUSED: a delta plane of step n for the gradient waves (rows repeated by a ragged tail are zeroed: they must not enter the sums twice)
+    auto publish = [&](int n, int plane, const float (&v)[4]) {
+        if constexpr (FUSED) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) dpl_all[pair][n & 1][plane][i][lane] = v[i] * rowf[i];
+        }
+    };
     // column `lane` of a (64, K) nn.Linear weight, columns c0 .. c0 + 63: w[l] = W[l][c0 + lane]
     auto load_col = [&](float (&w)[H], int off, int K, int c0) {
         const float* q = P + off + c0 + lane;
@@ -868,24 +921,28 @@ __global__ void __launch_bounds__(256, 2) snsde_w4_euler_reverse_kernel(W4RevArg
 
     if (wave == 0) {
         // ================================ drift wave: owns the adjoint ================================
-        float wo[H], wh[NHID > 0 ? NHID : 1][H], wi[H];
+        float wo[H], wh[NHID > 0 ? NHID : 1][H], wi[PARK ? 1 : H];
         load_col(wo, a.w_out, H, 0);
 #pragma unroll
         for (int l = 0; l < NHID; ++l) load_col(wh[l], a.w_hid[l], H, 0);
-        load_col(wi, a.w_in, a.k_in, a.t_in);
-        const bool geo = a.geo != 0;
-        int rslot[4];
-        float gfin[4], adj[4] = {0.f, 0.f, 0.f, 0.f};
+        const float* wil = &wpark_all[PARK ? pair : 0][0][lane][0];
+        if constexpr (PARK) {
+            const float* q = P + a.w_in + a.t_in + lane;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) { rslot[i] = a.row_out ? a.row_out[row0 + i] : -1; gfin[i] = a.row_out ? a.grad_ys[lo + (uint32_t)(i * H)] : 0.0f; }
-        float y[4], z[4], yn[4], zn[4];
+            for (int l = 0; l < H; ++l) wpark_all[pair][l >> 2][lane][l & 3] = q[(size_t)l * a.k_in];
+        } else load_col(wi, a.w_in, a.k_in, a.t_in);
+        const bool geo = a.geo != 0;
+        // (register budget: 192 weight registers; the next step's y is fetched into `y` itself once the step is done with it and the
+        //  per-row output gradient is re-read where an output is emitted - with both kept in registers the wave spilled ten of them)
+        int rslot[4];
+        float adj[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int i = 0; i < 4; ++i) rslot[i] = a.row_out ? a.row_out[row0 + i] : -1;
+        float y[4], z[4], zn[4];
         load4(a.traj + uoff(N - 1, BH), y);
         load4(a.act + uoff(N - 1, SBH, ZSLOT, BH), z);
         for (int n = N - 1; n >= 0; --n) {
-            if (n > 0) {                 // next step's inputs: a full step ahead of their use
-                load4(a.traj + uoff(n - 1, BH), yn);
-                load4(a.act + uoff(n - 1, SBH, ZSLOT, BH), zn);
-            }
+            if (n > 0) load4(a.act + uoff(n - 1, SBH, ZSLOT, BH), zn);      // next step's z: a full step ahead of its use
             CP st = step_tab_c + (size_t)n * SNSDE_STEP_STRIDE;
             const float h = st[1];
             const int nout = __float_as_int(st[8]), kfirst = __float_as_int(st[9]);
@@ -894,8 +951,9 @@ __global__ void __launch_bounds__(256, 2) snsde_w4_euler_reverse_kernel(W4RevArg
                 const float w0 = out_w_c[2 * k], w1 = out_w_c[2 * k + 1];
                 float gk[4];
                 if (a.row_out) {
+                    load4(a.grad_ys, gk);
 #pragma unroll
-                    for (int i = 0; i < 4; ++i) gk[i] = rslot[i] == k + 1 ? gfin[i] : 0.0f;
+                    for (int i = 0; i < 4; ++i) gk[i] = rslot[i] == k + 1 ? gk[i] : 0.0f;
                 } else load4(a.grad_ys + uoff(k + 1, BH), gk);
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
@@ -929,7 +987,9 @@ __global__ void __launch_bounds__(256, 2) snsde_w4_euler_reverse_kernel(W4RevArg
                 dz[i] = dzt * ty[i];
                 ay[i] = geo ? fmaf(dzt * zc[i], 1.0f - ty[i] * ty[i], adj[i]) : adj[i];
             }
+            if (n > 0) load4(a.traj + uoff(n - 1, BH), y);       // (y_n is not needed below)
             if (a.delta) store4(a.delta + uoff(n, DBH), dz);
+            publish(n, 0, dz);
             float v[4], vt[4];
             quad_transpose(dz, vt);
             {   // W_out^T, masked by the last hidden layer's relu sign (act slot NHID)
@@ -938,6 +998,7 @@ __global__ void __launch_bounds__(256, 2) snsde_w4_euler_reverse_kernel(W4RevArg
 #pragma unroll
                 for (int i = 0; i < 4; ++i) v[i] = ((zb[i] >> NHID) & 1u) ? c[i] + d[i] : 0.0f;
                 if (a.delta) store4(a.delta + uoff(n, DBH, 1, BH), v);
+                publish(n, 1, v);
                 quad_transpose(v, vt);
             }
 #pragma unroll
@@ -947,12 +1008,14 @@ __global__ void __launch_bounds__(256, 2) snsde_w4_euler_reverse_kernel(W4RevArg
 #pragma unroll
                 for (int i = 0; i < 4; ++i) v[i] = ((zb[i] >> l) & 1u) ? c[i] + d[i] : 0.0f;
                 if (a.delta) store4(a.delta + uoff(n, DBH, (uint32_t)(NHID - l + 1), BH), v);
+                publish(n, NHID - l + 1, v);
                 quad_transpose(v, vt);
             }
             float od[4];
             {   // W_in[:, y columns]^T
                 f32x4 c = {0.f, 0.f, 0.f, 0.f}, d = c;
-                gemm64(vt, wi, c, d, Seq{});
+                if constexpr (PARK) gemm64_lds(vt, wil, c, d, Seq{});
+                else gemm64(vt, wi, c, d, Seq{});
 #pragma unroll
                 for (int i = 0; i < 4; ++i) od[i] = c[i] + d[i];
             }
@@ -962,20 +1025,21 @@ __global__ void __launch_bounds__(256, 2) snsde_w4_euler_reverse_kernel(W4RevArg
 #pragma unroll
             for (int i = 0; i < 4; ++i) adj[i] = (ay[i] + od[i] + carry[i]) + on[i];
 #pragma unroll
-            for (int i = 0; i < 4; ++i) { y[i] = yn[i]; z[i] = zn[i]; }
+            for (int i = 0; i < 4; ++i) z[i] = zn[i];
         }
         {   // ys[0] = y0
             float g0[4];
+            load4(a.grad_ys, g0);
             if (a.row_out) {
 #pragma unroll
-                for (int i = 0; i < 4; ++i) g0[i] = rslot[i] == 0 ? gfin[i] : 0.0f;
-            } else load4(a.grad_ys, g0);
+                for (int i = 0; i < 4; ++i) g0[i] = rslot[i] == 0 ? g0[i] : 0.0f;
+            }
 #pragma unroll
             for (int i = 0; i < 4; ++i) adj[i] += g0[i];
             store4(a.adj, adj);
         }
         if (a.dth_part && live && lane < 3) a.dth_part[(size_t)tile * 4 + 1 + lane] = 0.0f;
-    } else {
+    } else if (wave == 1) {
         // ================================ diffusion-net wave ================================
         float w1t[NN > 1 ? H : 1], w0t[H];
         if constexpr (NN > 1) load_col(w1t, a.w_n1, H, 0);
@@ -1030,6 +1094,7 @@ __global__ void __launch_bounds__(256, 2) snsde_w4_euler_reverse_kernel(W4RevArg
                 th_acc = fmaf(av[i] * dw[i] * om * rowf[i], snsde_nan_to_num(raw[i]), th_acc);
             }
             if (a.delta) store4(a.delta + uoff(n, DBH, NB0, BH), dq);
+            publish(n, ND, dq);
             quad_transpose(dq, vt);
             if constexpr (NN == 2) {
                 f32x4 c = {0.f, 0.f, 0.f, 0.f}, d = c;
@@ -1037,6 +1102,7 @@ __global__ void __launch_bounds__(256, 2) snsde_w4_euler_reverse_kernel(W4RevArg
 #pragma unroll
                 for (int i = 0; i < 4; ++i) v[i] = hm[i] > 0.0f ? c[i] + d[i] : 0.0f;
                 if (a.delta) store4(a.delta + uoff(n, DBH, NB0 + 1, BH), v);
+                publish(n, ND + 1, v);
                 quad_transpose(v, vt);
             }
             float on[4];
@@ -1056,6 +1122,126 @@ __global__ void __launch_bounds__(256, 2) snsde_w4_euler_reverse_kernel(W4RevArg
             for (int off = 32; off > 0; off >>= 1) th_acc += __shfl_down(th_acc, off, 64);
             if (lane == 0 && live) a.dth_part[(size_t)tile * 4] = th_acc;
         }
+    } else if constexpr (FUSED) {
+        // ================================ gradient waves: wave 2 the drift layers, wave 3 the net's ================================
+        const bool dside = wave == 2;
+        constexpr int NLG = ND > NN ? ND : NN;               // layers a gradient wave accumulates (drift: ND, net: NN)
+        f32x4 acc[NLG][16];
+        float bacc[NLG], tsn = 0.0f, tcs = 0.0f;
+#pragma unroll
+        for (int g = 0; g < NLG; ++g) {
+            bacc[g] = 0.0f;
+#pragma unroll
+            for (int q = 0; q < 16; ++q) acc[g][q] = f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+        // layer inputs of step n in the D layout: drift wave layer g reads act slot NHID - g (g <= NHID), the first layer the state y_n;
+        // net: layer 0 of a two-layer net reads its hidden activation (slot ZSLOT + 1), the layer on [tau, y] the state
+        float in_cur[NLG][4], in_nxt[NLG][4];
+        auto fetch_in = [&](int n, float (&dst)[NLG][4]) {
+            if (dside) {
+#pragma unroll
+                for (int g = 0; g < ND; ++g) {
+                    if (g <= NHID) load4(a.act + uoff(n, SBH, (uint32_t)(NHID - g), BH), dst[g]);
+                    else load4(a.traj + uoff(n, BH), dst[g]);
+                }
+            } else {
+                if constexpr (NN == 2) load4(a.act + uoff(n, SBH, ZSLOT + 1, BH), dst[0]);
+                load4(a.traj + uoff(n, BH), dst[NN - 1]);
+            }
+        };
+        auto accumulate = [&](int n) {
+            CP st = step_tab_c + (size_t)n * SNSDE_STEP_STRIDE;
+            const float sn = st[2], cs = st[3];
+            const int nl = dside ? ND : NN, p0 = dside ? 0 : ND;
+#pragma unroll
+            for (int g = 0; g < NLG; ++g) {
+                if (g < nl) {
+                    float dl[4];
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) dl[i] = dpl_all[pair][n & 1][p0 + g][i][lane];
+                    outer64(in_cur[g], dl, acc[g], Seq{});
+                    const float sum = (dl[0] + dl[1]) + (dl[2] + dl[3]);
+                    bacc[g] += sum;
+                    if (g == nl - 1) { tsn = fmaf(sum, sn, tsn); tcs = fmaf(sum, cs, tcs); }      // the layer on [tau, state]
+                }
+            }
+        };
+        fetch_in(N - 1, in_cur);
+        for (int n = N - 1; n >= 0; --n) {
+            if (n > 0) fetch_in(n - 1, in_nxt);
+            pair_barrier();                                     // B1 (the deltas of step n are being written)
+            pair_barrier();                                     // B2: complete
+            accumulate(n);
+#pragma unroll
+            for (int g = 0; g < NLG; ++g)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) in_cur[g][i] = in_nxt[g][i];
+        }
+        if (live && a.gpart) {
+            float* blk = a.gpart + (size_t)tile * w4g_block_floats(NHID, NN);
+            const int nl = dside ? ND : NN;
+#pragma unroll
+            for (int g = 0; g < NLG; ++g) {
+                if (g < nl) {
+                    float* gp = blk + (dside ? g * w4g_layer_floats() : w4g_n_off(NHID, g));
+#pragma unroll
+                    for (int q = 0; q < 16; ++q)
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) gp[(4 * q + i) * 64 + lane] = acc[g][q][i];       // G^T [k][l]
+                    gp[4096 + lane] = bacc[g];
+                }
+            }
+            float* tp = blk + (dside ? w4g_d_time(NHID) : w4g_n_time(NHID, NN));
+            tp[lane] = tsn; tp[64 + lane] = tcs;
+        }
+    }
+}
+
+// Sum of the per-tile gradient blocks (stage 1: tiles split over blockIdx.y, stage 2 assembles the flat gradient).
+struct W4GSeg { int32_t src, dst, ld, col, kind; };      // kind 0: weight G^T [k][l] -> W[l][col + k]; 1: vector [l]; 2: column `col` of W
+struct W4GReduce {
+    const float* gpart; float* part2; float* grad; const float* dth_part; const float* params;
+    int32_t tiles, block, nsplit, nseg, off_theta, n_dth;
+    W4GSeg seg[16];
+};
+__global__ void __launch_bounds__(256) snsde_w4_grad_reduce1_kernel(W4GReduce r) {
+    const int e = blockIdx.x * 256 + threadIdx.x;
+    if (e >= r.block) return;
+    const int per = (r.tiles + r.nsplit - 1) / r.nsplit, t0 = blockIdx.y * per, t1 = min(t0 + per, r.tiles);
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    int t = t0;
+    for (; t + 3 < t1; t += 4) {        // four loads in flight, a fixed association: the result does not depend on the launch
+        s0 += r.gpart[(size_t)t * r.block + e]; s1 += r.gpart[(size_t)(t + 1) * r.block + e];
+        s2 += r.gpart[(size_t)(t + 2) * r.block + e]; s3 += r.gpart[(size_t)(t + 3) * r.block + e];
+    }
+    for (; t < t1; ++t) s0 += r.gpart[(size_t)t * r.block + e];
+    r.part2[(size_t)blockIdx.y * r.block + e] = (s0 + s1) + (s2 + s3);
+}
+__global__ void __launch_bounds__(256) snsde_w4_grad_reduce2_kernel(W4GReduce r) {
+    if (blockIdx.x == gridDim.x - 1) {      // last block: theta from the adjoint's per-tile sums of dL/d sigmoid(theta)
+        __shared__ float red[256];
+        float s = 0.0f;
+        for (int i = threadIdx.x; i < r.n_dth; i += 256) s += r.dth_part[i];
+        red[threadIdx.x] = s;
+        __syncthreads();
+        for (int o = 128; o > 0; o >>= 1) { if ((int)threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o]; __syncthreads(); }
+        if (threadIdx.x == 0) { const float sg = snsde_sigmoid(r.params[r.off_theta]); r.grad[r.off_theta] = red[0] * sg * (1.0f - sg); }
+        return;
+    }
+    const int e = blockIdx.x * 256 + threadIdx.x;
+    if (e >= r.block) return;
+    float s = 0.0f;
+    for (int k = 0; k < r.nsplit; ++k) s += r.part2[(size_t)k * r.block + e];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        if (i >= r.nseg) break;
+        const W4GSeg g = r.seg[i];
+        const int len = g.kind == 0 ? 4096 : 64, q = e - g.src;
+        if (q < 0 || q >= len) continue;
+        if (g.kind == 0) r.grad[g.dst + (q & 63) * g.ld + g.col + (q >> 6)] = s;
+        else if (g.kind == 1) r.grad[g.dst + q] = s;
+        else r.grad[g.dst + q * g.ld + g.col] = s;
+        return;
     }
 }
 

@@ -867,6 +867,13 @@ size_t snsde_wgrad_workspace_floats(const snsde_backward* b, const SnsdeNet& net
 // costs 7 - 12 us on this runtime (rocprofv3 timeline of the round-3 pass), more than the small kernels it overlapped.
 int snsde_wgrad_launch(const snsde_backward* b, const SnsdeNet& net, float* grad_params, int32_t n_params, float* ws,
                        hipStream_t stream) {
+    {   // wave-pair adjoint with fused weight gradients (snsde_w4_kernel.h): the sums are in the BACKWARD workspace, per tile
+        size_t gpart_off = 0, dth_off = 0;
+        if (snsde_mfma_w4_fused(b, net, &gpart_off, &dth_off)) {
+            float* bws = static_cast<float*>(b->workspace);
+            return snsde_w4_grad_reduce_launch(b, net, grad_params, n_params, bws + gpart_off, bws + dth_off, stream);
+        }
+    }
     WPlan plan;
     WPlan* wp = &plan;
     if (!make_wplan(b, net, wp)) return SNSDE_ERR_UNSUPPORTED;

@@ -457,11 +457,23 @@ class SolveCall:
         s.model = model
         s.batch, s.knots, s.n_steps, s.n_out = B, L, grid.N, grid.T
         s.method = {'euler': _lib.EULER, 'milstein': _lib.MILSTEIN, 'srk': _lib.SRK}[method]
+        # (kernel selector, flags and the kind of Philox key BEFORE the layout query below: which adjoint a solve gets - and with it
+        #  whether it needs delta planes at all - depends on them)
+        s.kernel = _lib.KERNELS[kernel]
+        self.base_flags = _lib.FLAG_EXACT_ORDER if exact_order else 0
+        s.flags = self.base_flags
+        if torch.is_tensor(seed):     # device-resident key: re-read by every launch / graph replay
+            if seed.dtype != torch.int64 or not seed.is_cuda or seed.numel() != 1:
+                raise ValueError('a tensor seed must be a one-element int64 CUDA tensor')
+            self.keep = self.keep + (seed,)
+            s.seed_dev = _ptr(seed)
+        else:
+            s.seed = int(seed) & 0xFFFFFFFFFFFFFFFF
         # host-side queries of the library (save layout, workspace sizes) depend on the configuration only: memoised
         self.cfg_key = (model.input_channels, model.hidden_channels, model.hidden_hidden_channels, model.num_hidden_layers,
                         model.input_option, model.noise_option, model.activation, model.drift_output, model.diffusion_output,
                         model.time_feature, B, L, grid.N, grid.T, method, kernel, bool(exact_order), noise_table is not None,
-                        dW is not None, row_out is not None, None if kl_column is None else int(kl_column[0]))
+                        dW is not None, row_out is not None, None if kl_column is None else int(kl_column[0]), torch.is_tensor(seed))
         if save_act:
             lay = _SIZE_CACHE.get(('layout',) + self.cfg_key)
             if lay is None:
@@ -479,17 +491,7 @@ class SolveCall:
             s.dU = _ptr(dU)
             self.dU_out = torch.empty((grid.N, B, H), device=dev, dtype=torch.float32) if save_dW else None
             s.dU_out = _ptr(self.dU_out)
-        s.kernel = _lib.KERNELS[kernel]
-        self.base_flags = _lib.FLAG_EXACT_ORDER if exact_order else 0
-        s.flags = self.base_flags
         s.row_offset = int(row_offset)
-        if torch.is_tensor(seed):     # device-resident key: re-read by every launch / graph replay
-            if seed.dtype != torch.int64 or not seed.is_cuda or seed.numel() != 1:
-                raise ValueError('a tensor seed must be a one-element int64 CUDA tensor')
-            self.keep = self.keep + (seed,)
-            s.seed_dev = _ptr(seed)
-        else:
-            s.seed = int(seed) & 0xFFFFFFFFFFFFFFFF
         s.params, s.coeffs = _ptr(flat_params), _ptr(coeffs)
         s.step_tab, s.out_step, s.out_w = _ptr(grid.d_step_tab), _ptr(grid.d_out_step), _ptr(grid.d_out_w)
         s.y0, s.dW, s.ys = _ptr(y0), _ptr(dW), _ptr(self.ys)
@@ -596,8 +598,8 @@ def solve_backward(call, grad_ys, stream=None, save_delta=False, adj0_only=False
     adj = torch.empty_like(call.traj[:1]) if adj0_only else torch.empty_like(call.traj)
     b.flags = _lib.BWD_ADJ0_ONLY if adj0_only else 0
     delta = None
-    if save_delta and call.act_save is not None:      # (passes, delta slots, B, H): snsde_save_layout
-        shp = call.act_save.shape
+    if save_delta and call.act_save is not None and getattr(call, 'delta_slots', 1) != 0:      # (passes, delta slots, B, H): snsde_save_layout
+        shp = call.act_save.shape                                                                # (0 slots: the adjoint sums the weight gradients itself)
         delta = torch.empty((shp[0], getattr(call, 'delta_slots', shp[1]), shp[2], shp[3]), device=call.act_save.device, dtype=torch.float32)
     b.grad_ys, b.adj, b.delta_save = _ptr(grad_ys), _ptr(adj), _ptr(delta)
     nbytes = _lib.lib().snsde_backward_workspace_bytes(C.byref(b))
@@ -651,7 +653,9 @@ def backward_with_gradients(call, grad_ys, stream=None, adj0_only=True, want_tab
     adj = torch.empty_like(call.traj[:1]) if adj0_only else torch.empty_like(call.traj)
     b.flags = _lib.BWD_ADJ0_ONLY if adj0_only else 0
     shp = call.act_save.shape
-    delta = torch.empty((shp[0], getattr(call, 'delta_slots', shp[1]), shp[2], shp[3]), device=dev, dtype=torch.float32)
+    delta = None          # (0 delta slots: the adjoint of this solve sums the weight gradients itself, include/snsde.h)
+    if getattr(call, 'delta_slots', shp[1]) != 0:
+        delta = torch.empty((shp[0], getattr(call, 'delta_slots', shp[1]), shp[2], shp[3]), device=dev, dtype=torch.float32)
     b.grad_ys, b.adj, b.delta_save = _ptr(grad_ys), _ptr(adj), _ptr(delta)
     L = _lib.lib()
     tab_grad = None

@@ -200,3 +200,35 @@ def test_w4_adjoint_with_in_kernel_philox_and_row_outputs_equals_the_tile_adjoin
     assert pa.keys() == pb.keys()
     for k in pb:
         assert float((pa[k] - pb[k]).abs().max()) <= 5e-5 * (float(pb[k].abs().max()) + 1e-12), k
+
+
+def test_fused_weight_gradients_need_no_delta_planes_and_fall_back_with_them():
+    """snsde_save_layout reports delta_slots = 0 where the wave-pair adjoint sums the weight gradients itself (auto / w4, host Philox
+    key); the 4-row-tile selector and a device-resident key keep their delta planes.  Through the engine's two-call form
+    (solve_backward + param_gradients) and the one-call form: same flat gradient as the tile path."""
+    io, no, NL, B, C, L, H = 3, 18, 2, 37, 5, 9, 64
+    pr = make_problem(9600, io, no, NL, B, H, C, L)
+    from tests.test_gpu_parity import flat_params
+    model = S.engine.model_struct(C, H, H, NL, io, no)
+    flat = flat_params(pr['params'], io, no, NL, C, H)
+    grid = S.engine.step_grid(pr['times'][[0, 3, 8]], 0.5, pr['times'], torch.device(DEV))
+    args = (torch.from_numpy(pr['coeffs']).to(DEV), grid, torch.from_numpy(pr['y0']).to(DEV))
+    g = torch.from_numpy(np.random.default_rng(1).standard_normal((3, B, H)).astype(np.float32)).to(DEV)
+    grads = {}
+    for kernel in ('auto', 'w4', 'mfma4'):
+        call = S.engine.SolveCall(model, flat, *args, seed=11, kernel=kernel, save_traj=True, save_dW=True, save_act=True)
+        call.launch()
+        assert (call.delta_slots == 0) == (kernel != 'mfma4'), (kernel, call.delta_slots)
+        adj, delta = S.engine.solve_backward(call, g, save_delta=True, adj0_only=True)
+        assert (delta is None) == (kernel != 'mfma4')
+        two = S.engine.param_gradients(call, adj, delta)
+        adj1, one = S.engine.backward_with_gradients(call, g)
+        assert torch.equal(adj, adj1) and torch.equal(one, two)
+        grads[kernel] = one
+    seed_dev = torch.tensor([11], dtype=torch.int64, device=DEV)
+    call = S.engine.SolveCall(model, flat, *args, seed=seed_dev, save_traj=True, save_dW=True, save_act=True)
+    assert call.delta_slots > 0                                   # device-resident key: the tile adjoint
+    ref = grads['mfma4']
+    for k in ('auto', 'w4'):
+        assert float((grads[k] - ref).abs().max()) <= 5e-5 * float(ref.abs().max()), k
+    assert float(ref.abs().max()) > 0
