@@ -29,6 +29,45 @@ static int launch(const W4Args& a, hipStream_t st) {
     return hipGetLastError() == hipSuccess ? SNSDE_OK : SNSDE_ERR_LAUNCH;
 }
 
+// adjoint of the SRID2 solve with the weight gradients inside (snsde_w4_srk_reverse_kernel); gpart is mandatory: there is no
+// delta-plane variant of this kernel
+template <int NHID, int NN, bool GEO, bool MULY>
+static int launch_srk_rev(const W4SrkRevArgs& a, hipStream_t st) {
+    using CF = CfgSR<NHID, NN, GEO, MULY>;
+    const size_t lds_bytes = (size_t)w4srk_rev_lds_floats<NHID, NN>() * sizeof(float);
+    static SnsdeLdsAttr lds_attr;   // per instantiation and device
+    if (const int rc = snsde_lds_attr(reinterpret_cast<const void*>(snsde_w4_srk_reverse_kernel<CF>), lds_bytes, lds_attr)) return rc;
+    hipLaunchKernelGGL((snsde_w4_srk_reverse_kernel<CF>), dim3((a.B + 7) / 8), dim3(512), lds_bytes, st, a);
+    return hipGetLastError() == hipSuccess ? SNSDE_OK : SNSDE_ERR_LAUNCH;
+}
+
+static int srk_rev_launch(const snsde_backward* b, const SnsdeNet& net, float* dth_part, float* gpart, hipStream_t stream) {
+    const snsde_solve* s = &b->fwd;
+    const snsde_model& m = s->model;
+    const float* ik = s->dW_out ? s->dW_out : s->dW;
+    const float* ik0 = s->dU_out ? s->dU_out : s->dU;
+    if (!gpart) return SNSDE_ERR_UNSUPPORTED;
+    if (!s->stage_save || !s->srk_tab || !ik || !ik0) return SNSDE_ERR_NULL;
+    W4SrkRevArgs a{};
+    a.params = s->params; a.step_tab = s->step_tab; a.srk_tab = s->srk_tab; a.out_w = s->out_w; a.act = s->act_save; a.stage = s->stage_save;
+    a.dW = ik; a.dU = ik0; a.grad_ys = b->grad_ys; a.adj = b->adj; a.dth_part = dth_part; a.gpart = gpart; a.row_out = s->row_out;
+    a.B = s->batch; a.N = s->n_steps; a.T = s->n_out; a.no = m.noise_option; a.geo = m.input_option == 5 ? 1 : 0;
+    const int nn = (m.noise_option >= 18) ? 2 : 1;
+    a.nsave = snsde_act_slots(&m) + nn;      // (snsde_save_layout: the fourth evaluation's net slots)
+    a.adj0_only = (b->flags & SNSDE_BWD_ADJ0_ONLY) ? 1 : 0; a.off_theta = net.off_theta;
+    a.w_in = net.in.src_w; a.k_in = net.in.K; a.t_in = net.in.tshift;
+    const int nhid = m.num_hidden_layers - 1;
+    for (int l = 0; l < nhid; ++l) a.w_hid[l] = net.hid[l].src_w;
+    a.w_out = net.out.src_w; a.w_n0 = net.ny0.src_w; a.w_n1 = net.ny1.src_w;
+    const bool muly = m.noise_option == 15 || m.noise_option == 19;
+#define W4SR_CASE(NH, N2) if (nhid == NH && nn == N2) { \
+        if (a.geo) return muly ? launch_srk_rev<NH, N2, true, true>(a, stream) : launch_srk_rev<NH, N2, true, false>(a, stream); \
+        return muly ? launch_srk_rev<NH, N2, false, true>(a, stream) : launch_srk_rev<NH, N2, false, false>(a, stream); }
+    W4SR_CASE(0, 1) W4SR_CASE(0, 2) W4SR_CASE(1, 1) W4SR_CASE(1, 2)
+#undef W4SR_CASE
+    return SNSDE_ERR_UNSUPPORTED;
+}
+
 }  // namespace snsde_w4
 
 bool snsde_w4_supported(const snsde_solve* s, const SnsdeNet& net) { return snsde_w4::shape_ok(s, net); }
@@ -62,7 +101,9 @@ int snsde_w4_launch(const snsde_solve* s, const SnsdeNet& net, hipStream_t strea
 
 // ---- adjoint of the Euler solve (snsde_w4_euler_reverse_kernel) --------------------------------------------------------------
 bool snsde_w4_rev_supported(const snsde_solve* s, const SnsdeNet& net) {
-    return s->method == SNSDE_EULER && snsde_w4::shape_ok(s, net) && !s->seed_dev;
+    // Euler: snsde_w4_euler_reverse_kernel (regenerates host-keyed Philox increments); SRK: snsde_w4_srk_reverse_kernel (reads the
+    // increments and the stage states the forward wrote)
+    return (s->method == SNSDE_EULER || s->method == SNSDE_SRK) && snsde_w4::shape_ok(s, net) && !s->seed_dev;
 }
 
 size_t snsde_w4_grad_floats(const snsde_solve* s) {      // per-tile gradient blocks + the stage-1 sums of the reduction
@@ -75,8 +116,10 @@ int snsde_w4_rev_launch(const snsde_backward* b, const SnsdeNet& net, float* dth
     using namespace snsde_w4;
     const snsde_solve* s = &b->fwd;
     if (!snsde_w4_rev_supported(s, net)) return SNSDE_ERR_UNSUPPORTED;
-    if (!s->traj || !s->act_save || !b->grad_ys || !b->adj) return SNSDE_ERR_NULL;
+    if (!s->act_save || !b->grad_ys || !b->adj) return SNSDE_ERR_NULL;
     const snsde_model& m = s->model;
+    if (s->method == SNSDE_SRK) return snsde_w4::srk_rev_launch(b, net, dth_part, gpart, stream);
+    if (!s->traj) return SNSDE_ERR_NULL;
     W4RevArgs a{};
     a.params = s->params; a.step_tab = s->step_tab; a.out_w = s->out_w; a.traj = s->traj; a.act = s->act_save;
     a.dW = s->dW_out ? s->dW_out : s->dW;

@@ -1197,6 +1197,490 @@ __global__ void __launch_bounds__(FUSED ? 512 : 256, 2) snsde_w4_euler_reverse_k
     }
 }
 
+// =====================================================================================================================================
+// Adjoint of the SRID2 solve on the wave groups, weight gradients included (the contract of snsde_m4n_srk_reverse_kernel + the
+// weight-gradient pass in one launch; no delta planes).  A step walked backwards is four phases
+//     G3 | G2 || drift 2 | G1 || drift 1 | G0 || drift 0
+// (snsde_m4n_rev_kernel.h: stage dependencies and the glue of the cotangents Fbar_s, Gbar_e).  The drift wave keeps ybar and Fbar_s and
+// runs the three drift chains, the net wave keeps Gbar_e and runs the four net chains; after every phase they exchange the chain
+// results (hb = the net chain's cotangent of its input state, d = the drift chain's).  Neither wave re-derives the stage states: the
+// forward saved them (stage_save planes H0_s | H1_e | H1_3), so F_s = tanh(z_s {tanh H0_s}) and G_e = g(q_e {H1_e}) need the saved
+// pre-activations only (K4's model - no gate, raw = q - reads no state plane at all).  The relu masks are bits of the saved z: the
+// drift wave publishes the net's four hidden-mask bits with the step's cotangent.  Every per-phase input is re-fetched IN PLACE for
+// the step below right after its last use (a full step ahead, no second register set).  Two gradient waves per tile accumulate
+// G[l][k] of every layer over the 3 drift passes / 4 net evaluations of every step (see the Euler kernel above): they work on step
+// n + 1 - one unit (pass / evaluation) per phase - while the chains of step n run, the delta planes double buffered by step parity.
+// =====================================================================================================================================
+struct W4SrkRevArgs {
+    const float* params;
+    const float* step_tab;
+    const float* srk_tab;
+    const float* out_w;
+    const float* act;         // (3N, nsave, B, H)
+    const float* stage;       // (3N + 1, 3, B, H)
+    const float* dW;          // I_k used by the forward
+    const float* dU;          // I_k0
+    const float* grad_ys;
+    float* adj;
+    float* dth_part;
+    float* gpart;
+    const int32_t* row_out;
+    int32_t B, N, T, no, geo, nsave, adj0_only, off_theta;
+    int32_t w_in, k_in, t_in, w_hid[3], w_out, w_n0, w_n1;
+};
+
+template <int V> using IC = std::integral_constant<int, V>;
+
+template <int NHID, int NN> __host__ __device__ constexpr int w4srk_rev_lds_floats() {
+    return 2 * (6 * 256 + 2 * (3 * (NHID + 2) + 4 * NN) * 256 + (NHID >= 1 ? 16 * 256 : 0));
+}
+
+// (GEO: the drift is gated by tanh of its input state, input_option 5; MULY: raw = q * state, noise_option 15 / 19 - compile-time:
+//  the state planes they need are twelve / sixteen resident registers the other models do not have room for)
+template <int NHID_, int NN_, bool GEO_, bool MULY_> struct CfgSR { static constexpr int NHID = NHID_, NN = NN_; static constexpr bool GEO = GEO_, MULY = MULY_; };
+
+template <class CF>
+__global__ void __launch_bounds__(512, 2) snsde_w4_srk_reverse_kernel(W4SrkRevArgs a) {
+    constexpr int H = 64, NHID = CF::NHID, NN = CF::NN;
+    constexpr bool geo = CF::GEO, mul_y = CF::MULY;
+    constexpr int ZSLOT = NHID + 1, ND = NHID + 2, NP = 3;
+    constexpr int SRK_BITS = NHID + 1 + (NN == 2 ? 2 : 0);
+    constexpr bool PARK = NHID >= 1;
+    using Seq = std::make_integer_sequence<int, 16>;
+    // dynamic LDS, per tile: exchange planes | delta planes [step parity][3 ND + 4 NN] | the drift wave's parked W_in,y^T
+    enum { XA = 0, XM, XD, XH, XCNT = XH + 2 };            // (XH: two planes, alternating by phase)
+    constexpr int NDP = 3 * ND + 4 * NN;
+    constexpr int TILE_FLOATS = w4srk_rev_lds_floats<NHID, NN>() / 2;
+    static_assert(TILE_FLOATS >= XCNT * 256 + 2 * NDP * 256 + (PARK ? 16 * 256 : 0), "LDS layout");
+    extern __shared__ __attribute__((aligned(16))) float w4srk_lds[];
+
+    const int lane = threadIdx.x & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int wave = (0x11332200u >> (4 * wv)) & 3;      // role / tile of a wave: see snsde_w4_euler_reverse_kernel
+    const int pair = (0x5Au >> wv) & 1;
+    float* xchg = w4srk_lds + pair * TILE_FLOATS;        // [XCNT][4][64]
+    float* dpl = xchg + XCNT * 256;                      // [2][NDP][4][64]
+    float* wpark = dpl + 2 * NDP * 256;                  // [16][64][4]
+    const int B = a.B;
+    const int tile = blockIdx.x * 2 + pair;
+    const int row_t = tile * 4;
+    const int row0 = row_t + 4 <= B ? row_t : B - 4;
+    const bool live = row_t < B;
+    float rowf[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) rowf[i] = (live && row0 + i >= row_t) ? 1.0f : 0.0f;
+    const uint32_t BH = (uint32_t)B * H;
+    const uint32_t SBH = (uint32_t)a.nsave * BH, PBH = (uint32_t)NP * BH;
+    const float* P = a.params;
+    typedef const float __attribute__((address_space(4)))* CP;
+    const CP step_tab_c = (CP)(uintptr_t)a.step_tab, out_w_c = (CP)(uintptr_t)a.out_w, srk_c = (CP)(uintptr_t)a.srk_tab;
+    const uint32_t lo = (uint32_t)(row0 * H + lane);
+    auto load4 = [&](const float* p, float (&v)[4]) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) v[i] = p[lo + (uint32_t)(i * H)];
+    };
+    auto store4 = [&](float* p, const float (&v)[4]) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) p[lo + (uint32_t)(i * H)] = v[i];
+    };
+    auto put = [&](int plane, const float (&v)[4]) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) xchg[plane * 256 + i * 64 + lane] = v[i];
+    };
+    auto get = [&](int plane, float (&v)[4]) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) v[i] = xchg[plane * 256 + i * 64 + lane];
+    };
+    auto publish = [&](int n, int plane, const float (&v)[4]) {      // delta plane of step n for the gradient waves (ragged tail: zeroed)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) dpl[((n & 1) * NDP + plane) * 256 + i * 64 + lane] = v[i] * rowf[i];
+    };
+    auto load_col = [&](float (&w)[H], int off, int K, int c0) {
+        const float* q = P + off + c0 + lane;
+#pragma unroll
+        for (int l = 0; l < H; ++l) w[l] = q[(size_t)l * K];
+    };
+    const int N = a.N;
+
+    if (wave == 0) {
+        // ================================ drift wave: ybar, Fbar_s, the three drift chains ================================
+        float wo[H], wh[NHID > 0 ? NHID : 1][H], wi[PARK ? 1 : H];
+        load_col(wo, a.w_out, H, 0);
+#pragma unroll
+        for (int l = 0; l < NHID; ++l) load_col(wh[l], a.w_hid[l], H, 0);
+        const float* wil = wpark + lane * 4;
+        if constexpr (PARK) {
+            const float* q = P + a.w_in + a.t_in + lane;
+#pragma unroll
+            for (int l = 0; l < H; ++l) wpark[(l >> 2) * 256 + lane * 4 + (l & 3)] = q[(size_t)l * a.k_in];
+        } else load_col(wi, a.w_in, a.k_in, a.t_in);
+        int rslot[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) rslot[i] = a.row_out ? a.row_out[row0 + i] : -1;
+        float adj[4] = {0.f, 0.f, 0.f, 0.f};
+        float z[3][4], h0[geo ? 3 : 1][4];
+        auto fetch = [&](int n, auto sc) {
+            constexpr int s2 = decltype(sc)::value;
+            load4(a.act + uoff(3 * n + s2, SBH, ZSLOT, BH), z[s2]);
+            if constexpr (geo) load4(a.stage + uoff(3 * n + s2, PBH), h0[s2]);
+        };
+#pragma unroll
+        for (int i = 0; i < 4; ++i) h0[0][i] = 0.0f;
+        fetch(N - 1, IC<0>{}); fetch(N - 1, IC<1>{}); fetch(N - 1, IC<2>{});
+        for (int n = N - 1; n >= 0; --n) {
+            CP st = step_tab_c + (size_t)n * SNSDE_STEP_STRIDE;
+            const float h = st[1];
+            const int nout = __float_as_int(st[8]), kfirst = __float_as_int(st[9]);
+            float carry[4] = {0.f, 0.f, 0.f, 0.f};
+            for (int k = kfirst; k < kfirst + nout; ++k) {
+                const float w0 = out_w_c[2 * k], w1 = out_w_c[2 * k + 1];
+                float gk[4];
+                if (a.row_out) {
+                    load4(a.grad_ys, gk);
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) gk[i] = rslot[i] == k + 1 ? gk[i] : 0.0f;
+                } else load4(a.grad_ys + uoff(k + 1, BH), gk);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    if (w0 == 0.0f) adj[i] += gk[i];
+                    else { adj[i] = fmaf(w1, gk[i], adj[i]); carry[i] = fmaf(w0, gk[i], carry[i]); }
+                }
+            }
+            {   // the step's cotangent and the net's hidden-mask bits (bit e: evaluation e) for the net wave
+                float msk[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    uint32_t m = 0;
+                    if constexpr (NN == 2) {
+                        const uint32_t b0 = __float_as_uint(z[0][i]), b1 = __float_as_uint(z[1][i]), b2 = __float_as_uint(z[2][i]);
+                        m = ((b0 >> (NHID + 1)) & 1u) | (((b1 >> (NHID + 1)) & 1u) << 1) | (((b2 >> (NHID + 1)) & 3u) << 2);
+                    }
+                    msk[i] = __uint_as_float(m);
+                }
+                put(XA, adj); put(XM, msk);
+            }
+            pair_barrier();                                     // B0: the net wave takes a_{n+1} and its masks
+            if (!a.adj0_only) store4(a.adj + uoff(n + 1, BH), adj);
+            float yb[4], fb0[4], fb1[4], fb2[4], hb[4], dr[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                yb[i] = carry[i] + adj[i];
+                fb0[i] = adj[i] * (h * (1.0f / 6.0f)); fb1[i] = fb0[i]; fb2[i] = adj[i] * (h * (2.0f / 3.0f));
+            }
+            // drift pass s2 walked backwards: Fbar -> dz -> W_out^T -> [mask] -> W_hid^T -> [mask] -> W_in,y^T (+ the gate's direct term);
+            // the pass's deltas go to the gradient waves, its saved z / state are re-fetched for step n - 1
+            auto drift_pass = [&](auto sc, const float (&fb)[4], float (&out)[4]) {
+                constexpr int s2 = decltype(sc)::value;
+                uint32_t zb[4];
+                float dz[4], dd[4], v[4], vt[4];
+                {
+                    float zc[4], ty[4], F[4];
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        zb[i] = __float_as_uint(z[s2][i]);
+                        zc[i] = __uint_as_float(zb[i] & ~((1u << SRK_BITS) - 1u));
+                        ty[i] = 1.0f; F[i] = zc[i];
+                    }
+                    if constexpr (geo) {
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) ty[i] = h0[s2][i];
+                        fast_tanh4(ty);
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) F[i] = zc[i] * ty[i];
+                    }
+                    fast_tanh4(F);
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        const float dzt = fb[i] * (1.0f - F[i] * F[i]);
+                        dd[i] = geo ? dzt * zc[i] * (1.0f - ty[i] * ty[i]) : 0.0f;
+                        dz[i] = dzt * ty[i];
+                    }
+                }
+                if (n > 0) fetch(n - 1, sc);
+                publish(n, s2 * ND, dz);
+                quad_transpose(dz, vt);
+                {
+                    f32x4 c = {0.f, 0.f, 0.f, 0.f}, d = c;
+                    gemm64(vt, wo, c, d, Seq{});
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) v[i] = ((zb[i] >> NHID) & 1u) ? c[i] + d[i] : 0.0f;
+                    publish(n, s2 * ND + 1, v);
+                    quad_transpose(v, vt);
+                }
+#pragma unroll
+                for (int l = NHID - 1; l >= 0; --l) {
+                    f32x4 c = {0.f, 0.f, 0.f, 0.f}, d = c;
+                    gemm64(vt, wh[l], c, d, Seq{});
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) v[i] = ((zb[i] >> l) & 1u) ? c[i] + d[i] : 0.0f;
+                    publish(n, s2 * ND + NHID - l + 1, v);
+                    quad_transpose(v, vt);
+                }
+                f32x4 c = {0.f, 0.f, 0.f, 0.f}, d = c;
+                if constexpr (PARK) gemm64_lds(vt, wil, c, d, Seq{});
+                else gemm64(vt, wi, c, d, Seq{});
+#pragma unroll
+                for (int i = 0; i < 4; ++i) out[i] = (c[i] + d[i]) + dd[i];
+            };
+            pair_barrier();                                     // B1: G3's chain is done
+            get(XH + 1, hb);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) { yb[i] += hb[i]; fb2[i] = fmaf(0.25f * h, hb[i], fb2[i]); }
+            // ---- drift pass 2 beside G2 ----
+            drift_pass(IC<2>{}, fb2, dr);
+            put(XD, dr);
+            pair_barrier();                                     // B2
+            get(XH, hb);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                yb[i] += hb[i]; fb0[i] = fmaf(h, hb[i], fb0[i]);
+                yb[i] += dr[i]; fb0[i] = fmaf(0.25f * h, dr[i], fb0[i]); fb1[i] = fmaf(0.25f * h, dr[i], fb1[i]);
+            }
+            // ---- drift pass 1 beside G1 ----
+            drift_pass(IC<1>{}, fb1, dr);
+            pair_barrier();                                     // B3
+            get(XH + 1, hb);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                yb[i] += hb[i]; fb0[i] = fmaf(0.25f * h, hb[i], fb0[i]);
+                yb[i] += dr[i]; fb0[i] = fmaf(h, dr[i], fb0[i]);
+            }
+            // ---- drift pass 0 beside G0 ----
+            drift_pass(IC<0>{}, fb0, dr);
+            pair_barrier();                                     // B4
+            get(XH, hb);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) adj[i] = yb[i] + hb[i] + dr[i];
+        }
+        {
+            float g0[4];
+            load4(a.grad_ys, g0);
+            if (a.row_out) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) g0[i] = rslot[i] == 0 ? g0[i] : 0.0f;
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i) adj[i] += g0[i];
+            store4(a.adj, adj);
+        }
+        if (a.dth_part && live && lane < 3) a.dth_part[(size_t)tile * 4 + 1 + lane] = 0.0f;
+    } else if (wave == 1) {
+        // ================================ net wave: Gbar_e, the four net chains ================================
+        float w1t[NN > 1 ? H : 1], w0t[H];
+        if constexpr (NN > 1) load_col(w1t, a.w_n1, H, 0);
+        load_col(w0t, a.w_n0, 66, 2);
+        const float sig_theta = snsde_sigmoid(P[a.off_theta]);
+        float th_acc = 0.0f;
+        float q[4][4], h1[mul_y ? 4 : 1][4], ik[4], ik0[4];
+        auto fetch = [&](int n, auto ec) {
+            constexpr int e = decltype(ec)::value;
+            const int p = 3 * n + (e < 3 ? e : 2);
+            load4(a.act + uoff(p, SBH, (uint32_t)(e < 3 ? ZSLOT + NN : ZSLOT + 2 * NN), BH), q[e]);
+            if constexpr (mul_y) load4(a.stage + uoff(p, PBH, e < 3 ? 1u : 2u, BH), h1[e]);
+        };
+#pragma unroll
+        for (int i = 0; i < 4; ++i) h1[0][i] = 1.0f;
+        fetch(N - 1, IC<0>{}); fetch(N - 1, IC<1>{}); fetch(N - 1, IC<2>{}); fetch(N - 1, IC<3>{});
+        load4(a.dW + uoff(N - 1, BH), ik);
+        load4(a.dU + uoff(N - 1, BH), ik0);
+        for (int n = N - 1; n >= 0; --n) {
+            CP st = step_tab_c + (size_t)n * SNSDE_STEP_STRIDE;
+            const float h = st[1], rdt = st[6];
+            const float rh = 1.0f / h, rrdt = 1.0f / rdt;
+            float wg[4][4], ik0h[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const float ikk = 0.5f * (ik[i] * ik[i] - h);
+                const float ikkk = (ik[i] * ik[i] * ik[i] - 3.0f * h * ik[i]) * (1.0f / 6.0f);
+                ik0h[i] = ik0[i] * rh;
+                const float a1 = ik[i], a2 = ikk * rrdt, a3 = ik0h[i], a4 = ikkk * rh;
+                wg[0][i] = -a1 - a2 + 2.0f * a3 - 2.0f * a4;
+                wg[1][i] = (4.0f / 3.0f) * a1 + (4.0f / 3.0f) * a2 - (4.0f / 3.0f) * a3 + (5.0f / 3.0f) * a4;
+                wg[2][i] = (2.0f / 3.0f) * a1 - (1.0f / 3.0f) * a2 - (2.0f / 3.0f) * a3 - (2.0f / 3.0f) * a4;
+                wg[3][i] = a4;
+            }
+            if (n > 0) { load4(a.dW + uoff(n - 1, BH), ik); load4(a.dU + uoff(n - 1, BH), ik0); }
+            pair_barrier();                                     // B0
+            float msk[4], gb[4][4], hb[4];
+            {
+                float av[4];
+                get(XA, av); get(XM, msk);
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) gb[e][i] = wg[e][i] * av[i];
+            }
+            // net evaluation e walked backwards: Gbar_e -> qb -> [W2^T -> mask] -> W1,y^T (+ the direct term of raw = q H1_e; theta's
+            // share); its deltas go to the gradient waves, its saved q / state are re-fetched for step n - 1
+            auto net_eval = [&](auto ec, float (&out)[4]) {
+                constexpr int e = decltype(ec)::value;
+                float qb[4], nd[4], v[4], vt[4];
+                {
+                    float g[4], rc[4];
+                    bool fin[4];
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        const float raw = q[e][i] * h1[mul_y ? e : 0][i];
+                        fin[i] = snsde_finite(raw);
+                        rc[i] = snsde_nan_to_num(raw);
+                        g[i] = sig_theta * rc[i];
+                    }
+                    fast_tanh4(g);
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        const float om = 1.0f - g[i] * g[i];
+                        const float rb = fin[i] ? gb[e][i] * om * sig_theta : 0.0f;
+                        th_acc = fmaf(gb[e][i] * om * rowf[i], rc[i], th_acc);
+                        nd[i] = mul_y ? rb * q[e][i] : 0.0f;
+                        float t = rb * h1[mul_y ? e : 0][i];
+                        if constexpr (NN == 2) t = q[e][i] > 0.0f ? t : 0.0f;
+                        qb[i] = t;
+                    }
+                }
+                if (n > 0) fetch(n - 1, ec);
+                publish(n, 3 * ND + e * NN, qb);
+                quad_transpose(qb, vt);
+                if constexpr (NN == 2) {
+                    f32x4 c = {0.f, 0.f, 0.f, 0.f}, d = c;
+                    gemm64(vt, w1t, c, d, Seq{});
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) v[i] = ((__float_as_uint(msk[i]) >> e) & 1u) ? c[i] + d[i] : 0.0f;
+                    publish(n, 3 * ND + e * NN + 1, v);
+                    quad_transpose(v, vt);
+                }
+                f32x4 c = {0.f, 0.f, 0.f, 0.f}, d = c;
+                gemm64(vt, w0t, c, d, Seq{});
+#pragma unroll
+                for (int i = 0; i < 4; ++i) out[i] = (c[i] + d[i]) + nd[i];
+            };
+            // ---- G3 ----
+            net_eval(IC<3>{}, hb);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                gb[0][i] = fmaf(-5.0f * rdt, hb[i], gb[0][i]); gb[1][i] = fmaf(3.0f * rdt, hb[i], gb[1][i]); gb[2][i] = fmaf(0.5f * rdt, hb[i], gb[2][i]);
+            }
+            put(XH + 1, hb);
+            pair_barrier();                                     // B1
+            // ---- G2 beside drift pass 2 ----
+            net_eval(IC<2>{}, hb);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) gb[0][i] = fmaf(-rdt, hb[i], gb[0][i]);
+            put(XH, hb);
+            pair_barrier();                                     // B2
+            {
+                float dr[4];
+                get(XD, dr);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) { gb[0][i] = fmaf(ik0h[i], dr[i], gb[0][i]); gb[1][i] = fmaf(0.5f * ik0h[i], dr[i], gb[1][i]); }
+            }
+            // ---- G1 beside drift pass 1 ----
+            net_eval(IC<1>{}, hb);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) gb[0][i] = fmaf(0.5f * rdt, hb[i], gb[0][i]);
+            put(XH + 1, hb);
+            pair_barrier();                                     // B3
+            // ---- G0 beside drift pass 0 ----
+            net_eval(IC<0>{}, hb);
+            put(XH, hb);
+            pair_barrier();                                     // B4
+        }
+        if (a.dth_part) {
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) th_acc += __shfl_down(th_acc, off, 64);
+            if (lane == 0 && live) a.dth_part[(size_t)tile * 4] = th_acc;
+        }
+    } else {
+        // ================================ gradient waves: wave 2 the drift layers, wave 3 the net's ================================
+        const bool dside = wave == 2;
+        constexpr int NLG = ND > NN ? ND : NN;
+        f32x4 acc[NLG][16];
+        float bacc[NLG], tsn = 0.0f, tcs = 0.0f;
+#pragma unroll
+        for (int g = 0; g < NLG; ++g) {
+            bacc[g] = 0.0f;
+#pragma unroll
+            for (int qq = 0; qq < 16; ++qq) acc[g][qq] = f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+        const int nl = dside ? ND : NN, nunits = dside ? 3 : 4;       // layers per unit; units (drift passes / net evaluations) per step
+        float in_cur[NLG][4];
+        // input of layer g of unit u of step m (D layout): drift pass u: act slots NHID - g, the layer on [tau, state] the pass's state
+        // H0_u; net evaluation u: its hidden activation (two-layer nets), the layer on [tau, state] the state H1_u
+        auto fetch_in = [&](int m, int u, auto gc) {
+            constexpr int g = decltype(gc)::value;
+            if (dside) {
+                if constexpr (g <= NHID) load4(a.act + uoff(3 * m + u, SBH, (uint32_t)(NHID - g), BH), in_cur[g]);
+                else if constexpr (g < ND) load4(a.stage + uoff(3 * m + u, PBH), in_cur[g]);
+            } else if constexpr (g < NN) {
+                const int p = 3 * m + (u < 3 ? u : 2);
+                if constexpr (NN == 2 && g == 0) load4(a.act + uoff(p, SBH, (uint32_t)(u < 3 ? ZSLOT + 1 : ZSLOT + NN + 1), BH), in_cur[0]);
+                else load4(a.stage + uoff(p, PBH, u < 3 ? 1u : 2u, BH), in_cur[NN - 1]);
+            }
+        };
+        // the walk over (step, unit), units of a step in the order the chains finish them; in_cur holds the inputs of (pm, pu): a
+        // layer's input of the unit after it is fetched in place as soon as the layer's MFMAs are issued
+        int pm = N - 1, pu = nunits - 1;
+        auto layer = [&](auto gc, int m2, int u2, float sn, float cs, int p0) {
+            constexpr int g = decltype(gc)::value;
+            if (g < nl) {
+                float dl[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) dl[i] = dpl[((pm & 1) * NDP + p0 + g) * 256 + i * 64 + lane];
+                outer64(in_cur[g], dl, acc[g], Seq{});
+                if (m2 >= 0) fetch_in(m2, u2, gc);
+                const float sum = (dl[0] + dl[1]) + (dl[2] + dl[3]);
+                bacc[g] += sum;
+                if (g == nl - 1) { tsn = fmaf(sum, sn, tsn); tcs = fmaf(sum, cs, tcs); }
+            }
+        };
+        auto unit = [&]() {
+            const int m2 = pu > 0 ? pm : pm - 1, u2 = pu > 0 ? pu - 1 : nunits - 1;
+            CP sk = srk_c + (size_t)pm * 4 * SNSDE_SRK_STRIDE;
+            // stage time of the unit: drift passes at t0, t0 + h, t0 + h/2 (rows 0, 3, 2), net evaluations at t0, t0 + h/4, t0 + h, t0 + h/4
+            const int c = dside ? (pu == 0 ? 0 : (pu == 1 ? 3 : 2)) : (pu == 0 ? 0 : (pu == 2 ? 3 : 1));
+            const float sn = sk[c * SNSDE_SRK_STRIDE + 1], cs = sk[c * SNSDE_SRK_STRIDE + 2];
+            const int p0 = dside ? pu * ND : 3 * ND + pu * NN;
+            layer(IC<0>{}, m2, u2, sn, cs, p0);
+            if constexpr (NLG > 1) layer(IC<1>{}, m2, u2, sn, cs, p0);
+            if constexpr (NLG > 2) layer(IC<2>{}, m2, u2, sn, cs, p0);
+            if constexpr (NLG > 3) layer(IC<3>{}, m2, u2, sn, cs, p0);
+            pm = m2; pu = u2;
+        };
+        fetch_in(pm, pu, IC<0>{});
+        if constexpr (NLG > 1) fetch_in(pm, pu, IC<1>{});
+        if constexpr (NLG > 2) fetch_in(pm, pu, IC<2>{});
+        if constexpr (NLG > 3) fetch_in(pm, pu, IC<3>{});
+        for (int n = N - 1; n >= 0; --n) {
+            const bool work = n < N - 1;                        // the units of step n + 1 (complete since its B4)
+            pair_barrier();                                     // B0
+            if (work && !dside) unit();
+            pair_barrier();                                     // B1
+            if (work) unit();
+            pair_barrier();                                     // B2
+            if (work) unit();
+            pair_barrier();                                     // B3
+            if (work) unit();
+            pair_barrier();                                     // B4
+        }
+        for (int u = 0; u < nunits; ++u) unit();               // step 0
+        if (live && a.gpart) {
+            float* blk = a.gpart + (size_t)tile * w4g_block_floats(NHID, NN);
+#pragma unroll
+            for (int g = 0; g < NLG; ++g) {
+                if (g < nl) {
+                    float* gp = blk + (dside ? g * w4g_layer_floats() : w4g_n_off(NHID, g));
+#pragma unroll
+                    for (int qq = 0; qq < 16; ++qq)
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) gp[(4 * qq + i) * 64 + lane] = acc[g][qq][i];
+                    gp[4096 + lane] = bacc[g];
+                }
+            }
+            float* tp = blk + (dside ? w4g_d_time(NHID) : w4g_n_time(NHID, NN));
+            tp[lane] = tsn; tp[64 + lane] = tcs;
+        }
+    }
+}
+
 // Sum of the per-tile gradient blocks (stage 1: tiles split over blockIdx.y, stage 2 assembles the flat gradient).
 struct W4GSeg { int32_t src, dst, ld, col, kind; };      // kind 0: weight G^T [k][l] -> W[l][col + k]; 1: vector [l]; 2: column `col` of W
 struct W4GReduce {

@@ -166,8 +166,53 @@ def test_w4_srk_training_saves_drive_the_fused_srk_adjoint(ci):
     grid = S.engine.step_grid(np.asarray(ts, np.float32), dt, np.arange(L, dtype=np.float32), torch.device(DEV))
     model = S.engine.model_struct(C, 64, 64, NL, io, no)
     assert S.engine.forward_path(model, B, L, grid.N, method='srk') == 'w4' and S.engine.backward_mode(model, B, L, grid, 'srk') == 1
+    """Forward SRID2 on the wave pair in training mode; backward: under 'w4' / 'auto' the wave-group SRK adjoint with the weight
+    gradients inside (snsde_w4_srk_reverse_kernel: stage states from stage_save, no delta planes), under 'mfma4' the tile adjoint +
+    weight-gradient pass on the same saves - all against fp64 autograd through the tensor loop."""
     _check_backward(9350 + ci, io, no, NL, B, 64, C, L, ts, dt, 'srk', 'w4', strict=True)
     _check_backward(9350 + ci, io, no, NL, B, 64, C, L, ts, dt, 'srk', 'auto', strict=True)
+    _check_backward(9350 + ci, io, no, NL, B, 64, C, L, ts, dt, 'srk', 'mfma4', strict=True)
+
+
+@pytest.mark.parametrize('case', [(3, 18, 2, 37, False), (5, 19, 2, 22, True), (1, 14, 1, 9, False), (3, 15, 2, 130, True), (5, 18, 1, 64, False)])
+def test_w4_srk_adjoint_equals_the_tile_adjoint(case):
+    """SRK training through sdeint with in-kernel Philox increments and (optionally) per-row outputs: the wave-group path ('auto':
+    fused SRK adjoint, delta_slots == 0) against the 4-row-tile path ('mfma4': snsde_m4n_srk_reverse_kernel + the weight-gradient
+    GEMMs) on the same key - states, dL/dy0 and every parameter gradient to round-off; ragged tails, gated drifts (io 5), raw = q y."""
+    io, no, NL, B, row_out = case
+    C, L, H = 5, 9, 64
+    pr = make_problem(9700 + B, io, no, NL, B, H, C, L)
+    ts = torch.from_numpy(pr['times'][[0, 2, 5, 8]]).to(DEV)
+    ro = torch.from_numpy(np.random.default_rng(2).integers(0, 4, size=B).astype(np.int32)).to(DEV) if row_out else None
+    model = S.engine.model_struct(C, H, H, NL, io, no)
+    grid = S.engine.step_grid(pr['times'][[0, 2, 5, 8]], 0.5, pr['times'], torch.device(DEV))
+    from tests.test_gpu_parity import flat_params
+    flat = flat_params(pr['params'], io, no, NL, C, H)
+    for kernel, fused in (('auto', True), ('w4', True), ('mfma4', False)):
+        call = S.engine.SolveCall(model, flat, torch.from_numpy(pr['coeffs']).to(DEV), grid, torch.from_numpy(pr['y0']).to(DEV), seed=5,
+                                  method='srk', kernel=kernel, save_traj=True, save_dW=True, save_act=True)
+        assert (call.delta_slots == 0) == fused, (kernel, call.delta_slots)
+    out = {}
+    for kernel in ('auto', 'mfma4'):
+        m = S.Diffusion_model(C, H, H, NL, input_option=io, noise_option=no)
+        m.load_state_dict({k: torch.from_numpy(v.copy()) for k, v in pr['params'].items()})
+        m = m.to(DEV)
+        m.set_X(torch.from_numpy(pr['coeffs']).to(DEV), torch.from_numpy(pr['times']).to(DEV))
+        y0 = torch.from_numpy(pr['y0']).to(DEV).requires_grad_(True)
+        opts = {'seed': 99, 'kernel': kernel, 'strict': True}
+        if ro is not None:
+            opts['row_out'] = ro
+        ys = S.sdeint(m, y0, ts, dt=0.5, method='srk', options=opts)
+        w = torch.from_numpy(np.random.default_rng(3).standard_normal(tuple(ys.shape)).astype(np.float32)).to(DEV)
+        (ys * w).sum().backward()
+        out[kernel] = (ys.detach(), y0.grad.clone(), {n: p.grad.clone() for n, p in m.named_parameters() if p.grad is not None})
+    ya, ga, pa = out['auto']
+    yb, gb, pb = out['mfma4']
+    assert float((ya - yb).abs().max()) <= 2e-5 * (float(yb.abs().max()) + 1.0)
+    assert float((ga - gb).abs().max()) <= 5e-5 * float(gb.abs().max())
+    assert pa.keys() == pb.keys()
+    for k in pb:
+        assert float((pa[k] - pb[k]).abs().max()) <= 1e-4 * (float(pb[k].abs().max()) + 1e-12), k
 
 
 @pytest.mark.parametrize('row_out', [False, True])
