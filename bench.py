@@ -268,6 +268,36 @@ def solve_kernel_ms(sde, y0, ts_host, method, stream, n=20, training=False, nois
     return event_times_ms(lambda: call.launch(stream, reuse_prepared=True), stream, n, 3)
 
 
+def graphed_step_ms(sde, params, y0, ts, method, dev, stream):
+    """The same forward + backward recorded into one HIP graph and replayed (what train.main does by default: GraphedStep; the
+    eager call is bound by the host's ~0.4 ms of Python between the launches at these sizes).  Increments from the device-resident
+    Philox key (fresh on every replay).  None where the capture is refused."""
+    try:
+        S.torchsde.prepare_graph_capture(dev)
+        opts = {'strict': True}
+        static_y0 = y0.clone()
+
+        def step():
+            for p in params:
+                p.grad = None
+            yy = static_y0.clone().requires_grad_(True)
+            S.torchsde.sdeint(sde, yy, ts, dt=1.0, method=method, options=opts)[-1].square().mean().backward()
+        side = torch.cuda.Stream(dev)
+        side.wait_stream(torch.cuda.current_stream(dev))
+        with torch.cuda.stream(side):
+            for _ in range(3):
+                step()
+        torch.cuda.current_stream(dev).wait_stream(side)
+        torch.cuda.synchronize(dev)
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):
+            step()
+        return event_times_ms(graph.replay, torch.cuda.current_stream(dev), 20, 5)
+    except Exception as exc:      # noqa: BLE001 - reported in the leg, the eager numbers stand
+        sys.stderr.write(f"graph replay leg skipped: {exc!r}\n")
+        return None
+
+
 def train_leg(dev, stream, io, no, rows, hh, cc, ll, method, label, outputs='ends'):
     """sdeint forward and forward + backward (fused adjoint + native weight-gradient pass) of one Diffusion_model shape:
     HIP-event medians of the whole calls AND of the solve launch alone; the forward's roofline fraction is computed from the
@@ -289,6 +319,7 @@ def train_leg(dev, stream, io, no, rows, hh, cc, ll, method, label, outputs='end
 
     t_f = event_times_ms(fwd, stream, 20, 5)
     t_s = event_times_ms(step, stream, 20, 5)
+    t_g = graphed_step_ms(sde, params, y0, ts, method, dev, stream)
     t_k = solve_kernel_ms(sde, y0, ts.cpu().numpy(), method, stream)
     t_kt = solve_kernel_ms(sde, y0, ts.cpu().numpy(), method, stream, training=True)
     n = ll - 1
@@ -299,6 +330,7 @@ def train_leg(dev, stream, io, no, rows, hh, cc, ll, method, label, outputs='end
            "forward_path": S.engine.forward_path(model, rows, ll, n, method=method),
            "backward_mode": S.engine.backward_mode(model, rows, ll, S.engine.step_grid(ts.cpu().numpy(), 1.0, times.cpu().numpy(), dev), method),
            "forward": spread(t_f), "forward_backward": spread(t_s),
+           "forward_backward_graph_replay": spread(t_g) if t_g is not None else None,
            "forward_kernel": spread(t_k), "training_mode_forward_kernel": spread(t_kt),
            "value": rows * n / (float(np.median(t_f)) * 1e-3), "unit": "row-steps/s (forward)",
            "flop_per_rowstep": fl,
@@ -446,6 +478,8 @@ def summary_of(out, extra):
         if e:
             s[key] = {"kernel_ms": round(e["forward_kernel"]["median_ms"], 4), "frac": round(e["roofline_forward"]["frac"], 4),
                       "fwd_bwd_ms": round(e["forward_backward"]["median_ms"], 4), "train_frac": round(e["roofline_training"]["frac"], 4)}
+            if e.get("forward_backward_graph_replay"):
+                s[key]["fwd_bwd_graph_ms"] = round(e["forward_backward_graph_replay"]["median_ms"], 4)
             if "roofline_bytes" in e and "traffic" in e["roofline_bytes"]:
                 s[key]["train_MB"] = round(e["roofline_bytes"]["traffic"] / 1e6, 1)
     for key in ("K3_strong", "K3_shard_512"):

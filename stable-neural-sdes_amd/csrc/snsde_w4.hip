@@ -103,7 +103,9 @@ int snsde_w4_launch(const snsde_solve* s, const SnsdeNet& net, hipStream_t strea
 bool snsde_w4_rev_supported(const snsde_solve* s, const SnsdeNet& net) {
     // Euler: snsde_w4_euler_reverse_kernel (regenerates host-keyed Philox increments); SRK: snsde_w4_srk_reverse_kernel (reads the
     // increments and the stage states the forward wrote)
-    return (s->method == SNSDE_EULER || s->method == SNSDE_SRK) && snsde_w4::shape_ok(s, net) && !s->seed_dev;
+    // (a device-resident Philox key - graph replays - cannot be regenerated from: the forward then leaves its increments in dW_out,
+    //  snsde_mfma_backward_launch refuses the launch without them)
+    return (s->method == SNSDE_EULER || s->method == SNSDE_SRK) && snsde_w4::shape_ok(s, net);
 }
 
 size_t snsde_w4_grad_floats(const snsde_solve* s) {      // per-tile gradient blocks + the stage-1 sums of the reduction

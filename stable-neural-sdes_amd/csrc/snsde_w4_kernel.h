@@ -841,6 +841,8 @@ __host__ __device__ constexpr int w4g_d_time(int NHID) { return (NHID + 2) * w4g
 __host__ __device__ constexpr int w4g_n_off(int NHID, int e) { return w4g_d_time(NHID) + 128 + e * w4g_layer_floats(); }
 __host__ __device__ constexpr int w4g_n_time(int NHID, int NN) { return w4g_n_off(NHID, NN); }
 
+template <int V> using IC = std::integral_constant<int, V>;
+
 template <int ABID> __device__ __forceinline__ void outer4(const float (&in)[4], const float (&dl)[4], f32x4& acc) {
 #pragma unroll
     for (int i = 0; i < 4; ++i) acc = mfma_bk<ABID>(in[i], dl[i], acc);
@@ -852,6 +854,10 @@ __device__ __forceinline__ void outer64(const float (&in)[4], const float (&dl)[
 
 template <class CF, bool FUSED>
 __global__ void __launch_bounds__(FUSED ? 512 : 256, 2) snsde_w4_euler_reverse_kernel(W4RevArgs a) {
+#ifdef W4_TRACE
+    float tr_acc[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    long long tr_last = __builtin_readcyclecounter();
+#endif
     constexpr int H = 64, NHID = CF::NHID, NN = CF::NN;
     constexpr int ZSLOT = NHID + 1, NB0 = NHID + 2, ND = NHID + 2;
     constexpr int WPT = FUSED ? 4 : 2;                 // waves per tile
@@ -938,22 +944,50 @@ __global__ void __launch_bounds__(FUSED ? 512 : 256, 2) snsde_w4_euler_reverse_k
         float adj[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int i = 0; i < 4; ++i) rslot[i] = a.row_out ? a.row_out[row0 + i] : -1;
+        // gradient of the first output emitted after step n, fetched a step ahead (an exposed load at the top of every step otherwise:
+        // 2000 of a step's cycles); per-row outputs: the one (B, H) plane, resident
+        float gpre[4] = {0.f, 0.f, 0.f, 0.f};
+        // the step's scalars (h, its outputs and the first one's weights) likewise: a scalar-cache miss per step and a dependent one
+        // behind it, waited for at the step's first barrier; fetched behind that barrier for the step below
+        // (two stages, so that no load waits for another one inside the window: the table row two steps ahead, the output's weights
+        //  and gradient - addressed by that row - one step ahead)
+        float h_c, w0_c, w1_c, h_p = 0.0f;
+        int nout_c, kf_c, nout_p = 0, kf_p = 0;
+        auto load_row = [&](int n, float& h, int& nout, int& kf) {
+            CP st = step_tab_c + (size_t)n * SNSDE_STEP_STRIDE;
+            h = st[1]; nout = __float_as_int(st[8]); kf = __float_as_int(st[9]);
+        };
+        auto load_out = [&](int nout, int kf) {
+            const int kc = kf < a.T - 1 ? (kf < 0 ? 0 : kf) : a.T - 2;
+            w0_c = out_w_c[2 * kc]; w1_c = out_w_c[2 * kc + 1];
+            if (!a.row_out && nout > 0) load4(a.grad_ys + uoff(kf + 1, BH), gpre);
+        };
+        auto step_scalars = [&](int n) {      // behind the first barrier of step n + 1: everything the top of step n reads
+            h_c = h_p; nout_c = nout_p; kf_c = kf_p;
+            load_out(nout_c, kf_c);
+            if (n > 0) load_row(n - 1, h_p, nout_p, kf_p);
+        };
+        if (a.row_out) load4(a.grad_ys, gpre);
+        load_row(N - 1, h_c, nout_c, kf_c);
+        load_out(nout_c, kf_c);
+        if (N > 1) load_row(N - 2, h_p, nout_p, kf_p);
         float y[4], z[4], zn[4];
         load4(a.traj + uoff(N - 1, BH), y);
         load4(a.act + uoff(N - 1, SBH, ZSLOT, BH), z);
         for (int n = N - 1; n >= 0; --n) {
             if (n > 0) load4(a.act + uoff(n - 1, SBH, ZSLOT, BH), zn);      // next step's z: a full step ahead of its use
-            CP st = step_tab_c + (size_t)n * SNSDE_STEP_STRIDE;
-            const float h = st[1];
-            const int nout = __float_as_int(st[8]), kfirst = __float_as_int(st[9]);
+            const float h = h_c, w0f = w0_c, w1f = w1_c;
+            const int nout = nout_c, kfirst = kf_c;
             float carry[4] = {0.f, 0.f, 0.f, 0.f};
             for (int k = kfirst; k < kfirst + nout; ++k) {      // outputs emitted after step n: ys[k + 1] = y_{n+1} or w0 y_n + w1 y_{n+1}
-                const float w0 = out_w_c[2 * k], w1 = out_w_c[2 * k + 1];
+                const float w0 = k == kfirst ? w0f : out_w_c[2 * k], w1 = k == kfirst ? w1f : out_w_c[2 * k + 1];
                 float gk[4];
                 if (a.row_out) {
-                    load4(a.grad_ys, gk);
 #pragma unroll
-                    for (int i = 0; i < 4; ++i) gk[i] = rslot[i] == k + 1 ? gk[i] : 0.0f;
+                    for (int i = 0; i < 4; ++i) gk[i] = rslot[i] == k + 1 ? gpre[i] : 0.0f;
+                } else if (k == kfirst) {
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) gk[i] = gpre[i];
                 } else load4(a.grad_ys + uoff(k + 1, BH), gk);
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
@@ -962,7 +996,8 @@ __global__ void __launch_bounds__(FUSED ? 512 : 256, 2) snsde_w4_euler_reverse_k
                 }
             }
             put(XA, adj);
-            pair_barrier();                                     // B1: the net wave takes a_{n+1}
+            W4_T(0) pair_barrier(); W4_T(1)                                     // B1: the net wave takes a_{n+1}
+            if (n > 0) step_scalars(n - 1);
             if (!a.adj0_only) store4(a.adj + uoff(n + 1, BH), adj);
             // dz = a h (1 - f^2) {tanh y};  direct y term of the gated drift
             float dz[4], ay[4], zc[4], f[4], ty[4] = {1.f, 1.f, 1.f, 1.f};
@@ -1019,7 +1054,7 @@ __global__ void __launch_bounds__(FUSED ? 512 : 256, 2) snsde_w4_euler_reverse_k
 #pragma unroll
                 for (int i = 0; i < 4; ++i) od[i] = c[i] + d[i];
             }
-            pair_barrier();                                     // B2: the net chain's share of a_n
+            W4_T(2) pair_barrier(); W4_T(3)                                     // B2: the net chain's share of a_n
             float on[4];
             get(XN, on);
 #pragma unroll
@@ -1029,16 +1064,18 @@ __global__ void __launch_bounds__(FUSED ? 512 : 256, 2) snsde_w4_euler_reverse_k
         }
         {   // ys[0] = y0
             float g0[4];
-            load4(a.grad_ys, g0);
             if (a.row_out) {
 #pragma unroll
-                for (int i = 0; i < 4; ++i) g0[i] = rslot[i] == 0 ? g0[i] : 0.0f;
-            }
+                for (int i = 0; i < 4; ++i) g0[i] = rslot[i] == 0 ? gpre[i] : 0.0f;
+            } else load4(a.grad_ys, g0);
 #pragma unroll
             for (int i = 0; i < 4; ++i) adj[i] += g0[i];
             store4(a.adj, adj);
         }
         if (a.dth_part && live && lane < 3) a.dth_part[(size_t)tile * 4 + 1 + lane] = 0.0f;
+#ifdef W4_TRACE
+        if (blockIdx.x == 0 && pair == 0 && lane < 12 && !a.adj0_only) { float v = 0; for (int i = 0; i < 12; ++i) v = lane == i ? tr_acc[i] : v; a.adj[uoff(2, BH) + 0 * 64 + lane] = v; }
+#endif
     } else if (wave == 1) {
         // ================================ diffusion-net wave ================================
         float w1t[NN > 1 ? H : 1], w0t[H];
@@ -1079,7 +1116,7 @@ __global__ void __launch_bounds__(FUSED ? 512 : 256, 2) snsde_w4_euler_reverse_k
 #pragma unroll
             for (int i = 0; i < 4; ++i) { raw[i] = q[i] * (mul_y ? y[i] : 1.0f); g[i] = sig_theta * snsde_nan_to_num(raw[i]); }
             fast_tanh4(g);
-            pair_barrier();                                     // B1
+            W4_T(0) pair_barrier(); W4_T(1)                                     // B1
             float av[4], dq[4], dir[4], vt[4], v[4];
             get(XA, av);
 #pragma unroll
@@ -1113,7 +1150,7 @@ __global__ void __launch_bounds__(FUSED ? 512 : 256, 2) snsde_w4_euler_reverse_k
                 for (int i = 0; i < 4; ++i) on[i] = (c[i] + d[i]) + dir[i];
             }
             put(XN, on);
-            pair_barrier();                                     // B2
+            W4_T(2) pair_barrier(); W4_T(3)                                     // B2
 #pragma unroll
             for (int i = 0; i < 4; ++i) { y[i] = yn[i]; q[i] = qn[i]; hm[i] = hmn[i]; dw[i] = dwn[i]; }
         }
@@ -1122,6 +1159,9 @@ __global__ void __launch_bounds__(FUSED ? 512 : 256, 2) snsde_w4_euler_reverse_k
             for (int off = 32; off > 0; off >>= 1) th_acc += __shfl_down(th_acc, off, 64);
             if (lane == 0 && live) a.dth_part[(size_t)tile * 4] = th_acc;
         }
+#ifdef W4_TRACE
+        if (blockIdx.x == 0 && pair == 0 && lane < 12 && !a.adj0_only) { float v = 0; for (int i = 0; i < 12; ++i) v = lane == i ? tr_acc[i] : v; a.adj[uoff(2, BH) + 1 * 64 + lane] = v; }
+#endif
     } else if constexpr (FUSED) {
         // ================================ gradient waves: wave 2 the drift layers, wave 3 the net's ================================
         const bool dside = wave == 2;
@@ -1136,50 +1176,56 @@ __global__ void __launch_bounds__(FUSED ? 512 : 256, 2) snsde_w4_euler_reverse_k
         }
         // layer inputs of step n in the D layout: drift wave layer g reads act slot NHID - g (g <= NHID), the first layer the state y_n;
         // net: layer 0 of a two-layer net reads its hidden activation (slot ZSLOT + 1), the layer on [tau, y] the state
-        float in_cur[NLG][4], in_nxt[NLG][4];
-        auto fetch_in = [&](int n, float (&dst)[NLG][4]) {
+        float in_cur[NLG][4];
+        const int nl = dside ? ND : NN, p0 = dside ? 0 : ND;
+        auto fetch_in = [&](int n, auto gc) {
+            constexpr int g = decltype(gc)::value;
             if (dside) {
-#pragma unroll
-                for (int g = 0; g < ND; ++g) {
-                    if (g <= NHID) load4(a.act + uoff(n, SBH, (uint32_t)(NHID - g), BH), dst[g]);
-                    else load4(a.traj + uoff(n, BH), dst[g]);
-                }
-            } else {
-                if constexpr (NN == 2) load4(a.act + uoff(n, SBH, ZSLOT + 1, BH), dst[0]);
-                load4(a.traj + uoff(n, BH), dst[NN - 1]);
+                if constexpr (g <= NHID) load4(a.act + uoff(n, SBH, (uint32_t)(NHID - g), BH), in_cur[g]);
+                else if constexpr (g < ND) load4(a.traj + uoff(n, BH), in_cur[g]);
+            } else if constexpr (g < NN) {
+                if constexpr (NN == 2 && g == 0) load4(a.act + uoff(n, SBH, ZSLOT + 1, BH), in_cur[0]);
+                else load4(a.traj + uoff(n, BH), in_cur[NN - 1]);
             }
         };
-        auto accumulate = [&](int n) {
-            CP st = step_tab_c + (size_t)n * SNSDE_STEP_STRIDE;
+        // layer g of step m from in_cur; its input of step m - 1 is fetched in place as soon as the layer's MFMAs are issued
+        auto layer = [&](auto gc, int m, float sn, float cs) {
+            constexpr int g = decltype(gc)::value;
+            if (g < nl) {
+                float dl[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) dl[i] = dpl_all[pair][m & 1][p0 + g][i][lane];
+                outer64(in_cur[g], dl, acc[g], Seq{});
+                if (m > 0) fetch_in(m - 1, gc);
+                const float sum = (dl[0] + dl[1]) + (dl[2] + dl[3]);
+                bacc[g] += sum;
+                if (g == nl - 1) { tsn = fmaf(sum, sn, tsn); tcs = fmaf(sum, cs, tcs); }      // the layer on [tau, state]
+            }
+        };
+        auto accumulate = [&](int m) {
+            CP st = step_tab_c + (size_t)m * SNSDE_STEP_STRIDE;
             const float sn = st[2], cs = st[3];
-            const int nl = dside ? ND : NN, p0 = dside ? 0 : ND;
-#pragma unroll
-            for (int g = 0; g < NLG; ++g) {
-                if (g < nl) {
-                    float dl[4];
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) dl[i] = dpl_all[pair][n & 1][p0 + g][i][lane];
-                    outer64(in_cur[g], dl, acc[g], Seq{});
-                    const float sum = (dl[0] + dl[1]) + (dl[2] + dl[3]);
-                    bacc[g] += sum;
-                    if (g == nl - 1) { tsn = fmaf(sum, sn, tsn); tcs = fmaf(sum, cs, tcs); }      // the layer on [tau, state]
-                }
-            }
+            layer(IC<0>{}, m, sn, cs);
+            if constexpr (NLG > 1) layer(IC<1>{}, m, sn, cs);
+            if constexpr (NLG > 2) layer(IC<2>{}, m, sn, cs);
+            if constexpr (NLG > 3) layer(IC<3>{}, m, sn, cs);
         };
-        fetch_in(N - 1, in_cur);
-        for (int n = N - 1; n >= 0; --n) {
-            if (n > 0) fetch_in(n - 1, in_nxt);
-            pair_barrier();                                     // B1 (the deltas of step n are being written)
-            pair_barrier();                                     // B2: complete
-            accumulate(n);
-#pragma unroll
-            for (int g = 0; g < NLG; ++g)
-#pragma unroll
-                for (int i = 0; i < 4; ++i) in_cur[g][i] = in_nxt[g][i];
+        fetch_in(N - 1, IC<0>{});
+        if constexpr (NLG > 1) fetch_in(N - 1, IC<1>{});
+        if constexpr (NLG > 2) fetch_in(N - 1, IC<2>{});
+        if constexpr (NLG > 3) fetch_in(N - 1, IC<3>{});
+        // one step behind the chains: the sums of step n + 1 (its planes complete since B2 of that step, the other parity) while the
+        // drift / net waves walk step n
+        for (int n = N - 1; n >= -1; --n) {                     // (one call site: the accumulators stay in registers)
+            if (n >= 0) { W4_T(0) pair_barrier(); W4_T(1) }                     // B1
+            if (n < N - 1) accumulate(n + 1);
+            if (n >= 0) { W4_T(2) pair_barrier(); W4_T(3) }                     // B2
         }
+#ifdef W4_TRACE
+        if (blockIdx.x == 0 && pair == 0 && lane < 12 && !a.adj0_only) { float v = 0; for (int i = 0; i < 12; ++i) v = lane == i ? tr_acc[i] : v; a.adj[uoff(2, BH) + wave * 64 + lane] = v; }
+#endif
         if (live && a.gpart) {
             float* blk = a.gpart + (size_t)tile * w4g_block_floats(NHID, NN);
-            const int nl = dside ? ND : NN;
 #pragma unroll
             for (int g = 0; g < NLG; ++g) {
                 if (g < nl) {
@@ -1229,8 +1275,6 @@ struct W4SrkRevArgs {
     int32_t w_in, k_in, t_in, w_hid[3], w_out, w_n0, w_n1;
 };
 
-template <int V> using IC = std::integral_constant<int, V>;
-
 template <int NHID, int NN> __host__ __device__ constexpr int w4srk_rev_lds_floats() {
     return 2 * (6 * 256 + 2 * (3 * (NHID + 2) + 4 * NN) * 256 + (NHID >= 1 ? 16 * 256 : 0));
 }
@@ -1241,6 +1285,10 @@ template <int NHID_, int NN_, bool GEO_, bool MULY_> struct CfgSR { static const
 
 template <class CF>
 __global__ void __launch_bounds__(512, 2) snsde_w4_srk_reverse_kernel(W4SrkRevArgs a) {
+#ifdef W4_TRACE
+    float tr_acc[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    long long tr_last = __builtin_readcyclecounter();
+#endif
     constexpr int H = 64, NHID = CF::NHID, NN = CF::NN;
     constexpr bool geo = CF::GEO, mul_y = CF::MULY;
     constexpr int ZSLOT = NHID + 1, ND = NHID + 2, NP = 3;
@@ -1318,6 +1366,33 @@ __global__ void __launch_bounds__(512, 2) snsde_w4_srk_reverse_kernel(W4SrkRevAr
 #pragma unroll
         for (int i = 0; i < 4; ++i) rslot[i] = a.row_out ? a.row_out[row0 + i] : -1;
         float adj[4] = {0.f, 0.f, 0.f, 0.f};
+        // gradient of the first output emitted after step n, fetched a step ahead (an exposed load at the top of every step otherwise:
+        // 2000 of a step's cycles); per-row outputs: the one (B, H) plane, resident
+        float gpre[4] = {0.f, 0.f, 0.f, 0.f};
+        // the step's scalars (h, its outputs and the first one's weights) likewise: a scalar-cache miss per step and a dependent one
+        // behind it, waited for at the step's first barrier; fetched behind that barrier for the step below
+        // (two stages, so that no load waits for another one inside the window: the table row two steps ahead, the output's weights
+        //  and gradient - addressed by that row - one step ahead)
+        float h_c, w0_c, w1_c, h_p = 0.0f;
+        int nout_c, kf_c, nout_p = 0, kf_p = 0;
+        auto load_row = [&](int n, float& h, int& nout, int& kf) {
+            CP st = step_tab_c + (size_t)n * SNSDE_STEP_STRIDE;
+            h = st[1]; nout = __float_as_int(st[8]); kf = __float_as_int(st[9]);
+        };
+        auto load_out = [&](int nout, int kf) {
+            const int kc = kf < a.T - 1 ? (kf < 0 ? 0 : kf) : a.T - 2;
+            w0_c = out_w_c[2 * kc]; w1_c = out_w_c[2 * kc + 1];
+            if (!a.row_out && nout > 0) load4(a.grad_ys + uoff(kf + 1, BH), gpre);
+        };
+        auto step_scalars = [&](int n) {      // behind the first barrier of step n + 1: everything the top of step n reads
+            h_c = h_p; nout_c = nout_p; kf_c = kf_p;
+            load_out(nout_c, kf_c);
+            if (n > 0) load_row(n - 1, h_p, nout_p, kf_p);
+        };
+        if (a.row_out) load4(a.grad_ys, gpre);
+        load_row(N - 1, h_c, nout_c, kf_c);
+        load_out(nout_c, kf_c);
+        if (N > 1) load_row(N - 2, h_p, nout_p, kf_p);
         float z[3][4], h0[geo ? 3 : 1][4];
         auto fetch = [&](int n, auto sc) {
             constexpr int s2 = decltype(sc)::value;
@@ -1328,17 +1403,18 @@ __global__ void __launch_bounds__(512, 2) snsde_w4_srk_reverse_kernel(W4SrkRevAr
         for (int i = 0; i < 4; ++i) h0[0][i] = 0.0f;
         fetch(N - 1, IC<0>{}); fetch(N - 1, IC<1>{}); fetch(N - 1, IC<2>{});
         for (int n = N - 1; n >= 0; --n) {
-            CP st = step_tab_c + (size_t)n * SNSDE_STEP_STRIDE;
-            const float h = st[1];
-            const int nout = __float_as_int(st[8]), kfirst = __float_as_int(st[9]);
+            const float h = h_c, w0f = w0_c, w1f = w1_c;
+            const int nout = nout_c, kfirst = kf_c;
             float carry[4] = {0.f, 0.f, 0.f, 0.f};
             for (int k = kfirst; k < kfirst + nout; ++k) {
-                const float w0 = out_w_c[2 * k], w1 = out_w_c[2 * k + 1];
+                const float w0 = k == kfirst ? w0f : out_w_c[2 * k], w1 = k == kfirst ? w1f : out_w_c[2 * k + 1];
                 float gk[4];
                 if (a.row_out) {
-                    load4(a.grad_ys, gk);
 #pragma unroll
-                    for (int i = 0; i < 4; ++i) gk[i] = rslot[i] == k + 1 ? gk[i] : 0.0f;
+                    for (int i = 0; i < 4; ++i) gk[i] = rslot[i] == k + 1 ? gpre[i] : 0.0f;
+                } else if (k == kfirst) {
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) gk[i] = gpre[i];
                 } else load4(a.grad_ys + uoff(k + 1, BH), gk);
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
@@ -1359,7 +1435,8 @@ __global__ void __launch_bounds__(512, 2) snsde_w4_srk_reverse_kernel(W4SrkRevAr
                 }
                 put(XA, adj); put(XM, msk);
             }
-            pair_barrier();                                     // B0: the net wave takes a_{n+1} and its masks
+            W4_T(0) pair_barrier(); W4_T(1)                                     // B0: the net wave takes a_{n+1} and its masks
+            if (n > 0) step_scalars(n - 1);
             if (!a.adj0_only) store4(a.adj + uoff(n + 1, BH), adj);
             float yb[4], fb0[4], fb1[4], fb2[4], hb[4], dr[4];
 #pragma unroll
@@ -1422,14 +1499,14 @@ __global__ void __launch_bounds__(512, 2) snsde_w4_srk_reverse_kernel(W4SrkRevAr
 #pragma unroll
                 for (int i = 0; i < 4; ++i) out[i] = (c[i] + d[i]) + dd[i];
             };
-            pair_barrier();                                     // B1: G3's chain is done
+            W4_T(2) pair_barrier(); W4_T(3)                                     // B1: G3's chain is done
             get(XH + 1, hb);
 #pragma unroll
             for (int i = 0; i < 4; ++i) { yb[i] += hb[i]; fb2[i] = fmaf(0.25f * h, hb[i], fb2[i]); }
             // ---- drift pass 2 beside G2 ----
             drift_pass(IC<2>{}, fb2, dr);
             put(XD, dr);
-            pair_barrier();                                     // B2
+            W4_T(4) pair_barrier(); W4_T(5)                                     // B2
             get(XH, hb);
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
@@ -1438,7 +1515,7 @@ __global__ void __launch_bounds__(512, 2) snsde_w4_srk_reverse_kernel(W4SrkRevAr
             }
             // ---- drift pass 1 beside G1 ----
             drift_pass(IC<1>{}, fb1, dr);
-            pair_barrier();                                     // B3
+            W4_T(6) pair_barrier(); W4_T(7)                                     // B3
             get(XH + 1, hb);
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
@@ -1447,23 +1524,25 @@ __global__ void __launch_bounds__(512, 2) snsde_w4_srk_reverse_kernel(W4SrkRevAr
             }
             // ---- drift pass 0 beside G0 ----
             drift_pass(IC<0>{}, fb0, dr);
-            pair_barrier();                                     // B4
+            W4_T(8) pair_barrier(); W4_T(9)                                     // B4
             get(XH, hb);
 #pragma unroll
             for (int i = 0; i < 4; ++i) adj[i] = yb[i] + hb[i] + dr[i];
         }
         {
             float g0[4];
-            load4(a.grad_ys, g0);
             if (a.row_out) {
 #pragma unroll
-                for (int i = 0; i < 4; ++i) g0[i] = rslot[i] == 0 ? g0[i] : 0.0f;
-            }
+                for (int i = 0; i < 4; ++i) g0[i] = rslot[i] == 0 ? gpre[i] : 0.0f;
+            } else load4(a.grad_ys, g0);
 #pragma unroll
             for (int i = 0; i < 4; ++i) adj[i] += g0[i];
             store4(a.adj, adj);
         }
         if (a.dth_part && live && lane < 3) a.dth_part[(size_t)tile * 4 + 1 + lane] = 0.0f;
+#ifdef W4_TRACE
+        if (blockIdx.x == 0 && pair == 0 && lane < 12 && !a.adj0_only) { float v = 0; for (int i = 0; i < 12; ++i) v = lane == i ? tr_acc[i] : v; a.adj[uoff(2, BH) + 0 * 64 + lane] = v; }
+#endif
     } else if (wave == 1) {
         // ================================ net wave: Gbar_e, the four net chains ================================
         float w1t[NN > 1 ? H : 1], w0t[H];
@@ -1483,9 +1562,9 @@ __global__ void __launch_bounds__(512, 2) snsde_w4_srk_reverse_kernel(W4SrkRevAr
         fetch(N - 1, IC<0>{}); fetch(N - 1, IC<1>{}); fetch(N - 1, IC<2>{}); fetch(N - 1, IC<3>{});
         load4(a.dW + uoff(N - 1, BH), ik);
         load4(a.dU + uoff(N - 1, BH), ik0);
+        float h_c = (step_tab_c + (size_t)(N - 1) * SNSDE_STEP_STRIDE)[1], rdt_c = (step_tab_c + (size_t)(N - 1) * SNSDE_STEP_STRIDE)[6];
         for (int n = N - 1; n >= 0; --n) {
-            CP st = step_tab_c + (size_t)n * SNSDE_STEP_STRIDE;
-            const float h = st[1], rdt = st[6];
+            const float h = h_c, rdt = rdt_c;
             const float rh = 1.0f / h, rrdt = 1.0f / rdt;
             float wg[4][4], ik0h[4];
 #pragma unroll
@@ -1500,7 +1579,11 @@ __global__ void __launch_bounds__(512, 2) snsde_w4_srk_reverse_kernel(W4SrkRevAr
                 wg[3][i] = a4;
             }
             if (n > 0) { load4(a.dW + uoff(n - 1, BH), ik); load4(a.dU + uoff(n - 1, BH), ik0); }
-            pair_barrier();                                     // B0
+            W4_T(0) pair_barrier(); W4_T(1)                                     // B0
+            if (n > 0) {      // (the scalars of the step below: see the drift wave)
+                CP st = step_tab_c + (size_t)(n - 1) * SNSDE_STEP_STRIDE;
+                h_c = st[1]; rdt_c = st[6];
+            }
             float msk[4], gb[4][4], hb[4];
             {
                 float av[4];
@@ -1560,13 +1643,13 @@ __global__ void __launch_bounds__(512, 2) snsde_w4_srk_reverse_kernel(W4SrkRevAr
                 gb[0][i] = fmaf(-5.0f * rdt, hb[i], gb[0][i]); gb[1][i] = fmaf(3.0f * rdt, hb[i], gb[1][i]); gb[2][i] = fmaf(0.5f * rdt, hb[i], gb[2][i]);
             }
             put(XH + 1, hb);
-            pair_barrier();                                     // B1
+            W4_T(2) pair_barrier(); W4_T(3)                                     // B1
             // ---- G2 beside drift pass 2 ----
             net_eval(IC<2>{}, hb);
 #pragma unroll
             for (int i = 0; i < 4; ++i) gb[0][i] = fmaf(-rdt, hb[i], gb[0][i]);
             put(XH, hb);
-            pair_barrier();                                     // B2
+            W4_T(4) pair_barrier(); W4_T(5)                                     // B2
             {
                 float dr[4];
                 get(XD, dr);
@@ -1578,17 +1661,20 @@ __global__ void __launch_bounds__(512, 2) snsde_w4_srk_reverse_kernel(W4SrkRevAr
 #pragma unroll
             for (int i = 0; i < 4; ++i) gb[0][i] = fmaf(0.5f * rdt, hb[i], gb[0][i]);
             put(XH + 1, hb);
-            pair_barrier();                                     // B3
+            W4_T(6) pair_barrier(); W4_T(7)                                     // B3
             // ---- G0 beside drift pass 0 ----
             net_eval(IC<0>{}, hb);
             put(XH, hb);
-            pair_barrier();                                     // B4
+            W4_T(8) pair_barrier(); W4_T(9)                                     // B4
         }
         if (a.dth_part) {
 #pragma unroll
             for (int off = 32; off > 0; off >>= 1) th_acc += __shfl_down(th_acc, off, 64);
             if (lane == 0 && live) a.dth_part[(size_t)tile * 4] = th_acc;
         }
+#ifdef W4_TRACE
+        if (blockIdx.x == 0 && pair == 0 && lane < 12 && !a.adj0_only) { float v = 0; for (int i = 0; i < 12; ++i) v = lane == i ? tr_acc[i] : v; a.adj[uoff(2, BH) + 1 * 64 + lane] = v; }
+#endif
     } else {
         // ================================ gradient waves: wave 2 the drift layers, wave 3 the net's ================================
         const bool dside = wave == 2;
@@ -1651,17 +1737,23 @@ __global__ void __launch_bounds__(512, 2) snsde_w4_srk_reverse_kernel(W4SrkRevAr
         if constexpr (NLG > 3) fetch_in(pm, pu, IC<3>{});
         for (int n = N - 1; n >= 0; --n) {
             const bool work = n < N - 1;                        // the units of step n + 1 (complete since its B4)
-            pair_barrier();                                     // B0
+            W4_T(0) pair_barrier(); W4_T(1)                                     // B0
             if (work && !dside) unit();
-            pair_barrier();                                     // B1
+            W4_T(2) pair_barrier(); W4_T(3)                                     // B1
             if (work) unit();
-            pair_barrier();                                     // B2
+            W4_T(4) pair_barrier(); W4_T(5)                                     // B2
             if (work) unit();
-            pair_barrier();                                     // B3
+            W4_T(6) pair_barrier(); W4_T(7)                                     // B3
             if (work) unit();
-            pair_barrier();                                     // B4
+            W4_T(8) pair_barrier(); W4_T(9)                                     // B4
         }
         for (int u = 0; u < nunits; ++u) unit();               // step 0
+#ifdef W4_TRACE
+        W4_T(10)
+#endif
+#ifdef W4_TRACE
+        if (blockIdx.x == 0 && pair == 0 && lane < 12 && !a.adj0_only) { float v = 0; for (int i = 0; i < 12; ++i) v = lane == i ? tr_acc[i] : v; a.adj[uoff(2, BH) + wave * 64 + lane] = v; }
+#endif
         if (live && a.gpart) {
             float* blk = a.gpart + (size_t)tile * w4g_block_floats(NHID, NN);
 #pragma unroll

@@ -248,8 +248,8 @@ def test_w4_adjoint_with_in_kernel_philox_and_row_outputs_equals_the_tile_adjoin
 
 
 def test_fused_weight_gradients_need_no_delta_planes_and_fall_back_with_them():
-    """snsde_save_layout reports delta_slots = 0 where the wave-pair adjoint sums the weight gradients itself (auto / w4, host Philox
-    key); the 4-row-tile selector and a device-resident key keep their delta planes.  Through the engine's two-call form
+    """snsde_save_layout reports delta_slots = 0 where the wave-pair adjoint sums the weight gradients itself (auto / w4, host or
+    device-resident Philox key); the 4-row-tile selector keeps its delta planes.  Through the engine's two-call form
     (solve_backward + param_gradients) and the one-call form: same flat gradient as the tile path."""
     io, no, NL, B, C, L, H = 3, 18, 2, 37, 5, 9, 64
     pr = make_problem(9600, io, no, NL, B, H, C, L)
@@ -270,10 +270,14 @@ def test_fused_weight_gradients_need_no_delta_planes_and_fall_back_with_them():
         adj1, one = S.engine.backward_with_gradients(call, g)
         assert torch.equal(adj, adj1) and torch.equal(one, two)
         grads[kernel] = one
+    # device-resident key (graph replays): the same adjoint, reading the increments the forward left in dW_out
     seed_dev = torch.tensor([11], dtype=torch.int64, device=DEV)
     call = S.engine.SolveCall(model, flat, *args, seed=seed_dev, save_traj=True, save_dW=True, save_act=True)
-    assert call.delta_slots > 0                                   # device-resident key: the tile adjoint
+    call.launch()
+    assert call.delta_slots == 0
+    grads['device key'] = S.engine.backward_with_gradients(call, g)[1]
     ref = grads['mfma4']
+    assert float((grads['device key'] - ref).abs().max()) <= 5e-5 * float(ref.abs().max())
     for k in ('auto', 'w4'):
         assert float((grads[k] - ref).abs().max()) <= 5e-5 * float(ref.abs().max()), k
     assert float(ref.abs().max()) > 0
