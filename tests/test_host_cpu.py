@@ -1094,6 +1094,30 @@ def test_memoised_mapping_does_not_travel_and_follows_rebound_functions():
     assert cf3 is not None and cf3 is not cf and cf3.parts['linears'][0] is m.linears[0]
 
 
+def test_param_index_follows_replaced_layers_and_added_parameters():
+    """engine.param_index caches the parameter lists on the module and validates them against the module TREE: a replaced
+    submodule (its old _parameters dict still holds the old tensors), a re-assigned, an added or a removed parameter rebuild it."""
+    m = S.Diffusion_model(3, 16, 16, 2, input_option=3, noise_option=18)
+    layout, _ = S.engine._lib.param_layout(S.engine.model_struct(3, 16, 16, 2, 3, 18))
+    idx = S.engine.param_index(m, layout)
+    assert S.engine.param_index(m, layout) is idx
+    m.linears[0] = torch.nn.Linear(16, 16)
+    idx2 = S.engine.param_index(m, layout)
+    assert idx2 is not idx and any(p is m.linears[0].weight for p in idx2.params)
+    m.linear_out.weight = torch.nn.Parameter(torch.zeros_like(m.linear_out.weight))
+    idx3 = S.engine.param_index(m, layout)
+    assert idx3 is not idx2 and any(p is m.linear_out.weight for p in idx3.params)
+    assert idx3.valid(m, layout)
+    m.register_parameter('extra', torch.nn.Parameter(torch.zeros(2)))      # (such a module is no longer the reference's: recognise() refuses it)
+    assert not idx3.valid(m, layout)
+    del m._parameters['extra']
+    assert idx3.valid(m, layout)
+    m.add_module('aux', torch.nn.Linear(2, 2))
+    assert not idx3.valid(m, layout)
+    del m._modules['aux']
+    assert idx3.valid(m, layout) and S.engine.param_index(m, layout) is idx3
+
+
 def test_every_step_grid_outputs_every_state_of_the_same_steps():
     """engine.every_step_grid: the caller's solver steps, one exact output after each (the LatentSDE split solve reads the whole
     trajectory through it)."""
