@@ -258,9 +258,9 @@ SNSDE_API int    snsde_save_layout(const snsde_solve* s, int32_t* act_slots, int
                                                           /* (drift input H0 | diffusion input H1 | H1 of the fourth evaluation);  */
                                                           /* delta_save is (passes, delta_slots, B, H): act_slots, plus the tangent */
                                                           /* factors of Milstein through a diffusion net; delta_slots == 0: the      */
-                                                          /* adjoint of this solve accumulates the weight gradients itself (Euler,   */
-                                                          /* H = 64 with a diffusion net: per-tile sums in the backward workspace),  */
-                                                          /* delta_save is not written and may be NULL                               */
+                                                          /* adjoint of this solve accumulates the weight gradients itself (Euler /  */
+                                                          /* SRK at H = 64 with a diffusion net: per-tile sums in the backward       */
+                                                          /* workspace), delta_save is not written and may be NULL                   */
 SNSDE_API int    snsde_backward_supported(const snsde_solve* s);    /* 1 / 2 / 0, see above                          */
 SNSDE_API size_t snsde_backward_workspace_bytes(const snsde_backward* b);
 /* INVARIANT between forward and backward (mode 1): `fwd.workspace` is untouched AND `fwd.params` holds the values the forward ran
@@ -322,7 +322,7 @@ enum { SNSDE_PATH_NONE = 0,          /* no kernel: snsde_solve_forward returns S
        SNSDE_PATH_LEAN_STREAMED = 5, /* MFMA, 4-row tiles, lean kernel with L2 -> LDS streamed weights (H = 256)     */
        SNSDE_PATH_GENERIC_SRK = 6,   /* SRK on the generic family                                                   */
        SNSDE_PATH_MFMA_SRK = 7,      /* SRK on the MFMA 4-row tiles                                                 */
-       SNSDE_PATH_MFMA_W4 = 8 };     /* MFMA, 4 rows per wave pair (csrc/snsde_w4_kernel.h: H = 64, diffusion nets, Euler) */
+       SNSDE_PATH_MFMA_W4 = 8 };     /* MFMA, 4 rows per wave pair (csrc/snsde_w4_kernel.h: H = 64, diffusion nets, Euler / SRK) */
 SNSDE_API int snsde_forward_path(const snsde_solve* s);
 
 /* Readout head of the wrappers in one launch (inference; replaces the 4-5 tensor ops of `self.linear(z)`,

@@ -114,6 +114,10 @@ if __name__ == '__main__':
                     check_resources=False))
     elif len(sys.argv) > 1 and sys.argv[1] == 'w4trace':
         print(build(force=True, defines=('-DW4_TRACE', '-DSNSDE_DEV_SUBSET'), out=os.path.join(HERE, 'libsnsde_w4trace.so'), check_resources=False))
+    elif len(sys.argv) > 2 and sys.argv[1] == 'variant':
+        # development experiments: python build.py variant NAME -DFLAG ... -> libsnsde_NAME.so (headline / K4 instantiations only)
+        print(build(force=True, defines=tuple(sys.argv[3:]) + ('-DSNSDE_DEV_SUBSET',), out=os.path.join(HERE, f'libsnsde_{sys.argv[2]}.so'),
+                    check_resources=False))
     elif len(sys.argv) > 1 and sys.argv[1] == 'inc':
         print(build(force=True, verbose=True, incremental=True))
     elif len(sys.argv) > 1 and sys.argv[1] == 'devtuning':

@@ -22,8 +22,16 @@ template <int NHID, int NN, bool TIME>
 static int launch(const W4Args& a, hipStream_t st) {
     const dim3 grid((a.B + 7) / 8), block(256);
     if (a.srk_tab) {
-        if (a.act_save) hipLaunchKernelGGL((snsde_w4_srk_kernel<CfgW<NHID, NN, TIME, true>>), grid, block, 0, st, a);
-        else hipLaunchKernelGGL((snsde_w4_srk_kernel<CfgW<NHID, NN, TIME, false>>), grid, block, 0, st, a);
+        if (a.act_save) {      // (training mode parks the drift wave's first matrix: more than 64 KB of dynamic LDS)
+            const size_t lds_bytes = (size_t)w4srk_fwd_lds_floats<NHID, true>() * sizeof(float);
+            static SnsdeLdsAttr lds_attr;   // per instantiation and device
+            void (*kern)(W4Args) = snsde_w4_srk_kernel<CfgW<NHID, NN, TIME, true>>;
+            if (const int rc = snsde_lds_attr(reinterpret_cast<const void*>(kern), lds_bytes, lds_attr)) return rc;
+            hipLaunchKernelGGL(kern, grid, block, lds_bytes, st, a);
+        } else {
+            constexpr size_t lds_bytes = (size_t)w4srk_fwd_lds_floats<NHID, false>() * sizeof(float);
+            hipLaunchKernelGGL((snsde_w4_srk_kernel<CfgW<NHID, NN, TIME, false>>), grid, block, lds_bytes, st, a);
+        }
     } else if (a.act_save) hipLaunchKernelGGL((snsde_w4_euler_kernel<CfgW<NHID, NN, TIME, true>>), grid, block, 0, st, a);
     else hipLaunchKernelGGL((snsde_w4_euler_kernel<CfgW<NHID, NN, TIME, false>>), grid, block, 0, st, a);
     return hipGetLastError() == hipSuccess ? SNSDE_OK : SNSDE_ERR_LAUNCH;

@@ -204,6 +204,13 @@ __global__ void __launch_bounds__(256, 2) snsde_w4_euler_kernel(W4Args a) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) p[lo + (uint32_t)(i * H)] = v[i];
     };
+    // The hidden activations' training saves as ONE 16-byte store per lane instead of four 4-byte ones, same (B, H) row-major layout:
+    // in the transposed (A-operand) layout, which the next layer needs anyway, lane 4q + j holds row j, features 4q .. 4q + 3 - 16
+    // contiguous bytes of row j.  A store instruction costs the wave ~37 issue cycles whatever its width; planes that exist in the D
+    // layout only (z, q, the states) keep their four stores: the eight-DPP transpose costs more than it saves (measured: + 12 us).
+    const uint32_t lot = (uint32_t)((row0 + (lane & 3)) * H + (lane >> 2) * 4);
+    auto store4x = [&](float* p, const float (&t)[4]) { *reinterpret_cast<float4*>(p + lot) = float4{t[0], t[1], t[2], t[3]}; };
+    auto save_x = [&](int n, int slot, const float (&t)[4]) { store4x(a.act_save + uoff(n, (uint32_t)a.nsave * BH, (uint32_t)slot, BH), t); };
     auto save = [&](int n, int slot, const float (&v)[4]) { store4(a.act_save + uoff(n, (uint32_t)a.nsave * BH, (uint32_t)slot, BH), v); };
     // relu epilogue of a hidden layer: v = relu(c + d) in the D layout (the bias came in through c), transposed into the next
     // layer's A layout; sign bit `bit` of every row's word
@@ -228,6 +235,7 @@ __global__ void __launch_bounds__(256, 2) snsde_w4_euler_kernel(W4Args a) {
     };
     if (wave == 0) {
         // ================================ drift wave ================================
+        // (parking the first matrix in LDS as the SRK kernel does in training mode: 112 -> 114 us here, nothing spills)
         float wi[CF::KIN], wh[NHID > 0 ? NHID : 1][H], wo[H], bi, bh[NHID > 0 ? NHID : 1], bo;
         {
             const float* w = P + a.w_in + (size_t)lane * CF::KIN;
@@ -276,7 +284,7 @@ __global__ void __launch_bounds__(256, 2) snsde_w4_euler_kernel(W4Args a) {
                 }
                 relu_hand_off(c, d, v, vt);
                 if constexpr (CF::SAVE) {
-                    save(n, 0, v);
+                    save_x(n, 0, vt);
 #pragma unroll
                     for (int i = 0; i < 4; ++i) sgn[i] = v[i] > 0.0f ? 1u : 0u;
                 }
@@ -288,7 +296,7 @@ __global__ void __launch_bounds__(256, 2) snsde_w4_euler_kernel(W4Args a) {
                 gemm64(vt, wh[l], c, d, Seq{});
                 relu_hand_off(c, d, v, vt);
                 if constexpr (CF::SAVE) {
-                    save(n, 1 + l, v);
+                    save_x(n, 1 + l, vt);
 #pragma unroll
                     for (int i = 0; i < 4; ++i) sgn[i] |= (v[i] > 0.0f ? 1u : 0u) << (1 + l);
                 }
@@ -402,7 +410,7 @@ __global__ void __launch_bounds__(256, 2) snsde_w4_euler_kernel(W4Args a) {
                 d = mfma_bk<0>(cur.cs, wn0[65], d);
                 if constexpr (NN == 2) {
                     relu_hand_off(c, d, v, vt);
-                    if constexpr (CF::SAVE) save(n, CF::ZSLOT + 1, v);
+                    if constexpr (CF::SAVE) save_x(n, CF::ZSLOT + 1, vt);
                 } else {
 #pragma unroll
                     for (int i = 0; i < 4; ++i) q[i] = c[i] + d[i];
@@ -456,6 +464,8 @@ __global__ void __launch_bounds__(256, 2) snsde_w4_euler_kernel(W4Args a) {
 // signs of the net evaluation beside it / of the fourth evaluation in the low bits of the saved z, stage_save planes H0 | H1 | H1_3):
 // the adjoint (snsde_m4n_rev_kernel.h) and the weight-gradient pass are unchanged.
 // =====================================================================================================================================
+template <int NHID, bool SAVE> __host__ __device__ constexpr int w4srk_fwd_lds_floats() { return 2 * 12 * 256 + 2 * 4096 + ((SAVE && NHID >= 1) ? 2 * 4096 : 0); }
+
 template <class CF>
 __global__ void __launch_bounds__(256, 2) snsde_w4_srk_kernel(W4Args a) {
     constexpr int H = 64, NHID = CF::NHID, NN = CF::NN;
@@ -465,14 +475,20 @@ __global__ void __launch_bounds__(256, 2) snsde_w4_srk_kernel(W4Args a) {
     using Seq = std::make_integer_sequence<int, 16>;
     // exchange planes of a pair: F0 F1 F2 | G0 G1 | I_k0 | y' | hidden-sign words of G0..G3 (training)
     enum { XF0 = 0, XF1, XF2, XG0, XG1, XDU, XY, XS0, XS1, XS2, XS3, XN };
-    __shared__ float xchg_all[2][XN][4][H];
-    __shared__ float zstash_all[2][2][2][4][4][H];     // [pair][stream: I_k, xi][block parity][row][step of the block][feature]
+    static_assert(XN <= 12, "w4srk_fwd_lds_floats");
+    // dynamic LDS: exchange planes [pair][XN][4][H] | Philox stash [pair][stream: I_k, xi][block parity][row][step of the block][feature]
+    // | training mode with a hidden drift layer: the drift wave's first matrix, parked (see snsde_w4_euler_kernel: 19 - 23 spilled
+    // registers, seventeen scratch reloads per step each waiting behind the step's save stores - that, not the stores themselves, was
+    // the "cost of the saves": 483 -> 40x us)
+    constexpr bool PARK = SAVE && NHID >= 1;
+    extern __shared__ __attribute__((aligned(16))) float w4srk_fwd_lds[];
 
     const int lane = threadIdx.x & 63;
     const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int wave = wv & 1, pair = wv >> 1;
-    float (*xchg)[4][H] = xchg_all[pair];
-    float (*zstash)[2][4][4][H] = zstash_all[pair];
+    float (*xchg)[4][H] = reinterpret_cast<float (*)[4][H]>(w4srk_fwd_lds + pair * XN * 256);
+    float (*zstash)[2][4][4][H] = reinterpret_cast<float (*)[2][4][4][H]>(w4srk_fwd_lds + 2 * XN * 256 + pair * 4096);
+    float* wpark = w4srk_fwd_lds + 2 * XN * 256 + 2 * 4096 + pair * 4096;      // [16][64][4]
     const int B = a.B;
     const int row_t = (blockIdx.x * 2 + pair) * 4;
     const int row0 = row_t + 4 <= B ? row_t : B - 4;       // (ragged tail: see snsde_w4_euler_kernel)
@@ -485,6 +501,11 @@ __global__ void __launch_bounds__(256, 2) snsde_w4_srk_kernel(W4Args a) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) p[lo + (uint32_t)(i * H)] = v[i];
     };
+    // 16-byte stores of the values that exist in the transposed layout anyway (see snsde_w4_euler_kernel): hidden activations and
+    // the stage states (each is the operand of the evaluation it feeds)
+    const uint32_t lot = (uint32_t)((row0 + (lane & 3)) * H + (lane >> 2) * 4);
+    auto store4x = [&](float* p, const float (&t)[4]) { *reinterpret_cast<float4*>(p + lot) = float4{t[0], t[1], t[2], t[3]}; };
+    auto save_x = [&](int pass, int slot, const float (&t)[4]) { store4x(a.act_save + uoff(pass, (uint32_t)NSAVE * BH, (uint32_t)slot, BH), t); };
     auto save = [&](int pass, int slot, const float (&v)[4]) { store4(a.act_save + uoff(pass, (uint32_t)NSAVE * BH, (uint32_t)slot, BH), v); };
     auto put = [&](int plane, const float (&v)[4]) {
 #pragma unroll
@@ -507,12 +528,16 @@ __global__ void __launch_bounds__(256, 2) snsde_w4_srk_kernel(W4Args a) {
 
     if (wave == 0) {
         // ================================ drift wave ================================
-        float wi[CF::KIN], wh[NHID > 0 ? NHID : 1][H], wo[H], bi, bh[NHID > 0 ? NHID : 1], bo;
+        float wi[PARK ? 1 : H], wt0 = 0.0f, wt1 = 0.0f, wh[NHID > 0 ? NHID : 1][H], wo[H], bi, bh[NHID > 0 ? NHID : 1], bo;
+        const float* wil = wpark + lane * 4;
         {
             const float* w = P + a.w_in + (size_t)lane * CF::KIN;
 #pragma unroll
-            for (int k = 0; k < H; ++k) wi[k] = w[(TIME ? 2 : 0) + k];
-            if constexpr (TIME) { wi[64] = w[0]; wi[65] = w[1]; }
+            for (int k = 0; k < H; ++k) {
+                if constexpr (PARK) wpark[(k >> 2) * 256 + lane * 4 + (k & 3)] = w[(TIME ? 2 : 0) + k];
+                else wi[k] = w[(TIME ? 2 : 0) + k];
+            }
+            if constexpr (TIME) { wt0 = w[0]; wt1 = w[1]; }
             bi = P[a.b_in + lane];
 #pragma unroll
             for (int l = 0; l < NHID; ++l) {
@@ -527,18 +552,19 @@ __global__ void __launch_bounds__(256, 2) snsde_w4_srk_kernel(W4Args a) {
             bo = P[a.b_out + lane];
         }
         const bool geo = a.geo != 0;
-        if constexpr (SAVE) { if (a.stage_save) store4(a.stage_save, y); }
         // one drift evaluation at (sn, cs) on the state `x` (D layout): f into `f`, training: act_save slots of `pass`, z (kept) and signs
         auto drift = [&](const float (&x)[4], float sn, float cs, int pass, float (&f)[4], float (&z)[4], uint32_t (&sgn)[4]) {
             float xt[4], v[4], vt[4];
             quad_transpose(x, xt);
+            if constexpr (SAVE) { if (a.stage_save) store4x(a.stage_save + uoff(pass, NP * BH), xt); }      // H0 of the pass
             {
                 f32x4 c = {bi, bi, bi, bi}, d = {0.f, 0.f, 0.f, 0.f};
-                gemm64(xt, wi, c, d, Seq{});
-                if constexpr (TIME) { c = mfma_bk<0>(sn, wi[64], c); d = mfma_bk<0>(cs, wi[65], d); }
+                if constexpr (PARK) gemm64_lds(xt, wil, c, d, Seq{});
+                else gemm64(xt, wi, c, d, Seq{});
+                if constexpr (TIME) { c = mfma_bk<0>(sn, wt0, c); d = mfma_bk<0>(cs, wt1, d); }
                 relu_hand_off(c, d, v, vt);
                 if constexpr (SAVE) {
-                    save(pass, 0, v);
+                    save_x(pass, 0, vt);
 #pragma unroll
                     for (int i = 0; i < 4; ++i) sgn[i] = v[i] > 0.0f ? 1u : 0u;
                 }
@@ -549,7 +575,7 @@ __global__ void __launch_bounds__(256, 2) snsde_w4_srk_kernel(W4Args a) {
                 gemm64(vt, wh[l], c, d, Seq{});
                 relu_hand_off(c, d, v, vt);
                 if constexpr (SAVE) {
-                    save(pass, 1 + l, v);
+                    save_x(pass, 1 + l, vt);
 #pragma unroll
                     for (int i = 0; i < 4; ++i) sgn[i] |= (v[i] > 0.0f ? 1u : 0u) << (1 + l);
                 }
@@ -597,7 +623,6 @@ __global__ void __launch_bounds__(256, 2) snsde_w4_srk_kernel(W4Args a) {
             if constexpr (SAVE) save_z(3 * n, z, sgn, XS0, -1);
 #pragma unroll
             for (int i = 0; i < 4; ++i) x[i] = y[i] + f0[i] * h;                     // H0_1
-            if constexpr (SAVE) { if (a.stage_save) store4(a.stage_save + uoff(3 * n + 1, NP * BH), x); }
             // ---- pass 1: F1 at (t0 + h, H0_1) ----
             drift(x, s1, c1, 3 * n + 1, f1, z, sgn);
             put(XF1, f1);
@@ -606,7 +631,6 @@ __global__ void __launch_bounds__(256, 2) snsde_w4_srk_kernel(W4Args a) {
             if constexpr (SAVE) save_z(3 * n + 1, z, sgn, XS1, -1);
 #pragma unroll
             for (int i = 0; i < 4; ++i) x[i] = y[i] + 0.25f * f0[i] * h + 0.25f * f1[i] * h + (g0[i] + 0.5f * g1[i]) * (du[i] * rh);   // H0_2
-            if constexpr (SAVE) { if (a.stage_save) store4(a.stage_save + uoff(3 * n + 2, NP * BH), x); }
             // ---- pass 2: F2 at (t0 + h/2, H0_2) ----
             drift(x, s2, c2, 3 * n + 2, f2, z, sgn);
             put(XF2, f2);
@@ -614,6 +638,14 @@ __global__ void __launch_bounds__(256, 2) snsde_w4_srk_kernel(W4Args a) {
             pair_barrier();                                   // B4: the net wave's G3, the step's result
             get(XY, y);
             if constexpr (SAVE) save_z(3 * n + 2, z, sgn, XS2, XS3);
+        }
+        if constexpr (SAVE) {      // the final state's planes (pass 3N): what a further step's first evaluations would have written
+            if (a.stage_save) {
+                float yt[4];
+                quad_transpose(y, yt);
+                store4x(a.stage_save + uoff(3 * n_steps, NP * BH), yt);
+                store4x(a.stage_save + uoff(3 * n_steps, NP * BH, 1, BH), yt);
+            }
         }
     } else {
         // ================================ diffusion-net wave ================================
@@ -643,7 +675,6 @@ __global__ void __launch_bounds__(256, 2) snsde_w4_srk_kernel(W4Args a) {
             if (!a.row_out || rslot[i] == 0) a.ys[(size_t)(row0 + i) * H + lane] = y[i];
             if (a.traj) a.traj[(size_t)(row0 + i) * H + lane] = y[i];
         }
-        if constexpr (SAVE) { if (a.stage_save) store4(a.stage_save + BH, y); }
         // Philox: stream 0 = the increments' normals, stream 1 = xi of the space-time Levy area; step n refills row n & 3 of the next block
         auto refill = [&](int row_k, int blk) {
 #pragma unroll
@@ -663,6 +694,9 @@ __global__ void __launch_bounds__(256, 2) snsde_w4_srk_kernel(W4Args a) {
         auto net = [&](const float (&x)[4], float sn, float cs, int pass, int slot0, int splane, float (&g)[4]) {
             float xt[4], v[4], vt[4], q[4];
             quad_transpose(x, xt);
+            if constexpr (SAVE) {      // H1 of the evaluation (plane 1; the fourth evaluation of a step: plane 2 of pass 3n + 2)
+                if (a.stage_save) store4x(a.stage_save + uoff(pass, NP * BH, slot0 == ZSLOT + 1 ? 1u : 2u, BH), xt);
+            }
             {
                 f32x4 c = {b0, b0, b0, b0}, d = {0.f, 0.f, 0.f, 0.f};
                 gemm64(xt, wn0, c, d, Seq{});
@@ -671,7 +705,7 @@ __global__ void __launch_bounds__(256, 2) snsde_w4_srk_kernel(W4Args a) {
                 if constexpr (NN == 2) {
                     relu_hand_off(c, d, v, vt);
                     if constexpr (SAVE) {
-                        save(pass, slot0, v);
+                        save_x(pass, slot0, vt);
 #pragma unroll
                         for (int i = 0; i < 4; ++i) xchg[splane][i][lane] = __uint_as_float(v[i] > 0.0f ? 1u : 0u);
                     }
@@ -727,7 +761,6 @@ __global__ void __launch_bounds__(256, 2) snsde_w4_srk_kernel(W4Args a) {
             get(XF0, f0);
 #pragma unroll
             for (int i = 0; i < 4; ++i) x[i] = y[i] + 0.25f * f0[i] * h + 0.5f * g0[i] * sqh;      // H1_1
-            if constexpr (SAVE) { if (a.stage_save) store4(a.stage_save + uoff(3 * n + 1, NP * BH, 1, BH), x); }
             // ---- G1 at (t0 + h/4, H1_1) ----
             net(x, sq, cq, 3 * n + 1, ZSLOT + 1, XS1, g1);
             put(XG1, g1);
@@ -735,7 +768,6 @@ __global__ void __launch_bounds__(256, 2) snsde_w4_srk_kernel(W4Args a) {
             get(XF1, f1);
 #pragma unroll
             for (int i = 0; i < 4; ++i) x[i] = y[i] + f0[i] * h - g0[i] * sqh;                     // H1_2
-            if constexpr (SAVE) { if (a.stage_save) store4(a.stage_save + uoff(3 * n + 2, NP * BH, 1, BH), x); }
             // ---- G2 at (t0 + h, H1_2) ----
             net(x, s1, c1, 3 * n + 2, ZSLOT + 1, XS2, g2);
             // everything of the step's result that does not need F2 / G3, while the drift wave finishes F2 (same association as the
@@ -757,7 +789,6 @@ __global__ void __launch_bounds__(256, 2) snsde_w4_srk_kernel(W4Args a) {
             get(XF2, f2);
 #pragma unroll
             for (int i = 0; i < 4; ++i) x[i] = y[i] + 0.25f * f2[i] * h + (-5.0f * g0[i] + 3.0f * g1[i] + 0.5f * g2[i]) * sqh;   // H1_3
-            if constexpr (SAVE) { if (a.stage_save) store4(a.stage_save + uoff(3 * n + 2, NP * BH, 2, BH), x); }
             // ---- G3 at (t0 + h/4, H1_3), then the step ----
             net(x, sq, cq, 3 * n + 2, ZSLOT + NN + 1, XS3, g3);
             float yn[4];
@@ -769,9 +800,7 @@ __global__ void __launch_bounds__(256, 2) snsde_w4_srk_kernel(W4Args a) {
             }
             put(XY, yn);
             pair_barrier();                                   // B4
-            if constexpr (SAVE) {
-                if (a.stage_save) { store4(a.stage_save + uoff(3 * n + 3, NP * BH), yn); store4(a.stage_save + uoff(3 * n + 3, NP * BH, 1, BH), yn); }
-            }
+            // (the state planes of pass 3n + 3 are written by the next step's first evaluations; after the last step: below)
             if (a.traj) store4(a.traj + uoff(n + 1, BH), yn);
             if (a.dW_out) store4(a.dW_out + uoff(n, BH), ik);
             if (a.dU_out) store4(a.dU_out + uoff(n, BH), ik0);
@@ -1331,6 +1360,20 @@ __global__ void __launch_bounds__(512, 2) snsde_w4_srk_reverse_kernel(W4SrkRevAr
 #pragma unroll
         for (int i = 0; i < 4; ++i) p[lo + (uint32_t)(i * H)] = v[i];
     };
+    // the gradient waves read their layer inputs as ONE 16-byte load per lane (snsde_w4_euler_kernel: lane 4q + j takes row j, features
+    // 4q .. 4q + 3); the values arrive in the transposed layout and are turned (eight DPP moves) where the unit uses them - not
+    // behind the load, which is issued a unit ahead.  (The chain waves keep their four 4-byte loads: the transposes on their critical
+    // path cost more than the load slots they free - adjoint 519 -> 544 us with them.)
+    const uint32_t lot = (uint32_t)((row0 + (lane & 3)) * H + (lane >> 2) * 4);
+    auto load4x = [&](const float* p, float (&t)[4]) {
+        const float4 q4 = *reinterpret_cast<const float4*>(p + lot);
+        t[0] = q4.x; t[1] = q4.y; t[2] = q4.z; t[3] = q4.w;
+    };
+    auto store4t = [&](float* p, const float (&v)[4]) {
+        float t[4];
+        quad_transpose(v, t);
+        *reinterpret_cast<float4*>(p + lot) = float4{t[0], t[1], t[2], t[3]};
+    };
     auto put = [&](int plane, const float (&v)[4]) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) xchg[plane * 256 + i * 64 + lane] = v[i];
@@ -1437,7 +1480,7 @@ __global__ void __launch_bounds__(512, 2) snsde_w4_srk_reverse_kernel(W4SrkRevAr
             }
             W4_T(0) pair_barrier(); W4_T(1)                                     // B0: the net wave takes a_{n+1} and its masks
             if (n > 0) step_scalars(n - 1);
-            if (!a.adj0_only) store4(a.adj + uoff(n + 1, BH), adj);
+            if (!a.adj0_only) store4t(a.adj + uoff(n + 1, BH), adj);
             float yb[4], fb0[4], fb1[4], fb2[4], hb[4], dr[4];
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
@@ -1688,18 +1731,18 @@ __global__ void __launch_bounds__(512, 2) snsde_w4_srk_reverse_kernel(W4SrkRevAr
             for (int qq = 0; qq < 16; ++qq) acc[g][qq] = f32x4{0.f, 0.f, 0.f, 0.f};
         }
         const int nl = dside ? ND : NN, nunits = dside ? 3 : 4;       // layers per unit; units (drift passes / net evaluations) per step
-        float in_cur[NLG][4];
-        // input of layer g of unit u of step m (D layout): drift pass u: act slots NHID - g, the layer on [tau, state] the pass's state
+        float in_cur[NLG][4];      // (as loaded: transposed layout)
+        // input of layer g of unit u of step m: drift pass u: act slots NHID - g, the layer on [tau, state] the pass's state
         // H0_u; net evaluation u: its hidden activation (two-layer nets), the layer on [tau, state] the state H1_u
         auto fetch_in = [&](int m, int u, auto gc) {
             constexpr int g = decltype(gc)::value;
             if (dside) {
-                if constexpr (g <= NHID) load4(a.act + uoff(3 * m + u, SBH, (uint32_t)(NHID - g), BH), in_cur[g]);
-                else if constexpr (g < ND) load4(a.stage + uoff(3 * m + u, PBH), in_cur[g]);
+                if constexpr (g <= NHID) load4x(a.act + uoff(3 * m + u, SBH, (uint32_t)(NHID - g), BH), in_cur[g]);
+                else if constexpr (g < ND) load4x(a.stage + uoff(3 * m + u, PBH), in_cur[g]);
             } else if constexpr (g < NN) {
                 const int p = 3 * m + (u < 3 ? u : 2);
-                if constexpr (NN == 2 && g == 0) load4(a.act + uoff(p, SBH, (uint32_t)(u < 3 ? ZSLOT + 1 : ZSLOT + NN + 1), BH), in_cur[0]);
-                else load4(a.stage + uoff(p, PBH, u < 3 ? 1u : 2u, BH), in_cur[NN - 1]);
+                if constexpr (NN == 2 && g == 0) load4x(a.act + uoff(p, SBH, (uint32_t)(u < 3 ? ZSLOT + 1 : ZSLOT + NN + 1), BH), in_cur[0]);
+                else load4x(a.stage + uoff(p, PBH, u < 3 ? 1u : 2u, BH), in_cur[NN - 1]);
             }
         };
         // the walk over (step, unit), units of a step in the order the chains finish them; in_cur holds the inputs of (pm, pu): a
@@ -1711,7 +1754,9 @@ __global__ void __launch_bounds__(512, 2) snsde_w4_srk_reverse_kernel(W4SrkRevAr
                 float dl[4];
 #pragma unroll
                 for (int i = 0; i < 4; ++i) dl[i] = dpl[((pm & 1) * NDP + p0 + g) * 256 + i * 64 + lane];
-                outer64(in_cur[g], dl, acc[g], Seq{});
+                float ind[4];
+                quad_transpose(in_cur[g], ind);
+                outer64(ind, dl, acc[g], Seq{});
                 if (m2 >= 0) fetch_in(m2, u2, gc);
                 const float sum = (dl[0] + dl[1]) + (dl[2] + dl[3]);
                 bacc[g] += sum;

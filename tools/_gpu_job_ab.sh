@@ -1,31 +1,29 @@
 #!/bin/bash
 cd $GRAFT_REPO_ROOT
-O=gpurun_out/r05w; mkdir -p $O
-cat > /tmp/hp.py <<'PY'
-import os, sys, time, cProfile, pstats, io
+O=gpurun_out/r05A; mkdir -p $O
+timeout 600 python -m pytest tests/test_gpu_w4.py -x -q -m gpu > $O/w4_tests.log 2>&1 < /dev/null; echo "w4 tests rc=$?" >> $O/w4_tests.log
+tail -4 $O/w4_tests.log
+cat > /tmp/ab.py <<'PY'
+import os, sys
 sys.path.insert(0, os.environ['GRAFT_REPO_ROOT'])
 import numpy as np, torch
 import bench, stable_neural_sdes_amd as S
 dev = torch.device('cuda:0'); stream = torch.cuda.current_stream(dev)
 sde, times, y0 = bench._module(dev, 3, 18, 2048, 64, 69, 72, 77)
 params = list(sde.parameters())
-opts = {'seed': 5, 'strict': True}
-def step():
-    for p in params: p.grad = None
-    yy = y0.clone().requires_grad_(True)
-    S.torchsde.sdeint(sde, yy, times, dt=1.0, method='euler', options=opts)[-1].square().mean().backward()
-for _ in range(20): step()
-torch.cuda.synchronize()
-# host time per step without waiting for the GPU (launch-only): enqueue 200 steps, time the enqueue
-t0 = time.perf_counter()
-for _ in range(200): step()
-t1 = time.perf_counter()
-torch.cuda.synchronize()
-t2 = time.perf_counter()
-print('host enqueue per step %.4f ms; incl. drain %.4f ms' % ((t1 - t0) / 200 * 1e3, (t2 - t0) / 200 * 1e3))
-pr = cProfile.Profile(); pr.enable()
-for _ in range(200): step()
-pr.disable(); torch.cuda.synchronize()
-s = io.StringIO(); pstats.Stats(pr, stream=s).sort_stats('cumulative').print_stats(45); print(s.getvalue()[:9000])
+for rep in range(2):
+    for method in ('srk', 'euler'):
+        for kernel in ('auto',):
+            opts = {'seed': 5, 'strict': True, 'kernel': kernel}
+            def step():
+                for p in params: p.grad = None
+                yy = y0.clone().requires_grad_(True)
+                S.torchsde.sdeint(sde, yy, times, dt=1.0, method=method, options=opts)[-1].square().mean().backward()
+            t = bench.event_times_ms(step, stream, 30, 5)
+            print(rep, method, kernel, 'fwd+bwd median %.4f p10 %.4f p90 %.4f' % (np.median(t), np.percentile(t, 10), np.percentile(t, 90)), flush=True)
 PY
-timeout 300 python /tmp/hp.py > $O/hostprof.txt 2>&1 < /dev/null; head -90 $O/hostprof.txt | cut -c1-170
+cd /tmp && export TMPDIR=/tmp
+timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof -o ab -- python /tmp/ab.py > /tmp/prof.log 2>&1 < /dev/null
+grep fwd /tmp/prof.log
+f=$(find /tmp/prof -name "*kernel_stats.csv" | head -1)
+if [ -n "$f" ]; then cp "$f" $GRAFT_REPO_ROOT/$O/ab_kernel_stats.csv; head -5 "$f" | cut -c1-220; else tail -5 /tmp/prof.log; fi
