@@ -42,7 +42,7 @@ static int launch(const W4Args& a, hipStream_t st) {
 template <int NHID, int NN, bool GEO, bool MULY>
 static int launch_srk_rev(const W4SrkRevArgs& a, hipStream_t st) {
     using CF = CfgSR<NHID, NN, GEO, MULY>;
-    const size_t lds_bytes = (size_t)w4srk_rev_lds_floats<NHID, NN>() * sizeof(float);
+    const size_t lds_bytes = (size_t)w4srk_rev_lds_floats<NHID, NN, MULY>() * sizeof(float);
     static SnsdeLdsAttr lds_attr;   // per instantiation and device
     if (const int rc = snsde_lds_attr(reinterpret_cast<const void*>(snsde_w4_srk_reverse_kernel<CF>), lds_bytes, lds_attr)) return rc;
     hipLaunchKernelGGL((snsde_w4_srk_reverse_kernel<CF>), dim3((a.B + 7) / 8), dim3(512), lds_bytes, st, a);

@@ -1304,8 +1304,8 @@ struct W4SrkRevArgs {
     int32_t w_in, k_in, t_in, w_hid[3], w_out, w_n0, w_n1;
 };
 
-template <int NHID, int NN> __host__ __device__ constexpr int w4srk_rev_lds_floats() {
-    return 2 * (6 * 256 + 2 * (3 * (NHID + 2) + 4 * NN) * 256 + (NHID >= 1 ? 16 * 256 : 0));
+template <int NHID, int NN, bool MULY = false> __host__ __device__ constexpr int w4srk_rev_lds_floats() {
+    return 2 * (6 * 256 + 2 * (3 * (NHID + 2) + 4 * NN) * 256 + (NHID >= 1 ? 16 * 256 : 0) + ((MULY && NN == 2) ? 16 * 256 : 0));
 }
 
 // (GEO: the drift is gated by tanh of its input state, input_option 5; MULY: raw = q * state, noise_option 15 / 19 - compile-time:
@@ -1327,8 +1327,11 @@ __global__ void __launch_bounds__(512, 2) snsde_w4_srk_reverse_kernel(W4SrkRevAr
     // dynamic LDS, per tile: exchange planes | delta planes [step parity][3 ND + 4 NN] | the drift wave's parked W_in,y^T
     enum { XA = 0, XM, XD, XH, XCNT = XH + 2 };            // (XH: two planes, alternating by phase)
     constexpr int NDP = 3 * ND + 4 * NN;
-    constexpr int TILE_FLOATS = w4srk_rev_lds_floats<NHID, NN>() / 2;
-    static_assert(TILE_FLOATS >= XCNT * 256 + 2 * NDP * 256 + (PARK ? 16 * 256 : 0), "LDS layout");
+    // raw = q * state with a two-layer net: the net wave keeps the four state planes besides its two matrices and spilled 25
+    // registers (scratch reloads in the step loop); its W1,y^T is parked like the drift wave's W_in,y^T
+    constexpr bool NPARK = mul_y && NN == 2;
+    constexpr int TILE_FLOATS = w4srk_rev_lds_floats<NHID, NN, mul_y>() / 2;
+    static_assert(TILE_FLOATS >= XCNT * 256 + 2 * NDP * 256 + (PARK ? 16 * 256 : 0) + (NPARK ? 16 * 256 : 0), "LDS layout");
     extern __shared__ __attribute__((aligned(16))) float w4srk_lds[];
 
     const int lane = threadIdx.x & 63;
@@ -1338,6 +1341,7 @@ __global__ void __launch_bounds__(512, 2) snsde_w4_srk_reverse_kernel(W4SrkRevAr
     float* xchg = w4srk_lds + pair * TILE_FLOATS;        // [XCNT][4][64]
     float* dpl = xchg + XCNT * 256;                      // [2][NDP][4][64]
     float* wpark = dpl + 2 * NDP * 256;                  // [16][64][4]
+    float* npark = wpark + (PARK ? 16 * 256 : 0);        // [16][64][4]
     const int B = a.B;
     const int tile = blockIdx.x * 2 + pair;
     const int row_t = tile * 4;
@@ -1588,9 +1592,14 @@ __global__ void __launch_bounds__(512, 2) snsde_w4_srk_reverse_kernel(W4SrkRevAr
 #endif
     } else if (wave == 1) {
         // ================================ net wave: Gbar_e, the four net chains ================================
-        float w1t[NN > 1 ? H : 1], w0t[H];
+        float w1t[NN > 1 ? H : 1], w0t[NPARK ? 1 : H];
         if constexpr (NN > 1) load_col(w1t, a.w_n1, H, 0);
-        load_col(w0t, a.w_n0, 66, 2);
+        const float* w0l = npark + lane * 4;
+        if constexpr (NPARK) {
+            const float* qw = P + a.w_n0 + 2 + lane;
+#pragma unroll
+            for (int l = 0; l < H; ++l) npark[(l >> 2) * 256 + lane * 4 + (l & 3)] = qw[(size_t)l * 66];
+        } else load_col(w0t, a.w_n0, 66, 2);
         const float sig_theta = snsde_sigmoid(P[a.off_theta]);
         float th_acc = 0.0f;
         float q[4][4], h1[mul_y ? 4 : 1][4], ik[4], ik0[4];
@@ -1675,7 +1684,8 @@ __global__ void __launch_bounds__(512, 2) snsde_w4_srk_reverse_kernel(W4SrkRevAr
                     quad_transpose(v, vt);
                 }
                 f32x4 c = {0.f, 0.f, 0.f, 0.f}, d = c;
-                gemm64(vt, w0t, c, d, Seq{});
+                if constexpr (NPARK) gemm64_lds(vt, w0l, c, d, Seq{});
+                else gemm64(vt, w0t, c, d, Seq{});
 #pragma unroll
                 for (int i = 0; i < 4; ++i) out[i] = (c[i] + d[i]) + nd[i];
             };
