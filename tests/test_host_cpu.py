@@ -82,6 +82,39 @@ def test_make_model_configurations_stay_on_the_mfma_families(pair):
                         assert path in ('lean', 'mfma4', 'mfma16', 'mfma-srk', 'w4') and mode == 1, (io, no, method, H, B, C_, path, mode)
 
 
+def test_save_layout_reports_the_delta_free_adjoints():
+    """snsde_save_layout (host-side query, include/snsde.h): delta_slots == 0 exactly where the wave-group adjoints accumulate the
+    weight gradients themselves - H = 64 with a diffusion net, Euler and SRK, up to 6144 rows, `auto` / `w4`, host or
+    device-resident Philox key; everything else keeps act_slots (+ the Milstein tangent factors) delta planes."""
+    import ctypes as C
+    lib = _lib.lib()
+
+    def layout(io, no, H, B, method, kernel='auto', seed_dev=False, NL=2):
+        s = _lib.Solve()
+        s.model = S.engine.model_struct(5, H, H, NL, io, no)
+        s.batch, s.knots, s.n_steps, s.n_out = B, 9, 8, 3
+        s.method = {'euler': _lib.EULER, 'milstein': _lib.MILSTEIN, 'srk': _lib.SRK}[method]
+        s.kernel = _lib.KERNELS[kernel]
+        if seed_dev:
+            s.seed_dev = C.c_void_p(64)      # (never dereferenced by the query)
+        a, b, c = C.c_int32(), C.c_int32(), C.c_int32()
+        assert lib.snsde_save_layout(C.byref(s), C.byref(a), C.byref(b), C.byref(c)) == 0
+        return a.value, b.value, c.value
+    for io, no in ((3, 18), (1, 14), (5, 19), (3, 15)):
+        nn = 2 if no >= 18 else 1
+        for method in ('euler', 'srk'):
+            slots, planes, dslots = layout(io, no, 64, 2048, method)
+            assert slots == 3 + nn * (2 if method == 'srk' else 1) and planes == (3 if method == 'srk' else 1) and dslots == 0
+            assert layout(io, no, 64, 2048, method, 'w4')[2] == 0 and layout(io, no, 64, 37, method)[2] == 0
+            assert layout(io, no, 64, 2048, method, seed_dev=True)[2] == 0
+            assert layout(io, no, 64, 2048, method, 'mfma4')[2] == slots            # the tile adjoint + weight-gradient GEMMs
+            assert layout(io, no, 64, 8192, method)[2] == slots                      # large batches stay on the tile adjoints
+            assert layout(io, no, 128, 1024, method)[2] > 0 and layout(io, no, 64, 2048, method, NL=3)[2] > 0
+        slots, _, dslots = layout(io, no, 64, 2048, 'milstein')
+        assert dslots == slots + (3 if nn == 2 else 1)
+    assert layout(4, 17, 128, 1024, 'euler')[2] == 3                                  # K2 (NL + 1 slots): no diffusion net, no fused gradients
+
+
 def test_stale_binding_is_refused():
     """A descriptor whose struct_size is not the library's sizeof (a binding compiled against an older header) is refused with
     SNSDE_ERR_ABI before any field is read; snsde_abi_check verifies a binding's sizes at load time."""
