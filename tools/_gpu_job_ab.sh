@@ -1,6 +1,6 @@
 #!/bin/bash
 cd $GRAFT_REPO_ROOT
-O=gpurun_out/r05E; mkdir -p $O
+O=gpurun_out/r05I; mkdir -p $O
 timeout 900 python -m pytest tests/test_gpu_w4.py -x -q -m gpu > $O/w4_tests.log 2>&1 < /dev/null; echo "w4 tests rc=$?" >> $O/w4_tests.log
 tail -5 $O/w4_tests.log
 cat > /tmp/ab.py <<'PY'
