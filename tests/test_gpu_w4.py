@@ -215,6 +215,19 @@ def test_w4_srk_adjoint_equals_the_tile_adjoint(case):
         assert float((pa[k] - pb[k]).abs().max()) <= 1e-4 * (float(pb[k].abs().max()) + 1e-12), k
 
 
+@pytest.mark.parametrize('method', ['euler', 'srk'])
+@pytest.mark.parametrize('case', [(4, [0, 1]), (5, [0, 1]), (4, [0, 2]), (7, [0, 1, 2]), (8, [0, 3])])
+def test_w4_adjoints_on_the_shortest_solves_and_smallest_batches(method, case):
+    """One-, two- and three-step solves (the adjoints' one-step-behind gradient waves and a-step-ahead fetches at their boundaries)
+    on one tile, on one tile + a ragged second one (rows solved twice must not enter the sums twice), on two tiles."""
+    B, ts = case
+    io, no, NL, C, L = 3, 18, 2, 4, 5
+    grid = S.engine.step_grid(np.asarray(ts, np.float32), 1.0, np.arange(L, dtype=np.float32), torch.device(DEV))
+    model = S.engine.model_struct(C, 64, 64, NL, io, no)
+    assert S.engine.forward_path(model, B, L, grid.N, method=method) == 'w4' and grid.N == int(ts[-1])
+    _check_backward(9800 + 10 * B + len(ts), io, no, NL, B, 64, C, L, ts, 1.0, method, 'auto', strict=True)
+
+
 @pytest.mark.parametrize('row_out', [False, True])
 def test_w4_adjoint_with_in_kernel_philox_and_row_outputs_equals_the_tile_adjoint(row_out):
     """Training through sdeint with in-kernel Philox increments (the adjoint regenerates them or reads the forward's dW_out) and,
