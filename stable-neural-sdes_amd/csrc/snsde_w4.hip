@@ -1,4 +1,5 @@
-// Host side of the wave-owns-rows forward kernels (snsde_w4_kernel.h): which solves they take, argument set-up, dispatch.
+// Host side of the wave-owns-rows kernels (snsde_w4_kernel.h: forward Euler / SRK, their adjoints with the weight gradients inside, the
+// reduction of the per-tile gradient blocks): which solves they take, argument set-up, dispatch.
 #include "snsde_w4_kernel.h"
 
 namespace snsde_w4 {

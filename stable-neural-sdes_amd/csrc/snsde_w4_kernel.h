@@ -1,4 +1,4 @@
-// "Wave-owns-rows" forward kernels for H = 64 models with a diffusion net (noise_option 14 / 15 / 18 / 19; BASELINE config 4:
+// "Wave-owns-rows" kernels for H = 64 models with a diffusion net (noise_option 14 / 15 / 18 / 19; BASELINE config 4:
 // neuralsde_3_18, B = 2048, H = 64) - round 5.
 //
 // The 4-row tiles of snsde_mfma_kernel / snsde_m4n_kernel split a layer's OUTPUT FEATURES over the waves of a workgroup: at H = 64
@@ -18,8 +18,11 @@
 //     step (double-buffered by step parity) and then both form y' = y + f h + g dW bit-identically.  2048 rows = 1024 waves = every
 //     SIMD of the chip, one wave each.
 //
-// Training-mode saves follow snsde_mfma_kernel's (act_save slots, relu signs folded into the saved z), so the adjoint and the
-// weight-gradient pass are unchanged.
+// Training-mode saves follow snsde_mfma_kernel's / snsde_m4n_kernel's layouts (act_save slots, relu signs folded into the saved z,
+// SRK: stage planes), so the 4-row-tile adjoints and the weight-gradient pass read them unchanged.  This file also holds the
+// adjoints on the same wave groups: snsde_w4_euler_reverse_kernel and snsde_w4_srk_reverse_kernel (drift wave + net wave + two
+// gradient waves per tile: every weight gradient accumulated in registers inside the adjoint, no delta planes) and the two
+// reduction kernels of their per-tile blocks.
 #pragma once
 #include <utility>
 
@@ -462,7 +465,8 @@ __global__ void __launch_bounds__(256, 2) snsde_w4_euler_kernel(W4Args a) {
 // (H0_1 needs F0 only; H0_2 needs F0, F1, G0, G1, I_k0; H1_2 needs F0, G0 only, so G1 and G2 do not wait for the drift wave.)
 // Training-mode saves = snsde_m4n_kernel's (act_save per pass 3n + s with 2 NN + NHID + 2 slots, the pass's drift signs and the hidden
 // signs of the net evaluation beside it / of the fourth evaluation in the low bits of the saved z, stage_save planes H0 | H1 | H1_3):
-// the adjoint (snsde_m4n_rev_kernel.h) and the weight-gradient pass are unchanged.
+// snsde_m4n_rev_kernel.h + the weight-gradient pass read them unchanged; the wave-group adjoint below (snsde_w4_srk_reverse_kernel)
+// reads the same planes.
 // =====================================================================================================================================
 template <int NHID, bool SAVE> __host__ __device__ constexpr int w4srk_fwd_lds_floats() { return 2 * 12 * 256 + 2 * 4096 + ((SAVE && NHID >= 1) ? 2 * 4096 : 0); }
 

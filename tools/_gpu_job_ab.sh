@@ -1,5 +1,5 @@
 #!/bin/bash
 cd $GRAFT_REPO_ROOT
-O=gpurun_out/r05J; mkdir -p $O
-timeout 900 python -m pytest tests/test_gpu_w4.py -x -q -m gpu -k "shortest" > $O/w4_tests.log 2>&1 < /dev/null; echo "rc=$?" >> $O/w4_tests.log
-tail -25 $O/w4_tests.log
+O=gpurun_out/r05K; mkdir -p $O
+timeout 300 python tools/prof_host_step.py euler > $O/host_prof.txt 2>&1 < /dev/null
+grep -v amdgpu $O/host_prof.txt | head -110
