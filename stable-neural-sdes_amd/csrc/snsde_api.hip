@@ -453,7 +453,10 @@ int snsde_save_layout(const snsde_solve* s, int32_t* act_slots, int32_t* stage_p
     const int no = s->model.noise_option;
     const int nn = (no == 18 || no == 19) ? 2 : ((no == 14 || no == 15) ? 1 : 0);
     int planes = 1;
-    if (s->method == SNSDE_SRK && nn > 0) { slots += nn; planes = 3; }
+    if (s->method == SNSDE_SRK && nn > 0) {
+        slots += nn; planes = 3;
+        if (nn == 2 && s->model.activation != SNSDE_ACT_RELU) slots += 1;      // (+ the fourth evaluation's hidden pre-activation)
+    }
     if (act_slots) *act_slots = slots;
     if (stage_planes) *stage_planes = planes;
     // Milstein through a diffusion net: the adjoint also leaves the tangent pass's factors (second-order parameter terms)

@@ -310,14 +310,14 @@ __global__ void __launch_bounds__(CF::NT, CF::WPS) snsde_m4n_kernel(MfmaArgs a) 
         if (__builtin_expect(g_raw, 0)) return raw;
         return fast_tanh(sig_theta * snsde_nan_to_num(raw));
     };
-    // smooth activations (field variants, Euler / Milstein): the NL drift pre-activations and the net's hidden pre-activation
-    // follow the regular slots (snsde_act_slots)
-    const int nsave_rt = (!SRK && act_fn != 0) ? NSAVE + NHID + 1 + (NN == 2 ? 1 : 0) : NSAVE;
+    // smooth activations (field variants): the NL drift pre-activations and the net's hidden pre-activation follow the regular slots
+    // (snsde_act_slots); SRK: per pass, + the hidden pre-activation of the step's fourth evaluation (pass 3n + 2) in one more slot
+    const int nsave_rt = act_fn != 0 ? NSAVE + NHID + 1 + (NN == 2 ? (SRK ? 2 : 1) : 0) : NSAVE;
     auto save_act = [&](int pass, int slot, float v) {
         if (a.act_save && row_ok) (a.act_save + uoff(pass, (uint32_t)nsave_rt * (uint32_t)BH, slot, (uint32_t)BH))[(uint32_t)(row * H + fcol)] = v;
     };
-    auto save_pre = [&](int pass, int idx, float v) {      // idx: drift layer 0 .. NHID, NHID + 1 = the net's hidden layer
-        if (!SRK && act_fn != 0) save_act(pass, NSAVE + idx, v);
+    auto save_pre = [&](int pass, int idx, float v) {      // idx: drift layer 0 .. NHID, NHID + 1 = the net's hidden layer (SRK: + 2 = the tail's)
+        if (act_fn != 0) save_act(pass, NSAVE + idx, v);
     };
     // one net evaluation's layer 1 (reads gyrow): NN == 2 -> relu'd hidden into nbuf (returned); NN == 1 -> the output q
     auto net_l1 = [&](int pass, int slot0, float& q) {
@@ -328,7 +328,7 @@ __global__ void __launch_bounds__(CF::NT, CF::WPS) snsde_m4n_kernel(MfmaArgs a) 
         if constexpr (NN == 2) {
             o = actf(o);
             nbuf[r * LDA + fcol] = o;
-            save_pre(pass, NHID + 1, pre);
+            save_pre(pass, slot0 == CF::ZSLOT + 1 ? NHID + 1 : NHID + 2, pre);
         } else {
             q = o;
         }

@@ -28,9 +28,13 @@ __host__ __device__ constexpr int m4nr_nlds(int H, int NHID, int NN) {
     return regs > m4nr_reg_budget(H) + 32 ? -1 : nl;
 }
 
-template <int H_, int NHID_, int NN_>
+// VAR: the field-variant switches (tutorial NeuralSDEFunc, fields.py: smooth activations - their derivative from the pre-activations
+// the forward saved behind the regular slots -, linear drift output, the net's linear output as the diffusion); a template
+// parameter because the pre-activations of a step are 3 (NHID + 1) + 4 more prefetched registers per lane
+template <int H_, int NHID_, int NN_, bool VAR_ = false>
 struct CfgNR {
     static constexpr int H = H_, NHID = NHID_, NN = NN_;
+    static constexpr bool VAR = VAR_;
     static constexpr int NW = H / 16, NT = NW * 64, WPS = NW >= 8 ? NW / 4 : 2, M = 4;
     static constexpr int KUH = H / 16, LDA = ld_for(16 * KUH, 16);
     static constexpr int ND = NHID + 2, NMAT = ND + NN;
@@ -94,6 +98,11 @@ __global__ void __launch_bounds__(CF::NT, CF::WPS) snsde_m4n_srk_reverse_kernel(
     const float sig_theta = snsde_sigmoid(a.params[a.off_theta]);
     const bool mul_y = (a.no == 15 || a.no == 19);
     const bool geo = a.geo != 0;
+    constexpr bool VAR = CF::VAR;
+    const bool smooth = VAR && a.act_fn != 0, f_lin = VAR && a.f_out != 0, g_raw = VAR && a.g_out != 0;
+    const bool net_lin = VAR && a.g_out == SNSDE_DIFFUSION_RAW_NET;
+    const float act_scale = a.act_fn == SNSDE_ACT_LIPSWISH ? 0.909f : 1.0f;
+    const uint32_t ASL = VAR ? (uint32_t)a.nsave * BH32 : SLBH;      // act_save stride per pass (smooth: + the pre-activation slots)
     const float rowf = row_ok ? 1.0f : 0.0f;
     const int rslot = a.row_out ? a.row_out[rowc] : -1;
     const float gfin = a.row_out ? a.grad_ys[goff] : 0.0f;
@@ -114,16 +123,29 @@ __global__ void __launch_bounds__(CF::NT, CF::WPS) snsde_m4n_srk_reverse_kernel(
         float y, ik, ik0, z[3], q[4];
         float h, rdt; int nout, kfirst;
     };
+    // VAR, smooth activations: pre-activations of the drift passes / the net's hidden layers (their own struct: members a flavour never
+    // touches would travel through scratch with every cur = nxt, see snsde_mfma_reverse_kernel)
+    struct PreIn { float dpre[3][NHID + 1], npre[4]; };
     constexpr int SRK_BITS = NHID + 1 + (NN == 2 ? 2 : 0);
-    auto fetch = [&](int n, StepIn& p) {
+    auto fetch = [&](int n, StepIn& p, PreIn& pp) {
         const size_t so = uoff(n, BH32) + goff;
         p.y = a.traj[so]; p.ik = a.dW[so]; p.ik0 = a.dU[so];
 #pragma unroll
         for (int st = 0; st < 3; ++st) {
-            const float* ap = a.act + uoff(3 * n + st, SLBH) + goff;
+            const float* ap = a.act + uoff(3 * n + st, ASL) + goff;
             p.z[st] = ap[(size_t)ZSLOT * BH];
             p.q[st] = ap[(size_t)(ZSLOT + NN) * BH];
             if (st == 2) p.q[3] = ap[(size_t)(ZSLOT + 2 * NN) * BH];
+            if constexpr (VAR) {
+                if (smooth) {      // (wave-uniform)
+#pragma unroll
+                    for (int k = 0; k <= NHID; ++k) pp.dpre[st][k] = ap[(size_t)(NSLOT + k) * BH];
+                    if constexpr (NN == 2) {
+                        pp.npre[st] = ap[(size_t)(NSLOT + NHID + 1) * BH];
+                        if (st == 2) pp.npre[3] = ap[(size_t)(NSLOT + NHID + 2) * BH];
+                    }
+                }
+            }
         }
         const float* stp = a.step_tab + uoff(n, SNSDE_STEP_STRIDE);
         p.h = stp[1]; p.rdt = stp[6]; p.nout = __float_as_int(stp[8]); p.kfirst = __float_as_int(stp[9]);
@@ -133,7 +155,7 @@ __global__ void __launch_bounds__(CF::NT, CF::WPS) snsde_m4n_srk_reverse_kernel(
     // 0), relu masks dm[]; returns first_y^T(..) for the own element.  Net: input cotangent qb at the net's output
     // pre-activation of an evaluation whose deltas go to pass pn, slots ns0 / ns0 + 1; hidden mask nm; returns ny0_y^T(..).
     auto chains = [&](bool do_d, int p, float dz, uint32_t dmbits, bool do_n, int pn, int ns0, float qb, bool nm,
-                      float& d_res, float& n_res) {      // dmbits: bit (NHID - k) = relu mask behind transposed GEMM k; nm: the net's hidden mask
+                      float& d_res, float& n_res, const float* dfac = nullptr, float nfac = 0.0f) {      // dmbits: bit (NHID - k) = relu mask behind transposed GEMM k; nm: the net's hidden mask; VAR: dfac[layer] / nfac = the activations' derivatives instead
         float* nbA = (NN == 1 && nsel) ? nb1 : nb0;
         float* nbB = nb1;
         if (do_d) {
@@ -155,7 +177,8 @@ __global__ void __launch_bounds__(CF::NT, CF::WPS) snsde_m4n_srk_reverse_kernel(
                 drift_gemm(k, lds + k * M * LDA + brow, c, d);
                 const float o = m4_reduce_scatter(c + d);
                 if (k < ND - 1) {
-                    const float dv = ((dmbits >> (NHID - k)) & 1u) ? o : 0.0f;
+                    float dv = ((dmbits >> (NHID - k)) & 1u) ? o : 0.0f;
+                    if constexpr (VAR) { if (smooth) dv = o * dfac[NHID - k]; }
                     lds[(k + 1) * M * LDA + lrow] = dv;
                     if (a.delta && row_ok) (a.delta + uoff(p, SLBH, k + 1, BH32))[goff] = dv;
                     more = true;
@@ -169,7 +192,8 @@ __global__ void __launch_bounds__(CF::NT, CF::WPS) snsde_m4n_srk_reverse_kernel(
                 else gemm4<KUH>(wnB, nbB + brow, c, d);
                 const float o = m4_reduce_scatter(c + d);
                 if (k < NN - 1) {
-                    const float dv = nm ? o : 0.0f;
+                    float dv = nm ? o : 0.0f;
+                    if constexpr (VAR) { if (smooth) dv = o * nfac; }
                     nbB[lrow] = dv;
                     if (a.delta && row_ok) (a.delta + uoff(pn, SLBH, ns0 + 1, BH32))[goff] = dv;
                     more = true;
@@ -182,10 +206,11 @@ __global__ void __launch_bounds__(CF::NT, CF::WPS) snsde_m4n_srk_reverse_kernel(
     };
 
     StepIn cur, nxt;
-    fetch(a.N - 1, cur);
+    PreIn curp, nxtp;
+    fetch(a.N - 1, cur, curp);
     for (int n = a.N - 1; n >= 0; --n) {
         nxt = cur;
-        if (n > 0) fetch(n - 1, nxt);
+        if (n > 0) fetch(n - 1, nxt, nxtp);
         const float h = cur.h, rdt = cur.rdt;
         float carry = 0.0f;
         for (int k = cur.kfirst; k < cur.kfirst + cur.nout; ++k) {
@@ -204,6 +229,7 @@ __global__ void __launch_bounds__(CF::NT, CF::WPS) snsde_m4n_srk_reverse_kernel(
             const float raw = mul_y ? q * yy : q;
             fin = snsde_finite(raw);
             rc = snsde_nan_to_num(raw);
+            if (g_raw) { om = 1.0f; fin = true; return raw; }      // (VAR: g = the raw value itself: dg / d raw = 1, no theta)
             const float g = fast_tanh(sig_theta * rc);
             om = 1.0f - g * g;
             return g;
@@ -215,18 +241,18 @@ __global__ void __launch_bounds__(CF::NT, CF::WPS) snsde_m4n_srk_reverse_kernel(
 #pragma unroll
         for (int st = 0; st < 3; ++st) {
             zb[st] = __builtin_bit_cast(uint32_t, cur.z[st]);
-            zc[st] = __builtin_bit_cast(float, zb[st] & ~((1u << SRK_BITS) - 1u));
+            zc[st] = smooth ? cur.z[st] : __builtin_bit_cast(float, zb[st] & ~((1u << SRK_BITS) - 1u));      // (smooth: z is saved as it is)
         }
-        const float f0 = fast_tanh(zc[0] * gate(y));
+        const float f0 = f_lin ? zc[0] : fast_tanh(zc[0] * gate(y));
         const float g0 = gfun(cur.q[0], y, om0, rc0, fi0);
         const float h01 = y + f0 * h;
         const float h11 = y + 0.25f * f0 * h + 0.5f * g0 * rdt;
-        const float f1 = fast_tanh(zc[1] * gate(h01));
+        const float f1 = f_lin ? zc[1] : fast_tanh(zc[1] * gate(h01));
         const float g1 = gfun(cur.q[1], h11, om1, rc1, fi1);
         const float rh = 1.0f / h, rrdt = 1.0f / rdt;      // (the forward's two divisions per step; every `/ h`, `/ rdt` below multiplies)
         const float ik0h = ik0 * rh;
         const float h02 = y + 0.25f * f0 * h + 0.25f * f1 * h + (g0 + 0.5f * g1) * ik0h;
-        const float f2 = fast_tanh(zc[2] * gate(h02));
+        const float f2 = f_lin ? zc[2] : fast_tanh(zc[2] * gate(h02));
         const float h12 = y + f0 * h - g0 * rdt;
         const float g2 = gfun(cur.q[2], h12, om2, rc2, fi2);
         const float h13 = y + 0.25f * f2 * h + (-5.0f * g0 + 3.0f * g1 + 0.5f * g2) * rdt;
@@ -247,32 +273,47 @@ __global__ void __launch_bounds__(CF::NT, CF::WPS) snsde_m4n_srk_reverse_kernel(
 
         // cotangent of a diffusion evaluation -> input of its net chain (+ the direct term of raw = q * y); theta's share
         auto net_in = [&](float gb, float om, float rc, bool fin, float q, float hin, float& direct) {
-            const float rb = fin ? gb * om * sig_theta : 0.0f;
-            th_acc = fmaf(gb * om * rowf, rc, th_acc);
+            const float rb = g_raw ? gb : (fin ? gb * om * sig_theta : 0.0f);
+            if (!g_raw) th_acc = fmaf(gb * om * rowf, rc, th_acc);
             direct = mul_y ? rb * q : 0.0f;
             float qb = mul_y ? rb * hin : rb;
-            if constexpr (NN == 2) qb = q > 0.0f ? qb : 0.0f;
+            if constexpr (NN == 2) { if (!net_lin) qb = q > 0.0f ? qb : 0.0f; }      // (VAR: the net may end in its linear layer)
             return qb;
         };
         // cotangent of a drift evaluation F = tanh(z * gate(hin)) -> input of its chain (+ the gate's direct term)
         auto drift_in = [&](float fb, float F, float z, float hin, float& direct) {
             const float ty = gate(hin);
-            const float dzt = fb * (1.0f - F * F);
+            const float dzt = f_lin ? fb : fb * (1.0f - F * F);
             direct = geo ? dzt * z * (1.0f - ty * ty) : 0.0f;
             return dzt * ty;
         };
         float dd, nd, dres = 0.0f, nres = 0.0f;
+        // VAR, smooth activations: d act / dx at the saved pre-activations (drift layers of the three passes, the net's hidden layer of
+        // the four evaluations) instead of the relu bits
+        float df[VAR ? 3 : 1][NHID + 1], nf[4] = {0.f, 0.f, 0.f, 0.f};
+        if constexpr (VAR) {
+            if (smooth) {
+#pragma unroll
+                for (int st = 0; st < 3; ++st)
+#pragma unroll
+                    for (int k = 0; k <= NHID; ++k) df[st][k] = swish_grad(curp.dpre[st][k], act_scale);
+                if constexpr (NN == 2) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) nf[e] = swish_grad(curp.npre[e], act_scale);
+                }
+            }
+        }
 
         // ---- G3 = g(t0 + h/4, H1_3): the tail evaluation (second set of net slots of pass 3n + 2) ----
         float qb = net_in(gb3, om3, rc3, fi3, cur.q[3], h13, nd);
-        chains(false, 0, 0.0f, zb[2], true, 3 * n + 2, NB0 + NN, qb, ((zb[2] >> (NHID + 2)) & 1u) != 0, dres, nres);
+        chains(false, 0, 0.0f, zb[2], true, 3 * n + 2, NB0 + NN, qb, ((zb[2] >> (NHID + 2)) & 1u) != 0, dres, nres, nullptr, nf[3]);
         float hb = nres + nd;
         yb += hb; fb2 = fmaf(0.25f * h, hb, fb2);
         gb0 = fmaf(-5.0f * rdt, hb, gb0); gb1 = fmaf(3.0f * rdt, hb, gb1); gb2 = fmaf(0.5f * rdt, hb, gb2);
         // ---- G2 = g(t0 + h, H1_2) beside the drift at (t0 + h/2, H0_2) ----
         qb = net_in(gb2, om2, rc2, fi2, cur.q[2], h12, nd);
         float dz = drift_in(fb2, f2, zc[2], h02, dd);
-        chains(true, 3 * n + 2, dz, zb[2], true, 3 * n + 2, NB0, qb, ((zb[2] >> (NHID + 1)) & 1u) != 0, dres, nres);
+        chains(true, 3 * n + 2, dz, zb[2], true, 3 * n + 2, NB0, qb, ((zb[2] >> (NHID + 1)) & 1u) != 0, dres, nres, df[VAR ? 2 : 0], nf[2]);
         hb = nres + nd;
         float d = dres + dd;
         yb += hb; fb0 = fmaf(h, hb, fb0); gb0 = fmaf(-rdt, hb, gb0);
@@ -282,7 +323,7 @@ __global__ void __launch_bounds__(CF::NT, CF::WPS) snsde_m4n_srk_reverse_kernel(
         // ---- G1 = g(t0 + h/4, H1_1) beside the drift at (t0 + h, H0_1) ----
         qb = net_in(gb1, om1, rc1, fi1, cur.q[1], h11, nd);
         dz = drift_in(fb1, f1, zc[1], h01, dd);
-        chains(true, 3 * n + 1, dz, zb[1], true, 3 * n + 1, NB0, qb, ((zb[1] >> (NHID + 1)) & 1u) != 0, dres, nres);
+        chains(true, 3 * n + 1, dz, zb[1], true, 3 * n + 1, NB0, qb, ((zb[1] >> (NHID + 1)) & 1u) != 0, dres, nres, df[VAR ? 1 : 0], nf[1]);
         hb = nres + nd;
         d = dres + dd;
         yb += hb; fb0 = fmaf(0.25f * h, hb, fb0); gb0 = fmaf(0.5f * rdt, hb, gb0);
@@ -290,9 +331,10 @@ __global__ void __launch_bounds__(CF::NT, CF::WPS) snsde_m4n_srk_reverse_kernel(
         // ---- G0 and F0, both at (t0, y) ----
         qb = net_in(gb0, om0, rc0, fi0, cur.q[0], y, nd);
         dz = drift_in(fb0, f0, zc[0], y, dd);
-        chains(true, 3 * n, dz, zb[0], true, 3 * n, NB0, qb, ((zb[0] >> (NHID + 1)) & 1u) != 0, dres, nres);
+        chains(true, 3 * n, dz, zb[0], true, 3 * n, NB0, qb, ((zb[0] >> (NHID + 1)) & 1u) != 0, dres, nres, df[0], nf[0]);
         adj = yb + (nres + nd) + (dres + dd);
         cur = nxt;
+        if constexpr (VAR) { if (smooth) curp = nxtp; }
     }
     if (row_ok) a.adj[goff] = adj + (a.row_out ? (rslot == 0 ? gfin : 0.0f) : a.grad_ys[goff]);
     if (a.dth_part) {
@@ -321,6 +363,12 @@ inline bool m4n_rev_instantiated(int H, int NHID, int NN) {
 
 template <int H>
 int dispatch_m4n_rev(const RevPlan& p, const RevArgs& a, hipStream_t st) {
+    if (a.act_fn != 0 || a.f_out != 0 || a.g_out != 0) {      // field variants: the two-layer nets of NeuralSDEFunc-shaped fields (fields.py)
+#define SNSDE_NRV(NHID_) if (p.NHID == NHID_ && p.NN == 2) return launch_m4n_rev<CfgNR<H, NHID_, 2, true>>(a, st);
+        SNSDE_NRV(0) SNSDE_NRV(1) SNSDE_NRV(2)
+#undef SNSDE_NRV
+        return SNSDE_ERR_UNSUPPORTED;
+    }
 #define SNSDE_NR(NHID_, NN_) if (p.NHID == NHID_ && p.NN == NN_) return launch_m4n_rev<CfgNR<H, NHID_, NN_>>(a, st);
     SNSDE_NR(0, 1) SNSDE_NR(0, 2) SNSDE_NR(1, 1) SNSDE_NR(1, 2) SNSDE_NR(2, 1) SNSDE_NR(2, 2) SNSDE_NR(3, 1) SNSDE_NR(3, 2)
 #undef SNSDE_NR

@@ -461,13 +461,17 @@ RevPlan make_rev_plan(const snsde_solve* s, const SnsdeNet& net, const MfmaPlan&
     const bool m4n_rev = fp.M4N && !variant_of(s) &&
                          ((s->method == SNSDE_SRK && m4n_rev_instantiated(fp.H, fp.NHID, fp.NN)) ||
                           (s->method == SNSDE_MILSTEIN && m4n_mil_rev_instantiated(fp.H, fp.NHID, fp.NN)));
-    if (fp.NN != 0 && s->method != SNSDE_EULER && !m4n_rev) return p;
+    // ... field variants under SRK on snsde_m4n_srk_reverse_kernel's VAR instantiations (two-layer nets: NeuralSDEFunc; round 5)
+    const bool variant_srk_net_rev = fp.M4N && variant_of(s) && s->method == SNSDE_SRK && fp.H <= 128 && fp.IO != 0 && fp.NN == 2 &&
+                                     fp.NHID <= 2 && !s->noise_table && s->model.diffusion_output != SNSDE_DIFFUSION_TANH &&
+                                     s->model.drift_output != SNSDE_DRIFT_TIMES_Y && m4n_rev_instantiated(fp.H, fp.NHID, fp.NN);
+    if (fp.NN != 0 && s->method != SNSDE_EULER && !m4n_rev && !variant_srk_net_rev) return p;
     // field variants with a net (NeuralSDEFunc-shaped, fields.py): Euler on the general adjoint kernel's 4-row tiles
     const bool variant_net_rev = fp.M4N && variant_of(s) && s->method == SNSDE_EULER && fp.FL == 1 && fp.H <= 128 && fp.IO != 0 &&
                                  !s->noise_table && s->model.diffusion_output != SNSDE_DIFFUSION_TANH &&
                                  s->model.drift_output != SNSDE_DRIFT_TIMES_Y;
-    if (fp.M4N && variant_of(s) && !variant_net_rev) return p;
-    p.M4N = m4n_rev ? (s->method == SNSDE_SRK ? 1 : 2) : 0;
+    if (fp.M4N && variant_of(s) && !variant_net_rev && !variant_srk_net_rev) return p;
+    p.M4N = (m4n_rev || variant_srk_net_rev) ? (s->method == SNSDE_SRK ? 1 : 2) : 0;
     // tutorial-style fields under SRK (the general kernel's SRK variant ran the forward): the SRK adjoint kernel carries the
     // switches; a raw diffusion from a supplied table (rows = the four stage times of every step) or none
     const bool variant_srk_rev = fp.SRK && s->method == SNSDE_SRK && variant_of(s) && !fp.M4N && fp.FL == 1 && fp.H <= 128 &&
@@ -475,7 +479,7 @@ RevPlan make_rev_plan(const snsde_solve* s, const SnsdeNet& net, const MfmaPlan&
                                  ((s->model.diffusion_output == SNSDE_DIFFUSION_RAW && s->noise_table != nullptr) ||
                                   s->model.noise_option == 0);
     // tutorial-style fields: the register-resident lean forward (its training-mode instantiations), Euler / Milstein
-    if (variant_of(s) && !variant_net_rev && !variant_srk_rev && !(fp.LEAN && fp.FL == 1 && fp.H <= 128 && !fp.SRK && s->method != SNSDE_SRK &&
+    if (variant_of(s) && !variant_net_rev && !variant_srk_net_rev && !variant_srk_rev && !(fp.LEAN && fp.FL == 1 && fp.H <= 128 && !fp.SRK && s->method != SNSDE_SRK &&
                            (s->model.activation == SNSDE_ACT_RELU || lean_act_save_fits(fp.H, fp.NHID, fp.KUXT)) &&
                            (s->model.diffusion_output == SNSDE_DIFFUSION_RAW || s->model.noise_option == 0) &&
                            (s->noise_table != nullptr || s->model.noise_option == 0)))
@@ -780,6 +784,8 @@ int snsde_mfma_backward_launch(const snsde_backward* b, const SnsdeNet& net, hip
     a.gt = s->noise_table ? s->noise_table : (fp.gt_off >= 0 ? static_cast<const float*>(s->workspace) + fp.gt_off : nullptr);
     a.act_fn = s->model.activation; a.f_out = s->model.drift_output; a.g_out = s->model.diffusion_output;
     a.nsave = s->model.num_hidden_layers + 1 + fp.NN + (s->model.activation != SNSDE_ACT_RELU ? s->model.num_hidden_layers + (fp.NN == 2 ? 1 : 0) : 0);
+    if (s->method == SNSDE_SRK && fp.NN > 0)      // (snsde_save_layout: the fourth evaluation's net slots, smooth: + its hidden pre-activation)
+        a.nsave += fp.NN + ((fp.NN == 2 && s->model.activation != SNSDE_ACT_RELU) ? 1 : 0);
     a.step_tab = s->step_tab; a.out_w = s->out_w; a.traj = s->traj; a.act = s->act_save;
     // increments: the ones the forward wrote out, else the supplied ones, else (Philox, host key) regenerated by the kernel
     a.dW = s->dW_out ? s->dW_out : s->dW;

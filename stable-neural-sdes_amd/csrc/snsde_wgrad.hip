@@ -891,7 +891,7 @@ int snsde_wgrad_launch(const snsde_backward* b, const SnsdeNet& net, float* grad
     }
     const bool smooth = s.model.activation != SNSDE_ACT_RELU;      // act_save then also holds the NL pre-activations per step
     a.B = s.batch; a.H = H; a.N = wp->n_pass; a.NG = wp->ndelta;
-    a.NSAVE = wp->nact + (smooth ? s.model.num_hidden_layers + ((no == 18 || no == 19) ? 1 : 0) : 0);
+    a.NSAVE = wp->nact + (smooth ? s.model.num_hidden_layers + ((no == 18 || no == 19) ? (srk ? 2 : 1) : 0) : 0);      // (SRK: + the fourth evaluation's)
     a.adj = b->adj;
     a.R = wp->n_pass * s.batch; a.ntiles = wp->ntiles; a.NP = wp->NP;
     for (int i = 0; i < wp->ntiles; ++i) a.tile[i] = wp->tile[i];

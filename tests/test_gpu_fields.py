@@ -124,6 +124,10 @@ GRAD_CASES += [(kind, H, layers, act, 'srk') for kind in ('lsde', 'lnsde', 'lnsd
 # NeuralSDEFunc-shaped fields (drift and diffusion both MLPs of [t, y]): Euler, the net kernels + the general adjoint kernel
 GRAD_CASES += [('nsde', H, 1, act, 'euler') for H, act in ((16, 'lipswish'), (32, 'lipswish'), (64, 'relu'), (64, 'silu'),
                                                             (128, 'lipswish'), (128, 'relu'))]
+# ... and under SRK (torchsde's default method): the net kernels' SRK forward with the pre-activations saved, the SRK net adjoint's
+# variant switches (snsde_m4n_srk_reverse_kernel<CfgNR<.., VAR>>)
+GRAD_CASES += [('nsde', H, 1, act, 'srk') for H, act in ((16, 'lipswish'), (32, 'lipswish'), (64, 'silu'), (64, 'relu'), (128, 'lipswish'),
+                                                          (128, 'relu'))]
 
 
 @pytest.mark.parametrize('kind,H,layers,act,method', GRAD_CASES)
@@ -270,7 +274,7 @@ def test_tutorial_field_solve_records_into_a_graph():
     assert not torch.allclose(c, b)
 
 
-@pytest.mark.parametrize('kind,method', [('lnsde', 'euler'), ('gsde', 'srk'), ('nsde', 'euler')])
+@pytest.mark.parametrize('kind,method', [('lnsde', 'euler'), ('gsde', 'srk'), ('nsde', 'euler'), ('nsde', 'srk')])
 def test_tutorial_field_training_step_records_into_a_graph(kind, method):
     """Forward + loss.backward() + Adam step of a composed field recorded into ONE CUDA/HIP graph (composition, fused solve,
     adjoint, weight-gradient pass with its side-stream fork / join, the composition's backward, the optimizer): replays draw
@@ -358,7 +362,7 @@ def test_fused_path_vs_trajectories_of_the_reference_notebooks_fields(case):
     assert err <= 4 * np.abs(g['ys32'].astype(np.float64) - ref).max() + 1e-5 * scale
 
 
-@pytest.mark.parametrize('kind,method', [('gsde', 'srk'), ('nsde', 'euler')])
+@pytest.mark.parametrize('kind,method', [('gsde', 'srk'), ('nsde', 'euler'), ('nsde', 'srk')])
 def test_field_training_step_at_the_timed_size_vs_fp64_autograd(kind, method):
     """The sizes tools/time_fields.py / bench.py time (1024 rows, H = 128; 40 steps here to bound the float64 loop): loss.backward()
     through the fused solve against float64 autograd through the tensor-op loop on the same increments."""
