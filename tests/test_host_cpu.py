@@ -115,6 +115,32 @@ def test_save_layout_reports_the_delta_free_adjoints():
     assert layout(4, 17, 128, 1024, 'euler')[2] == 3                                  # K2 (NL + 1 slots): no diffusion net, no fused gradients
 
 
+def test_neural_sde_func_shapes_train_on_the_fused_path_under_euler_and_srk():
+    """The NeuralSDEFunc mapping of fields.py ((3, 18) with the variant switches: smooth activation, linear drift output, the net's
+    linear output as the diffusion, raw time) has a fused backward (mode 1) under Euler and SRK at every instantiated width and one
+    to three drift layers; under SRK the forward saves one more slot than under Euler for every pre-activation set it needs later
+    (snsde_save_layout); Milstein stays without one."""
+    import ctypes as C
+    from stable_neural_sdes_amd import fields
+    lib = _lib.lib()
+    times = np.linspace(0, 1, 9).astype(np.float32)
+    grid = S.engine.StepGrid(times, 0.125, times, None)
+    for H in (16, 32, 64, 128):
+        for NL in (1, 2, 3):
+            for act in (0, 1, 2):
+                m = S.engine.model_struct(3, H, H, NL, 3, 18, activation=act, drift_output=fields.DRIFT_LINEAR,
+                                          diffusion_output=fields.DIFFUSION_RAW_NET, time_feature=fields.TIME_RAW)
+                assert S.engine.backward_mode(m, 19, 9, grid, 'euler') == 1 and S.engine.backward_mode(m, 19, 9, grid, 'srk') == 1, (H, NL, act)
+                assert S.engine.backward_mode(m, 19, 9, grid, 'milstein') != 1
+                s = _lib.Solve()
+                s.model = m
+                s.batch, s.knots, s.n_steps, s.n_out = 19, 9, grid.N, grid.T
+                s.method = _lib.SRK
+                a, b, c = C.c_int32(), C.c_int32(), C.c_int32()
+                assert lib.snsde_save_layout(C.byref(s), C.byref(a), C.byref(b), C.byref(c)) == 0
+                assert a.value == NL + 1 + 4 + (NL + 2 if act else 0) and b.value == 3, (H, NL, act, a.value)
+
+
 def test_stale_binding_is_refused():
     """A descriptor whose struct_size is not the library's sizeof (a binding compiled against an older header) is refused with
     SNSDE_ERR_ABI before any field is read; snsde_abi_check verifies a binding's sizes at load time."""
