@@ -30,9 +30,13 @@ __host__ __device__ constexpr int m4nm_nlds(int H, int NHID, int NN) {
     return regs > m4nr_reg_budget(H) + 32 ? -1 : nl;
 }
 
-template <int H_, int NHID_, int NN_>
+// VAR: the field-variant switches (NeuralSDEFunc-shaped fields, fields.py; see CfgNR): smooth activations - first AND second
+// derivative at the pre-activations the forward saved behind the regular slots: the tangent hdot = act'(p1) (W1_y a) depends on the
+// hidden pre-activation p1, so its cotangent reaches p1 through act''(p1) -, linear drift output, the net's linear output as g
+template <int H_, int NHID_, int NN_, bool VAR_ = false>
 struct CfgNM {
     static constexpr int H = H_, NHID = NHID_, NN = NN_;
+    static constexpr bool VAR = VAR_;
     static constexpr int NW = H / 16, NT = NW * 64, WPS = NW >= 8 ? NW / 4 : 2, M = 4;
     static constexpr int KUH = H / 16, LDA = ld_for(16 * KUH, 16);
     static constexpr int ND = NHID + 2, NMAT = m4nm_nmat(NHID, NN);
@@ -105,6 +109,11 @@ __global__ void __launch_bounds__(CF::NT, CF::WPS) snsde_m4n_mil_reverse_kernel(
     const float sig = snsde_sigmoid(a.params[a.off_theta]);
     const bool mul_y = (a.no == 15 || a.no == 19);
     const bool geo = a.geo != 0;
+    constexpr bool VAR = CF::VAR;
+    const bool smooth = VAR && a.act_fn != 0, f_lin = VAR && a.f_out != 0, g_raw = VAR && a.g_out != 0;
+    const bool net_lin = VAR && a.g_out == SNSDE_DIFFUSION_RAW_NET;
+    const float act_scale = a.act_fn == SNSDE_ACT_LIPSWISH ? 0.909f : 1.0f;
+    const uint32_t ASL = VAR ? (uint32_t)a.nsave * BH32 : (uint32_t)NSAVE * BH32;      // act_save stride per step (smooth: + the pre-activations)
     const float rowf = row_ok ? 1.0f : 0.0f;
     const int rslot = a.row_out ? a.row_out[rowc] : -1;
     const float gfin = a.row_out ? a.grad_ys[goff] : 0.0f;
@@ -123,10 +132,18 @@ __global__ void __launch_bounds__(CF::NT, CF::WPS) snsde_m4n_mil_reverse_kernel(
 
     // (round 4: the relu masks - drift chain, the net's hidden layer - are sign bits in the low mantissa bits of the saved z)
     struct StepIn { float y, z, dw, q; float h; int nout, kfirst; };
+    struct PreIn { float dpre[NHID + 1], npre; };      // VAR, smooth activations: pre-activations of the drift layers / the net's hidden layer
     constexpr int MIL_BITS = NHID + 1 + (NN == 2 ? 1 : 0);
-    auto fetch = [&](int n, StepIn& p) {
+    auto fetch = [&](int n, StepIn& p, PreIn& pp) {
         const size_t so = uoff(n, BH32) + goff;
-        const float* ap = a.act + uoff(n, (uint32_t)NSAVE * BH32) + goff;
+        const float* ap = a.act + uoff(n, ASL) + goff;
+        if constexpr (VAR) {
+            if (smooth) {      // (wave-uniform)
+#pragma unroll
+                for (int k = 0; k <= NHID; ++k) pp.dpre[k] = ap[(size_t)(NSAVE + k) * BH];
+                pp.npre = NN == 2 ? ap[(size_t)(NSAVE + NHID + 1) * BH] : 0.0f;
+            }
+        }
         p.y = a.traj[so]; p.dw = a.dW[so];
         p.z = ap[(size_t)ZSLOT * BH];
         p.q = ap[(size_t)(ZSLOT + NN) * BH];
@@ -135,10 +152,11 @@ __global__ void __launch_bounds__(CF::NT, CF::WPS) snsde_m4n_mil_reverse_kernel(
     };
 
     StepIn cur, nxt;
-    fetch(a.N - 1, cur);
+    PreIn curp, nxtp;
+    fetch(a.N - 1, cur, curp);
     for (int n = a.N - 1; n >= 0; --n) {
         nxt = cur;
-        if (n > 0) fetch(n - 1, nxt);
+        if (n > 0) fetch(n - 1, nxt, nxtp);
         const float h = cur.h;
         float carry = 0.0f;
         for (int k = cur.kfirst; k < cur.kfirst + cur.nout; ++k) {
@@ -150,21 +168,37 @@ __global__ void __launch_bounds__(CF::NT, CF::WPS) snsde_m4n_mil_reverse_kernel(
         if (row_ok) (a.adj + uoff(n + 1, BH32))[goff] = adj;
         const float av = adj, y = cur.y, dw = cur.dw, q = cur.q;
         const uint32_t zb = __builtin_bit_cast(uint32_t, cur.z);
-        const float zc = __builtin_bit_cast(float, zb & ~((1u << MIL_BITS) - 1u));      // z with its sign bits cleared
+        const float zc = smooth ? cur.z : __builtin_bit_cast(float, zb & ~((1u << MIL_BITS) - 1u));      // z with its sign bits cleared (smooth: saved as it is)
         const bool h1pos = NN == 2 && ((zb >> (NHID + 1)) & 1u) != 0;                       // [h1 > 0]: the net's hidden mask
+        // VAR, smooth: act' of the drift layers, act' and act'' of the net's hidden layer (x sigma(x) family: act'' = c s (1 - s)(2 + x (1 - 2 s)))
+        float dfac[NHID + 1], nf1 = 0.0f, nf2 = 0.0f;
+#pragma unroll
+        for (int k = 0; k <= NHID; ++k) dfac[k] = 0.0f;
+        if constexpr (VAR) {
+            if (smooth) {
+#pragma unroll
+                for (int k = 0; k <= NHID; ++k) dfac[k] = swish_grad(curp.dpre[k], act_scale);
+                if constexpr (NN == 2) {
+                    const float x = curp.npre;
+                    const float sg = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(x * -1.4426950408889634f));
+                    nf1 = act_scale * sg * fmaf(x, 1.0f - sg, 1.0f);
+                    nf2 = act_scale * sg * (1.0f - sg) * fmaf(x, 1.0f - 2.0f * sg, 2.0f);
+                }
+            }
+        }
 
         // drift: F = tanh(z gate(y)); cotangent a h
         const float ty = geo ? fast_tanh(y) : 1.0f;
-        const float F = fast_tanh(zc * ty);
-        const float dzt = av * h * (1.0f - F * F);
+        const float F = f_lin ? zc : fast_tanh(zc * ty);
+        const float dzt = f_lin ? av * h : av * h * (1.0f - F * F);
         const float dz = dzt * ty;
         const float direct_d = geo ? dzt * zc * (1.0f - ty * ty) : 0.0f;
         // diffusion value and its derivatives in raw
         const float raw = mul_y ? q * y : q;
         const bool fin = snsde_finite(raw);
         const float rc = snsde_nan_to_num(raw);
-        const float g = fast_tanh(sig * rc), om = 1.0f - g * g;
-        const float gp = fin ? om * sig : 0.0f;                     // dg / d raw
+        const float g = g_raw ? raw : fast_tanh(sig * rc), om = g_raw ? 0.0f : 1.0f - g * g;
+        const float gp = g_raw ? 1.0f : (fin ? om * sig : 0.0f);      // dg / d raw (VAR: g = the raw value)
         const float v = fmaf(dw, dw, -h);
 
         // ---- phase 0: inputs of the drift chain (dL/d zout) and of the tangent chain (a) ----
@@ -174,13 +208,15 @@ __global__ void __launch_bounds__(CF::NT, CF::WPS) snsde_m4n_mil_reverse_kernel(
         __syncthreads();
 
         float d_res = 0.0f, n_res = 0.0f, direct_y = 0.0f, qdot = 0.0f;
+        [[maybe_unused]] float s_raw = 0.0f;      // W1_y a before the activation's derivative (VAR)
         auto drift_phase = [&](int k) {       // transposed GEMM k of the drift chain; returns true when it wrote a buffer
             if (k >= ND) return false;
             f32x4 c = {0.f, 0.f, 0.f, 0.f}, d = c;
             drift_gemm(k, lds + k * M * LDA + brow, c, d);
             const float o = m4_reduce_scatter(c + d);
             if (k < ND - 1) {
-                const float dv = ((zb >> (NHID - k)) & 1u) ? o : 0.0f;
+                float dv = ((zb >> (NHID - k)) & 1u) ? o : 0.0f;
+                if constexpr (VAR) { if (smooth) dv = o * dfac[NHID - k]; }
                 lds[(k + 1) * M * LDA + lrow] = dv;
                 put_delta(n, k + 1, dv);
                 return true;
@@ -192,14 +228,16 @@ __global__ void __launch_bounds__(CF::NT, CF::WPS) snsde_m4n_mil_reverse_kernel(
         auto after_tangent = [&]() {
             const float rawdot = mul_y ? fmaf(qdot, y, q * av) : qdot;
             const float alpha = 0.5f * v * g * gp;
-            const float beta = fin ? 0.5f * v * sig * sig * om * fmaf(-3.0f * g, g, 1.0f) * rawdot : 0.0f;
+            const float beta = g_raw ? 0.5f * v * rawdot : (fin ? 0.5f * v * sig * sig * om * fmaf(-3.0f * g, g, 1.0f) * rawdot : 0.0f);      // (g = raw: u = g g' = raw, u' = 1)
             const float rho = fmaf(av * dw, gp, beta);
             float cq = mul_y ? fmaf(rho, y, alpha * av) : rho;
             float cqd = mul_y ? alpha * y : alpha;
             direct_y = mul_y ? fmaf(rho, q, alpha * qdot) : 0.0f;
-            th_acc = fmaf(av * dw * om * rowf, rc, th_acc);
-            if (fin) th_acc = fmaf(0.5f * v * rawdot * om * rowf, fmaf(sig * rc, fmaf(-3.0f * g, g, 1.0f), g), th_acc);
-            if constexpr (NN == 2) { cq = q > 0.0f ? cq : 0.0f; cqd = q > 0.0f ? cqd : 0.0f; }
+            if (!g_raw) {
+                th_acc = fmaf(av * dw * om * rowf, rc, th_acc);
+                if (fin) th_acc = fmaf(0.5f * v * rawdot * om * rowf, fmaf(sig * rc, fmaf(-3.0f * g, g, 1.0f), g), th_acc);
+            }
+            if constexpr (NN == 2) { if (!net_lin) { cq = q > 0.0f ? cq : 0.0f; cqd = q > 0.0f ? cqd : 0.0f; } }      // (VAR: the net may end in its linear layer)
             bRA[lrow] = cq;
             put_delta(n, NB0, cq);
             put_delta(n, NSAVE, cqd);                 // eps2 (NN = 2) / eps (NN = 1): left factor of the second-order term
@@ -212,7 +250,9 @@ __global__ void __launch_bounds__(CF::NT, CF::WPS) snsde_m4n_mil_reverse_kernel(
                 f32x4 c = {0.f, 0.f, 0.f, 0.f}, d = c;
                 gemm4<KUH>(n1f, bTA + brow, c, d);
                 const float hd_all = m4_reduce_scatter(c + d);      // (DPP: every lane takes part - never inside a select's branch)
-                const float hd = h1pos ? hd_all : 0.0f;
+                s_raw = hd_all;
+                float hd = h1pos ? hd_all : 0.0f;
+                if constexpr (VAR) { if (smooth) hd = nf1 * hd_all; }
                 bTB[lrow] = hd;
                 put_delta(n, NSAVE + 2, hd);
             }
@@ -223,7 +263,7 @@ __global__ void __launch_bounds__(CF::NT, CF::WPS) snsde_m4n_mil_reverse_kernel(
                 f32x4 c = {0.f, 0.f, 0.f, 0.f}, d = c;
                 gemm4<KUH>(n2f, bTB + brow, c, d);
                 const float qd_all = m4_reduce_scatter(c + d);
-                qdot = q > 0.0f ? qd_all : 0.0f;
+                qdot = (net_lin || q > 0.0f) ? qd_all : 0.0f;
             }
             after_tangent();
             __syncthreads();
@@ -233,13 +273,19 @@ __global__ void __launch_bounds__(CF::NT, CF::WPS) snsde_m4n_mil_reverse_kernel(
                 f32x4 c = {0.f, 0.f, 0.f, 0.f}, d = c;
                 gemm4<KUH>(n2t, bRA + brow, c, d);
                 const float d1_all = m4_reduce_scatter(c + d);
-                const float d1 = h1pos ? d1_all : 0.0f;
-                bRC[lrow] = d1;
-                put_delta(n, NB0 + 1, d1);
                 f32x4 c2 = {0.f, 0.f, 0.f, 0.f}, d2 = c2;
                 gemm4<KUH>(n2t, bRB + brow, c2, d2);
                 const float e1_all = m4_reduce_scatter(c2 + d2);
-                put_delta(n, NSAVE + 1, h1pos ? e1_all : 0.0f);
+                float d1 = h1pos ? d1_all : 0.0f, e1 = h1pos ? e1_all : 0.0f;
+                if constexpr (VAR) {
+                    if (smooth) {      // the tangent's cotangent reaches the hidden pre-activation through act''
+                        d1 = fmaf(nf1, d1_all, nf2 * s_raw * e1_all);
+                        e1 = nf1 * e1_all;
+                    }
+                }
+                bRC[lrow] = d1;
+                put_delta(n, NB0 + 1, d1);
+                put_delta(n, NSAVE + 1, e1);
             }
             __syncthreads();
             // phase 4: drift 3 || dy = W1_y^T delta1
@@ -279,6 +325,7 @@ __global__ void __launch_bounds__(CF::NT, CF::WPS) snsde_m4n_mil_reverse_kernel(
         }
         adj = av + carry + (d_res + direct_d) + (n_res + direct_y);
         cur = nxt;
+        if constexpr (VAR) { if (smooth) curp = nxtp; }
     }
     if (row_ok) a.adj[goff] = adj + (a.row_out ? (rslot == 0 ? gfin : 0.0f) : a.grad_ys[goff]);
     if (a.dth_part) {
@@ -307,6 +354,12 @@ inline bool m4n_mil_rev_instantiated(int H, int NHID, int NN) {
 
 template <int H>
 int dispatch_m4n_mil_rev(const RevPlan& p, const RevArgs& a, hipStream_t st) {
+    if (a.act_fn != 0 || a.f_out != 0 || a.g_out != 0) {      // field variants: two-layer nets (NeuralSDEFunc)
+#define SNSDE_NMV(NHID_) if (p.NHID == NHID_ && p.NN == 2) return launch_m4n_mil_rev<CfgNM<H, NHID_, 2, true>>(a, st);
+        SNSDE_NMV(0) SNSDE_NMV(1) SNSDE_NMV(2)
+#undef SNSDE_NMV
+        return SNSDE_ERR_UNSUPPORTED;
+    }
 #define SNSDE_NMR(NHID_, NN_) if (p.NHID == NHID_ && p.NN == NN_) return launch_m4n_mil_rev<CfgNM<H, NHID_, NN_>>(a, st);
     SNSDE_NMR(0, 1) SNSDE_NMR(0, 2) SNSDE_NMR(1, 1) SNSDE_NMR(1, 2) SNSDE_NMR(2, 1) SNSDE_NMR(2, 2) SNSDE_NMR(3, 1) SNSDE_NMR(3, 2)
 #undef SNSDE_NMR

@@ -461,10 +461,12 @@ RevPlan make_rev_plan(const snsde_solve* s, const SnsdeNet& net, const MfmaPlan&
     const bool m4n_rev = fp.M4N && !variant_of(s) &&
                          ((s->method == SNSDE_SRK && m4n_rev_instantiated(fp.H, fp.NHID, fp.NN)) ||
                           (s->method == SNSDE_MILSTEIN && m4n_mil_rev_instantiated(fp.H, fp.NHID, fp.NN)));
-    // ... field variants under SRK on snsde_m4n_srk_reverse_kernel's VAR instantiations (two-layer nets: NeuralSDEFunc; round 5)
-    const bool variant_srk_net_rev = fp.M4N && variant_of(s) && s->method == SNSDE_SRK && fp.H <= 128 && fp.IO != 0 && fp.NN == 2 &&
-                                     fp.NHID <= 2 && !s->noise_table && s->model.diffusion_output != SNSDE_DIFFUSION_TANH &&
-                                     s->model.drift_output != SNSDE_DRIFT_TIMES_Y && m4n_rev_instantiated(fp.H, fp.NHID, fp.NN);
+    // ... field variants under SRK / Milstein on the VAR instantiations of the same two kernels (two-layer nets: NeuralSDEFunc; round 5)
+    const bool variant_srk_net_rev = fp.M4N && variant_of(s) && (s->method == SNSDE_SRK || s->method == SNSDE_MILSTEIN) && fp.H <= 128 &&
+                                     fp.IO != 0 && fp.NN == 2 && fp.NHID <= 2 && !s->noise_table &&
+                                     s->model.diffusion_output != SNSDE_DIFFUSION_TANH && s->model.drift_output != SNSDE_DRIFT_TIMES_Y &&
+                                     (s->method == SNSDE_SRK ? m4n_rev_instantiated(fp.H, fp.NHID, fp.NN)
+                                                             : m4n_mil_rev_instantiated(fp.H, fp.NHID, fp.NN));
     if (fp.NN != 0 && s->method != SNSDE_EULER && !m4n_rev && !variant_srk_net_rev) return p;
     // field variants with a net (NeuralSDEFunc-shaped, fields.py): Euler on the general adjoint kernel's 4-row tiles
     const bool variant_net_rev = fp.M4N && variant_of(s) && s->method == SNSDE_EULER && fp.FL == 1 && fp.H <= 128 && fp.IO != 0 &&

@@ -128,6 +128,10 @@ GRAD_CASES += [('nsde', H, 1, act, 'euler') for H, act in ((16, 'lipswish'), (32
 # variant switches (snsde_m4n_srk_reverse_kernel<CfgNR<.., VAR>>)
 GRAD_CASES += [('nsde', H, 1, act, 'srk') for H, act in ((16, 'lipswish'), (32, 'lipswish'), (64, 'silu'), (64, 'relu'), (128, 'lipswish'),
                                                           (128, 'relu'))]
+# ... and under Milstein (snsde_m4n_mil_reverse_kernel<CfgNM<.., VAR>>: the tangent's cotangent reaches the hidden pre-activation
+# through the activation's SECOND derivative)
+GRAD_CASES += [('nsde', H, 1, act, 'milstein') for H, act in ((16, 'lipswish'), (32, 'silu'), (64, 'lipswish'), (64, 'relu'), (128, 'lipswish'),
+                                                               (128, 'silu'))]
 
 
 @pytest.mark.parametrize('kind,H,layers,act,method', GRAD_CASES)
@@ -362,7 +366,7 @@ def test_fused_path_vs_trajectories_of_the_reference_notebooks_fields(case):
     assert err <= 4 * np.abs(g['ys32'].astype(np.float64) - ref).max() + 1e-5 * scale
 
 
-@pytest.mark.parametrize('kind,method', [('gsde', 'srk'), ('nsde', 'euler'), ('nsde', 'srk')])
+@pytest.mark.parametrize('kind,method', [('gsde', 'srk'), ('nsde', 'euler'), ('nsde', 'srk'), ('nsde', 'milstein')])
 def test_field_training_step_at_the_timed_size_vs_fp64_autograd(kind, method):
     """The sizes tools/time_fields.py / bench.py time (1024 rows, H = 128; 40 steps here to bound the float64 loop): loss.backward()
     through the fused solve against float64 autograd through the tensor-op loop on the same increments."""

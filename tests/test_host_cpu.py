@@ -115,11 +115,11 @@ def test_save_layout_reports_the_delta_free_adjoints():
     assert layout(4, 17, 128, 1024, 'euler')[2] == 3                                  # K2 (NL + 1 slots): no diffusion net, no fused gradients
 
 
-def test_neural_sde_func_shapes_train_on_the_fused_path_under_euler_and_srk():
+def test_neural_sde_func_shapes_train_on_the_fused_path():
     """The NeuralSDEFunc mapping of fields.py ((3, 18) with the variant switches: smooth activation, linear drift output, the net's
-    linear output as the diffusion, raw time) has a fused backward (mode 1) under Euler and SRK at every instantiated width and one
-    to three drift layers; under SRK the forward saves one more slot than under Euler for every pre-activation set it needs later
-    (snsde_save_layout); Milstein stays without one."""
+    linear output as the diffusion, raw time) has a fused backward (mode 1) under Euler, SRK and Milstein at every instantiated width and
+    one to three drift layers; under SRK the forward saves one more slot than under Euler for every pre-activation set it needs later
+    (snsde_save_layout)."""
     import ctypes as C
     from stable_neural_sdes_amd import fields
     lib = _lib.lib()
@@ -131,7 +131,9 @@ def test_neural_sde_func_shapes_train_on_the_fused_path_under_euler_and_srk():
                 m = S.engine.model_struct(3, H, H, NL, 3, 18, activation=act, drift_output=fields.DRIFT_LINEAR,
                                           diffusion_output=fields.DIFFUSION_RAW_NET, time_feature=fields.TIME_RAW)
                 assert S.engine.backward_mode(m, 19, 9, grid, 'euler') == 1 and S.engine.backward_mode(m, 19, 9, grid, 'srk') == 1, (H, NL, act)
-                assert S.engine.backward_mode(m, 19, 9, grid, 'milstein') != 1
+                # (Milstein through a two-layer net at H = 128 with more than one drift layer has no MFMA forward: four net matrices +
+                #  the drift's exceed registers + LDS; such fields take the graph-replayed stepper)
+                assert S.engine.backward_mode(m, 19, 9, grid, 'milstein') == (0 if H == 128 and NL >= 2 else 1), (H, NL, act)
                 s = _lib.Solve()
                 s.model = m
                 s.batch, s.knots, s.n_steps, s.n_out = 19, 9, grid.N, grid.T

@@ -32,7 +32,7 @@ for kind in ('gsde', 'lnsde', 'nsde', 'ode'):
         path = S.engine.forward_path(cf.model, rows, len(times), n, method=method, table=cf.tabulated) if cf is not None else None
         print(f'{kind:6s} {method:8s} fused path {path}: sdeint {res[0]:.3f} ms | tensor-op / graph stepper {res[1]:.1f} ms')
     # one training step: loss.backward() through the fused solve vs autograd through the tensor-op loop
-    for tmethod in (('euler',) if kind == 'ode' else ('euler', 'srk')):
+    for tmethod in (('euler',) if kind == 'ode' else (('euler', 'milstein', 'srk') if kind == 'nsde' else ('euler', 'srk'))):
         res = []
         for backend in ('auto', 'torch'):
             def step():
