@@ -550,6 +550,7 @@ bool snsde_mfma_supported(const snsde_solve* s, const SnsdeNet& net) { return ma
 
 // adjoint on the wave groups: Euler or SRK (SRID2) with a diffusion net, 4-row-tile plan, every a_n or dL/dy0 only
 static bool w4_rev_takes(const snsde_solve* s, const SnsdeNet& net, const MfmaPlan& fp, const RevPlan& p, int hint) {
+    // (p.NW >= 4: the per-tile theta partials - four floats per 4-row tile - live in the plan's dth block of nwg x NW floats)
     const bool method_ok = s->method == SNSDE_SRK ? (p.SRK && p.M4N == 1 && p.NW >= 4) : (!p.M4N && !p.SRK);
     return hint != 0 && hint != 1 && p.ok && p.FL == 1 && method_ok && fp.NN > 0 && s->kl_column1 == 0 &&
            (hint == 2 || s->batch <= 6144) && snsde_w4_rev_supported(s, net);
