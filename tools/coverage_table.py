@@ -13,7 +13,7 @@ from stable_neural_sdes_amd import _lib, engine
 
 L = _lib.lib()
 METHODS = (('euler', _lib.EULER), ('milstein', _lib.MILSTEIN), ('srk', _lib.SRK))
-FWD = {0: 'LOOP', 1: 'gen', 2: 'M16', 3: 'M4', 4: 'lean', 5: 'leanS', 6: 'genS', 7: 'M4S'}
+FWD = {0: 'LOOP', 1: 'gen', 2: 'M16', 3: 'M4', 4: 'lean', 5: 'leanS', 6: 'genS', 7: 'M4S', 8: 'W4'}
 BWD = {0: 'loop', 1: 'mfma', 2: 'gen'}
 
 
@@ -26,7 +26,7 @@ def query(H, C_, io, no, NL, B, method, N=50, knots=51):
 
 def main():
     print('Fused-path coverage (host-side query of the C ABI; no GPU involved).  Cell = forward kernel family / backward mode.')
-    print('forward: lean = lean 4-row-tile MFMA kernel, leanS = its streamed-weight variant (H = 256), M4 / M16 = general MFMA')
+    print('forward: lean = lean 4-row-tile MFMA kernel, leanS = its streamed-weight variant (H = 256), W4 = wave-owns-rows kernels (H = 64, diffusion nets), M4 / M16 = general MFMA')
     print('         kernel with 4- / 16-row tiles, M4S = SRK on MFMA 4-row tiles, gen / genS = generic kernels (any option),')
     print('         LOOP = no kernel: the host layer integrates with its graph-captured tensor-op stepper.')
     print('backward: mfma = MFMA adjoint kernel + native weight-gradient pass, gen = generic adjoint kernels + batched')
