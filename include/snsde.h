@@ -276,7 +276,10 @@ SNSDE_API int    snsde_solve_backward(const snsde_backward* b, void* hip_stream)
  * grad_params (device, snsde_param_numel floats, same flat layout as `params`, overwritten) — what autograd
  * accumulates through the unrolled loop (benchmark_classification/common_sde.py:158-160): split-R MFMA GEMMs
  * sum_r delta^T . input with per-workgroup partials and one deterministic reduction, the elementwise diffusion
- * reductions (theta, the time-only noise MLP; Euler and Milstein) and the first-layer/emb algebra. */
+ * reductions (theta, the time-only noise MLP; Euler and Milstein) and the first-layer/emb algebra.
+ * `b` is the descriptor snsde_solve_backward ran with, workspace included: the adjoint's workspace is an INPUT here (its
+ * per-workgroup diffusion-side sums; with delta_slots == 0 the per-tile weight-gradient blocks) - SNSDE_ERR_NULL without it,
+ * SNSDE_ERR_WORKSPACE when workspace_bytes < snsde_backward_workspace_bytes(b). */
 SNSDE_API size_t snsde_param_gradients_workspace_bytes(const snsde_backward* b);
 SNSDE_API int    snsde_param_gradients(const snsde_backward* b, float* grad_params, void* workspace, size_t workspace_bytes,
                              void* hip_stream);

@@ -495,24 +495,36 @@ def step_grid(ts, dt):
             np.array(w0, f32), np.array(w1, f32))
 
 
-# SRID2 tableau (Roessler 2010, strong order 1.5 for diagonal noise) as used by torchsde 0.2.5 `method='srk'`
-# (restated from the published scheme; torchsde's source is not in the reference tree: parity unpinned, guarded by
-# the strong-order test in tests/test_oracle_analytic.py).
+# SRK tableau: Roessler's SRI2W1 - A. Roessler, "Runge-Kutta methods for the strong approximation of solutions of stochastic
+# differential equations", SIAM J. Numer. Anal. 48(3), 2010, section 5 (order (3.0, 1.5) for scalar / diagonal noise, four stages).
+# torchsde 0.2.5 carries it as `_core/methods/tableaus/srid2.py` and `SRK.diagonal_or_scalar_step` (method='srk', the only SRK
+# torchsde has for non-additive noise) walks it: the names below are srid2.py's.  torchsde's source is not in the reference tree
+# (parity unpinned); what pins the TRANSCRIPTION is tests/golden/make_srk_golden.py, which evaluates the published table
+# in exact rational arithmetic without importing this file (tests/test_oracle_golden.py, tests/test_gpu_parity.py check both against
+# its vectors), and tests/test_oracle_analytic.py checks Roessler's order conditions on every row.
+#   row by row (Roessler's Butcher array  c(0) | A(0) | B(0)  over  c(1) | A(1) | B(1)  over  alpha | beta(1) beta(2) | beta(3) beta(4)):
+#     c(0) = (0, 1, 1/2, 0)     A(0) = [1; 1/4 1/4; 0 0 0]        B(0) = [0; 1 1/2; 0 0 0]
+#     c(1) = (0, 1/4, 1, 1/4)   A(1) = [1/4; 1 0; 0 0 1/4]        B(1) = [-1/2; 1 0; 2 -1 1/2]
+#     alpha = (1/6, 1/6, 2/3, 0)  beta(1) = (-1, 4/3, 2/3, 0)  beta(2) = (1, -4/3, 1/3, 0)  beta(3) = (2, -4/3, -2/3, 0)  beta(4) = (-2, 5/3, -2/3, 1)
+# (Rounds 1 - 5 of this repo had B(1) = [1/2; -1 0; -5 3 1/2] and beta(2) = (-1, 4/3, -1/3, 0): those are the B(1) / beta(2) rows of
+#  SRI1W1 = torchsde's srid1.py inside SRI2W1's other rows - also strong order 1.5, which is why the convergence test could not see
+#  it, but a different trajectory on identical draws.)
 SRK_C0 = (0.0, 1.0, 0.5, 0.0)
 SRK_C1 = (0.0, 0.25, 1.0, 0.25)
 SRK_A0 = ((), (1.0,), (0.25, 0.25), (0.0, 0.0, 0.0))
 SRK_A1 = ((), (0.25,), (1.0, 0.0), (0.0, 0.0, 0.25))
 SRK_B0 = ((), (0.0,), (1.0, 0.5), (0.0, 0.0, 0.0))
-SRK_B1 = ((), (0.5,), (-1.0, 0.0), (-5.0, 3.0, 0.5))
+SRK_B1 = ((), (-0.5,), (1.0, 0.0), (2.0, -1.0, 0.5))
 SRK_ALPHA = (1 / 6, 1 / 6, 2 / 3, 0.0)
 SRK_BETA1 = (-1.0, 4 / 3, 2 / 3, 0.0)
-SRK_BETA2 = (-1.0, 4 / 3, -1 / 3, 0.0)
+SRK_BETA2 = (1.0, -4 / 3, 1 / 3, 0.0)
 SRK_BETA3 = (2.0, -4 / 3, -2 / 3, 0.0)
 SRK_BETA4 = (-2.0, 5 / 3, -2 / 3, 1.0)
 
 
 def srk_step(f, g, t0, h, y, I_k, I_k0):
-    """One SRID2 step.  I_k = W(t1) - W(t0);  I_k0 = int_{t0}^{t1} (W(s) - W(t0)) ds (space-time Levy integral)."""
+    """One SRK step (torchsde 0.2.5 SRK.diagonal_or_scalar_step over srid2 = SRI2W1).  I_k = W(t1) - W(t0);  I_k0 = int_{t0}^{t1}
+    (W(s) - W(t0)) ds (torchsde: `bm(t0, t1, return_U=True)`), I_kk = (I_k^2 - h) / 2, I_kkk = (I_k^3 - 3 h I_k) / 6."""
     dt = y.dtype.type
     rdt = np.sqrt(h)
     I_kk = (I_k * I_k - h) / dt(2)

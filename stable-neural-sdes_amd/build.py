@@ -95,7 +95,7 @@ def build(force=False, verbose=False, defines=(), out=None, check_resources=True
     vs = os.path.join(objdir, 'exports.map')
     with open(vs, 'w') as f:
         f.write('{\n  global:\n' + ''.join(f'    {n};\n' for n in names) + '  local:\n    *;\n};\n')
-    cmd = [cc, '--offload-arch=gfx950', '-shared', '-fPIC', '-Wl,--version-script=' + vs, '-Wl,--undefined-version', '-o', out + '.tmp'] + objs
+    cmd = [cc, '--offload-arch=gfx950', '-shared', '-fPIC', '-Wl,--version-script=' + vs, '-Wl,--no-undefined-version', '-o', out + '.tmp'] + objs
     r = subprocess.run(cmd, capture_output=True, text=True)
     if r.returncode != 0:
         raise RuntimeError('link failed:\n' + r.stdout + r.stderr)

@@ -539,6 +539,10 @@ int snsde_param_gradients(const snsde_backward* b, float* grad_params, void* wor
     if (rc) return rc;
     if (snsde_backward_supported(&b->fwd) != 1) return SNSDE_ERR_UNSUPPORTED;
     if (!b->delta_save && !snsde_mfma_w4_fused(b, net, nullptr, nullptr)) return SNSDE_ERR_NULL;      // (delta_slots == 0: no planes)
+    // the adjoint's workspace is an INPUT of this pass (its per-workgroup diffusion-side sums; on the wave-group path the per-tile
+    // weight-gradient blocks themselves): the descriptor must still carry it, at the size the adjoint was given
+    if (!b->workspace) return SNSDE_ERR_NULL;
+    if (b->workspace_bytes < snsde_backward_workspace_bytes(b)) return SNSDE_ERR_WORKSPACE;
     if (workspace_bytes < snsde_param_gradients_workspace_bytes(b)) return SNSDE_ERR_WORKSPACE;
     return snsde_wgrad_launch(b, net, grad_params, (int32_t)snsde_param_numel(&b->fwd.model), static_cast<float*>(workspace),
                               static_cast<hipStream_t>(hip_stream));

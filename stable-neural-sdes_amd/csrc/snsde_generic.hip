@@ -496,28 +496,28 @@ __global__ void __launch_bounds__(GW) snsde_generic_srk_kernel(SrkArgs sa) {
         // stage 0
         drift(S0, tp0, F0);
         diffusion(S1, tp0, n, 0, G0);
-        // stage 1: H0 = y + f0 h ; H1 = y + f0 h/4 + g0 sqrt(h)/2
+        // stage 1: H0 = y + f0 h ; H1 = y + f0 h/4 - g0 sqrt(h)/2
         for_elems([&](int r, int j, int) {
             const float y = Y[r * ldy + j], f0 = F0[r * ldf + j], g0 = G0[r * ldf + j];
             S0[r * ldy + j] = y + f0 * h;
-            S1[r * ldy + j] = y + 0.25f * f0 * h + 0.5f * g0 * rdt;
+            S1[r * ldy + j] = y + 0.25f * f0 * h + SRK_B1_10 * g0 * rdt;
         });
         drift(S0, tp1, F1);
         diffusion(S1, tpq, n, 1, G1);
-        // stage 2: H0 = y + (f0 + f1) h/4 + (g0 + g1/2) I_k0/h ; H1 = y + f0 h - g0 sqrt(h)
+        // stage 2: H0 = y + (f0 + f1) h/4 + (g0 + g1/2) I_k0/h ; H1 = y + f0 h + g0 sqrt(h)
         for_elems([&](int r, int j, int) {
             const float y = Y[r * ldy + j], f0 = F0[r * ldf + j], f1 = F1[r * ldf + j];
             const float g0 = G0[r * ldf + j], g1 = G1[r * ldf + j], du = DU[r * ldf + j];
             S0[r * ldy + j] = y + 0.25f * f0 * h + 0.25f * f1 * h + g0 * du / h + 0.5f * g1 * du / h;
-            S1[r * ldy + j] = y + f0 * h - g0 * rdt;
+            S1[r * ldy + j] = y + f0 * h + SRK_B1_20 * g0 * rdt;
         });
         drift(S0, tph, F2);
         diffusion(S1, tp1, n, 3, G2);
-        // stage 3: H1 = y + f2 h/4 + (-5 g0 + 3 g1 + g2/2) sqrt(h)  (its drift has weight 0)
+        // stage 3: H1 = y + f2 h/4 + (2 g0 - g1 + g2/2) sqrt(h)  (its drift has weight 0)
         for_elems([&](int r, int j, int) {
             const float y = Y[r * ldy + j];
             S1[r * ldy + j] = y + 0.25f * F2[r * ldf + j] * h +
-                              (-5.0f * G0[r * ldf + j] + 3.0f * G1[r * ldf + j] + 0.5f * G2[r * ldf + j]) * rdt;
+                              (SRK_B1_30 * G0[r * ldf + j] + SRK_B1_31 * G1[r * ldf + j] + SRK_B1_32 * G2[r * ldf + j]) * rdt;
         });
         const float* nb3 = diffusion_net(S1, tpq);
         // combination
@@ -530,9 +530,9 @@ __global__ void __launch_bounds__(GW) snsde_generic_srk_kernel(SrkArgs sa) {
             const float ikkk = (ik * ik * ik - 3.0f * h * ik) / 6.0f;
             const float g3 = g_elem(S1[r * ldy + j], tpq[0], n, 1, r, j, nb3);
             const float a1 = ik, a2 = ikk / rdt, a3 = ik0 / h, a4 = ikkk / h;
-            const float w0 = -a1 - a2 + 2.0f * a3 - 2.0f * a4;
-            const float w1 = (4.0f / 3.0f) * a1 + (4.0f / 3.0f) * a2 - (4.0f / 3.0f) * a3 + (5.0f / 3.0f) * a4;
-            const float w2 = (2.0f / 3.0f) * a1 - (1.0f / 3.0f) * a2 - (2.0f / 3.0f) * a3 - (2.0f / 3.0f) * a4;
+            const float w0 = srk_w0(a1, a2, a3, a4);
+            const float w1 = srk_w1(a1, a2, a3, a4);
+            const float w2 = srk_w2(a1, a2, a3, a4);
             const float w3 = a4;
             float ynew = y + (F0[r * ldf + j] + F1[r * ldf + j]) * (h / 6.0f) + F2[r * ldf + j] * (2.0f * h / 3.0f);
             ynew += w0 * G0[r * ldf + j] + w1 * G1[r * ldf + j] + w2 * G2[r * ldf + j] + w3 * g3;
@@ -1270,8 +1270,8 @@ __global__ void __launch_bounds__(GW) snsde_generic_srk_adjoint_kernel(SrkAdjArg
             for_elems([&](int r, int j, int) { S0[r * ldy + j] = Y[r * ldy + j] + F0[r * ldf + j] * h; });     // H0_1
             fwd_chain(tp1);
             f_value(F1);
-            auto h11 = [&](int r, int j) { return Y[r * ldy + j] + 0.25f * F0[r * ldf + j] * h + 0.5f * G0[r * ldf + j] * rdt; };
-            auto h12 = [&](int r, int j) { return Y[r * ldy + j] + F0[r * ldf + j] * h - G0[r * ldf + j] * rdt; };
+            auto h11 = [&](int r, int j) { return Y[r * ldy + j] + 0.25f * F0[r * ldf + j] * h + SRK_B1_10 * G0[r * ldf + j] * rdt; };
+            auto h12 = [&](int r, int j) { return Y[r * ldy + j] + F0[r * ldf + j] * h + SRK_B1_20 * G0[r * ldf + j] * rdt; };
             gnet_value(h11, tpq, G1);
             for_elems([&](int r, int j, int) {
                 const float du = DU[r * ldf + j];
@@ -1288,28 +1288,28 @@ __global__ void __launch_bounds__(GW) snsde_generic_srk_adjoint_kernel(SrkAdjArg
                 const float ikkk = (ik * ik * ik - 3.0f * h * ik) / 6.0f;
                 const float a1 = ik, a2 = ikk / rdt, a3 = ik0 / h, a4 = ikkk / h;
                 FB0[r * ldf + j] = av * (h / 6.0f); FB1[r * ldf + j] = av * (h / 6.0f); FB2[r * ldf + j] = av * (2.0f * h / 3.0f);
-                GB0[r * ldf + j] = (-a1 - a2 + 2.0f * a3 - 2.0f * a4) * av;
-                GB1[r * ldf + j] = ((4.0f / 3.0f) * a1 + (4.0f / 3.0f) * a2 - (4.0f / 3.0f) * a3 + (5.0f / 3.0f) * a4) * av;
-                GB2[r * ldf + j] = ((2.0f / 3.0f) * a1 - (1.0f / 3.0f) * a2 - (2.0f / 3.0f) * a3 - (2.0f / 3.0f) * a4) * av;
+                GB0[r * ldf + j] = (srk_w0(a1, a2, a3, a4)) * av;
+                GB1[r * ldf + j] = (srk_w1(a1, a2, a3, a4)) * av;
+                GB2[r * ldf + j] = (srk_w2(a1, a2, a3, a4)) * av;
             });
-            // stage 3: g(t0 + h/4, H1_3), H1_3 = y + f2 h/4 + (-5 g0 + 3 g1 + g2/2) sqrt(h), weight I_kkk / h
+            // stage 3: g(t0 + h/4, H1_3), H1_3 = y + f2 h/4 + (2 g0 - g1 + g2/2) sqrt(h), weight I_kkk / h
             gnet_stage_vjp([&](int r, int j) {
                                return Y[r * ldy + j] + 0.25f * F2[r * ldf + j] * h +
-                                      (-5.0f * G0[r * ldf + j] + 3.0f * G1[r * ldf + j] + 0.5f * G2[r * ldf + j]) * rdt; },
+                                      (SRK_B1_30 * G0[r * ldf + j] + SRK_B1_31 * G1[r * ldf + j] + SRK_B1_32 * G2[r * ldf + j]) * rdt; },
                            tpq,
                            [&](int r, int j) {
                                const float ik = DW[r * ldf + j];
                                return AV[r * ldf + j] * ((ik * ik * ik - 3.0f * h * ik) / 6.0f) / h; },
                            [&](int r, int j, float hb) {
                                YB[r * ldf + j] += hb; FB2[r * ldf + j] = fmaf(0.25f * h, hb, FB2[r * ldf + j]);
-                               GB0[r * ldf + j] = fmaf(-5.0f * rdt, hb, GB0[r * ldf + j]);
-                               GB1[r * ldf + j] = fmaf(3.0f * rdt, hb, GB1[r * ldf + j]);
-                               GB2[r * ldf + j] = fmaf(0.5f * rdt, hb, GB2[r * ldf + j]); });
-            // stage 2, diffusion half: H1_2 = y + f0 h - g0 sqrt(h)
+                               GB0[r * ldf + j] = fmaf(SRK_B1_30 * rdt, hb, GB0[r * ldf + j]);
+                               GB1[r * ldf + j] = fmaf(SRK_B1_31 * rdt, hb, GB1[r * ldf + j]);
+                               GB2[r * ldf + j] = fmaf(SRK_B1_32 * rdt, hb, GB2[r * ldf + j]); });
+            // stage 2, diffusion half: H1_2 = y + f0 h + g0 sqrt(h)
             gnet_stage_vjp(h12, tp1, [&](int r, int j) { return GB2[r * ldf + j]; },
                            [&](int r, int j, float hb) {
                                YB[r * ldf + j] += hb; FB0[r * ldf + j] = fmaf(h, hb, FB0[r * ldf + j]);
-                               GB0[r * ldf + j] = fmaf(-rdt, hb, GB0[r * ldf + j]); });
+                               GB0[r * ldf + j] = fmaf(SRK_B1_20 * rdt, hb, GB0[r * ldf + j]); });
             // stage 2, drift half: H0_2 = y + (f0 + f1) h/4 + (g0 + g1/2) I_k0/h
             {
                 const float* dH = vjp(FB2);
@@ -1322,11 +1322,11 @@ __global__ void __launch_bounds__(GW) snsde_generic_srk_adjoint_kernel(SrkAdjArg
                     GB1[r * ldf + j] = fmaf(0.5f * du / h, dv, GB1[r * ldf + j]);
                 });
             }
-            // stage 1: H1_1 = y + f0 h/4 + g0 sqrt(h)/2 (diffusion at t0 + h/4), H0_1 = y + f0 h (drift at t0 + h)
+            // stage 1: H1_1 = y + f0 h/4 - g0 sqrt(h)/2 (diffusion at t0 + h/4), H0_1 = y + f0 h (drift at t0 + h)
             gnet_stage_vjp(h11, tpq, [&](int r, int j) { return GB1[r * ldf + j]; },
                            [&](int r, int j, float hb) {
                                YB[r * ldf + j] += hb; FB0[r * ldf + j] = fmaf(0.25f * h, hb, FB0[r * ldf + j]);
-                               GB0[r * ldf + j] = fmaf(0.5f * rdt, hb, GB0[r * ldf + j]); });
+                               GB0[r * ldf + j] = fmaf(SRK_B1_10 * rdt, hb, GB0[r * ldf + j]); });
             for_elems([&](int r, int j, int) { S0[r * ldy + j] = Y[r * ldy + j] + F0[r * ldf + j] * h; });
             fwd_chain(tp1);
             {
@@ -1364,7 +1364,7 @@ __global__ void __launch_bounds__(GW) snsde_generic_srk_adjoint_kernel(SrkAdjArg
             const float y = Y[r * ldy + j], f0 = F0[r * ldf + j], f1 = F1[r * ldf + j], g0 = G0[r * ldf + j];
             const float du = DU[r * ldf + j];
             float g1p;
-            const float g1 = g_and_prime(y + 0.25f * f0 * h + 0.5f * g0 * rdt, tpq[0], n, 1, j, g1p);   // at H1_1
+            const float g1 = g_and_prime(y + 0.25f * f0 * h + SRK_B1_10 * g0 * rdt, tpq[0], n, 1, j, g1p);   // at H1_1
             G1[r * ldf + j] = g1;
             S0[r * ldy + j] = y + 0.25f * f0 * h + 0.25f * f1 * h + g0 * du / h + 0.5f * g1 * du / h;  // H0_2
         });
@@ -1376,27 +1376,27 @@ __global__ void __launch_bounds__(GW) snsde_generic_srk_adjoint_kernel(SrkAdjArg
             const float f0 = F0[r * ldf + j], f2 = F2[r * ldf + j], g0 = G0[r * ldf + j], g1 = G1[r * ldf + j];
             const float ik = DW[r * ldf + j], ik0 = DU[r * ldf + j];
             float gp;
-            const float h12 = y + f0 * h - g0 * rdt;
+            const float h12 = y + f0 * h + SRK_B1_20 * g0 * rdt;
             const float g2 = g_and_prime(h12, tp1[0], n, 3, j, gp);
             const float g2p = gp;
             const float ikk = 0.5f * (ik * ik - h);
             const float ikkk = (ik * ik * ik - 3.0f * h * ik) / 6.0f;
             const float a1 = ik, a2 = ikk / rdt, a3 = ik0 / h, a4 = ikkk / h;
-            const float w0 = -a1 - a2 + 2.0f * a3 - 2.0f * a4;
-            const float w1 = (4.0f / 3.0f) * a1 + (4.0f / 3.0f) * a2 - (4.0f / 3.0f) * a3 + (5.0f / 3.0f) * a4;
-            const float w2 = (2.0f / 3.0f) * a1 - (1.0f / 3.0f) * a2 - (2.0f / 3.0f) * a3 - (2.0f / 3.0f) * a4;
+            const float w0 = srk_w0(a1, a2, a3, a4);
+            const float w1 = srk_w1(a1, a2, a3, a4);
+            const float w2 = srk_w2(a1, a2, a3, a4);
             const float w3 = a4;
             float fb0 = av * (h / 6.0f), fb1 = fb0, fb2 = av * (2.0f * h / 3.0f);
             float gb0 = w0 * av, gb1 = w1 * av, gb2 = w2 * av, yb = YB[r * ldf + j];
-            // stage 3: H1_3 = y + f2 h/4 + (-5 g0 + 3 g1 + g2/2) sqrt(h), evaluated at t0 + h/4
-            const float h13 = y + 0.25f * f2 * h + (-5.0f * g0 + 3.0f * g1 + 0.5f * g2) * rdt;
+            // stage 3: H1_3 = y + f2 h/4 + (2 g0 - g1 + g2/2) sqrt(h), evaluated at t0 + h/4
+            const float h13 = y + 0.25f * f2 * h + (SRK_B1_30 * g0 + SRK_B1_31 * g1 + SRK_B1_32 * g2) * rdt;
             g_and_prime(h13, tpq[0], n, 1, j, gp);
             float hb = w3 * av * gp;
             yb += hb; fb2 = fmaf(0.25f * h, hb, fb2);
-            gb0 = fmaf(-5.0f * rdt, hb, gb0); gb1 = fmaf(3.0f * rdt, hb, gb1); gb2 = fmaf(0.5f * rdt, hb, gb2);
-            // stage 2, diffusion half: H1_2 = y + f0 h - g0 sqrt(h)
+            gb0 = fmaf(SRK_B1_30 * rdt, hb, gb0); gb1 = fmaf(SRK_B1_31 * rdt, hb, gb1); gb2 = fmaf(SRK_B1_32 * rdt, hb, gb2);
+            // stage 2, diffusion half: H1_2 = y + f0 h + g0 sqrt(h)
             hb = gb2 * g2p;
-            yb += hb; fb0 = fmaf(h, hb, fb0); gb0 = fmaf(-rdt, hb, gb0);
+            yb += hb; fb0 = fmaf(h, hb, fb0); gb0 = fmaf(SRK_B1_20 * rdt, hb, gb0);
             FB0[r * ldf + j] = fb0; FB1[r * ldf + j] = fb1; FB2[r * ldf + j] = fb2;
             GB0[r * ldf + j] = gb0; GB1[r * ldf + j] = gb1; GB2[r * ldf + j] = gb2;
             G2[r * ldf + j] = g2;
@@ -1414,15 +1414,15 @@ __global__ void __launch_bounds__(GW) snsde_generic_srk_adjoint_kernel(SrkAdjArg
                 GB1[r * ldf + j] = fmaf(0.5f * du / h, dv, GB1[r * ldf + j]);
             });
         }
-        // stage 1: H1_1 = y + f0 h/4 + g0 sqrt(h)/2 (diffusion at t0 + h/4), H0_1 = y + f0 h (drift at t0 + h)
+        // stage 1: H1_1 = y + f0 h/4 - g0 sqrt(h)/2 (diffusion at t0 + h/4), H0_1 = y + f0 h (drift at t0 + h)
         for_elems([&](int r, int j, int) {
             const float y = Y[r * ldy + j], f0 = F0[r * ldf + j], g0 = G0[r * ldf + j];
             float gp;
-            g_and_prime(y + 0.25f * f0 * h + 0.5f * g0 * rdt, tpq[0], n, 1, j, gp);
+            g_and_prime(y + 0.25f * f0 * h + SRK_B1_10 * g0 * rdt, tpq[0], n, 1, j, gp);
             const float hb = GB1[r * ldf + j] * gp;
             YB[r * ldf + j] += hb;
             FB0[r * ldf + j] = fmaf(0.25f * h, hb, FB0[r * ldf + j]);
-            GB0[r * ldf + j] = fmaf(0.5f * rdt, hb, GB0[r * ldf + j]);
+            GB0[r * ldf + j] = fmaf(SRK_B1_10 * rdt, hb, GB0[r * ldf + j]);
             S0[r * ldy + j] = y + f0 * h;
         });
         fwd_chain(tp1);

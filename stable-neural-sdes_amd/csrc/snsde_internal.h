@@ -94,6 +94,30 @@ int snsde_spline_launch(const float* coeffs, int32_t B, int32_t L, int32_t C, in
 // ------------------------------------------------------------------------------------------------
 #ifdef __HIPCC__
 
+// ---- SRK tableau: Roessler's SRI2W1 (SIAM J. Numer. Anal. 48(3), 2010, Table 5.2: strong order 1.5, diagonal noise; the
+// coefficients torchsde 0.2.5 ships as _core/methods/tableaus/srid2.py and SRK.diagonal_or_scalar_step walks).  The kernels spell the
+// stage formulas out, so only the rows with more than one possible transcription are named here; the whole tableau is in
+// oracle/sde_oracle.py (SRK_*), checked term by term against an exact-rational evaluation of the published table
+// (tests/golden/make_srk_golden.py).  Rounds 1 - 5 carried B(1) / beta(2) of SRI1W1 (srid1) in these two places: a valid order-1.5
+// scheme, but not torchsde's trajectory on the same draws.
+//   c(1) = (0, 1/4, 1, 1/4)     A(1) = [1/4; 1 0; 0 0 1/4]     B(1) = [-1/2; 1 0; 2 -1 1/2]
+//   H1_1 = y + f0 h/4 + B1_10 g0 sqrt h        H1_2 = y + f0 h + B1_20 g0 sqrt h
+//   H1_3 = y + f2 h/4 + (B1_30 g0 + B1_31 g1 + B1_32 g2) sqrt h
+#define SRK_B1_10 (-0.5f)
+#define SRK_B1_20 (1.0f)
+#define SRK_B1_30 (2.0f)
+#define SRK_B1_31 (-1.0f)
+#define SRK_B1_32 (0.5f)
+// diffusion weights of the stages: w_s = beta1_s I_k + beta2_s I_kk / sqrt h + beta3_s I_k0 / h + beta4_s I_kkk / h  (a1 .. a4);
+//   beta1 = (-1, 4/3, 2/3, 0)  beta2 = (1, -4/3, 1/3, 0)  beta3 = (2, -4/3, -2/3, 0)  beta4 = (-2, 5/3, -2/3, 1)   (w_3 = a4)
+__device__ __forceinline__ float srk_w0(float a1, float a2, float a3, float a4) { return -a1 + a2 + 2.0f * a3 - 2.0f * a4; }
+__device__ __forceinline__ float srk_w1(float a1, float a2, float a3, float a4) {
+    return (4.0f / 3.0f) * a1 - (4.0f / 3.0f) * a2 - (4.0f / 3.0f) * a3 + (5.0f / 3.0f) * a4;
+}
+__device__ __forceinline__ float srk_w2(float a1, float a2, float a3, float a4) {
+    return (2.0f / 3.0f) * a1 + (1.0f / 3.0f) * a2 - (2.0f / 3.0f) * a3 - (2.0f / 3.0f) * a4;
+}
+
 __device__ __forceinline__ float snsde_sigmoid(float x) { return 1.0f / (1.0f + expf(-x)); }
 
 // torch.nan_to_num defaults: NaN -> 0, +inf -> FLT_MAX, -inf -> -FLT_MAX (neuralsde.py:306)

@@ -532,17 +532,17 @@ __global__ void __launch_bounds__(CF::NT, CF::WPS) snsde_m4n_kernel(MfmaArgs a) 
                 sk_f0 = f;
                 sk_g0 = gfun(q, yb);
                 h0n = yb + f * h;
-                h1n = yb + 0.25f * f * h + 0.5f * sk_g0 * sqh;
+                h1n = yb + 0.25f * f * h + SRK_B1_10 * sk_g0 * sqh;
             } else if (stage == 1) {     // F1 at (t0 + h, H0_1), G1 at (t0 + h/4, H1_1)
                 sk_f1 = f;
                 const float g1 = gfun(q, sk_h1);
                 sk_g1 = g1;
                 const float du = sk_du;
                 h0n = yb + 0.25f * f0 * h + 0.25f * f * h + (g0 + 0.5f * g1) * (du * sk_rh);
-                h1n = yb + f0 * h - g0 * sqh;
+                h1n = yb + f0 * h + SRK_B1_20 * g0 * sqh;
             } else {                     // F2 at (t0 + h/2, H0_2), G2 at (t0 + h, H1_2); H1_3 for the tail
                 sk_g2 = gfun(q, sk_h1);
-                h1n = yb + 0.25f * f * h + (-5.0f * g0 + 3.0f * sk_g1 + 0.5f * sk_g2) * sqh;
+                h1n = yb + 0.25f * f * h + (SRK_B1_30 * g0 + SRK_B1_31 * sk_g1 + SRK_B1_32 * sk_g2) * sqh;
                 h0n = 0.0f;
             }
             sk_h1 = h1n;
@@ -571,9 +571,9 @@ __global__ void __launch_bounds__(CF::NT, CF::WPS) snsde_m4n_kernel(MfmaArgs a) 
                 const float ikk = 0.5f * (ik * ik - h);
                 const float ikkk = (ik * ik * ik - 3.0f * h * ik) * (1.0f / 6.0f);
                 const float a1 = ik, a2 = ikk * sk_rsqh, a3 = ik0 * sk_rh, a4 = ikkk * sk_rh;
-                const float w0 = -a1 - a2 + 2.0f * a3 - 2.0f * a4;
-                const float w1 = (4.0f / 3.0f) * a1 + (4.0f / 3.0f) * a2 - (4.0f / 3.0f) * a3 + (5.0f / 3.0f) * a4;
-                const float w2 = (2.0f / 3.0f) * a1 - (1.0f / 3.0f) * a2 - (2.0f / 3.0f) * a3 - (2.0f / 3.0f) * a4;
+                const float w0 = srk_w0(a1, a2, a3, a4);
+                const float w1 = srk_w1(a1, a2, a3, a4);
+                const float w2 = srk_w2(a1, a2, a3, a4);
                 float yn1 = yb + (f0 + f1) * (h * (1.0f / 6.0f)) + f * (h * (2.0f / 3.0f));
                 yn1 += w0 * g0 + w1 * g1 + w2 * g2 + a4 * g3;
                 sk_y = yn1; sk_h1 = yn1; yv = yn1;

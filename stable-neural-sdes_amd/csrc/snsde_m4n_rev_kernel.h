@@ -246,16 +246,16 @@ __global__ void __launch_bounds__(CF::NT, CF::WPS) snsde_m4n_srk_reverse_kernel(
         const float f0 = f_lin ? zc[0] : fast_tanh(zc[0] * gate(y));
         const float g0 = gfun(cur.q[0], y, om0, rc0, fi0);
         const float h01 = y + f0 * h;
-        const float h11 = y + 0.25f * f0 * h + 0.5f * g0 * rdt;
+        const float h11 = y + 0.25f * f0 * h + SRK_B1_10 * g0 * rdt;
         const float f1 = f_lin ? zc[1] : fast_tanh(zc[1] * gate(h01));
         const float g1 = gfun(cur.q[1], h11, om1, rc1, fi1);
         const float rh = 1.0f / h, rrdt = 1.0f / rdt;      // (the forward's two divisions per step; every `/ h`, `/ rdt` below multiplies)
         const float ik0h = ik0 * rh;
         const float h02 = y + 0.25f * f0 * h + 0.25f * f1 * h + (g0 + 0.5f * g1) * ik0h;
         const float f2 = f_lin ? zc[2] : fast_tanh(zc[2] * gate(h02));
-        const float h12 = y + f0 * h - g0 * rdt;
+        const float h12 = y + f0 * h + SRK_B1_20 * g0 * rdt;
         const float g2 = gfun(cur.q[2], h12, om2, rc2, fi2);
-        const float h13 = y + 0.25f * f2 * h + (-5.0f * g0 + 3.0f * g1 + 0.5f * g2) * rdt;
+        const float h13 = y + 0.25f * f2 * h + (SRK_B1_30 * g0 + SRK_B1_31 * g1 + SRK_B1_32 * g2) * rdt;
         const float g3 = gfun(cur.q[3], h13, om3, rc3, fi3);
         (void)g3;
 
@@ -263,9 +263,9 @@ __global__ void __launch_bounds__(CF::NT, CF::WPS) snsde_m4n_srk_reverse_kernel(
         const float ikk = 0.5f * (ik * ik - h);
         const float ikkk = (ik * ik * ik - 3.0f * h * ik) * (1.0f / 6.0f);
         const float a1 = ik, a2 = ikk * rrdt, a3 = ik0h, a4 = ikkk * rh;
-        const float wg0 = -a1 - a2 + 2.0f * a3 - 2.0f * a4;
-        const float wg1 = (4.0f / 3.0f) * a1 + (4.0f / 3.0f) * a2 - (4.0f / 3.0f) * a3 + (5.0f / 3.0f) * a4;
-        const float wg2 = (2.0f / 3.0f) * a1 - (1.0f / 3.0f) * a2 - (2.0f / 3.0f) * a3 - (2.0f / 3.0f) * a4;
+        const float wg0 = srk_w0(a1, a2, a3, a4);
+        const float wg1 = srk_w1(a1, a2, a3, a4);
+        const float wg2 = srk_w2(a1, a2, a3, a4);
         float yb = carry + av;
         float fb0 = av * (h * (1.0f / 6.0f)), fb1 = fb0, fb2 = av * (h * (2.0f / 3.0f));
         float gb0 = wg0 * av, gb1 = wg1 * av, gb2 = wg2 * av;
@@ -309,14 +309,14 @@ __global__ void __launch_bounds__(CF::NT, CF::WPS) snsde_m4n_srk_reverse_kernel(
         chains(false, 0, 0.0f, zb[2], true, 3 * n + 2, NB0 + NN, qb, ((zb[2] >> (NHID + 2)) & 1u) != 0, dres, nres, nullptr, nf[3]);
         float hb = nres + nd;
         yb += hb; fb2 = fmaf(0.25f * h, hb, fb2);
-        gb0 = fmaf(-5.0f * rdt, hb, gb0); gb1 = fmaf(3.0f * rdt, hb, gb1); gb2 = fmaf(0.5f * rdt, hb, gb2);
+        gb0 = fmaf(SRK_B1_30 * rdt, hb, gb0); gb1 = fmaf(SRK_B1_31 * rdt, hb, gb1); gb2 = fmaf(SRK_B1_32 * rdt, hb, gb2);
         // ---- G2 = g(t0 + h, H1_2) beside the drift at (t0 + h/2, H0_2) ----
         qb = net_in(gb2, om2, rc2, fi2, cur.q[2], h12, nd);
         float dz = drift_in(fb2, f2, zc[2], h02, dd);
         chains(true, 3 * n + 2, dz, zb[2], true, 3 * n + 2, NB0, qb, ((zb[2] >> (NHID + 1)) & 1u) != 0, dres, nres, df[VAR ? 2 : 0], nf[2]);
         hb = nres + nd;
         float d = dres + dd;
-        yb += hb; fb0 = fmaf(h, hb, fb0); gb0 = fmaf(-rdt, hb, gb0);
+        yb += hb; fb0 = fmaf(h, hb, fb0); gb0 = fmaf(SRK_B1_20 * rdt, hb, gb0);
         yb += d;
         fb0 = fmaf(0.25f * h, d, fb0); fb1 = fmaf(0.25f * h, d, fb1);
         gb0 = fmaf(ik0h, d, gb0); gb1 = fmaf(0.5f * ik0h, d, gb1);
@@ -326,7 +326,7 @@ __global__ void __launch_bounds__(CF::NT, CF::WPS) snsde_m4n_srk_reverse_kernel(
         chains(true, 3 * n + 1, dz, zb[1], true, 3 * n + 1, NB0, qb, ((zb[1] >> (NHID + 1)) & 1u) != 0, dres, nres, df[VAR ? 1 : 0], nf[1]);
         hb = nres + nd;
         d = dres + dd;
-        yb += hb; fb0 = fmaf(0.25f * h, hb, fb0); gb0 = fmaf(0.5f * rdt, hb, gb0);
+        yb += hb; fb0 = fmaf(0.25f * h, hb, fb0); gb0 = fmaf(SRK_B1_10 * rdt, hb, gb0);
         yb += d; fb0 = fmaf(h, d, fb0);
         // ---- G0 and F0, both at (t0, y) ----
         qb = net_in(gb0, om0, rc0, fi0, cur.q[0], y, nd);

@@ -273,6 +273,9 @@ MfmaPlan make_plan(const snsde_solve* s, const SnsdeNet& net, int flavor_hint) {
     const snsde_model& m = s->model;
     const int H = m.hidden_channels, io = m.input_option, no = m.noise_option;
     p.ok = false;
+    // kernel = 'w4' is a strict request: where the wave-pair kernels do not take the configuration there is no plan, so that the
+    // path query, the launch, snsde_backward_supported and snsde_save_layout all report the same thing
+    if (hint_in == 2 && !snsde_w4_supported(s, net)) return p;
     if (m.hidden_hidden_channels != H) return p;
     // the MFMA kernels form their per-step save offsets from 32-bit uniform factors (uoff): slots x B x H must fit.  Refused HERE
     // (not only in the launchers) so that `auto` falls through to the generic kernels and snsde_backward_supported reports what the

@@ -912,21 +912,21 @@ __global__ void __launch_bounds__(CF::NT, CF::WPS) snsde_mfma_kernel(MfmaArgs a)
                         yin = yb + f * h;
                     } else if (stage == 1) {     // F1 at (t0 + h, H0_1), G1 at (t0 + h/4, H1_1);  H0_2
                         sk_f1[e] = f;
-                        const float g1 = gfun(sk_t1[e], yb + 0.25f * f0 * h + 0.5f * g0 * sqh);
+                        const float g1 = gfun(sk_t1[e], yb + 0.25f * f0 * h + SRK_B1_10 * g0 * sqh);
                         sk_g1[e] = g1;
                         const float du = sk_du[e];
                         yin = yb + 0.25f * f0 * h + 0.25f * f * h + (g0 + 0.5f * g1) * (du * (1.0f / h));      // (1 / h: one division for the tile's EPT elements)
                     } else {                     // F2 at (t0 + h/2, H0_2), G2 at (t0 + h, H1_2), G3 at (t0 + h/4, H1_3): combine
                         const float f1 = sk_f1[e], g1 = sk_g1[e], ik = sk_dw[e], ik0 = sk_du[e];
-                        const float g2 = gfun(sk_t3[e], yb + f0 * h - g0 * sqh);
-                        const float g3 = gfun(sk_t1[e], yb + 0.25f * f * h + (-5.0f * g0 + 3.0f * g1 + 0.5f * g2) * sqh);
+                        const float g2 = gfun(sk_t3[e], yb + f0 * h + SRK_B1_20 * g0 * sqh);
+                        const float g3 = gfun(sk_t1[e], yb + 0.25f * f * h + (SRK_B1_30 * g0 + SRK_B1_31 * g1 + SRK_B1_32 * g2) * sqh);
                         const float ikk = 0.5f * (ik * ik - h);
                         const float rh = 1.0f / h, rsqh = 1.0f / sqh;      // (uniform: two divisions per pass instead of five per element)
                         const float ikkk = (ik * ik * ik - 3.0f * h * ik) * (1.0f / 6.0f);
                         const float a1 = ik, a2 = ikk * rsqh, a3 = ik0 * rh, a4 = ikkk * rh;
-                        const float w0 = -a1 - a2 + 2.0f * a3 - 2.0f * a4;
-                        const float w1 = (4.0f / 3.0f) * a1 + (4.0f / 3.0f) * a2 - (4.0f / 3.0f) * a3 + (5.0f / 3.0f) * a4;
-                        const float w2 = (2.0f / 3.0f) * a1 - (1.0f / 3.0f) * a2 - (2.0f / 3.0f) * a3 - (2.0f / 3.0f) * a4;
+                        const float w0 = srk_w0(a1, a2, a3, a4);
+                        const float w1 = srk_w1(a1, a2, a3, a4);
+                        const float w2 = srk_w2(a1, a2, a3, a4);
                         float yn1 = yb + (f0 + f1) * (h * (1.0f / 6.0f)) + f * (h * (2.0f / 3.0f));
                         yn1 += w0 * g0 + w1 * g1 + w2 * g2 + a4 * g3;
                         sk_y[e] = yn1;
@@ -1717,33 +1717,33 @@ __global__ void __launch_bounds__(CF::NT, CF::WPS) snsde_mfma_srk_reverse_kernel
         const float g0 = gfun(t0v, y, g0p, rc0, fi0);
         const float h01 = y + f0 * h;
         const float f1 = fout(z1, h01);
-        const float h11 = y + 0.25f * f0 * h + 0.5f * g0 * rdt;
+        const float h11 = y + 0.25f * f0 * h + SRK_B1_10 * g0 * rdt;
         const float g1 = gfun(t1v, h11, g1p, rc1, fi1);
         const float rh = 1.0f / h, rrdt = 1.0f / rdt;      // (as the forward: every `/ h`, `/ rdt` below multiplies)
         const float ik0h = ik0 * rh;
         const float h02 = y + 0.25f * f0 * h + 0.25f * f1 * h + (g0 + 0.5f * g1) * ik0h;
         const float f2 = fout(z2, h02);
-        const float h12 = y + f0 * h - g0 * rdt;
+        const float h12 = y + f0 * h + SRK_B1_20 * g0 * rdt;
         const float g2 = gfun(t3v, h12, g2p, rc2, fi2);
-        const float h13 = y + 0.25f * f2 * h + (-5.0f * g0 + 3.0f * g1 + 0.5f * g2) * rdt;
+        const float h13 = y + 0.25f * f2 * h + (SRK_B1_30 * g0 + SRK_B1_31 * g1 + SRK_B1_32 * g2) * rdt;
         const float g3 = gfun(t1v, h13, g3p, rc3, fi3);
         // ---- reverse of the combination and of stage 3 / the diffusion half of stage 2 ----
         const float av = adj;
         const float ikk = 0.5f * (ik * ik - h);
         const float ikkk = (ik * ik * ik - 3.0f * h * ik) * (1.0f / 6.0f);
         const float a1 = ik, a2 = ikk * rrdt, a3 = ik0h, a4 = ikkk * rh;
-        const float w0 = -a1 - a2 + 2.0f * a3 - 2.0f * a4;
-        const float w1 = (4.0f / 3.0f) * a1 + (4.0f / 3.0f) * a2 - (4.0f / 3.0f) * a3 + (5.0f / 3.0f) * a4;
-        const float w2 = (2.0f / 3.0f) * a1 - (1.0f / 3.0f) * a2 - (2.0f / 3.0f) * a3 - (2.0f / 3.0f) * a4;
+        const float w0 = srk_w0(a1, a2, a3, a4);
+        const float w1 = srk_w1(a1, a2, a3, a4);
+        const float w2 = srk_w2(a1, a2, a3, a4);
         float yb = carry + av;
         float fb0 = av * (h * (1.0f / 6.0f)), fb1 = fb0, fb2 = av * (h * (2.0f / 3.0f));
         float gb0 = w0 * av, gb1 = w1 * av, gb2 = w2 * av;
         const float gb3 = a4 * av;
         float hb = gb3 * g3p;
         yb += hb; fb2 = fmaf(0.25f * h, hb, fb2);
-        gb0 = fmaf(-5.0f * rdt, hb, gb0); gb1 = fmaf(3.0f * rdt, hb, gb1); gb2 = fmaf(0.5f * rdt, hb, gb2);
+        gb0 = fmaf(SRK_B1_30 * rdt, hb, gb0); gb1 = fmaf(SRK_B1_31 * rdt, hb, gb1); gb2 = fmaf(SRK_B1_32 * rdt, hb, gb2);
         hb = gb2 * g2p;
-        yb += hb; fb0 = fmaf(h, hb, fb0); gb0 = fmaf(-rdt, hb, gb0);
+        yb += hb; fb0 = fmaf(h, hb, fb0); gb0 = fmaf(SRK_B1_20 * rdt, hb, gb0);
         // parameter side of G3 (slot 1, completed below with G1) and G2 (slot 3)
         float ds1 = 0.0f;
         if (tsum) {
@@ -1762,7 +1762,7 @@ __global__ void __launch_bounds__(CF::NT, CF::WPS) snsde_mfma_srk_reverse_kernel
         gb0 = fmaf(ik0h, d, gb0); gb1 = fmaf(0.5f * ik0h, d, gb1);
         // ---- stage 1: diffusion at (t0 + h/4, H1_1), drift at (t0 + h, H0_1) ----
         hb = gb1 * g1p;
-        yb += hb; fb0 = fmaf(0.25f * h, hb, fb0); gb0 = fmaf(0.5f * rdt, hb, gb0);
+        yb += hb; fb0 = fmaf(0.25f * h, hb, fb0); gb0 = fmaf(SRK_B1_10 * rdt, hb, gb0);
         if (tsum) {
             const float c1 = gb1 * (g_raw ? 1.0f : 1.0f - g1 * g1) * rowf;
             if (!g_raw) th_acc = fmaf(c1, rc1, th_acc);

@@ -764,14 +764,14 @@ __global__ void __launch_bounds__(256, 2) snsde_w4_srk_kernel(W4Args a) {
             pair_barrier();                                   // B1
             get(XF0, f0);
 #pragma unroll
-            for (int i = 0; i < 4; ++i) x[i] = y[i] + 0.25f * f0[i] * h + 0.5f * g0[i] * sqh;      // H1_1
+            for (int i = 0; i < 4; ++i) x[i] = y[i] + 0.25f * f0[i] * h + SRK_B1_10 * g0[i] * sqh;      // H1_1
             // ---- G1 at (t0 + h/4, H1_1) ----
             net(x, sq, cq, 3 * n + 1, ZSLOT + 1, XS1, g1);
             put(XG1, g1);
             pair_barrier();                                   // B2
             get(XF1, f1);
 #pragma unroll
-            for (int i = 0; i < 4; ++i) x[i] = y[i] + f0[i] * h - g0[i] * sqh;                     // H1_2
+            for (int i = 0; i < 4; ++i) x[i] = y[i] + f0[i] * h + SRK_B1_20 * g0[i] * sqh;                     // H1_2
             // ---- G2 at (t0 + h, H1_2) ----
             net(x, s1, c1, 3 * n + 2, ZSLOT + 1, XS2, g2);
             // everything of the step's result that does not need F2 / G3, while the drift wave finishes F2 (same association as the
@@ -782,9 +782,9 @@ __global__ void __launch_bounds__(256, 2) snsde_w4_srk_kernel(W4Args a) {
                 const float ikk = 0.5f * (ik[i] * ik[i] - h);
                 const float ikkk = (ik[i] * ik[i] * ik[i] - 3.0f * h * ik[i]) * (1.0f / 6.0f);
                 const float a1 = ik[i], a2 = ikk * rsqh, a3 = ik0[i] * rh, a4 = ikkk * rh;
-                const float w0 = -a1 - a2 + 2.0f * a3 - 2.0f * a4;
-                const float w1 = (4.0f / 3.0f) * a1 + (4.0f / 3.0f) * a2 - (4.0f / 3.0f) * a3 + (5.0f / 3.0f) * a4;
-                const float w2 = (2.0f / 3.0f) * a1 - (1.0f / 3.0f) * a2 - (2.0f / 3.0f) * a3 - (2.0f / 3.0f) * a4;
+                const float w0 = srk_w0(a1, a2, a3, a4);
+                const float w1 = srk_w1(a1, a2, a3, a4);
+                const float w2 = srk_w2(a1, a2, a3, a4);
                 pa[i] = y[i] + (f0[i] + f1[i]) * (h * (1.0f / 6.0f));
                 ps[i] = w0 * g0[i] + w1 * g1[i] + w2 * g2[i];
                 a4v[i] = a4;
@@ -792,7 +792,7 @@ __global__ void __launch_bounds__(256, 2) snsde_w4_srk_kernel(W4Args a) {
             pair_barrier();                                   // B3
             get(XF2, f2);
 #pragma unroll
-            for (int i = 0; i < 4; ++i) x[i] = y[i] + 0.25f * f2[i] * h + (-5.0f * g0[i] + 3.0f * g1[i] + 0.5f * g2[i]) * sqh;   // H1_3
+            for (int i = 0; i < 4; ++i) x[i] = y[i] + 0.25f * f2[i] * h + (SRK_B1_30 * g0[i] + SRK_B1_31 * g1[i] + SRK_B1_32 * g2[i]) * sqh;   // H1_3
             // ---- G3 at (t0 + h/4, H1_3), then the step ----
             net(x, sq, cq, 3 * n + 2, ZSLOT + NN + 1, XS3, g3);
             float yn[4];
@@ -1629,9 +1629,9 @@ __global__ void __launch_bounds__(512, 2) snsde_w4_srk_reverse_kernel(W4SrkRevAr
                 const float ikkk = (ik[i] * ik[i] * ik[i] - 3.0f * h * ik[i]) * (1.0f / 6.0f);
                 ik0h[i] = ik0[i] * rh;
                 const float a1 = ik[i], a2 = ikk * rrdt, a3 = ik0h[i], a4 = ikkk * rh;
-                wg[0][i] = -a1 - a2 + 2.0f * a3 - 2.0f * a4;
-                wg[1][i] = (4.0f / 3.0f) * a1 + (4.0f / 3.0f) * a2 - (4.0f / 3.0f) * a3 + (5.0f / 3.0f) * a4;
-                wg[2][i] = (2.0f / 3.0f) * a1 - (1.0f / 3.0f) * a2 - (2.0f / 3.0f) * a3 - (2.0f / 3.0f) * a4;
+                wg[0][i] = srk_w0(a1, a2, a3, a4);
+                wg[1][i] = srk_w1(a1, a2, a3, a4);
+                wg[2][i] = srk_w2(a1, a2, a3, a4);
                 wg[3][i] = a4;
             }
             if (n > 0) { load4(a.dW + uoff(n - 1, BH), ik); load4(a.dU + uoff(n - 1, BH), ik0); }
@@ -1697,14 +1697,14 @@ __global__ void __launch_bounds__(512, 2) snsde_w4_srk_reverse_kernel(W4SrkRevAr
             net_eval(IC<3>{}, hb);
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
-                gb[0][i] = fmaf(-5.0f * rdt, hb[i], gb[0][i]); gb[1][i] = fmaf(3.0f * rdt, hb[i], gb[1][i]); gb[2][i] = fmaf(0.5f * rdt, hb[i], gb[2][i]);
+                gb[0][i] = fmaf(SRK_B1_30 * rdt, hb[i], gb[0][i]); gb[1][i] = fmaf(SRK_B1_31 * rdt, hb[i], gb[1][i]); gb[2][i] = fmaf(SRK_B1_32 * rdt, hb[i], gb[2][i]);
             }
             put(XH + 1, hb);
             W4_T(2) pair_barrier(); W4_T(3)                                     // B1
             // ---- G2 beside drift pass 2 ----
             net_eval(IC<2>{}, hb);
 #pragma unroll
-            for (int i = 0; i < 4; ++i) gb[0][i] = fmaf(-rdt, hb[i], gb[0][i]);
+            for (int i = 0; i < 4; ++i) gb[0][i] = fmaf(SRK_B1_20 * rdt, hb[i], gb[0][i]);
             put(XH, hb);
             W4_T(4) pair_barrier(); W4_T(5)                                     // B2
             {
@@ -1716,7 +1716,7 @@ __global__ void __launch_bounds__(512, 2) snsde_w4_srk_reverse_kernel(W4SrkRevAr
             // ---- G1 beside drift pass 1 ----
             net_eval(IC<1>{}, hb);
 #pragma unroll
-            for (int i = 0; i < 4; ++i) gb[0][i] = fmaf(0.5f * rdt, hb[i], gb[0][i]);
+            for (int i = 0; i < 4; ++i) gb[0][i] = fmaf(SRK_B1_10 * rdt, hb[i], gb[0][i]);
             put(XH + 1, hb);
             W4_T(6) pair_barrier(); W4_T(7)                                     // B3
             // ---- G0 beside drift pass 0 ----

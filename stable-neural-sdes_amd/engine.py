@@ -481,6 +481,12 @@ class SolveCall:
             s.seed_dev = _ptr(seed)
         else:
             s.seed = int(seed) & 0xFFFFFFFFFFFFFFFF
+        # every configuration field the plan looks at goes in BEFORE the layout / workspace queries (which adjoint a solve gets
+        # depends on the supplied increments, the noise table, the accumulator column and the per-row output selection)
+        s.dW, s.row_out, s.noise_table = _ptr(dW), _ptr(row_out), _ptr(noise_table)
+        s.row_offset = int(row_offset)
+        if kl_column is not None:     # (column, a, b): path-integral accumulator column with the linear prior drift a y + b (snsde.h)
+            s.kl_column1, s.kl_prior_a, s.kl_prior_b = int(kl_column[0]) + 1, float(kl_column[1]), float(kl_column[2])
         # host-side queries of the library (save layout, workspace sizes) depend on the configuration only: memoised
         self.cfg_key = (model.input_channels, model.hidden_channels, model.hidden_hidden_channels, model.num_hidden_layers,
                         model.input_option, model.noise_option, model.activation, model.drift_output, model.diffusion_output,
@@ -503,19 +509,14 @@ class SolveCall:
             s.dU = _ptr(dU)
             self.dU_out = torch.empty((grid.N, B, H), device=dev, dtype=torch.float32) if save_dW else None
             s.dU_out = _ptr(self.dU_out)
-        s.row_offset = int(row_offset)
         s.params, s.coeffs = _ptr(flat_params), _ptr(coeffs)
         s.step_tab, s.out_step, s.out_w = _ptr(grid.d_step_tab), _ptr(grid.d_out_step), _ptr(grid.d_out_w)
-        s.y0, s.dW, s.ys = _ptr(y0), _ptr(dW), _ptr(self.ys)
+        s.y0, s.ys = _ptr(y0), _ptr(self.ys)
         s.traj, s.dW_out = _ptr(self.traj), _ptr(self.dW_out)
         s.act_save = _ptr(self.act_save)
         s.stage_save = _ptr(self.stage_save)
-        s.row_out = _ptr(row_out)
-        s.noise_table = _ptr(noise_table)
         if z0_linear is not None:
             s.z0_weight, s.z0_bias = _ptr(z0_linear[0]), _ptr(z0_linear[1])
-        if kl_column is not None:     # (column, a, b): path-integral accumulator column with the linear prior drift a y + b (snsde.h)
-            s.kl_column1, s.kl_prior_a, s.kl_prior_b = int(kl_column[0]) + 1, float(kl_column[1]), float(kl_column[2])
         nbytes = _SIZE_CACHE.get(('fwd',) + self.cfg_key)
         if nbytes is None:
             nbytes = _SIZE_CACHE[('fwd',) + self.cfg_key] = int(_lib.lib().snsde_workspace_bytes(C.byref(s)))
@@ -532,19 +533,22 @@ class SolveCall:
         flat, table = self.keep[0], self.keep[7]
         return (flat.data_ptr(), flat._version, None if table is None else (table.data_ptr(), table._version))
 
-    def launch(self, stream=None, reuse_prepared=False, auto_reuse=True):
+    def launch(self, stream=None, reuse_prepared=False, auto_reuse=False):
         """Enqueue the solve.  reuse_prepared=True skips weight packing / time tables (legal while the parameter block and grid are
-        unchanged since the previous launch of this call); with auto_reuse (default) the call sets the flag itself from the second
-        launch on while the parameter block's version counter has not moved (evaluation epochs, graph replays between optimizer
-        steps: the prepare launch is ~8 us of a 200 us K2 solve)."""
+        unchanged since the previous launch of this call).  auto_reuse=True (opt-in: evaluation epochs over frozen parameters) lets
+        the call set the flag itself from the second launch on while the parameter block's version counter has not moved - the
+        counter does NOT see writes through an alias (`p.data`, the per-parameter views of the arena an optimizer steps on), so a
+        call that lives across optimizer steps must not use it.  The prepare launch is ~8 us of a 200 us K2 solve."""
         stream = torch.cuda.current_stream(self.ys.device) if stream is None else stream
+        capturing = torch.cuda.is_current_stream_capturing()
         key = self._prepared_key()
-        if auto_reuse and not reuse_prepared and getattr(self, '_prep_key', None) == key and not torch.cuda.is_current_stream_capturing():
+        if auto_reuse and not reuse_prepared and not capturing and getattr(self, '_prep_key', None) == key:
             reuse_prepared = True
         self.desc.flags = self.base_flags | (_lib.FLAG_REUSE_PREPARED if reuse_prepared else 0)
         _lib.check(_lib.lib().snsde_solve_forward(C.byref(self.desc), C.c_void_p(stream.cuda_stream)),
                    'snsde_solve_forward')
-        self._prep_key = key
+        if not capturing:             # a recorded prepare launch has not run: it prepared nothing an eager launch could reuse
+            self._prep_key = key
         return self.ys
 
 

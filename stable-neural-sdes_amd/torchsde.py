@@ -875,11 +875,12 @@ def _call(sde, names, key, default):
     return getattr(sde, (names or {}).get(key, default))
 
 
-# SRID2 (Roessler 2010; torchsde 0.2.5 `srk` for diagonal noise), restated - see oracle/sde_oracle.py
+# Roessler's SRI2W1 (SIAM J. Numer. Anal. 48(3), 2010) = torchsde 0.2.5 `tableaus/srid2.py`, the scheme behind method='srk' for
+# diagonal noise; the same numbers as csrc/snsde_internal.h (SRK_B1_*, srk_w*) and, independently transcribed, oracle/sde_oracle.py
 _SRK = dict(C0=(0.0, 1.0, 0.5, 0.0), C1=(0.0, 0.25, 1.0, 0.25),
             A0=((), (1.0,), (0.25, 0.25), (0.0, 0.0, 0.0)), A1=((), (0.25,), (1.0, 0.0), (0.0, 0.0, 0.25)),
-            B0=((), (0.0,), (1.0, 0.5), (0.0, 0.0, 0.0)), B1=((), (0.5,), (-1.0, 0.0), (-5.0, 3.0, 0.5)),
-            alpha=(1 / 6, 1 / 6, 2 / 3, 0.0), beta1=(-1.0, 4 / 3, 2 / 3, 0.0), beta2=(-1.0, 4 / 3, -1 / 3, 0.0),
+            B0=((), (0.0,), (1.0, 0.5), (0.0, 0.0, 0.0)), B1=((), (-0.5,), (1.0, 0.0), (2.0, -1.0, 0.5)),
+            alpha=(1 / 6, 1 / 6, 2 / 3, 0.0), beta1=(-1.0, 4 / 3, 2 / 3, 0.0), beta2=(1.0, -4 / 3, 1 / 3, 0.0),
             beta3=(2.0, -4 / 3, -2 / 3, 0.0), beta4=(-2.0, 5 / 3, -2 / 3, 1.0))
 
 

@@ -163,7 +163,7 @@ class GraphedStep:
     shape run eagerly (on a side stream, as capture requires); a learning-rate change drops the recordings (the rate is a
     constant of the recorded optimizer kernel).  Needs an optimizer created with capturable=True."""
 
-    def __init__(self, model, times, optimizer, loss_fn, kwargs, device, warmup=3):
+    def __init__(self, model, times, optimizer, loss_fn, kwargs, device, warmup=3, log=None):
         from . import torchsde as _T
         _T.prepare_graph_capture(device)
         self.model, self.times, self.opt, self.loss_fn, self.kwargs = model, times, optimizer, loss_fn, kwargs
@@ -171,6 +171,8 @@ class GraphedStep:
         self.entries, self.lrs = {}, None
         self.side = torch.cuda.Stream(device)
         self.replays = 0
+        self.log = log or (lambda msg: None)
+        self.disabled = None          # reason the recordings were given up (a model that is not capture-safe): eager steps from then on
 
     def _step(self, coeffs, y, lengths):
         pred = self.model(self.times, coeffs, lengths, **self.kwargs)
@@ -179,7 +181,18 @@ class GraphedStep:
         self.opt.step()
         self.opt.zero_grad(set_to_none=True)
 
+    def _eager(self, coeffs, y, lengths):
+        """One eager step with the reference loop's handling of a failing batch (common_sde.py:157-166: an AssertionError of a
+        batch is reported and the loop goes on)."""
+        try:
+            self._step(list(coeffs), y, lengths)
+        except AssertionError as exc:
+            self.log('Caught AssertionError: ' + str(exc))
+            self.opt.zero_grad(set_to_none=True)
+
     def __call__(self, coeffs, y, lengths):
+        if self.disabled is not None:
+            return self._eager(coeffs, y, lengths)
         lrs = tuple(float(g['lr']) for g in self.opt.param_groups)
         if lrs != self.lrs:
             self.entries, self.lrs = {}, lrs
@@ -191,14 +204,23 @@ class GraphedStep:
                 entry['seen'] += 1
                 self.side.wait_stream(torch.cuda.current_stream(self.device))
                 with torch.cuda.stream(self.side):
-                    self._step(list(coeffs), y, lengths)
+                    self._eager(coeffs, y, lengths)
                 torch.cuda.current_stream(self.device).wait_stream(self.side)
                 return
             static = tuple(b.clone() for b in batch)
-            graph = torch.cuda.CUDAGraph()
             torch.cuda.synchronize(self.device)
-            with torch.cuda.graph(graph):
-                self._step(list(static[:-2]), static[-2], static[-1])
+            try:
+                graph = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(graph):
+                    self._step(list(static[:-2]), static[-2], static[-1])
+            except Exception as exc:                  # a host sync, .item(), an allocation the capture cannot take, a failing batch ...
+                self.disabled = f'{type(exc).__name__}: {exc}'
+                self.log('GraphedStep: the training step cannot be recorded (' + self.disabled.splitlines()[0] +
+                         '); eager steps from here on')
+                self.entries = {}
+                torch.cuda.synchronize(self.device)
+                self.opt.zero_grad(set_to_none=True)  # (nothing of the failed recording ran; drop gradients it may have allocated)
+                return self._eager(coeffs, y, lengths)
             entry['graph'], entry['static'] = graph, static
             graph.replay()                            # (the capture itself does not execute: run this batch's step now)
             self.replays += 1
@@ -229,7 +251,7 @@ def train_loop(train_dataloader, val_dataloader, model, times, optimizer, loss_f
     best_train_accuracy, best_train_accuracy_epoch = 0.0, 0
     best_val = -math.inf
     history = []
-    graphed = GraphedStep(model, times, optimizer, loss_fn, kwargs, torch.device(device)) if graph_steps else None
+    graphed = GraphedStep(model, times, optimizer, loss_fn, kwargs, torch.device(device), log=log) if graph_steps else None
     for epoch in range(max_epochs):
         sampler = getattr(train_dataloader, 'sampler', None)
         if hasattr(sampler, 'set_epoch'):

