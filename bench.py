@@ -48,10 +48,10 @@ BYTES_PER_ROWSTEP = 346             # SURVEY.md 8d algorithmic HBM bytes, Philox
 PEAK_FP32_TFLOPS = 157.3            # MI355X_MICROARCH.md: fp32 vector = fp32 MFMA peak
 PEAK_HBM_GBS = 8000.0
 # HBM bytes per launch of the solve kernel from rocprofv3 PMC passes (FETCH_SIZE doubled per the gfx950 correction
-# in MI355X_MICROARCH.md, + WRITE_SIZE; profiles/r05_pmc_counters.txt); re-measure when the kernel's memory behaviour changes.
+# in MI355X_MICROARCH.md, + WRITE_SIZE; profiles/r06_pmc_counters.txt); re-measure when the kernel's memory behaviour changes.
 HBM_TRAFFIC_BYTES_PER_LAUNCH = 38070272   # K2, lean M4 kernel: (2 x 18077.0 + 1024.0) KB
 HBM_TRAFFIC_KERNEL = ('lean', 'snsde_m4_kernel<CfgL<128, 1, 2, 1, 0, 0>>')     # the path / instantiation the profile was taken on
-HBM_TRAFFIC_SOURCE = ("profiles/r05_pmc_counters.txt: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes over this bench command, "
+HBM_TRAFFIC_SOURCE = ("profiles/r06_pmc_counters.txt: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes over this bench command, "
                       "mean of 187 dispatches of the solve kernel), 2 x FETCH_SIZE + WRITE_SIZE per the gfx950 correction of "
                       "MI355X_MICROARCH.md; a constant of the kernel's memory behaviour, not re-measured in this run")
 # L2-fabric bytes of one K2 training step (forward + adjoint + weight gradients): profiles/r04_train_traffic.txt
@@ -675,7 +675,7 @@ def main():
                          "note": "fp32 FMA/MFMA roof binds (intensity ~490 FLOP/B); frac counts the reference's algorithmic "
                                  "FLOPs, executed_frac the MFMA FLOPs the kernel issues (folded first layer); the kernel issues "
                                  "1664 MFMA cycles per SIMD and step (two waves x 104 x 8) - measured MFMA-busy share and clock: "
-                                 "profiles/r05_pmc_counters.txt (SQ_VALU_MFMA_BUSY_CYCLES / GRBM_GUI_ACTIVE); hbm_* = algorithmic 346 B/row-step"},
+                                 "profiles/r06_pmc_counters.txt (SQ_VALU_MFMA_BUSY_CYCLES / GRBM_GUI_ACTIVE); hbm_* = algorithmic 346 B/row-step"},
         }
         if extra:
             out["extra"] = extra

@@ -496,8 +496,14 @@ def test_bench_runs_its_rccl_branch_on_one_gpu_and_emits_the_contract_line():
     r = subprocess.run([sys.executable, os.path.join(root, 'bench.py'), '--steps', '5', '--warmup', '2', '--no-cpu-baseline'],
                        capture_output=True, text=True, env=env, timeout=600)
     assert r.returncode == 0, r.stderr[-2000:]
-    line = json.loads(r.stdout.strip().splitlines()[-1])
+    text = r.stdout.strip().splitlines()[-1]
+    assert len(text) < 4096, len(text)                  # the driver keeps a bounded tail of stdout (BENCH_r05: 21 KB line, parsed = null)
+    line = json.loads(text)
     assert line['n_gpus'] == 1 and line['steps'] == 5 and line['unit'] == 'row-steps/s' and line['value'] > 1e7
-    assert 0.0 < line['roofline']['frac'] < 1.0 and line['roofline']['traffic_source']
+    assert 0.0 < line['roofline']['frac'] < 1.0 and line['roofline']['kernel_ms'] <= line['ms_per_step']
+    assert 0.0 < line['summary']['K3_strong']['frac'] < 1.0 and 0.0 < line['summary']['K5_strong_train']['train_frac'] < 1.0
+    # the full record (every leg with its own roofline object, timing spreads, provenance) is a file beside the repo copy
+    full = json.load(open(os.path.join(root, line['full_record'])))
+    assert full['roofline']['traffic_source'] and full['value'] == line['value']
     for leg in ('K3_strong', 'K5_strong_train'):
-        assert 0.0 < line['extra'][leg]['roofline']['frac'] < 1.0, leg
+        assert 0.0 < full['extra'][leg]['roofline']['frac'] < 1.0, leg

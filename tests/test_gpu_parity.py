@@ -654,10 +654,23 @@ def test_k4_sepsis_shaped_nsde_full_size():
     dW = draw_dW(4004, ts, dt, B, H)
     ref64, _ = oracle_solve(pr, ts, dt, dW, 'euler', np.float64)
     cpu32, _ = oracle_solve(pr, ts, dt, dW, 'euler', np.float32)
-    for kernel in ('mfma4', 'mfma16', 'generic'):
+    model = S.engine.model_struct(C, H, H, 2, 3, 18)
+    assert S.engine.forward_path(model, B, L, len(times) - 1) == 'w4'      # `auto` = the wave-pair kernels (snsde_w4_euler_kernel) since round 5
+    for kernel in ('auto', 'w4', 'mfma4', 'mfma16', 'generic'):
         ys, _ = hip_solve(pr, ts, dt, dW=dW, kernel=kernel)
         assert ys.shape[0] == len(ts)
         print('K4', kernel, assert_parity(ys, ref64, cpu32, what='K4 ' + kernel))
+    # ... and under torch_ists' default method (nsde_model.py:63-74), SRI2W1 through the net at the full K4 size
+    rng2 = np.random.default_rng(4005)
+    g0, g1 = O.step_grid(ts, dt)[:2]
+    hh = (g1 - g0).astype(np.float32).reshape(-1, 1, 1)
+    dU = (hh * (0.5 * dW + np.sqrt(hh / 12) * rng2.standard_normal(dW.shape).astype(np.float32))).astype(np.float32)
+    ref64s, _ = O.solve_diffusion_model(pr['params'], 3, 18, pr['coeffs'], pr['times'], pr['y0'], ts, dt, dW, method='srk', dtype=np.float64, dU=dU)
+    cpu32s, _ = O.solve_diffusion_model(pr['params'], 3, 18, pr['coeffs'], pr['times'], pr['y0'], ts, dt, dW, method='srk', dtype=np.float32, dU=dU)
+    assert S.engine.forward_path(model, B, L, len(times) - 1, method='srk') == 'w4'
+    for kernel in ('auto', 'mfma4'):
+        ys, _ = hip_solve(pr, ts, dt, dW=dW, dU=dU, method='srk', kernel=kernel)
+        print('K4 srk', kernel, assert_parity(ys, ref64s, cpu32s, what='K4 srk ' + kernel))
 
 
 def test_k5_milstein_h256_forecast_shaped():
@@ -895,7 +908,8 @@ def test_backward_sweep_generic_diffusion_nets(io, no, method):
 # scheme amplifies round-off (4009: srk with raw = t y; 907: Milstein through y^3-like closed forms on the generic kernels).
 GRAD_TOL_MAX, GRAD_TOL_MEAN = 1e-4, 1e-4
 GRAD_TOL_LOOSE = {2009: 5e-4, 4006: 5e-4, 4009: 5e-4, 906: 5e-4, 907: 5e-4,
-                  9354: 5e-4}      # (tests/test_gpu_w4.py, srk (1,18) NL = 1: theta's gradient cancels to -0.012, measured 1.3e-4 on either kernel family)
+                  9354: 5e-4,      # (tests/test_gpu_w4.py, srk (1,18) NL = 1: theta's gradient cancels to -0.012, measured 1.3e-4 on either kernel family)
+                  3035: 5e-4}      # (round 6, srk (6,5) on the generic kernels under the SRI2W1 rows: theta's gradient cancels to 0.0027, measured 2.5e-4)
 
 
 def _check_backward(seed, io, no, NL, B, H, C, L, ts, dt, method, kernel, strict=False):
