@@ -74,7 +74,11 @@ enum {
      * (flag clear): emb o linear_in and emb o initial_network are pre-multiplied once per solve (there is no
      * non-linearity between them, neuralsde.py:200-210), which removes one layer and one barrier per step;
      * the result differs from the unfused order by float32 round-off only. */
-    SNSDE_FLAG_EXACT_ORDER = 2
+    SNSDE_FLAG_EXACT_ORDER = 2,
+    /* H = 256 on 4-row tiles: keep the fully streamed kernel (sixteen waves, every weight through the LDS ring each step) instead of
+     * the two-tiles-per-wave kernel that holds a quarter of every layer in registers.  Same results bit for bit (same MFMA chains);
+     * exists for A/B measurements and the bit-identity test. */
+    SNSDE_FLAG_STREAM_ALL = 4
 };
 
 /* Variants of the vector field beyond the benchmark Diffusion_model: the tutorial's Neural LSDE / LNSDE / GSDE fields

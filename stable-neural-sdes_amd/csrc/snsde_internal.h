@@ -194,8 +194,11 @@ __device__ __forceinline__ float snsde_spline_deriv(float b, float two_c, float 
 // Philox4x32-10 (Salmon et al., SC'11).  Specification = oracle/sde_oracle.py:philox4x32_10.
 __device__ __forceinline__ void snsde_philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3,
                                                     uint32_t k0, uint32_t k1, uint32_t out[4]) {
+#ifndef SNSDE_DEV_PHILOX_ROUNDS
+#define SNSDE_DEV_PHILOX_ROUNDS 10      // (development knock-out only - build.py variant: fewer rounds are NOT the specified stream)
+#endif
 #pragma unroll
-    for (int r = 0; r < 10; ++r) {
+    for (int r = 0; r < SNSDE_DEV_PHILOX_ROUNDS; ++r) {
         const uint64_t p0 = (uint64_t)0xD2511F53u * c0, p1 = (uint64_t)0xCD9E8D57u * c2;   // one v_mad_u64_u32 each
         const uint32_t hi0 = (uint32_t)(p0 >> 32), lo0 = (uint32_t)p0;
         const uint32_t hi1 = (uint32_t)(p1 >> 32), lo1 = (uint32_t)p1;

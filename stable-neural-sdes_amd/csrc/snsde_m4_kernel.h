@@ -460,7 +460,11 @@ __global__ void __launch_bounds__(CF::NT, CF::WPS) snsde_m4_kernel(MfmaArgs a) {
         qb = *reinterpret_cast<const f32x4*>(rowtab + 4);
     }
     __syncthreads();
-    if (__builtin_amdgcn_readfirstlane(tid) >= NT / 2 && CF::NW >= 8) __builtin_amdgcn_s_setprio(1);   // younger half
+#ifndef LEAN_PRIO_MODE
+#define LEAN_PRIO_MODE 1      // development A/B (build.py variant): 0 = no priorities, 1 = the younger half first (product), 2 = the older half first
+#endif
+    if constexpr (LEAN_PRIO_MODE == 1) { if (__builtin_amdgcn_readfirstlane(tid) >= NT / 2 && CF::NW >= 8) __builtin_amdgcn_s_setprio(1); }   // younger half
+    if constexpr (LEAN_PRIO_MODE == 2) { if (__builtin_amdgcn_readfirstlane(tid) < NT / 2 && CF::NW >= 8) __builtin_amdgcn_s_setprio(1); }
 
     // B-operand read addresses (LDS byte offsets; only lanes 0-15 read: q = 0 there)
     const uint32_t yrow = lean_lds_addr(ybuf + r * LDY + 4 * s);
@@ -715,6 +719,6 @@ int dispatch_lean(const MfmaPlan& p, const MfmaArgs& a, hipStream_t st) {
 int dispatch_lean_h32(const MfmaPlan& p, const MfmaArgs& a, hipStream_t st);
 int dispatch_lean_h64(const MfmaPlan& p, const MfmaArgs& a, hipStream_t st);
 int dispatch_lean_h128(const MfmaPlan& p, const MfmaArgs& a, hipStream_t st);
-int dispatch_lean_h256(const MfmaPlan& p, const MfmaArgs& a, hipStream_t st);   // snsde_m4s_kernel.h
+int dispatch_lean_h256(const MfmaPlan& p, const MfmaArgs& a, hipStream_t st, bool stream_all);   // snsde_m4s_kernel.h / snsde_m4s2_kernel.h
 
 }  // namespace snsde_mfma

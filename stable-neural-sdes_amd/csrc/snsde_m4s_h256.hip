@@ -3,9 +3,17 @@
 
 namespace snsde_mfma {
 
-int dispatch_lean_h256(const MfmaPlan& p, const MfmaArgs& a, hipStream_t st) {
+int dispatch_lean_h256_two_tile(const MfmaPlan& p, const MfmaArgs& a, hipStream_t st);   // snsde_m4s2_h256.hip
+
+int dispatch_lean_h256(const MfmaPlan& p, const MfmaArgs& a, hipStream_t st, bool stream_all) {
     const bool save = a.act_save || a.traj || a.dW_out;
     if (p.IO == 0) return SNSDE_ERR_UNSUPPORTED;
+    // round 6: eight waves of two tiles with a quarter of every layer resident (snsde_m4s2_kernel.h, bit-identical results);
+    // SNSDE_FLAG_STREAM_ALL keeps the sixteen-wave kernel below (A/B measurements, the bit-identity test)
+    if (!stream_all && a.act == SNSDE_ACT_RELU) {
+        const int rc = dispatch_lean_h256_two_tile(p, a, st);
+        if (rc != SNSDE_ERR_UNSUPPORTED) return rc;
+    }
     if (a.act != SNSDE_ACT_RELU) {      // tutorial fields (LipSwish / SiLU): inference only
         if (save) return SNSDE_ERR_UNSUPPORTED;
 #define SNSDE_STREAM_ACT(NH_, KX_) if (p.NHID == NH_ && p.KUXT == KX_) return launch_stream<CfgS<NH_, KX_, 0, 1>>(a, st);

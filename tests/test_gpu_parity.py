@@ -673,6 +673,40 @@ def test_k4_sepsis_shaped_nsde_full_size():
         print('K4 srk', kernel, assert_parity(ys, ref64s, cpu32s, what='K4 srk ' + kernel))
 
 
+@pytest.mark.parametrize('case', [(4, 17, 2, 14, 37, 'milstein'), (4, 17, 2, 14, 128, 'euler'), (6, 16, 2, 21, 9, 'euler'), (1, 13, 1, 3, 21, 'milstein'),
+                                  (3, 12, 2, 3, 5, 'euler'), (4, 9, 2, 40, 12, 'euler'), (2, 17, 3, 14, 8, 'euler')])
+@pytest.mark.parametrize('train', [False, True])
+def test_h256_two_tile_kernel_is_bit_identical_to_the_streamed_one(case, train):
+    """H = 256 on 4-row tiles (round 6): eight waves of two tiles with the first 4 k-blocks of every layer in registers
+    (snsde_m4s2_kernel.h) keep the k order and accumulator chains of the fully streamed sixteen-wave kernel (snsde_m4s_kernel.h, kept
+    behind SNSDE_FLAG_STREAM_ALL): every output, the trajectory and every saved plane agree bit for bit - Philox and supplied
+    increments, ragged tiles, interpolated outputs.  (NL = 3 and wide control blocks fall back to the streamed kernel where the
+    two-tile instantiation would spill: equal by construction there.)"""
+    io, no, NL, C, B, method = case
+    pr = make_problem(6100 + B, io, no, NL, B, 256, C, 9)
+    ts, dt = np.array([0., 2.5, 6., 8.], np.float32), 1.0
+    model = S.engine.model_struct(C, 256, 256, NL, io, no)
+    flat = flat_params(pr['params'], io, no, NL, C, 256)
+    grid = S.engine.step_grid(ts, dt, pr['times'], torch.device(DEV))
+    dW = draw_dW(6100 + B, ts, dt, B, 256)
+    for supplied in (None, torch.from_numpy(dW).to(DEV)):
+        outs = []
+        for all_ in (True, False):
+            call = S.engine.SolveCall(model, flat, torch.from_numpy(pr['coeffs']).to(DEV), grid, torch.from_numpy(pr['y0']).to(DEV),
+                                      dW=supplied, method=method, seed=11, kernel='mfma4', stream_all=all_, save_traj=train, save_dW=train,
+                                      save_act=train)
+            ys = call.launch().clone()
+            outs.append((ys, call.traj, call.act_save, call.dW_out))
+        assert torch.isfinite(outs[0][0]).all()
+        for x, y in zip(*outs):
+            assert (x is None and y is None) or torch.equal(x, y)
+    if no == 17 and io == 4:      # ... and the K5 model against the oracle, through the two-tile kernel
+        ref64, _ = oracle_solve(pr, ts, dt, dW, method, np.float64)
+        cpu32, _ = oracle_solve(pr, ts, dt, dW, method, np.float32)
+        ys, _ = hip_solve(pr, ts, dt, dW=dW, method=method, kernel='mfma4')
+        assert_parity(ys, ref64, cpu32, what='H=256 two-tile')
+
+
 def test_k5_milstein_h256_forecast_shaped():
     """configs[4] forward leg: (4,17) Milstein, H=256, MuJoCo-shaped L=50 C=14, ts = times (T=50), 128 rows per GPU."""
     B, H, C, L = 128, 256, 14, 50
