@@ -54,9 +54,9 @@ HBM_TRAFFIC_KERNEL = ('lean', 'snsde_m4_kernel<CfgL<128, 1, 2, 1, 0, 0>>')     #
 HBM_TRAFFIC_SOURCE = ("profiles/r06_pmc_counters.txt: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes over this bench command, "
                       "mean of 187 dispatches of the solve kernel), 2 x FETCH_SIZE + WRITE_SIZE per the gfx950 correction of "
                       "MI355X_MICROARCH.md; a constant of the kernel's memory behaviour, not re-measured in this run")
-# L2-fabric bytes of one K2 training step (forward + adjoint + weight gradients): profiles/r04_train_traffic.txt
-TRAIN_TRAFFIC_FILE = 'r04_train_traffic.txt'
-TRAIN_TRAFFIC_SOURCE = ("profiles/r04_train_traffic.txt (tools/pmc_train_modes.sh: FETCH_SIZE / WRITE_SIZE summed over every kernel of 10 "
+# L2-fabric bytes of one K2 training step (forward + adjoint + weight gradients): profiles/r06_train_traffic.txt (re-measured in round 6)
+TRAIN_TRAFFIC_FILE = 'r06_train_traffic.txt'
+TRAIN_TRAFFIC_SOURCE = ("profiles/r06_train_traffic.txt (tools/pmc_train_modes.sh: FETCH_SIZE / WRITE_SIZE summed over every kernel of 10 "
                         "steps; a constant of the path's memory behaviour taken under rocprofv3, not re-measured in this run - valid while the "
                         "forward path reported beside it is the profiled one)")
 TRAIN_TRAFFIC_PATHS = ('lean', 1)          # forward path / backward mode the profile was taken on
@@ -357,7 +357,7 @@ def k2_training(dev, stream):
     path = os.path.join(ROOT, 'profiles', TRAIN_TRAFFIC_FILE)
     if os.path.exists(path):
         for line in open(path):
-            if line.startswith('current default'):
+            if line.startswith(('current default', 'saved activations')):
                 traffic = float(line.split('total')[1].split('MB')[0]) * 1e6
     sec = out["forward_backward"]["median_ms"] * 1e-3
     if traffic and (out["forward_path"], out["backward_mode"]) == TRAIN_TRAFFIC_PATHS:      # (the profiled kernels are the launched ones)

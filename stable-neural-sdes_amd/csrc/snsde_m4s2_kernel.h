@@ -49,6 +49,9 @@ struct CfgS2 {
 template <int SRC, int DST>
 __device__ __forceinline__ void s2_refill(uint32_t ring_m0, const uint32_t (&vo4)[4], uint64_t sb) {
     constexpr int IMM = (SRC % 4) * 1024;
+#ifdef SNSDE_S2_NO_STREAM      // development knock-out (build.py variant): no weight stream at all - stale ring contents, timing only
+    return;
+#endif
     asm volatile("s_add_u32 m0, %0, %3\n\ts_nop 4\n\tglobal_load_lds_dwordx4 %1, %2 offset:%4"
                  :: "s"(ring_m0), "v"(vo4[SRC / 4]), "s"(sb), "n"(DST - IMM), "n"(IMM) : "memory", "scc");
 }
