@@ -78,7 +78,11 @@ enum {
     /* H = 256 on 4-row tiles: keep the fully streamed kernel (sixteen waves, every weight through the LDS ring each step) instead of
      * the two-tiles-per-wave kernel that holds a quarter of every layer in registers.  Same results bit for bit (same MFMA chains);
      * exists for A/B measurements and the bit-identity test. */
-    SNSDE_FLAG_STREAM_ALL = 4
+    SNSDE_FLAG_STREAM_ALL = 4,
+    /* H = 128 on 4-row tiles (Euler / Milstein, elementwise diffusions, relu fields): four waves of two tiles, one wave per SIMD with
+     * the whole register file (snsde_m4t_kernel.h), instead of the eight-wave lean kernel.  Same results bit for bit.  An A/B switch:
+     * measured slower at the K2 shape, so it is opt-in. */
+    SNSDE_FLAG_TWO_TILE = 8
 };
 
 /* Variants of the vector field beyond the benchmark Diffusion_model: the tutorial's Neural LSDE / LNSDE / GSDE fields

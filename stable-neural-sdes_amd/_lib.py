@@ -16,6 +16,7 @@ KERNEL_AUTO, KERNEL_GENERIC, KERNEL_MFMA = 0, 1, 2
 FLAG_REUSE_PREPARED = 1
 FLAG_EXACT_ORDER = 2
 FLAG_STREAM_ALL = 4
+FLAG_TWO_TILE = 8
 BWD_ADJ0_ONLY = 1
 PATHS = ('none', 'generic', 'mfma16', 'mfma4', 'lean', 'lean-streamed', 'generic-srk', 'mfma-srk', 'w4')
 KERNELS = {'auto': KERNEL_AUTO, 'generic': KERNEL_GENERIC, 'mfma': KERNEL_MFMA, 'mfma16': 3, 'mfma4': 4, 'w4': 5}

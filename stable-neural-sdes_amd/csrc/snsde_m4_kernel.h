@@ -719,6 +719,7 @@ int dispatch_lean(const MfmaPlan& p, const MfmaArgs& a, hipStream_t st) {
 int dispatch_lean_h32(const MfmaPlan& p, const MfmaArgs& a, hipStream_t st);
 int dispatch_lean_h64(const MfmaPlan& p, const MfmaArgs& a, hipStream_t st);
 int dispatch_lean_h128(const MfmaPlan& p, const MfmaArgs& a, hipStream_t st);
+int dispatch_lean_h128_two_tile(const MfmaPlan& p, const MfmaArgs& a, hipStream_t st);   // snsde_m4t_kernel.h
 int dispatch_lean_h256(const MfmaPlan& p, const MfmaArgs& a, hipStream_t st, bool stream_all);   // snsde_m4s_kernel.h / snsde_m4s2_kernel.h
 
 }  // namespace snsde_mfma

@@ -677,6 +677,10 @@ int snsde_mfma_launch(const snsde_solve* s, const SnsdeNet& net, hipStream_t str
         a.act = s->model.activation; a.f_out = s->model.drift_output; a.g_out = s->model.diffusion_output;
         a.raw_time = s->model.time_feature; a.gt_ext = s->noise_table;
         if (p.H == 256) return dispatch_lean_h256(p, a, stream, (s->flags & SNSDE_FLAG_STREAM_ALL) != 0);
+        if (p.H == 128 && (s->flags & SNSDE_FLAG_TWO_TILE)) {
+            const int rc = dispatch_lean_h128_two_tile(p, a, stream);
+            if (rc != SNSDE_ERR_UNSUPPORTED) return rc;
+        }
         if (p.H == 128) return dispatch_lean_h128(p, a, stream);
         if (p.H == 64) return dispatch_lean_h64(p, a, stream);
         if (p.H == 32) return dispatch_lean_h32(p, a, stream);

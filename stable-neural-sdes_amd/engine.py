@@ -438,7 +438,7 @@ class SolveCall:
 
     def __init__(self, model, flat_params, coeffs, grid, y0, dW=None, method='euler', seed=0, row_offset=0,
                  kernel='auto', save_traj=False, save_dW=False, exact_order=False, save_act=False, dU=None, row_out=None,
-                 noise_table=None, z0_linear=None, kl_column=None, stream_all=False):
+                 noise_table=None, z0_linear=None, kl_column=None, stream_all=False, two_tile=False):
         B, H = y0.shape
         C_ = model.input_channels
         L = coeffs.shape[1] + 1
@@ -472,7 +472,7 @@ class SolveCall:
         # (kernel selector, flags and the kind of Philox key BEFORE the layout query below: which adjoint a solve gets - and with it
         #  whether it needs delta planes at all - depends on them)
         s.kernel = _lib.KERNELS[kernel]
-        self.base_flags = (_lib.FLAG_EXACT_ORDER if exact_order else 0) | (_lib.FLAG_STREAM_ALL if stream_all else 0)
+        self.base_flags = (_lib.FLAG_EXACT_ORDER if exact_order else 0) | (_lib.FLAG_STREAM_ALL if stream_all else 0) | (_lib.FLAG_TWO_TILE if two_tile else 0)
         s.flags = self.base_flags
         if torch.is_tensor(seed):     # device-resident key: re-read by every launch / graph replay
             if seed.dtype != torch.int64 or not seed.is_cuda or seed.numel() != 1:

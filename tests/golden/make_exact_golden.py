@@ -41,6 +41,71 @@ def f32(x):
     return Fr(struct.unpack('f', struct.pack('f', float(x)))[0])
 
 
+class Dual:
+    """value + eps * der over the rationals: forward-mode derivative of everything below along ONE direction (relu differentiates by the
+    sign of the value).  Fraction op Dual falls through Fraction's NotImplemented to the reflected methods here."""
+    __slots__ = ('val', 'der')
+
+    def __init__(self, val, der=Fr(0)):
+        self.val, self.der = Fr(val), Fr(der)
+
+    @staticmethod
+    def of(x):
+        return x if isinstance(x, Dual) else Dual(x)
+
+    def __add__(self, o):
+        o = Dual.of(o); return Dual(self.val + o.val, self.der + o.der)
+    __radd__ = __add__
+
+    def __sub__(self, o):
+        o = Dual.of(o); return Dual(self.val - o.val, self.der - o.der)
+
+    def __rsub__(self, o):
+        o = Dual.of(o); return Dual(o.val - self.val, o.der - self.der)
+
+    def __mul__(self, o):
+        o = Dual.of(o); return Dual(self.val * o.val, self.val * o.der + self.der * o.val)
+    __rmul__ = __mul__
+
+    def __truediv__(self, o):
+        o = Dual.of(o); return Dual(self.val / o.val, (self.der * o.val - self.val * o.der) / (o.val * o.val))
+
+    def __neg__(self):
+        return Dual(-self.val, -self.der)
+
+    def __pow__(self, k):
+        out = Dual(1)
+        for _ in range(int(k)):
+            out = out * self
+        return out
+
+    def __gt__(self, o):
+        return self.val > (o.val if isinstance(o, Dual) else o)
+
+    def __lt__(self, o):
+        return self.val < (o.val if isinstance(o, Dual) else o)
+
+    def __ne__(self, o):          # (only used to skip exact zeros in matvec: a zero value with a derivative is not skippable)
+        o = Dual.of(o); return self.val != o.val or self.der != o.der
+
+    def __eq__(self, o):
+        o = Dual.of(o); return self.val == o.val and self.der == o.der
+
+    def __hash__(self):
+        return hash((self.val, self.der))
+
+    def __float__(self):
+        return float(self.val)
+
+
+def val_of(x):
+    return x.val if isinstance(x, Dual) else x
+
+
+def der_of(x):
+    return x.der if isinstance(x, Dual) else Fr(0)
+
+
 def isqrt_fr(x):
     """Exact square root of a Fraction that is a perfect square (the step sizes below are chosen that way)."""
     n, d = x.numerator, x.denominator
@@ -377,6 +442,90 @@ def kernel_cases(out):
             store(out, f'{key}/{name}', ys, traj, steps, outs, I1, I10, y0, ts, dt)
 
 
+def directional_cases(out):
+    """K/*/grad: exact directional derivatives of L = sum w . ys (all outputs, all rows) for the `tab` and `net16` fields under SRK, Euler
+    and Milstein on the grids above - along one random dyadic direction per parameter tensor, one over y0, and one per batch row of y0
+    (forward-mode over the rationals, `Dual`).  The fused ADJOINT kernels + the native weight-gradient pass must reproduce
+    <gradient, direction> for each (tests/test_gpu_exact.py)."""
+    ex = dict(np.load(os.path.join(HERE, 'exact.npz'))) if False else None
+    rng = random.Random(777)
+
+    def frac_arr(a):          # float array holding dyadic rationals -> object array of Fractions (exact)
+        return np.vectorize(lambda x: Fr(float(x)), otypes=[object])(a)
+
+    def run(prefix, case, method, ts, dt, P, y0, I1, I10, w, coeffs=None, times=None):
+        H = len(y0[0])
+        B = len(y0)
+        if prefix == 'K/tab':
+            s_of = lambda t: [Fr(i % 4 + 1, 8) + t / 2 for i in range(H)]
+
+            def make_f(row):
+                def f(t, y):
+                    X = spline_eval(times, [coeffs[row]], t)[0]
+                    yy = matvec(P['linear_in.weight'], P['linear_in.bias'], [t, Fr(0)] + list(y))
+                    xx = matvec(P['initial_network.weight'], P['initial_network.bias'], X)
+                    z = relu(matvec(P['emb.weight'], P['emb.bias'], yy + xx))
+                    z = relu(matvec(P['linears.0.weight'], P['linears.0.bias'], z))
+                    return matvec(P['linear_out.weight'], P['linear_out.bias'], z)
+                return f
+            g = lambda t, y: [s * v for s, v in zip(s_of(t), y)]
+            gvjp = lambda t, y, cot: [s * c for s, c in zip(s_of(t), cot)]
+            total = Fr(0)
+            for b in range(B):
+                ys, _, steps, _ = integrate(method, make_f(b), g, gvjp, [y0[b]], ts, dt, [[I1[n][b]] for n in range(len(I1))],
+                                            None if I10 is None else [[I10[n][b]] for n in range(len(I10))])
+                total += sum(w[k][b][i] * der_of(ys[k][0][i]) for k in range(len(ts)) for i in range(H))
+            return total
+
+        def f(t, y):
+            z = relu(matvec(P['linear_in.weight'], P['linear_in.bias'], [t, Fr(0)] + list(y)))
+            z = relu(matvec(P['linears.0.weight'], P['linears.0.bias'], z))
+            return matvec(P['linear_out.weight'], P['linear_out.bias'], z)
+
+        def g(t, y):
+            z = relu(matvec(P['noise_y.0.weight'], P['noise_y.0.bias'], [t, Fr(0)] + list(y)))
+            return matvec(P['noise_y.2.weight'], P['noise_y.2.bias'], z)
+
+        def gvjp(t, y, cot):
+            pre = matvec(P['noise_y.0.weight'], P['noise_y.0.bias'], [t, Fr(0)] + list(y))
+            W2, W0 = P['noise_y.2.weight'], P['noise_y.0.weight']
+            ch = [sum(W2[i][j] * cot[i] for i in range(H)) if pre[j] > 0 else Fr(0) for j in range(H)]
+            return [sum(W0[j][2 + k] * ch[j] for j in range(H)) for k in range(H)]
+        ys, _, _, _ = integrate(method, f, g, gvjp, y0, ts, dt, I1, I10)
+        return sum(w[k][b][i] * der_of(ys[k][b][i]) for k in range(len(ts)) for b in range(B) for i in range(H))
+
+    for prefix in ('K/tab', 'K/net16'):
+        Pn = {k[len(prefix) + 7:]: frac_arr(out[k]) for k in out if k.startswith(prefix + '/param/')}
+        coeffs = times = None
+        if prefix == 'K/tab':
+            times = [Fr(float(x)) for x in out['K/tab/times']]
+            cf = frac_arr(out['K/tab/coeffs'])                      # (B, L - 1, 4C)
+            C = cf.shape[-1] // 4
+            coeffs = [[tuple(list(iv[k * C:(k + 1) * C]) for k in range(4)) for iv in row] for row in cf]
+        for case, (ts, dt), method in (('srk', GRID_SRK, 'srk'), ('euler_mis', GRID_MIS, 'euler'), ('milstein_mis', GRID_MIS, 'milstein')):
+            key = f'{prefix}/{case}'
+            y0 = frac_arr(out[key + '/y0']).tolist()
+            I1 = frac_arr(out[key + '/dW']).tolist()
+            I10 = frac_arr(out[key + '/dU']).tolist() if key + '/dU' in out else None
+            B, H = len(y0), len(y0[0])
+            w = [[[Fr(rng.randint(-4, 4), 4) for _ in range(H)] for _ in range(B)] for _ in range(len(ts))]
+            out[key + '/grad/w'] = to_np(w)
+            # directions: y0 as a whole, y0 row by row, every parameter tensor
+            dirs = [('y0', None)] + [(f'y0_row{b}', b) for b in range(B)]
+            for name, rowsel in dirs:
+                v = [[Fr(rng.randint(-2, 2), 4) if (rowsel is None or b == rowsel) else Fr(0) for _ in range(H)] for b in range(B)]
+                y0d = [[Dual(y0[b][i], v[b][i]) for i in range(H)] for b in range(B)]
+                out[f'{key}/grad/dir/{name}'] = to_np(v)
+                out[f'{key}/grad/dL/{name}'] = np.float64(float(run(prefix, case, method, ts, dt, Pn, y0d, I1, I10, w, coeffs, times)))
+            for pname in sorted(Pn):
+                v = np.vectorize(lambda _: Fr(rng.randint(-2, 2), 4), otypes=[object])(Pn[pname])
+                Pd = dict(Pn)
+                Pd[pname] = np.vectorize(lambda a, b: Dual(a, b), otypes=[object])(Pn[pname], v)
+                out[f'{key}/grad/dir/{pname}'] = to_np(v.tolist())
+                out[f'{key}/grad/dL/{pname}'] = np.float64(float(run(prefix, case, method, ts, dt, Pd, y0, I1, I10, w, coeffs, times)))
+            print('  directional derivatives', key, flush=True)
+
+
 def main():
     n = check_order_conditions(SRI2W1)
     check_order_conditions(HYBRID)          # (also an order-1.5 scheme: the conditions cannot tell the two apart, the vectors do)
@@ -387,6 +536,7 @@ def main():
         out[f'tableau/{k}'] = to_np(SRI2W1[k])
     scalar_cases(out)
     kernel_cases(out)
+    directional_cases(out)
     path = os.path.join(HERE, 'exact.npz')
     np.savez_compressed(path, **out)
     print('wrote', path, f'{os.path.getsize(path)} bytes, {len(out)} arrays')

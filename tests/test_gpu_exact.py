@@ -127,3 +127,51 @@ def test_sdeint_on_an_unrecognised_module_on_the_gpu(case):
     ys = S.torchsde.sdeint(_Poly().to(DEV), torch.from_numpy(g['y0']).to(DEV), torch.from_numpy(g['ts']).to(DEV), bm=bm,
                            method=METHOD[case], dt=float(g['dt']))
     np.testing.assert_allclose(ys.cpu().numpy(), g['ys'], rtol=1e-12, atol=1e-14)
+
+
+GRAD_CASES = ['srk', 'euler_mis', 'milstein_mis']
+
+
+@pytest.mark.parametrize('kernel', ['auto', 'mfma4'])
+@pytest.mark.parametrize('case', GRAD_CASES)
+@pytest.mark.parametrize('prefix', ['K/tab', 'K/net16'])
+def test_adjoint_kernels_reproduce_the_exact_directional_derivatives(prefix, case, kernel):
+    """The fused backward (adjoint kernel + native weight-gradient pass, one C call) against EXACT derivatives: the generator
+    differentiates L = sum w . ys in forward mode over the rationals (make_exact_golden.Dual) along a random dyadic direction per
+    parameter tensor, over y0, and per batch row of y0.  <gradient, direction> from the kernels must match each to float32 round-off:
+    |err| <= 2e-4 max(|dL|, scale) with scale = the largest |<gradient, direction>| of the case (sums of ~1e3 products of O(1) terms)."""
+    method = METHOD[case]
+    model, flat, coeffs, times, g = build(prefix, case)
+    dev = torch.device(DEV)
+    grid = S.engine.step_grid(g['ts'], float(g['dt']), times, dev)
+    B = g['y0'].shape[0]
+    assert S.engine.backward_mode(model, B, len(times), grid, method, kernel=kernel, table='noise_table' in g) == 1
+    f32 = lambda a: torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32)).to(DEV)
+    tab = f32(g['noise_table']) if 'noise_table' in g else None
+    call = S.engine.SolveCall(model, flat, coeffs, grid, f32(g['y0']), dW=f32(g['dW']), dU=f32(g['dU']) if 'dU' in g else None,
+                              method=method, kernel=kernel, noise_table=tab, save_traj=True, save_act=True,
+                              save_dW=method == 'srk')      # (the SRK adjoint reads the forward's dU_out)
+    ys = call.launch()
+    assert np.abs(ys.double().cpu().numpy() - g['ys']).max() <= 2e-5 * (1 + np.abs(g['ys']).max())
+    # (Milstein through a diffusion net: its second-order weight-gradient jobs read every adjoint state - no adj0-only form)
+    adj, grad = S.engine.backward_with_gradients(call, f32(g['grad/w']), adj0_only=S.engine.adj0_suffices(call))[:2]
+    adj0 = adj[0].double().cpu().numpy()
+    grad = grad.double().cpu().numpy()
+    layout, _ = S._lib.param_layout(model)
+    where = {name: (off, shape) for name, off, shape in layout}
+    got, want = {}, {}
+    for key in g:
+        if not key.startswith('grad/dir/'):
+            continue
+        name = key[len('grad/dir/'):]
+        v = g[key]
+        want[name] = float(g['grad/dL/' + name])
+        if name.startswith('y0'):
+            got[name] = float((adj0 * v).sum())
+        else:
+            off, shape = where[name]
+            got[name] = float((grad[off:off + v.size].reshape(v.shape) * v).sum())
+    assert len(got) >= 7 + B
+    scale = max(abs(x) for x in want.values())
+    bad = {n: (got[n], want[n]) for n in got if abs(got[n] - want[n]) > 2e-4 * max(abs(want[n]), scale)}
+    assert not bad, (prefix, case, kernel, scale, bad)

@@ -707,6 +707,30 @@ def test_h256_two_tile_kernel_is_bit_identical_to_the_streamed_one(case, train):
         assert_parity(ys, ref64, cpu32, what='H=256 two-tile')
 
 
+@pytest.mark.parametrize('train', [False, True])
+@pytest.mark.parametrize('case', [(4, 17, 21, 64, 'euler'), (4, 17, 21, 37, 'milstein'), (6, 16, 5, 9, 'euler'), (3, 13, 3, 21, 'milstein')])
+def test_h128_two_tile_kernel_is_bit_identical_to_the_lean_one(case, train):
+    """SNSDE_FLAG_TWO_TILE (round 6 experiment): four waves of two tiles, one wave per SIMD, hidden / output weights pinned in
+    AccVGPRs with asm-issued MFMAs - measured slower than the eight-wave lean kernel at K2 (214 vs 184 us), kept opt-in; its results are
+    the lean kernel's bit for bit (same chains), which this pins together with the asm MFMAs' hand-placed wait states."""
+    io, no, C, B, method = case
+    pr = make_problem(6300 + B, io, no, 2, B, 128, C, 9)
+    ts, dt = np.array([0., 2.5, 6., 8.], np.float32), 1.0
+    model = S.engine.model_struct(C, 128, 128, 2, io, no)
+    flat = flat_params(pr['params'], io, no, 2, C, 128)
+    grid = S.engine.step_grid(ts, dt, pr['times'], torch.device(DEV))
+    dW = torch.from_numpy(draw_dW(6300 + B, ts, dt, B, 128)).to(DEV)
+    for supplied in (None, dW):
+        outs = []
+        for two in (False, True):
+            call = S.engine.SolveCall(model, flat, torch.from_numpy(pr['coeffs']).to(DEV), grid, torch.from_numpy(pr['y0']).to(DEV), dW=supplied,
+                                      method=method, seed=11, kernel='mfma4', two_tile=two, save_traj=train, save_dW=train, save_act=train)
+            outs.append((call.launch().clone(), call.traj, call.act_save, call.dW_out))
+        assert torch.isfinite(outs[0][0]).all()
+        for x, y in zip(*outs):
+            assert (x is None and y is None) or torch.equal(x, y)
+
+
 def test_k5_milstein_h256_forecast_shaped():
     """configs[4] forward leg: (4,17) Milstein, H=256, MuJoCo-shaped L=50 C=14, ts = times (T=50), 128 rows per GPU."""
     B, H, C, L = 128, 256, 14, 50
