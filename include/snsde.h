@@ -359,6 +359,33 @@ typedef struct snsde_head {
 } snsde_head;
 SNSDE_API int snsde_readout_head(const snsde_head* h, void* hip_stream);
 
+/* ---- composed parameter blocks (tutorial-style fields) ---------------------------------------------------------
+ * The tutorial notebooks' fields (cell 7 of the tutorial notebooks: linear_in / emb / f_net / linear_out, NeuralSDEFunc's f_net / g_net on
+ * [t, y]) map onto the Diffusion_model parameter block by multiplying adjacent affine maps out: W' = W_outer W_inner,
+ * b' = W_outer b_inner + b_outer.  These two calls build the block from the field's own tensors and carry the block's gradient back
+ * to them, ONE launch each (in torch the same is ~25 + ~35 small launches per training step, which is what bounded that step).
+ * A job writes one (weight, bias) pair of the block:
+ *   w_outer == NULL : copy         W' = W_inner (R x Cin), b' = b_inner
+ *   else            : composition  W' = W_outer (R x K) . W_inner (K x Cin),  b' = W_outer b_inner + b_outer
+ * zero_col >= 0 inserts a zero column at that index of W' (the field's [t, y] columns -> the block's [t, 0, y]).
+ * dst_w / dst_b: float offsets into `dst` (snsde_param_info); the caller zero-fills what no job writes.
+ * The backward reads grad_dst at the same offsets and writes dL/d(each source tensor) at g_* float offsets of `grad_src`
+ * (-1: not wanted).  All pointers device, fp32, row-major contiguous; at most SNSDE_MAX_AFFINE_JOBS jobs per call. */
+#define SNSDE_MAX_AFFINE_JOBS 12
+typedef struct snsde_affine_job {
+    const float* w_outer;    /* (R, K) or NULL                                  */
+    const float* b_outer;    /* (R) or NULL (only with w_outer)                 */
+    const float* w_inner;    /* (K, Cin); copy jobs: (R, Cin)                   */
+    const float* b_inner;    /* (K) (copy jobs: (R)) or NULL: b' = b_outer / 0  */
+    int32_t R, K, Cin;       /* copy jobs: K ignored                            */
+    int32_t zero_col;        /* -1: none                                        */
+    int64_t dst_w, dst_b;    /* into dst / grad_dst                             */
+    int64_t g_w_outer, g_b_outer, g_w_inner, g_b_inner;   /* into grad_src (backward only; -1: skip) */
+} snsde_affine_job;
+SNSDE_API int snsde_affine_compose(const snsde_affine_job* jobs, int32_t n_jobs, float* dst, void* hip_stream);
+SNSDE_API int snsde_affine_compose_backward(const snsde_affine_job* jobs, int32_t n_jobs, const float* grad_dst, float* grad_src,
+                                            void* hip_stream);
+
 SNSDE_API int         snsde_version(void);
 /* SNSDE_OK when `version` == SNSDE_VERSION and the four sizes equal the library's sizeof(snsde_model / snsde_solve /
  * snsde_backward / snsde_head); SNSDE_ERR_ABI otherwise.  A size of 0 means "this binding does not declare that struct"

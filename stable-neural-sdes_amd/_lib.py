@@ -80,7 +80,19 @@ EXPORTS = ('snsde_version', 'snsde_abi_check', 'snsde_strerror', 'snsde_param_co
            'snsde_spline_evaluate', 'snsde_eval_fg', 'snsde_act_slots', 'snsde_backward_supported',
            'snsde_backward_workspace_bytes', 'snsde_solve_backward', 'snsde_spline_workspace_bytes',
            'snsde_natural_cubic_coeffs', 'snsde_hermite_coeffs', 'snsde_param_gradients_workspace_bytes',
-           'snsde_param_gradients', 'snsde_backward_with_gradients', 'snsde_forward_path', 'snsde_readout_head', 'snsde_save_layout')
+           'snsde_param_gradients', 'snsde_backward_with_gradients', 'snsde_forward_path', 'snsde_readout_head', 'snsde_save_layout',
+           'snsde_affine_compose', 'snsde_affine_compose_backward')
+
+
+MAX_AFFINE_JOBS = 12
+
+
+class AffineJob(C.Structure):
+    """snsde_affine_job (include/snsde.h): one (weight, bias) pair of a composed parameter block."""
+    _fields_ = [('w_outer', C.c_void_p), ('b_outer', C.c_void_p), ('w_inner', C.c_void_p), ('b_inner', C.c_void_p),
+                ('R', C.c_int32), ('K', C.c_int32), ('Cin', C.c_int32), ('zero_col', C.c_int32),
+                ('dst_w', C.c_int64), ('dst_b', C.c_int64),
+                ('g_w_outer', C.c_int64), ('g_b_outer', C.c_int64), ('g_w_inner', C.c_int64), ('g_b_inner', C.c_int64)]
 
 
 def lib():
@@ -125,6 +137,8 @@ def lib():
     L.snsde_backward_supported.argtypes = [C.POINTER(Solve)]
     L.snsde_forward_path.argtypes = [C.POINTER(Solve)]
     L.snsde_readout_head.argtypes = [C.POINTER(Head), C.c_void_p]
+    L.snsde_affine_compose.argtypes = [C.POINTER(AffineJob), C.c_int32, C.c_void_p, C.c_void_p]
+    L.snsde_affine_compose_backward.argtypes = [C.POINTER(AffineJob), C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]
     L.snsde_backward_workspace_bytes.argtypes = [C.POINTER(Backward)]
     L.snsde_backward_workspace_bytes.restype = C.c_size_t
     L.snsde_solve_backward.argtypes = [C.POINTER(Backward), C.c_void_p]

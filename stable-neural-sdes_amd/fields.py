@@ -76,6 +76,71 @@ def _capturing(dev):
     return torch.device(dev).type == 'cuda' and torch.cuda.is_current_stream_capturing()
 
 
+class _ComposeAffine(torch.autograd.Function):
+    """The composed parameter block from the field's own Linear layers, natively: snsde_affine_compose (one launch) and, backward,
+    snsde_affine_compose_backward (one launch) - in place of ~25 + ~35 small torch launches per training step (matmuls, cats, zeros
+    and their autograd nodes), which is what bounded the tutorial fields' eager training step.
+    spec: list of (name in the block, outer index or None, inner index, zero_col) over `tensors` = (w0, b0, w1, b1, ...) per layer."""
+
+    @staticmethod
+    def forward(ctx, spec, layout, numel, *tensors):
+        dev = tensors[0].device
+        where = {name: (off, shape) for name, off, shape in layout}
+        src = [t.detach().contiguous() for t in tensors]
+        sizes = [t.numel() for t in src]
+        offs = [0]
+        for n in sizes:
+            offs.append(offs[-1] + n)
+        jobs = (_lib.AffineJob * len(spec))()
+        for q, (name, outer, inner, zero_col) in zip(jobs, spec):
+            wi, bi = src[2 * inner], src[2 * inner + 1]
+            q.w_inner, q.b_inner = wi.data_ptr(), bi.data_ptr()
+            q.g_w_inner, q.g_b_inner = offs[2 * inner], offs[2 * inner + 1]
+            q.zero_col = zero_col
+            if outer is None:
+                q.w_outer = q.b_outer = None
+                q.R, q.K, q.Cin = wi.shape[0], 0, wi.shape[1]
+                q.g_w_outer = q.g_b_outer = -1
+            else:
+                wo, bo = src[2 * outer], src[2 * outer + 1]
+                q.w_outer, q.b_outer = wo.data_ptr(), bo.data_ptr()
+                q.R, q.K, q.Cin = wo.shape[0], wo.shape[1], wi.shape[1]
+                assert wi.shape[0] == q.K
+                q.g_w_outer, q.g_b_outer = offs[2 * outer], offs[2 * outer + 1]
+            q.dst_w, q.dst_b = where[name + '.weight'][0], where[name + '.bias'][0]
+            assert tuple(where[name + '.weight'][1]) == (q.R, q.Cin + (1 if zero_col >= 0 else 0)), (name, where[name + '.weight'][1])
+        flat = torch.zeros(numel, device=dev, dtype=torch.float32)      # (theta, unused noise_t entries: zero)
+        stream = torch.cuda.current_stream(dev)
+        _lib.check(_lib.lib().snsde_affine_compose(jobs, len(spec), flat.data_ptr(), stream.cuda_stream), 'snsde_affine_compose')
+        ctx.jobs, ctx.src, ctx.offs, ctx.shapes = jobs, src, offs, [tuple(t.shape) for t in tensors]
+        return flat
+
+    @staticmethod
+    def backward(ctx, gflat):
+        gflat = gflat.contiguous()
+        gsrc = torch.zeros(ctx.offs[-1], device=gflat.device, dtype=torch.float32)
+        stream = torch.cuda.current_stream(gflat.device)
+        _lib.check(_lib.lib().snsde_affine_compose_backward(ctx.jobs, len(ctx.jobs), gflat.data_ptr(), gsrc.data_ptr(), stream.cuda_stream),
+                   'snsde_affine_compose_backward')
+        grads = tuple(gsrc[ctx.offs[i]:ctx.offs[i + 1]].view(shape) for i, shape in enumerate(ctx.shapes))
+        return (None, None, None) + grads
+
+
+def _native_block(layers, spec, layout, numel, dev):
+    """layers: the field's nn.Linear modules in the order `spec` indexes them; None when the native route does not apply (CPU,
+    non-float32 parameters, more jobs than the C ABI takes)."""
+    dev = torch.device(dev)
+    if dev.type != 'cuda' or len(spec) > _lib.MAX_AFFINE_JOBS:
+        return None
+    tensors = []
+    for lin in layers:
+        w = lin.weight
+        if w.dtype != torch.float32 or not w.is_cuda or (dev.index is not None and w.device.index != dev.index) or lin.bias is None:
+            return None
+        tensors += [lin.weight, lin.bias]
+    return _ComposeAffine.apply(spec, layout, numel, *tensors)
+
+
 class ComposedField:
     """A tutorial-style field mapped onto the fused step: `model` (snsde_model with the variant switches), `flat(dev)`
     (the composed parameter block, rebuilt from the module's current weights on every solve) and `noise_table(grid)`."""
@@ -142,6 +207,17 @@ class ComposedField:
         noise_y.0' = g_net[0] o noise_in, noise_y.2 = g_net[1]."""
         p = self.parts
         H, C_ = self.model.hidden_channels, self.model.input_channels
+        if grad:      # training: the block and its backward natively, one launch each (snsde_affine_compose)
+            layers = [p['mlp'][0], p['linear_in']] + list(p['mlp'][1:])
+            spec = [('linear_in', 0, 1, 1)] + [(f'linears.{i}', None, 2 + i, -1) for i in range(len(p['mlp']) - 2)]
+            spec.append(('linear_out', None, len(layers) - 1, -1))
+            if 'noise_first' in p:
+                n0 = len(layers)
+                layers += [p['noise_first'], p['noise_in'], p['noise_last']]
+                spec += [('noise_y.0', n0, n0 + 1, 1), ('noise_y.2', None, n0 + 2, -1)]
+            out = _native_block(layers, spec, self.layout, self.numel, dev)
+            if out is not None:
+                return out
         f64 = dict(device=dev, dtype=torch.float32 if grad else torch.float64)
         W = lambda lin: (lin.weight if grad else lin.weight.detach()).to(**f64)
         b = lambda lin: (lin.bias if grad else lin.bias.detach()).to(**f64)
@@ -205,6 +281,14 @@ class ComposedField:
             return self._flat_net(dev, grad)
         p = self.parts
         H = self.model.hidden_channels
+        if grad and p['linear_in'] is not None:      # training (LNSDE / GSDE shapes): natively, one launch each way
+            first, last = p['mlp'][0], p['mlp'][-1]
+            layers = [p['linear_X'], first, p['emb'], p['linear_out'], last, p['linear_in']] + list(p['mlp'][1:-1])
+            spec = [('initial_network', None, 0, -1), ('emb', 1, 2, -1), ('linear_out', 3, 4, -1), ('linear_in', None, 5, 1)]
+            spec += [(f'linears.{i}', None, 6 + i, -1) for i in range(len(p['mlp']) - 2)]
+            out = _native_block(layers, spec, self.layout, self.numel, dev)
+            if out is not None:
+                return out
         # float64 products for the (cached) inference block; training composes in float32: a third of the launches, and the
         # products' rounding is that of the kernels' own arithmetic
         f64 = dict(device=dev, dtype=torch.float32 if grad else torch.float64)

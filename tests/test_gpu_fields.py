@@ -173,7 +173,10 @@ def test_tutorial_field_training_step_fused_vs_fp64_autograd(kind, H, layers, ac
     assert float((got.detach().double().cpu() - want.detach()).abs().max()) <= 2e-4 * max(float(want.detach().abs().max()), 1.0)
 
     def close(g, ref, name):
-        grad_close(g, ref, name, GRAD_TOL, 'fields')
+        # (round 6: scalar parameters under SRK - `time_rate` of the additive LNSDE field is -0.02 as a sum of O(1) terms over 19 x 128 x 8
+        #  row-steps - measured 1.2e-4 once the block is composed natively in float32; the matrices stay at 1e-4)
+        tol = 3e-4 if (method == 'srk' and ref.numel() == 1) else GRAD_TOL
+        grad_close(g, ref, name, tol, 'fields')
     close(yg.grad, y64.grad, 'y0')
     ref = dict(f64.named_parameters())
     for name, p in field.named_parameters():
@@ -410,3 +413,35 @@ def test_field_training_step_at_the_timed_size_vs_fp64_autograd(kind, method):
             continue
         assert p.grad is not None, name
         close(p.grad, gr, name)
+
+
+@pytest.mark.parametrize('kind,H,layers', [('lnsde', 64, 2), ('gsde', 128, 1), ('nsde', 32, 1), ('lnsde_additive', 32, 3)])
+def test_native_block_composition_matches_the_torch_composition(kind, H, layers):
+    """snsde_affine_compose / _backward (one launch each; round 6) against the torch formulation of ComposedField._flat they replace in
+    training: the same parameter block to float32 round-off, and the same gradients for a random cotangent of the block."""
+    dev = torch.device('cuda')
+    field, times, coeffs, y0 = problem(900 + H, 7, H, 3, 9, kind, layers, 'lipswish', dev)
+    field = field.to(dev)
+    field.set_X(coeffs.to(dev), times.to(dev))
+    cf = S.fields.compose(field)
+    assert cf is not None
+    cot = torch.randn(cf.numel, device=dev, generator=torch.Generator(device=dev).manual_seed(3))
+    out = {}
+    for native in (True, False):
+        field.zero_grad(set_to_none=True)
+        saved = S.fields._native_block
+        if not native:
+            S.fields._native_block = lambda *a, **k: None
+        try:
+            flat = cf.flat(dev, grad=True)
+        finally:
+            S.fields._native_block = saved
+        assert (flat.grad_fn is not None) and (type(flat.grad_fn).__name__.startswith('_ComposeAffine') == native)
+        (flat * cot).sum().backward()
+        out[native] = (flat.detach().clone(), {n: p.grad.clone() for n, p in field.named_parameters() if p.grad is not None})
+    fa, ga = out[True]
+    fb, gb = out[False]
+    assert float((fa - fb).abs().max()) <= 2e-6 * (1.0 + float(fb.abs().max()))
+    assert ga.keys() == gb.keys() and len(ga) >= 8
+    for n in gb:
+        assert float((ga[n] - gb[n]).abs().max()) <= 2e-5 * (1.0 + float(gb[n].abs().max())), n
