@@ -41,7 +41,7 @@ def check_lean_resources(src, remarks):
         if m:
             name = m.group(1)
             continue
-        if name and ('snsde_m4_kernel' in name or 'snsde_m4s_kernel' in name or 'snsde_m4s2_kernel' in name):
+        if name and ('snsde_m4_kernel' in name or 'snsde_m4s_kernel' in name or 'snsde_m4s2_kernel' in name or 'snsde_m4s2_reverse_kernel' in name):
             m = re.search(r'remark:\s+(VGPRs|ScratchSize \[bytes/lane\]|VGPRs Spill): (\d+)', line)
             if m:
                 LEAN_RESOURCES.setdefault(name, {})[m.group(1)] = int(m.group(2))
@@ -73,7 +73,7 @@ def build(force=False, verbose=False, defines=(), out=None, check_resources=True
         obj = os.path.join(objdir, os.path.basename(src)[:-4] + '.o')
         if incremental and os.path.exists(obj) and os.path.getmtime(obj) > max(os.path.getmtime(src), hdr_time):
             return obj          # (development: `python build.py inc`; the lean resource check only sees what was recompiled)
-        lean = os.path.basename(src).startswith(('snsde_m4_h', 'snsde_m4s_h', 'snsde_m4s2_h'))
+        lean = os.path.basename(src).startswith(('snsde_m4_h', 'snsde_m4s_h', 'snsde_m4s2_h', 'snsde_m4s2_rev_h'))
         cmd = base + (['-Rpass-analysis=kernel-resource-usage'] if lean else []) + ['-c', src, '-o', obj]
         if verbose:
             print(' '.join(cmd))

@@ -830,6 +830,10 @@ int snsde_mfma_backward_launch(const snsde_backward* b, const SnsdeNet& net, hip
         if (p.H == 16) return dispatch_m4n_rev_h16(p, a, stream);
         return SNSDE_ERR_UNSUPPORTED;
     }
+    if (p.H == 256 && !(s->flags & SNSDE_FLAG_STREAM_ALL)) {      // two tiles per wave, a quarter of the transposed weights resident (round 6)
+        const int rc = dispatch_rev_h256_two_tile(p, a, stream);
+        if (rc != SNSDE_ERR_UNSUPPORTED) return rc;
+    }
     if (p.H == 256) return dispatch_rev_h256(p, a, stream);
     if (p.H == 128) return dispatch_rev_h128(p, a, stream);
     if (p.H == 64) return dispatch_rev_h64(p, a, stream);

@@ -1953,6 +1953,7 @@ int dispatch_rev(const RevPlan& p, const RevArgs& a, hipStream_t st) {
 int dispatch_fwd_m16_h16(const MfmaPlan& p, const MfmaArgs& a, hipStream_t st);
 int dispatch_fwd_m4_h16(const MfmaPlan& p, const MfmaArgs& a, hipStream_t st);
 int dispatch_rev_h16(const RevPlan& p, const RevArgs& a, hipStream_t st);
+int dispatch_rev_h256_two_tile(const RevPlan& p, const RevArgs& a, hipStream_t st);   // snsde_m4s2_rev_kernel.h
 int dispatch_fwd_m16_h32(const MfmaPlan& p, const MfmaArgs& a, hipStream_t st);
 int dispatch_fwd_m4_h32(const MfmaPlan& p, const MfmaArgs& a, hipStream_t st);
 int dispatch_rev_h32(const RevPlan& p, const RevArgs& a, hipStream_t st);

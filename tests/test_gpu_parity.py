@@ -731,6 +731,38 @@ def test_h128_two_tile_kernel_is_bit_identical_to_the_lean_one(case, train):
             assert (x is None and y is None) or torch.equal(x, y)
 
 
+@pytest.mark.parametrize('case', [(4, 17, 2, 14, 37, 'milstein', False), (4, 17, 2, 14, 128, 'euler', True), (6, 16, 2, 21, 9, 'euler', False),
+                                  (1, 13, 1, 3, 21, 'milstein', True), (3, 9, 2, 3, 5, 'euler', False), (5, 3, 1, 4, 12, 'milstein', False)])
+def test_h256_two_tile_adjoint_is_bit_identical_to_the_streamed_one(case):
+    """The H = 256 adjoint on two tiles per wave (snsde_m4s2_rev_kernel.h, round 6) against the sixteen-wave streamed adjoint
+    (SNSDE_FLAG_STREAM_ALL): dL/dy0, every adjoint state, every delta plane and the flat parameter gradient (which also sums the
+    per-tile theta / table partials) bit for bit - supplied and Philox increments, per-row outputs, gated drifts (io 5 / 6), y-only and
+    table diffusions."""
+    io, no, NL, C, B, method, row_out = case
+    pr = make_problem(6200 + B, io, no, NL, B, 256, C, 9)
+    ts, dt = np.array([0., 2.5, 6., 8.], np.float32), 1.0
+    model = S.engine.model_struct(C, 256, 256, NL, io, no)
+    flat = flat_params(pr['params'], io, no, NL, C, 256)
+    grid = S.engine.step_grid(ts, dt, pr['times'], torch.device(DEV))
+    dW = torch.from_numpy(draw_dW(6200 + B, ts, dt, B, 256)).to(DEV)
+    ro = torch.from_numpy(np.random.default_rng(5).integers(0, len(ts), size=B).astype(np.int32)).to(DEV) if row_out else None
+    rng = np.random.default_rng(7)
+    for supplied in (None, dW):
+        outs = []
+        for all_ in (True, False):
+            call = S.engine.SolveCall(model, flat, torch.from_numpy(pr['coeffs']).to(DEV), grid, torch.from_numpy(pr['y0']).to(DEV), dW=supplied,
+                                      method=method, seed=11, kernel='mfma4', stream_all=all_, save_traj=True, save_dW=supplied is None, save_act=True,
+                                      row_out=ro)
+            ys = call.launch()
+            gy = torch.from_numpy(rng.standard_normal(tuple(ys.shape)).astype(np.float32)).to(DEV) if not outs else outs[0][-1]
+            adj, delta = S.engine.solve_backward(call, gy, save_delta=True)
+            grad = S.engine.param_gradients(call, adj, delta)
+            outs.append((adj.clone(), delta.clone(), grad.clone(), gy))
+        assert torch.isfinite(outs[0][2]).all() and float(outs[0][2].abs().max()) > 0
+        for x, y in zip(outs[0][:3], outs[1][:3]):
+            assert torch.equal(x, y)
+
+
 def test_k5_milstein_h256_forecast_shaped():
     """configs[4] forward leg: (4,17) Milstein, H=256, MuJoCo-shaped L=50 C=14, ts = times (T=50), 128 rows per GPU."""
     B, H, C, L = 128, 256, 14, 50
