@@ -763,6 +763,29 @@ def test_h256_two_tile_adjoint_is_bit_identical_to_the_streamed_one(case):
             assert torch.equal(x, y)
 
 
+def test_h256_two_tile_kernels_over_more_steps_than_one_table_chunk():
+    """160 steps (> the 128-row chunk of the step table both kernels stage in LDS: fill_rows re-stages mid-solve), ragged batch: forward
+    (training mode) and adjoint + gradients of the two-tile kernels bit for bit against the sixteen-wave ones."""
+    io, no, NL, C, B, L = 4, 17, 2, 14, 23, 161
+    pr = make_problem(6400, io, no, NL, B, 256, C, L, weight_scale=0.5)
+    ts, dt = np.array([0., 77.5, 160.], np.float32), 1.0
+    model = S.engine.model_struct(C, 256, 256, NL, io, no)
+    flat = flat_params(pr['params'], io, no, NL, C, 256)
+    grid = S.engine.step_grid(ts, dt, pr['times'], torch.device(DEV))
+    assert grid.N == 160
+    outs = []
+    for all_ in (True, False):
+        call = S.engine.SolveCall(model, flat, torch.from_numpy(pr['coeffs']).to(DEV), grid, torch.from_numpy(pr['y0']).to(DEV), method='milstein',
+                                  seed=5, kernel='mfma4', stream_all=all_, save_traj=True, save_act=True)
+        ys = call.launch().clone()
+        gy = torch.ones_like(ys) if not outs else outs[0][-1]
+        adj, grad = S.engine.backward_with_gradients(call, gy, adj0_only=True)
+        outs.append((ys, call.traj.clone(), adj.clone(), grad.clone(), gy))
+    assert torch.isfinite(outs[0][3]).all()
+    for x, y in zip(outs[0][:4], outs[1][:4]):
+        assert torch.equal(x, y)
+
+
 def test_k5_milstein_h256_forecast_shaped():
     """configs[4] forward leg: (4,17) Milstein, H=256, MuJoCo-shaped L=50 C=14, ts = times (T=50), 128 rows per GPU."""
     B, H, C, L = 128, 256, 14, 50
