@@ -52,7 +52,7 @@ __device__ __forceinline__ void s2_refill(uint32_t ring_m0, const uint32_t (&vo4
 #ifdef SNSDE_S2_NO_STREAM      // development knock-out (build.py variant): no weight stream at all - stale ring contents, timing only
     return;
 #endif
-    asm volatile("s_add_u32 m0, %0, %3\n\ts_nop 4\n\tglobal_load_lds_dwordx4 %1, %2 offset:%4"
+    asm volatile("s_add_u32 m0, %0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2 offset:%4"
                  :: "s"(ring_m0), "v"(vo4[SRC / 4]), "s"(sb), "n"(DST - IMM), "n"(IMM) : "memory", "scc");
 }
 
@@ -88,9 +88,11 @@ __device__ __forceinline__ void s2_consume(S2Set& t, uint32_t ring_m0, const uin
                                            uint64_t sn1, f32x4 (&c)[2], f32x4 (&d)[2]) {
     constexpr int SLOT = UB % CF::R, UN = (UB + CF::R) % CF::NS;
     constexpr bool SAME = UB + CF::R < CF::NS;
-    s2_wait<LATER>(t);
+    // (the reads went out as b, a0, a1: tile 0's MFMAs start when b and a0 have landed, tile 1's fragment may still be in flight)
+    asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(t.b), "+v"(t.a0) : "n"(LATER + 1));
     s2_refill<CF::RK + UN, SLOT * 1024>(ring_m0, vo4, SAME ? sb0 : sn0);
     SNSDE_S2_MFMA4(c[0], d[0], t.a0, t.b)
+    asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(t.a1) : "n"(LATER));
     s2_refill<CF::RK + UN, CF::R * 1024 + SLOT * 1024>(ring_m0, vo4, SAME ? sb1 : sn1);
     SNSDE_S2_MFMA4(c[1], d[1], t.a1, t.b)
     __builtin_amdgcn_sched_barrier(0);
