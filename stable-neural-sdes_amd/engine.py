@@ -434,7 +434,9 @@ def _check_f32(name, t, shape=None):
 
 class SolveCall:
     """A fully prepared solve: owns references to every device buffer named in the descriptor so the
-    launch itself is one C call that only enqueues kernels (hipGraph-capturable)."""
+    launch itself is one C call that only enqueues kernels (hipGraph-capturable).
+    stream_all / two_tile: the A/B switches of include/snsde.h (SNSDE_FLAG_STREAM_ALL: H = 256 on the fully streamed sixteen-wave
+    kernels instead of the two-tile ones; SNSDE_FLAG_TWO_TILE: H = 128 on the four-wave two-tile kernel) - same results bit for bit."""
 
     def __init__(self, model, flat_params, coeffs, grid, y0, dW=None, method='euler', seed=0, row_offset=0,
                  kernel='auto', save_traj=False, save_dW=False, exact_order=False, save_act=False, dU=None, row_out=None,
