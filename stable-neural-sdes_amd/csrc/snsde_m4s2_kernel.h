@@ -359,10 +359,10 @@ __global__ void __launch_bounds__(CF::NT, 1) snsde_m4s2_kernel(MfmaArgs a) {
     __syncthreads();
     // the rings' first turns: streamed blocks 0 .. R - 1 (k-blocks RK ..) of layer 0, in consumption order (tile 0's pair, tile 1's pair)
     static_assert(CF::R == 6 && RK == 4, "initial fill below");
+    // (in CONSUMPTION order - per block: tile 0's slot, tile 1's slot - which is what the vmcnt of the first layer's first block counts on)
 #define SNSDE_S2_FILL(UB) \
-    s2_refill<RK + UB, UB * 1024>(ring_m0, vo4, sb[0][0]); s2_refill<RK + UB + 1, UB * 1024 + 1024>(ring_m0, vo4, sb[0][0]); \
-    s2_refill<RK + UB, CF::R * 1024 + UB * 1024>(ring_m0, vo4, sb[0][1]); s2_refill<RK + UB + 1, CF::R * 1024 + UB * 1024 + 1024>(ring_m0, vo4, sb[0][1]);
-    SNSDE_S2_FILL(0) SNSDE_S2_FILL(2) SNSDE_S2_FILL(4)
+    s2_refill<RK + UB, UB * 1024>(ring_m0, vo4, sb[0][0]); s2_refill<RK + UB, CF::R * 1024 + UB * 1024>(ring_m0, vo4, sb[0][1]);
+    SNSDE_S2_FILL(0) SNSDE_S2_FILL(1) SNSDE_S2_FILL(2) SNSDE_S2_FILL(3) SNSDE_S2_FILL(4) SNSDE_S2_FILL(5)
 #undef SNSDE_S2_FILL
 
     const uint32_t yrow = lean_lds_addr(ybuf + r * LDY + 4 * s);
