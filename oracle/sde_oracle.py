@@ -19,8 +19,16 @@ Pinning status
   ``hermite_cubic_coefficients_with_backward_differences`` (torchcde 0.2.5) are
   restated from the published behaviour of those pinned third-party packages,
   whose sources are NOT under /root/reference and are not installed here:
-  **parity unpinned** at that boundary.  They are guarded by
-  analytic known-answer tests instead (tests/test_oracle_analytic.py).
+  **parity unpinned** at that boundary: no fixture of the
+  reference and no output of torchsde / torchcde themselves stands behind them.
+  What does (round 6): exact-rational known-answer vectors computed from the
+  PUBLISHED definitions - torchsde's fixed-step grid with float32 time
+  accumulation, Euler-Maruyama, Milstein, Roessler's SRI2W1 table (= srid2.py) -
+  by tests/golden/make_exact_golden.py, which imports nothing from here or from
+  the package; ``step_grid`` reproduces them bit for bit, ``integrate`` /
+  ``srk_step`` to 1e-13, and forward-mode exact derivatives pin the gradients
+  (tests/test_exact_cpu.py).  Plus the analytic tests of
+  tests/test_oracle_analytic.py (exact line, OU recursion, strong orders).
 
 Reference lines followed (relative to /root/reference):
   benchmark_classification/models_sde/neuralsde.py:186-231   drift helpers
