@@ -91,6 +91,8 @@ class _ComposeAffine(torch.autograd.Function):
         offs = [0]
         for n in sizes:
             offs.append(offs[-1] + n)
+        eyes = [name for name, outer, inner, zero_col in spec if inner is None]      # identity layers: written after the launch
+        spec = [e for e in spec if e[2] is not None]
         jobs = (_lib.AffineJob * len(spec))()
         for q, (name, outer, inner, zero_col) in zip(jobs, spec):
             wi, bi = src[2 * inner], src[2 * inner + 1]
@@ -112,6 +114,9 @@ class _ComposeAffine(torch.autograd.Function):
         flat = torch.zeros(numel, device=dev, dtype=torch.float32)      # (theta, unused noise_t entries: zero)
         stream = torch.cuda.current_stream(dev)
         _lib.check(_lib.lib().snsde_affine_compose(jobs, len(spec), flat.data_ptr(), stream.cuda_stream), 'snsde_affine_compose')
+        for name in eyes:      # (a constant of the block: no gradient flows to it)
+            off, shape = where[name + '.weight']
+            flat[off:off + shape[0] * shape[1]].view(shape).diagonal().fill_(1.0)
         ctx.jobs, ctx.src, ctx.offs, ctx.shapes = jobs, src, offs, [tuple(t.shape) for t in tensors]
         return flat
 
@@ -281,11 +286,16 @@ class ComposedField:
             return self._flat_net(dev, grad)
         p = self.parts
         H = self.model.hidden_channels
-        if grad and p['linear_in'] is not None:      # training (LNSDE / GSDE shapes): natively, one launch each way
+        if grad:      # training: natively, one launch each way (LSDE: emb sees y itself - linear_in is the identity, a constant)
             first, last = p['mlp'][0], p['mlp'][-1]
-            layers = [p['linear_X'], first, p['emb'], p['linear_out'], last, p['linear_in']] + list(p['mlp'][1:-1])
-            spec = [('initial_network', None, 0, -1), ('emb', 1, 2, -1), ('linear_out', 3, 4, -1), ('linear_in', None, 5, 1)]
-            spec += [(f'linears.{i}', None, 6 + i, -1) for i in range(len(p['mlp']) - 2)]
+            layers = [p['linear_X'], first, p['emb'], p['linear_out'], last] + list(p['mlp'][1:-1])
+            spec = [('initial_network', None, 0, -1), ('emb', 1, 2, -1), ('linear_out', 3, 4, -1)]
+            spec += [(f'linears.{i}', None, 5 + i, -1) for i in range(len(p['mlp']) - 2)]
+            if p['linear_in'] is None:
+                spec.append(('linear_in', None, None, -1))
+            else:
+                layers.append(p['linear_in'])
+                spec.append(('linear_in', None, len(layers) - 1, 1))
             out = _native_block(layers, spec, self.layout, self.numel, dev)
             if out is not None:
                 return out

@@ -415,7 +415,7 @@ def test_field_training_step_at_the_timed_size_vs_fp64_autograd(kind, method):
         close(p.grad, gr, name)
 
 
-@pytest.mark.parametrize('kind,H,layers', [('lnsde', 64, 2), ('gsde', 128, 1), ('nsde', 32, 1), ('lnsde_additive', 32, 3)])
+@pytest.mark.parametrize('kind,H,layers', [('lnsde', 64, 2), ('gsde', 128, 1), ('nsde', 32, 1), ('lnsde_additive', 32, 3), ('lsde', 32, 1), ('lsde', 64, 2)])
 def test_native_block_composition_matches_the_torch_composition(kind, H, layers):
     """snsde_affine_compose / _backward (one launch each; round 6) against the torch formulation of ComposedField._flat they replace in
     training: the same parameter block to float32 round-off, and the same gradients for a random cotangent of the block."""
@@ -442,6 +442,6 @@ def test_native_block_composition_matches_the_torch_composition(kind, H, layers)
     fa, ga = out[True]
     fb, gb = out[False]
     assert float((fa - fb).abs().max()) <= 2e-6 * (1.0 + float(fb.abs().max()))
-    assert ga.keys() == gb.keys() and len(ga) >= 8
+    assert ga.keys() == gb.keys() and len(ga) >= 8 - (2 if kind == 'lsde' else 0)
     for n in gb:
         assert float((ga[n] - gb[n]).abs().max()) <= 2e-5 * (1.0 + float(gb[n].abs().max())), n
