@@ -21,7 +21,10 @@ Two kinds of cases:
   K/*  vector fields the fused kernels can evaluate EXACTLY as rational functions: relu MLPs with dyadic weights, linear drift
        output, un-squashed diffusion, raw time feature (the variant switches of include/snsde.h that the tutorial fields use) -
        one with a time-only diffusion table (g = s(t) y), one with a two-layer diffusion net; Euler, Milstein and SRK on
-       mis-aligned grids.  The GPU tests feed the same parameters to the HIP kernels through the C ABI.
+       mis-aligned grids.  The GPU tests feed the same parameters to the HIP kernels through the C ABI;
+  K/*/grad  exact DERIVATIVES of L = sum w . ys for `tab` and `net16` (forward mode over the rationals, class Dual): one direction per
+       parameter tensor, one over y0, one per batch row - checked against fp64 autograd through the tensor-op loop and against the
+       fused adjoint + weight-gradient kernels.
 
 Run from the repo root:  python tests/golden/make_exact_golden.py     (needs numpy only; no torch, no /root/reference)
 """
@@ -258,6 +261,7 @@ def integrate(method, f, g, gvjp, y0, ts, dt, I1, I10=None, table=SRI2W1):
 
 # ---------------------------------------------------------------------------------------------------------------
 def to_np(x, dtype=np.float64):
+    """nested lists of Fractions (or one Fraction) -> numpy array of `dtype` (one rounding: rational -> float64 [-> float32])"""
     return np.array(x, dtype=object).astype(np.float64).astype(dtype) if not isinstance(x, Fr) else dtype(float(x))
 
 
@@ -447,7 +451,6 @@ def directional_cases(out):
     and Milstein on the grids above - along one random dyadic direction per parameter tensor, one over y0, and one per batch row of y0
     (forward-mode over the rationals, `Dual`).  The fused ADJOINT kernels + the native weight-gradient pass must reproduce
     <gradient, direction> for each (tests/test_gpu_exact.py)."""
-    ex = dict(np.load(os.path.join(HERE, 'exact.npz'))) if False else None
     rng = random.Random(777)
 
     def frac_arr(a):          # float array holding dyadic rationals -> object array of Fractions (exact)
