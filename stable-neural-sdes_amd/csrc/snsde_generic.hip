@@ -299,7 +299,7 @@ __global__ void __launch_bounds__(GT) snsde_generic_kernel(GenericArgs a) {
                 int k = kout;
                 while (k < d.T - 1 && a.out_step[k] == n) {
                     const float w0 = a.out_w[2 * k], w1 = a.out_w[2 * k + 1];
-                    const float o = (w0 == 0.0f) ? ynew : w0 * y + w1 * ynew;
+                    const float o = (w0 == 0.0f) ? ynew : snsde_interp_out(w0, w1, y, ynew);
                     if (!a.row_out) a.ys[(size_t)(k + 1) * BH + (size_t)row * H + j] = o;
                     else if (a.row_out[row] == k + 1) a.ys[(size_t)row * H + j] = o;
                     ++k;
@@ -541,7 +541,7 @@ __global__ void __launch_bounds__(GW) snsde_generic_srk_kernel(SrkArgs sa) {
                 if (a.traj) a.traj[(size_t)(n + 1) * BH + (size_t)row * H + j] = ynew;
                 for (int k = kout; k < kend; ++k) {
                     const float c0 = a.out_w[2 * k], c1 = a.out_w[2 * k + 1];
-                    const float o = (c0 == 0.0f) ? ynew : c0 * y + c1 * ynew;
+                    const float o = (c0 == 0.0f) ? ynew : snsde_interp_out(c0, c1, y, ynew);
                     if (!a.row_out) a.ys[(size_t)(k + 1) * BH + (size_t)row * H + j] = o;
                     else if (a.row_out[row] == k + 1) a.ys[(size_t)row * H + j] = o;
                 }
@@ -745,7 +745,7 @@ __global__ void __launch_bounds__(GW) snsde_generic_milnet_kernel(GenericArgs a)
                 if (a.traj) a.traj[(size_t)(n + 1) * BH + (size_t)row * H + j] = ynew;
                 for (int k = kout; k < kend; ++k) {
                     const float c0 = a.out_w[2 * k], c1 = a.out_w[2 * k + 1];
-                    const float o = (c0 == 0.0f) ? ynew : c0 * y + c1 * ynew;
+                    const float o = (c0 == 0.0f) ? ynew : snsde_interp_out(c0, c1, y, ynew);
                     if (!a.row_out) a.ys[(size_t)(k + 1) * BH + (size_t)row * H + j] = o;
                     else if (a.row_out[row] == k + 1) a.ys[(size_t)row * H + j] = o;
                 }

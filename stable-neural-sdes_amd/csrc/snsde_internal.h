@@ -185,6 +185,14 @@ __device__ __forceinline__ void snsde_z0_rows(const SnsdeZ0Job& z, int bx, int n
         z.y0[i] = acc;
     }
 }
+// output between two solver states: torchsde's linear_interp on float32 tensors, (t1 - t) / (t1 - t0) * y0 + (t - t0) / (t1 - t0) * y1 -
+// two rounded products and a rounded sum (eager tensor ops do not contract into an fma).  One form in every kernel: left to hipcc the
+// contraction differs between instantiations (w0 y0 + fma or fma + w1 y1), a last-bit difference between kernel families on the same states.
+__device__ __forceinline__ float snsde_interp_out(float w0, float w1, float y_prev, float y_new) {
+#pragma clang fp contract(off)
+    const float a = w0 * y_prev, b = w1 * y_new;
+    return a + b;
+}
 __device__ __forceinline__ float snsde_spline_deriv(float b, float two_c, float three_d, float frac) {
 #pragma clang fp contract(off)
     float inner = two_c + three_d * frac;

@@ -640,7 +640,7 @@ __global__ void __launch_bounds__(CF::NT, CF::WPS) snsde_m4_kernel(MfmaArgs a) {
     }
     if (row_ok) {          // output ko + 1 (linear interpolation inside the last step when the output time is not on the grid)
         const float w0 = a.out_w[2 * ko], w1 = a.out_w[2 * ko + 1];
-        const float o = (w0 == 0.0f) ? yv : w0 * yold + w1 * yv;
+        const float o = (w0 == 0.0f) ? yv : snsde_interp_out(w0, w1, yold, yv);
         if (!a.row_out) a.ys[(size_t)(ko + 1) * BH + goff] = o;
         else if (rslot == ko + 1) a.ys[goff] = o;
     }

@@ -518,7 +518,7 @@ __global__ void __launch_bounds__(CF::NT, CF::WPS) snsde_m4n_kernel(MfmaArgs a) 
 #endif
                 for (int k = cur_row.kfirst; k < cur_row.kfirst + cur_row.nout; ++k) {
                     const float w0 = a.out_w[2 * k], w1 = a.out_w[2 * k + 1];
-                    const float o = (w0 == 0.0f) ? yn : w0 * yold + w1 * yn;
+                    const float o = (w0 == 0.0f) ? yn : snsde_interp_out(w0, w1, yold, yn);
                     if (!a.row_out) a.ys[(size_t)(k + 1) * BH + goff] = o;
                     else if (rslot == k + 1) a.ys[goff] = o;
                 }

@@ -326,7 +326,7 @@ __global__ void __launch_bounds__(CF::NT, 1) snsde_m4s_kernel(MfmaArgs a) {
     }
     if (row_ok) {
         const float w0 = a.out_w[2 * ko], w1 = a.out_w[2 * ko + 1];
-        const float o = (w0 == 0.0f) ? yv : w0 * yold + w1 * yv;
+        const float o = (w0 == 0.0f) ? yv : snsde_interp_out(w0, w1, yold, yv);
         if (!a.row_out) a.ys[(size_t)(ko + 1) * BH + goff] = o;
         else if (rslot == ko + 1) a.ys[goff] = o;
     }

@@ -425,7 +425,7 @@ __global__ void __launch_bounds__(CF::NT, 1) snsde_m4t_kernel(MfmaArgs a) {
         const float w0 = a.out_w[2 * ko], w1 = a.out_w[2 * ko + 1];
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
-            const float o = (w0 == 0.0f) ? yv[j] : w0 * yold[j] + w1 * yv[j];
+            const float o = (w0 == 0.0f) ? yv[j] : snsde_interp_out(w0, w1, yold[j], yv[j]);
             const size_t go = (size_t)rowc * H + fo[j];
             if (!a.row_out) a.ys[(size_t)(ko + 1) * BH + go] = o;
             else if (rslot == ko + 1) a.ys[go] = o;

@@ -971,7 +971,7 @@ __global__ void __launch_bounds__(CF::NT, CF::WPS) snsde_mfma_kernel(MfmaArgs a)
                     if constexpr (CF::SRK) { if (a.dU_out) a.dU_out[(size_t)ns * BH + goff] = sk_du[0]; }
                     for (int k = c_kfirst; k < c_kfirst + c_nout; ++k) {
                         const float w0 = a.out_w[2 * k], w1 = a.out_w[2 * k + 1];
-                        const float o = (w0 == 0.0f) ? ynew[0] : w0 * yold[0] + w1 * ynew[0];
+                        const float o = (w0 == 0.0f) ? ynew[0] : snsde_interp_out(w0, w1, yold[0], ynew[0]);
                         if (!a.row_out) a.ys[(size_t)(k + 1) * BH + goff] = o;
                         else if (rslot == k + 1) a.ys[goff] = o;
                     }
@@ -992,7 +992,7 @@ __global__ void __launch_bounds__(CF::NT, CF::WPS) snsde_mfma_kernel(MfmaArgs a)
                         const float w0 = a.out_w[2 * k], w1 = a.out_w[2 * k + 1];
                         f32x4 o;
 #pragma unroll
-                        for (int e = 0; e < 4; ++e) o[e] = (w0 == 0.0f) ? ynew[e] : w0 * yold[e] + w1 * ynew[e];
+                        for (int e = 0; e < 4; ++e) o[e] = (w0 == 0.0f) ? ynew[e] : snsde_interp_out(w0, w1, yold[e], ynew[e]);
                         if (!a.row_out) *reinterpret_cast<f32x4*>(a.ys + (size_t)(k + 1) * BH + goff) = o;
                         else if (rslot == k + 1) *reinterpret_cast<f32x4*>(a.ys + goff) = o;
                     }

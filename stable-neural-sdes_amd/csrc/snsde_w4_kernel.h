@@ -343,7 +343,7 @@ __global__ void __launch_bounds__(256, 2) snsde_w4_euler_kernel(W4Args a) {
                 auto emit = [&](int k, float w0, float w1) {
                     float o[4];
 #pragma unroll
-                    for (int i = 0; i < 4; ++i) o[i] = (w0 == 0.0f) ? yn[i] : w0 * y[i] + w1 * yn[i];
+                    for (int i = 0; i < 4; ++i) o[i] = (w0 == 0.0f) ? yn[i] : snsde_interp_out(w0, w1, y[i], yn[i]);
                     if (!a.row_out) store4(a.ys + uoff(k + 1, BH), o);
                     else {
 #pragma unroll
@@ -812,7 +812,7 @@ __global__ void __launch_bounds__(256, 2) snsde_w4_srk_kernel(W4Args a) {
                 auto emit = [&](int k, float w0, float w1) {
                     float o[4];
 #pragma unroll
-                    for (int i = 0; i < 4; ++i) o[i] = (w0 == 0.0f) ? yn[i] : w0 * y[i] + w1 * yn[i];
+                    for (int i = 0; i < 4; ++i) o[i] = (w0 == 0.0f) ? yn[i] : snsde_interp_out(w0, w1, y[i], yn[i]);
                     if (!a.row_out) store4(a.ys + uoff(k + 1, BH), o);
                     else {
 #pragma unroll

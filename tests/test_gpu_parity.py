@@ -786,6 +786,18 @@ def test_h256_two_tile_kernels_over_more_steps_than_one_table_chunk():
         assert torch.equal(x, y)
 
 
+def test_h256_two_tile_kernels_fuzz_against_the_streamed_ones():
+    """60 random configurations (input / noise options, depth, channels, ragged batches, output grids with interpolated outputs, Euler /
+    Milstein, supplied / Philox increments, per-row outputs): forward in training mode, adjoint and parameter gradients of the two-tile
+    H = 256 kernels bit for bit against the sixteen-wave ones (tools/fuzz_h256.py; 300 cases were run when the kernels were written)."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, 'tools', 'fuzz_h256.py'), '60', '7'], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert '60 cases, 0 mismatches' in r.stdout, r.stdout[-2000:]
+
+
 def test_k5_milstein_h256_forecast_shaped():
     """configs[4] forward leg: (4,17) Milstein, H=256, MuJoCo-shaped L=50 C=14, ts = times (T=50), 128 rows per GPU."""
     B, H, C, L = 128, 256, 14, 50
