@@ -10,7 +10,7 @@ int dispatch_rev_h256_two_tile(const RevPlan& p, const RevArgs& a, hipStream_t s
     if (p.NHID == 1 && !p.GEO) return launch_rev2<CfgS2R<1, 0>>(a, st);
 #else
 #define SNSDE_R2(NH_) if (p.NHID == NH_) return p.GEO ? launch_rev2<CfgS2R<NH_, 1>>(a, st) : launch_rev2<CfgS2R<NH_, 0>>(a, st);
-    SNSDE_R2(0) SNSDE_R2(1)
+    SNSDE_R2(0) SNSDE_R2(1) SNSDE_R2(2)
 #undef SNSDE_R2
 #endif
     return SNSDE_ERR_UNSUPPORTED;

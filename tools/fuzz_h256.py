@@ -12,7 +12,7 @@ ncase = int(sys.argv[1]) if len(sys.argv) > 1 else 40
 bad = 0
 for ci in range(ncase):
     io = int(rng.integers(1, 7)); no = int(rng.choice([0, 1, 2, 3, 4, 5, 6, 8, 9, 10, 11, 12, 13, 16, 17]))
-    NL = int(rng.integers(1, 3)); C = int(rng.choice([1, 3, 14])); B = int(rng.integers(1, 70)); L = int(rng.integers(3, 12))
+    NL = int(rng.integers(1, 4)); C = int(rng.choice([1, 3, 14, 21])); B = int(rng.integers(1, 70)); L = int(rng.integers(3, 12))
     method = str(rng.choice(['euler', 'milstein']))
     pr = make_problem(9000 + ci, io, no, NL, B, 256, C, L, weight_scale=0.7)
     nt = int(rng.integers(2, 5))
