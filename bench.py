@@ -500,6 +500,11 @@ def summary_of(out, extra):
         e = extra.get(key)
         if e:
             s[key] = {"step_ms": round(e["ms_per_step"], 4), "train_frac": round(e["roofline"]["frac"], 4)}
+    for key in ("K1_tutorial_lsde", "tutorial_field"):      # BASELINE config 0 (the OU tutorial's LSDE field) and the K2-sized LNSDE field
+        e = extra.get(key)
+        if e and "fused" in e:
+            s[key] = {"fwd_ms": round(e["fused"]["median_ms"], 4), "fwd_bwd_ms": round(e["fused_forward_backward"]["median_ms"], 4),
+                      "step_graph_ms": round(e["optimizer_step_graph_replayed"]["median_ms"], 4)}
     return s
 
 

@@ -15,6 +15,8 @@ def canned(extra_legs=12):
         extra[key] = {"kernel_ms": 1.2345678, "roofline": {"frac": 0.857}, "ms_per_solve": 1.25}
     for key in ("K5_strong_train", "K5_shard_128_train"):
         extra[key] = {"ms_per_step": 1.286, "roofline": {"frac": 0.085}}
+    for key in ("K1_tutorial_lsde", "tutorial_field"):
+        extra[key] = {"fused": big, "fused_forward_backward": big, "optimizer_step_graph_replayed": big}
     out = {
         "metric": "SDE solver steps/sec (batch x steps / s), forward solve", "value": 4.97e8, "unit": "row-steps/s", "n_gpus": 1,
         "steps": 50, "warmup": 10, "ms_per_step": 0.2061, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
